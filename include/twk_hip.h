@@ -1,0 +1,183 @@
+/*
+ * twk_hip.h -- C ABI of the MI355X (gfx950) pairwise-LD engine.
+ *
+ * This is the drop-in boundary for the `tomahawk calc` hot path.  The
+ * reference (mklarqvist/tomahawk) has no FFI of its own: its replacement point
+ * is the per-thread block-pair loop `twk_ld_slave::Phased/Unphased`
+ * (lib/ld/ld_engine.cpp:1898-2188) that calls one `twk_ld_engine` kernel per
+ * variant pair (lib/ld/ld_engine.h:225, kernels ld_engine.cpp:185-1160) and
+ * `PhasedMath`/`UnphasedMath` (ld_engine.cpp:1162-1740).  Each entry point
+ * below names the reference interface it replaces.
+ *
+ * Conventions: plain C types only; every function returns 0 (TWK_HIP_OK) or a
+ * negative TWK_HIP_E_* code and never throws; the caller owns every host
+ * buffer; the library owns all device memory inside the ctx; one ctx per
+ * device, used from one host thread at a time.  There is NO CPU fallback: if
+ * no HIP device is usable the calls fail with TWK_HIP_E_DEVICE.
+ */
+#ifndef TWK_HIP_H_
+#define TWK_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TWK_HIP_ABI_VERSION 1
+
+enum {
+	TWK_HIP_OK         =  0,
+	TWK_HIP_E_INVALID  = -1, /* bad argument */
+	TWK_HIP_E_NOMEM    = -2, /* host or device allocation failed */
+	TWK_HIP_E_DEVICE   = -3, /* HIP runtime error / no device */
+	TWK_HIP_E_OVERFLOW = -4, /* record buffer too small; *n_out holds the required count */
+	TWK_HIP_E_STATE    = -5  /* call sequence error (e.g. compute before upload) */
+};
+
+/* Pair math selection; mirrors twk_ld_settings.force_phased / forced_unphased
+ * (include/core.h:916) and the default per-pair rule of
+ * twk_ld_slave::Calculate (ld_engine.cpp:2775,2803). */
+enum {
+	TWK_HIP_MODE_PHASED   = 1, /* calc -p : PhasedListVector/PhasedVectorized + PhasedMath   */
+	TWK_HIP_MODE_UNPHASED = 2, /* calc -u : UnphasedVectorized(NoMissing) + UnphasedMath      */
+	TWK_HIP_MODE_AUTO     = 3  /* calc    : unphased iff either variant has missing alleles   */
+};
+
+typedef struct twk_hip_ctx twk_hip_ctx;
+
+/* Per-variant metadata: the fields of twk1_t (include/core.h:291-295) that the
+ * pair loop and the math read (ac, an, pos, rid, hwe, gt_missing). */
+typedef struct {
+	uint32_t ac;      /* ALT allele count                       */
+	uint32_t an;      /* number of MISSING alleles (sic)        */
+	uint32_t pos;     /* 0-based position                       */
+	uint32_t rid;     /* contig id                              */
+	uint32_t missing; /* twk1_t.gt_missing (variant has a mask) */
+	uint32_t _pad;
+	double   hwe;     /* Hardy-Weinberg P                       */
+} twk_hip_variant_meta;
+
+/* Output filters: twk_ld_settings.minR2/maxR2/minDprime/maxDprime/minP
+ * (include/core.h:921; defaults lib/core.cpp:304). */
+typedef struct {
+	double minR2, maxR2, minDprime, maxDprime, minP;
+} twk_hip_filters;
+
+/* A rectangular slice of the variant-pair space, in variant indices as
+ * uploaded.  Replaces one ticket of twk_ld_dynamic_balancer::GetBlockPair
+ * (lib/ld/ld_balancing.h:214-233): rows [rowA0,rowA0+nA) x cols [rowB0,rowB0+nB).
+ * When diag != 0 (requires rowA0 == rowB0, nA == nB) only pairs with col > row
+ * are evaluated (ticket type 1, ld_engine.cpp:1913-1933). */
+typedef struct {
+	uint32_t rowA0, nA, rowB0, nB;
+	int32_t  diag;
+	int32_t  window;   /* != 0: keep only same-contig pairs with |posA-posB| <= l_window */
+	uint32_t l_window; /* base pairs (twk_ld_settings.l_window)                         */
+	uint32_t _pad;
+} twk_hip_tile_desc;
+
+/* One surviving pair, device-compacted.  Field-for-field the payload of
+ * twk1_two_t (include/core.h:826-833) with variant indices instead of
+ * rid/pos (the host expands them and writes the forward + reverse copies,
+ * ld_engine.cpp:1290-1298). */
+typedef struct {
+	uint32_t idxA, idxB; /* variant indices as uploaded           */
+	uint32_t flags;      /* twk1_two_t.controller                 */
+	uint32_t _pad;
+	double   cnt[4];     /* REFREF, ALTREF-slot, REFALT-slot, ALTALT (core.h:833) */
+	double   D, Dprime, R, R2, P, ChiSqFisher, ChiSqModel;
+} twk_hip_record;
+
+/* ---- device / context ------------------------------------------------- */
+int twk_hip_abi_version(void);
+int twk_hip_device_count(void);
+const char* twk_hip_strerror(int code);
+/* Last HIP runtime error text recorded on this ctx ("" if none). */
+const char* twk_hip_last_error(const twk_hip_ctx* ctx);
+int twk_hip_ctx_create(int device, twk_hip_ctx** out);
+int twk_hip_ctx_destroy(twk_hip_ctx* ctx);
+
+/* ---- input ------------------------------------------------------------ */
+/* Declare the problem: n_samples diploid samples, n_variants variants.
+ * Replaces twk_ld_engine::SetSamples (ld_engine.cpp:55-71) + the ldd block
+ * arrays (ld.cpp:390-391). Frees any previous data. */
+int twk_hip_set_problem(twk_hip_ctx* ctx, uint32_t n_samples, uint32_t n_variants);
+
+/* Upload variants [first, first+count) as reference-layout bitvectors
+ * (twk_igt_vec, include/core.h:724-753 built by core.cpp:349-438): for sample
+ * s bit 2s = first allele is ALT, bit 2s+1 = second allele is ALT, little-
+ * endian uint64 words, stride64 words per variant (>= ceil(2N/64)).  `mask`
+ * may be NULL (no variant has missing data); otherwise same layout with both
+ * bits of a sample set when either allele is missing (core.cpp:379-380).
+ * Replaces twk1_ldd_blk::Inflate (ld_structs.cpp:125-203). */
+int twk_hip_upload_bitvectors(twk_hip_ctx* ctx, uint32_t first, uint32_t count,
+                              const uint64_t* data, const uint64_t* mask, size_t stride64,
+                              const twk_hip_variant_meta* meta);
+
+/* Fill the whole problem with the synthetic benchmark input of SURVEY 8(d)
+ * directly in HBM (iid alleles, per-variant ALT frequency U(0.05,0.5), one
+ * contig, pos = 1000+100*v, no missing data).  Bit-identical to the host
+ * generator twk_synth_bitvector() below. */
+int twk_hip_generate_synthetic(twk_hip_ctx* ctx, uint64_t seed);
+/* Host twin of the device generator: writes variant v's bitvector
+ * (ceil(2N/64) words) and returns its ALT allele count. */
+uint32_t twk_synth_bitvector(uint64_t seed, uint32_t n_samples, uint32_t v, uint64_t* out_words);
+
+/* Copy back per-variant ALT allele count / het / hom-alt / missing-sample
+ * counts as seen by the device (popcounts of the planes).  Any pointer may be
+ * NULL. */
+int twk_hip_get_marginals(twk_hip_ctx* ctx, uint32_t* ac, uint32_t* n_het, uint32_t* n_hom,
+                          uint32_t* n_miss_samples);
+
+/* ---- compute ---------------------------------------------------------- */
+/* Raw contingency counts for one tile (debug/parity entry point; replaces the
+ * `helper.alleleCounts` filled by the K1-K6 kernels before the math).
+ * mode PHASED  : out[4*(i*nB+j)+{0,1,2,3}] = REFREF, ALTREF(1), REFALT(4), ALTALT(5)
+ *                cells of twk_ld_count (ld_engine.h:27-30).
+ * mode UNPHASED: out[9*(i*nB+j)+k] = cells {0,1+4,5,16+64,17+20+65+68,21+69,80,81+84,85}.
+ * Pairs excluded by `diag` are zero-filled. */
+int twk_hip_count_tile(twk_hip_ctx* ctx, int mode, const twk_hip_tile_desc* tile, uint64_t* out);
+
+/* LD for one tile: counts -> math -> filters -> compacted survivors.
+ * `out` is a HOST buffer of `capacity` records; *n_out receives the number of
+ * survivors (on TWK_HIP_E_OVERFLOW: the number required, nothing guaranteed in
+ * out).  *n_pairs (may be NULL) receives the number of pairs compared, counted
+ * as the reference's progress counter does (ld_engine.cpp:1933,2015). */
+int twk_hip_ld_tile(twk_hip_ctx* ctx, int mode, const twk_hip_tile_desc* tile,
+                    const twk_hip_filters* filters, twk_hip_record* out, uint64_t capacity,
+                    uint64_t* n_out, uint64_t* n_pairs);
+
+/* All-vs-all LD over the upper triangle, restricted to shard `part` of
+ * `n_parts` (static cost-balanced assignment of super-tiles; replaces
+ * twk_ld_balancer::Build, ld_balancing.h:23-80, for multi-GPU sharding).
+ * tile_variants = edge of a super-tile in variants (0 = choose).  Survivors
+ * are handed to `sink` (may be NULL to discard) tile by tile on the calling
+ * thread.  *n_pairs / *n_records (may be NULL) receive totals for this shard. */
+typedef int (*twk_hip_record_sink)(void* user, const twk_hip_record* recs, uint64_t n);
+int twk_hip_ld_all(twk_hip_ctx* ctx, int mode, const twk_hip_filters* filters,
+                   uint32_t part, uint32_t n_parts, uint32_t tile_variants,
+                   int32_t window, uint32_t l_window,
+                   twk_hip_record_sink sink, void* user, uint64_t* n_pairs, uint64_t* n_records);
+
+/* ---- measurement ------------------------------------------------------ */
+/* Cumulative device time (HIP events on the engine's own stream) and launch
+ * count of the dominant kernel (count-tile) and of the math kernel since the
+ * last reset, plus the algorithmic units they processed. */
+typedef struct {
+	double   count_ms;      /* sum of count-kernel durations                     */
+	double   stats_ms;      /* sum of math/filter-kernel durations               */
+	uint64_t count_launches;
+	uint64_t stats_launches;
+	uint64_t row_pairs;     /* plane-row pairs contracted by the count kernel    */
+	uint64_t variant_pairs; /* variant pairs evaluated by the math kernel        */
+	uint64_t words_per_row; /* 32-bit words contracted per row pair (unpadded)   */
+} twk_hip_timing;
+int twk_hip_timing_reset(twk_hip_ctx* ctx);
+int twk_hip_timing_get(twk_hip_ctx* ctx, twk_hip_timing* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TWK_HIP_H_ */

@@ -1,0 +1,211 @@
+// Count kernel: the AND+popcount contraction over the sample axis.
+//
+//   C[r][c] = sum_k popc( rows[rowA0 + r][k] & rows[rowB0 + c][k] )
+//
+// `rows` is a row-major matrix of bit-planes (uint32 words, row pitch W words,
+// W a multiple of KC, zero padded).  One row is one plane of one variant; what
+// the planes mean (haplotype bits, het / hom-alt indicator, missing mask) is
+// the caller's business (ld_prep.hip.h builds them, ld_math.hip.h turns the
+// plane products back into the reference's contingency cells).  This replaces
+// the word loops of the reference kernels PhasedListVector / PhasedVectorized /
+// UnphasedVectorized(NoMissing) (lib/ld/ld_engine.cpp:230-242, 583-585,
+// 668, 941-943): same AND, same popcount, but as a tiled contraction instead
+// of one pair at a time.
+//
+// CDNA4 mapping (gfx950, wave64, 4 x SIMD32 per CU):
+//   * block = 256 threads = 4 waves, computes a 128 x 128 tile of row pairs;
+//     wave (wr,wc) owns a 64 x 64 quadrant; lane (li,lj) of the 8 x 8 lane grid
+//     owns the 8 x 8 pairs { wr*64 + li + 8t } x { wc*64 + lj + 8u }: 64 u32
+//     accumulators in VGPRs.  Per 16 bytes of K a lane issues 16 ds_read_b128
+//     (8 A rows, 8 B rows) against 256 v_and_b32 + 256 v_bcnt_u32_b32: the
+//     loop is VALU-issue bound by construction (LDS pipe at ~25 %).
+//   * K is walked in chunks of KC = 32 words (128 B = one cache line per row).
+//     A chunk of the A tile and of the B tile (2 x 16 KiB) is DMA'd HBM -> LDS
+//     with global_load_lds_dwordx4 (no VGPR staging), double buffered: the
+//     loads of chunk c+1 are in flight while chunk c is contracted; one
+//     barrier per chunk.
+//   * LDS image is lane-linear per wave-instruction (8 rows x 128 B), so the
+//     bank swizzle lives on the *source* address: 16-byte slot q of row r is
+//     stored at slot q ^ ((r >> 1) & 7).  A ds_read_b128 lane group then sees
+//     8 consecutive rows at 8 distinct (row parity, slot) bank positions:
+//     conflict free (MI355X_MICROARCH.md, LDS table).
+//   * no MFMA: this is integer popcount.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace twk {
+
+constexpr int TILE = 128;       // rows per block tile edge
+constexpr int KC   = 32;        // 32-bit words of K per chunk (128 B per row)
+constexpr int LDS_TILE_BYTES = TILE * KC * 4;   // 16 KiB: one operand, one chunk
+
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
+
+// One LDS-DMA: 64 lanes x 16 B, HBM -> LDS at (wave-uniform lds_byte + 16*lane).
+// Issued through asm so that hipcc does not see it: with the builtin it drains
+// vmcnt(0) in front of the next ds_read (it cannot prove the DMA does not alias
+// the reads), which serialises staging with the contraction.  We count it
+// ourselves: one `s_waitcnt vmcnt(0)` per chunk, right before the barrier
+// (cdna_hip_programming.md 5.7: M0 is written in the same statement).
+__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_byte) {
+	uint32_t keep;
+	asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+	             "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+	             : "=&s"(keep) : "v"(gsrc), "s"(lds_byte) : "memory");
+}
+
+// HBM -> LDS for one chunk of one 128-row operand tile: 16 wave-instructions
+// of 1 KiB; this wave issues `n` of them starting at segment `seg0`.
+// lds_tile_byte: LDS byte address of the operand tile (wave-uniform).
+__device__ __forceinline__ void stage_rows(const uint32_t* __restrict__ rows, size_t W,
+                                           uint32_t row0, uint32_t chunk, uint32_t lds_tile_byte,
+                                           int seg0, int n, int lane) {
+	const int lr = lane >> 3;          // row within the 8-row segment
+	const int ls = lane & 7;           // 16-byte slot written by this lane
+#pragma unroll
+	for (int i = 0; i < n; ++i) {
+		const int seg = seg0 + i;
+		const int r = seg * 8 + lr;                    // row within the tile
+		const int src_slot = ls ^ ((r >> 1) & 7);      // swizzle on the source
+		const uint32_t* g = rows + (size_t)(row0 + r) * W + (size_t)chunk * KC + src_slot * 4;
+		glds16(g, lds_tile_byte + seg * 8 * KC * 4);
+	}
+}
+
+// Eight independent (AND, popcount-accumulate) pairs against one B word:
+//     acc[t] += popc(a[t] & b),  t = 0..7
+// v_bcnt_u32_b32 D = popc(S0) + S1 folds the accumulate into the popcount, so
+// a word pair costs exactly one v_and_b32 (full rate) + one v_bcnt_u32_b32
+// (half rate on gfx950: measured 3.7e13 vs 7.2e13 lane-ops/s).  Left to itself
+// hipcc (a) reassociates the adds into bcnt(x,0) + v_add3 (+25 % VALU) and
+// (b) serialises everything through one temporary, so every instruction waits
+// for the previous one.  The asm block pins the accumulate form and issues the
+// 8 ANDs, then the 8 BCNTs: every dependent pair is 8 issue slots apart.
+__device__ __forceinline__ void and_bcnt8(uint32_t (&acc)[8][8], int u, uint32_t a0, uint32_t a1,
+                                          uint32_t a2, uint32_t a3, uint32_t a4, uint32_t a5,
+                                          uint32_t a6, uint32_t a7, uint32_t b) {
+	uint32_t t0, t1, t2, t3, t4, t5, t6, t7;
+	asm("v_and_b32 %8, %16, %24\n\t"
+	    "v_and_b32 %9, %17, %24\n\t"
+	    "v_and_b32 %10, %18, %24\n\t"
+	    "v_and_b32 %11, %19, %24\n\t"
+	    "v_and_b32 %12, %20, %24\n\t"
+	    "v_and_b32 %13, %21, %24\n\t"
+	    "v_and_b32 %14, %22, %24\n\t"
+	    "v_and_b32 %15, %23, %24\n\t"
+	    "v_bcnt_u32_b32 %0, %8, %0\n\t"
+	    "v_bcnt_u32_b32 %1, %9, %1\n\t"
+	    "v_bcnt_u32_b32 %2, %10, %2\n\t"
+	    "v_bcnt_u32_b32 %3, %11, %3\n\t"
+	    "v_bcnt_u32_b32 %4, %12, %4\n\t"
+	    "v_bcnt_u32_b32 %5, %13, %5\n\t"
+	    "v_bcnt_u32_b32 %6, %14, %6\n\t"
+	    "v_bcnt_u32_b32 %7, %15, %7"
+	    : "+v"(acc[0][u]), "+v"(acc[1][u]), "+v"(acc[2][u]), "+v"(acc[3][u]),
+	      "+v"(acc[4][u]), "+v"(acc[5][u]), "+v"(acc[6][u]), "+v"(acc[7][u]),
+	      "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
+	    : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7), "v"(b));
+}
+
+// acc[t][u] += popc(a[t] & b) over the four words of a 16-byte slot.
+__device__ __forceinline__ void contract_slot(uint32_t (&acc)[8][8], int u, const uint4 (&a)[8], const uint4& b) {
+	and_bcnt8(acc, u, a[0].x, a[1].x, a[2].x, a[3].x, a[4].x, a[5].x, a[6].x, a[7].x, b.x);
+	and_bcnt8(acc, u, a[0].y, a[1].y, a[2].y, a[3].y, a[4].y, a[5].y, a[6].y, a[7].y, b.y);
+	and_bcnt8(acc, u, a[0].z, a[1].z, a[2].z, a[3].z, a[4].z, a[5].z, a[6].z, a[7].z, b.z);
+	and_bcnt8(acc, u, a[0].w, a[1].w, a[2].w, a[3].w, a[4].w, a[5].w, a[6].w, a[7].w, b.w);
+}
+
+// grid: x = column tiles, y = row tiles of the super-tile.  C is the count
+// matrix of the super-tile: C[(by*128 + r) * ldc + bx*128 + c].
+// diag != 0: the super-tile sits on the diagonal (rowA0 == rowB0); tiles with
+// bx < by are not needed and exit at once.
+__global__ __launch_bounds__(256, 2)
+void k_count_tile(const uint32_t* __restrict__ rows, uint32_t W, uint32_t rowA0, uint32_t rowB0,
+                  int diag, uint32_t* __restrict__ C, uint32_t ldc) {
+	__shared__ __attribute__((aligned(16))) uint32_t lds[2 * 2 * TILE * KC];   // [buf][A|B] 64 KiB
+
+	const uint32_t bx = blockIdx.x, by = blockIdx.y;
+	if (diag && bx < by) return;
+
+	const int tid  = threadIdx.x;
+	const int lane = tid & 63;
+	const int wave = tid >> 6;
+	const int wr = wave >> 1, wc = wave & 1;
+	const int li = lane >> 3, lj = lane & 7;
+
+	const uint32_t tileA0 = rowA0 + by * TILE;
+	const uint32_t tileB0 = rowB0 + bx * TILE;
+	const uint32_t nchunks = W / KC;
+
+	uint32_t acc[8][8];
+#pragma unroll
+	for (int t = 0; t < 8; ++t)
+#pragma unroll
+		for (int u = 0; u < 8; ++u) acc[t][u] = 0;
+
+	// Per-lane LDS byte offsets.  Row (w*64 + l + 8t): (row >> 1) & 7 =
+	// ((l >> 1) + 4t) & 7 = (l >> 1) ^ ((t & 1) << 2), so slot q of that row
+	// lives at slot q ^ (l >> 1) ^ ((t & 1) << 2).  offX[k] = row base +
+	// 16 * ((l >> 1) ^ k); the reads below pick k = q ^ ((t & 1) << 2) and add
+	// the compile-time row stride 8*t*128.
+	uint32_t offA[8], offB[8];
+#pragma unroll
+	for (int k = 0; k < 8; ++k) {
+		offA[k] = (uint32_t)((wr * 64 + li) * (KC * 4) + (((li >> 1) ^ k) << 4));
+		offB[k] = (uint32_t)(LDS_TILE_BYTES + (wc * 64 + lj) * (KC * 4) + (((lj >> 1) ^ k) << 4));
+	}
+	const char* lds_b = reinterpret_cast<const char*>(lds);
+
+	// Staging split: 32 wave-instructions per chunk (16 A + 16 B), 8 per wave.
+	// waves 0,1 -> A segments 0-7 / 8-15; waves 2,3 -> B segments 0-7 / 8-15.
+	const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+	const uint32_t st_row0 = (wave_u < 2) ? tileA0 : tileB0;
+	const int st_seg0 = (wave_u & 1) * 8;
+	const uint32_t lds_base = (uint32_t)(uintptr_t)(lptr_t*)lds;                    // LDS byte address
+	const uint32_t st_lds = lds_base + ((wave_u < 2) ? 0u : (uint32_t)LDS_TILE_BYTES);
+
+	stage_rows(rows, W, st_row0, 0, st_lds, st_seg0, 8, lane);
+
+	for (uint32_t c = 0; c < nchunks; ++c) {
+		const int buf = c & 1;
+		// Chunk c was issued one contraction ago: drain this wave's DMAs, then
+		// the barrier makes every wave's part visible and proves every wave is
+		// done reading the other buffer (chunk c-1).
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__syncthreads();
+		if (c + 1 < nchunks)
+			stage_rows(rows, W, st_row0, c + 1, st_lds + (buf ^ 1) * (2 * LDS_TILE_BYTES), st_seg0, 8, lane);
+
+		const char* base = lds_b + buf * (2 * LDS_TILE_BYTES);
+		uint4 a[2][8];
+#pragma unroll
+		for (int t = 0; t < 8; ++t)
+			a[0][t] = *reinterpret_cast<const uint4*>(base + offA[(t & 1) << 2] + t * 8 * (KC * 4));
+#pragma unroll
+		for (int q = 0; q < 8; ++q) {
+			// prefetch the A rows of the next 16-byte slot while this one is contracted
+			if (q + 1 < 8) {
+#pragma unroll
+				for (int t = 0; t < 8; ++t)
+					a[(q + 1) & 1][t] = *reinterpret_cast<const uint4*>(base + offA[(q + 1) ^ ((t & 1) << 2)] + t * 8 * (KC * 4));
+			}
+#pragma unroll
+			for (int u = 0; u < 8; ++u) {
+				const uint4 b = *reinterpret_cast<const uint4*>(base + offB[q ^ ((u & 1) << 2)] + u * 8 * (KC * 4));
+				contract_slot(acc, u, a[q & 1], b);
+			}
+		}
+	}
+
+	// Epilogue: each lane stores its 8 x 8 counts.  For fixed (t,u) the 8 lanes
+	// of one li write 8 consecutive u32 (32 B); small next to the K loop.
+	uint32_t* Cblk = C + (size_t)(by * TILE + wr * 64 + li) * ldc + bx * TILE + wc * 64 + lj;
+#pragma unroll
+	for (int t = 0; t < 8; ++t)
+#pragma unroll
+		for (int u = 0; u < 8; ++u) Cblk[(size_t)(8 * t) * ldc + 8 * u] = acc[t][u];
+}
+
+}  // namespace twk
