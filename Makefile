@@ -1,0 +1,52 @@
+# Build everything in-tree for gfx950 (MI355X).  hipcc cross-compiles without a GPU.
+#   lib/libtwk_hip.so       HIP kernels + C ABI (include/twk_hip.h)
+#   lib/libtomahawk_amd.so  host C++: .twk/.two formats, tomahawk::twk_ld, test C API
+#   bin/tomahawk            `tomahawk calc` CLI
+#   oracle/liboracle.so     CPU oracle (tests only)   oracle/_ref/  compiled reference (tests/baseline only)
+HIPCC    ?= /opt/rocm/bin/hipcc
+CXX      ?= g++
+ARCH     ?= gfx950
+PKG      := tomahawk_amd
+LIBDIR   := $(PKG)/lib
+BINDIR   := $(PKG)/bin
+ZSTD_LIB ?= /usr/lib/x86_64-linux-gnu/libzstd.so.1
+
+HIP_SRC  := $(PKG)/csrc/hip/twk_hip.hip
+HIP_DEPS := $(wildcard $(PKG)/csrc/hip/*.h) include/twk_hip.h
+# -ffp-contract=off: the pair statistics must round like the reference's SSE4.2 build (ld_math.hip.h)
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function
+
+HOST_SRC := $(wildcard $(PKG)/csrc/host/*.cpp)
+HOST_LIB_SRC := $(filter-out %/calc_main.cpp,$(HOST_SRC))
+HOST_DEPS := $(wildcard $(PKG)/csrc/host/*.h) include/twk_hip.h
+CXXFLAGS := -O2 -std=c++17 -fPIC -Wall -pthread -Iinclude -I$(PKG)/csrc/host
+
+.PHONY: all hip host cli oracle tools clean
+all: hip host cli oracle
+
+hip: $(LIBDIR)/libtwk_hip.so
+$(LIBDIR)/libtwk_hip.so: $(HIP_SRC) $(HIP_DEPS)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -shared $(HIP_SRC) -o $@
+
+host: $(LIBDIR)/libtomahawk_amd.so
+$(LIBDIR)/libtomahawk_amd.so: $(HOST_LIB_SRC) $(HOST_DEPS) $(LIBDIR)/libtwk_hip.so
+	@mkdir -p $(LIBDIR)
+	$(CXX) $(CXXFLAGS) -shared $(HOST_LIB_SRC) -o $@ -L$(LIBDIR) -ltwk_hip $(ZSTD_LIB) -Wl,-rpath,'$$ORIGIN'
+
+cli: $(BINDIR)/tomahawk
+$(BINDIR)/tomahawk: $(PKG)/csrc/host/calc_main.cpp $(LIBDIR)/libtomahawk_amd.so
+	@mkdir -p $(BINDIR)
+	$(CXX) $(CXXFLAGS) $< -o $@ -L$(LIBDIR) -ltomahawk_amd -ltwk_hip $(ZSTD_LIB) -Wl,-rpath,'$$ORIGIN/../lib'
+
+oracle:
+	$(MAKE) -C oracle all
+
+tools: build/count_microbench build/valu_rate
+build/%: $(PKG)/csrc/tools/%.hip $(HIP_DEPS)
+	@mkdir -p build
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 $< -o $@
+
+clean:
+	rm -rf $(LIBDIR) $(BINDIR) build
+	$(MAKE) -C oracle clean

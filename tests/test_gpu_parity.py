@@ -1,0 +1,170 @@
+"""GPU parity: HIP path (through the C ABI) vs the CPU oracle on the same seeded inputs.
+
+Bar: contingency counts bit-exact; D, D', r, r2, chi-squared and Fisher P within 1e-6 relative
+(P with an absolute floor where it underflows).
+"""
+import numpy as np
+import pytest
+
+import tomahawk_amd as T
+from oracle import oracle as O
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+CASES = [  # (N, M, seed)  N=100 is not a multiple of 32/64: exercises the padding paths
+    (64, 40, 1), (100, 150, 2), (1000, 200, 3), (2049, 131, 4),
+]
+
+
+@pytest.mark.parametrize("N,M,seed", CASES)
+def test_counts_phased_bitexact(hip, N, M, seed):
+    al = util.random_alleles(M, N, seed, low_ac=6)
+    data, mask, _ = util.upload(hip, al)
+    got = hip.count_tile(T.MODE_PHASED, 0, M, 0, M, diag=False)
+    for i in range(0, M, 7):
+        for j in range(0, M, 5):
+            want = O.count_phased(data[i], None, data[j], None, N)
+            assert np.array_equal(got[i, j], want), (i, j, got[i, j], want)
+
+
+@pytest.mark.parametrize("N,M,seed", CASES)
+def test_counts_unphased_bitexact(hip, N, M, seed):
+    al = util.random_alleles(M, N, seed, low_ac=6)
+    data, mask, _ = util.upload(hip, al)
+    got = hip.count_tile(T.MODE_UNPHASED, 0, M, 0, M, diag=False)
+    for i in range(0, M, 7):
+        for j in range(0, M, 5):
+            want = O.count_unphased(data[i], None, data[j], None, N)
+            assert np.array_equal(got[i, j], want), (i, j, got[i, j], want)
+
+
+@pytest.mark.parametrize("N,M,seed", [(64, 60, 11), (128, 140, 12), (192, 90, 13)])
+def test_counts_with_missing_bitexact(hip, N, M, seed):
+    al = util.random_alleles(M, N, seed, miss_rate=0.1, miss_variants=0.4)
+    data, mask, variants = util.upload(hip, al)
+    assert mask is not None
+    gp = hip.count_tile(T.MODE_PHASED, 0, M, 0, M)
+    gu = hip.count_tile(T.MODE_UNPHASED, 0, M, 0, M)
+    for i in range(0, M, 3):
+        for j in range(0, M, 4):
+            mi = mask[i] if variants["gt_missing"][i] else None
+            mj = mask[j] if variants["gt_missing"][j] else None
+            assert np.array_equal(gp[i, j], O.count_phased(data[i], mi, data[j], mj, N)), (i, j)
+            assert np.array_equal(gu[i, j], O.count_unphased(data[i], mi, data[j], mj, N)), (i, j)
+
+
+def test_count_tile_offsets_and_diag(hip):
+    N, M = 300, 400
+    al = util.random_alleles(M, N, 21)
+    data, _, _ = util.upload(hip, al)
+    sq = hip.count_tile(T.MODE_UNPHASED, 130, 100, 257, 143, diag=False)
+    for i, j in [(0, 0), (99, 142), (50, 77), (3, 140)]:
+        assert np.array_equal(sq[i, j], O.count_unphased(data[130 + i], None, data[257 + j], None, N))
+    dg = hip.count_tile(T.MODE_PHASED, 128, 200, 128, 200, diag=True)
+    assert not dg[10, 10].any() and not dg[20, 5].any()          # excluded by diag -> zero-filled
+    assert np.array_equal(dg[5, 20], O.count_phased(data[133], None, data[148], None, N))
+    assert np.array_equal(dg[0, 199], O.count_phased(data[128], None, data[327], None, N))
+
+
+@pytest.mark.parametrize("mode,phased", [(T.MODE_PHASED, True), (T.MODE_UNPHASED, False)])
+@pytest.mark.parametrize("N,M,seed", CASES)
+def test_records_match_oracle(hip, mode, phased, N, M, seed):
+    al = util.random_alleles(M, N, seed, low_ac=6)
+    data, mask, variants = util.upload(hip, al, phase=int(phased))
+    st = O.settings(minR2=0.0, phased=phased, unphased=not phased)
+    want = O.all_pairs(data, mask, variants, N, st, vector_only=True)
+    got, npairs, nrec = hip.ld_all(mode, T.Filters(minR2=0.0))
+    assert npairs == M * (M - 1) // 2
+    assert nrec == len(got) == len(want)
+    util.assert_records_match(got, want, variants, exact_counts=phased)
+
+
+@pytest.mark.parametrize("minR2,minP,minD", [(0.1, 1.0, 0.0), (0.02, 1e-3, 0.0), (0.0, 1.0, 0.5)])
+def test_filters(hip, minR2, minP, minD):
+    N, M = 500, 160
+    rng = np.random.default_rng(5)
+    al = util.random_alleles(M, N, 5)
+    for v in range(1, M, 2):        # correlated neighbours so that some pairs pass r2 >= 0.1
+        flip = rng.random((N, 2)) < 0.15
+        al[v] = np.where(flip, al[v], al[v - 1])
+    data, mask, variants = util.upload(hip, al)
+    for mode, phased in ((T.MODE_PHASED, True), (T.MODE_UNPHASED, False)):
+        st = O.settings(minR2=minR2, minP=minP, minDprime=minD, phased=phased, unphased=not phased)
+        want = O.all_pairs(data, mask, variants, N, st)
+        got, _, _ = hip.ld_all(mode, T.Filters(minR2=minR2, minP=minP, minDprime=minD))
+        assert len(want) > 0
+        util.assert_records_match(got, want, variants, exact_counts=phased)
+
+
+@pytest.mark.parametrize("mode", [T.MODE_PHASED, T.MODE_UNPHASED, T.MODE_AUTO])
+def test_records_with_missing(hip, mode):
+    N, M = 128, 120
+    al = util.random_alleles(M, N, 31, miss_rate=0.08, miss_variants=0.3, low_ac=4)
+    data, mask, variants = util.upload(hip, al)
+    st = O.settings(minR2=0.0, phased=(mode == T.MODE_PHASED), unphased=(mode == T.MODE_UNPHASED))
+    want = O.all_pairs(data, mask, variants, N, st, vector_only=True)
+    got, _, _ = hip.ld_all(mode, T.Filters(minR2=0.0))
+    util.assert_records_match(got, want, variants, exact_counts=False)
+
+
+def test_sharded_union_equals_whole(hip):
+    """The multi-GPU partition: shards are disjoint and their union is the whole triangle."""
+    N, M = 200, 700
+    al = util.random_alleles(M, N, 41)
+    data, mask, variants = util.upload(hip, al)
+    f = T.Filters(minR2=0.0)
+    whole, npairs, _ = hip.ld_all(T.MODE_PHASED, f, tile_variants=128)
+    parts = [hip.ld_all(T.MODE_PHASED, f, part=k, n_parts=3, tile_variants=128) for k in range(3)]
+    assert sum(p[1] for p in parts) == npairs == M * (M - 1) // 2
+    keys = [set(zip(p[0]["idxA"].tolist(), p[0]["idxB"].tolist())) for p in parts]
+    assert not (keys[0] & keys[1]) and not (keys[0] & keys[2]) and not (keys[1] & keys[2])
+    assert set().union(*keys) == set(zip(whole["idxA"].tolist(), whole["idxB"].tolist()))
+    loads = [p[1] for p in parts]
+    assert max(loads) < 1.35 * min(loads)
+
+
+def test_overflow_is_reported_and_recovered(hip):
+    N, M = 64, 300
+    al = util.random_alleles(M, N, 51)
+    util.upload(hip, al)
+    with pytest.raises(T.HipError) as e:
+        hip.ld_tile(T.MODE_PHASED, 0, M, 0, M, True, T.Filters(minR2=0.0), capacity=10)
+    assert e.value.code == -4
+    recs, npairs = hip.ld_tile(T.MODE_PHASED, 0, M, 0, M, True, T.Filters(minR2=0.0))
+    assert npairs == M * (M - 1) // 2 and len(recs) > 10
+
+
+def test_synthetic_generator_matches_host_twin(hip):
+    N, M = 1000, 64
+    hip.set_problem(N, M)
+    hip.generate_synthetic(42)
+    ac, het, hom, miss = hip.marginals()
+    data = np.zeros((M, O.words64(N)), dtype=np.uint64)
+    for v in range(M):
+        data[v], a = T.synth_bitvector(42, N, v)
+        assert a == ac[v]
+    got = hip.count_tile(T.MODE_UNPHASED, 0, M, 0, M)
+    for i, j in [(0, 1), (5, 60), (63, 2)]:
+        assert np.array_equal(got[i, j], O.count_unphased(data[i], None, data[j], None, N))
+    assert 0.04 * 2 * N < ac.min() and ac.max() < 0.56 * 2 * N and not miss.any()
+
+
+def test_large_sample_axis_roundtrip_property(hip):
+    """Full-size rows (N = 1M samples): size-independent invariants of the tables."""
+    N, M = 1_000_000, 256
+    hip.set_problem(N, M)
+    hip.generate_synthetic(7)
+    ac, het, hom, _ = hip.marginals()
+    cu = hip.count_tile(T.MODE_UNPHASED, 0, M, 0, M)
+    cp = hip.count_tile(T.MODE_PHASED, 0, M, 0, M)
+    assert (cu.sum(axis=2) == N).all() and (cp.sum(axis=2) == 2 * N).all()
+    # row / column marginals of the 3x3 table are the per-variant genotype counts
+    assert (cu[:, :, 3:6].sum(axis=2) == het[:, None]).all() and (cu[:, :, 6:9].sum(axis=2) == hom[:, None]).all()
+    assert (cu[:, :, [1, 4, 7]].sum(axis=2) == het[None, :]).all()
+    # phased: ALTALT + c[1] = ac_A ; table of (i,j) is the transpose of (j,i)
+    assert (cp[:, :, 3] + cp[:, :, 1] == ac[:, None]).all()
+    assert np.array_equal(cp[:, :, 1], cp[:, :, 2].T) and np.array_equal(cu[:, :, 5], cu[:, :, 7].T)
+    # self-pair: every sample is on the diagonal of the table
+    d = np.arange(M)
+    assert (cu[d, d][:, [1, 2, 3, 5, 6, 7]] == 0).all()

@@ -1,0 +1,438 @@
+// Pair statistics on the device: plane products -> contingency cells -> D, D',
+// r, r2, Fisher's exact P, chi-squared, flags -> filters -> compacted records.
+//
+// Device counterpart of twk_ld_engine::PhasedMath / UnphasedMath /
+// ChiSquaredUnphasedTable / ChooseF11Calculate (lib/ld/ld_engine.cpp:1162-1740)
+// and kt_fisher_exact (lib/fisher_math.cpp:183-267).  All floating point is
+// FP64 and this translation unit is compiled with -ffp-contract=off so that
+// products and sums round exactly where the reference's SSE4.2 build rounds
+// them (filter decisions on r2 and D' are then bit-identical; lgamma / exp /
+// pow / acos / cos come from the device math library and agree with glibc to
+// a few ulp, well inside the 1e-6 relative budget).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include "../../../include/twk_hip.h"
+
+namespace twk {
+
+// lib/ld/ld_engine.h:33-37
+#define TWK_D_LOW_AC        5
+#define TWK_D_INVALID_HWE   1e-4
+#define TWK_D_LONG_RANGE    500e3
+#define TWK_D_MIN_ALLELES   5
+#define TWK_D_ROUNDING_ERR  0.00001
+
+struct VariantMeta {       // SoA view of twk_hip_variant_meta on the device
+	const uint32_t* ac;
+	const uint32_t* an;
+	const uint32_t* pos;
+	const uint32_t* rid;
+	const uint32_t* missing;
+	const double*   hwe;
+};
+
+// ---- Fisher's exact test: fisher_math.cpp:183-267 ------------------------------
+__device__ inline double d_lbinom(int n, int k) {
+	if (k == 0 || n == k) return 0;
+	return lgamma((double)(n + 1)) - lgamma((double)(k + 1)) - lgamma((double)(n - k + 1));
+}
+__device__ inline double d_hypergeo(int n11, int n1_, int n_1, int n) {
+	return exp(d_lbinom(n1_, n11) + d_lbinom(n - n1_, n_1 - n11) - d_lbinom(n, n_1));
+}
+struct hgacc { int n11, n1_, n_1, n; double p; };
+__device__ inline double d_hypergeo_acc(int n11, int n1_, int n_1, int n, hgacc* aux) {
+	if (n1_ || n_1 || n) {
+		aux->n11 = n11; aux->n1_ = n1_; aux->n_1 = n_1; aux->n = n;
+	} else {
+		if (n11 % 11 && n11 + aux->n - aux->n1_ - aux->n_1) {
+			if (n11 == aux->n11 + 1) {
+				aux->p *= (double)(aux->n1_ - aux->n11) / n11
+				        * (aux->n_1 - aux->n11) / (n11 + aux->n - aux->n1_ - aux->n_1);
+				aux->n11 = n11;
+				return aux->p;
+			}
+			if (n11 == aux->n11 - 1) {
+				aux->p *= (double)aux->n11 / (aux->n1_ - n11)
+				        * (aux->n11 + aux->n - aux->n1_ - aux->n_1) / (aux->n_1 - n11);
+				aux->n11 = n11;
+				return aux->p;
+			}
+		}
+		aux->n11 = n11;
+	}
+	aux->p = d_hypergeo(aux->n11, aux->n1_, aux->n_1, aux->n);
+	return aux->p;
+}
+// Two-sided P only (left / right tails are not stored in the record).
+__device__ inline double d_fisher_two(int n11, int n12, int n21, int n22) {
+	int i, j, max, min;
+	double p, q, left, right;
+	hgacc aux;
+	const int n1_ = n11 + n12, n_1 = n11 + n21, n = n11 + n12 + n21 + n22;
+	max = (n_1 < n1_) ? n_1 : n1_;
+	min = n1_ + n_1 - n;
+	if (min < 0) min = 0;
+	if (min == max) return 1.;
+	q = d_hypergeo_acc(n11, n1_, n_1, n, &aux);
+	p = d_hypergeo_acc(min, 0, 0, 0, &aux);
+	for (left = 0., i = min + 1; p < 0.99999999 * q && i <= max; ++i)
+		left += p, p = d_hypergeo_acc(i, 0, 0, 0, &aux);
+	if (p < 1.00000001 * q) left += p;
+	p = d_hypergeo_acc(max, 0, 0, 0, &aux);
+	for (right = 0., j = max - 1; p < 0.99999999 * q && j >= 0; --j)
+		right += p, p = d_hypergeo_acc(j, 0, 0, 0, &aux);
+	if (p < 1.00000001 * q) right += p;
+	double two = left + right;
+	if (two > 1.) two = 1.;
+	return two;
+}
+
+// ---- flags shared by both maths: ld_engine.cpp:1244-1255 / 1674-1684 -----------------
+__device__ inline uint32_t d_common_flags(const VariantMeta& vm, uint32_t A, uint32_t B,
+                                          const double cnt[4], double R2) {
+	uint32_t c = 0;
+	if (vm.ac[A] < TWK_D_LOW_AC) c |= 1u << 10;
+	if (vm.ac[B] < TWK_D_LOW_AC) c |= 1u << 11;
+	if (cnt[0] < 1 || cnt[1] < 1 || cnt[2] < 1 || cnt[3] < 1) c |= 1u << 3;
+	if (R2 > 0.99) c |= 1u << 4;
+	if (vm.an[A]) c |= 1u << 8;
+	if (vm.an[B]) c |= 1u << 9;
+	const int32_t diff = (int32_t)vm.pos[A] - (int32_t)vm.pos[B];
+	const bool same = vm.rid[A] == vm.rid[B];
+	if (abs(diff) > TWK_D_LONG_RANGE && same) c |= 1u << 2;
+	if (same) c |= 1u << 1;
+	if (vm.hwe[A] < TWK_D_INVALID_HWE) c |= 1u << 12;
+	if (vm.hwe[B] < TWK_D_INVALID_HWE) c |= 1u << 13;
+	return c;
+}
+
+// ---- PhasedMath: ld_engine.cpp:1162-1310 ------------------------------------------------
+// c0,c1,c4,c5 = alleleCounts[0],[1],[4],[5].  Returns true if the pair survives.
+__device__ inline bool d_phased_math(uint64_t c0, uint64_t c1, uint64_t c4, uint64_t c5,
+                                     const VariantMeta& vm, uint32_t A, uint32_t B,
+                                     const twk_hip_filters& f, twk_hip_record* rec) {
+	const uint64_t total = c0 + c4 + c1 + c5;
+	if (total < TWK_D_MIN_ALLELES) return false;
+	if (c0 < c5) { if (c4 + c1 + c0 < 5) return false; }
+	else         { if (c5 + c4 + c1 < 5) return false; }
+	const double T = (double)total;
+	const double pA = (double)c0 / T, qA = (double)c1 / T, pB = (double)c4 / T, qB = (double)c5 / T;
+	const double D = pA * qB - qA * pB;
+	if (D == 0) return false;
+	const double g0 = ((double)c0 + (double)c4) / T;
+	const double g1 = ((double)c1 + (double)c5) / T;
+	const double h0 = ((double)c0 + (double)c1) / T;
+	const double h1 = ((double)c4 + (double)c5) / T;
+	const double R2 = D * D / (g0 * g1 * h0 * h1);
+	if (R2 < f.minR2 || R2 > f.maxR2) return false;
+	double dmax;
+	if (D >= 0) dmax = g0 * h1 < h0 * g1 ? g0 * h1 : h0 * g1;
+	else        dmax = g0 * g1 < h0 * h1 ? -g0 * g1 : -h0 * h1;
+	const double Dprime = D / dmax;
+	if (Dprime < f.minDprime || Dprime > f.maxDprime) return false;
+	const double both = d_fisher_two((int)c0, (int)c4, (int)c1, (int)c5);
+	if (both > f.minP) return false;
+	rec->idxA = A; rec->idxB = B; rec->_pad = 0;
+	rec->cnt[0] = (double)c0; rec->cnt[1] = (double)c1; rec->cnt[2] = (double)c4; rec->cnt[3] = (double)c5;
+	rec->D = D; rec->Dprime = Dprime; rec->R = sqrt(R2); rec->R2 = R2; rec->P = both;
+	rec->ChiSqFisher = T * R2; rec->ChiSqModel = 0;
+	rec->flags = d_common_flags(vm, A, B, rec->cnt, R2) | 1u;
+	return true;
+}
+
+// ---- ChiSquaredUnphasedTable: ld_engine.cpp:1562-1588 -------------------------------------
+// o = {0, 1+4, 5, 16+64, hets, 21+69, 80, 81+84, 85}
+__device__ inline double d_chisq_unphased(const double o[9], double total, double target, double p, double q) {
+	const double f12 = p - target;
+	const double f21 = q - target;
+	const double f22 = 1 - (target + f12 + f21);
+	double e[9];
+	e[0] = total * (target * target);
+	e[1] = 2 * total * target * f12;
+	e[2] = total * (f12 * f12);
+	e[3] = 2 * total * target * f21;
+	e[4] = 2 * total * f12 * f21 + 2 * total * target * f22;
+	e[5] = 2 * total * f12 * f22;
+	e[6] = total * (f21 * f21);
+	e[7] = 2 * total * f21 * f22;
+	e[8] = total * (f22 * f22);
+	double s = 0;
+#pragma unroll
+	for (int k = 0; k < 9; ++k) {
+		const double d = o[k] - e[k];
+		s += e[k] > 0 ? (d * d) / e[k] : 0;
+	}
+	return s;
+}
+
+// ---- ChooseF11Calculate: ld_engine.cpp:1590-1740 ---------------------------------------------
+__device__ inline bool d_choose_f11(double total, double target, double p, double q, uint32_t pre_flags,
+                                    const VariantMeta& vm, uint32_t A, uint32_t B,
+                                    const twk_hip_filters& f, twk_hip_record* rec) {
+	const double f11 = target;
+	const double f12 = p - f11;
+	const double f21 = q - f11;
+	const double f22 = 1 - (f11 + f12 + f21);
+	const double D = (f11 * f22) - (f12 * f21);
+	const double R2 = (D * D) / (p * (1 - p) * q * (1 - q));
+	if (R2 < f.minR2 || R2 > f.maxR2) return false;
+	double cnt[4];
+	cnt[0] = f11 * 2 * total;
+	cnt[2] = f12 * 2 * total;
+	cnt[1] = f21 * 2 * total;
+	cnt[3] = f22 * 2 * total;
+	if (cnt[0] < cnt[3]) { if (cnt[2] + cnt[1] + cnt[0] < 5) return false; }
+	else                 { if (cnt[3] + cnt[2] + cnt[1] < 5) return false; }
+	double dmax;
+	if (D >= 0) dmax = p * (1.0 - q) < q * (1.0 - p) ? p * (1.0 - q) : q * (1.0 - p);
+	else        dmax = p * q < (1 - p) * (1 - q) ? -p * q : -(1 - p) * (1 - q);
+	const double Dprime = D / dmax;
+	if (Dprime < f.minDprime || Dprime > f.maxDprime) return false;
+	const double both = d_fisher_two((int)round(cnt[0]), (int)round(cnt[2]), (int)round(cnt[1]), (int)round(cnt[3]));
+	if (both > f.minP) return false;
+	rec->idxA = A; rec->idxB = B; rec->_pad = 0;
+	rec->cnt[0] = cnt[0]; rec->cnt[1] = cnt[1]; rec->cnt[2] = cnt[2]; rec->cnt[3] = cnt[3];
+	rec->D = D; rec->Dprime = Dprime; rec->R = sqrt(R2); rec->R2 = R2; rec->P = both;
+	rec->ChiSqModel = 0;
+	rec->ChiSqFisher = (cnt[0] + cnt[2] + cnt[1] + cnt[3]) * R2;
+	rec->flags = pre_flags | d_common_flags(vm, A, B, cnt, R2);
+	return true;
+}
+
+// ---- UnphasedMath: ld_engine.cpp:1312-1560 ------------------------------------------------------
+// cell order: {0, 1+4, 5, 16+64, hets, 21+69, 80, 81+84, 85}
+__device__ inline bool d_unphased_math(const uint64_t c[9], const VariantMeta& vm, uint32_t A, uint32_t B,
+                                       const twk_hip_filters& f, twk_hip_record* rec) {
+	const uint64_t a0 = c[0], a14 = c[1], a5 = c[2], a1664 = c[3], hets = c[4], a2169 = c[5],
+	               a80 = c[6], a8184 = c[7], a85 = c[8];
+	const uint64_t total_u = a0 + a14 + a5 + a1664 + hets + a2169 + a80 + a8184 + a85;
+	if (total_u < TWK_D_MIN_ALLELES) return false;
+	if (hets == 0)   // no phase uncertainty: collapse to the 2x2 table (:1334-1348)
+		return d_phased_math(2 * a0 + a14 + a1664, 2 * a80 + a1664 + a8184, 2 * a5 + a14 + a2169,
+		                     2 * a85 + a8184 + a2169, vm, A, B, f, rec);
+
+	const double total = (double)total_u;
+	const double dh = (double)hets;
+	const double P = ((double)(a0 + a14 + a5) * 2.0 + (double)(a1664 + hets + a2169)) / (2.0 * total);
+	const double Q = ((double)(a0 + a1664 + a80) * 2.0 + (double)(a14 + hets + a8184)) / (2.0 * total);
+	const double n11 = (double)(2 * a0 + a14 + a1664);
+	const double minhap = n11 / (2.0 * total);
+	const double maxhap = (n11 + dh) / (2.0 * total);
+	const double dee = -n11 * P * Q;
+	const double cc = -n11 * (1.0 - 2.0 * P - 2.0 * Q) - dh * (1.0 - P - Q) + (2.0 * total * P * Q);
+	const double b = 2.0 * total * (1.0 - 2.0 * P - 2.0 * Q) - 2.0 * n11 - dh;
+	const double a = 4.0 * total;
+
+	const double xN  = -b / (3.0 * a);
+	const double d2  = ((b * b) - 3.0 * a * cc) / (9 * (a * a));
+	const double yN  = a * pow(xN, 3.0) + b * (xN * xN) + cc * xN + dee;
+	const double yN2 = yN * yN;
+	const double h2  = 4 * (a * a) * pow(d2, 3.0);
+	const double diff = yN2 - h2;
+	const double lo = minhap - TWK_D_ROUNDING_ERR, hi = maxhap + TWK_D_ROUNDING_ERR;
+	const double o[9] = { (double)a0, (double)a14, (double)a5, (double)a1664, dh, (double)a2169,
+	                      (double)a80, (double)a8184, (double)a85 };
+
+	if (diff < 0) {
+		const double h = pow(h2, 0.5);
+		const double theta = acos(-yN / h) / 3.0;
+		const double delta = pow(d2, 0.5);
+		const double alpha = xN + 2.0 * delta * cos(theta);
+		const double beta  = xN + 2.0 * delta * cos(2.0 * M_PI / 3.0 + theta);
+		const double gamma = xN + 2.0 * delta * cos(4.0 * M_PI / 3.0 + theta);
+		int possible = 0;
+		double best = 1.7976931348623157e308, chosen = alpha;
+		if (alpha >= lo && alpha <= hi) { ++possible; best = d_chisq_unphased(o, total, alpha, P, Q); }
+		if (beta >= lo && beta <= hi) {
+			++possible;
+			const double x = d_chisq_unphased(o, total, beta, P, Q);
+			if (x < best) { chosen = beta; best = x; }
+		}
+		if (gamma >= lo && gamma <= hi) {
+			++possible;
+			const double x = d_chisq_unphased(o, total, gamma, P, Q);
+			if (x < best) { chosen = gamma; best = x; }
+		}
+		if (possible == 0) return false;
+		return d_choose_f11(total, chosen, P, Q, possible > 1 ? (1u << 5) : 0u, vm, A, B, f, rec);
+	} else if (diff > 0) {
+		const double sq = pow(yN2 - h2, 0.5);
+		const double t1 = 1.0 / (2.0 * a) * (-yN + sq);
+		const double t2 = 1.0 / (2.0 * a) * (-yN - sq);
+		const double number1 = t1 < 0 ? -pow(-t1, 1.0 / 3.0) : pow(t1, 1.0 / 3.0);
+		const double number2 = t2 < 0 ? -pow(-t2, 1.0 / 3.0) : pow(t2, 1.0 / 3.0);
+		const double alpha = xN + number1 + number2;
+		if (!(alpha >= lo && alpha <= hi)) return false;
+		return d_choose_f11(total, alpha, P, Q, 0u, vm, A, B, f, rec);
+	} else {
+		const double delta = pow((yN / 2.0 * a), (1.0 / 3.0));
+		const double alpha = xN + delta;
+		const double gamma = xN - 2.0 * delta;
+		if (isnan(alpha) || isnan(gamma)) return false;
+		int possible = 0;
+		double best = 1.7976931348623157e308, chosen = alpha;
+		if (alpha >= lo && alpha <= hi) { ++possible; best = d_chisq_unphased(o, total, alpha, P, Q); }
+		if (gamma >= lo && gamma <= hi) {
+			++possible;
+			const double x = d_chisq_unphased(o, total, gamma, P, Q);
+			if (x < best) { chosen = gamma; best = x; }
+		}
+		if (possible == 0) return false;
+		return d_choose_f11(total, chosen, P, Q, 0u, vm, A, B, f, rec);
+	}
+}
+
+// ---- plane products -> contingency cells ---------------------------------------------------
+// How the rows of one variant are laid out and what the table is made from.
+enum PlaneKind : int {
+	PK_PHASED        = 0,  // 1 row : a                 (2N bits)
+	PK_PHASED_MASKED = 1,  // 2 rows: a & ~m, m
+	PK_UNPHASED      = 2,  // 2 rows: H, Q              (N bits)
+	PK_UNPHASED_MASKED = 3 // 3 rows: H & ~M, Q & ~M, M
+};
+__host__ __device__ inline int planes_per_variant(int kind) {
+	return kind == PK_PHASED ? 1 : (kind == PK_UNPHASED_MASKED ? 3 : 2);
+}
+
+struct TileView {
+	const uint32_t* C;        // plane-product counts of the super-tile
+	uint32_t ldc;
+	const uint32_t* rowpop;   // popcount of every plane row (global row index)
+	int kind;
+	uint32_t n_samples;
+	uint32_t a0, b0;          // first variant of the tile rows / cols
+};
+
+// 2x2 table (alleleCounts[0],[1],[4],[5]) of local pair (i,j).
+// PhasedListVector derivation (ld_engine.cpp:244-246) when nothing is masked;
+// PhasedVectorized masking (~(mA|mB), ld_engine.h:139-143) otherwise.
+__device__ inline void d_cells_phased(const TileView& t, uint32_t i, uint32_t j, uint64_t c[4]) {
+	const uint64_t twoN = 2ull * t.n_samples;
+	if (t.kind == PK_PHASED) {
+		const uint64_t AA = t.C[(size_t)i * t.ldc + j];
+		const uint64_t acA = t.rowpop[t.a0 + i], acB = t.rowpop[t.b0 + j];
+		c[3] = AA; c[1] = acA - AA; c[2] = acB - AA; c[0] = twoN - ((acA + acB) - AA);
+	} else {
+		const uint32_t* r0 = t.C + (size_t)(2 * i) * t.ldc + 2 * j;
+		const uint32_t* r1 = r0 + t.ldc;
+		const uint64_t AA = r0[0], AM = r0[1], MA = r1[0], MM = r1[1];
+		const uint64_t acA = t.rowpop[2 * (t.a0 + i)], nmA = t.rowpop[2 * (t.a0 + i) + 1];
+		const uint64_t acB = t.rowpop[2 * (t.b0 + j)], nmB = t.rowpop[2 * (t.b0 + j) + 1];
+		const uint64_t valid = twoN - nmA - nmB + MM;
+		c[3] = AA; c[1] = acA - AA - AM; c[2] = acB - AA - MA; c[0] = valid - c[1] - c[2] - c[3];
+	}
+}
+
+// 3x3 table as the nine sums UnphasedMath reads.
+__device__ inline void d_cells_unphased(const TileView& t, uint32_t i, uint32_t j, uint64_t c[9]) {
+	uint64_t HH, HQ, QH, QQ, nhA, nqA, nhB, nqB, nvalid;
+	if (t.kind == PK_UNPHASED) {
+		const uint32_t* r0 = t.C + (size_t)(2 * i) * t.ldc + 2 * j;
+		const uint32_t* r1 = r0 + t.ldc;
+		HH = r0[0]; HQ = r0[1]; QH = r1[0]; QQ = r1[1];
+		nhA = t.rowpop[2 * (t.a0 + i)]; nqA = t.rowpop[2 * (t.a0 + i) + 1];
+		nhB = t.rowpop[2 * (t.b0 + j)]; nqB = t.rowpop[2 * (t.b0 + j) + 1];
+		nvalid = t.n_samples;
+	} else {
+		const uint32_t* r0 = t.C + (size_t)(3 * i) * t.ldc + 3 * j;
+		const uint32_t* r1 = r0 + t.ldc;
+		const uint32_t* r2 = r1 + t.ldc;
+		HH = r0[0]; HQ = r0[1]; QH = r1[0]; QQ = r1[1];
+		const uint64_t HM = r0[2], QM = r1[2], MH = r2[0], MQ = r2[1], MM = r2[2];
+		const uint32_t ra = 3 * (t.a0 + i), rb = 3 * (t.b0 + j);
+		nhA = t.rowpop[ra] - HM; nqA = t.rowpop[ra + 1] - QM;
+		nhB = t.rowpop[rb] - MH; nqB = t.rowpop[rb + 1] - MQ;
+		nvalid = (uint64_t)t.n_samples - t.rowpop[ra + 2] - t.rowpop[rb + 2] + MM;
+	}
+	c[4] = HH;                 // (het, het)   cells 17+20+65+68
+	c[5] = HQ;                 // (het, 1/1)   cells 21+69
+	c[7] = QH;                 // (1/1, het)   cells 81+84
+	c[8] = QQ;                 // (1/1, 1/1)   cell  85
+	c[3] = nhA - HH - HQ;      // (het, 0/0)   cells 16+64
+	c[6] = nqA - QH - QQ;      // (1/1, 0/0)   cell  80
+	c[1] = nhB - HH - QH;      // (0/0, het)   cells 1+4
+	c[2] = nqB - HQ - QQ;      // (0/0, 1/1)   cell  5
+	c[0] = nvalid - (c[1] + c[2] + c[3] + c[4] + c[5] + c[6] + c[7] + c[8]);
+}
+
+// ---- the math / filter / compaction kernel ---------------------------------------------------
+struct StatsParams {
+	TileView tv;
+	VariantMeta vm;
+	uint32_t nA, nB;          // variants in the tile
+	uint32_t n_variants;      // total (pairs beyond it do not exist)
+	int diag;                 // keep only col > row (global indices)
+	int phased_math;          // 1: PhasedMath on the 2x2 table, 0: UnphasedMath on the 3x3
+	int auto_select;          // 0: all pairs; 1: only pairs with an_A == 0 && an_B == 0;
+	                          // 2: only pairs with an_A != 0 || an_B != 0   
+	int window; uint32_t l_window;
+	twk_hip_filters filt;
+	twk_hip_record* out;
+	unsigned long long capacity;
+	unsigned long long* n_out; // device counter
+};
+
+__global__ __launch_bounds__(256)
+void k_ld_stats(const StatsParams p) {
+	const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t i = blockIdx.y;
+	bool keep = false;
+	twk_hip_record rec;
+	if (i < p.nA && j < p.nB) {
+		const uint32_t A = p.tv.a0 + i, B = p.tv.b0 + j;
+		bool todo = A < p.n_variants && B < p.n_variants && (!p.diag || B > A);
+		// ld_engine.cpp:1918 / 2033: nothing to learn from two singletons
+		if (todo && p.vm.ac[A] + p.vm.ac[B] <= 2) todo = false;
+		if (todo && p.auto_select) {
+			const bool anymiss = p.vm.an[A] || p.vm.an[B];
+			if ((p.auto_select == 1) == anymiss) todo = false;
+		}
+		if (todo && p.window) {   // exact window: same contig, |dpos| <= w
+			const int64_t d = (int64_t)p.vm.pos[A] - (int64_t)p.vm.pos[B];
+			if (p.vm.rid[A] != p.vm.rid[B] || (d < 0 ? -d : d) > (int64_t)p.l_window) todo = false;
+		}
+		if (todo) {
+			if (p.phased_math) {
+				uint64_t c[4];
+				d_cells_phased(p.tv, i, j, c);
+				keep = d_phased_math(c[0], c[1], c[2], c[3], p.vm, A, B, p.filt, &rec);
+			} else {
+				uint64_t c[9];
+				d_cells_unphased(p.tv, i, j, c);
+				keep = d_unphased_math(c, p.vm, A, B, p.filt, &rec);
+			}
+		}
+	}
+	// wave-level compaction: one atomic per wave
+	const unsigned long long ballot = __ballot(keep);
+	if (ballot) {
+		const int lane = threadIdx.x & 63;
+		const int leader = __ffsll((long long)ballot) - 1;
+		unsigned long long base = 0;
+		if (lane == leader) base = atomicAdd(p.n_out, (unsigned long long)__popcll(ballot));
+		base = __shfl(base, leader);
+		if (keep) {
+			const unsigned long long slot = base + __popcll(ballot & ((1ull << lane) - 1));
+			if (slot < p.capacity) p.out[slot] = rec;
+		}
+	}
+}
+
+// Raw cells for parity tests: out[(i*nB + j)*ncell + k] (uint64).
+__global__ void k_ld_cells(const TileView tv, uint32_t nA, uint32_t nB, uint32_t n_variants, int diag,
+                           int phased, unsigned long long* __restrict__ out) {
+	const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t i = blockIdx.y;
+	if (i >= nA || j >= nB) return;
+	const uint32_t A = tv.a0 + i, B = tv.b0 + j;
+	const int ncell = phased ? 4 : 9;
+	unsigned long long* o = out + ((size_t)i * nB + j) * ncell;
+	const bool todo = A < n_variants && B < n_variants && (!diag || B > A);
+	uint64_t c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+	if (todo) { if (phased) d_cells_phased(tv, i, j, c); else d_cells_unphased(tv, i, j, c); }
+	for (int k = 0; k < ncell; ++k) o[k] = c[k];
+}
+
+}  // namespace twk

@@ -1,0 +1,143 @@
+// Input preparation kernels: reference bitvector layout -> contraction planes.
+//
+// The reference keeps, per variant, one bitvector with two bits per sample
+// (bit 2s / 2s+1 = first / second allele is ALT) and an optional mask with both
+// bits of a sample set when either allele is missing (twk_igt_vec,
+// include/core.h:724-753; built by lib/core.cpp:349-391).  The count kernel
+// wants rows whose AND-popcounts are the cells of the contingency table:
+//
+//   phased, no missing   1 row  / variant: the raw bitvector (2N bits)
+//   phased, missing      2 rows / variant: a' = a & ~m,  m            (2N bits)
+//   unphased, no missing 2 rows / variant: H = a0 ^ a1 (het), Q = a0 & a1 (hom-alt)
+//                                          de-interleaved to one bit per sample (N bits)
+//   unphased, missing    3 rows / variant: H & ~M, Q & ~M, M  (M = sample missing)
+//
+// All rows are uint32 words, pitch a multiple of KC (=32) words, zero padded;
+// the row count is padded to a multiple of 128 with zero rows.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace twk {
+
+// splitmix64 finaliser; shared with the host twin in twk_synth.cpp.
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
+	z += 0x9E3779B97F4A7C15ull;
+	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+	z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+	return z ^ (z >> 31);
+}
+// ALT-allele threshold of variant v: p_v ~ U(0.05, 0.5) as a 32-bit fraction.
+__host__ __device__ __forceinline__ uint32_t synth_threshold(uint64_t seed, uint32_t v) {
+	const uint64_t u = mix64(seed + 0x632BE59BD9B4E019ull * (uint64_t)(v + 1)) >> 11;    // 53 bits
+	const double p = 0.05 + 0.45 * ((double)u * (1.0 / 9007199254740992.0));
+	return (uint32_t)(p * 4294967296.0);
+}
+// Two alleles of sample s of variant v: low / high half of one 64-bit draw.
+__host__ __device__ __forceinline__ uint32_t synth_sample_bits(uint64_t seed, uint32_t v, uint32_t s, uint32_t thr) {
+	const uint64_t key = mix64(seed ^ (0xD1342543DE82EF95ull * (uint64_t)(v + 1)));
+	const uint64_t x = mix64(key + s);
+	return ((uint32_t)x < thr ? 1u : 0u) | ((uint32_t)(x >> 32) < thr ? 2u : 0u);
+}
+
+// Synthetic genotypes straight into the raw layout: one thread per 32-bit word
+// (16 samples).  raw[v * Wp + w].
+__global__ void k_synth(uint32_t* __restrict__ raw, uint32_t Wp, uint32_t n_samples, uint32_t n_variants,
+                        uint64_t seed) {
+	const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t v = blockIdx.y;
+	if (v >= n_variants || w >= Wp) return;
+	const uint32_t thr = synth_threshold(seed, v);
+	uint32_t word = 0;
+	const uint32_t s0 = w * 16;
+	for (uint32_t i = 0; i < 16; ++i) {
+		const uint32_t s = s0 + i;
+		if (s < n_samples) word |= synth_sample_bits(seed, v, s, thr) << (2 * i);
+	}
+	raw[(size_t)v * Wp + w] = word;
+}
+
+// Population count of every row: out[r] = sum_k popc(rows[r][k]).  One wave per row.
+__global__ void k_row_popcount(const uint32_t* __restrict__ rows, uint32_t W, uint32_t n_rows,
+                               uint32_t* __restrict__ out) {
+	const uint32_t r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+	if (r >= n_rows) return;
+	const int lane = threadIdx.x & 63;
+	const uint4* p = reinterpret_cast<const uint4*>(rows + (size_t)r * W);
+	uint32_t c = 0;
+	for (uint32_t k = lane; k < W / 4; k += 64) {
+		const uint4 x = p[k];
+		c += __builtin_popcount(x.x) + __builtin_popcount(x.y) + __builtin_popcount(x.z) + __builtin_popcount(x.w);
+	}
+	for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+	if (lane == 0) out[r] = c;
+}
+
+// Keep the even bits of a 64-bit word, packed into 32 bits.
+__device__ __forceinline__ uint32_t compress_even(uint64_t x) {
+	x &= 0x5555555555555555ull;
+	x = (x | (x >> 1)) & 0x3333333333333333ull;
+	x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+	x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
+	x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull;
+	x = (x | (x >> 16)) & 0x00000000FFFFFFFFull;
+	return (uint32_t)x;
+}
+
+// raw (2 bits / sample) -> unphased planes.  P = 2 (H,Q) or 3 (H,Q,M).
+// One thread per output word (32 samples) of one variant.
+__global__ void k_build_unphased(const uint32_t* __restrict__ raw, const uint32_t* __restrict__ rawmask,
+                                 uint32_t Wp, uint32_t n_samples, uint32_t n_variants,
+                                 uint32_t* __restrict__ planes, uint32_t Wu, int P) {
+	const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t v = blockIdx.y;
+	if (v >= n_variants || w >= Wu) return;
+	uint64_t x = 0, m = 0;
+	if (2 * w + 1 < Wp || 2 * w < Wp) {
+		const uint32_t lo = (2 * w < Wp) ? raw[(size_t)v * Wp + 2 * w] : 0;
+		const uint32_t hi = (2 * w + 1 < Wp) ? raw[(size_t)v * Wp + 2 * w + 1] : 0;
+		x = (uint64_t)lo | ((uint64_t)hi << 32);
+		if (rawmask) {
+			const uint32_t mlo = (2 * w < Wp) ? rawmask[(size_t)v * Wp + 2 * w] : 0;
+			const uint32_t mhi = (2 * w + 1 < Wp) ? rawmask[(size_t)v * Wp + 2 * w + 1] : 0;
+			m = (uint64_t)mlo | ((uint64_t)mhi << 32);
+		}
+	}
+	const uint32_t a0 = compress_even(x), a1 = compress_even(x >> 1);
+	uint32_t ms = compress_even(m) | compress_even(m >> 1);
+	// samples beyond N do not exist
+	const uint32_t s0 = w * 32;
+	uint32_t valid = 0xFFFFFFFFu;
+	if (s0 >= n_samples) valid = 0;
+	else if (n_samples - s0 < 32) valid = (1u << (n_samples - s0)) - 1;
+	ms &= valid;
+	const uint32_t keep = valid & ~ms;
+	planes[((size_t)v * P + 0) * Wu + w] = (a0 ^ a1) & keep;
+	planes[((size_t)v * P + 1) * Wu + w] = (a0 & a1) & keep;
+	if (P == 3) planes[((size_t)v * P + 2) * Wu + w] = ms;
+}
+
+// raw + mask -> phased-with-missing planes (a & ~m, m), 2 rows per variant.
+__global__ void k_build_phased_masked(const uint32_t* __restrict__ raw, const uint32_t* __restrict__ rawmask,
+                                      uint32_t Wp, uint32_t n_variants, uint32_t* __restrict__ planes) {
+	const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t v = blockIdx.y;
+	if (v >= n_variants || w >= Wp) return;
+	const uint32_t a = raw[(size_t)v * Wp + w], m = rawmask[(size_t)v * Wp + w];
+	planes[((size_t)v * 2 + 0) * Wp + w] = a & ~m;
+	planes[((size_t)v * 2 + 1) * Wp + w] = m;
+}
+
+// Zero the bits of the raw layout that lie beyond allele 2N (defensive: the
+// reference guarantees it, core.cpp:361).
+__global__ void k_clear_tail(uint32_t* __restrict__ raw, uint32_t Wp, uint32_t n_samples, uint32_t n_variants) {
+	const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t v = blockIdx.y;
+	if (v >= n_variants || w >= Wp) return;
+	const uint64_t bit0 = (uint64_t)w * 32, nb = 2ull * n_samples;
+	if (bit0 + 32 <= nb) return;
+	const uint32_t keep = bit0 >= nb ? 0u : ((1u << (uint32_t)(nb - bit0)) - 1);
+	raw[(size_t)v * Wp + w] &= keep;
+}
+
+}  // namespace twk

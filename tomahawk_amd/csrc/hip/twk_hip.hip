@@ -1,0 +1,678 @@
+// C ABI of the MI355X pairwise-LD engine (include/twk_hip.h).
+//
+// Host-side orchestration of the three device stages
+//   prep  (ld_prep.hip.h)  reference bitvectors -> contraction planes
+//   count (ld_count.hip.h) LDS-tiled AND+popcount contraction  [dominant kernel]
+//   math  (ld_math.hip.h)  cells -> D/D'/r2/Fisher -> filters -> compaction
+// over super-tiles of the variant-pair triangle.  Device memory lives in the
+// ctx; nothing here falls back to the CPU.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../../include/twk_hip.h"
+#include "ld_count.hip.h"
+#include "ld_prep.hip.h"
+#include "ld_math.hip.h"
+
+using namespace twk;
+
+namespace {
+
+inline uint32_t round_up(uint32_t x, uint32_t m) { return (x + m - 1) / m * m; }
+
+struct PlaneSet {
+	uint32_t* rows = nullptr;     // [rows_alloc][W]
+	uint32_t* rowpop = nullptr;   // [rows_alloc]
+	uint32_t  W = 0;              // words per row (padded to KC)
+	uint32_t  W_live = 0;         // words per row that carry data
+	uint32_t  rows_alloc = 0;
+	bool      built = false;
+	bool      owns_rows = false;
+};
+
+struct Slot {                      // one in-flight tile (double buffered)
+	uint32_t* C = nullptr; size_t C_words = 0;
+	twk_hip_record* out = nullptr; unsigned long long capacity = 0;
+	unsigned long long* n_out = nullptr;          // device counter
+	unsigned long long* h_n_out = nullptr;        // pinned host copy
+	hipEvent_t ev_c0 = nullptr, ev_c1 = nullptr, ev_s1 = nullptr, ev_c0b = nullptr, ev_c1b = nullptr;
+	bool two_pass = false;
+	uint64_t row_pairs = 0, row_pairs_b = 0;
+};
+
+}  // namespace
+
+struct twk_hip_ctx {
+	int device = 0;
+	hipStream_t s_compute = nullptr, s_copy = nullptr;
+	uint32_t N = 0, M = 0, M_alloc = 0;
+	uint32_t Wp = 0, Wu = 0;       // padded words per row: raw (2N bits) / unphased planes (N bits)
+	uint32_t* raw = nullptr;       // [M_alloc][Wp]
+	uint32_t* rawmask = nullptr;   // [M_alloc][Wp] or null
+	bool any_missing = false;
+	// metadata (device SoA) + host mirror
+	uint32_t *d_ac = nullptr, *d_an = nullptr, *d_pos = nullptr, *d_rid = nullptr, *d_missing = nullptr;
+	double* d_hwe = nullptr;
+	std::vector<twk_hip_variant_meta> h_meta;
+	PlaneSet planes[4];
+	Slot slot[3];                  // [0],[1]: ld_all pipeline; [2]: synchronous single-tile calls
+	twk_hip_record* h_recs = nullptr; unsigned long long h_recs_cap = 0;   // pinned staging
+	twk_hip_timing timing{};
+	char err[512] = {0};
+};
+
+namespace {
+
+#define HIPCHK(ctx, call)                                                                         \
+	do {                                                                                          \
+		hipError_t e__ = (call);                                                                  \
+		if (e__ != hipSuccess) {                                                                  \
+			snprintf((ctx)->err, sizeof((ctx)->err), "%s failed: %s (%s:%d)", #call,              \
+			         hipGetErrorString(e__), __FILE__, __LINE__);                                 \
+			return e__ == hipErrorOutOfMemory ? TWK_HIP_E_NOMEM : TWK_HIP_E_DEVICE;               \
+		}                                                                                         \
+	} while (0)
+
+void free_planes(twk_hip_ctx* c) {
+	for (auto& p : c->planes) {
+		if (p.owns_rows && p.rows) (void)hipFree(p.rows);
+		if (p.rowpop) (void)hipFree(p.rowpop);
+		p = PlaneSet();
+	}
+}
+void free_slots(twk_hip_ctx* c) {
+	for (auto& s : c->slot) {
+		if (s.C) (void)hipFree(s.C);
+		if (s.out) (void)hipFree(s.out);
+		s.C = nullptr; s.C_words = 0; s.out = nullptr; s.capacity = 0;
+	}
+}
+void free_problem(twk_hip_ctx* c) {
+	free_planes(c);
+	free_slots(c);
+	void* ptrs[] = {c->raw, c->rawmask, c->d_ac, c->d_an, c->d_pos, c->d_rid, c->d_missing, c->d_hwe};
+	for (void* p : ptrs) if (p) (void)hipFree(p);
+	c->raw = c->rawmask = nullptr;
+	c->d_ac = c->d_an = c->d_pos = c->d_rid = c->d_missing = nullptr; c->d_hwe = nullptr;
+	c->h_meta.clear();
+	c->N = c->M = c->M_alloc = 0; c->any_missing = false;
+}
+
+int plane_kind_for(const twk_hip_ctx* c, bool phased) {
+	if (phased) return c->any_missing ? PK_PHASED_MASKED : PK_PHASED;
+	return c->any_missing ? PK_UNPHASED_MASKED : PK_UNPHASED;
+}
+
+int ensure_planes(twk_hip_ctx* c, int kind) {
+	PlaneSet& ps = c->planes[kind];
+	if (ps.built) return TWK_HIP_OK;
+	const int P = planes_per_variant(kind);
+	const bool wide = (kind == PK_PHASED || kind == PK_PHASED_MASKED);
+	ps.W = wide ? c->Wp : c->Wu;
+	ps.W_live = wide ? (uint32_t)((2ull * c->N + 31) / 32) : (c->N + 31) / 32;
+	ps.rows_alloc = round_up(c->M * P, TILE) + TILE;
+	if ((kind == PK_PHASED_MASKED || kind == PK_UNPHASED_MASKED) && !c->rawmask) return TWK_HIP_E_STATE;
+	if (kind == PK_PHASED) {
+		ps.rows = c->raw; ps.owns_rows = false;       // the raw layout *is* the phased plane
+	} else {
+		const size_t bytes = (size_t)ps.rows_alloc * ps.W * 4;
+		HIPCHK(c, hipMalloc((void**)&ps.rows, bytes));
+		ps.owns_rows = true;
+		HIPCHK(c, hipMemsetAsync(ps.rows, 0, bytes, c->s_compute));
+		const dim3 blk(256), grd((ps.W + 255) / 256, c->M);
+		if (kind == PK_PHASED_MASKED)
+			hipLaunchKernelGGL(k_build_phased_masked, grd, blk, 0, c->s_compute, c->raw, c->rawmask, c->Wp, c->M, ps.rows);
+		else
+			hipLaunchKernelGGL(k_build_unphased, grd, blk, 0, c->s_compute, c->raw,
+			                   kind == PK_UNPHASED_MASKED ? c->rawmask : (const uint32_t*)nullptr,
+			                   c->Wp, c->N, c->M, ps.rows, ps.W, P);
+		HIPCHK(c, hipGetLastError());
+	}
+	HIPCHK(c, hipMalloc((void**)&ps.rowpop, (size_t)ps.rows_alloc * 4));
+	HIPCHK(c, hipMemsetAsync(ps.rowpop, 0, (size_t)ps.rows_alloc * 4, c->s_compute));
+	const uint32_t live_rows = c->M * P;
+	hipLaunchKernelGGL(k_row_popcount, dim3((live_rows + 3) / 4), dim3(256), 0, c->s_compute, ps.rows, ps.W, live_rows, ps.rowpop);
+	HIPCHK(c, hipGetLastError());
+	HIPCHK(c, hipStreamSynchronize(c->s_compute));
+	ps.built = true;
+	return TWK_HIP_OK;
+}
+
+int ensure_slot(twk_hip_ctx* c, Slot& s, size_t C_words, unsigned long long capacity) {
+	if (s.C_words < C_words) {
+		if (s.C) (void)hipFree(s.C);
+		s.C = nullptr; s.C_words = 0;
+		HIPCHK(c, hipMalloc((void**)&s.C, C_words * 4));
+		s.C_words = C_words;
+	}
+	if (s.capacity < capacity) {
+		if (s.out) (void)hipFree(s.out);
+		s.out = nullptr; s.capacity = 0;
+		HIPCHK(c, hipMalloc((void**)&s.out, (size_t)capacity * sizeof(twk_hip_record)));
+		s.capacity = capacity;
+	}
+	return TWK_HIP_OK;
+}
+
+int ensure_host_records(twk_hip_ctx* c, unsigned long long n) {
+	if (c->h_recs_cap >= n) return TWK_HIP_OK;
+	if (c->h_recs) (void)hipHostFree(c->h_recs);
+	c->h_recs = nullptr; c->h_recs_cap = 0;
+	const unsigned long long cap = std::max<unsigned long long>(n, 1ull << 16);
+	HIPCHK(c, hipHostMalloc((void**)&c->h_recs, (size_t)cap * sizeof(twk_hip_record), hipHostMallocDefault));
+	c->h_recs_cap = cap;
+	return TWK_HIP_OK;
+}
+
+struct Geometry { uint32_t rowsA, rowsB, gx, gy, ldc; };
+Geometry tile_geometry(int P, const twk_hip_tile_desc& t) {
+	Geometry g;
+	g.rowsA = round_up(t.nA * P, TILE); g.rowsB = round_up(t.nB * P, TILE);
+	g.gy = g.rowsA / TILE; g.gx = g.rowsB / TILE; g.ldc = g.rowsB;
+	return g;
+}
+
+// Launch the count kernel for one tile on the compute stream.
+int launch_count(twk_hip_ctx* c, int kind, const twk_hip_tile_desc& t, Slot& s, hipEvent_t e0, hipEvent_t e1, uint64_t* row_pairs) {
+	const PlaneSet& ps = c->planes[kind];
+	const int P = planes_per_variant(kind);
+	const Geometry g = tile_geometry(P, t);
+	if ((uint64_t)t.rowA0 * P + g.rowsA > ps.rows_alloc || (uint64_t)t.rowB0 * P + g.rowsB > ps.rows_alloc) return TWK_HIP_E_INVALID;
+	const int diag = (t.diag && t.rowA0 == t.rowB0) ? 1 : 0;
+	HIPCHK(c, hipEventRecord(e0, c->s_compute));
+	hipLaunchKernelGGL(k_count_tile, dim3(g.gx, g.gy), dim3(256), 0, c->s_compute, ps.rows, ps.W,
+	                   t.rowA0 * P, t.rowB0 * P, diag, s.C, g.ldc);
+	HIPCHK(c, hipGetLastError());
+	HIPCHK(c, hipEventRecord(e1, c->s_compute));
+	const uint64_t tiles = diag ? (uint64_t)g.gy * (g.gy + 1) / 2 : (uint64_t)g.gx * g.gy;
+	*row_pairs = tiles * TILE * TILE;
+	return TWK_HIP_OK;
+}
+
+StatsParams make_stats(twk_hip_ctx* c, int kind, const twk_hip_tile_desc& t, const Slot& s, bool phased_math,
+                       int auto_select, const twk_hip_filters& f) {
+	const PlaneSet& ps = c->planes[kind];
+	const int P = planes_per_variant(kind);
+	StatsParams p;
+	p.tv.C = s.C; p.tv.ldc = tile_geometry(P, t).ldc; p.tv.rowpop = ps.rowpop; p.tv.kind = kind;
+	p.tv.n_samples = c->N; p.tv.a0 = t.rowA0; p.tv.b0 = t.rowB0;
+	p.vm = VariantMeta{c->d_ac, c->d_an, c->d_pos, c->d_rid, c->d_missing, c->d_hwe};
+	p.nA = t.nA; p.nB = t.nB; p.n_variants = c->M;
+	p.diag = (t.diag && t.rowA0 == t.rowB0) ? 1 : 0;
+	p.phased_math = phased_math ? 1 : 0; p.auto_select = auto_select;
+	p.window = t.window; p.l_window = t.l_window;
+	p.filt = f; p.out = s.out; p.capacity = s.capacity; p.n_out = s.n_out;
+	return p;
+}
+
+uint64_t pairs_in_tile(const twk_hip_ctx* c, const twk_hip_tile_desc& t) {
+	const uint64_t nA = t.rowA0 >= c->M ? 0 : std::min<uint64_t>(t.nA, c->M - t.rowA0);
+	const uint64_t nB = t.rowB0 >= c->M ? 0 : std::min<uint64_t>(t.nB, c->M - t.rowB0);
+	if (t.diag && t.rowA0 == t.rowB0) { const uint64_t n = std::min(nA, nB); return n * (n - 1) / 2 + (nB > n ? n * (nB - n) : 0); }
+	return nA * nB;
+}
+
+// Enqueue everything for one tile into slot s (count [+ second pass], math, counter copy).
+int enqueue_tile(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, const twk_hip_filters& f, Slot& s,
+                 unsigned long long capacity) {
+	const bool auto_mode = (mode == TWK_HIP_MODE_AUTO);
+	const bool two_pass = auto_mode && c->any_missing;
+	const bool phased = (mode == TWK_HIP_MODE_PHASED) || (auto_mode && !two_pass);
+	// kinds: single pass -> by mode; auto two-pass -> plain phased (pairs without missing) then masked unphased
+	const int kind1 = two_pass ? (int)PK_PHASED : plane_kind_for(c, phased);
+	const int kind2 = PK_UNPHASED_MASKED;
+	int rc = ensure_planes(c, kind1); if (rc) return rc;
+	if (two_pass) { rc = ensure_planes(c, kind2); if (rc) return rc; }
+	const int Pmax = two_pass ? 3 : planes_per_variant(kind1);
+	const Geometry g = tile_geometry(Pmax, t);
+	rc = ensure_slot(c, s, (size_t)g.rowsA * g.rowsB, capacity); if (rc) return rc;
+	s.two_pass = two_pass;
+
+	HIPCHK(c, hipMemsetAsync(s.n_out, 0, sizeof(unsigned long long), c->s_compute));
+	rc = launch_count(c, kind1, t, s, s.ev_c0, s.ev_c1, &s.row_pairs); if (rc) return rc;
+	{
+		const StatsParams p = make_stats(c, kind1, t, s, two_pass ? true : phased, two_pass ? 1 : 0, f);
+		hipLaunchKernelGGL(k_ld_stats, dim3((t.nB + 255) / 256, t.nA), dim3(256), 0, c->s_compute, p);
+		HIPCHK(c, hipGetLastError());
+	}
+	if (two_pass) {
+		rc = launch_count(c, kind2, t, s, s.ev_c0b, s.ev_c1b, &s.row_pairs_b); if (rc) return rc;
+		const StatsParams p = make_stats(c, kind2, t, s, false, 2, f);
+		hipLaunchKernelGGL(k_ld_stats, dim3((t.nB + 255) / 256, t.nA), dim3(256), 0, c->s_compute, p);
+		HIPCHK(c, hipGetLastError());
+	}
+	HIPCHK(c, hipMemcpyAsync(s.h_n_out, s.n_out, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->s_compute));
+	HIPCHK(c, hipEventRecord(s.ev_s1, c->s_compute));
+	return TWK_HIP_OK;
+}
+
+// Wait for slot s, account timing, fetch its records into the pinned staging buffer.
+int finish_tile(twk_hip_ctx* c, Slot& s, const twk_hip_tile_desc& t, unsigned long long* n_out) {
+	HIPCHK(c, hipEventSynchronize(s.ev_s1));
+	float ms = 0;
+	HIPCHK(c, hipEventElapsedTime(&ms, s.ev_c0, s.ev_c1));
+	c->timing.count_ms += ms; c->timing.count_launches += 1; c->timing.row_pairs += s.row_pairs;
+	float ms_all = 0;
+	if (s.two_pass) {
+		HIPCHK(c, hipEventElapsedTime(&ms, s.ev_c0b, s.ev_c1b));
+		c->timing.count_ms += ms; c->timing.count_launches += 1; c->timing.row_pairs += s.row_pairs_b;
+		float m1 = 0, m2 = 0;
+		HIPCHK(c, hipEventElapsedTime(&m1, s.ev_c1, s.ev_c0b));
+		HIPCHK(c, hipEventElapsedTime(&m2, s.ev_c1b, s.ev_s1));
+		ms_all = m1 + m2; c->timing.stats_launches += 2;
+	} else {
+		HIPCHK(c, hipEventElapsedTime(&ms_all, s.ev_c1, s.ev_s1));
+		c->timing.stats_launches += 1;
+	}
+	c->timing.stats_ms += ms_all;
+	c->timing.variant_pairs += pairs_in_tile(c, t);
+	const unsigned long long n = *s.h_n_out;
+	*n_out = n;
+	if (n > s.capacity) return TWK_HIP_E_OVERFLOW;
+	if (n) {
+		int rc = ensure_host_records(c, n); if (rc) return rc;
+		HIPCHK(c, hipMemcpyAsync(c->h_recs, s.out, (size_t)n * sizeof(twk_hip_record), hipMemcpyDeviceToHost, c->s_copy));
+		HIPCHK(c, hipStreamSynchronize(c->s_copy));
+	}
+	return TWK_HIP_OK;
+}
+
+// One tile, synchronously, on the spare slot; survivors end up in c->h_recs.
+int run_tile_sync(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, const twk_hip_filters& f,
+                  unsigned long long capacity, unsigned long long* n_out) {
+	Slot& s = c->slot[2];
+	int rc = enqueue_tile(c, mode, t, f, s, capacity); if (rc) return rc;
+	return finish_tile(c, s, t, n_out);
+}
+
+// A tile whose survivors overflowed the device buffer: redo it in row strips
+// that cannot overflow (strip_rows * cols <= capacity).
+int redo_tile_in_strips(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, const twk_hip_filters& f,
+                        unsigned long long capacity, twk_hip_record_sink sink, void* user, uint64_t* n_recs) {
+	const uint32_t strip = (uint32_t)std::max<unsigned long long>(1, capacity / std::max<uint32_t>(t.nB, 1));
+	const bool diag = t.diag && t.rowA0 == t.rowB0;
+	for (uint32_t r0 = 0; r0 < t.nA; r0 += strip) {
+		const uint32_t nr = std::min(strip, t.nA - r0);
+		twk_hip_tile_desc parts[2]; int np = 0;
+		if (diag) {      // rows [r0, r0+nr): the diagonal sub-block, then the rectangle to its right
+			twk_hip_tile_desc d = t; d.rowA0 = t.rowA0 + r0; d.nA = nr; d.rowB0 = d.rowA0; d.nB = nr; d.diag = 1;
+			parts[np++] = d;
+			if (r0 + nr < t.nB) {
+				twk_hip_tile_desc r = t; r.rowA0 = t.rowA0 + r0; r.nA = nr; r.rowB0 = t.rowB0 + r0 + nr; r.nB = t.nB - (r0 + nr); r.diag = 0;
+				parts[np++] = r;
+			}
+		} else {
+			twk_hip_tile_desc r = t; r.rowA0 = t.rowA0 + r0; r.nA = nr; r.diag = 0;
+			parts[np++] = r;
+		}
+		for (int k = 0; k < np; ++k) {
+			unsigned long long n = 0;
+			int rc = run_tile_sync(c, mode, parts[k], f, (unsigned long long)parts[k].nA * parts[k].nB, &n);
+			if (rc) return rc;
+			if (sink && n && sink(user, c->h_recs, n)) return TWK_HIP_E_INVALID;
+			*n_recs += n;
+		}
+	}
+	return TWK_HIP_OK;
+}
+
+bool valid_mode(int m) { return m == TWK_HIP_MODE_PHASED || m == TWK_HIP_MODE_UNPHASED || m == TWK_HIP_MODE_AUTO; }
+bool valid_tile(const twk_hip_ctx* c, const twk_hip_tile_desc* t) {
+	if (!t || t->nA == 0 || t->nB == 0 || t->nA > 32768 || t->nB > 32768) return false;
+	if ((uint64_t)t->rowA0 + t->nA > c->M || (uint64_t)t->rowB0 + t->nB > c->M) return false;
+	if (t->diag && (t->rowA0 != t->rowB0 || t->nA != t->nB)) return false;
+	return true;
+}
+
+}  // namespace
+
+// ================================ C ABI =======================================================
+extern "C" {
+
+int twk_hip_abi_version(void) { return TWK_HIP_ABI_VERSION; }
+
+int twk_hip_device_count(void) {
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+
+const char* twk_hip_strerror(int code) {
+	switch (code) {
+	case TWK_HIP_OK: return "ok";
+	case TWK_HIP_E_INVALID: return "invalid argument";
+	case TWK_HIP_E_NOMEM: return "out of memory";
+	case TWK_HIP_E_DEVICE: return "HIP device error";
+	case TWK_HIP_E_OVERFLOW: return "record buffer too small";
+	case TWK_HIP_E_STATE: return "call sequence error";
+	default: return "unknown error";
+	}
+}
+
+const char* twk_hip_last_error(const twk_hip_ctx* ctx) { return ctx ? ctx->err : ""; }
+
+int twk_hip_ctx_create(int device, twk_hip_ctx** out) {
+	if (!out) return TWK_HIP_E_INVALID;
+	*out = nullptr;
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return TWK_HIP_E_DEVICE;
+	if (device < 0 || device >= n) return TWK_HIP_E_INVALID;
+	twk_hip_ctx* c = new (std::nothrow) twk_hip_ctx();
+	if (!c) return TWK_HIP_E_NOMEM;
+	c->device = device;
+	auto fail = [&](int code) { twk_hip_ctx_destroy(c); return code; };
+	if (hipSetDevice(device) != hipSuccess) return fail(TWK_HIP_E_DEVICE);
+	if (hipStreamCreateWithFlags(&c->s_compute, hipStreamNonBlocking) != hipSuccess) return fail(TWK_HIP_E_DEVICE);
+	if (hipStreamCreateWithFlags(&c->s_copy, hipStreamNonBlocking) != hipSuccess) return fail(TWK_HIP_E_DEVICE);
+	for (auto& s : c->slot) {
+		hipEvent_t* evs[] = {&s.ev_c0, &s.ev_c1, &s.ev_s1, &s.ev_c0b, &s.ev_c1b};
+		for (auto* e : evs) if (hipEventCreate(e) != hipSuccess) return fail(TWK_HIP_E_DEVICE);
+		if (hipMalloc((void**)&s.n_out, sizeof(unsigned long long)) != hipSuccess) return fail(TWK_HIP_E_NOMEM);
+		if (hipHostMalloc((void**)&s.h_n_out, sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) return fail(TWK_HIP_E_NOMEM);
+	}
+	*out = c;
+	return TWK_HIP_OK;
+}
+
+int twk_hip_ctx_destroy(twk_hip_ctx* c) {
+	if (!c) return TWK_HIP_OK;
+	(void)hipSetDevice(c->device);
+	(void)hipDeviceSynchronize();
+	free_problem(c);
+	for (auto& s : c->slot) {
+		hipEvent_t evs[] = {s.ev_c0, s.ev_c1, s.ev_s1, s.ev_c0b, s.ev_c1b};
+		for (auto e : evs) if (e) (void)hipEventDestroy(e);
+		if (s.n_out) (void)hipFree(s.n_out);
+		if (s.h_n_out) (void)hipHostFree(s.h_n_out);
+	}
+	if (c->h_recs) (void)hipHostFree(c->h_recs);
+	if (c->s_compute) (void)hipStreamDestroy(c->s_compute);
+	if (c->s_copy) (void)hipStreamDestroy(c->s_copy);
+	delete c;
+	return TWK_HIP_OK;
+}
+
+int twk_hip_set_problem(twk_hip_ctx* c, uint32_t n_samples, uint32_t n_variants) {
+	if (!c || n_samples == 0 || n_variants == 0) return TWK_HIP_E_INVALID;
+	if (n_samples > (1u << 30)) return TWK_HIP_E_INVALID;       // counts are u32 on the device
+	HIPCHK(c, hipSetDevice(c->device));
+	free_problem(c);
+	c->N = n_samples; c->M = n_variants;
+	c->M_alloc = round_up(n_variants, TILE) + TILE;
+	c->Wp = round_up((uint32_t)((2ull * n_samples + 31) / 32), KC);
+	c->Wu = round_up((n_samples + 31) / 32, KC);
+	const size_t raw_bytes = (size_t)c->M_alloc * c->Wp * 4;
+	HIPCHK(c, hipMalloc((void**)&c->raw, raw_bytes));
+	HIPCHK(c, hipMemset(c->raw, 0, raw_bytes));
+	const size_t m4 = (size_t)c->M_alloc * 4;
+	HIPCHK(c, hipMalloc((void**)&c->d_ac, m4)); HIPCHK(c, hipMalloc((void**)&c->d_an, m4));
+	HIPCHK(c, hipMalloc((void**)&c->d_pos, m4)); HIPCHK(c, hipMalloc((void**)&c->d_rid, m4));
+	HIPCHK(c, hipMalloc((void**)&c->d_missing, m4)); HIPCHK(c, hipMalloc((void**)&c->d_hwe, (size_t)c->M_alloc * 8));
+	HIPCHK(c, hipMemset(c->d_ac, 0, m4)); HIPCHK(c, hipMemset(c->d_an, 0, m4)); HIPCHK(c, hipMemset(c->d_pos, 0, m4));
+	HIPCHK(c, hipMemset(c->d_rid, 0, m4)); HIPCHK(c, hipMemset(c->d_missing, 0, m4)); HIPCHK(c, hipMemset(c->d_hwe, 0, (size_t)c->M_alloc * 8));
+	c->h_meta.assign(n_variants, twk_hip_variant_meta{});
+	c->timing.words_per_row = 0;
+	return TWK_HIP_OK;
+}
+
+int twk_hip_upload_bitvectors(twk_hip_ctx* c, uint32_t first, uint32_t count, const uint64_t* data,
+                              const uint64_t* mask, size_t stride64, const twk_hip_variant_meta* meta) {
+	if (!c || !data || !meta || count == 0) return TWK_HIP_E_INVALID;
+	if (!c->raw) return TWK_HIP_E_STATE;
+	const size_t w64 = ((size_t)2 * c->N + 63) / 64;
+	if (stride64 < w64 || (uint64_t)first + count > c->M) return TWK_HIP_E_INVALID;
+	HIPCHK(c, hipSetDevice(c->device));
+	free_planes(c);                                             // derived planes are stale now
+	HIPCHK(c, hipMemcpy2D(c->raw + (size_t)first * c->Wp, (size_t)c->Wp * 4, data, stride64 * 8, w64 * 8, count, hipMemcpyHostToDevice));
+	hipLaunchKernelGGL(k_clear_tail, dim3((c->Wp + 255) / 256, count), dim3(256), 0, c->s_compute,
+	                   c->raw + (size_t)first * c->Wp, c->Wp, c->N, count);
+	HIPCHK(c, hipGetLastError());
+	if (mask) {
+		if (!c->rawmask) {
+			const size_t raw_bytes = (size_t)c->M_alloc * c->Wp * 4;
+			HIPCHK(c, hipMalloc((void**)&c->rawmask, raw_bytes));
+			HIPCHK(c, hipMemset(c->rawmask, 0, raw_bytes));
+		}
+		HIPCHK(c, hipMemcpy2D(c->rawmask + (size_t)first * c->Wp, (size_t)c->Wp * 4, mask, stride64 * 8, w64 * 8, count, hipMemcpyHostToDevice));
+		hipLaunchKernelGGL(k_clear_tail, dim3((c->Wp + 255) / 256, count), dim3(256), 0, c->s_compute,
+		                   c->rawmask + (size_t)first * c->Wp, c->Wp, c->N, count);
+		HIPCHK(c, hipGetLastError());
+	}
+	std::vector<uint32_t> ac(count), an(count), pos(count), rid(count), miss(count);
+	std::vector<double> hwe(count);
+	for (uint32_t i = 0; i < count; ++i) {
+		ac[i] = meta[i].ac; an[i] = meta[i].an; pos[i] = meta[i].pos; rid[i] = meta[i].rid;
+		miss[i] = meta[i].missing ? 1 : 0; hwe[i] = meta[i].hwe;
+		c->h_meta[first + i] = meta[i];
+		if (meta[i].missing) { if (!mask) return TWK_HIP_E_INVALID; c->any_missing = true; }
+	}
+	HIPCHK(c, hipMemcpy(c->d_ac + first, ac.data(), (size_t)count * 4, hipMemcpyHostToDevice));
+	HIPCHK(c, hipMemcpy(c->d_an + first, an.data(), (size_t)count * 4, hipMemcpyHostToDevice));
+	HIPCHK(c, hipMemcpy(c->d_pos + first, pos.data(), (size_t)count * 4, hipMemcpyHostToDevice));
+	HIPCHK(c, hipMemcpy(c->d_rid + first, rid.data(), (size_t)count * 4, hipMemcpyHostToDevice));
+	HIPCHK(c, hipMemcpy(c->d_missing + first, miss.data(), (size_t)count * 4, hipMemcpyHostToDevice));
+	HIPCHK(c, hipMemcpy(c->d_hwe + first, hwe.data(), (size_t)count * 8, hipMemcpyHostToDevice));
+	HIPCHK(c, hipStreamSynchronize(c->s_compute));
+	return TWK_HIP_OK;
+}
+
+int twk_hip_generate_synthetic(twk_hip_ctx* c, uint64_t seed) {
+	if (!c) return TWK_HIP_E_INVALID;
+	if (!c->raw) return TWK_HIP_E_STATE;
+	HIPCHK(c, hipSetDevice(c->device));
+	free_planes(c);
+	if (c->rawmask) { (void)hipFree(c->rawmask); c->rawmask = nullptr; }
+	c->any_missing = false;
+	hipLaunchKernelGGL(k_synth, dim3((c->Wp + 255) / 256, c->M), dim3(256), 0, c->s_compute, c->raw, c->Wp, c->N, c->M, seed);
+	HIPCHK(c, hipGetLastError());
+	// metadata: ac = popcount, pos = 1000 + 100 v, one contig, hwe = 1
+	hipLaunchKernelGGL(k_row_popcount, dim3((c->M + 3) / 4), dim3(256), 0, c->s_compute, c->raw, c->Wp, c->M, c->d_ac);
+	HIPCHK(c, hipGetLastError());
+	std::vector<uint32_t> pos(c->M), zero(c->M, 0), ac(c->M);
+	std::vector<double> hwe(c->M, 1.0);
+	for (uint32_t v = 0; v < c->M; ++v) pos[v] = 1000u + 100u * v;
+	HIPCHK(c, hipMemcpyAsync(c->d_pos, pos.data(), (size_t)c->M * 4, hipMemcpyHostToDevice, c->s_compute));
+	HIPCHK(c, hipMemcpyAsync(c->d_an, zero.data(), (size_t)c->M * 4, hipMemcpyHostToDevice, c->s_compute));
+	HIPCHK(c, hipMemcpyAsync(c->d_rid, zero.data(), (size_t)c->M * 4, hipMemcpyHostToDevice, c->s_compute));
+	HIPCHK(c, hipMemcpyAsync(c->d_missing, zero.data(), (size_t)c->M * 4, hipMemcpyHostToDevice, c->s_compute));
+	HIPCHK(c, hipMemcpyAsync(c->d_hwe, hwe.data(), (size_t)c->M * 8, hipMemcpyHostToDevice, c->s_compute));
+	HIPCHK(c, hipMemcpyAsync(ac.data(), c->d_ac, (size_t)c->M * 4, hipMemcpyDeviceToHost, c->s_compute));
+	HIPCHK(c, hipStreamSynchronize(c->s_compute));
+	for (uint32_t v = 0; v < c->M; ++v) {
+		twk_hip_variant_meta m{}; m.ac = ac[v]; m.pos = pos[v]; m.hwe = 1.0;
+		c->h_meta[v] = m;
+	}
+	return TWK_HIP_OK;
+}
+
+uint32_t twk_synth_bitvector(uint64_t seed, uint32_t n_samples, uint32_t v, uint64_t* out_words) {
+	const size_t w64 = ((size_t)2 * n_samples + 63) / 64;
+	std::memset(out_words, 0, w64 * 8);
+	const uint32_t thr = synth_threshold(seed, v);
+	uint32_t ac = 0;
+	for (uint32_t s = 0; s < n_samples; ++s) {
+		const uint64_t bits = synth_sample_bits(seed, v, s, thr);
+		out_words[(2ull * s) >> 6] |= bits << ((2ull * s) & 63);
+		ac += (uint32_t)(bits & 1) + (uint32_t)(bits >> 1);
+	}
+	return ac;
+}
+
+int twk_hip_get_marginals(twk_hip_ctx* c, uint32_t* ac, uint32_t* n_het, uint32_t* n_hom, uint32_t* n_miss) {
+	if (!c) return TWK_HIP_E_INVALID;
+	if (!c->raw) return TWK_HIP_E_STATE;
+	HIPCHK(c, hipSetDevice(c->device));
+	if (ac) {
+		const int kind = plane_kind_for(c, true);
+		int rc = ensure_planes(c, kind); if (rc) return rc;
+		const int P = planes_per_variant(kind);
+		std::vector<uint32_t> rp((size_t)c->M * P);
+		HIPCHK(c, hipMemcpy(rp.data(), c->planes[kind].rowpop, rp.size() * 4, hipMemcpyDeviceToHost));
+		for (uint32_t v = 0; v < c->M; ++v) ac[v] = rp[(size_t)v * P];
+	}
+	if (n_het || n_hom || n_miss) {
+		const int kind = plane_kind_for(c, false);
+		int rc = ensure_planes(c, kind); if (rc) return rc;
+		const int P = planes_per_variant(kind);
+		std::vector<uint32_t> rp((size_t)c->M * P);
+		HIPCHK(c, hipMemcpy(rp.data(), c->planes[kind].rowpop, rp.size() * 4, hipMemcpyDeviceToHost));
+		for (uint32_t v = 0; v < c->M; ++v) {
+			if (n_het) n_het[v] = rp[(size_t)v * P];
+			if (n_hom) n_hom[v] = rp[(size_t)v * P + 1];
+			if (n_miss) n_miss[v] = P == 3 ? rp[(size_t)v * P + 2] : 0;
+		}
+	}
+	return TWK_HIP_OK;
+}
+
+int twk_hip_count_tile(twk_hip_ctx* c, int mode, const twk_hip_tile_desc* t, uint64_t* out) {
+	if (!c || !out || (mode != TWK_HIP_MODE_PHASED && mode != TWK_HIP_MODE_UNPHASED)) return TWK_HIP_E_INVALID;
+	if (!c->raw) return TWK_HIP_E_STATE;
+	if (!valid_tile(c, t)) return TWK_HIP_E_INVALID;
+	HIPCHK(c, hipSetDevice(c->device));
+	const bool phased = mode == TWK_HIP_MODE_PHASED;
+	const int kind = plane_kind_for(c, phased);
+	int rc = ensure_planes(c, kind); if (rc) return rc;
+	Slot& s = c->slot[2];
+	const Geometry g = tile_geometry(planes_per_variant(kind), *t);
+	rc = ensure_slot(c, s, (size_t)g.rowsA * g.rowsB, 1); if (rc) return rc;
+	uint64_t rp = 0;
+	rc = launch_count(c, kind, *t, s, s.ev_c0, s.ev_c1, &rp); if (rc) return rc;
+	const int ncell = phased ? 4 : 9;
+	const size_t n = (size_t)t->nA * t->nB * ncell;
+	unsigned long long* d_cells = nullptr;
+	HIPCHK(c, hipMalloc((void**)&d_cells, n * 8));
+	StatsParams p = make_stats(c, kind, *t, s, phased, 0, twk_hip_filters{});
+	hipLaunchKernelGGL(k_ld_cells, dim3((t->nB + 255) / 256, t->nA), dim3(256), 0, c->s_compute, p.tv, t->nA, t->nB, c->M, p.diag, phased ? 1 : 0, d_cells);
+	hipError_t e = hipGetLastError();
+	if (e == hipSuccess) e = hipMemcpyAsync(out, d_cells, n * 8, hipMemcpyDeviceToHost, c->s_compute);
+	if (e == hipSuccess) e = hipStreamSynchronize(c->s_compute);
+	(void)hipFree(d_cells);
+	HIPCHK(c, e);
+	return TWK_HIP_OK;
+}
+
+int twk_hip_ld_tile(twk_hip_ctx* c, int mode, const twk_hip_tile_desc* t, const twk_hip_filters* f,
+                    twk_hip_record* out, uint64_t capacity, uint64_t* n_out, uint64_t* n_pairs) {
+	if (!c || !f || !n_out || !valid_mode(mode) || (capacity && !out)) return TWK_HIP_E_INVALID;
+	if (!c->raw) return TWK_HIP_E_STATE;
+	if (!valid_tile(c, t)) return TWK_HIP_E_INVALID;
+	HIPCHK(c, hipSetDevice(c->device));
+	unsigned long long n = 0;
+	int rc = run_tile_sync(c, mode, *t, *f, std::max<unsigned long long>(capacity, 1), &n);
+	*n_out = n;
+	if (n_pairs) *n_pairs = pairs_in_tile(c, *t);
+	if (rc == TWK_HIP_OK && n > capacity) rc = TWK_HIP_E_OVERFLOW;
+	if (rc) return rc;
+	if (n) std::memcpy(out, c->h_recs, (size_t)n * sizeof(twk_hip_record));
+	return TWK_HIP_OK;
+}
+
+int twk_hip_ld_all(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint32_t part, uint32_t n_parts,
+                   uint32_t tile_variants, int32_t window, uint32_t l_window, twk_hip_record_sink sink,
+                   void* user, uint64_t* n_pairs, uint64_t* n_records) {
+	if (!c || !f || !valid_mode(mode) || n_parts == 0 || part >= n_parts) return TWK_HIP_E_INVALID;
+	if (!c->raw) return TWK_HIP_E_STATE;
+	HIPCHK(c, hipSetDevice(c->device));
+	const uint32_t M = c->M;
+	// Super-tile edge: multiple of 128 variants; default aims at >= 16 tiles per shard.
+	uint32_t S = tile_variants;
+	if (S == 0) {
+		S = 8192;
+		while (S > 1024) {
+			const uint64_t nb = (M + S - 1) / S;
+			if (nb * (nb + 1) / 2 >= 16ull * n_parts) break;
+			S /= 2;
+		}
+	}
+	S = round_up(std::min(S, round_up(M, TILE)), TILE);
+	const uint32_t nb = (M + S - 1) / S;
+
+	// Static cost-balanced assignment: walk the triangle, give each tile to the
+	// currently lightest shard (diagonal tiles cost half).  Deterministic, so
+	// every rank derives the same partition without talking to the others.
+	std::vector<twk_hip_tile_desc> mine;
+	{
+		std::vector<uint64_t> load(n_parts, 0);
+		for (uint32_t bi = 0; bi < nb; ++bi) {
+			for (uint32_t bj = bi; bj < nb; ++bj) {
+				twk_hip_tile_desc t{};
+				t.rowA0 = bi * S; t.nA = std::min(S, M - bi * S);
+				t.rowB0 = bj * S; t.nB = std::min(S, M - bj * S);
+				t.diag = (bi == bj); t.window = window; t.l_window = l_window;
+				if (window && bi != bj) {
+					// Inputs are sorted by (rid, pos) like every .twk: if both tiles lie on one
+					// contig and the gap between them exceeds the window, no pair can qualify
+					// (the reference's ticker skips the rest of the row, ld_balancing.h:191).
+					const twk_hip_variant_meta& firstA = c->h_meta[t.rowA0];
+					const twk_hip_variant_meta& lastA  = c->h_meta[t.rowA0 + t.nA - 1];
+					const twk_hip_variant_meta& firstB = c->h_meta[t.rowB0];
+					const twk_hip_variant_meta& lastB  = c->h_meta[t.rowB0 + t.nB - 1];
+					if (firstA.rid == lastB.rid && firstB.pos > lastA.pos && firstB.pos - lastA.pos > l_window) continue;
+					if (firstA.rid == lastA.rid && firstB.rid == lastB.rid && firstA.rid != firstB.rid) continue;
+				}
+				const uint64_t cost = pairs_in_tile(c, t);
+				const uint32_t who = (uint32_t)(std::min_element(load.begin(), load.end()) - load.begin());
+				load[who] += cost;
+				if (who == part) mine.push_back(t);
+			}
+		}
+	}
+
+	uint64_t tot_pairs = 0, tot_recs = 0;
+	// Worst case every pair of a tile survives; cap the device buffer and split on overflow.
+	const unsigned long long cap_default = std::min<unsigned long long>((unsigned long long)S * S, 1ull << 24);
+	int rc = TWK_HIP_OK;
+	size_t issued = 0, done = 0;
+	const size_t n = mine.size();
+	// two-deep software pipeline over the tiles of this shard
+	while (done < n) {
+		while (issued < n && issued < done + 2) {
+			rc = enqueue_tile(c, mode, mine[issued], *f, c->slot[issued & 1], cap_default);
+			if (rc) return rc;
+			++issued;
+		}
+		Slot& s = c->slot[done & 1];
+		unsigned long long nrec = 0;
+		rc = finish_tile(c, s, mine[done], &nrec);
+		if (rc == TWK_HIP_E_OVERFLOW) {
+			uint64_t nr = 0;
+			rc = redo_tile_in_strips(c, mode, mine[done], *f, s.capacity, sink, user, &nr);
+			if (rc) return rc;
+			tot_recs += nr;
+		} else if (rc) {
+			return rc;
+		} else {
+			if (sink && nrec) { if (sink(user, c->h_recs, nrec)) return TWK_HIP_E_INVALID; }
+			tot_recs += nrec;
+		}
+		tot_pairs += pairs_in_tile(c, mine[done]);
+		++done;
+	}
+	if (n_pairs) *n_pairs = tot_pairs;
+	if (n_records) *n_records = tot_recs;
+	return TWK_HIP_OK;
+}
+
+int twk_hip_timing_reset(twk_hip_ctx* c) {
+	if (!c) return TWK_HIP_E_INVALID;
+	const uint64_t w = c->timing.words_per_row;
+	c->timing = twk_hip_timing{};
+	c->timing.words_per_row = w;
+	return TWK_HIP_OK;
+}
+
+int twk_hip_timing_get(twk_hip_ctx* c, twk_hip_timing* out) {
+	if (!c || !out) return TWK_HIP_E_INVALID;
+	*out = c->timing;
+	// words contracted per row pair: live words of whichever plane set was used last
+	for (const auto& p : c->planes) if (p.built) out->words_per_row = p.W_live;
+	return TWK_HIP_OK;
+}
+
+}  // extern "C"

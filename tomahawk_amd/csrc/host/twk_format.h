@@ -1,0 +1,179 @@
+// On-disk formats of the calc path: `.twk` in, `.two` out.
+//
+// Written from the format description in SURVEY.md Appendix B; every struct
+// cites the reference serialiser it is byte-compatible with.  All integers are
+// little-endian, packed, no alignment (reference: include/buffer.h:38-156 raw
+// primitive append).  Compression: one-shot zstd frames (lib/zstd_codec.cpp:
+// 136-168).
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <fstream>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace tomahawk {
+
+// include/tomahawk.h:47-51,66-68
+extern const char     TWK_MAGIC[9];           // "TOMAHAWK\1"
+extern const char     TWO_MAGIC[4];           // "TWO\1"
+extern const char     TWK_EOF_HEX[33];        // first 32 chars of the EOF digest
+constexpr uint64_t    TWK_INDEX_START_MARKER = 1954702206512158641ull;
+
+// ---- byte buffer ---------------------------------------------------------
+class ByteBuf {
+public:
+	std::vector<uint8_t> v;
+	size_t rd = 0;
+	template <class T> void put(const T& x) { const size_t o = v.size(); v.resize(o + sizeof(T)); std::memcpy(&v[o], &x, sizeof(T)); }
+	void put_bytes(const void* p, size_t n) { const size_t o = v.size(); v.resize(o + n); if (n) std::memcpy(&v[o], p, n); }
+	void put_str(const std::string& s) { put<uint32_t>((uint32_t)s.size()); put_bytes(s.data(), s.size()); } // buffer.cpp:410-414
+	template <class T> bool get(T& x) { if (rd + sizeof(T) > v.size()) return false; std::memcpy(&x, &v[rd], sizeof(T)); rd += sizeof(T); return true; }
+	bool get_bytes(void* p, size_t n) { if (rd + n > v.size()) return false; if (n) std::memcpy(p, &v[rd], n); rd += n; return true; }
+	bool get_str(std::string& s) { uint32_t n; if (!get(n) || rd + n > v.size()) return false; s.assign((const char*)&v[rd], n); rd += n; return true; }
+	size_t size() const { return v.size(); }
+	void clear() { v.clear(); rd = 0; }
+};
+
+bool zstd_compress(const uint8_t* src, size_t n, std::vector<uint8_t>& dst, int level);
+bool zstd_decompress(const uint8_t* src, size_t n, std::vector<uint8_t>& dst, size_t n_uncompressed);
+const char* zstd_version();
+
+// ---- header (include/header.h:115-128,312-416; lib/header.cpp:330-363) ----
+struct Contig {
+	uint32_t idx = 0;
+	std::string name, description;
+	int64_t n_bases = 0;
+	std::vector<std::pair<std::string, std::string>> extra;
+};
+struct Header {
+	std::string fileformat = "##fileformat=VCFv4.2";
+	std::string literals;
+	std::vector<std::string> samples;
+	std::vector<Contig> contigs;
+	void serialize(ByteBuf& b) const;
+	bool deserialize(ByteBuf& b);
+	int  contig_id(const std::string& name) const;
+};
+
+// ---- index (include/index.h:35-132; lib/index.cpp) ------------------------
+struct IndexEntry {      // index.cpp:8-18 (40 bytes)
+	int32_t  rid = 0;
+	uint32_t n = 0, minpos = 0, maxpos = 0, b_unc = 0, b_cmp = 0;
+	uint64_t foff = 0, fend = 0;
+};
+struct IndexEntryOutput : IndexEntry { int32_t ridB = -1; };  // index.cpp:41-52 (+4)
+struct IndexEntryEntry {  // index.cpp:90-99: rid,n,minpos,maxpos,foff,fend,nn
+	int32_t rid = 0; uint32_t n = 0, minpos = 0, maxpos = 0; uint64_t foff = 0, fend = 0, nn = 0;
+};
+struct TwkIndex {         // index.cpp:158-181
+	std::vector<IndexEntry> ent;
+	std::vector<IndexEntryEntry> meta;
+	void serialize(ByteBuf& b) const;
+	bool deserialize(ByteBuf& b);
+};
+struct TwoIndex {         // index.cpp:242-267
+	uint8_t state = 0;    // 0 unsorted
+	std::vector<IndexEntryOutput> ent;
+	std::vector<IndexEntryEntry> meta;
+	void serialize(ByteBuf& b) const;
+	bool deserialize(ByteBuf& b);
+};
+
+// ---- .twk records (include/core.h:160-350; lib/core.cpp:59-101,245-261) ---
+struct Variant {          // twk1_t
+	uint8_t  gt_ptype = 1;      // bytes per RLE word: 1, 2 or 4
+	bool     gt_flipped = false, gt_phase = false, gt_missing = false;
+	uint8_t  alleles = 0;
+	uint32_t pos = 0, ac = 0, an = 0, rid = 0, n_het = 0, n_hom = 0;
+	double   hwe = 1.0;
+	std::vector<uint32_t> runs; // RLE words, widened (core.h:195-198)
+	uint32_t run_length(size_t i) const { return runs[i] >> (2 + 2 * (gt_missing ? 1 : 0)); }
+	uint8_t  run_a(size_t i) const { const int m = gt_missing ? 1 : 0; return (runs[i] >> (1 + m)) & ((1u << (1 + m)) - 1); }
+	uint8_t  run_b(size_t i) const { const int m = gt_missing ? 1 : 0; return runs[i] & ((1u << (1 + m)) - 1); }
+	void serialize(ByteBuf& b) const;
+	bool deserialize(ByteBuf& b);
+	// RLE-encode a genotype vector (alleles[2*s], alleles[2*s+1] in {0,1,2}) the
+	// way lib/genotype_encoder.h:277-343 does (minimum-cost word width :150-192,
+	// run limit :17) and fill ac/an/n_het/n_hom/gt_missing.
+	void encode(const int8_t* alleles, uint32_t n_samples, bool phased);
+	// Expand to the reference bitvector layout (twk_igt_vec::Build,
+	// lib/core.cpp:349-391).  mask may be nullptr.
+	bool build_bitvector(uint32_t n_samples, uint64_t* data, uint64_t* mask) const;
+};
+struct Block {            // twk1_block_t (core.cpp:245-261)
+	uint32_t rid = 0;
+	std::vector<Variant> rcds;
+	void serialize(ByteBuf& b) const;
+	bool deserialize(ByteBuf& b);
+};
+
+// ---- .twk container (lib/importer.cpp:192-326, lib/twk_reader.cpp)
+class TwkWriter {
+public:
+	bool open(const std::string& path, const Header& hdr, int c_level = 1);
+	// Append a block (one contig per block, importer.cpp:192-260).
+	bool write_block(const Block& blk);
+	bool close();
+private:
+	std::ofstream out_;
+	TwkIndex index_;
+	int c_level_ = 1;
+};
+class TwkReader {
+public:
+	Header hdr;
+	TwkIndex index;
+	bool open(const std::string& path);
+	// Read block `i` of the index.
+	bool read_block(size_t i, Block& blk);
+	std::string error;
+private:
+	std::ifstream in_;
+};
+
+// ---- .two records / container --------------------------------
+#pragma pack(push, 1)
+struct TwoRecord {        // twk1_two_t serialised form, 106 bytes (core.cpp:470-490)
+	uint16_t controller;
+	uint32_t ridA, ridB;
+	uint32_t packA, packB;   // pos << 2 | phased << 1 | miss
+	double   cnt[4];
+	double   D, Dprime, R, R2, P, ChiSqFisher, ChiSqModel;
+	uint32_t Apos() const { return packA >> 2; }
+	uint32_t Bpos() const { return packB >> 2; }
+};
+#pragma pack(pop)
+static_assert(sizeof(TwoRecord) == 106, "twk1_two_t::packed_size");
+
+class TwoWriter {         // include/writer.h:163-406 as used by calc
+public:
+	// path "-" or "" -> stdout (ld.cpp:585-587)
+	bool open(const std::string& path, const Header& hdr, int c_level = 1);
+	// One block: u32 n, u32 m, n records -> zstd -> [1][b_unc][b_cmp][bytes]
+	// plus its IndexEntryOutput (ld_engine.cpp:1742-1802, writer.h:70-87).
+	bool write_block(const TwoRecord* recs, uint32_t n);
+	bool close();             // writer.h:293-313
+	uint64_t n_records = 0, n_blocks = 0;
+private:
+	std::ostream* os_ = nullptr;
+	std::ofstream file_;
+	uint64_t off_ = 0;        // bytes written so far (tellp is unusable on stdout)
+	TwoIndex index_;
+	int c_level_ = 1;
+	bool put(const void* p, size_t n);
+};
+class TwoReader {         // lib/two_reader.cpp:11-160
+public:
+	Header hdr;
+	TwoIndex index;
+	bool open(const std::string& path);
+	// Next block of records; false at the end marker.
+	bool next_block(std::vector<TwoRecord>& recs);
+	std::string error;
+private:
+	std::ifstream in_;
+};
+
+}  // namespace tomahawk

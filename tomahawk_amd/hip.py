@@ -1,0 +1,235 @@
+"""ctypes binding of the C ABI in include/twk_hip.h (lib/libtwk_hip.so).
+
+Fails loudly when the HIP library is missing or no device is usable: there is
+no CPU path behind these calls.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtwk_hip.so")
+
+MODE_PHASED, MODE_UNPHASED, MODE_AUTO = 1, 2, 3
+E_OVERFLOW = -4
+
+# twk_hip_record (include/twk_hip.h): 104 bytes
+RECORD_DTYPE = np.dtype([("idxA", "<u4"), ("idxB", "<u4"), ("flags", "<u4"), ("_pad", "<u4"),
+                         ("cnt", "<f8", (4,)), ("D", "<f8"), ("Dprime", "<f8"), ("R", "<f8"),
+                         ("R2", "<f8"), ("P", "<f8"), ("ChiSqFisher", "<f8"), ("ChiSqModel", "<f8")])
+assert RECORD_DTYPE.itemsize == 104
+
+# twk_hip_variant_meta: 32 bytes
+META_DTYPE = np.dtype([("ac", "<u4"), ("an", "<u4"), ("pos", "<u4"), ("rid", "<u4"),
+                       ("missing", "<u4"), ("_pad", "<u4"), ("hwe", "<f8")])
+assert META_DTYPE.itemsize == 32
+
+
+class _Filters(C.Structure):
+    _fields_ = [("minR2", C.c_double), ("maxR2", C.c_double), ("minDprime", C.c_double),
+                ("maxDprime", C.c_double), ("minP", C.c_double)]
+
+
+class _Tile(C.Structure):
+    _fields_ = [("rowA0", C.c_uint32), ("nA", C.c_uint32), ("rowB0", C.c_uint32), ("nB", C.c_uint32),
+                ("diag", C.c_int32), ("window", C.c_int32), ("l_window", C.c_uint32), ("_pad", C.c_uint32)]
+
+
+class _Timing(C.Structure):
+    _fields_ = [("count_ms", C.c_double), ("stats_ms", C.c_double), ("count_launches", C.c_uint64),
+                ("stats_launches", C.c_uint64), ("row_pairs", C.c_uint64), ("variant_pairs", C.c_uint64),
+                ("words_per_row", C.c_uint64)]
+
+
+@dataclass
+class Filters:
+    """twk_ld_settings filter defaults (reference lib/core.cpp:304)."""
+    minR2: float = 0.1
+    maxR2: float = 100.0
+    minDprime: float = 0.0
+    maxDprime: float = 100.0
+    minP: float = 1.0
+
+    def _c(self) -> _Filters:
+        return _Filters(self.minR2, self.maxR2, self.minDprime, self.maxDprime, self.minP)
+
+
+class HipError(RuntimeError):
+    def __init__(self, code: int, what: str, detail: str = ""):
+        super().__init__(f"{what}: error {code}" + (f" ({detail})" if detail else ""))
+        self.code = code
+
+
+_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64)
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """Load lib/libtwk_hip.so (built by `make hip` / __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} not built: run `make hip` (no CPU fallback exists)")
+    lib = C.CDLL(LIB_PATH)
+    p = C.c_void_p
+    lib.twk_hip_abi_version.restype = C.c_int
+    lib.twk_hip_device_count.restype = C.c_int
+    lib.twk_hip_strerror.restype = C.c_char_p
+    lib.twk_hip_strerror.argtypes = [C.c_int]
+    lib.twk_hip_last_error.restype = C.c_char_p
+    lib.twk_hip_last_error.argtypes = [p]
+    lib.twk_hip_ctx_create.argtypes = [C.c_int, C.POINTER(p)]
+    lib.twk_hip_ctx_destroy.argtypes = [p]
+    lib.twk_hip_set_problem.argtypes = [p, C.c_uint32, C.c_uint32]
+    lib.twk_hip_upload_bitvectors.argtypes = [p, C.c_uint32, C.c_uint32, p, p, C.c_size_t, p]
+    lib.twk_hip_generate_synthetic.argtypes = [p, C.c_uint64]
+    lib.twk_synth_bitvector.restype = C.c_uint32
+    lib.twk_synth_bitvector.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, p]
+    lib.twk_hip_get_marginals.argtypes = [p, p, p, p, p]
+    lib.twk_hip_count_tile.argtypes = [p, C.c_int, C.POINTER(_Tile), p]
+    lib.twk_hip_ld_tile.argtypes = [p, C.c_int, C.POINTER(_Tile), C.POINTER(_Filters), p, C.c_uint64,
+                                    C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.twk_hip_ld_all.argtypes = [p, C.c_int, C.POINTER(_Filters), C.c_uint32, C.c_uint32, C.c_uint32,
+                                   C.c_int32, C.c_uint32, _SINK, p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.twk_hip_timing_reset.argtypes = [p]
+    lib.twk_hip_timing_get.argtypes = [p, C.POINTER(_Timing)]
+    _lib = lib
+    return lib
+
+
+def device_count() -> int:
+    return load_library().twk_hip_device_count()
+
+
+def words64(n_samples: int) -> int:
+    return (2 * n_samples + 63) // 64
+
+
+def synth_bitvector(seed: int, n_samples: int, v: int) -> tuple[np.ndarray, int]:
+    """Host twin of the device generator (twk_synth_bitvector)."""
+    out = np.zeros(words64(n_samples), dtype=np.uint64)
+    ac = load_library().twk_synth_bitvector(seed, n_samples, v, out.ctypes.data)
+    return out, int(ac)
+
+
+class HipLd:
+    """One engine context on one GPU (twk_hip_ctx)."""
+
+    def __init__(self, device: int = 0):
+        self._lib = load_library()
+        self._ctx = C.c_void_p()
+        rc = self._lib.twk_hip_ctx_create(device, C.byref(self._ctx))
+        if rc != 0:
+            raise HipError(rc, "twk_hip_ctx_create", self._lib.twk_hip_strerror(rc).decode())
+        self.n_samples = 0
+        self.n_variants = 0
+
+    def close(self):
+        if self._ctx:
+            self._lib.twk_hip_ctx_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            detail = self._lib.twk_hip_last_error(self._ctx).decode() or self._lib.twk_hip_strerror(rc).decode()
+            raise HipError(rc, what, detail)
+
+    # ---- input ----
+    def set_problem(self, n_samples: int, n_variants: int):
+        self._check(self._lib.twk_hip_set_problem(self._ctx, n_samples, n_variants), "twk_hip_set_problem")
+        self.n_samples, self.n_variants = n_samples, n_variants
+
+    def upload(self, data: np.ndarray, meta: np.ndarray, mask: np.ndarray | None = None, first: int = 0):
+        """data/mask: uint64 [count, stride64] reference-layout bitvectors; meta: META_DTYPE[count]."""
+        data = np.ascontiguousarray(data, dtype=np.uint64)
+        meta = np.ascontiguousarray(meta, dtype=META_DTYPE)
+        assert data.ndim == 2 and data.shape[0] == meta.shape[0]
+        mptr = None
+        if mask is not None:
+            mask = np.ascontiguousarray(mask, dtype=np.uint64)
+            assert mask.shape == data.shape
+            mptr = mask.ctypes.data
+        self._check(self._lib.twk_hip_upload_bitvectors(self._ctx, first, data.shape[0], data.ctypes.data, mptr,
+                                                        data.shape[1], meta.ctypes.data), "twk_hip_upload_bitvectors")
+
+    def generate_synthetic(self, seed: int = 42):
+        self._check(self._lib.twk_hip_generate_synthetic(self._ctx, seed), "twk_hip_generate_synthetic")
+
+    def marginals(self):
+        M = self.n_variants
+        ac, het, hom, miss = (np.zeros(M, dtype=np.uint32) for _ in range(4))
+        self._check(self._lib.twk_hip_get_marginals(self._ctx, ac.ctypes.data, het.ctypes.data, hom.ctypes.data,
+                                                    miss.ctypes.data), "twk_hip_get_marginals")
+        return ac, het, hom, miss
+
+    # ---- compute ----
+    @staticmethod
+    def _tile(a0, nA, b0, nB, diag, window=0, l_window=0) -> _Tile:
+        return _Tile(a0, nA, b0, nB, int(bool(diag)), int(bool(window)), l_window, 0)
+
+    def count_tile(self, mode: int, a0: int, nA: int, b0: int, nB: int, diag: bool = False) -> np.ndarray:
+        ncell = 4 if mode == MODE_PHASED else 9
+        out = np.zeros((nA, nB, ncell), dtype=np.uint64)
+        t = self._tile(a0, nA, b0, nB, diag)
+        self._check(self._lib.twk_hip_count_tile(self._ctx, mode, C.byref(t), out.ctypes.data), "twk_hip_count_tile")
+        return out
+
+    def ld_tile(self, mode: int, a0: int, nA: int, b0: int, nB: int, diag: bool, filters: Filters,
+                capacity: int | None = None, window: int = 0, l_window: int = 0):
+        cap = capacity if capacity is not None else nA * nB
+        out = np.zeros(max(cap, 1), dtype=RECORD_DTYPE)
+        n, npairs = C.c_uint64(0), C.c_uint64(0)
+        t = self._tile(a0, nA, b0, nB, diag, window, l_window)
+        f = filters._c()
+        rc = self._lib.twk_hip_ld_tile(self._ctx, mode, C.byref(t), C.byref(f), out.ctypes.data, cap,
+                                       C.byref(n), C.byref(npairs))
+        if rc == E_OVERFLOW:
+            raise HipError(rc, "twk_hip_ld_tile", f"need capacity {n.value}")
+        self._check(rc, "twk_hip_ld_tile")
+        return out[: n.value].copy(), npairs.value
+
+    def ld_all(self, mode: int, filters: Filters, part: int = 0, n_parts: int = 1, tile_variants: int = 0,
+               window: int = 0, l_window: int = 0, collect: bool = True):
+        """All-vs-all over shard `part` of `n_parts`. Returns (records, n_pairs, n_records)."""
+        chunks = []
+
+        def sink(_user, recs, n):
+            if collect and n:
+                buf = (C.c_char * (n * RECORD_DTYPE.itemsize)).from_address(recs)
+                chunks.append(np.frombuffer(buf, dtype=RECORD_DTYPE).copy())
+            return 0
+
+        cb = _SINK(sink)
+        npairs, nrec = C.c_uint64(0), C.c_uint64(0)
+        f = filters._c()
+        self._check(self._lib.twk_hip_ld_all(self._ctx, mode, C.byref(f), part, n_parts, tile_variants,
+                                             int(bool(window)), l_window, cb, None, C.byref(npairs), C.byref(nrec)),
+                    "twk_hip_ld_all")
+        recs = np.concatenate(chunks) if chunks else np.zeros(0, dtype=RECORD_DTYPE)
+        return recs, npairs.value, nrec.value
+
+    # ---- measurement ----
+    def timing_reset(self):
+        self._check(self._lib.twk_hip_timing_reset(self._ctx), "twk_hip_timing_reset")
+
+    def timing(self) -> dict:
+        t = _Timing()
+        self._check(self._lib.twk_hip_timing_get(self._ctx, C.byref(t)), "twk_hip_timing_get")
+        return {k: getattr(t, k) for k, _ in _Timing._fields_}
