@@ -161,6 +161,15 @@ int twk_hip_ld_all(twk_hip_ctx* ctx, int mode, const twk_hip_filters* filters,
                    int32_t window, uint32_t l_window,
                    twk_hip_record_sink sink, void* user, uint64_t* n_pairs, uint64_t* n_records);
 
+/* Same over a sub-region of the pair space: rows [a0,a0+nA) x cols [b0,b0+nB).
+ * triangle != 0 (requires a0 == b0, nA == nB): only col > row.  This is what a
+ * `-c/-C` chunk of the reference is (ld_balancing.h:59-78: diagonal or square). */
+int twk_hip_ld_region(twk_hip_ctx* ctx, int mode, const twk_hip_filters* filters,
+                      uint32_t a0, uint32_t nA, uint32_t b0, uint32_t nB, int32_t triangle,
+                      uint32_t part, uint32_t n_parts, uint32_t tile_variants,
+                      int32_t window, uint32_t l_window,
+                      twk_hip_record_sink sink, void* user, uint64_t* n_pairs, uint64_t* n_records);
+
 /* ---- measurement ------------------------------------------------------ */
 /* Cumulative device time (HIP events on the engine's own stream) and launch
  * count of the dominant kernel (count-tile) and of the math kernel since the

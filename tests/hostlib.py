@@ -1,0 +1,110 @@
+"""ctypes binding of the test C API of lib/libtomahawk_amd.so (tomahawk_amd/csrc/host/twk_capi.cpp)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from tomahawk_amd.hip import META_DTYPE
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(ROOT, "tomahawk_amd", "lib", "libtomahawk_amd.so")
+CLI_PATH = os.path.join(ROOT, "tomahawk_amd", "bin", "tomahawk")
+
+# twk1_two_t as serialised (reference lib/core.cpp:470-490): 106 bytes, packed
+TWO_DTYPE = np.dtype({"names": ["controller", "ridA", "ridB", "packA", "packB", "cnt", "D", "Dprime", "R", "R2", "P",
+                                "ChiSqFisher", "ChiSqModel"],
+                      "formats": ["<u2", "<u4", "<u4", "<u4", "<u4", ("<f8", (4,)), "<f8", "<f8", "<f8", "<f8", "<f8",
+                                  "<f8", "<f8"],
+                      "offsets": [0, 2, 6, 10, 14, 18, 50, 58, 66, 74, 82, 90, 98], "itemsize": 106})
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} not built: run `make host`")
+        L = C.CDLL(LIB_PATH)
+        p = C.c_void_p
+        L.twk_file_write_twk.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, p, p, p, p, p, C.c_uint32, C.c_uint32, C.c_int]
+        L.twk_file_write_synthetic_twk.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int, C.c_uint32,
+                                                   C.c_int, C.c_int]
+        L.twk_file_read_twk.argtypes = [C.c_char_p, p, p, p, p, p, p]
+        L.twk_file_read_two.argtypes = [C.c_char_p, p, C.c_uint64, p, p]
+        L.twk_file_header_literals.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_size_t]
+        L.twk_ld_compute.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
+                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, p, p]
+        _lib = L
+    return _lib
+
+
+def write_twk(path, alleles, pos, rid, phased, n_contigs=1, block_size=500, hwe=None, c_level=1):
+    M, N, _ = alleles.shape
+    al = np.ascontiguousarray(alleles.reshape(M, 2 * N), dtype=np.int8)
+    pos = np.ascontiguousarray(pos, dtype=np.uint32)
+    rid = np.ascontiguousarray(rid, dtype=np.uint32)
+    ph = np.ascontiguousarray(phased, dtype=np.uint8)
+    hw = None if hwe is None else np.ascontiguousarray(hwe, dtype=np.float64)
+    rc = lib().twk_file_write_twk(path.encode(), N, M, al.ctypes.data, pos.ctypes.data, rid.ctypes.data, ph.ctypes.data,
+                                  None if hw is None else hw.ctypes.data, n_contigs, block_size, c_level)
+    if rc != 0:
+        raise RuntimeError(f"twk_file_write_twk failed: {rc}")
+
+
+def write_synthetic_twk(path, n_samples, n_variants, seed=42, phased=False, block_size=50, c_level=1, n_threads=8):
+    rc = lib().twk_file_write_synthetic_twk(path.encode(), n_samples, n_variants, seed, int(phased), block_size, c_level,
+                                            n_threads)
+    if rc != 0:
+        raise RuntimeError(f"twk_file_write_synthetic_twk failed: {rc}")
+
+
+def read_twk(path):
+    n_s, n_v = C.c_uint32(), C.c_uint32()
+    rc = lib().twk_file_read_twk(path.encode(), C.byref(n_s), C.byref(n_v), None, None, None, None)
+    if rc != 0:
+        raise RuntimeError(f"twk_file_read_twk failed: {rc}")
+    N, M = n_s.value, n_v.value
+    w = (2 * N + 63) // 64
+    data = np.zeros((M, w), dtype=np.uint64)
+    mask = np.zeros((M, w), dtype=np.uint64)
+    meta = np.zeros(M, dtype=META_DTYPE)
+    extra = np.zeros((M, 4), dtype=np.uint32)
+    rc = lib().twk_file_read_twk(path.encode(), None, None, data.ctypes.data, mask.ctypes.data, meta.ctypes.data,
+                                 extra.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(f"twk_file_read_twk failed: {rc}")
+    return N, data, mask, meta, extra
+
+
+def read_two(path):
+    n = C.c_uint64()
+    info = (C.c_uint64 * 4)()
+    rc = lib().twk_file_read_two(path.encode(), None, 0, C.byref(n), info)
+    if rc != 0:
+        raise RuntimeError(f"twk_file_read_two failed: {rc}")
+    recs = np.zeros(n.value, dtype=TWO_DTYPE)
+    if n.value:
+        rc = lib().twk_file_read_two(path.encode(), recs.ctypes.data, n.value, C.byref(n), info)
+        if rc != 0:
+            raise RuntimeError(f"twk_file_read_two failed: {rc}")
+    return recs, dict(n_samples=info[0], n_contigs=info[1], n_blocks=info[2], state=info[3])
+
+
+def header_literals(path, is_two=True):
+    buf = C.create_string_buffer(1 << 16)
+    rc = lib().twk_file_header_literals(path.encode(), int(is_two), buf, len(buf))
+    if rc != 0:
+        raise RuntimeError(f"twk_file_header_literals failed: {rc}")
+    return buf.value.decode()
+
+
+def two_as_matrix(recs):
+    """TWO_DTYPE records -> float64 [n, 16] in the column order of `tomahawk_ref dump`."""
+    out = np.zeros((len(recs), 16))
+    out[:, 0] = recs["controller"]; out[:, 1] = recs["ridA"]; out[:, 2] = recs["packA"] >> 2
+    out[:, 3] = recs["ridB"]; out[:, 4] = recs["packB"] >> 2
+    out[:, 5:9] = recs["cnt"]
+    for i, f in enumerate(("D", "Dprime", "R", "R2", "P", "ChiSqFisher", "ChiSqModel")):
+        out[:, 9 + i] = recs[f]
+    return out

@@ -1,0 +1,120 @@
+"""Host-side formats and the C-ABI surface (CPU only, no compute calls)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import tomahawk_amd as T
+from oracle import oracle as O
+from tests import hostlib, util
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def test_c_abi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "twk_hip.h")).read()
+    names = sorted(set(re.findall(r"\b(twk_hip_[a-z_]+|twk_synth_[a-z_]+)\s*\(", hdr)))
+    names = [n for n in names if n != "twk_hip_record_sink"]
+    assert len(names) >= 17
+    lib = T.load_library()
+    for n in names:
+        assert hasattr(lib, n), f"libtwk_hip.so does not export {n}"
+    assert lib.twk_hip_abi_version() == 1
+    assert lib.twk_hip_strerror(-4).decode() == "record buffer too small"
+
+
+def test_struct_layouts_match_header():
+    assert T.RECORD_DTYPE.itemsize == 104 and hostlib.TWO_DTYPE.itemsize == 106
+    assert T.hip.META_DTYPE.itemsize == 32 and ctypes.sizeof(T.hip._Tile) == 32 and ctypes.sizeof(T.hip._Filters) == 40
+
+
+def test_no_device_fails_loudly_without_fallback():
+    if T.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(T.HipError) as e:
+        T.HipLd(0)
+    assert e.value.code == -3
+
+
+def test_read_reference_written_two():
+    """Our .two reader on a file written by the reference itself."""
+    recs, info = hostlib.read_two(os.path.join(GOLDEN, "ref_n64_small_p.two"))
+    z = np.load(os.path.join(GOLDEN, "n64_small.npz"))
+    want = z["rec_p"]
+    assert info["n_samples"] == 64 and info["n_contigs"] == 1 and info["state"] == 0
+    assert len(recs) == 2 * len(want)
+    m = hostlib.two_as_matrix(recs)
+    fwd = m[m[:, 2] < m[:, 4]]
+    fwd = fwd[np.lexsort((fwd[:, 4], fwd[:, 2]))]
+    assert np.array_equal(fwd, want)
+    rev = m[m[:, 2] > m[:, 4]]
+    rev = rev[np.lexsort((rev[:, 2], rev[:, 4]))]
+    # reverse copy: (rid,pos) swapped, everything else (including cnt) untouched
+    assert np.array_equal(rev[:, [4, 2]], want[:, [2, 4]]) and np.array_equal(rev[:, 5:], want[:, 5:])
+    assert "##tomahawk_calcCommand=" in hostlib.header_literals(os.path.join(GOLDEN, "ref_n64_small_p.two"))
+
+
+@pytest.mark.parametrize("N,M,kw", [(64, 30, {}), (100, 45, dict(low_ac=5)), (257, 20, dict(miss_rate=0.2, miss_variants=0.5)),
+                                    (5000, 6, dict(maf_lo=0.0005, maf_hi=0.002))])
+def test_twk_roundtrip(tmp_path, N, M, kw):
+    al = util.random_alleles(M, N, 77, **kw)
+    pos = (1000 + 50 * np.arange(M)).astype(np.uint32)
+    rid = (np.arange(M) * 2 // M).astype(np.uint32)
+    p = str(tmp_path / "x.twk")
+    hostlib.write_twk(p, al, pos, rid, phased=np.arange(M) % 2, n_contigs=2, block_size=7,
+                      hwe=np.linspace(0, 1, M))
+    n, data, mask, meta, extra = hostlib.read_twk(p)
+    want_data, want_mask = O.bitvectors_from_alleles(al)
+    assert n == N and np.array_equal(data, want_data)
+    assert np.array_equal(mask, want_mask if want_mask is not None else np.zeros_like(data))
+    assert np.array_equal(meta["pos"], pos) and np.array_equal(meta["rid"], rid)
+    assert np.array_equal(meta["ac"], (al == 1).sum(axis=(1, 2))) and np.array_equal(meta["an"], (al == 2).sum(axis=(1, 2)))
+    assert np.array_equal(meta["missing"], (al == 2).any(axis=(1, 2)))
+    np.testing.assert_array_equal(meta["hwe"], np.linspace(0, 1, M))
+    assert np.array_equal(extra[:, 2], np.arange(M) % 2)
+
+
+def test_truncated_and_foreign_files_are_rejected(tmp_path):
+    al = util.random_alleles(10, 64, 1)
+    p = str(tmp_path / "x.twk")
+    hostlib.write_twk(p, al, np.arange(10, dtype=np.uint32), np.zeros(10, np.uint32), np.ones(10, np.uint8))
+    raw = open(p, "rb").read()
+    open(p, "wb").write(raw[: len(raw) - 20])
+    with pytest.raises(RuntimeError):
+        hostlib.read_twk(p)
+    open(p, "wb").write(b"NOTATWKFILE" + raw[11:])
+    with pytest.raises(RuntimeError):
+        hostlib.read_twk(p)
+    with pytest.raises(RuntimeError):
+        hostlib.read_two(os.path.join(GOLDEN, "n64_small.npz"))
+
+
+def test_synthetic_twk_matches_host_generator(tmp_path):
+    N, M = 300, 12
+    p = str(tmp_path / "s.twk")
+    hostlib.write_synthetic_twk(p, N, M, seed=42, phased=False, block_size=5, n_threads=3)
+    n, data, mask, meta, extra = hostlib.read_twk(p)
+    assert n == N and not mask.any()
+    for v in range(M):
+        bv, ac = T.synth_bitvector(42, N, v)
+        assert np.array_equal(data[v], bv) and meta["ac"][v] == ac and meta["pos"][v] == 1000 + 100 * v
+    # determinism + seed sensitivity
+    assert np.array_equal(T.synth_bitvector(42, N, 3)[0], T.synth_bitvector(42, N, 3)[0])
+    assert not np.array_equal(T.synth_bitvector(42, N, 3)[0], T.synth_bitvector(43, N, 3)[0])
+
+
+def test_cli_usage_and_errors():
+    import subprocess
+    r = subprocess.run([hostlib.CLI_PATH], capture_output=True, text=True)
+    assert r.returncode == 1 and "tomahawk calc" in r.stderr
+    r = subprocess.run([hostlib.CLI_PATH, "calc", "-i", "/nonexistent.twk", "-o", "/tmp/x", "-r", "2"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Cannot have minimum R-squared value > 1" in r.stderr
+    r = subprocess.run([hostlib.CLI_PATH, "calc", "-i", "/nonexistent.twk", "-o", "/tmp/x"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Failed to open file" in r.stderr
+    r = subprocess.run([hostlib.CLI_PATH, "calc", "-i", "a", "-o", "b", "-a", "3"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Unrecognized option" in r.stderr          # reference: calc.h:216-218
+    r = subprocess.run([hostlib.CLI_PATH, "view"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Illegal command" in r.stderr

@@ -1,0 +1,131 @@
+"""GPU vs the reference's own output (golden fixtures), through the C ABI and through the CLI."""
+import glob
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import tomahawk_amd as T
+from oracle import oracle as O
+from tests import hostlib, util
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
+MODES = {"p": T.MODE_PHASED, "u": T.MODE_UNPHASED, "d": T.MODE_AUTO}
+
+
+def golden_as_oracle_records(mat):
+    r = np.zeros(len(mat), dtype=O.RECORD_DTYPE)
+    r["controller"] = mat[:, 0]; r["ridA"] = mat[:, 1]; r["Apos"] = mat[:, 2]; r["ridB"] = mat[:, 3]; r["Bpos"] = mat[:, 4]
+    r["cnt"] = mat[:, 5:9]
+    for i, f in enumerate(("D", "Dprime", "R", "R2", "P", "ChiSqFisher", "ChiSqModel")):
+        r[f] = mat[:, 9 + i]
+    return r
+
+
+def normalise_orientation(recs, cnt_field="cnt"):
+    """cnt[1]/cnt[2] orientation depends on which CPU kernel the reference picked for a pair with
+    missing data (run-length vs vector); the statistics do not.  Sort the two."""
+    recs = recs.copy()
+    c = recs[cnt_field]
+    lo, hi = np.minimum(c[:, 1], c[:, 2]), np.maximum(c[:, 1], c[:, 2])
+    c[:, 1], c[:, 2] = lo, hi
+    recs[cnt_field] = c
+    return recs
+
+
+@pytest.mark.parametrize("tag", ["p", "u", "d"])
+@pytest.mark.parametrize("name", CASES)
+def test_hip_equals_reference_records(hip, name, tag):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    al = z["alleles"]
+    variants = O.variants_from_alleles(al, pos=z["pos"], rid=z["rid"], phase=1)
+    util.upload(hip, al, variants)
+    got, npairs, _ = hip.ld_all(MODES[tag], T.Filters(minR2=0.0))
+    M = al.shape[0]
+    assert npairs == M * (M - 1) // 2
+    want = golden_as_oracle_records(z["rec_" + tag])
+    if (al == 2).any():
+        got, want = normalise_orientation(got), normalise_orientation(want)
+    util.assert_records_match(got, want, variants)
+
+
+@pytest.mark.parametrize("name,flag,tag", [("n64_small", "-p", "p"), ("n100_pad", "-u", "u"), ("n1000", "-p", "p"),
+                                           ("n128_missing", None, "d")])
+def test_cli_calc_end_to_end(tmp_path, name, flag, tag):
+    """`tomahawk calc -i in.twk -o out.two -r 0`: .twk in, .two out, every record twice."""
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    al = z["alleles"]
+    M = al.shape[0]
+    n_contigs = int(z["rid"].max()) + 1
+    twk = str(tmp_path / "in.twk")
+    hostlib.write_twk(twk, al, z["pos"], z["rid"], phased=np.ones(M, np.uint8), n_contigs=n_contigs, block_size=23)
+    out = str(tmp_path / "res")            # extension is forced to .two (ld.cpp:589-598)
+    cmd = [hostlib.CLI_PATH, "calc", "-i", twk, "-o", out, "-r", "0", "-t", "2"] + ([flag] if flag else [])
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "variants/s" in r.stderr and not r.stdout
+    recs, info = hostlib.read_two(out + ".two")
+    assert info["n_samples"] == al.shape[1] and info["n_contigs"] == n_contigs and info["state"] == 0
+    want = z["rec_" + tag]
+    assert len(recs) == 2 * len(want)
+    m = hostlib.two_as_matrix(recs)
+    keyA, keyB = m[:, 1] * 2**32 + m[:, 2], m[:, 3] * 2**32 + m[:, 4]
+    fwd = m[keyA < keyB]
+    rev = m[keyA > keyB]
+    fwd = fwd[np.lexsort((fwd[:, 4], fwd[:, 3], fwd[:, 2], fwd[:, 1]))]
+    rev = rev[np.lexsort((rev[:, 2], rev[:, 1], rev[:, 4], rev[:, 3]))]
+    assert np.array_equal(fwd[:, 1:5], want[:, 1:5])
+    assert np.array_equal(rev[:, [3, 4, 1, 2]], want[:, 1:5]) and np.array_equal(rev[:, 5:], fwd[:, 5:])
+    variants = O.variants_from_alleles(al, pos=z["pos"], rid=z["rid"], phase=1)
+    pos2idx = {(int(v["rid"]), int(v["pos"])): i for i, v in enumerate(variants)}
+    got = np.zeros(len(fwd), dtype=T.RECORD_DTYPE)
+    got["idxA"] = [pos2idx[(int(a), int(b))] for a, b in fwd[:, 1:3]]
+    got["idxB"] = [pos2idx[(int(a), int(b))] for a, b in fwd[:, 3:5]]
+    got["flags"] = fwd[:, 0]; got["cnt"] = fwd[:, 5:9]
+    for i, f in enumerate(("D", "Dprime", "R", "R2", "P", "ChiSqFisher", "ChiSqModel")):
+        got[f] = fwd[:, 9 + i]
+    w = golden_as_oracle_records(want)
+    if (al == 2).any():
+        got, w = normalise_orientation(got), normalise_orientation(w)
+    util.assert_records_match(got, w, variants)
+    lit = hostlib.header_literals(out + ".two")
+    assert "##tomahawk_calcCommand=tomahawk calc -i" in lit and "##tomahawk_calcVersion=" in lit
+
+
+def test_cli_chunked_equals_whole(tmp_path):
+    """-c 3 -C k (reference farm mode): the three parts partition the whole output."""
+    N, M = 96, 240
+    al = util.random_alleles(M, N, 5)
+    pos = (1000 + 10 * np.arange(M)).astype(np.uint32)
+    twk = str(tmp_path / "in.twk")
+    hostlib.write_twk(twk, al, pos, np.zeros(M, np.uint32), np.ones(M, np.uint8), block_size=20)   # 12 blocks
+    def run(extra, out):
+        r = subprocess.run([hostlib.CLI_PATH, "calc", "-i", twk, "-o", out, "-r", "0.05", "-p"] + extra, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        return hostlib.two_as_matrix(hostlib.read_two(out)[0])
+    whole = run([], str(tmp_path / "w.two"))
+    parts = [run(["-c", "3", "-C", str(k)], str(tmp_path / f"p{k}.two")) for k in (1, 2, 3)]
+    cat = np.concatenate(parts)
+    key = lambda m: m[np.lexsort((m[:, 4], m[:, 2]))]
+    assert len(cat) == len(whole) > 0 and np.array_equal(key(cat), key(whole))
+
+
+def test_cli_window_mode(tmp_path):
+    N, M = 64, 200
+    al = util.random_alleles(M, N, 9)
+    pos = (1000 + 1000 * np.arange(M)).astype(np.uint32)
+    twk = str(tmp_path / "in.twk")
+    hostlib.write_twk(twk, al, pos, np.zeros(M, np.uint32), np.ones(M, np.uint8), block_size=16)
+    def run(extra, out):
+        r = subprocess.run([hostlib.CLI_PATH, "calc", "-i", twk, "-o", out, "-r", "0", "-u"] + extra, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        return hostlib.two_as_matrix(hostlib.read_two(out)[0])
+    whole = run([], str(tmp_path / "w.two"))
+    win = run(["-w", "20000"], str(tmp_path / "win.two"))
+    sel = whole[np.abs(whole[:, 2] - whole[:, 4]) <= 20000]
+    key = lambda m: m[np.lexsort((m[:, 4], m[:, 2]))]
+    assert 0 < len(win) < len(whole) and np.array_equal(key(win), key(sel))

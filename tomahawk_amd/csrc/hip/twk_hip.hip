@@ -576,36 +576,48 @@ int twk_hip_ld_tile(twk_hip_ctx* c, int mode, const twk_hip_tile_desc* t, const 
 int twk_hip_ld_all(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint32_t part, uint32_t n_parts,
                    uint32_t tile_variants, int32_t window, uint32_t l_window, twk_hip_record_sink sink,
                    void* user, uint64_t* n_pairs, uint64_t* n_records) {
+	if (!c) return TWK_HIP_E_INVALID;
+	return twk_hip_ld_region(c, mode, f, 0, c->M, 0, c->M, 1, part, n_parts, tile_variants, window, l_window,
+	                         sink, user, n_pairs, n_records);
+}
+
+int twk_hip_ld_region(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint32_t a0, uint32_t nA,
+                      uint32_t b0, uint32_t nB, int32_t triangle, uint32_t part, uint32_t n_parts,
+                      uint32_t tile_variants, int32_t window, uint32_t l_window, twk_hip_record_sink sink,
+                      void* user, uint64_t* n_pairs, uint64_t* n_records) {
 	if (!c || !f || !valid_mode(mode) || n_parts == 0 || part >= n_parts) return TWK_HIP_E_INVALID;
 	if (!c->raw) return TWK_HIP_E_STATE;
+	if (nA == 0 || nB == 0 || (uint64_t)a0 + nA > c->M || (uint64_t)b0 + nB > c->M) return TWK_HIP_E_INVALID;
+	if (triangle && (a0 != b0 || nA != nB)) return TWK_HIP_E_INVALID;
 	HIPCHK(c, hipSetDevice(c->device));
-	const uint32_t M = c->M;
 	// Super-tile edge: multiple of 128 variants; default aims at >= 16 tiles per shard.
 	uint32_t S = tile_variants;
+	const uint32_t span = std::max(nA, nB);
 	if (S == 0) {
 		S = 8192;
 		while (S > 1024) {
-			const uint64_t nb = (M + S - 1) / S;
-			if (nb * (nb + 1) / 2 >= 16ull * n_parts) break;
+			const uint64_t na = (nA + S - 1) / S, nb_ = (nB + S - 1) / S;
+			const uint64_t ntiles = triangle ? na * (na + 1) / 2 : na * nb_;
+			if (ntiles >= 16ull * n_parts) break;
 			S /= 2;
 		}
 	}
-	S = round_up(std::min(S, round_up(M, TILE)), TILE);
-	const uint32_t nb = (M + S - 1) / S;
+	S = round_up(std::min(S, round_up(span, TILE)), TILE);
+	const uint32_t nba = (nA + S - 1) / S, nbb = (nB + S - 1) / S;
 
-	// Static cost-balanced assignment: walk the triangle, give each tile to the
+	// Static cost-balanced assignment: walk the region, give each tile to the
 	// currently lightest shard (diagonal tiles cost half).  Deterministic, so
 	// every rank derives the same partition without talking to the others.
 	std::vector<twk_hip_tile_desc> mine;
 	{
 		std::vector<uint64_t> load(n_parts, 0);
-		for (uint32_t bi = 0; bi < nb; ++bi) {
-			for (uint32_t bj = bi; bj < nb; ++bj) {
+		for (uint32_t bi = 0; bi < nba; ++bi) {
+			for (uint32_t bj = triangle ? bi : 0; bj < nbb; ++bj) {
 				twk_hip_tile_desc t{};
-				t.rowA0 = bi * S; t.nA = std::min(S, M - bi * S);
-				t.rowB0 = bj * S; t.nB = std::min(S, M - bj * S);
-				t.diag = (bi == bj); t.window = window; t.l_window = l_window;
-				if (window && bi != bj) {
+				t.rowA0 = a0 + bi * S; t.nA = std::min(S, nA - bi * S);
+				t.rowB0 = b0 + bj * S; t.nB = std::min(S, nB - bj * S);
+				t.diag = (triangle && bi == bj); t.window = window; t.l_window = l_window;
+				if (window && !t.diag) {
 					// Inputs are sorted by (rid, pos) like every .twk: if both tiles lie on one
 					// contig and the gap between them exceeds the window, no pair can qualify
 					// (the reference's ticker skips the rest of the row, ld_balancing.h:191).

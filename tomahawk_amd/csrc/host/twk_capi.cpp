@@ -1,0 +1,157 @@
+// Small C API over the host library for tests, tools and the benchmark harness
+// (ctypes-friendly; plain pointers and sizes).
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "twk_format.h"
+#include "twk_ld.h"
+#include "twk_hip.h"
+
+using namespace tomahawk;
+
+extern "C" {
+
+// Write a .twk from dense genotypes.  alleles: int8 [n_variants][2*n_samples] in {0,1,2};
+// pos/rid: per variant (sorted by rid,pos); phased: per variant 0/1; hwe may be NULL (1.0);
+// n_contigs contigs named "1".."n"; block_size variants per block (one contig per block).
+int twk_file_write_twk(const char* path, uint32_t n_samples, uint32_t n_variants, const int8_t* alleles,
+                       const uint32_t* pos, const uint32_t* rid, const uint8_t* phased, const double* hwe,
+                       uint32_t n_contigs, uint32_t block_size, int c_level) {
+	if (!path || !alleles || !pos || !rid || !phased || n_samples == 0 || block_size == 0) return -1;
+	Header hdr;
+	hdr.literals = "##fileformat=VCFv4.2\n##source=tomahawk_amd synthetic writer";
+	for (uint32_t s = 0; s < n_samples; ++s) hdr.samples.push_back("S" + std::to_string(s));
+	for (uint32_t c = 0; c < n_contigs; ++c) { Contig k; k.idx = c; k.name = std::to_string(c + 1); k.n_bases = 250000000; hdr.contigs.push_back(k); }
+	TwkWriter w;
+	if (!w.open(path, hdr, c_level)) return -2;
+	Block blk;
+	for (uint32_t v = 0; v < n_variants; ++v) {
+		if (rid[v] >= n_contigs) return -1;
+		if (!blk.rcds.empty() && (blk.rid != rid[v] || blk.rcds.size() == block_size)) { if (!w.write_block(blk)) return -3; blk.rcds.clear(); }
+		if (blk.rcds.empty()) blk.rid = rid[v];
+		Variant x;
+		x.encode(alleles + (size_t)v * 2 * n_samples, n_samples, phased[v] != 0);
+		x.pos = pos[v]; x.rid = rid[v]; x.hwe = hwe ? hwe[v] : 1.0; x.alleles = 0x12;
+		blk.rcds.push_back(std::move(x));
+	}
+	if (!blk.rcds.empty() && !w.write_block(blk)) return -3;
+	return w.close() ? 0 : -3;
+}
+
+// Write the first n_variants of the synthetic benchmark input as a .twk:
+// the CPU-baseline sample shares its bits with twk_hip_generate_synthetic().
+int twk_file_write_synthetic_twk(const char* path, uint32_t n_samples, uint32_t n_variants, uint64_t seed,
+                                 int phased, uint32_t block_size, int c_level, int n_threads) {
+	if (!path || n_samples == 0 || n_variants == 0 || block_size == 0) return -1;
+	Header hdr;
+	hdr.literals = "##fileformat=VCFv4.2\n##source=tomahawk_amd synthetic benchmark input seed=" + std::to_string(seed);
+	for (uint32_t s = 0; s < n_samples; ++s) hdr.samples.push_back("S" + std::to_string(s));
+	Contig k; k.idx = 0; k.name = "1"; k.n_bases = 250000000; hdr.contigs.push_back(k);
+	TwkWriter w;
+	if (!w.open(path, hdr, c_level)) return -2;
+	const size_t w64 = ((size_t)2 * n_samples + 63) / 64;
+	const uint32_t T = (uint32_t)std::max(1, n_threads);
+	for (uint32_t v0 = 0; v0 < n_variants; v0 += block_size) {
+		const uint32_t nb = std::min(block_size, n_variants - v0);
+		Block blk; blk.rid = 0; blk.rcds.resize(nb);
+		auto job = [&](uint32_t t) {
+			std::vector<uint64_t> bv(w64);
+			std::vector<int8_t> al((size_t)2 * n_samples);
+			for (uint32_t i = t; i < nb; i += T) {
+				twk_synth_bitvector(seed, n_samples, v0 + i, bv.data());
+				for (size_t p = 0; p < (size_t)2 * n_samples; ++p) al[p] = (int8_t)((bv[p >> 6] >> (p & 63)) & 1);
+				Variant& x = blk.rcds[i];
+				x.encode(al.data(), n_samples, phased != 0);
+				x.pos = 1000u + 100u * (v0 + i); x.rid = 0; x.hwe = 1.0; x.alleles = 0x12;
+			}
+		};
+		std::vector<std::thread> th;
+		for (uint32_t t = 0; t < T; ++t) th.emplace_back(job, t);
+		for (auto& t : th) t.join();
+		if (!w.write_block(blk)) return -3;
+	}
+	return w.close() ? 0 : -3;
+}
+
+// Read a whole .twk: two-call pattern (first with data == NULL to get the sizes).
+// meta: twk_hip_variant_meta[n_variants]; extra (may be NULL): uint32 [n_variants][4] = n_het, n_hom, gt_phase, n_runs.
+int twk_file_read_twk(const char* path, uint32_t* n_samples, uint32_t* n_variants, uint64_t* data, uint64_t* mask,
+                      twk_hip_variant_meta* meta, uint32_t* extra) {
+	TwkReader rd;
+	if (!path || !rd.open(path)) return -2;
+	uint32_t M = 0;
+	for (const auto& e : rd.index.ent) M += e.n;
+	const uint32_t N = (uint32_t)rd.hdr.samples.size();
+	if (n_samples) *n_samples = N;
+	if (n_variants) *n_variants = M;
+	if (!data) return 0;
+	const size_t w64 = ((size_t)2 * N + 63) / 64;
+	uint32_t v = 0;
+	for (size_t b = 0; b < rd.index.ent.size(); ++b) {
+		Block blk;
+		if (!rd.read_block(b, blk)) return -3;
+		for (const auto& x : blk.rcds) {
+			if (!x.build_bitvector(N, data + (size_t)v * w64, mask ? mask + (size_t)v * w64 : nullptr)) return -4;
+			if (meta) { twk_hip_variant_meta& m = meta[v]; m.ac = x.ac; m.an = x.an; m.pos = x.pos; m.rid = x.rid; m.missing = x.gt_missing; m._pad = 0; m.hwe = x.hwe; }
+			if (extra) { extra[4 * v] = x.n_het; extra[4 * v + 1] = x.n_hom; extra[4 * v + 2] = x.gt_phase; extra[4 * v + 3] = (uint32_t)x.runs.size(); }
+			++v;
+		}
+	}
+	return 0;
+}
+
+// Read a whole .two: records are the 106-byte packed twk1_two_t.  Two-call pattern.
+// info (may be NULL): [n_samples, n_contigs, n_index_blocks, index_state].
+int twk_file_read_two(const char* path, void* records, uint64_t capacity, uint64_t* n_records, uint64_t* info) {
+	TwoReader rd;
+	if (!path || !rd.open(path)) return -2;
+	if (info) { info[0] = rd.hdr.samples.size(); info[1] = rd.hdr.contigs.size(); info[2] = rd.index.ent.size(); info[3] = rd.index.state; }
+	std::vector<TwoRecord> blk;
+	uint64_t n = 0;
+	while (rd.next_block(blk)) {
+		if (records) {
+			if (n + blk.size() > capacity) return -4;
+			std::memcpy((uint8_t*)records + n * sizeof(TwoRecord), blk.data(), blk.size() * sizeof(TwoRecord));
+		}
+		n += blk.size();
+	}
+	if (!rd.error.empty()) return -3;
+	if (n_records) *n_records = n;
+	// index consistency: entries must tile the block stream
+	uint64_t idx_n = 0;
+	for (const auto& e : rd.index.ent) idx_n += e.n;
+	return idx_n == n ? 0 : -5;
+}
+
+// Header literals of a .two / .twk (NUL terminated, truncated to cap).
+int twk_file_header_literals(const char* path, int is_two, char* out, size_t cap) {
+	Header h;
+	if (is_two) { TwoReader r; if (!r.open(path)) return -2; h = r.hdr; }
+	else { TwkReader r; if (!r.open(path)) return -2; h = r.hdr; }
+	if (out && cap) { std::strncpy(out, h.literals.c_str(), cap - 1); out[cap - 1] = 0; }
+	return 0;
+}
+
+// twk_ld::Compute through a flat argument list (what calc.h:96-238 builds).
+int twk_ld_compute(const char* in, const char* out, int force_phased, int force_unphased, double minR2, double minP,
+                   double minDprime, int window, int l_window, int n_chunks, int c_chunk, int n_threads, int c_level,
+                   int b_size, uint64_t* n_pairs, uint64_t* n_records) {
+	twk_ld_settings s;
+	s.in = in ? in : ""; s.out = out ? out : "-";
+	s.force_phased = force_phased != 0; s.forced_unphased = force_unphased != 0;
+	s.minR2 = minR2; s.minP = minP; s.minDprime = minDprime;
+	s.window = window != 0; if (window) s.l_window = l_window;
+	s.n_chunks = n_chunks; s.c_chunk = c_chunk;
+	if (n_threads > 0) s.n_threads = n_threads;
+	s.c_level = c_level; if (b_size > 0) s.b_size = b_size;
+	twk_ld ld;
+	const bool ok = ld.Compute(s);
+	if (n_pairs) *n_pairs = ld.n_pairs();
+	if (n_records) *n_records = ld.n_records();
+	return ok ? 0 : 1;
+}
+
+}  // extern "C"

@@ -1,0 +1,364 @@
+// tomahawk::twk_ld on the MI355X engine.
+//
+// Host orchestration that the reference does in lib/ld/ld.cpp:477-671 (Compute):
+// open the .twk, pick the chunk of the block triangle (-c/-C), unpack the blocks
+// to bitvectors on worker threads, hand them to the device through the C ABI
+// (include/twk_hip.h), stream the surviving pairs back and write the .two file
+// (forward + reverse copies in separate blocks, ld_engine.cpp:1270-1309).
+#include "twk_ld.h"
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <ctime>
+#include <iomanip>
+#include <iostream>
+#include <sstream>
+#include <thread>
+#include <sys/time.h>
+
+#include "twk_format.h"
+#include "twk_hip.h"
+
+#ifndef TWK_AMD_VERSION
+#define TWK_AMD_VERSION "0.7.0-mi355x"
+#endif
+
+namespace tomahawk {
+
+// Defined by the executable, as with the reference (lib/main.cpp:4).  A weak
+// *reference*: clients that do not define it (ctypes, tests) get an empty string.
+extern __attribute__((weak)) std::string LITERAL_COMMAND_LINE;
+static std::string command_line() {
+	std::string* volatile p = &LITERAL_COMMAND_LINE;
+	return p ? *p : std::string();
+}
+
+// ---- utility (reference lib/utility.cpp:68-144) -------------------------------------
+namespace {
+std::string datetime() {
+	time_t t = time(nullptr);
+	struct timeval tv; gettimeofday(&tv, nullptr);
+	struct tm now; localtime_r(&t, &now);
+	char buf[64];
+	snprintf(buf, sizeof(buf), "%04u-%02u-%02u %02u:%02u:%02u,%03u", now.tm_year + 1900, now.tm_mon + 1,
+	         now.tm_mday, now.tm_hour, now.tm_min, now.tm_sec, (unsigned)(tv.tv_usec / 1000));
+	return std::string(buf, 23);
+}
+std::string stamp(const std::string& a) { return "[" + datetime() + "][" + a + "] "; }
+std::string stamp(const std::string& a, const std::string& b) { return "[" + datetime() + "][" + a + "][" + b + "] "; }
+std::string pretty(uint64_t v) {
+	std::string s = std::to_string(v);
+	for (int i = (int)s.size() - 3; i > 0; i -= 3) s.insert(i, ",");
+	return s;
+}
+std::string base_path(const std::string& in) { const size_t f = in.find_last_of("/\\"); return f == std::string::npos ? std::string() : in.substr(0, f); }
+std::string base_name(const std::string& in) { const size_t f = in.find_last_of("/\\"); return f == std::string::npos ? in : in.substr(f + 1); }
+std::string extension(const std::string& in) {
+	const std::string b = base_name(in);
+	const size_t d = b.rfind('.');
+	return d == std::string::npos ? std::string() : b.substr(d + 1);
+}
+std::string elapsed_string(double sec) {
+	std::ostringstream o;
+	const uint64_t s = (uint64_t)sec;
+	if (s >= 3600) o << s / 3600 << "h";
+	if (s >= 60) o << (s % 3600) / 60 << "m";
+	o << std::fixed << std::setprecision(3) << (sec - (double)(s / 60 * 60)) << "s";
+	return o.str();
+}
+
+// twk_ld_balancer::Build (lib/ld/ld_balancing.h:23-80), including its chunk
+// arithmetic (last chunk of a row is `chunk_size` blocks ending at n_blocks).
+struct Balancer {
+	bool diag = true;
+	uint32_t fromL = 0, toL = 0, fromR = 0, toR = 0;
+	bool build(uint32_t n_blocks, uint32_t parts, uint32_t chosen) {
+		if (chosen >= parts) { std::cerr << stamp("ERROR", "BALANCER") << "Illegal chosen block: " << chosen << " >= " << parts << std::endl; return false; }
+		if (parts > n_blocks) { std::cerr << stamp("ERROR", "BALANCER") << "Illegal desired number of blocks! You are asking for more subproblems than there are blocks available (" << parts << ">" << n_blocks << ")..." << std::endl; return false; }
+		if (parts == 1) { fromL = 0; toL = n_blocks; fromR = 0; toR = n_blocks; diag = true; return true; }
+		uint32_t factor = 0;
+		for (uint32_t i = 1; i < parts; ++i) if ((((i * i) - i) / 2) + i == parts) { factor = i; break; }
+		if (factor == 0) { std::cerr << stamp("ERROR", "BALANCER") << "Could not partition into " << parts << " number of subproblems. This number is not a function of x!2 + x..." << std::endl; return false; }
+		const uint32_t chunk = n_blocks / factor;
+		for (uint32_t i = 0, k = 0; i < factor; ++i) {
+			for (uint32_t j = i; j < factor; ++j, ++k) {
+				if (k != chosen) continue;
+				toR = (j + 1 == factor ? n_blocks : chunk * (j + 1)); fromR = toR - chunk;
+				toL = (i + 1 == factor ? n_blocks : chunk * (i + 1)); fromL = toL - chunk;
+				diag = (i == j);
+				return true;
+			}
+		}
+		return true;
+	}
+};
+}  // namespace
+
+// ---- settings (lib/core.cpp:297-332) -----------------------------------------------------
+twk_ld_settings::twk_ld_settings()
+    : square(true), window(false), low_memory(false), bitmaps(false), single(false), force_phased(false),
+      forced_unphased(false), force_cross_intervals(false), c_level(1), bl_size(500), b_size(10000),
+      l_window(1000000), n_threads((int32_t)std::thread::hardware_concurrency()), cycle_threshold(0),
+      ldd_load_type(TWK_LDD_ALL), l_surrounding(500000), out("-"), minP(1), minR2(0.1), maxR2(100),
+      minDprime(0), maxDprime(100), n_chunks(1), c_chunk(0) {}
+
+std::string twk_ld_settings::GetString() const {
+	auto tf = [](bool b) { return std::string(b ? "TRUE" : "FALSE"); };
+	return "square=" + tf(square) + ",window=" + tf(window) + ",low_memory=" + tf(low_memory) + ",bitmaps=" + tf(bitmaps)
+	     + ",single=" + tf(single) + ",force_phased=" + tf(force_phased) + ",force_unphased=" + tf(forced_unphased)
+	     + ",compression_level=" + std::to_string(c_level) + ",block_size=" + std::to_string(bl_size)
+	     + ",output_block_size=" + std::to_string(b_size) + (window ? ",window_size=" + std::to_string(l_window) : "")
+	     + ",l_surrounding=" + std::to_string(l_surrounding) + ",minP=" + std::to_string(minP) + ",minR2=" + std::to_string(minR2)
+	     + ",maxR2=" + std::to_string(maxR2) + ",minDprime=" + std::to_string(minDprime) + ",maxDprime=" + std::to_string(maxDprime)
+	     + ",n_chunks=" + std::to_string(n_chunks) + ",c_chunk=" + std::to_string(c_chunk) + ",n_threads=" + std::to_string(n_threads)
+	     + ",ldd_type=" + std::to_string((int)ldd_load_type) + ",cycle_threshold=" + std::to_string(cycle_threshold);
+}
+
+// ---- implementation ---------------------------------------------------------------------------
+class twk_ld::twk_ld_impl {
+public:
+	uint64_t n_pairs = 0, n_records = 0;
+
+	// per-variant (rid,pos) of the uploaded selection
+	std::vector<uint32_t> rid, pos;
+
+	// output state: one forward and one reverse block (ld_engine.h:321)
+	std::vector<TwoRecord> blk_f, blk_r;
+	TwoWriter writer;
+	uint32_t b_size = 10000;
+	bool write_failed = false;
+	std::vector<twk_hip_record> sort_buf;
+
+	bool flush() { // CompressBlock (ld_engine.cpp:1804-1810): forward, then reverse
+		if (!blk_f.empty()) { if (!writer.write_block(blk_f.data(), (uint32_t)blk_f.size())) return false; blk_f.clear(); }
+		if (!blk_r.empty()) { if (!writer.write_block(blk_r.data(), (uint32_t)blk_r.size())) return false; blk_r.clear(); }
+		return true;
+	}
+
+	bool add(const twk_hip_record& r) {
+		TwoRecord f;
+		f.controller = (uint16_t)r.flags;
+		f.ridA = rid[r.idxA]; f.ridB = rid[r.idxB];
+		f.packA = pos[r.idxA] << 2; f.packB = pos[r.idxB] << 2;
+		std::memcpy(f.cnt, r.cnt, sizeof(f.cnt));
+		f.D = r.D; f.Dprime = r.Dprime; f.R = r.R; f.R2 = r.R2; f.P = r.P;
+		f.ChiSqFisher = r.ChiSqFisher; f.ChiSqModel = r.ChiSqModel;
+		// flush rule of ld_engine.cpp:1270-1281
+		if (!blk_f.empty() && (blk_f.size() == b_size || blk_f.front().ridA != f.ridA || blk_r.front().ridA != f.ridB))
+			if (!flush()) return false;
+		blk_f.push_back(f);
+		TwoRecord v = f;                 // reverse copy swaps (rid,pos) only; cnt is NOT transposed (:1292-1298)
+		std::swap(v.ridA, v.ridB); std::swap(v.packA, v.packB);
+		blk_r.push_back(v);
+		return true;
+	}
+
+	static int sink(void* user, const twk_hip_record* recs, uint64_t n) {
+		auto* self = static_cast<twk_ld_impl*>(user);
+		// Survivors of a tile arrive in device-compaction order; restore (row, col) order so that
+		// the file is deterministic (the reference's order is thread-timing dependent anyway).
+		self->sort_buf.assign(recs, recs + n);
+		std::sort(self->sort_buf.begin(), self->sort_buf.end(), [](const twk_hip_record& a, const twk_hip_record& b) {
+			return a.idxA != b.idxA ? a.idxA < b.idxA : a.idxB < b.idxB;
+		});
+		for (const auto& r : self->sort_buf)
+			if (!self->add(r)) { self->write_failed = true; return 1; }
+		self->n_records += 2 * n;
+		return 0;
+	}
+};
+
+twk_ld::twk_ld() : mImpl(new twk_ld_impl) {}
+twk_ld::~twk_ld() { delete mImpl; }
+uint64_t twk_ld::n_pairs() const { return mImpl->n_pairs; }
+uint64_t twk_ld::n_records() const { return mImpl->n_records; }
+
+bool twk_ld::Compute(const twk_ld_settings& s) { settings = s; return Compute(); }
+bool twk_ld::ComputeSingle(const twk_ld_settings& s, bool verbose, bool progress) { settings = s; return ComputeSingle(verbose, progress); }
+bool twk_ld::ComputePerformance() {
+	std::cerr << stamp("ERROR") << "ComputePerformance is a compile-time debug harness of the CPU reference; not available." << std::endl;
+	return false;
+}
+bool twk_ld::ComputeSingle(bool, bool) {
+	std::cerr << stamp("ERROR") << "scalc (single-site mode) is not implemented by the MI355X engine yet." << std::endl;
+	return false;
+}
+
+namespace {
+struct DeviceCtx {
+	twk_hip_ctx* ctx = nullptr;
+	~DeviceCtx() { if (ctx) twk_hip_ctx_destroy(ctx); }
+};
+bool hip_ok(twk_hip_ctx* ctx, int rc, const char* what) {
+	if (rc == TWK_HIP_OK) return true;
+	std::cerr << stamp("ERROR", "HIP") << what << ": " << twk_hip_strerror(rc);
+	if (ctx && twk_hip_last_error(ctx)[0]) std::cerr << " (" << twk_hip_last_error(ctx) << ")";
+	std::cerr << std::endl;
+	return false;
+}
+}  // namespace
+
+bool twk_ld::Compute() {
+	using clock = std::chrono::steady_clock;
+	mImpl->n_pairs = mImpl->n_records = 0;
+	if (settings.in.empty()) { std::cerr << stamp("ERROR") << "No file-name provided..." << std::endl; return false; }
+	if (settings.window && settings.n_chunks != 1) { std::cerr << stamp("ERROR") << "Cannot use chunking in window mode!" << std::endl; return false; }
+	if (!settings.ival_strings.empty()) { std::cerr << stamp("ERROR") << "Interval slicing (-I) is not implemented by the MI355X engine yet." << std::endl; return false; }
+	if (settings.bitmaps || settings.low_memory)
+		std::cerr << stamp("LOG") << "Note: -m/-M are CPU memory-saving modes; the GPU engine keeps dense bit-planes in HBM." << std::endl;
+
+	std::cerr << stamp("LOG", "READER") << "Opening " << settings.in << "..." << std::endl;
+	TwkReader reader;
+	if (!reader.open(settings.in)) { std::cerr << stamp("ERROR") << "Failed to open file: " << settings.in << "... (" << reader.error << ")" << std::endl; return false; }
+	const uint32_t n_samples = (uint32_t)reader.hdr.samples.size();
+	std::cerr << stamp("LOG") << "Samples: " << pretty(n_samples) << "..." << std::endl;
+	const uint32_t n_blocks = (uint32_t)reader.index.ent.size();
+	if (n_blocks == 0 || n_samples == 0) { std::cerr << stamp("ERROR") << "No valid data available..." << std::endl; return true; }
+
+	if (settings.window) settings.c_chunk = 0;
+	Balancer bal;
+	if (!bal.build(n_blocks, (uint32_t)settings.n_chunks, (uint32_t)settings.c_chunk)) return false;
+	std::cerr << stamp("LOG", "BALANCING") << "Using ranges [" << bal.fromL << "-" << bal.toL << "," << bal.fromR << "-" << bal.toR
+	          << "] in " << (settings.window ? "window mode" : "square mode") << "..." << std::endl;
+
+	// Selected blocks: the L range, then (square chunk only) the R range.
+	std::vector<uint32_t> sel;
+	for (uint32_t b = bal.fromL; b < bal.toL; ++b) sel.push_back(b);
+	uint32_t nL = 0, nR = 0;
+	for (uint32_t b : sel) nL += reader.index.ent[b].n;
+	if (!bal.diag) { for (uint32_t b = bal.fromR; b < bal.toR; ++b) { sel.push_back(b); nR += reader.index.ent[b].n; } }
+	const uint32_t M = nL + nR;
+	std::vector<uint32_t> first(sel.size() + 1, 0);
+	for (size_t k = 0; k < sel.size(); ++k) first[k + 1] = first[k] + reader.index.ent[sel[k]].n;
+	const uint64_t n_cmp = bal.diag ? (uint64_t)M * (M - 1) / 2 : (uint64_t)nL * nR;
+	std::cerr << stamp("LOG") << pretty(M) << " variants from " << pretty(sel.size()) << " blocks..." << std::endl;
+	std::cerr << stamp("LOG", "PARAMS") << settings.GetString() << std::endl;
+	std::cerr << stamp("LOG") << "Performing: " << pretty(n_cmp) << " variant comparisons..." << std::endl;
+
+	// ---- device ----
+	const char* dev_env = std::getenv("TWK_HIP_DEVICE");
+	const int device = dev_env ? std::atoi(dev_env) : 0;
+	if (twk_hip_device_count() <= 0) { std::cerr << stamp("ERROR", "HIP") << "No HIP device available (this build has no CPU path)." << std::endl; return false; }
+	DeviceCtx dc;
+	if (!hip_ok(nullptr, twk_hip_ctx_create(device, &dc.ctx), "twk_hip_ctx_create")) return false;
+	if (!hip_ok(dc.ctx, twk_hip_set_problem(dc.ctx, n_samples, M), "twk_hip_set_problem")) return false;
+
+	// ---- unpack + upload (ld.cpp:370-465, ld_unpacker.h): batches of blocks, T threads per batch ----
+	const auto t_load = clock::now();
+	const size_t w64 = ((size_t)2 * n_samples + 63) / 64;
+	const uint32_t T = (uint32_t)std::max(1, settings.n_threads);
+	mImpl->rid.assign(M, 0); mImpl->pos.assign(M, 0);
+	const size_t batch_bytes = (size_t)512 << 20;
+	std::cerr << stamp("LOG", "THREAD") << "Unpacking using " << T << " threads..." << std::endl;
+	size_t k0 = 0;
+	while (k0 < sel.size()) {
+		size_t k1 = k0; uint32_t nv = 0;
+		while (k1 < sel.size() && (nv == 0 || (size_t)(nv + reader.index.ent[sel[k1]].n) * w64 * 8 <= batch_bytes)) nv += reader.index.ent[sel[k1++]].n;
+		std::vector<uint64_t> data((size_t)nv * w64), mask;
+		std::vector<twk_hip_variant_meta> meta(nv);
+		std::vector<uint8_t> has_mask(k1 - k0, 0);
+		std::atomic<size_t> next(k0);
+		std::atomic<bool> failed(false);
+		// masks are allocated lazily: first pass detects whether any variant in the batch needs one
+		std::vector<Block> blocks(k1 - k0);
+		auto reader_job = [&]() {
+			TwkReader rd;
+			if (!rd.open(settings.in)) { failed = true; return; }
+			for (size_t k = next++; k < k1; k = next++) {
+				Block& blk = blocks[k - k0];
+				if (!rd.read_block(sel[k], blk) || blk.rcds.size() != reader.index.ent[sel[k]].n) { failed = true; return; }
+				for (const auto& v : blk.rcds) if (v.gt_missing) has_mask[k - k0] = 1;
+			}
+		};
+		{
+			std::vector<std::thread> th;
+			for (uint32_t t = 0; t < std::min<uint32_t>(T, (uint32_t)(k1 - k0)); ++t) th.emplace_back(reader_job);
+			for (auto& t : th) t.join();
+		}
+		if (failed) { std::cerr << stamp("ERROR") << "Failed to load blocks " << k0 << "-" << k1 << "!" << std::endl; return false; }
+		const bool any_mask = std::any_of(has_mask.begin(), has_mask.end(), [](uint8_t x) { return x != 0; });
+		if (any_mask) mask.assign((size_t)nv * w64, 0);
+		next = k0;
+		auto build_job = [&]() {
+			for (size_t k = next++; k < k1; k = next++) {
+				const Block& blk = blocks[k - k0];
+				const uint32_t base = first[k] - first[k0];
+				for (size_t i = 0; i < blk.rcds.size(); ++i) {
+					const Variant& v = blk.rcds[i];
+					uint64_t* d = &data[(size_t)(base + i) * w64];
+					uint64_t* m = (any_mask && v.gt_missing) ? &mask[(size_t)(base + i) * w64] : nullptr;
+					if (!v.build_bitvector(n_samples, d, m)) { failed = true; return; }
+					twk_hip_variant_meta& mm = meta[base + i];
+					mm.ac = v.ac; mm.an = v.an; mm.pos = v.pos; mm.rid = v.rid; mm.missing = v.gt_missing ? 1 : 0; mm._pad = 0; mm.hwe = v.hwe;
+				}
+			}
+		};
+		{
+			std::vector<std::thread> th;
+			for (uint32_t t = 0; t < std::min<uint32_t>(T, (uint32_t)(k1 - k0)); ++t) th.emplace_back(build_job);
+			for (auto& t : th) t.join();
+		}
+		if (failed) { std::cerr << stamp("ERROR") << "Corrupt genotype runs in blocks " << k0 << "-" << k1 << "!" << std::endl; return false; }
+		for (uint32_t i = 0; i < nv; ++i) { mImpl->rid[first[k0] + i] = meta[i].rid; mImpl->pos[first[k0] + i] = meta[i].pos; }
+		if (!hip_ok(dc.ctx, twk_hip_upload_bitvectors(dc.ctx, first[k0], nv, data.data(), any_mask ? mask.data() : nullptr, w64, meta.data()),
+		            "twk_hip_upload_bitvectors")) return false;
+		k0 = k1;
+	}
+	std::cerr << stamp("LOG") << "Unpacked and uploaded " << pretty(M) << " variants. "
+	          << elapsed_string(std::chrono::duration<double>(clock::now() - t_load).count()) << std::endl;
+
+	// ---- output file (ld.cpp:583-618) ----
+	std::string out = settings.out;
+	if (out.empty() || out == "-") {
+		std::cerr << stamp("LOG", "WRITER") << "Writing to stdout..." << std::endl;
+		out = "-";
+	} else {
+		const std::string ext = extension(out);
+		if (!(ext.size() == 3 && strncasecmp(ext.c_str(), "two", 3) == 0)) {
+			const std::string bp = base_path(out);
+			out = (bp.size() ? bp + "/" : "") + base_name(out) + ".two";
+		}
+		std::cerr << stamp("LOG", "WRITER") << "Opening " << out << "..." << std::endl;
+	}
+	Header hdr = reader.hdr;
+	hdr.literals += "\n##tomahawk_calcVersion=" + std::string(TWK_AMD_VERSION) + "\n";
+	hdr.literals += "##tomahawk_calcCommand=" + command_line() + "; Date=" + datetime() + "\n";
+	if (!mImpl->writer.open(out, hdr, settings.c_level)) { std::cerr << stamp("ERROR", "WRITER") << "Failed to open file: " << out << "..." << std::endl; return false; }
+	mImpl->b_size = (uint32_t)std::max(2, settings.b_size);
+	mImpl->blk_f.clear(); mImpl->blk_r.clear(); mImpl->write_failed = false;
+
+	// ---- compute ----
+	const int mode = settings.force_phased ? TWK_HIP_MODE_PHASED : (settings.forced_unphased ? TWK_HIP_MODE_UNPHASED : TWK_HIP_MODE_AUTO);
+	twk_hip_filters f{settings.minR2, settings.maxR2, settings.minDprime, settings.maxDprime, settings.minP};
+	const auto t0 = clock::now();
+	uint64_t np = 0, nr = 0;
+	int rc;
+	if (bal.diag)
+		rc = twk_hip_ld_region(dc.ctx, mode, &f, 0, M, 0, M, 1, 0, 1, 0, settings.window ? 1 : 0, (uint32_t)settings.l_window,
+		                       twk_ld_impl::sink, mImpl, &np, &nr);
+	else
+		rc = twk_hip_ld_region(dc.ctx, mode, &f, 0, nL, nL, nR, 0, 0, 1, 0, settings.window ? 1 : 0, (uint32_t)settings.l_window,
+		                       twk_ld_impl::sink, mImpl, &np, &nr);
+	if (mImpl->write_failed) { std::cerr << stamp("ERROR", "WRITER") << "Failed to write output block!" << std::endl; return false; }
+	if (!hip_ok(dc.ctx, rc, "twk_hip_ld_region")) return false;
+	mImpl->n_pairs = np;
+	if (!mImpl->flush()) { std::cerr << stamp("ERROR", "WRITER") << "Failed to write output block!" << std::endl; return false; }
+	const double sec = std::chrono::duration<double>(clock::now() - t0).count();
+	// ld_progress.h:89-96
+	std::cerr << stamp("PROGRESS") << "Finished in " << elapsed_string(sec) << ". Variants: " << pretty(np) << ", genotypes: "
+	          << pretty(np * n_samples) << ", output: " << pretty(mImpl->n_records) << std::endl;
+	std::cerr << stamp("PROGRESS") << pretty((uint64_t)(np / std::max(sec, 1e-9))) << " variants/s and "
+	          << pretty((uint64_t)((double)np * n_samples / std::max(sec, 1e-9))) << " genotypes/s" << std::endl;
+	twk_hip_timing tm;
+	if (twk_hip_timing_get(dc.ctx, &tm) == TWK_HIP_OK)
+		std::cerr << stamp("LOG", "HIP") << "count kernel " << tm.count_ms << " ms in " << tm.count_launches << " launches, math kernel "
+		          << tm.stats_ms << " ms" << std::endl;
+	if (!mImpl->writer.close()) { std::cerr << stamp("ERROR", "WRITER") << "Failed to write final block!" << std::endl; return false; }
+	std::cerr << stamp("LOG", "PROGRESS") << "All done..." << elapsed_string(std::chrono::duration<double>(clock::now() - t_load).count()) << "!" << std::endl;
+	return true;
+}
+
+}  // namespace tomahawk
