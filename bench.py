@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""Headline benchmark: all-vs-all pairwise LD, variant pairs per second (BASELINE.json).
+
+    python bench.py --gpus 1 --steps 2 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (config.workload): BASELINE.json configs[2] -- 1,000,000 diploid samples x 50,000 biallelic
+variants, all-vs-all *unphased* genotype LD (`calc -u`, default filters r2 >= 0.1), synthetic iid
+genotypes generated directly in HBM (bit-identical host twin feeds the CPU baseline).
+A step is one pass over the whole upper triangle: 1,249,975,000 variant pairs.  With N GPUs the
+triangle is cut into equal-area row bands, one per rank (no data-path collective), survivors are
+gathered to rank 0 over RCCL inside the timed region, and `value` is total pairs / max-over-ranks
+time: total work is fixed, so "scaling" is "strong".
+
+The JSON line also carries
+  roofline     the dominant kernel (k_count_tile), timed live with HIP events on the engine's own
+               stream: achieved = variant pairs of the launches x N/4 bytes per pair (one partner
+               bitvector) / kernel time, against the 8 TB/s HBM peak.  The kernel tiles
+               128 x 128 plane rows through LDS, so a streamed row is reused 128x and `frac` exceeds
+               1: the binding limit is VALU issue (v_and_b32 + v_bcnt_u32_b32), reported under "valu".
+  cpu_baseline the compiled reference (oracle/_ref, SSE4.2) on this box's host cores, on the first
+               M_s variants of the same synthetic input (rank 0, N=1 only).
+"""
+import argparse
+import ctypes
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: (n_samples, n_variants, mode)
+    "cfg3": (1_000_000, 50_000, "unphased"),   # BASELINE.json configs[2]: the metric's workload
+    "cfg2": (100_000, 10_000, "phased"),       # configs[1]
+    "cfg1": (1_000, 1_000, "unphased"),        # configs[0] (plumbing size)
+}
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
+VALU_PAIR_PEAK = 256 * 4 * 64 / 6.0 * 2.4e9   # and(2 cyc)+bcnt(4 cyc) per wave64 word pair, 2.4 GHz
+
+
+def cpu_baseline(n_samples, mode, seed, log):
+    """Time the reference's SSE4.2 calc path (oracle/_ref) on a bounded sample of the same workload."""
+    from oracle import oracle as O
+    from tests import hostlib
+    cores = os.cpu_count() or 1
+    if not O.have_ref():
+        return None
+    # ~15 s of CPU work: SURVEY 6: 5.4 G (unphased) / 52 G (phased) genotype-pairs/s/core
+    per_core = (5.4e9 if mode == "unphased" else 52e9) / n_samples
+    pairs_target = per_core * cores * 15.0
+    m = int(min(1500, max(200, (2 * pairs_target) ** 0.5)))
+    block = max(10, min(50, m // (4 * min(cores, 32)) or 10))
+    twk = os.path.join(tempfile.gettempdir(), f"twk_bench_{n_samples}_{m}_{seed}_{mode}.twk")
+    if not os.path.exists(twk):
+        t0 = time.time()
+        hostlib.write_synthetic_twk(twk + ".tmp", n_samples, m, seed=seed, phased=(mode == "phased"),
+                                    block_size=block, n_threads=min(cores, 32))
+        os.replace(twk + ".tmp", twk)
+        log(f"cpu_baseline: wrote {twk} ({os.path.getsize(twk) / 1e6:.1f} MB) in {time.time() - t0:.1f}s")
+    out = os.path.join(tempfile.gettempdir(), f"twk_bench_{os.getpid()}.two")
+    flag = "-u" if mode == "unphased" else "-p"
+    t0 = time.time()
+    r = subprocess.run([O.REF_BIN, "calc", "-i", twk, "-o", out, flag, "-t", str(cores)], capture_output=True, text=True)
+    wall = time.time() - t0
+    try:
+        os.remove(out)
+    except OSError:
+        pass
+    if r.returncode != 0:
+        log("cpu_baseline: reference failed: " + r.stderr[-300:])
+        return None
+    pairs = m * (m - 1) // 2
+    rate = None
+    mo = re.search(r"\] ([0-9,]+) variants/s", r.stderr)     # ld_progress.h:94 ("variants" = pairs)
+    if mo:
+        rate = float(mo.group(1).replace(",", ""))
+    if not rate:
+        rate = pairs / wall
+    return {"value": rate, "unit": "variant-pairs/s", "cores": cores, "kind": "reference",
+            "sample": f"first {m} variants of the same synthetic input ({pairs} pairs, N={n_samples}, calc {flag} "
+                      f"-t {cores}, {block} variants/block, SSE4.2 build of the reference, {wall:.1f}s wall)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
+    ap.add_argument("--variants", type=int, default=0, help="override the number of variants (debug)")
+    ap.add_argument("--tile", type=int, default=0, help="super-tile edge in variants (0 = engine default)")
+    ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import numpy as np
+    import tomahawk_amd as T
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        sys.exit(2)
+
+    def log(msg):
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+    if not torch.cuda.is_available() or T.device_count() < 1:
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    n_samples, n_variants, mode = CONFIGS[args.config]
+    if args.variants:
+        n_variants = args.variants
+    hip_mode = T.MODE_UNPHASED if mode == "unphased" else T.MODE_PHASED
+    filters = T.Filters()                      # reference defaults: r2 >= 0.1, P <= 1
+
+    eng = T.HipLd(local_rank)
+    t0 = time.time()
+    eng.set_problem(n_samples, n_variants)
+    eng.generate_synthetic(args.seed)          # every rank generates the same bits in its own HBM
+    torch.cuda.synchronize()
+    log(f"{args.config}: N={n_samples} M={n_variants} {mode}; input resident in HBM after {time.time() - t0:.1f}s")
+
+    total_pairs = n_variants * (n_variants - 1) // 2
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        """One pass of the hot path over this rank's shard + the gather of survivors to rank 0."""
+        recs, npairs, nrec = eng.ld_all(hip_mode, filters, part=rank, n_parts=world, tile_variants=args.tile)
+        if world > 1:
+            cnt = torch.tensor([nrec], dtype=torch.int64, device=dev)
+            counts = [torch.zeros_like(cnt) for _ in range(world)]
+            dist.all_gather(counts, cnt)
+            maxc = max(int(c.item()) for c in counts)
+            if maxc:
+                payload = torch.zeros(maxc * T.RECORD_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+                if nrec:
+                    payload[: nrec * T.RECORD_DTYPE.itemsize] = torch.from_numpy(recs.view(np.uint8).reshape(-1)).to(dev)
+                gl = [torch.empty_like(payload) for _ in range(world)] if rank == 0 else None
+                dist.gather(payload, gl, dst=0)
+        return npairs, nrec
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    eng.timing_reset()
+    t0 = time.perf_counter()
+    my_pairs = my_recs = 0
+    for _ in range(args.steps):
+        p, r = step()
+        my_pairs += p
+        my_recs += r
+    barrier()
+    elapsed = time.perf_counter() - t0
+    tm = eng.timing()
+
+    stats = torch.tensor([elapsed, tm["count_ms"], tm["stats_ms"]], dtype=torch.float64, device=dev)
+    sums = torch.tensor([my_pairs, my_recs, tm["count_launches"], tm["row_pairs"]], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(stats, op=dist.ReduceOp.MAX)
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+    elapsed_max, count_ms_max, stats_ms_max = (float(x) for x in stats.tolist())
+    pairs_all, recs_all, launches_all, row_pairs_all = (float(x) for x in sums.tolist())
+    assert int(round(pairs_all)) == total_pairs * args.steps, (pairs_all, total_pairs * args.steps)
+
+    if rank == 0:
+        value = pairs_all / elapsed_max
+        bytes_per_pair = n_samples / 4.0                    # one partner bitvector: 8*ceil(2N/64) = N/4 bytes
+        # dominant kernel on rank 0: its own launches, its own HIP-event time
+        k_pairs = my_pairs
+        k_ms = tm["count_ms"]
+        achieved = k_pairs * bytes_per_pair / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        words = tm["words_per_row"]
+        word_pairs_per_s = tm["row_pairs"] * words / (k_ms * 1e-3) if k_ms > 0 else 0.0
+        out = {
+            "metric": "variant-pairs/sec all-vs-all LD, 1M samples; achieved HBM GB/s vs roofline",
+            "value": value, "unit": "variant-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[2]: {n_samples} samples x {n_variants} variants, all-vs-all "
+                                   f"{mode} genotype LD (calc {'-u' if mode == 'unphased' else '-p'}, r2>=0.1), "
+                                   f"{total_pairs} pairs/step",
+                       "n_samples": n_samples, "n_variants": n_variants, "mode": mode, "tile_variants": args.tile,
+                       "partition": f"equal-area row bands of the pair triangle over {world} GPU(s), RCCL gather of survivors",
+                       "survivors_per_step": recs_all / args.steps},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "twk::k_count_tile", "launches": int(tm["count_launches"]),
+                         "avg_launch_ms": k_ms / max(tm["count_launches"], 1),
+                         "algorithmic_bytes_per_pair": bytes_per_pair,
+                         "note": "algorithmic bytes = one partner bitvector per pair (SURVEY 8(d)); rows are reused "
+                                 "128x from LDS so frac > 1; real limit is VALU issue, see valu"},
+            "valu": {"word_pairs_per_s": word_pairs_per_s, "peak_word_pairs_per_s": VALU_PAIR_PEAK,
+                     "frac": word_pairs_per_s / VALU_PAIR_PEAK, "words_per_row": int(words),
+                     "note": "32-bit AND+popcount word pairs; peak = 256 CU x 4 SIMD x 64 lanes / 6 cycles x 2.4 GHz "
+                             "(v_and_b32 2 cycles + v_bcnt_u32_b32 4 cycles per wave64)"},
+            "kernel_ms": {"count": count_ms_max, "math": stats_ms_max, "wall": elapsed_max * 1e3},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                cb = cpu_baseline(n_samples, mode, args.seed, log)
+            except Exception as e:  # the baseline must never take the GPU number down with it
+                log(f"cpu_baseline failed: {e!r}")
+                cb = None
+            if cb:
+                out["cpu_baseline"] = cb
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

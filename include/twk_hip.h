@@ -150,8 +150,10 @@ int twk_hip_ld_tile(twk_hip_ctx* ctx, int mode, const twk_hip_tile_desc* tile,
                     uint64_t* n_out, uint64_t* n_pairs);
 
 /* All-vs-all LD over the upper triangle, restricted to shard `part` of
- * `n_parts` (static cost-balanced assignment of super-tiles; replaces
- * twk_ld_balancer::Build, ld_balancing.h:23-80, for multi-GPU sharding).
+ * `n_parts`: shard k is the contiguous band of rows that holds the k-th n_parts-th
+ * of the pairs (equal-area bands of the triangle, boundaries on multiples of 64
+ * variants; every rank derives the same partition without communication).  This
+ * replaces twk_ld_balancer::Build (ld_balancing.h:23-80) for multi-GPU sharding.
  * tile_variants = edge of a super-tile in variants (0 = choose).  Survivors
  * are handed to `sink` (may be NULL to discard) tile by tile on the calling
  * thread.  *n_pairs / *n_records (may be NULL) receive totals for this shard. */

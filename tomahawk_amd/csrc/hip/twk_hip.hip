@@ -590,50 +590,55 @@ int twk_hip_ld_region(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint32
 	if (nA == 0 || nB == 0 || (uint64_t)a0 + nA > c->M || (uint64_t)b0 + nB > c->M) return TWK_HIP_E_INVALID;
 	if (triangle && (a0 != b0 || nA != nB)) return TWK_HIP_E_INVALID;
 	HIPCHK(c, hipSetDevice(c->device));
-	// Super-tile edge: multiple of 128 variants; default aims at >= 16 tiles per shard.
-	uint32_t S = tile_variants;
-	const uint32_t span = std::max(nA, nB);
-	if (S == 0) {
-		S = 8192;
-		while (S > 1024) {
-			const uint64_t na = (nA + S - 1) / S, nb_ = (nB + S - 1) / S;
-			const uint64_t ntiles = triangle ? na * (na + 1) / 2 : na * nb_;
-			if (ntiles >= 16ull * n_parts) break;
-			S /= 2;
-		}
-	}
-	S = round_up(std::min(S, round_up(span, TILE)), TILE);
-	const uint32_t nba = (nA + S - 1) / S, nbb = (nB + S - 1) / S;
+	// ---- shard: a contiguous band of rows holding 1/n_parts of the region's pairs ----------
+	// Row i of a triangle has nA-1-i pairs, of a rectangle nB.  Equal-area bands, boundaries
+	// on multiples of 64 variants, derived identically (and without communication) by every rank.
+	// Replaces the reference's square-chunk farm partition (ld_balancing.h:59-78) for GPUs.
+	auto pairs_before = [&](uint64_t r) -> uint64_t {     // pairs in rows [0, r)
+		return triangle ? r * (uint64_t)nA - r * (r + 1) / 2 : r * (uint64_t)nB;
+	};
+	const uint64_t region_pairs = pairs_before(triangle ? nA : nA);
+	auto boundary = [&](uint32_t k) -> uint32_t {
+		if (k == 0) return 0;
+		if (k >= n_parts) return nA;
+		const long double target = (long double)region_pairs * k / n_parts;
+		uint32_t lo = 0, hi = nA;
+		while (lo < hi) { const uint32_t mid = lo + (hi - lo) / 2; if ((long double)pairs_before(mid) < target) lo = mid + 1; else hi = mid; }
+		return std::min(nA, (lo + 32) / 64 * 64);
+	};
+	const uint32_t r0 = boundary(part), r1 = boundary(part + 1);
 
-	// Static cost-balanced assignment: walk the region, give each tile to the
-	// currently lightest shard (diagonal tiles cost half).  Deterministic, so
-	// every rank derives the same partition without talking to the others.
+	// ---- super-tiles of the band --------------------------------------------------------------
+	// Edge S in variants (multiple of 128).  Default: ~16384 plane rows per tile edge so that a
+	// launch holds >= 16 rounds of resident blocks and the partial last round costs < 3 %.
+	const bool two_pass_auto = (mode == TWK_HIP_MODE_AUTO) && c->any_missing;
+	const int Pmax = two_pass_auto ? 3 : planes_per_variant(plane_kind_for(c, mode == TWK_HIP_MODE_PHASED || (mode == TWK_HIP_MODE_AUTO && !c->any_missing)));
+	uint32_t S = tile_variants ? tile_variants : (16384u / (uint32_t)Pmax);
+	S = std::max<uint32_t>(TILE, std::min<uint32_t>(S / TILE * TILE, 32768u));
+	S = std::min(S, round_up(std::max(nA, nB), TILE));
+
 	std::vector<twk_hip_tile_desc> mine;
-	{
-		std::vector<uint64_t> load(n_parts, 0);
-		for (uint32_t bi = 0; bi < nba; ++bi) {
-			for (uint32_t bj = triangle ? bi : 0; bj < nbb; ++bj) {
-				twk_hip_tile_desc t{};
-				t.rowA0 = a0 + bi * S; t.nA = std::min(S, nA - bi * S);
-				t.rowB0 = b0 + bj * S; t.nB = std::min(S, nB - bj * S);
-				t.diag = (triangle && bi == bj); t.window = window; t.l_window = l_window;
-				if (window && !t.diag) {
-					// Inputs are sorted by (rid, pos) like every .twk: if both tiles lie on one
-					// contig and the gap between them exceeds the window, no pair can qualify
-					// (the reference's ticker skips the rest of the row, ld_balancing.h:191).
-					const twk_hip_variant_meta& firstA = c->h_meta[t.rowA0];
-					const twk_hip_variant_meta& lastA  = c->h_meta[t.rowA0 + t.nA - 1];
-					const twk_hip_variant_meta& firstB = c->h_meta[t.rowB0];
-					const twk_hip_variant_meta& lastB  = c->h_meta[t.rowB0 + t.nB - 1];
-					if (firstA.rid == lastB.rid && firstB.pos > lastA.pos && firstB.pos - lastA.pos > l_window) continue;
-					if (firstA.rid == lastA.rid && firstB.rid == lastB.rid && firstA.rid != firstB.rid) continue;
-				}
-				const uint64_t cost = pairs_in_tile(c, t);
-				const uint32_t who = (uint32_t)(std::min_element(load.begin(), load.end()) - load.begin());
-				load[who] += cost;
-				if (who == part) mine.push_back(t);
-			}
+	auto push_tile = [&](uint32_t ra, uint32_t na, uint32_t cb, uint32_t nb_, int diag) {
+		twk_hip_tile_desc t{};
+		t.rowA0 = a0 + ra; t.nA = na; t.rowB0 = b0 + cb; t.nB = nb_; t.diag = diag; t.window = window; t.l_window = l_window;
+		if (window && !diag) {
+			// Inputs are sorted by (rid, pos) like every .twk: if both tiles lie on one contig and
+			// the gap between them exceeds the window, no pair can qualify (the reference's ticker
+			// skips the rest of the row, ld_balancing.h:191).
+			const twk_hip_variant_meta& firstA = c->h_meta[t.rowA0];
+			const twk_hip_variant_meta& lastA  = c->h_meta[t.rowA0 + t.nA - 1];
+			const twk_hip_variant_meta& firstB = c->h_meta[t.rowB0];
+			const twk_hip_variant_meta& lastB  = c->h_meta[t.rowB0 + t.nB - 1];
+			if (firstA.rid == lastB.rid && firstB.pos > lastA.pos && firstB.pos - lastA.pos > l_window) return;
+			if (firstA.rid == lastA.rid && firstB.rid == lastB.rid && firstA.rid != firstB.rid) return;
 		}
+		mine.push_back(t);
+	};
+	for (uint32_t x = r0; x < r1; x += S) {
+		const uint32_t h = std::min(S, r1 - x);
+		uint32_t col = 0;
+		if (triangle) { push_tile(x, h, x, h, 1); col = x + h; }     // aligned square on the diagonal
+		for (; col < nB; col += S) push_tile(x, h, col, std::min(S, nB - col), 0);
 	}
 
 	uint64_t tot_pairs = 0, tot_recs = 0;
