@@ -104,6 +104,7 @@ def main():
     import torch.distributed as dist
     import numpy as np
     import tomahawk_amd as T
+    from tomahawk_amd.dist import gather_records
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -150,16 +151,7 @@ def main():
         """One pass of the hot path over this rank's shard + the gather of survivors to rank 0."""
         recs, npairs, nrec = eng.ld_all(hip_mode, filters, part=rank, n_parts=world, tile_variants=args.tile)
         if world > 1:
-            cnt = torch.tensor([nrec], dtype=torch.int64, device=dev)
-            counts = [torch.zeros_like(cnt) for _ in range(world)]
-            dist.all_gather(counts, cnt)
-            maxc = max(int(c.item()) for c in counts)
-            if maxc:
-                payload = torch.zeros(maxc * T.RECORD_DTYPE.itemsize, dtype=torch.uint8, device=dev)
-                if nrec:
-                    payload[: nrec * T.RECORD_DTYPE.itemsize] = torch.from_numpy(recs.view(np.uint8).reshape(-1)).to(dev)
-                gl = [torch.empty_like(payload) for _ in range(world)] if rank == 0 else None
-                dist.gather(payload, gl, dst=0)
+            gather_records(recs, dst=0, device=dev)      # RCCL: all_gather(counts) + gather(payload)
         return npairs, nrec
 
     for _ in range(args.warmup):
@@ -194,6 +186,18 @@ def main():
         achieved = k_pairs * bytes_per_pair / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         words = tm["words_per_row"]
         word_pairs_per_s = tm["row_pairs"] * words / (k_ms * 1e-3) if k_ms > 0 else 0.0
+        # HBM bytes per launch: PMC-measured bytes per plane-row pair (profiles/r*_pmc_hbm_traffic.json,
+        # FETCH_SIZE x2-corrected per MI355X_MICROARCH.md + WRITE_SIZE) x the row pairs of a launch.
+        traffic, traffic_src = None, None
+        try:
+            pm = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_hbm_traffic.json"))
+            if pm and n_samples == 1_000_000 and mode == "unphased" and tm["count_launches"]:
+                k = json.load(open(os.path.join(ROOT, "profiles", pm[-1])))["k_count_tile"]
+                per_rp = k["hbm_read_bytes_per_row_pair"] + k["write_bytes_per_launch"] * k["launches"] / k["plane_row_pairs"]
+                traffic = per_rp * tm["row_pairs"] / tm["count_launches"]
+                traffic_src = f"profiles/{pm[-1]} (rocprofv3 --pmc, separate pass; scaled by plane-row pairs per launch)"
+        except Exception:
+            pass
         out = {
             "metric": "variant-pairs/sec all-vs-all LD, 1M samples; achieved HBM GB/s vs roofline",
             "value": value, "unit": "variant-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -206,7 +210,7 @@ def main():
                        "partition": f"equal-area row bands of the pair triangle over {world} GPU(s), RCCL gather of survivors",
                        "survivors_per_step": recs_all / args.steps},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "twk::k_count_tile", "launches": int(tm["count_launches"]),
                          "avg_launch_ms": k_ms / max(tm["count_launches"], 1),
                          "algorithmic_bytes_per_pair": bytes_per_pair,

@@ -172,6 +172,13 @@ int twk_hip_ld_region(twk_hip_ctx* ctx, int mode, const twk_hip_filters* filters
                       int32_t window, uint32_t l_window,
                       twk_hip_record_sink sink, void* user, uint64_t* n_pairs, uint64_t* n_records);
 
+/* The row band [row_begin,row_end) that shard `part` of `n_parts` owns in a region of
+ * n_rows x n_cols variants (triangle != 0: col > row only, n_rows == n_cols) and the
+ * number of pairs in it.  Pure host arithmetic (no device needed): lets a launcher
+ * or a test derive the multi-GPU partition that twk_hip_ld_all/ld_region use. */
+int twk_hip_shard_rows(uint32_t n_rows, uint32_t n_cols, int32_t triangle, uint32_t part, uint32_t n_parts,
+                       uint32_t* row_begin, uint32_t* row_end, uint64_t* n_pairs);
+
 /* ---- measurement ------------------------------------------------------ */
 /* Cumulative device time (HIP events on the engine's own stream) and launch
  * count of the dominant kernel (count-tile) and of the math kernel since the

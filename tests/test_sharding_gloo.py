@@ -1,0 +1,97 @@
+"""The N > 1 path on CPU: the row-band partition (host arithmetic of the C ABI) and the gather of
+survivor records over torch.distributed with the gloo backend, world size 2."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import tomahawk_amd as T
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("M", [1, 64, 700, 50_000, 200_000])
+@pytest.mark.parametrize("n_parts", [1, 2, 3, 8])
+def test_bands_partition_the_triangle(M, n_parts):
+    total = M * (M - 1) // 2
+    prev_end, pairs = 0, []
+    for k in range(n_parts):
+        r0, r1, n = T.shard_rows(M, k, n_parts)
+        assert r0 == prev_end and r0 <= r1 <= M
+        assert n == sum(M - 1 - i for i in range(r0, r1)) if M <= 700 else n >= 0
+        prev_end = r1
+        pairs.append(n)
+    assert prev_end == M and sum(pairs) == total
+    if M >= 50_000:
+        assert max(pairs) <= 1.02 * total / n_parts          # balanced to 2 % at the headline size
+        assert all(r % 64 == 0 for r in [T.shard_rows(M, k, n_parts)[0] for k in range(n_parts)])
+
+
+def test_rectangle_bands():
+    spans = [T.shard_rows(1000, k, 4, n_cols=333, triangle=False) for k in range(4)]
+    assert spans[0][0] == 0 and spans[-1][1] == 1000 and sum(s[2] for s in spans) == 333_000
+    with pytest.raises(T.HipError):
+        T.shard_rows(10, 3, 3)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, M, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tomahawk_amd.dist import gather_records
+    r0, r1, n = T.shard_rows(M, rank, world)
+    # stand-in survivors: every 7th pair of this rank's band (no device in this test)
+    recs = np.zeros(0, dtype=T.RECORD_DTYPE)
+    ij = [(i, j) for i in range(r0, r1) for j in range(i + 1, M)][::7]
+    if rank == 1:
+        ij = ij[:5]                                         # ragged: very different counts per rank
+    recs = np.zeros(len(ij), dtype=T.RECORD_DTYPE)
+    recs["idxA"] = [p[0] for p in ij]; recs["idxB"] = [p[1] for p in ij]
+    recs["R2"] = recs["idxA"] * 1e-3 + recs["idxB"] * 1e-6
+    got = gather_records(recs, dst=0)
+    empty = gather_records(np.zeros(0, dtype=T.RECORD_DTYPE), dst=0)
+    if rank == 0:
+        q.put((got["idxA"].tolist(), got["idxB"].tolist(), got["R2"].tolist(), len(empty), (r0, r1, n)))
+    else:
+        assert got is None and empty is None
+        q.put((len(ij), (r0, r1, n)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_records_world2_gloo():
+    M, world = 300, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, M, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    root = next(o for o in outs if len(o) == 5)
+    other = next(o for o in outs if len(o) == 2)
+    idxA, idxB, r2, n_empty, band0 = root
+    n1, band1 = other
+    assert n_empty == 0 and n1 == 5
+    assert band0[1] == band1[0] and band0[2] + band1[2] == M * (M - 1) // 2
+    # rank order is preserved; rank 0's records all lie in its band, rank 1's in the other
+    n0 = len(idxA) - n1
+    assert all(band0[0] <= a < band0[1] for a in idxA[:n0]) and all(band1[0] <= a < band1[1] for a in idxA[n0:])
+    assert all(a < b for a, b in zip(idxA, idxB))
+    np.testing.assert_allclose(r2, np.array(idxA) * 1e-3 + np.array(idxB) * 1e-6)

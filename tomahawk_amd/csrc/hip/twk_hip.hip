@@ -321,6 +321,23 @@ int redo_tile_in_strips(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, co
 	return TWK_HIP_OK;
 }
 
+// Rows [0, r) of a triangle of n rows hold r*n - r(r+1)/2 pairs; of an n x m rectangle r*m.
+uint64_t band_pairs_before(uint64_t r, uint64_t nA, uint64_t nB, bool triangle) {
+	return triangle ? r * nA - r * (r + 1) / 2 : r * nB;
+}
+// First row of shard k: equal-area bands, boundaries on multiples of 64 variants.
+uint32_t band_boundary(uint32_t k, uint32_t n_parts, uint32_t nA, uint32_t nB, bool triangle) {
+	if (k == 0) return 0;
+	if (k >= n_parts) return nA;
+	const long double target = (long double)band_pairs_before(nA, nA, nB, triangle) * k / n_parts;
+	uint32_t lo = 0, hi = nA;
+	while (lo < hi) {
+		const uint32_t mid = lo + (hi - lo) / 2;
+		if ((long double)band_pairs_before(mid, nA, nB, triangle) < target) lo = mid + 1; else hi = mid;
+	}
+	return std::min(nA, (lo + 32) / 64 * 64);
+}
+
 bool valid_mode(int m) { return m == TWK_HIP_MODE_PHASED || m == TWK_HIP_MODE_UNPHASED || m == TWK_HIP_MODE_AUTO; }
 bool valid_tile(const twk_hip_ctx* c, const twk_hip_tile_desc* t) {
 	if (!t || t->nA == 0 || t->nB == 0 || t->nA > 32768 || t->nB > 32768) return false;
@@ -594,19 +611,7 @@ int twk_hip_ld_region(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint32
 	// Row i of a triangle has nA-1-i pairs, of a rectangle nB.  Equal-area bands, boundaries
 	// on multiples of 64 variants, derived identically (and without communication) by every rank.
 	// Replaces the reference's square-chunk farm partition (ld_balancing.h:59-78) for GPUs.
-	auto pairs_before = [&](uint64_t r) -> uint64_t {     // pairs in rows [0, r)
-		return triangle ? r * (uint64_t)nA - r * (r + 1) / 2 : r * (uint64_t)nB;
-	};
-	const uint64_t region_pairs = pairs_before(triangle ? nA : nA);
-	auto boundary = [&](uint32_t k) -> uint32_t {
-		if (k == 0) return 0;
-		if (k >= n_parts) return nA;
-		const long double target = (long double)region_pairs * k / n_parts;
-		uint32_t lo = 0, hi = nA;
-		while (lo < hi) { const uint32_t mid = lo + (hi - lo) / 2; if ((long double)pairs_before(mid) < target) lo = mid + 1; else hi = mid; }
-		return std::min(nA, (lo + 32) / 64 * 64);
-	};
-	const uint32_t r0 = boundary(part), r1 = boundary(part + 1);
+	const uint32_t r0 = band_boundary(part, n_parts, nA, nB, triangle != 0), r1 = band_boundary(part + 1, n_parts, nA, nB, triangle != 0);
 
 	// ---- super-tiles of the band --------------------------------------------------------------
 	// Edge S in variants (multiple of 128).  Default: ~16384 plane rows per tile edge so that a
@@ -673,6 +678,17 @@ int twk_hip_ld_region(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint32
 	}
 	if (n_pairs) *n_pairs = tot_pairs;
 	if (n_records) *n_records = tot_recs;
+	return TWK_HIP_OK;
+}
+
+int twk_hip_shard_rows(uint32_t n_rows, uint32_t n_cols, int32_t triangle, uint32_t part, uint32_t n_parts,
+                       uint32_t* row_begin, uint32_t* row_end, uint64_t* n_pairs) {
+	if (n_parts == 0 || part >= n_parts || n_rows == 0 || n_cols == 0 || (triangle && n_rows != n_cols)) return TWK_HIP_E_INVALID;
+	const uint32_t r0 = band_boundary(part, n_parts, n_rows, n_cols, triangle != 0);
+	const uint32_t r1 = band_boundary(part + 1, n_parts, n_rows, n_cols, triangle != 0);
+	if (row_begin) *row_begin = r0;
+	if (row_end) *row_end = r1;
+	if (n_pairs) *n_pairs = band_pairs_before(r1, n_rows, n_cols, triangle != 0) - band_pairs_before(r0, n_rows, n_cols, triangle != 0);
 	return TWK_HIP_OK;
 }
 

@@ -96,6 +96,8 @@ def load_library() -> C.CDLL:
                                     C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.twk_hip_ld_all.argtypes = [p, C.c_int, C.POINTER(_Filters), C.c_uint32, C.c_uint32, C.c_uint32,
                                    C.c_int32, C.c_uint32, _SINK, p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.twk_hip_shard_rows.argtypes = [C.c_uint32, C.c_uint32, C.c_int32, C.c_uint32, C.c_uint32,
+                                       C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
     lib.twk_hip_timing_reset.argtypes = [p]
     lib.twk_hip_timing_get.argtypes = [p, C.POINTER(_Timing)]
     _lib = lib
@@ -104,6 +106,16 @@ def load_library() -> C.CDLL:
 
 def device_count() -> int:
     return load_library().twk_hip_device_count()
+
+
+def shard_rows(n_variants: int, part: int, n_parts: int, n_cols: int | None = None, triangle: bool = True):
+    """Row band [r0, r1) and pair count of shard `part` (the partition ld_all uses). Host-only."""
+    r0, r1, n = C.c_uint32(), C.c_uint32(), C.c_uint64()
+    rc = load_library().twk_hip_shard_rows(n_variants, n_variants if n_cols is None else n_cols, int(triangle), part,
+                                           n_parts, C.byref(r0), C.byref(r1), C.byref(n))
+    if rc != 0:
+        raise HipError(rc, "twk_hip_shard_rows")
+    return r0.value, r1.value, n.value
 
 
 def words64(n_samples: int) -> int:
