@@ -34,6 +34,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef TWK_EXP
+#define TWK_EXP 0
+#endif
 namespace twk {
 
 constexpr int TILE = 128;       // rows per block tile edge
@@ -83,47 +86,77 @@ __device__ __forceinline__ void stage_rows(const uint32_t* __restrict__ rows, si
 // (b) serialises everything through one temporary, so every instruction waits
 // for the previous one.  The asm block pins the accumulate form and issues the
 // 8 ANDs, then the 8 BCNTs: every dependent pair is 8 issue slots apart.
-__device__ __forceinline__ void and_bcnt8(uint32_t (&acc)[8][8], int u, uint32_t a0, uint32_t a1,
+__device__ __forceinline__ void and_bcnt8(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t& c4,
+                                          uint32_t& c5, uint32_t& c6, uint32_t& c7, uint32_t a0, uint32_t a1,
                                           uint32_t a2, uint32_t a3, uint32_t a4, uint32_t a5,
                                           uint32_t a6, uint32_t a7, uint32_t b) {
 	uint32_t t0, t1, t2, t3, t4, t5, t6, t7;
+	// gfx950 issue quirk (csrc/tools/issue_test2.hip): a v_bcnt_u32_b32 issued directly
+	// behind another VALU op of the same wave costs 6 cycles instead of 4 (and+bcnt streams run
+	// at 1.84e13 word pairs/s); with a non-VALU instruction in the slot before it the pair costs
+	// the ideal 2 + 4 cycles (2.52e13).  The s_nop itself is free: the SIMD issues another
+	// wave's VALU op in that slot.  Order used: 2 ANDs, then (s_nop, BCNT) x 2 -- pattern O of the tool.
 	asm("v_and_b32 %8, %16, %24\n\t"
 	    "v_and_b32 %9, %17, %24\n\t"
+	    "s_nop 0\n\t"
+	    "v_bcnt_u32_b32 %0, %8, %0\n\t"
+	    "s_nop 0\n\t"
+	    "v_bcnt_u32_b32 %1, %9, %1\n\t"
 	    "v_and_b32 %10, %18, %24\n\t"
 	    "v_and_b32 %11, %19, %24\n\t"
+	    "s_nop 0\n\t"
+	    "v_bcnt_u32_b32 %2, %10, %2\n\t"
+	    "s_nop 0\n\t"
+	    "v_bcnt_u32_b32 %3, %11, %3\n\t"
 	    "v_and_b32 %12, %20, %24\n\t"
 	    "v_and_b32 %13, %21, %24\n\t"
+	    "s_nop 0\n\t"
+	    "v_bcnt_u32_b32 %4, %12, %4\n\t"
+	    "s_nop 0\n\t"
+	    "v_bcnt_u32_b32 %5, %13, %5\n\t"
 	    "v_and_b32 %14, %22, %24\n\t"
 	    "v_and_b32 %15, %23, %24\n\t"
-	    "v_bcnt_u32_b32 %0, %8, %0\n\t"
-	    "v_bcnt_u32_b32 %1, %9, %1\n\t"
-	    "v_bcnt_u32_b32 %2, %10, %2\n\t"
-	    "v_bcnt_u32_b32 %3, %11, %3\n\t"
-	    "v_bcnt_u32_b32 %4, %12, %4\n\t"
-	    "v_bcnt_u32_b32 %5, %13, %5\n\t"
+	    "s_nop 0\n\t"
 	    "v_bcnt_u32_b32 %6, %14, %6\n\t"
+	    "s_nop 0\n\t"
 	    "v_bcnt_u32_b32 %7, %15, %7"
-	    : "+v"(acc[0][u]), "+v"(acc[1][u]), "+v"(acc[2][u]), "+v"(acc[3][u]),
-	      "+v"(acc[4][u]), "+v"(acc[5][u]), "+v"(acc[6][u]), "+v"(acc[7][u]),
+	    : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7),
 	      "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
 	    : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7), "v"(b));
 }
 
-// acc[t][u] += popc(a[t] & b) over the four words of a 16-byte slot.
-__device__ __forceinline__ void contract_slot(uint32_t (&acc)[8][8], int u, const uint4 (&a)[8], const uint4& b) {
-	and_bcnt8(acc, u, a[0].x, a[1].x, a[2].x, a[3].x, a[4].x, a[5].x, a[6].x, a[7].x, b.x);
-	and_bcnt8(acc, u, a[0].y, a[1].y, a[2].y, a[3].y, a[4].y, a[5].y, a[6].y, a[7].y, b.y);
-	and_bcnt8(acc, u, a[0].z, a[1].z, a[2].z, a[3].z, a[4].z, a[5].z, a[6].z, a[7].z, b.z);
-	and_bcnt8(acc, u, a[0].w, a[1].w, a[2].w, a[3].w, a[4].w, a[5].w, a[6].w, a[7].w, b.w);
+// acc[t][u] += popc(a[t] & b) over the four words of a 16-byte slot, t = 0..7.
+template <int TB>
+__device__ __forceinline__ void contract_slot(uint32_t (&acc)[8][TB], int u, const uint4 (&a)[8], const uint4& b) {
+	and_bcnt8(acc[0][u], acc[1][u], acc[2][u], acc[3][u], acc[4][u], acc[5][u], acc[6][u], acc[7][u],
+	          a[0].x, a[1].x, a[2].x, a[3].x, a[4].x, a[5].x, a[6].x, a[7].x, b.x);
+	and_bcnt8(acc[0][u], acc[1][u], acc[2][u], acc[3][u], acc[4][u], acc[5][u], acc[6][u], acc[7][u],
+	          a[0].y, a[1].y, a[2].y, a[3].y, a[4].y, a[5].y, a[6].y, a[7].y, b.y);
+	and_bcnt8(acc[0][u], acc[1][u], acc[2][u], acc[3][u], acc[4][u], acc[5][u], acc[6][u], acc[7][u],
+	          a[0].z, a[1].z, a[2].z, a[3].z, a[4].z, a[5].z, a[6].z, a[7].z, b.z);
+	and_bcnt8(acc[0][u], acc[1][u], acc[2][u], acc[3][u], acc[4][u], acc[5][u], acc[6][u], acc[7][u],
+	          a[0].w, a[1].w, a[2].w, a[3].w, a[4].w, a[5].w, a[6].w, a[7].w, b.w);
 }
 
 // grid: x = column tiles, y = row tiles of the super-tile.  C is the count
 // matrix of the super-tile: C[(by*128 + r) * ldc + bx*128 + c].
 // diag != 0: the super-tile sits on the diagonal (rowA0 == rowB0); tiles with
 // bx < by are not needed and exit at once.
-__global__ __launch_bounds__(256, 2)
-void k_count_tile(const uint32_t* __restrict__ rows, uint32_t W, uint32_t rowA0, uint32_t rowB0,
-                  int diag, uint32_t* __restrict__ C, uint32_t ldc) {
+//
+// NW waves per block share one 128 x 128 tile as a 2 x (NW/2) wave grid; a
+// lane owns 8 x TB pairs, TB = 16 / NW * 2:
+//   NW = 4: lane tile 8 x 8, ~210 VGPR, 2 blocks/CU = 2 waves/SIMD
+//   NW = 8: lane tile 8 x 4, <=128 VGPR, 2 blocks/CU = 4 waves/SIMD
+// A lone wave issues a VALU op only every other slot on gfx950 (measured: one
+// wave/SIMD reaches half the and/bcnt rate of two), so stalls of one wave are
+// only covered when >= 2 others are runnable: NW = 8 is the production shape.
+template <int NW>
+__global__ __launch_bounds__(NW * 64, NW / 2)
+void k_count_tile_t(const uint32_t* __restrict__ rows, uint32_t W, uint32_t rowA0, uint32_t rowB0,
+                    int diag, uint32_t* __restrict__ C, uint32_t ldc) {
+	constexpr int WC = NW / 2;            // wave columns (2 wave rows)
+	constexpr int TB = 16 / WC;           // B rows per lane: 8 (NW=4) or 4 (NW=8)
+	constexpr int NSEG = 32 / NW;         // DMA instructions per wave per chunk
 	__shared__ __attribute__((aligned(16))) uint32_t lds[2 * 2 * TILE * KC];   // [buf][A|B] 64 KiB
 
 	const uint32_t bx = blockIdx.x, by = blockIdx.y;
@@ -132,80 +165,83 @@ void k_count_tile(const uint32_t* __restrict__ rows, uint32_t W, uint32_t rowA0,
 	const int tid  = threadIdx.x;
 	const int lane = tid & 63;
 	const int wave = tid >> 6;
-	const int wr = wave >> 1, wc = wave & 1;
+	const int wr = wave / WC, wc = wave % WC;
 	const int li = lane >> 3, lj = lane & 7;
 
 	const uint32_t tileA0 = rowA0 + by * TILE;
 	const uint32_t tileB0 = rowB0 + bx * TILE;
 	const uint32_t nchunks = W / KC;
 
-	uint32_t acc[8][8];
+	uint32_t acc[8][TB];
 #pragma unroll
 	for (int t = 0; t < 8; ++t)
 #pragma unroll
-		for (int u = 0; u < 8; ++u) acc[t][u] = 0;
+		for (int u = 0; u < TB; ++u) acc[t][u] = 0;
 
-	// Per-lane LDS byte offsets.  Row (w*64 + l + 8t): (row >> 1) & 7 =
-	// ((l >> 1) + 4t) & 7 = (l >> 1) ^ ((t & 1) << 2), so slot q of that row
-	// lives at slot q ^ (l >> 1) ^ ((t & 1) << 2).  offX[k] = row base +
-	// 16 * ((l >> 1) ^ k); the reads below pick k = q ^ ((t & 1) << 2) and add
-	// the compile-time row stride 8*t*128.
+	// Per-lane LDS byte offsets.  Row (base + l + 8t), base a multiple of 16:
+	// (row >> 1) & 7 = ((l >> 1) + 4t) & 7 = (l >> 1) ^ ((t & 1) << 2), so slot q
+	// of that row lives at slot q ^ (l >> 1) ^ ((t & 1) << 2).  offX[k] = row
+	// base + 16 * ((l >> 1) ^ k); the reads below pick k = q ^ ((t & 1) << 2)
+	// and add the compile-time row stride 8*t*128.
 	uint32_t offA[8], offB[8];
 #pragma unroll
 	for (int k = 0; k < 8; ++k) {
 		offA[k] = (uint32_t)((wr * 64 + li) * (KC * 4) + (((li >> 1) ^ k) << 4));
-		offB[k] = (uint32_t)(LDS_TILE_BYTES + (wc * 64 + lj) * (KC * 4) + (((lj >> 1) ^ k) << 4));
+		offB[k] = (uint32_t)(LDS_TILE_BYTES + (wc * 8 * TB + lj) * (KC * 4) + (((lj >> 1) ^ k) << 4));
 	}
 	const char* lds_b = reinterpret_cast<const char*>(lds);
 
-	// Staging split: 32 wave-instructions per chunk (16 A + 16 B), 8 per wave.
-	// waves 0,1 -> A segments 0-7 / 8-15; waves 2,3 -> B segments 0-7 / 8-15.
+	// Staging split: 32 wave-instructions per chunk (16 A + 16 B), NSEG per wave:
+	// the first half of the waves stages A, the second half B.
 	const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-	const uint32_t st_row0 = (wave_u < 2) ? tileA0 : tileB0;
-	const int st_seg0 = (wave_u & 1) * 8;
+	const bool st_isB = wave_u >= NW / 2;
+	const uint32_t st_row0 = st_isB ? tileB0 : tileA0;
+	const int st_seg0 = (wave_u % (NW / 2)) * NSEG;
 	const uint32_t lds_base = (uint32_t)(uintptr_t)(lptr_t*)lds;                    // LDS byte address
-	const uint32_t st_lds = lds_base + ((wave_u < 2) ? 0u : (uint32_t)LDS_TILE_BYTES);
+	const uint32_t st_lds = lds_base + (st_isB ? (uint32_t)LDS_TILE_BYTES : 0u);
 
-	stage_rows(rows, W, st_row0, 0, st_lds, st_seg0, 8, lane);
+	stage_rows(rows, W, st_row0, 0, st_lds, st_seg0, NSEG, lane);
 
 	for (uint32_t c = 0; c < nchunks; ++c) {
 		const int buf = c & 1;
 		// Chunk c was issued one contraction ago: drain this wave's DMAs, then
 		// the barrier makes every wave's part visible and proves every wave is
 		// done reading the other buffer (chunk c-1).
+#if !(TWK_EXP & 2)
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		__syncthreads();
-		if (c + 1 < nchunks)
-			stage_rows(rows, W, st_row0, c + 1, st_lds + (buf ^ 1) * (2 * LDS_TILE_BYTES), st_seg0, 8, lane);
+#endif
+		if (c + 1 < nchunks && !(TWK_EXP & 4))
+			stage_rows(rows, W, st_row0, c + 1, st_lds + (buf ^ 1) * (2 * LDS_TILE_BYTES), st_seg0, NSEG, lane);
 
 		const char* base = lds_b + buf * (2 * LDS_TILE_BYTES);
-		uint4 a[2][8];
-#pragma unroll
-		for (int t = 0; t < 8; ++t)
-			a[0][t] = *reinterpret_cast<const uint4*>(base + offA[(t & 1) << 2] + t * 8 * (KC * 4));
 #pragma unroll
 		for (int q = 0; q < 8; ++q) {
-			// prefetch the A rows of the next 16-byte slot while this one is contracted
-			if (q + 1 < 8) {
+			uint4 a[8];
 #pragma unroll
-				for (int t = 0; t < 8; ++t)
-					a[(q + 1) & 1][t] = *reinterpret_cast<const uint4*>(base + offA[(q + 1) ^ ((t & 1) << 2)] + t * 8 * (KC * 4));
-			}
+			for (int t = 0; t < 8; ++t)
+				a[t] = *reinterpret_cast<const uint4*>(base + offA[q ^ ((t & 1) << 2)] + t * 8 * (KC * 4));
 #pragma unroll
-			for (int u = 0; u < 8; ++u) {
+			for (int u = 0; u < TB; ++u) {
 				const uint4 b = *reinterpret_cast<const uint4*>(base + offB[q ^ ((u & 1) << 2)] + u * 8 * (KC * 4));
-				contract_slot(acc, u, a[q & 1], b);
+				contract_slot<TB>(acc, u, a, b);
 			}
 		}
 	}
 
-	// Epilogue: each lane stores its 8 x 8 counts.  For fixed (t,u) the 8 lanes
+	// Epilogue: each lane stores its 8 x TB counts.  For fixed (t,u) the 8 lanes
 	// of one li write 8 consecutive u32 (32 B); small next to the K loop.
-	uint32_t* Cblk = C + (size_t)(by * TILE + wr * 64 + li) * ldc + bx * TILE + wc * 64 + lj;
+	uint32_t* Cblk = C + (size_t)(by * TILE + wr * 64 + li) * ldc + bx * TILE + wc * 8 * TB + lj;
 #pragma unroll
 	for (int t = 0; t < 8; ++t)
 #pragma unroll
-		for (int u = 0; u < 8; ++u) Cblk[(size_t)(8 * t) * ldc + 8 * u] = acc[t][u];
+		for (int u = 0; u < TB; ++u) Cblk[(size_t)(8 * t) * ldc + 8 * u] = acc[t][u];
 }
+
+#ifndef TWK_COUNT_NW
+#define TWK_COUNT_NW 8
+#endif
+constexpr int COUNT_NW = TWK_COUNT_NW;
+constexpr int COUNT_THREADS = COUNT_NW * 64;
 
 }  // namespace twk

@@ -185,7 +185,7 @@ int launch_count(twk_hip_ctx* c, int kind, const twk_hip_tile_desc& t, Slot& s, 
 	if ((uint64_t)t.rowA0 * P + g.rowsA > ps.rows_alloc || (uint64_t)t.rowB0 * P + g.rowsB > ps.rows_alloc) return TWK_HIP_E_INVALID;
 	const int diag = (t.diag && t.rowA0 == t.rowB0) ? 1 : 0;
 	HIPCHK(c, hipEventRecord(e0, c->s_compute));
-	hipLaunchKernelGGL(k_count_tile, dim3(g.gx, g.gy), dim3(256), 0, c->s_compute, ps.rows, ps.W,
+	hipLaunchKernelGGL((k_count_tile_t<COUNT_NW>), dim3(g.gx, g.gy), dim3(COUNT_THREADS), 0, c->s_compute, ps.rows, ps.W,
 	                   t.rowA0 * P, t.rowB0 * P, diag, s.C, g.ldc);
 	HIPCHK(c, hipGetLastError());
 	HIPCHK(c, hipEventRecord(e1, c->s_compute));

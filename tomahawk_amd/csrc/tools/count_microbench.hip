@@ -14,12 +14,12 @@ int main(int argc,char**argv){
   std::vector<uint32_t> h(nw); std::mt19937 rng(1); for(auto&x:h) x=rng();
   uint32_t *d,*C; CK(hipMalloc(&d,nw*4)); CK(hipMalloc(&C,(size_t)R*R*4));
   CK(hipMemcpy(d,h.data(),nw*4,hipMemcpyHostToDevice)); CK(hipMemset(C,0xff,(size_t)R*R*4));
-  dim3 grid(R/128,R/128), block(256);
+  dim3 grid(R/128,R/128), block(twk::COUNT_THREADS);
   hipEvent_t e0,e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for(int diag=0; diag<2; ++diag){
-    hipLaunchKernelGGL(twk::k_count_tile,grid,block,0,0,d,W,0u,0u,diag,C,R); CK(hipDeviceSynchronize());
+    hipLaunchKernelGGL((twk::k_count_tile_t<twk::COUNT_NW>),grid,block,0,0,d,W,0u,0u,diag,C,R); CK(hipDeviceSynchronize());
     float best=1e30f;
-    for(int i=0;i<reps;++i){ CK(hipEventRecord(e0)); hipLaunchKernelGGL(twk::k_count_tile,grid,block,0,0,d,W,0u,0u,diag,C,R); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms,e0,e1)); if(ms<best)best=ms; }
+    for(int i=0;i<reps;++i){ CK(hipEventRecord(e0)); hipLaunchKernelGGL((twk::k_count_tile_t<twk::COUNT_NW>),grid,block,0,0,d,W,0u,0u,diag,C,R); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms,e0,e1)); if(ms<best)best=ms; }
     double tiles = diag? (double)(R/128)*(R/128+1)/2 : (double)(R/128)*(R/128);
     double rowpairs = tiles*128*128;
     double wordops = rowpairs*W;            // and+bcnt pairs
