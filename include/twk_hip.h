@@ -73,10 +73,17 @@ typedef struct {
 typedef struct {
 	uint32_t rowA0, nA, rowB0, nB;
 	int32_t  diag;
-	int32_t  window;   /* != 0: keep only same-contig pairs with |posA-posB| <= l_window */
+	int32_t  window;   /* option bits, see TWK_HIP_OPT_*                                */
 	uint32_t l_window; /* base pairs (twk_ld_settings.l_window)                         */
 	uint32_t _pad;
 } twk_hip_tile_desc;
+
+/* Option bits for twk_hip_tile_desc.window and the `window` argument of ld_all / ld_region. */
+enum {
+	TWK_HIP_OPT_WINDOW      = 1, /* keep only same-contig pairs with |posA-posB| <= l_window (calc -w) */
+	TWK_HIP_OPT_KEEP_LOW_AC = 2  /* do not skip pairs with ac_A + ac_B <= 2: the single-site loop has the
+	                                skip commented out (ld_engine.cpp:2267-2269, 2293-2295)            */
+};
 
 /* One surviving pair, device-compacted.  Field-for-field the payload of
  * twk1_two_t (include/core.h:826-833) with variant indices instead of

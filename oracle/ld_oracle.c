@@ -21,7 +21,7 @@
 
 void orc_default_settings(orc_settings* s) { /* lib/core.cpp:297-306 */
 	s->minR2 = 0.1; s->maxR2 = 100; s->minDprime = 0; s->maxDprime = 100; s->minP = 1;
-	s->force_phased = 0; s->forced_unphased = 0;
+	s->force_phased = 0; s->forced_unphased = 0; s->keep_low_ac = 0;
 }
 
 uint32_t orc_words64(uint32_t n_samples) { /* ld_engine.cpp:58, core.cpp:353 */
@@ -390,7 +390,7 @@ int orc_unphased_math(const uint64_t o[9], const orc_variant* A, const orc_varia
 int orc_pair(const uint64_t* a, const uint64_t* ma, const orc_variant* A,
              const uint64_t* b, const uint64_t* mb, const orc_variant* B,
              uint32_t n_samples, const orc_settings* st, int vector_only, orc_record* rec) {
-	if (A->ac + B->ac <= 2) return 0;                                      /* :1918, :2033 */
+	if (!st->keep_low_ac && A->ac + B->ac <= 2) return 0;                  /* :1918, :2033; not in :2267 */
 	const uint64_t* mA = A->gt_missing ? ma : NULL;
 	const uint64_t* mB = B->gt_missing ? mb : NULL;
 	int phased;

@@ -34,6 +34,7 @@ typedef struct {
 typedef struct {
 	double minR2, maxR2, minDprime, maxDprime, minP;
 	int force_phased, forced_unphased;
+	int keep_low_ac;   /* single-site loop: the ac skip is commented out (ld_engine.cpp:2267-2269) */
 } orc_settings;
 
 /* twk1_two_t (include/core.h:826-833). */

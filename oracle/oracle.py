@@ -26,7 +26,7 @@ assert VARIANT_DTYPE.itemsize == 32 and RECORD_DTYPE.itemsize == 112
 class Settings(C.Structure):
     _fields_ = [("minR2", C.c_double), ("maxR2", C.c_double), ("minDprime", C.c_double),
                 ("maxDprime", C.c_double), ("minP", C.c_double), ("force_phased", C.c_int),
-                ("forced_unphased", C.c_int)]
+                ("forced_unphased", C.c_int), ("keep_low_ac", C.c_int)]
 
 
 _lib = None
@@ -61,8 +61,9 @@ def lib() -> C.CDLL:
     return _lib
 
 
-def settings(minR2=0.1, maxR2=100.0, minDprime=0.0, maxDprime=100.0, minP=1.0, phased=False, unphased=False) -> Settings:
-    return Settings(minR2, maxR2, minDprime, maxDprime, minP, int(phased), int(unphased))
+def settings(minR2=0.1, maxR2=100.0, minDprime=0.0, maxDprime=100.0, minP=1.0, phased=False, unphased=False,
+             keep_low_ac=False) -> Settings:
+    return Settings(minR2, maxR2, minDprime, maxDprime, minP, int(phased), int(unphased), int(keep_low_ac))
 
 
 def words64(n_samples: int) -> int:

@@ -36,6 +36,7 @@ CASES = {
     "n1000":        (1000, 110, 103, dict(low_ac=6), 2, 50),    # two contigs
     "n64_missing":  (64, 70, 104, dict(miss_rate=0.1, miss_variants=0.35, low_ac=4), 1, 30),
     "n128_missing": (128, 80, 105, dict(miss_rate=0.06, miss_variants=0.3, low_ac=4), 1, 30),
+    "n64_scalc":    (64, 300, 106, dict(miss_rate=0.1, miss_variants=0.1), 1, 64),
 }
 
 
@@ -74,7 +75,7 @@ def main():
         assert len(info_arr) == M and (info_arr[:, 1] == pos).all() and (info_arr[:, 0] == rid).all()
         assert (info_arr[:, 2] == (al == 1).sum(axis=(1, 2))).all() and (info_arr[:, 3] == (al == 2).sum(axis=(1, 2))).all()
         out = {}
-        for tag, flag in (("p", ["-p"]), ("u", ["-u"]), ("d", [])):
+        for tag, flag in ((("p", ["-p"]), ("u", ["-u"]), ("d", [])) if name != "n64_scalc" else ()):
             two = os.path.join(tmp, f"{name}_{tag}.two")
             O.run_ref(["calc", "-i", twk, "-o", two, "-r", "0", "-t", "1"] + flag)
             rec = parse_dump(O.run_ref(["dump", two]).stdout)
@@ -82,6 +83,19 @@ def main():
             assert len(rec) == 2 * len(out["rec_" + tag])
             if name == "n64_small" and tag == "p":
                 shutil.copy(two, os.path.join(HERE, "ref_n64_small_p.two"))
+        if name == "n1000":
+            # interval slicing and single-site mode (calc -I, scalc): two contigs, 55 variants each, 50/block
+            for tag, args in (("I_contig2", ["calc", "-I", "2", "-p"]), ("I_range", ["calc", "-I", "1:2500-4300", "-u"])):
+                two = os.path.join(tmp, f"{name}_{tag}.two")
+                O.run_ref(args[:1] + ["-i", twk, "-o", two, "-r", "0", "-t", "1"] + args[1:])
+                rec = parse_dump(O.run_ref(["dump", two]).stdout)
+                out["rec_" + tag] = forward_only(rec)
+        if name == "n64_scalc":
+            # scalc: target = variant 150 (0-based pos 16000 -> 1-based 16001), +-5000 bp = exactly 100 neighbours.
+            # (The reference only keeps neighbours in full groups of 100, ld.cpp:203-205,239-244.)
+            two = os.path.join(tmp, f"{name}_scalc.two")
+            O.run_ref(["scalc", "-i", twk, "-o", two, "-t", "1", "-I", "1:16001", "-w", "5000"])
+            out["rec_scalc"] = parse_dump(O.run_ref(["dump", two]).stdout)
         np.savez_compressed(os.path.join(HERE, name + ".npz"), alleles=al, pos=pos, rid=rid,
                             info=info_arr[:, [2, 3, 4, 5, 6, 7, 8, 10]].astype(np.uint32), **out)
         print(name, {k: v.shape for k, v in out.items()})

@@ -116,5 +116,7 @@ def test_cli_usage_and_errors():
     assert r.returncode == 1 and "Failed to open file" in r.stderr
     r = subprocess.run([hostlib.CLI_PATH, "calc", "-i", "a", "-o", "b", "-a", "3"], capture_output=True, text=True)
     assert r.returncode == 1 and "Unrecognized option" in r.stderr          # reference: calc.h:216-218
+    r = subprocess.run([hostlib.CLI_PATH, "scalc", "-i", "/nonexistent.twk", "-o", "/tmp/x", "-w", "0"], capture_output=True, text=True)
+    assert r.returncode == 1 and "non-positive window" in r.stderr
     r = subprocess.run([hostlib.CLI_PATH, "view"], capture_output=True, text=True)
     assert r.returncode == 1 and "Illegal command" in r.stderr

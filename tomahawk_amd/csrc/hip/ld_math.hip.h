@@ -367,7 +367,7 @@ struct StatsParams {
 	int phased_math;          // 1: PhasedMath on the 2x2 table, 0: UnphasedMath on the 3x3
 	int auto_select;          // 0: all pairs; 1: only pairs with an_A == 0 && an_B == 0;
 	                          // 2: only pairs with an_A != 0 || an_B != 0   
-	int window; uint32_t l_window;
+	int window; uint32_t l_window;   // window: TWK_HIP_OPT_* bits
 	twk_hip_filters filt;
 	twk_hip_record* out;
 	unsigned long long capacity;
@@ -384,12 +384,12 @@ void k_ld_stats(const StatsParams p) {
 		const uint32_t A = p.tv.a0 + i, B = p.tv.b0 + j;
 		bool todo = A < p.n_variants && B < p.n_variants && (!p.diag || B > A);
 		// ld_engine.cpp:1918 / 2033: nothing to learn from two singletons
-		if (todo && p.vm.ac[A] + p.vm.ac[B] <= 2) todo = false;
+		if (todo && !(p.window & TWK_HIP_OPT_KEEP_LOW_AC) && p.vm.ac[A] + p.vm.ac[B] <= 2) todo = false;
 		if (todo && p.auto_select) {
 			const bool anymiss = p.vm.an[A] || p.vm.an[B];
 			if ((p.auto_select == 1) == anymiss) todo = false;
 		}
-		if (todo && p.window) {   // exact window: same contig, |dpos| <= w
+		if (todo && (p.window & TWK_HIP_OPT_WINDOW)) {   // exact window: same contig, |dpos| <= w
 			const int64_t d = (int64_t)p.vm.pos[A] - (int64_t)p.vm.pos[B];
 			if (p.vm.rid[A] != p.vm.rid[B] || (d < 0 ? -d : d) > (int64_t)p.l_window) todo = false;
 		}

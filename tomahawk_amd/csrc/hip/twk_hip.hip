@@ -626,7 +626,7 @@ int twk_hip_ld_region(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint32
 	auto push_tile = [&](uint32_t ra, uint32_t na, uint32_t cb, uint32_t nb_, int diag) {
 		twk_hip_tile_desc t{};
 		t.rowA0 = a0 + ra; t.nA = na; t.rowB0 = b0 + cb; t.nB = nb_; t.diag = diag; t.window = window; t.l_window = l_window;
-		if (window && !diag) {
+		if ((window & TWK_HIP_OPT_WINDOW) && !diag) {
 			// Inputs are sorted by (rid, pos) like every .twk: if both tiles lie on one contig and
 			// the gap between them exceeds the window, no pair can qualify (the reference's ticker
 			// skips the rest of the row, ld_balancing.h:191).

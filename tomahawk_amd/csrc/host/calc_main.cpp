@@ -35,7 +35,7 @@ static void calc_usage() {
 	"  -m, -M    accepted for compatibility (CPU low-memory modes; no effect on the GPU engine)\n"
 	"  -b        number of records in a block (accepted; unused by calc, as in the reference)\n"
 	"  -w INT    sliding window width in bases\n"
-	"  -I STRING filter interval <contig>:pos-pos (not implemented yet)\n"
+	"  -I STRING filter interval <contig>:pos-pos (see manual)\n"
 	"  -p        force computations to use phased math\n"
 	"  -u        force computations to use unphased math\n"
 	"  -P FLOAT  Fisher's exact test / Chi-squared cutoff P-value (default: 1)\n"
@@ -115,14 +115,77 @@ static int calc(int argc, char** argv) {
 	return ld.Compute(settings) ? 0 : 1;
 }
 
+// `tomahawk scalc` (lib/scalc.h:50-194): one site against its neighbourhood.
+static int scalc(int argc, char** argv) {
+	if (argc < 3) {
+		program_message();
+		std::cerr << "About:  Calculate linkage disequilibrium for a single site\n"
+		             "Usage:  tomahawk scalc [options] -i <in.twk> -I <chr:pos> -o <output.two>\n\n"
+		             "Options:\n"
+		             "  -i FILE   input Tomahawk (required)\n  -o FILE   output file or file prefix (required)\n"
+		             "  -I STRING target site <contig>:pos (required)\n  -w INT    flanking width in bases (default: 500000)\n"
+		             "  -t INT    number of CPU threads\n  -P FLOAT  Fisher's exact test cutoff P-value (default: 1)\n"
+		             "  -k INT    compression level to use (default: 1)\n" << std::endl;
+		return 1;
+	}
+	tomahawk::twk_ld_settings settings;
+	int c;
+	while ((c = getopt(argc, argv, "i:o:t:I:mMb:r:R:P:k:w:?")) != -1) {
+		switch (c) {
+		case 'i': settings.in = optarg; break;
+		case 'o': settings.out = optarg; break;
+		case 'I': settings.ival_strings.push_back(optarg); break;
+		case 'm': settings.low_memory = true; break;
+		case 'M': settings.force_phased = true; settings.low_memory = true; settings.bitmaps = true; break;
+		case 't':
+			settings.n_threads = atoi(optarg);
+			if (settings.n_threads <= 0) { std::cerr << stamp("ERROR") << "Cannot have a non-positive number of worker threads" << std::endl; return 1; }
+			break;
+		case 'b':
+			settings.bl_size = atoi(optarg);
+			if (settings.bl_size <= 0) { std::cerr << stamp("ERROR") << "Cannot have a non-positive number of entries in a block!" << std::endl; return 1; }
+			break;
+		case 'r':
+			settings.minR2 = atof(optarg);
+			if (settings.minR2 < 0 || settings.minR2 > 1) { std::cerr << stamp("ERROR") << "Cannot have a minimum R-squared value outside [0,1]" << std::endl; return 1; }
+			break;
+		case 'R':
+			settings.maxR2 = atof(optarg);
+			if (settings.maxR2 < 0 || settings.maxR2 > 1) { std::cerr << stamp("ERROR") << "Cannot have a maximum R-squared value outside [0,1]" << std::endl; return 1; }
+			break;
+		case 'P':
+			settings.minP = atof(optarg);
+			if (settings.minP < 0 || settings.minP > 1) { std::cerr << stamp("ERROR") << "Cannot have a cutoff P-value outside [0,1]" << std::endl; return 1; }
+			break;
+		case 'k': settings.c_level = atoi(optarg); break;
+		case 'w':
+			settings.l_surrounding = atoi(optarg);
+			if (settings.l_surrounding < 1) { std::cerr << stamp("ERROR") << "Cannot have a non-positive window size" << std::endl; return 1; }
+			break;
+		default:
+			std::cerr << stamp("ERROR") << "Unrecognized option: " << (char)c << std::endl;
+			return 1;
+		}
+	}
+	if (settings.in.empty()) { std::cerr << stamp("ERROR") << "No input value specified..." << std::endl; return 1; }
+	if (settings.out.empty()) { std::cerr << stamp("ERROR") << "No output value specified..." << std::endl; return 1; }
+	program_message();
+	std::cerr << stamp("LOG") << "Calling calc..." << std::endl;
+	settings.single = true;
+	settings.minR2 = 0;           // scalc.h:188-189: -r is parsed, then overwritten
+	tomahawk::twk_ld ld;
+	return ld.ComputeSingle(settings, true, true) ? 0 : 1;
+}
+
 int main(int argc, char** argv) {
 	if (argc == 1) { program_message(); std::cerr << "Usage: tomahawk calc [options] -i <in.twk> -o <output.two>" << std::endl; return 1; }
 	tomahawk::LITERAL_COMMAND_LINE = "tomahawk";
 	for (int i = 1; i < argc; ++i) tomahawk::LITERAL_COMMAND_LINE += " " + std::string(argv[i]);
 	if (strcmp(argv[1], "calc") == 0) return calc(argc, argv);
+	if (strcmp(argv[1], "calc-single") == 0 || strcmp(argv[1], "scalc") == 0) return scalc(argc, argv);
 	if (strcmp(argv[1], "--version") == 0 || strcmp(argv[1], "version") == 0) { program_message(); return 0; }
 	if (strcmp(argv[1], "--help") == 0 || strcmp(argv[1], "help") == 0) { calc_usage(); return 0; }
 	program_message();
-	std::cerr << stamp("ERROR") << "Illegal command: only `calc` is provided by the MI355X engine (scalc/view/sort/... are the reference's)" << std::endl;
+	std::cerr << stamp("ERROR") << "Illegal command: only `calc` and `scalc` are provided by the MI355X engine (view/sort/concat/... are the reference's)" << std::endl;
 	return 1;
 }

@@ -15,6 +15,7 @@
 #include <ctime>
 #include <iomanip>
 #include <iostream>
+#include <regex>
 #include <sstream>
 #include <thread>
 #include <sys/time.h>
@@ -156,6 +157,8 @@ public:
 		return true;
 	}
 
+	bool run(twk_ld_settings& settings, const Header& hdr, twk_hip_ctx* ctx, uint32_t n_samples, const void* spec);
+
 	static int sink(void* user, const twk_hip_record* recs, uint64_t n) {
 		auto* self = static_cast<twk_ld_impl*>(user);
 		// Survivors of a tile arrive in device-compaction order; restore (row, col) order so that
@@ -182,11 +185,6 @@ bool twk_ld::ComputePerformance() {
 	std::cerr << stamp("ERROR") << "ComputePerformance is a compile-time debug harness of the CPU reference; not available." << std::endl;
 	return false;
 }
-bool twk_ld::ComputeSingle(bool, bool) {
-	std::cerr << stamp("ERROR") << "scalc (single-site mode) is not implemented by the MI355X engine yet." << std::endl;
-	return false;
-}
-
 namespace {
 struct DeviceCtx {
 	twk_hip_ctx* ctx = nullptr;
@@ -201,58 +199,88 @@ bool hip_ok(twk_hip_ctx* ctx, int rc, const char* what) {
 }
 }  // namespace
 
-bool twk_ld::Compute() {
-	using clock = std::chrono::steady_clock;
-	mImpl->n_pairs = mImpl->n_records = 0;
-	if (settings.in.empty()) { std::cerr << stamp("ERROR") << "No file-name provided..." << std::endl; return false; }
-	if (settings.window && settings.n_chunks != 1) { std::cerr << stamp("ERROR") << "Cannot use chunking in window mode!" << std::endl; return false; }
-	if (!settings.ival_strings.empty()) { std::cerr << stamp("ERROR") << "Interval slicing (-I) is not implemented by the MI355X engine yet." << std::endl; return false; }
-	if (settings.bitmaps || settings.low_memory)
-		std::cerr << stamp("LOG") << "Note: -m/-M are CPU memory-saving modes; the GPU engine keeps dense bit-planes in HBM." << std::endl;
+// ---- interval strings (lib/intervals.cpp:96-139; regexes include/tomahawk.h:57-59) -------------
+struct Interval { int32_t rid; uint32_t from, to; };
+static bool parse_interval(const std::string& str, const Header& hdr, Interval& out) {
+	static const std::regex re_range("^[A-Za-z0-9\\-_]+\\:[0-9]+([\\.]{1}[0-9]+){0,1}([eE]{1}[0-9]{1})?\\-[0-9]+([\\.]{1}[0-9]+){0,1}([eE]{1}[0-9]{1})?$");
+	static const std::regex re_pos("^[A-Za-z0-9\\-_]+\\:[0-9]+([\\.]{1}[0-9]+){0,1}([eE]{1}[0-9]{1})?$");
+	static const std::regex re_contig("^[A-Za-z0-9\\-_]+$");
+	auto contig = [&](const std::string& name) -> int {
+		const int id = hdr.contig_id(name);
+		if (id < 0) std::cerr << stamp("ERROR", "INTERVAL") << "Contig does not exist in string " << str << std::endl;
+		return id;
+	};
+	if (std::regex_match(str, re_range)) {
+		const size_t c = str.find(':'), d = str.find('-', c);
+		const int id = contig(str.substr(0, c));
+		if (id < 0) return false;
+		out = {hdr.contigs[id].idx == (uint32_t)id ? id : (int32_t)hdr.contigs[id].idx,
+		       (uint32_t)std::atof(str.substr(c + 1, d - c - 1).c_str()), (uint32_t)std::atof(str.substr(d + 1).c_str())};
+		return true;
+	}
+	if (std::regex_match(str, re_pos)) {
+		const size_t c = str.find(':');
+		const int id = contig(str.substr(0, c));
+		if (id < 0) return false;
+		const uint32_t p = (uint32_t)std::atof(str.substr(c + 1).c_str());
+		out = {(int32_t)hdr.contigs[id].idx, p, p + 1};
+		return true;
+	}
+	if (std::regex_match(str, re_contig)) {
+		const int id = contig(str);
+		if (id < 0) return false;
+		out = {(int32_t)hdr.contigs[id].idx, 0, (uint32_t)hdr.contigs[id].n_bases};
+		return true;
+	}
+	std::cerr << stamp("ERROR", "INTERVAL") << "Illegal format: " << str << std::endl;
+	return false;
+}
+// Index::FindOverlap (lib/index.cpp:124-133): blocks with rid match and [minpos,maxpos] meeting [from,to].
+static void overlapping_blocks(const TwkIndex& idx, const Interval& iv, std::vector<uint32_t>& out) {
+	for (size_t i = 0; i < idx.ent.size(); ++i)
+		if (idx.ent[i].rid == iv.rid && idx.ent[i].minpos <= iv.to && idx.ent[i].maxpos >= iv.from) out.push_back((uint32_t)i);
+}
 
-	std::cerr << stamp("LOG", "READER") << "Opening " << settings.in << "..." << std::endl;
-	TwkReader reader;
-	if (!reader.open(settings.in)) { std::cerr << stamp("ERROR") << "Failed to open file: " << settings.in << "... (" << reader.error << ")" << std::endl; return false; }
-	const uint32_t n_samples = (uint32_t)reader.hdr.samples.size();
-	std::cerr << stamp("LOG") << "Samples: " << pretty(n_samples) << "..." << std::endl;
-	const uint32_t n_blocks = (uint32_t)reader.index.ent.size();
-	if (n_blocks == 0 || n_samples == 0) { std::cerr << stamp("ERROR") << "No valid data available..." << std::endl; return true; }
+namespace {
+// Everything after the variants are in HBM: output file, compute, final statistics.
+struct RunSpec {
+	uint32_t nA = 0, nB = 0;     // variants [0,nA) are the row set, [nA,nA+nB) the column set (nB = 0: one set)
+	bool triangleA = true;       // all pairs inside the row set
+	bool rectAB = false;         // row set x column set
+	int options = 0;             // TWK_HIP_OPT_*
+	uint32_t l_window = 0;
+};
+}  // namespace
 
-	if (settings.window) settings.c_chunk = 0;
-	Balancer bal;
-	if (!bal.build(n_blocks, (uint32_t)settings.n_chunks, (uint32_t)settings.c_chunk)) return false;
-	std::cerr << stamp("LOG", "BALANCING") << "Using ranges [" << bal.fromL << "-" << bal.toL << "," << bal.fromR << "-" << bal.toR
-	          << "] in " << (settings.window ? "window mode" : "square mode") << "..." << std::endl;
+static bool open_output(twk_ld_settings& settings, const Header& in_hdr, TwoWriter& writer) {   // ld.cpp:583-618
+	std::string out = settings.out;
+	if (out.empty() || out == "-") {
+		std::cerr << stamp("LOG", "WRITER") << "Writing to stdout..." << std::endl;
+		out = "-";
+	} else {
+		const std::string ext = extension(out);
+		if (!(ext.size() == 3 && strncasecmp(ext.c_str(), "two", 3) == 0)) {
+			const std::string bp = base_path(out);
+			out = (bp.size() ? bp + "/" : "") + base_name(out) + ".two";
+		}
+		std::cerr << stamp("LOG", "WRITER") << "Opening " << out << "..." << std::endl;
+	}
+	settings.out = out;
+	Header hdr = in_hdr;
+	hdr.literals += "\n##tomahawk_calcVersion=" + std::string(TWK_AMD_VERSION) + "\n";
+	hdr.literals += "##tomahawk_calcCommand=" + command_line() + "; Date=" + datetime() + "\n";
+	if (!writer.open(out, hdr, settings.c_level)) { std::cerr << stamp("ERROR", "WRITER") << "Failed to open file: " << out << "..." << std::endl; return false; }
+	return true;
+}
 
-	// Selected blocks: the L range, then (square chunk only) the R range.
-	std::vector<uint32_t> sel;
-	for (uint32_t b = bal.fromL; b < bal.toL; ++b) sel.push_back(b);
-	uint32_t nL = 0, nR = 0;
-	for (uint32_t b : sel) nL += reader.index.ent[b].n;
-	if (!bal.diag) { for (uint32_t b = bal.fromR; b < bal.toR; ++b) { sel.push_back(b); nR += reader.index.ent[b].n; } }
-	const uint32_t M = nL + nR;
+// Unpack `sel` blocks (ld.cpp:370-465, ld_unpacker.h) in batches on T threads and upload them in file order.
+static bool load_blocks(const std::string& path, const TwkReader& reader, const std::vector<uint32_t>& sel,
+                        uint32_t n_samples, uint32_t T, twk_hip_ctx* ctx, std::vector<uint32_t>& rid, std::vector<uint32_t>& pos) {
+	const size_t w64 = ((size_t)2 * n_samples + 63) / 64;
 	std::vector<uint32_t> first(sel.size() + 1, 0);
 	for (size_t k = 0; k < sel.size(); ++k) first[k + 1] = first[k] + reader.index.ent[sel[k]].n;
-	const uint64_t n_cmp = bal.diag ? (uint64_t)M * (M - 1) / 2 : (uint64_t)nL * nR;
-	std::cerr << stamp("LOG") << pretty(M) << " variants from " << pretty(sel.size()) << " blocks..." << std::endl;
-	std::cerr << stamp("LOG", "PARAMS") << settings.GetString() << std::endl;
-	std::cerr << stamp("LOG") << "Performing: " << pretty(n_cmp) << " variant comparisons..." << std::endl;
-
-	// ---- device ----
-	const char* dev_env = std::getenv("TWK_HIP_DEVICE");
-	const int device = dev_env ? std::atoi(dev_env) : 0;
-	if (twk_hip_device_count() <= 0) { std::cerr << stamp("ERROR", "HIP") << "No HIP device available (this build has no CPU path)." << std::endl; return false; }
-	DeviceCtx dc;
-	if (!hip_ok(nullptr, twk_hip_ctx_create(device, &dc.ctx), "twk_hip_ctx_create")) return false;
-	if (!hip_ok(dc.ctx, twk_hip_set_problem(dc.ctx, n_samples, M), "twk_hip_set_problem")) return false;
-
-	// ---- unpack + upload (ld.cpp:370-465, ld_unpacker.h): batches of blocks, T threads per batch ----
-	const auto t_load = clock::now();
-	const size_t w64 = ((size_t)2 * n_samples + 63) / 64;
-	const uint32_t T = (uint32_t)std::max(1, settings.n_threads);
-	mImpl->rid.assign(M, 0); mImpl->pos.assign(M, 0);
+	rid.assign(first.back(), 0); pos.assign(first.back(), 0);
 	const size_t batch_bytes = (size_t)512 << 20;
-	std::cerr << stamp("LOG", "THREAD") << "Unpacking using " << T << " threads..." << std::endl;
 	size_t k0 = 0;
 	while (k0 < sel.size()) {
 		size_t k1 = k0; uint32_t nv = 0;
@@ -260,24 +288,20 @@ bool twk_ld::Compute() {
 		std::vector<uint64_t> data((size_t)nv * w64), mask;
 		std::vector<twk_hip_variant_meta> meta(nv);
 		std::vector<uint8_t> has_mask(k1 - k0, 0);
+		std::vector<Block> blocks(k1 - k0);
 		std::atomic<size_t> next(k0);
 		std::atomic<bool> failed(false);
-		// masks are allocated lazily: first pass detects whether any variant in the batch needs one
-		std::vector<Block> blocks(k1 - k0);
 		auto reader_job = [&]() {
 			TwkReader rd;
-			if (!rd.open(settings.in)) { failed = true; return; }
+			if (!rd.open(path)) { failed = true; return; }
 			for (size_t k = next++; k < k1; k = next++) {
 				Block& blk = blocks[k - k0];
 				if (!rd.read_block(sel[k], blk) || blk.rcds.size() != reader.index.ent[sel[k]].n) { failed = true; return; }
 				for (const auto& v : blk.rcds) if (v.gt_missing) has_mask[k - k0] = 1;
 			}
 		};
-		{
-			std::vector<std::thread> th;
-			for (uint32_t t = 0; t < std::min<uint32_t>(T, (uint32_t)(k1 - k0)); ++t) th.emplace_back(reader_job);
-			for (auto& t : th) t.join();
-		}
+		const uint32_t nt = std::min<uint32_t>(T, (uint32_t)(k1 - k0));
+		{ std::vector<std::thread> th; for (uint32_t t = 0; t < nt; ++t) th.emplace_back(reader_job); for (auto& t : th) t.join(); }
 		if (failed) { std::cerr << stamp("ERROR") << "Failed to load blocks " << k0 << "-" << k1 << "!" << std::endl; return false; }
 		const bool any_mask = std::any_of(has_mask.begin(), has_mask.end(), [](uint8_t x) { return x != 0; });
 		if (any_mask) mask.assign((size_t)nv * w64, 0);
@@ -296,69 +320,194 @@ bool twk_ld::Compute() {
 				}
 			}
 		};
-		{
-			std::vector<std::thread> th;
-			for (uint32_t t = 0; t < std::min<uint32_t>(T, (uint32_t)(k1 - k0)); ++t) th.emplace_back(build_job);
-			for (auto& t : th) t.join();
-		}
+		{ std::vector<std::thread> th; for (uint32_t t = 0; t < nt; ++t) th.emplace_back(build_job); for (auto& t : th) t.join(); }
 		if (failed) { std::cerr << stamp("ERROR") << "Corrupt genotype runs in blocks " << k0 << "-" << k1 << "!" << std::endl; return false; }
-		for (uint32_t i = 0; i < nv; ++i) { mImpl->rid[first[k0] + i] = meta[i].rid; mImpl->pos[first[k0] + i] = meta[i].pos; }
-		if (!hip_ok(dc.ctx, twk_hip_upload_bitvectors(dc.ctx, first[k0], nv, data.data(), any_mask ? mask.data() : nullptr, w64, meta.data()),
+		for (uint32_t i = 0; i < nv; ++i) { rid[first[k0] + i] = meta[i].rid; pos[first[k0] + i] = meta[i].pos; }
+		if (!hip_ok(ctx, twk_hip_upload_bitvectors(ctx, first[k0], nv, data.data(), any_mask ? mask.data() : nullptr, w64, meta.data()),
 		            "twk_hip_upload_bitvectors")) return false;
 		k0 = k1;
 	}
-	std::cerr << stamp("LOG") << "Unpacked and uploaded " << pretty(M) << " variants. "
-	          << elapsed_string(std::chrono::duration<double>(clock::now() - t_load).count()) << std::endl;
+	return true;
+}
 
-	// ---- output file (ld.cpp:583-618) ----
-	std::string out = settings.out;
-	if (out.empty() || out == "-") {
-		std::cerr << stamp("LOG", "WRITER") << "Writing to stdout..." << std::endl;
-		out = "-";
-	} else {
-		const std::string ext = extension(out);
-		if (!(ext.size() == 3 && strncasecmp(ext.c_str(), "two", 3) == 0)) {
-			const std::string bp = base_path(out);
-			out = (bp.size() ? bp + "/" : "") + base_name(out) + ".two";
-		}
-		std::cerr << stamp("LOG", "WRITER") << "Opening " << out << "..." << std::endl;
-	}
-	Header hdr = reader.hdr;
-	hdr.literals += "\n##tomahawk_calcVersion=" + std::string(TWK_AMD_VERSION) + "\n";
-	hdr.literals += "##tomahawk_calcCommand=" + command_line() + "; Date=" + datetime() + "\n";
-	if (!mImpl->writer.open(out, hdr, settings.c_level)) { std::cerr << stamp("ERROR", "WRITER") << "Failed to open file: " << out << "..." << std::endl; return false; }
-	mImpl->b_size = (uint32_t)std::max(2, settings.b_size);
-	mImpl->blk_f.clear(); mImpl->blk_r.clear(); mImpl->write_failed = false;
+static bool create_device(DeviceCtx& dc) {
+	const char* dev_env = std::getenv("TWK_HIP_DEVICE");
+	const int device = dev_env ? std::atoi(dev_env) : 0;
+	if (twk_hip_device_count() <= 0) { std::cerr << stamp("ERROR", "HIP") << "No HIP device available (this build has no CPU path)." << std::endl; return false; }
+	return hip_ok(nullptr, twk_hip_ctx_create(device, &dc.ctx), "twk_hip_ctx_create");
+}
 
-	// ---- compute ----
-	const int mode = settings.force_phased ? TWK_HIP_MODE_PHASED : (settings.forced_unphased ? TWK_HIP_MODE_UNPHASED : TWK_HIP_MODE_AUTO);
+// compute + write + final log lines (ld.cpp:620-668, ld_progress.h:89-96)
+bool twk_ld::twk_ld_impl::run(twk_ld_settings& settings, const Header& hdr, twk_hip_ctx* ctx, uint32_t n_samples, const void* spec_) {
+	using clock = std::chrono::steady_clock;
+	const RunSpec& spec = *static_cast<const RunSpec*>(spec_);
+	if (!open_output(settings, hdr, writer)) return false;
+	b_size = (uint32_t)std::max(2, settings.b_size);
+	blk_f.clear(); blk_r.clear(); write_failed = false; n_records = 0; n_pairs = 0;
+	const int mode = settings.single ? TWK_HIP_MODE_AUTO
+	               : settings.force_phased ? TWK_HIP_MODE_PHASED : (settings.forced_unphased ? TWK_HIP_MODE_UNPHASED : TWK_HIP_MODE_AUTO);
 	twk_hip_filters f{settings.minR2, settings.maxR2, settings.minDprime, settings.maxDprime, settings.minP};
 	const auto t0 = clock::now();
 	uint64_t np = 0, nr = 0;
-	int rc;
-	if (bal.diag)
-		rc = twk_hip_ld_region(dc.ctx, mode, &f, 0, M, 0, M, 1, 0, 1, 0, settings.window ? 1 : 0, (uint32_t)settings.l_window,
-		                       twk_ld_impl::sink, mImpl, &np, &nr);
-	else
-		rc = twk_hip_ld_region(dc.ctx, mode, &f, 0, nL, nL, nR, 0, 0, 1, 0, settings.window ? 1 : 0, (uint32_t)settings.l_window,
-		                       twk_ld_impl::sink, mImpl, &np, &nr);
-	if (mImpl->write_failed) { std::cerr << stamp("ERROR", "WRITER") << "Failed to write output block!" << std::endl; return false; }
-	if (!hip_ok(dc.ctx, rc, "twk_hip_ld_region")) return false;
-	mImpl->n_pairs = np;
-	if (!mImpl->flush()) { std::cerr << stamp("ERROR", "WRITER") << "Failed to write output block!" << std::endl; return false; }
+	int rc = TWK_HIP_OK;
+	if (spec.triangleA && spec.nA > 1) {
+		rc = twk_hip_ld_region(ctx, mode, &f, 0, spec.nA, 0, spec.nA, 1, 0, 1, 0, spec.options, spec.l_window, sink, this, &np, &nr);
+		n_pairs += np;
+	}
+	if (rc == TWK_HIP_OK && spec.rectAB && spec.nA && spec.nB) {
+		rc = twk_hip_ld_region(ctx, mode, &f, 0, spec.nA, spec.nA, spec.nB, 0, 0, 1, 0, spec.options, spec.l_window, sink, this, &np, &nr);
+		n_pairs += np;
+	}
+	if (write_failed) { std::cerr << stamp("ERROR", "WRITER") << "Failed to write output block!" << std::endl; return false; }
+	if (!hip_ok(ctx, rc, "twk_hip_ld_region")) return false;
+	if (!flush()) { std::cerr << stamp("ERROR", "WRITER") << "Failed to write output block!" << std::endl; return false; }
 	const double sec = std::chrono::duration<double>(clock::now() - t0).count();
-	// ld_progress.h:89-96
-	std::cerr << stamp("PROGRESS") << "Finished in " << elapsed_string(sec) << ". Variants: " << pretty(np) << ", genotypes: "
-	          << pretty(np * n_samples) << ", output: " << pretty(mImpl->n_records) << std::endl;
-	std::cerr << stamp("PROGRESS") << pretty((uint64_t)(np / std::max(sec, 1e-9))) << " variants/s and "
-	          << pretty((uint64_t)((double)np * n_samples / std::max(sec, 1e-9))) << " genotypes/s" << std::endl;
+	std::cerr << stamp("PROGRESS") << "Finished in " << elapsed_string(sec) << ". Variants: " << pretty(n_pairs) << ", genotypes: "
+	          << pretty(n_pairs * n_samples) << ", output: " << pretty(n_records) << std::endl;
+	std::cerr << stamp("PROGRESS") << pretty((uint64_t)(n_pairs / std::max(sec, 1e-9))) << " variants/s and "
+	          << pretty((uint64_t)((double)n_pairs * n_samples / std::max(sec, 1e-9))) << " genotypes/s" << std::endl;
 	twk_hip_timing tm;
-	if (twk_hip_timing_get(dc.ctx, &tm) == TWK_HIP_OK)
+	if (twk_hip_timing_get(ctx, &tm) == TWK_HIP_OK)
 		std::cerr << stamp("LOG", "HIP") << "count kernel " << tm.count_ms << " ms in " << tm.count_launches << " launches, math kernel "
 		          << tm.stats_ms << " ms" << std::endl;
-	if (!mImpl->writer.close()) { std::cerr << stamp("ERROR", "WRITER") << "Failed to write final block!" << std::endl; return false; }
+	if (!writer.close()) { std::cerr << stamp("ERROR", "WRITER") << "Failed to write final block!" << std::endl; return false; }
+	return true;
+}
+
+bool twk_ld::Compute() {
+	using clock = std::chrono::steady_clock;
+	mImpl->n_pairs = mImpl->n_records = 0;
+	if (settings.in.empty()) { std::cerr << stamp("ERROR") << "No file-name provided..." << std::endl; return false; }
+	if (settings.window && settings.n_chunks != 1) { std::cerr << stamp("ERROR") << "Cannot use chunking in window mode!" << std::endl; return false; }
+	if (settings.bitmaps || settings.low_memory)
+		std::cerr << stamp("LOG") << "Note: -m/-M are CPU memory-saving modes; the GPU engine keeps dense bit-planes in HBM." << std::endl;
+
+	std::cerr << stamp("LOG", "READER") << "Opening " << settings.in << "..." << std::endl;
+	TwkReader reader;
+	if (!reader.open(settings.in)) { std::cerr << stamp("ERROR") << "Failed to open file: " << settings.in << "... (" << reader.error << ")" << std::endl; return false; }
+	const uint32_t n_samples = (uint32_t)reader.hdr.samples.size();
+	std::cerr << stamp("LOG") << "Samples: " << pretty(n_samples) << "..." << std::endl;
+
+	// The universe of blocks: all of them, or (-I) those overlapping the intervals
+	// (ld.cpp:523-527, 257-277: whole blocks are loaded, like the reference).
+	std::vector<uint32_t> universe;
+	if (settings.ival_strings.empty()) {
+		for (uint32_t b = 0; b < reader.index.ent.size(); ++b) universe.push_back(b);
+	} else {
+		for (const auto& str : settings.ival_strings) {
+			Interval iv;
+			if (!parse_interval(str, reader.hdr, iv)) return false;
+			overlapping_blocks(reader.index, iv, universe);
+		}
+		std::sort(universe.begin(), universe.end());
+		universe.erase(std::unique(universe.begin(), universe.end()), universe.end());
+		if (universe.empty()) { std::cerr << stamp("ERROR", "INTERVAL") << "Found no blocks overlapping the provided range(s)..." << std::endl; return false; }
+	}
+	const uint32_t n_blocks = (uint32_t)universe.size();
+	if (n_blocks == 0 || n_samples == 0) { std::cerr << stamp("ERROR") << "No valid data available..." << std::endl; return true; }
+
+	if (settings.window) settings.c_chunk = 0;
+	Balancer bal;
+	if (!bal.build(n_blocks, (uint32_t)settings.n_chunks, (uint32_t)settings.c_chunk)) return false;
+	std::cerr << stamp("LOG", "BALANCING") << "Using ranges [" << bal.fromL << "-" << bal.toL << "," << bal.fromR << "-" << bal.toR
+	          << "] in " << (settings.window ? "window mode" : "square mode") << "..." << std::endl;
+
+	// Selected blocks: the L range, then (square chunk only) the R range.
+	std::vector<uint32_t> sel;
+	uint32_t nL = 0, nR = 0;
+	for (uint32_t b = bal.fromL; b < bal.toL; ++b) { sel.push_back(universe[b]); nL += reader.index.ent[universe[b]].n; }
+	if (!bal.diag) for (uint32_t b = bal.fromR; b < bal.toR; ++b) { sel.push_back(universe[b]); nR += reader.index.ent[universe[b]].n; }
+	const uint32_t M = nL + nR;
+	const uint64_t n_cmp = bal.diag ? (uint64_t)M * (M - 1) / 2 : (uint64_t)nL * nR;
+	std::cerr << stamp("LOG") << pretty(M) << " variants from " << pretty(sel.size()) << " blocks..." << std::endl;
+	std::cerr << stamp("LOG", "PARAMS") << settings.GetString() << std::endl;
+	std::cerr << stamp("LOG") << "Performing: " << pretty(n_cmp) << " variant comparisons..." << std::endl;
+
+	DeviceCtx dc;
+	if (!create_device(dc)) return false;
+	if (!hip_ok(dc.ctx, twk_hip_set_problem(dc.ctx, n_samples, M), "twk_hip_set_problem")) return false;
+	const auto t_load = clock::now();
+	const uint32_t T = (uint32_t)std::max(1, settings.n_threads);
+	std::cerr << stamp("LOG", "THREAD") << "Unpacking using " << T << " threads..." << std::endl;
+	if (!load_blocks(settings.in, reader, sel, n_samples, T, dc.ctx, mImpl->rid, mImpl->pos)) return false;
+	std::cerr << stamp("LOG") << "Unpacked and uploaded " << pretty(M) << " variants. "
+	          << elapsed_string(std::chrono::duration<double>(clock::now() - t_load).count()) << std::endl;
+
+	RunSpec spec;
+	spec.nA = bal.diag ? M : nL; spec.nB = bal.diag ? 0 : nR;
+	spec.triangleA = bal.diag; spec.rectAB = !bal.diag;
+	spec.options = settings.window ? TWK_HIP_OPT_WINDOW : 0; spec.l_window = (uint32_t)settings.l_window;
+	if (!mImpl->run(settings, reader.hdr, dc.ctx, n_samples, &spec)) return false;
 	std::cerr << stamp("LOG", "PROGRESS") << "All done..." << elapsed_string(std::chrono::duration<double>(clock::now() - t_load).count()) << "!" << std::endl;
 	return true;
+}
+
+// scalc: one target site against its neighbourhood (ld.cpp:673-876, LoadTargetSingle :123-255,
+// CalculateSingle ld_engine.cpp:2226-2332).
+bool twk_ld::ComputeSingle(bool verbose, bool) {
+	mImpl->n_pairs = mImpl->n_records = 0;
+	if (settings.in.empty()) { std::cerr << stamp("ERROR") << "No file-name provided..." << std::endl; return false; }
+	if (settings.n_chunks != 1) { std::cerr << stamp("ERROR") << "Cannot use chunking in single mode!" << std::endl; return false; }
+	if (settings.window) { std::cerr << stamp("ERROR") << "Cannot use window mode when running in single mode!" << std::endl; return false; }
+	if (settings.ival_strings.size() != 1) { std::cerr << stamp("ERROR") << "Single mode requires exactly one target interval (-I)..." << std::endl; return false; }
+	settings.single = true;
+	if (verbose) std::cerr << stamp("LOG", "READER") << "Opening " << settings.in << "..." << std::endl;
+	TwkReader reader;
+	if (!reader.open(settings.in)) { std::cerr << stamp("ERROR") << "Failed to open file: " << settings.in << "... (" << reader.error << ")" << std::endl; return false; }
+	const uint32_t n_samples = (uint32_t)reader.hdr.samples.size();
+	Interval tgt;
+	if (!parse_interval(settings.ival_strings[0], reader.hdr, tgt)) return false;
+	// Flanks (ld.cpp:145-153), 1-based inclusive matching of pos+1 (ld.cpp:192):
+	//   left  [max(from - l_surrounding, 0), max(from - 1, 0)]    right [to, to + l_surrounding]
+	const uint32_t L = (uint32_t)std::max(0, settings.l_surrounding);
+	const uint32_t left_lo = tgt.from > L ? tgt.from - L : 0, left_hi = tgt.from > 0 ? tgt.from - 1 : 0;
+	const uint32_t right_lo = tgt.to, right_hi = tgt.to + L;
+	std::vector<uint32_t> blocks;
+	overlapping_blocks(reader.index, Interval{tgt.rid, left_lo, right_hi}, blocks);
+	if (blocks.empty()) { std::cerr << stamp("ERROR", "INTERVAL") << "Found no blocks overlapping the provided range(s)..." << std::endl; return false; }
+
+	// Neighbourhoods are small: read the overlapping blocks whole, keep targets first then the rest.
+	std::vector<Variant> targets, others;
+	for (uint32_t b : blocks) {
+		Block blk;
+		if (!reader.read_block(b, blk)) { std::cerr << stamp("ERROR") << "Failed to load block " << b << "..." << std::endl; return false; }
+		for (auto& v : blk.rcds) {
+			if ((int32_t)v.rid != tgt.rid) continue;
+			const uint32_t p1 = v.pos + 1;
+			if (p1 >= tgt.from && p1 <= tgt.to) targets.push_back(std::move(v));
+			else if ((p1 >= left_lo && p1 <= left_hi) || (p1 >= right_lo && p1 <= right_hi)) others.push_back(std::move(v));
+		}
+	}
+	if (targets.empty()) { std::cerr << "no data found for reference" << std::endl; return false; }
+	if (others.empty()) { std::cerr << "no surrounding variants" << std::endl; return false; }
+	const uint32_t nT = (uint32_t)targets.size(), nO = (uint32_t)others.size(), M = nT + nO;
+	if (verbose) std::cerr << stamp("LOG") << pretty(nT) << " target and " << pretty(nO) << " surrounding variants..." << std::endl;
+
+	DeviceCtx dc;
+	if (!create_device(dc)) return false;
+	if (!hip_ok(dc.ctx, twk_hip_set_problem(dc.ctx, n_samples, M), "twk_hip_set_problem")) return false;
+	const size_t w64 = ((size_t)2 * n_samples + 63) / 64;
+	std::vector<uint64_t> data((size_t)M * w64), mask;
+	std::vector<twk_hip_variant_meta> meta(M);
+	bool any_mask = false;
+	for (uint32_t i = 0; i < M; ++i) any_mask |= (i < nT ? targets[i] : others[i - nT]).gt_missing;
+	if (any_mask) mask.assign((size_t)M * w64, 0);
+	mImpl->rid.assign(M, 0); mImpl->pos.assign(M, 0);
+	for (uint32_t i = 0; i < M; ++i) {
+		const Variant& v = i < nT ? targets[i] : others[i - nT];
+		if (!v.build_bitvector(n_samples, &data[(size_t)i * w64], (any_mask && v.gt_missing) ? &mask[(size_t)i * w64] : nullptr)) {
+			std::cerr << stamp("ERROR") << "Corrupt genotype runs!" << std::endl; return false;
+		}
+		twk_hip_variant_meta& mm = meta[i];
+		mm.ac = v.ac; mm.an = v.an; mm.pos = v.pos; mm.rid = v.rid; mm.missing = v.gt_missing ? 1 : 0; mm._pad = 0; mm.hwe = v.hwe;
+		mImpl->rid[i] = v.rid; mImpl->pos[i] = v.pos;
+	}
+	if (!hip_ok(dc.ctx, twk_hip_upload_bitvectors(dc.ctx, 0, M, data.data(), any_mask ? mask.data() : nullptr, w64, meta.data()),
+	            "twk_hip_upload_bitvectors")) return false;
+	RunSpec spec;
+	spec.nA = nT; spec.nB = nO; spec.triangleA = true; spec.rectAB = true;
+	spec.options = TWK_HIP_OPT_KEEP_LOW_AC;      // the skip is commented out in CalculateSingle (:2267-2269)
+	return mImpl->run(settings, reader.hdr, dc.ctx, n_samples, &spec);
 }
 
 }  // namespace tomahawk
