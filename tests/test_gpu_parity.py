@@ -135,6 +135,53 @@ def test_overflow_is_reported_and_recovered(hip):
     assert npairs == M * (M - 1) // 2 and len(recs) > 10
 
 
+def test_ld_all_recovers_from_survivor_overflow(hip, monkeypatch):
+    """Dense output larger than the device record buffer: the tile is redone in row strips."""
+    N, M = 64, 333
+    al = util.random_alleles(M, N, 52)
+    util.upload(hip, al)
+    f = T.Filters(minR2=0.0)
+    whole, npairs, nrec = hip.ld_all(T.MODE_PHASED, f)
+    for cap in ("1000", "777", "50000"):
+        monkeypatch.setenv("TWK_HIP_RECORD_CAP", cap)
+        got, np2, nrec2 = hip.ld_all(T.MODE_PHASED, f, tile_variants=256)
+        assert np2 == npairs and nrec2 == nrec == len(got)
+        key = lambda r: np.lexsort((r["idxB"], r["idxA"]))
+        a, b = whole[key(whole)], got[key(got)]
+        assert np.array_equal(a["idxA"], b["idxA"]) and np.array_equal(a["idxB"], b["idxB"]) and np.array_equal(a["R2"], b["R2"])
+    monkeypatch.delenv("TWK_HIP_RECORD_CAP")
+
+
+@pytest.mark.parametrize("N,M", [(1, 2), (3, 5), (64, 1), (31, 129)])
+def test_degenerate_shapes(hip, N, M):
+    """Tiny problems: one or two variants, a single sample, odd sizes."""
+    al = util.random_alleles(M, N, 61, maf_lo=0.3, maf_hi=0.7)
+    data, mask, variants = util.upload(hip, al)
+    for mode, phased in ((T.MODE_PHASED, True), (T.MODE_UNPHASED, False)):
+        st = O.settings(minR2=0.0, phased=phased, unphased=not phased)
+        want = O.all_pairs(data, mask, variants, N, st) if M > 1 else np.zeros(0, dtype=O.RECORD_DTYPE)
+        got, npairs, nrec = hip.ld_all(mode, T.Filters(minR2=0.0))
+        assert npairs == M * (M - 1) // 2 and nrec == len(want)
+        util.assert_records_match(got, want, variants)
+
+
+def test_invalid_arguments_are_rejected(hip):
+    hip.set_problem(10, 20)
+    hip.generate_synthetic(1)
+    with pytest.raises(T.HipError):
+        hip.count_tile(T.MODE_PHASED, 0, 30, 0, 5)             # rows beyond the problem
+    with pytest.raises(T.HipError):
+        hip.count_tile(T.MODE_AUTO, 0, 5, 0, 5)                # raw cells need an explicit mode
+    with pytest.raises(T.HipError):
+        hip.ld_tile(T.MODE_PHASED, 0, 5, 1, 5, True, T.Filters())   # diag needs the same origin
+    with pytest.raises(T.HipError):
+        hip.ld_all(7, T.Filters())
+    with pytest.raises(T.HipError):
+        hip.ld_all(T.MODE_PHASED, T.Filters(), part=2, n_parts=2)
+    with pytest.raises(T.HipError):
+        hip.set_problem(0, 5)
+
+
 def test_synthetic_generator_matches_host_twin(hip):
     N, M = 1000, 64
     hip.set_problem(N, M)

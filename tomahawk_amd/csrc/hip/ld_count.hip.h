@@ -34,9 +34,6 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#ifndef TWK_EXP
-#define TWK_EXP 0
-#endif
 namespace twk {
 
 constexpr int TILE = 128;       // rows per block tile edge
@@ -209,11 +206,9 @@ void k_count_tile_t(const uint32_t* __restrict__ rows, uint32_t W, uint32_t rowA
 		// Chunk c was issued one contraction ago: drain this wave's DMAs, then
 		// the barrier makes every wave's part visible and proves every wave is
 		// done reading the other buffer (chunk c-1).
-#if !(TWK_EXP & 2)
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		__syncthreads();
-#endif
-		if (c + 1 < nchunks && !(TWK_EXP & 4))
+		if (c + 1 < nchunks)
 			stage_rows(rows, W, st_row0, c + 1, st_lds + (buf ^ 1) * (2 * LDS_TILE_BYTES), st_seg0, NSEG, lane);
 
 		const char* base = lds_b + buf * (2 * LDS_TILE_BYTES);

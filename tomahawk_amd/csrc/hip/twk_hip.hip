@@ -648,7 +648,11 @@ int twk_hip_ld_region(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint32
 
 	uint64_t tot_pairs = 0, tot_recs = 0;
 	// Worst case every pair of a tile survives; cap the device buffer and split on overflow.
-	const unsigned long long cap_default = std::min<unsigned long long>((unsigned long long)S * S, 1ull << 24);
+	unsigned long long cap_default = std::min<unsigned long long>((unsigned long long)S * S, 1ull << 24);
+	if (const char* e = std::getenv("TWK_HIP_RECORD_CAP")) {       // test hook: force the overflow / strip path
+		const unsigned long long v = std::strtoull(e, nullptr, 10);
+		if (v) cap_default = std::min(cap_default, v);
+	}
 	int rc = TWK_HIP_OK;
 	size_t issued = 0, done = 0;
 	const size_t n = mine.size();
