@@ -63,6 +63,7 @@ struct twk_hip_ctx {
 	Slot slot[3];                  // [0],[1]: ld_all pipeline; [2]: synchronous single-tile calls
 	twk_hip_record* h_recs = nullptr; unsigned long long h_recs_cap = 0;   // pinned staging
 	twk_hip_timing timing{};
+	uint32_t resident_blocks = 512;   // count-kernel blocks the chip holds at once (2 per CU)
 	char err[512] = {0};
 };
 
@@ -384,6 +385,10 @@ int twk_hip_ctx_create(int device, twk_hip_ctx** out) {
 	c->device = device;
 	auto fail = [&](int code) { twk_hip_ctx_destroy(c); return code; };
 	if (hipSetDevice(device) != hipSuccess) return fail(TWK_HIP_E_DEVICE);
+	{
+		int cus = 0;
+		if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->resident_blocks = 2u * (uint32_t)cus;
+	}
 	if (hipStreamCreateWithFlags(&c->s_compute, hipStreamNonBlocking) != hipSuccess) return fail(TWK_HIP_E_DEVICE);
 	if (hipStreamCreateWithFlags(&c->s_copy, hipStreamNonBlocking) != hipSuccess) return fail(TWK_HIP_E_DEVICE);
 	for (auto& s : c->slot) {
@@ -639,16 +644,41 @@ int twk_hip_ld_region(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint32
 		}
 		mine.push_back(t);
 	};
+	// Column step per row block.  A launch of B blocks takes ceil(B / resident) rounds of (equal
+	// length) blocks, so the partial last round is pure loss.  With the default tiling the column
+	// step is chosen, per row block, to minimise the total number of rounds (ties: fewer launches);
+	// it matters for the thin bands of a multi-GPU shard.  C stays <= 2 GiB per tile.
+	auto rows_of = [&](uint32_t nv) -> uint64_t { return ((uint64_t)nv * Pmax + TILE - 1) / TILE; };
+	auto choose_col_step = [&](uint32_t h, uint32_t col0) -> uint32_t {
+		if (tile_variants || col0 >= nB) return S;
+		const uint64_t R = c->resident_blocks, ra = rows_of(h);
+		const uint64_t max_rows_b = std::min<uint64_t>(((2ull << 30) / 4) / (ra * TILE) , 32768ull * Pmax) / TILE;   // blocks
+		uint32_t best = S; uint64_t best_cost = ~0ull;
+		for (uint32_t sc = 64; sc <= 32768; sc += 64) {
+			if (rows_of(sc) > max_rows_b) break;
+			if (sc * 4 < S) continue;                               // keep launches reasonably large
+			uint64_t cost = 0;
+			for (uint32_t col = col0; col < nB; col += sc) cost += (ra * rows_of(std::min(sc, nB - col)) + R - 1) / R;
+			if (cost < best_cost || (cost == best_cost && sc > best)) { best_cost = cost; best = sc; }
+		}
+		return best;
+	};
 	for (uint32_t x = r0; x < r1; x += S) {
 		const uint32_t h = std::min(S, r1 - x);
 		uint32_t col = 0;
 		if (triangle) { push_tile(x, h, x, h, 1); col = x + h; }     // aligned square on the diagonal
-		for (; col < nB; col += S) push_tile(x, h, col, std::min(S, nB - col), 0);
+		const uint32_t sc = choose_col_step(h, col);
+		for (; col < nB; col += sc) push_tile(x, h, col, std::min(sc, nB - col), 0);
 	}
 
 	uint64_t tot_pairs = 0, tot_recs = 0;
 	// Worst case every pair of a tile survives; cap the device buffer and split on overflow.
-	unsigned long long cap_default = std::min<unsigned long long>((unsigned long long)S * S, 1ull << 24);
+	unsigned long long cap_default = 1ull << 24;
+	{
+		unsigned long long worst = 0;
+		for (const auto& t : mine) worst = std::max<unsigned long long>(worst, (unsigned long long)t.nA * t.nB);
+		cap_default = std::min<unsigned long long>(worst ? worst : 1, 1ull << 24);
+	}
 	if (const char* e = std::getenv("TWK_HIP_RECORD_CAP")) {       // test hook: force the overflow / strip path
 		const unsigned long long v = std::strtoull(e, nullptr, 10);
 		if (v) cap_default = std::min(cap_default, v);
