@@ -68,8 +68,9 @@ typedef struct {
 /* A rectangular slice of the variant-pair space, in variant indices as
  * uploaded.  Replaces one ticket of twk_ld_dynamic_balancer::GetBlockPair
  * (lib/ld/ld_balancing.h:214-233): rows [rowA0,rowA0+nA) x cols [rowB0,rowB0+nB).
- * When diag != 0 (requires rowA0 == rowB0, nA == nB) only pairs with col > row
- * are evaluated (ticket type 1, ld_engine.cpp:1913-1933). */
+ * When diag != 0 (requires rowA0 == rowB0, nB >= nA) only pairs with col > row
+ * are evaluated (ticket type 1, ld_engine.cpp:1913-1933); the columns beyond nA
+ * form the rectangle to the right of the diagonal square. */
 typedef struct {
 	uint32_t rowA0, nA, rowB0, nB;
 	int32_t  diag;

@@ -190,7 +190,7 @@ int launch_count(twk_hip_ctx* c, int kind, const twk_hip_tile_desc& t, Slot& s, 
 	                   t.rowA0 * P, t.rowB0 * P, diag, s.C, g.ldc);
 	HIPCHK(c, hipGetLastError());
 	HIPCHK(c, hipEventRecord(e1, c->s_compute));
-	const uint64_t tiles = diag ? (uint64_t)g.gy * (g.gy + 1) / 2 : (uint64_t)g.gx * g.gy;
+	const uint64_t tiles = diag ? (uint64_t)g.gy * (g.gy + 1) / 2 + (uint64_t)g.gy * (g.gx - g.gy) : (uint64_t)g.gx * g.gy;
 	*row_pairs = tiles * TILE * TILE;
 	return TWK_HIP_OK;
 }
@@ -343,7 +343,7 @@ bool valid_mode(int m) { return m == TWK_HIP_MODE_PHASED || m == TWK_HIP_MODE_UN
 bool valid_tile(const twk_hip_ctx* c, const twk_hip_tile_desc* t) {
 	if (!t || t->nA == 0 || t->nB == 0 || t->nA > 32768 || t->nB > 32768) return false;
 	if ((uint64_t)t->rowA0 + t->nA > c->M || (uint64_t)t->rowB0 + t->nB > c->M) return false;
-	if (t->diag && (t->rowA0 != t->rowB0 || t->nA != t->nB)) return false;
+	if (t->diag && (t->rowA0 != t->rowB0 || t->nB < t->nA)) return false;
 	return true;
 }
 
@@ -649,26 +649,35 @@ int twk_hip_ld_region(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint32
 	// step is chosen, per row block, to minimise the total number of rounds (ties: fewer launches);
 	// it matters for the thin bands of a multi-GPU shard.  C stays <= 2 GiB per tile.
 	auto rows_of = [&](uint32_t nv) -> uint64_t { return ((uint64_t)nv * Pmax + TILE - 1) / TILE; };
-	auto choose_col_step = [&](uint32_t h, uint32_t col0) -> uint32_t {
-		if (tile_variants || col0 >= nB) return S;
+	// blocks of a launch: a diagonal tile only runs the blocks on and above its diagonal
+	auto blocks_of = [&](uint32_t h, uint32_t w, bool diag) -> uint64_t {
+		const uint64_t ra = rows_of(h), rb = rows_of(w);
+		return diag ? ra * (ra + 1) / 2 + ra * (rb - ra) : ra * rb;
+	};
+	auto choose_col_step = [&](uint32_t h, uint32_t col0, bool first_is_diag) -> uint32_t {
+		// window mode: keep square tiles so that whole out-of-window tiles can be skipped
+		if (tile_variants || (window & TWK_HIP_OPT_WINDOW) || col0 >= nB) return std::max(S, h);
 		const uint64_t R = c->resident_blocks, ra = rows_of(h);
-		const uint64_t max_rows_b = std::min<uint64_t>(((2ull << 30) / 4) / (ra * TILE) , 32768ull * Pmax) / TILE;   // blocks
-		uint32_t best = S; uint64_t best_cost = ~0ull;
-		for (uint32_t sc = 64; sc <= 32768; sc += 64) {
+		const uint64_t max_rows_b = std::min<uint64_t>(((2ull << 30) / 4) / (ra * TILE), 32768ull * Pmax / TILE);   // blocks
+		uint32_t best = std::max(S, h); uint64_t best_cost = ~0ull;
+		for (uint32_t sc = round_up(h, 64); sc <= 32768; sc += 64) {
 			if (rows_of(sc) > max_rows_b) break;
 			if (sc * 4 < S) continue;                               // keep launches reasonably large
-			uint64_t cost = 0;
-			for (uint32_t col = col0; col < nB; col += sc) cost += (ra * rows_of(std::min(sc, nB - col)) + R - 1) / R;
+			uint64_t cost = 0; bool diag = first_is_diag;
+			for (uint32_t col = col0; col < nB; col += sc, diag = false)
+				cost += (blocks_of(h, std::min(sc, nB - col), diag) + R - 1) / R;
 			if (cost < best_cost || (cost == best_cost && sc > best)) { best_cost = cost; best = sc; }
 		}
 		return best;
 	};
 	for (uint32_t x = r0; x < r1; x += S) {
 		const uint32_t h = std::min(S, r1 - x);
-		uint32_t col = 0;
-		if (triangle) { push_tile(x, h, x, h, 1); col = x + h; }     // aligned square on the diagonal
-		const uint32_t sc = choose_col_step(h, col);
-		for (; col < nB; col += sc) push_tile(x, h, col, std::min(sc, nB - col), 0);
+		// triangle: the first tile of the row block starts on the diagonal (rows [x,x+h) x cols [x,x+w),
+		// w >= h, only col > row) and continues into the rectangle to its right in the same launch
+		uint32_t col = triangle ? x : 0;
+		const uint32_t sc = choose_col_step(h, col, triangle != 0);
+		bool diag = triangle != 0;
+		for (; col < nB; col += sc, diag = false) push_tile(x, h, col, std::min(sc, nB - col), diag ? 1 : 0);
 	}
 
 	uint64_t tot_pairs = 0, tot_recs = 0;
