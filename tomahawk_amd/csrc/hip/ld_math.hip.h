@@ -132,11 +132,10 @@ __device__ inline bool d_phased_math(uint64_t c0, uint64_t c1, uint64_t c4, uint
 	else        dmax = g0 * g1 < h0 * h1 ? -g0 * g1 : -h0 * h1;
 	const double Dprime = D / dmax;
 	if (Dprime < f.minDprime || Dprime > f.maxDprime) return false;
-	const double both = d_fisher_two((int)c0, (int)c4, (int)c1, (int)c5);
-	if (both > f.minP) return false;
+	// Fisher's exact test (:1221-1231) runs in k_ld_fisher on the compacted survivors
 	rec->idxA = A; rec->idxB = B; rec->_pad = 0;
 	rec->cnt[0] = (double)c0; rec->cnt[1] = (double)c1; rec->cnt[2] = (double)c4; rec->cnt[3] = (double)c5;
-	rec->D = D; rec->Dprime = Dprime; rec->R = sqrt(R2); rec->R2 = R2; rec->P = both;
+	rec->D = D; rec->Dprime = Dprime; rec->R = sqrt(R2); rec->R2 = R2; rec->P = 0;
 	rec->ChiSqFisher = T * R2; rec->ChiSqModel = 0;
 	rec->flags = d_common_flags(vm, A, B, rec->cnt, R2) | 1u;
 	return true;
@@ -190,11 +189,10 @@ __device__ inline bool d_choose_f11(double total, double target, double p, doubl
 	else        dmax = p * q < (1 - p) * (1 - q) ? -p * q : -(1 - p) * (1 - q);
 	const double Dprime = D / dmax;
 	if (Dprime < f.minDprime || Dprime > f.maxDprime) return false;
-	const double both = d_fisher_two((int)round(cnt[0]), (int)round(cnt[2]), (int)round(cnt[1]), (int)round(cnt[3]));
-	if (both > f.minP) return false;
+	// Fisher's exact test on the rounded counts (:1655-1664) runs in k_ld_fisher
 	rec->idxA = A; rec->idxB = B; rec->_pad = 0;
 	rec->cnt[0] = cnt[0]; rec->cnt[1] = cnt[1]; rec->cnt[2] = cnt[2]; rec->cnt[3] = cnt[3];
-	rec->D = D; rec->Dprime = Dprime; rec->R = sqrt(R2); rec->R2 = R2; rec->P = both;
+	rec->D = D; rec->Dprime = Dprime; rec->R = sqrt(R2); rec->R2 = R2; rec->P = 0;
 	rec->ChiSqModel = 0;
 	rec->ChiSqFisher = (cnt[0] + cnt[2] + cnt[1] + cnt[3]) * R2;
 	rec->flags = pre_flags | d_common_flags(vm, A, B, cnt, R2);
@@ -417,6 +415,27 @@ void k_ld_stats(const StatsParams p) {
 			const unsigned long long slot = base + __popcll(ballot & ((1ull << lane) - 1));
 			if (slot < p.capacity) p.out[slot] = rec;
 		}
+	}
+}
+
+// Second stage of the math: Fisher's exact test on the compacted survivors (one thread per
+// record, grid-stride).  Inside k_ld_stats the test's data-dependent loops (up to min(n1_, n_1)
+// iterations) would run with one live lane per wave while 63 wait; here every lane has a record.
+// Arguments as at ld_engine.cpp:1222-1226 (integer cells) / :1656-1658 (round() of the expected
+// haplotype counts): n11 = cnt[0], n12 = cnt[2] (REFALT slot), n21 = cnt[1], n22 = cnt[3].
+// Records with P > minP are dropped (:1228, :1661): marked idxA = 0xFFFFFFFF for the host.
+#define TWK_DROPPED_RECORD 0xFFFFFFFFu
+__global__ __launch_bounds__(256)
+void k_ld_fisher(twk_hip_record* __restrict__ recs, const unsigned long long* __restrict__ n_out,
+                 unsigned long long capacity, double minP) {
+	unsigned long long n = *n_out;
+	if (n > capacity) n = capacity;
+	for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+	     i += (unsigned long long)gridDim.x * blockDim.x) {
+		twk_hip_record* r = recs + i;
+		const double both = d_fisher_two((int)round(r->cnt[0]), (int)round(r->cnt[2]), (int)round(r->cnt[1]), (int)round(r->cnt[3]));
+		r->P = both;
+		if (both > minP) r->idxA = TWK_DROPPED_RECORD;
 	}
 }
 

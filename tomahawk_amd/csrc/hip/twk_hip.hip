@@ -42,6 +42,7 @@ struct Slot {                      // one in-flight tile (double buffered)
 	unsigned long long* h_n_out = nullptr;        // pinned host copy
 	hipEvent_t ev_c0 = nullptr, ev_c1 = nullptr, ev_s1 = nullptr, ev_c0b = nullptr, ev_c1b = nullptr;
 	bool two_pass = false;
+	double minP = 1.0;
 	uint64_t row_pairs = 0, row_pairs_b = 0;
 };
 
@@ -247,6 +248,9 @@ int enqueue_tile(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, const twk
 		hipLaunchKernelGGL(k_ld_stats, dim3((t.nB + 255) / 256, t.nA), dim3(256), 0, c->s_compute, p);
 		HIPCHK(c, hipGetLastError());
 	}
+	hipLaunchKernelGGL(k_ld_fisher, dim3(c->resident_blocks * 2), dim3(256), 0, c->s_compute, s.out, s.n_out, s.capacity, f.minP);
+	HIPCHK(c, hipGetLastError());
+	s.minP = f.minP;
 	HIPCHK(c, hipMemcpyAsync(s.h_n_out, s.n_out, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->s_compute));
 	HIPCHK(c, hipEventRecord(s.ev_s1, c->s_compute));
 	return TWK_HIP_OK;
@@ -279,6 +283,12 @@ int finish_tile(twk_hip_ctx* c, Slot& s, const twk_hip_tile_desc& t, unsigned lo
 		int rc = ensure_host_records(c, n); if (rc) return rc;
 		HIPCHK(c, hipMemcpyAsync(c->h_recs, s.out, (size_t)n * sizeof(twk_hip_record), hipMemcpyDeviceToHost, c->s_copy));
 		HIPCHK(c, hipStreamSynchronize(c->s_copy));
+		if (s.minP < 1.0) {        // records that failed the Fisher cutoff were only marked on the device
+			unsigned long long k = 0;
+			for (unsigned long long i = 0; i < n; ++i)
+				if (c->h_recs[i].idxA != TWK_DROPPED_RECORD) { if (k != i) c->h_recs[k] = c->h_recs[i]; ++k; }
+			*n_out = k;
+		}
 	}
 	return TWK_HIP_OK;
 }

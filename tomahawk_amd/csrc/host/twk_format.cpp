@@ -352,25 +352,36 @@ bool TwoWriter::open(const std::string& path, const Header& hdr, int c_level) {
 	return true;
 }
 
-bool TwoWriter::write_block(const TwoRecord* recs, uint32_t n) {
-	if (n == 0) return true;
+bool TwoWriter::pack(const TwoRecord* recs, uint32_t n, int c_level, Packed& out) {
 	ByteBuf b;
 	b.put<uint32_t>(n); b.put<uint32_t>(n);               // core.cpp:626-631 (n, m)
 	b.put_bytes(recs, (size_t)n * sizeof(TwoRecord));
-	std::vector<uint8_t> z;
-	if (!zstd_compress(b.v.data(), b.v.size(), z, c_level_)) return false;
-	IndexEntryOutput e;                                   // ld_engine.cpp:1270-1288,1757-1763
+	if (!zstd_compress(b.v.data(), b.v.size(), out.z, c_level)) return false;
+	IndexEntryOutput& e = out.entry;                      // ld_engine.cpp:1270-1288,1757-1763
+	e = IndexEntryOutput();
 	e.rid = (int32_t)recs[0].ridA; e.ridB = (int32_t)recs[0].ridB;
 	e.minpos = recs[0].Apos(); e.maxpos = recs[n - 1].Apos();
 	for (uint32_t i = 1; i < n; ++i) if ((int32_t)recs[i].ridB != e.ridB) { e.ridB = -1; break; }
-	e.n = n; e.b_unc = 106u * n + 8u; e.b_cmp = (uint32_t)z.size();
+	e.n = n; e.b_unc = 106u * n + 8u; e.b_cmp = (uint32_t)out.z.size();
+	out.b_unc = (uint32_t)b.size();
+	return true;
+}
+
+bool TwoWriter::write_packed(const Packed& p) {
+	IndexEntryOutput e = p.entry;
 	e.foff = off_;
-	const uint8_t marker = 1; const uint32_t unc = (uint32_t)b.size(), cmp = (uint32_t)z.size();
-	if (!put(&marker, 1) || !put(&unc, 4) || !put(&cmp, 4) || !put(z.data(), z.size())) return false;
+	const uint8_t marker = 1; const uint32_t unc = p.b_unc, cmp = (uint32_t)p.z.size();
+	if (!put(&marker, 1) || !put(&unc, 4) || !put(&cmp, 4) || !put(p.z.data(), p.z.size())) return false;
 	e.fend = off_;
 	index_.ent.push_back(e);
-	n_records += n; ++n_blocks;
+	n_records += e.n; ++n_blocks;
 	return true;
+}
+
+bool TwoWriter::write_block(const TwoRecord* recs, uint32_t n) {
+	if (n == 0) return true;
+	Packed p;
+	return pack(recs, n, c_level_, p) && write_packed(p);
 }
 
 bool TwoWriter::close() { // writer.h:293-313

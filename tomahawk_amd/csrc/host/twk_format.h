@@ -154,6 +154,12 @@ public:
 	// One block: u32 n, u32 m, n records -> zstd -> [1][b_unc][b_cmp][bytes]
 	// plus its IndexEntryOutput (ld_engine.cpp:1742-1802, writer.h:70-87).
 	bool write_block(const TwoRecord* recs, uint32_t n);
+	// The same in two steps so that compression can run on worker threads:
+	// pack() is thread-safe and touches no writer state; write_packed() appends in call order.
+	struct Packed { std::vector<uint8_t> z; IndexEntryOutput entry; uint32_t b_unc = 0; };
+	static bool pack(const TwoRecord* recs, uint32_t n, int c_level, Packed& out);
+	bool write_packed(const Packed& p);
+	int  compression_level() const { return c_level_; }
 	bool close();             // writer.h:293-313
 	uint64_t n_records = 0, n_blocks = 0;
 private:

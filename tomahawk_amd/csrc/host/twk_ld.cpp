@@ -8,6 +8,7 @@
 #include "twk_ld.h"
 
 #include <algorithm>
+#include <memory>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -18,6 +19,9 @@
 #include <regex>
 #include <sstream>
 #include <thread>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <sys/time.h>
 
 #include "twk_format.h"
@@ -133,10 +137,76 @@ public:
 	bool write_failed = false;
 	std::vector<twk_hip_record> sort_buf;
 
+	// Block compression runs on worker threads (the reference compresses on its n_threads LD
+	// threads, ld_engine.cpp:1742-1802); blocks are appended to the file in submission order.
+	struct Job { std::vector<TwoRecord> recs; TwoWriter::Packed packed; bool done = false, ok = true; };
+	std::deque<std::shared_ptr<Job>> pending;     // submission order
+	std::deque<std::shared_ptr<Job>> todo;        // not yet picked by a worker
+	std::vector<std::thread> workers;
+	std::mutex mu;
+	std::condition_variable cv_work, cv_done;
+	bool stopping = false;
+	int c_level = 1;
+
+	void start_workers(int n, int level) {
+		c_level = level; stopping = false;
+		for (int i = 0; i < std::max(1, n); ++i) workers.emplace_back([this] {
+			for (;;) {
+				std::shared_ptr<Job> j;
+				{
+					std::unique_lock<std::mutex> lk(mu);
+					cv_work.wait(lk, [this] { return stopping || !todo.empty(); });
+					if (todo.empty()) return;
+					j = todo.front(); todo.pop_front();
+				}
+				const bool ok = TwoWriter::pack(j->recs.data(), (uint32_t)j->recs.size(), c_level, j->packed);
+				{ std::lock_guard<std::mutex> lk(mu); j->ok = ok; j->done = true; }
+				cv_done.notify_all();
+			}
+		});
+	}
+	// write every finished block at the head of the queue; wait == true drains everything
+	bool drain(bool wait) {
+		std::unique_lock<std::mutex> lk(mu);
+		for (;;) {
+			while (!pending.empty() && pending.front()->done) {
+				auto j = pending.front(); pending.pop_front();
+				lk.unlock();
+				const bool ok = j->ok && writer.write_packed(j->packed);
+				lk.lock();
+				if (!ok) return false;
+			}
+			if (!wait || pending.empty()) return true;
+			cv_done.wait(lk, [this] { return pending.front()->done; });
+		}
+	}
+	void stop_workers() {
+		{ std::lock_guard<std::mutex> lk(mu); stopping = true; }
+		cv_work.notify_all();
+		for (auto& t : workers) t.join();
+		workers.clear();
+	}
+	bool submit(std::vector<TwoRecord>& blk) {
+		if (blk.empty()) return true;
+		auto j = std::make_shared<Job>();
+		j->recs.swap(blk);
+		{
+			std::unique_lock<std::mutex> lk(mu);
+			pending.push_back(j); todo.push_back(j);
+		}
+		cv_work.notify_one();
+		// bound the memory in flight: ~256 blocks of <= b_size records
+		while (true) {
+			{ std::lock_guard<std::mutex> lk(mu); if (pending.size() < 256) break; }
+			if (!drain(false)) return false;
+			std::unique_lock<std::mutex> lk(mu);
+			if (pending.size() >= 256) cv_done.wait(lk, [this] { return pending.front()->done; });
+		}
+		return drain(false);
+	}
+
 	bool flush() { // CompressBlock (ld_engine.cpp:1804-1810): forward, then reverse
-		if (!blk_f.empty()) { if (!writer.write_block(blk_f.data(), (uint32_t)blk_f.size())) return false; blk_f.clear(); }
-		if (!blk_r.empty()) { if (!writer.write_block(blk_r.data(), (uint32_t)blk_r.size())) return false; blk_r.clear(); }
-		return true;
+		return submit(blk_f) && submit(blk_r);
 	}
 
 	bool add(const twk_hip_record& r) {
@@ -344,6 +414,8 @@ bool twk_ld::twk_ld_impl::run(twk_ld_settings& settings, const Header& hdr, twk_
 	if (!open_output(settings, hdr, writer)) return false;
 	b_size = (uint32_t)std::max(2, settings.b_size);
 	blk_f.clear(); blk_r.clear(); write_failed = false; n_records = 0; n_pairs = 0;
+	start_workers(std::min(std::max(1, settings.n_threads), 64), settings.c_level);
+	struct StopGuard { twk_ld_impl* s; ~StopGuard() { s->stop_workers(); } } stop_guard{this};
 	const int mode = settings.single ? TWK_HIP_MODE_AUTO
 	               : settings.force_phased ? TWK_HIP_MODE_PHASED : (settings.forced_unphased ? TWK_HIP_MODE_UNPHASED : TWK_HIP_MODE_AUTO);
 	twk_hip_filters f{settings.minR2, settings.maxR2, settings.minDprime, settings.maxDprime, settings.minP};
@@ -360,7 +432,7 @@ bool twk_ld::twk_ld_impl::run(twk_ld_settings& settings, const Header& hdr, twk_
 	}
 	if (write_failed) { std::cerr << stamp("ERROR", "WRITER") << "Failed to write output block!" << std::endl; return false; }
 	if (!hip_ok(ctx, rc, "twk_hip_ld_region")) return false;
-	if (!flush()) { std::cerr << stamp("ERROR", "WRITER") << "Failed to write output block!" << std::endl; return false; }
+	if (!flush() || !drain(true)) { std::cerr << stamp("ERROR", "WRITER") << "Failed to write output block!" << std::endl; return false; }
 	const double sec = std::chrono::duration<double>(clock::now() - t0).count();
 	std::cerr << stamp("PROGRESS") << "Finished in " << elapsed_string(sec) << ". Variants: " << pretty(n_pairs) << ", genotypes: "
 	          << pretty(n_pairs * n_samples) << ", output: " << pretty(n_records) << std::endl;
