@@ -48,7 +48,7 @@ VALU_PAIR_PEAK = 256 * 4 * 64 / 6.0 * 2.4e9   # and(2 cyc)+bcnt(4 cyc) per wave6
 def cpu_baseline(n_samples, mode, seed, log):
     """Time the reference's SSE4.2 calc path (oracle/_ref) on a bounded sample of the same workload."""
     from oracle import oracle as O
-    from tests import hostlib
+    from tomahawk_amd import hostlib
     cores = os.cpu_count() or 1
     if not O.have_ref():
         return None

@@ -27,7 +27,8 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 
 from oracle import oracle as O          # noqa: E402
-from tests import util, hostlib        # noqa: E402
+from tests import util                  # noqa: E402
+from tomahawk_amd import hostlib        # noqa: E402
 
 CASES = {
     # name: (N, M, seed, kwargs for util.random_alleles, n_contigs, block_size)

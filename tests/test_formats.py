@@ -8,7 +8,8 @@ import pytest
 
 import tomahawk_amd as T
 from oracle import oracle as O
-from tests import hostlib, util
+from tests import util
+from tomahawk_amd import hostlib
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
@@ -120,3 +121,26 @@ def test_cli_usage_and_errors():
     assert r.returncode == 1 and "non-positive window" in r.stderr
     r = subprocess.run([hostlib.CLI_PATH, "view"], capture_output=True, text=True)
     assert r.returncode == 1 and "Illegal command" in r.stderr
+
+
+def test_concat_copies_blocks_and_rebases_index(tmp_path):
+    """`tomahawk concat` (lib/concat.h): two copies of a reference-written .two -> every record twice, valid index."""
+    import subprocess
+    src = os.path.join(GOLDEN, "ref_n64_small_p.two")
+    out = str(tmp_path / "cat")
+    r = subprocess.run([hostlib.CLI_PATH, "concat", "-i", src, "-i", src, "-o", out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    one, info1 = hostlib.read_two(src)
+    two, info2 = hostlib.read_two(out + ".two")           # read_two also checks index vs block stream
+    assert len(two) == 2 * len(one) and info2["n_blocks"] == 2 * info1["n_blocks"]
+    assert two[: len(one)].tobytes() == one.tobytes() and two[len(one):].tobytes() == one.tobytes()
+    assert "##tomahawk_concatCommand=tomahawk concat" in hostlib.header_literals(out + ".two")
+    if O.have_ref():                                       # the reference reads what we wrote
+        d = O.run_ref(["dump", out + ".two"]).stdout.splitlines()
+        assert len([l for l in d if not l.startswith("#")]) == len(two)
+    lst = tmp_path / "files.txt"
+    lst.write_text(src + "\n" + src + "\n" + src + "\n")
+    r = subprocess.run([hostlib.CLI_PATH, "concat", "-I", str(lst), "-o", str(tmp_path / "c3.two")], capture_output=True, text=True)
+    assert r.returncode == 0 and len(hostlib.read_two(str(tmp_path / "c3.two"))[0]) == 3 * len(one)
+    r = subprocess.run([hostlib.CLI_PATH, "concat", "-i", src, "-o", out], capture_output=True, text=True)
+    assert r.returncode == 1 and "Only one input file" in r.stderr

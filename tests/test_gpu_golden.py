@@ -8,7 +8,8 @@ import pytest
 
 import tomahawk_amd as T
 from oracle import oracle as O
-from tests import hostlib, util
+from tests import util
+from tomahawk_amd import hostlib
 
 pytestmark = pytest.mark.gpu
 
@@ -186,3 +187,23 @@ def test_cli_window_mode(tmp_path):
     sel = whole[np.abs(whole[:, 2] - whole[:, 4]) <= 20000]
     key = lambda m: m[np.lexsort((m[:, 4], m[:, 2]))]
     assert 0 < len(win) < len(whole) and np.array_equal(key(win), key(sel))
+
+
+def test_cli_multi_process_shards_equal_single(tmp_path):
+    """TWK_HIP_GPUS=n: one worker process per shard (here all on GPU 0), parts concatenated."""
+    N, M = 80, 500
+    al = util.random_alleles(M, N, 77)
+    pos = (1000 + 10 * np.arange(M)).astype(np.uint32)
+    twk = str(tmp_path / "in.twk")
+    hostlib.write_twk(twk, al, pos, np.zeros(M, np.uint32), np.ones(M, np.uint8), block_size=50)
+    def run(env_extra, out):
+        env = dict(os.environ, **env_extra)
+        r = subprocess.run([hostlib.CLI_PATH, "calc", "-i", twk, "-o", out, "-r", "0.02", "-u"], capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr
+        return hostlib.two_as_matrix(hostlib.read_two(out)[0]), r.stderr
+    whole, _ = run({}, str(tmp_path / "w.two"))
+    # three workers; every worker is pinned to device 0 because the box has one GPU
+    multi, log = run({"TWK_HIP_GPUS": "3", "TWK_HIP_FORCE_DEVICE": "0"}, str(tmp_path / "m.two"))
+    key = lambda m: m[np.lexsort((m[:, 4], m[:, 2]))]
+    assert len(whole) > 0 and np.array_equal(key(whole), key(multi))
+    assert "Merged 3 GPU shards" in log and not [f for f in os.listdir(tmp_path) if ".part" in f]

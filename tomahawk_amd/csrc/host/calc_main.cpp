@@ -6,6 +6,11 @@
 #include <iostream>
 #include <regex>
 #include <string>
+#include <vector>
+#include <fstream>
+#include <ctime>
+#include <unistd.h>
+#include <sys/wait.h>
 
 #include "twk_ld.h"
 #include "twk_format.h"
@@ -18,6 +23,9 @@ static void program_message() {
 	          << "Libraries: tomahawk_amd; ZSTD-" << tomahawk::zstd_version() << "; twk_hip ABI " << twk_hip_abi_version() << "\n"
 	          << "----------" << std::endl;
 }
+
+static std::vector<std::string> g_argv;     // argv as given (getopt_long permutes the live one)
+static int launch_multi_gpu(int n_gpus, const std::string& out_final);
 
 static void calc_usage() {
 	program_message();
@@ -41,7 +49,8 @@ static void calc_usage() {
 	"  -P FLOAT  Fisher's exact test / Chi-squared cutoff P-value (default: 1)\n"
 	"  -r FLOAT  Pearson's R-squared minimum cut-off value (default: 0.1)\n"
 	"  -k INT    compression level to use (default: 1, max = 22).\n"
-	"Environment: TWK_HIP_DEVICE=<n> selects the GPU (default 0).\n" << std::endl;
+	"Environment: TWK_HIP_DEVICE=<n> selects the GPU (default 0); TWK_HIP_GPUS=<n> runs one worker\n"
+	"             process per GPU on n GPUs (equal-area row bands) and concatenates their output.\n" << std::endl;
 }
 
 static std::string stamp(const char* t) { return std::string("[") + t + "] "; }
@@ -109,10 +118,105 @@ static int calc(int argc, char** argv) {
 	}
 	if (settings.in.empty()) { std::cerr << stamp("ERROR") << "No input value specified..." << std::endl; return 1; }
 	if (settings.out.empty()) { std::cerr << stamp("ERROR") << "No output value specified..." << std::endl; return 1; }
+	if (const char* g = std::getenv("TWK_HIP_GPUS")) {
+		const int n = atoi(g);
+		if (n > 1) {
+			return launch_multi_gpu(n, settings.out);
+		}
+	}
 	program_message();
 	std::cerr << stamp("LOG") << "Calling calc..." << std::endl;
 	tomahawk::twk_ld ld;
 	return ld.Compute(settings) ? 0 : 1;
+}
+
+// `tomahawk concat` (lib/concat.h:63-251): copy the compressed blocks of several .two files into one.
+static int concat(int argc, char** argv) {
+	if (argc < 3) {
+		program_message();
+		std::cerr << "About:  Concatenate two or more TWO files\n\n"
+		             "Usage:  tomahawk concat [options] -i <in.two> -i <in.two> -o <out.two>\n\n"
+		             "Options:\n  -i FILE    input TWO file specified 1-or-more times (required)\n"
+		             "  -I STRING  input file list (required)\n  -o FILE    output file (- for stdout; default: -)\n" << std::endl;
+		return 0;
+	}
+	std::vector<std::string> in_list, lists;
+	std::string out = "-";
+	int c;
+	while ((c = getopt(argc, argv, "i:I:o:?")) != -1) {
+		switch (c) {
+		case 'i': in_list.push_back(optarg); break;
+		case 'I': lists.push_back(optarg); break;
+		case 'o': out = optarg; break;
+		default: fprintf(stderr, "%s: option `-%c' is invalid: ignored\n", argv[0], optopt); break;
+		}
+	}
+	for (const auto& l : lists) {
+		std::ifstream f(l);
+		if (!f.good()) { std::cerr << "faield to open list=" << l << std::endl; return 1; }
+		std::string line;
+		while (std::getline(f, line)) if (!line.empty()) in_list.push_back(line);
+	}
+	if (in_list.empty()) { std::cerr << stamp("ERROR") << "No input value specified..." << std::endl; return 1; }
+	if (in_list.size() == 1) { std::cerr << stamp("ERROR") << "Only one input file provided..." << std::endl; return 1; }
+	if (out != "-") {      // extension forced to .two like calc (concat.h:163-171)
+		const size_t sl = out.find_last_of("/\\"), dot = out.rfind('.');
+		const std::string ext = (dot == std::string::npos || (sl != std::string::npos && dot < sl)) ? "" : out.substr(dot + 1);
+		if (!(ext.size() == 3 && strncasecmp(ext.c_str(), "two", 3) == 0)) out += ".two";
+	}
+	char date[64]; time_t t = time(nullptr); struct tm now; localtime_r(&t, &now);
+	strftime(date, sizeof(date), "%Y-%m-%d %H:%M:%S", &now);
+	const std::string note = "\n##tomahawk_concatVersion=mi355x\n##tomahawk_concatCommand=" + tomahawk::LITERAL_COMMAND_LINE + "; Date=" + date;
+	std::string err;
+	std::cerr << stamp("LOG") << "Concatenating " << in_list.size() << " files into " << out << "..." << std::endl;
+	if (!tomahawk::two_concat(in_list, out, note, err)) { std::cerr << stamp("ERROR") << err << std::endl; return 1; }
+	return 0;
+}
+
+// Multi-GPU `calc`: one process per GPU (TWK_HIP_GPUS=n).  The launcher itself never touches
+// HIP: it re-executes this binary n times with TWK_HIP_DEVICE=k, TWK_HIP_PART=k/n and a private
+// part file, waits, and concatenates the parts (the reference's farm mode -c/-C + concat,
+// docs/job-balancing.md, with row bands instead of square chunks).
+static int launch_multi_gpu(int n_gpus, const std::string& out_final) {
+	std::vector<std::string> parts;
+	std::vector<pid_t> pids;
+	const std::string base = (out_final == "-" || out_final.empty()) ? std::string("/tmp/twk_calc_") + std::to_string(getpid()) : out_final;
+	for (int k = 0; k < n_gpus; ++k) {
+		const std::string part = base + ".part" + std::to_string(k) + ".two";
+		parts.push_back(part);
+		std::vector<std::string> args = g_argv;
+		bool replaced = false;
+		for (size_t i = 1; i + 1 < args.size(); ++i) if (args[i] == "-o" || args[i] == "--output") { args[i + 1] = part; replaced = true; }
+		if (!replaced) { args.push_back("-o"); args.push_back(part); }
+		const pid_t pid = fork();
+		if (pid < 0) { std::cerr << stamp("ERROR") << "fork failed" << std::endl; return 1; }
+		if (pid == 0) {
+			setenv("TWK_HIP_DEVICE", std::to_string(k).c_str(), 1);
+			setenv("TWK_HIP_PART", (std::to_string(k) + "/" + std::to_string(n_gpus)).c_str(), 1);
+			unsetenv("TWK_HIP_GPUS");
+			std::vector<char*> av;
+			for (auto& a : args) av.push_back(const_cast<char*>(a.c_str()));
+			av.push_back(nullptr);
+			execv("/proc/self/exe", av.data());
+			_exit(127);
+		}
+		pids.push_back(pid);
+	}
+	bool ok = true;
+	for (pid_t pid : pids) { int st = 0; if (waitpid(pid, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) ok = false; }
+	if (!ok) { std::cerr << stamp("ERROR") << "A GPU worker failed; part files are left in place" << std::endl; return 1; }
+	std::string err;
+	const std::string note = "\n##tomahawk_calcGPUs=" + std::to_string(n_gpus);
+	std::string out = out_final.empty() ? "-" : out_final;
+	if (out != "-") {
+		const size_t sl = out.find_last_of("/\\"), dot = out.rfind('.');
+		const std::string ext = (dot == std::string::npos || (sl != std::string::npos && dot < sl)) ? "" : out.substr(dot + 1);
+		if (!(ext.size() == 3 && strncasecmp(ext.c_str(), "two", 3) == 0)) out += ".two";
+	}
+	if (!tomahawk::two_concat(parts, out, note, err)) { std::cerr << stamp("ERROR") << err << std::endl; return 1; }
+	for (const auto& p : parts) unlink(p.c_str());
+	std::cerr << stamp("LOG") << "Merged " << n_gpus << " GPU shards into " << out << std::endl;
+	return 0;
 }
 
 // `tomahawk scalc` (lib/scalc.h:50-194): one site against its neighbourhood.
@@ -179,13 +283,15 @@ static int scalc(int argc, char** argv) {
 
 int main(int argc, char** argv) {
 	if (argc == 1) { program_message(); std::cerr << "Usage: tomahawk calc [options] -i <in.twk> -o <output.two>" << std::endl; return 1; }
+	g_argv.assign(argv, argv + argc);
 	tomahawk::LITERAL_COMMAND_LINE = "tomahawk";
 	for (int i = 1; i < argc; ++i) tomahawk::LITERAL_COMMAND_LINE += " " + std::string(argv[i]);
 	if (strcmp(argv[1], "calc") == 0) return calc(argc, argv);
+	if (strncmp(argv[1], "concat", 6) == 0) return concat(argc, argv);
 	if (strcmp(argv[1], "calc-single") == 0 || strcmp(argv[1], "scalc") == 0) return scalc(argc, argv);
 	if (strcmp(argv[1], "--version") == 0 || strcmp(argv[1], "version") == 0) { program_message(); return 0; }
 	if (strcmp(argv[1], "--help") == 0 || strcmp(argv[1], "help") == 0) { calc_usage(); return 0; }
 	program_message();
-	std::cerr << stamp("ERROR") << "Illegal command: only `calc` and `scalc` are provided by the MI355X engine (view/sort/concat/... are the reference's)" << std::endl;
+	std::cerr << stamp("ERROR") << "Illegal command: only `calc`, `scalc` and `concat` are provided by the MI355X engine (view/sort/... are the reference's)" << std::endl;
 	return 1;
 }

@@ -378,6 +378,16 @@ bool TwoWriter::write_packed(const Packed& p) {
 	return true;
 }
 
+bool TwoWriter::write_raw(uint32_t b_unc, const std::vector<uint8_t>& z, IndexEntryOutput e) {
+	e.foff = off_;
+	const uint8_t marker = 1; const uint32_t cmp = (uint32_t)z.size();
+	if (!put(&marker, 1) || !put(&b_unc, 4) || !put(&cmp, 4) || !put(z.data(), z.size())) return false;
+	e.fend = off_; e.b_cmp = cmp; e.b_unc = b_unc;      // concat.h:165-166 stores the frame sizes
+	index_.ent.push_back(e);
+	n_records += e.n; ++n_blocks;
+	return true;
+}
+
 bool TwoWriter::write_block(const TwoRecord* recs, uint32_t n) {
 	if (n == 0) return true;
 	Packed p;
@@ -416,6 +426,44 @@ bool TwoReader::next_block(std::vector<TwoRecord>& recs) { // two_reader.cpp:11-
 	if (!b.get(n) || !b.get(m) || (size_t)n * sizeof(TwoRecord) + 8 > b.size()) { error = "bad block payload"; return false; }
 	recs.resize(n);
 	b.get_bytes(recs.data(), (size_t)n * sizeof(TwoRecord));
+	return true;
+}
+
+bool TwoReader::next_block_raw(uint32_t& unc, std::vector<uint8_t>& z) {
+	uint8_t marker = 0;
+	in_.read((char*)&marker, 1);
+	if (!in_.good() || marker == 0) return false;
+	if (marker != 1) { error = "bad block marker"; return false; }
+	uint32_t cmp = 0;
+	in_.read((char*)&unc, 4); in_.read((char*)&cmp, 4);
+	z.resize(cmp);
+	in_.read((char*)z.data(), cmp);
+	if (!in_.good()) { error = "truncated block"; return false; }
+	return true;
+}
+
+bool two_concat(const std::vector<std::string>& inputs, const std::string& out, const std::string& note, std::string& error) {
+	if (inputs.empty()) { error = "no input"; return false; }
+	std::vector<std::unique_ptr<TwoReader>> rd;
+	for (const auto& p : inputs) {
+		rd.emplace_back(new TwoReader);
+		if (!rd.back()->open(p)) { error = "Failed to open \"" + p + "\": " + rd.back()->error; return false; }
+		if (rd.back()->hdr.samples != rd.front()->hdr.samples) { error = "Sample have different sample names or lengths: " + p; return false; }   // concat.h:141-154
+		if (rd.back()->hdr.contigs.size() != rd.front()->hdr.contigs.size()) { error = "Files have different contigs: " + p; return false; }
+	}
+	Header hdr = rd.front()->hdr;
+	hdr.literals += note;
+	TwoWriter w;
+	if (!w.open(out, hdr, 1)) { error = "failed to open " + out; return false; }
+	for (auto& r : rd) {
+		uint32_t unc = 0; std::vector<uint8_t> z; size_t k = 0;
+		while (r->next_block_raw(unc, z)) {
+			if (k >= r->index.ent.size()) { error = "index shorter than block stream"; return false; }
+			if (!w.write_raw(unc, z, r->index.ent[k++])) { error = "write failed"; return false; }
+		}
+		if (!r->error.empty()) { error = r->error; return false; }
+	}
+	if (!w.close()) { error = "write failed"; return false; }
 	return true;
 }
 

@@ -159,6 +159,8 @@ public:
 	struct Packed { std::vector<uint8_t> z; IndexEntryOutput entry; uint32_t b_unc = 0; };
 	static bool pack(const TwoRecord* recs, uint32_t n, int c_level, Packed& out);
 	bool write_packed(const Packed& p);
+	// Append an already compressed block under the given index entry (concat, lib/concat.h:160-175).
+	bool write_raw(uint32_t b_unc, const std::vector<uint8_t>& z, IndexEntryOutput entry);
 	int  compression_level() const { return c_level_; }
 	bool close();             // writer.h:293-313
 	uint64_t n_records = 0, n_blocks = 0;
@@ -177,9 +179,15 @@ public:
 	bool open(const std::string& path);
 	// Next block of records; false at the end marker.
 	bool next_block(std::vector<TwoRecord>& recs);
+	// Next block as stored (still compressed): twk1_two_iterator::NextBlockRaw (two_reader.cpp:11-44).
+	bool next_block_raw(uint32_t& b_unc, std::vector<uint8_t>& z);
 	std::string error;
 private:
 	std::ifstream in_;
 };
+
+// Concatenate .two files of the same sample set by copying their compressed blocks and
+// re-basing the index (lib/concat.h:63-251).  `note` is appended to the header literals.
+bool two_concat(const std::vector<std::string>& inputs, const std::string& out, const std::string& note, std::string& error);
 
 }  // namespace tomahawk

@@ -23,6 +23,7 @@
 #include <deque>
 #include <mutex>
 #include <sys/time.h>
+#include <cstdio>
 
 #include "twk_format.h"
 #include "twk_hip.h"
@@ -401,7 +402,8 @@ static bool load_blocks(const std::string& path, const TwkReader& reader, const 
 }
 
 static bool create_device(DeviceCtx& dc) {
-	const char* dev_env = std::getenv("TWK_HIP_DEVICE");
+	const char* dev_env = std::getenv("TWK_HIP_FORCE_DEVICE");        // testing: several workers on one GPU
+	if (!dev_env) dev_env = std::getenv("TWK_HIP_DEVICE");
 	const int device = dev_env ? std::atoi(dev_env) : 0;
 	if (twk_hip_device_count() <= 0) { std::cerr << stamp("ERROR", "HIP") << "No HIP device available (this build has no CPU path)." << std::endl; return false; }
 	return hip_ok(nullptr, twk_hip_ctx_create(device, &dc.ctx), "twk_hip_ctx_create");
@@ -419,15 +421,22 @@ bool twk_ld::twk_ld_impl::run(twk_ld_settings& settings, const Header& hdr, twk_
 	const int mode = settings.single ? TWK_HIP_MODE_AUTO
 	               : settings.force_phased ? TWK_HIP_MODE_PHASED : (settings.forced_unphased ? TWK_HIP_MODE_UNPHASED : TWK_HIP_MODE_AUTO);
 	twk_hip_filters f{settings.minR2, settings.maxR2, settings.minDprime, settings.maxDprime, settings.minP};
+	// One process per GPU: shard k of n of every region (TWK_HIP_PART=k/n, set by the multi-GPU launcher).
+	uint32_t part = 0, n_parts = 1;
+	if (const char* e = std::getenv("TWK_HIP_PART")) {
+		unsigned k = 0, n = 1;
+		if (sscanf(e, "%u/%u", &k, &n) == 2 && n >= 1 && k < n) { part = k; n_parts = n; }
+		else { std::cerr << stamp("ERROR") << "Bad TWK_HIP_PART (want k/n): " << e << std::endl; return false; }
+	}
 	const auto t0 = clock::now();
 	uint64_t np = 0, nr = 0;
 	int rc = TWK_HIP_OK;
 	if (spec.triangleA && spec.nA > 1) {
-		rc = twk_hip_ld_region(ctx, mode, &f, 0, spec.nA, 0, spec.nA, 1, 0, 1, 0, spec.options, spec.l_window, sink, this, &np, &nr);
+		rc = twk_hip_ld_region(ctx, mode, &f, 0, spec.nA, 0, spec.nA, 1, part, n_parts, 0, spec.options, spec.l_window, sink, this, &np, &nr);
 		n_pairs += np;
 	}
 	if (rc == TWK_HIP_OK && spec.rectAB && spec.nA && spec.nB) {
-		rc = twk_hip_ld_region(ctx, mode, &f, 0, spec.nA, spec.nA, spec.nB, 0, 0, 1, 0, spec.options, spec.l_window, sink, this, &np, &nr);
+		rc = twk_hip_ld_region(ctx, mode, &f, 0, spec.nA, spec.nA, spec.nB, 0, part, n_parts, 0, spec.options, spec.l_window, sink, this, &np, &nr);
 		n_pairs += np;
 	}
 	if (write_failed) { std::cerr << stamp("ERROR", "WRITER") << "Failed to write output block!" << std::endl; return false; }

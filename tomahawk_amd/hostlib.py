@@ -1,14 +1,15 @@
-"""ctypes binding of the test C API of lib/libtomahawk_amd.so (tomahawk_amd/csrc/host/twk_capi.cpp)."""
+"""ctypes binding of the flat C API of lib/libtomahawk_amd.so (tomahawk_amd/csrc/host/twk_capi.cpp):
+.twk / .two file helpers and twk_ld::Compute, for tests, tools and the benchmark harness."""
 import ctypes as C
 import os
 
 import numpy as np
 
-from tomahawk_amd.hip import META_DTYPE
+from .hip import META_DTYPE
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(ROOT, "tomahawk_amd", "lib", "libtomahawk_amd.so")
-CLI_PATH = os.path.join(ROOT, "tomahawk_amd", "bin", "tomahawk")
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtomahawk_amd.so")
+CLI_PATH = os.path.join(_HERE, "bin", "tomahawk")
 
 # twk1_two_t as serialised (reference lib/core.cpp:470-490): 106 bytes, packed
 TWO_DTYPE = np.dtype({"names": ["controller", "ridA", "ridB", "packA", "packB", "cnt", "D", "Dprime", "R", "R2", "P",
