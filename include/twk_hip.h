@@ -129,6 +129,10 @@ int twk_hip_upload_bitvectors(twk_hip_ctx* ctx, uint32_t first, uint32_t count,
  * contig, pos = 1000+100*v, no missing data).  Bit-identical to the host
  * generator twk_synth_bitvector() below. */
 int twk_hip_generate_synthetic(twk_hip_ctx* ctx, uint64_t seed);
+/* The same for a slab: local variant v is global variant first_variant + v (bits, ALT
+ * frequency and position all follow the global id), so that ranks that hold different
+ * slabs of one synthetic data set agree on every variant they share (halo). */
+int twk_hip_generate_synthetic_range(twk_hip_ctx* ctx, uint64_t seed, uint32_t first_variant);
 /* Host twin of the device generator: writes variant v's bitvector
  * (ceil(2N/64) words) and returns its ALT allele count. */
 uint32_t twk_synth_bitvector(uint64_t seed, uint32_t n_samples, uint32_t v, uint64_t* out_words);

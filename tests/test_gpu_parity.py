@@ -124,6 +124,49 @@ def test_sharded_union_equals_whole(hip):
     assert max(loads) < 1.35 * min(loads)
 
 
+def test_window_mode_sharded_and_slab(hip):
+    """calc -w: in-window pairs only; shards partition them; a slab (rows band + halo) gives its band's records."""
+    N, M, W = 96, 1500, 2500                      # positions 1000 + 100 v  ->  25 partners each side
+    hip.set_problem(N, M)
+    hip.generate_synthetic(5)
+    f = T.Filters(minR2=0.0)
+    whole, npairs_all, _ = hip.ld_all(T.MODE_PHASED, f)
+    keyset = lambda r: set(zip(r["idxA"].tolist(), r["idxB"].tolist()))
+    want = {(a, b) for (a, b) in keyset(whole) if (b - a) * 100 <= W}
+    win, npw, nrw = hip.ld_all(T.MODE_PHASED, f, window=1, l_window=W)
+    assert keyset(win) == want and nrw == len(want)
+    assert npw == sum(min(25, M - 1 - i) for i in range(M))           # pairs inside the window
+    parts = [hip.ld_all(T.MODE_PHASED, f, part=k, n_parts=4, window=1, l_window=W) for k in range(4)]
+    assert sum(p[1] for p in parts) == npw and set().union(*[keyset(p[0]) for p in parts]) == want
+    assert max(p[1] for p in parts) < 1.35 * min(p[1] for p in parts)  # by in-window pairs (64-row granularity), not triangle area
+    # slab: rows [600, 900) + halo of 25 columns, generated with the global variant ids
+    r0, r1, halo = 600, 900, 25
+    hip.set_problem(N, r1 - r0 + halo)
+    hip.generate_synthetic(5, first_variant=r0)
+    slab, nps, _ = hip.ld_region(T.MODE_PHASED, f, 0, r1 - r0, 0, r1 - r0 + halo, True, window=1, l_window=W)
+    got = {(a + r0, b + r0) for (a, b) in keyset(slab)}
+    assert got == {(a, b) for (a, b) in want if r0 <= a < r1}
+    bykey = {(int(r["idxA"]), int(r["idxB"])): r for r in whole}
+    for r in slab[:: max(1, len(slab) // 50)]:
+        w = bykey[(int(r["idxA"]) + r0, int(r["idxB"]) + r0)]
+        assert r["R2"] == w["R2"] and np.array_equal(r["cnt"], w["cnt"])
+
+
+def test_many_variants_beyond_grid_limits(hip):
+    """More variants than a launch grid's y extent (65535): prep kernels loop, tiles cover everything."""
+    N, M = 40, 70_000
+    hip.set_problem(N, M)
+    hip.generate_synthetic(3)
+    ac, het, hom, _ = hip.marginals()
+    for v in (0, 65534, 65535, 65536, 69_999):
+        bv, a = T.synth_bitvector(3, N, v)
+        assert a == ac[v]
+    c = hip.count_tile(T.MODE_UNPHASED, 65500, 100, 69_900, 100)
+    assert (c.sum(axis=2) == N).all() and (c[:, :, 3:6].sum(axis=2) == het[65500:65600, None]).all()
+    recs, npairs, nrec = hip.ld_all(T.MODE_PHASED, T.Filters(minR2=0.9), collect=False)
+    assert npairs == M * (M - 1) // 2
+
+
 def test_overflow_is_reported_and_recovered(hip):
     N, M = 64, 300
     al = util.random_alleles(M, N, 51)

@@ -43,18 +43,20 @@ __host__ __device__ __forceinline__ uint32_t synth_sample_bits(uint64_t seed, ui
 // Synthetic genotypes straight into the raw layout: one thread per 32-bit word
 // (16 samples).  raw[v * Wp + w].
 __global__ void k_synth(uint32_t* __restrict__ raw, uint32_t Wp, uint32_t n_samples, uint32_t n_variants,
-                        uint64_t seed) {
+                        uint64_t seed, uint32_t first_variant) {
 	const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
-	const uint32_t v = blockIdx.y;
-	if (v >= n_variants || w >= Wp) return;
-	const uint32_t thr = synth_threshold(seed, v);
-	uint32_t word = 0;
-	const uint32_t s0 = w * 16;
-	for (uint32_t i = 0; i < 16; ++i) {
-		const uint32_t s = s0 + i;
-		if (s < n_samples) word |= synth_sample_bits(seed, v, s, thr) << (2 * i);
+	if (w >= Wp) return;
+	for (uint32_t v = blockIdx.y; v < n_variants; v += gridDim.y) {     // grid.y is capped at 65535
+		const uint32_t gv = first_variant + v;                           // global variant id
+		const uint32_t thr = synth_threshold(seed, gv);
+		uint32_t word = 0;
+		const uint32_t s0 = w * 16;
+		for (uint32_t i = 0; i < 16; ++i) {
+			const uint32_t s = s0 + i;
+			if (s < n_samples) word |= synth_sample_bits(seed, gv, s, thr) << (2 * i);
+		}
+		raw[(size_t)v * Wp + w] = word;
 	}
-	raw[(size_t)v * Wp + w] = word;
 }
 
 // Population count of every row: out[r] = sum_k popc(rows[r][k]).  One wave per row.
@@ -90,8 +92,8 @@ __global__ void k_build_unphased(const uint32_t* __restrict__ raw, const uint32_
                                  uint32_t Wp, uint32_t n_samples, uint32_t n_variants,
                                  uint32_t* __restrict__ planes, uint32_t Wu, int P) {
 	const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
-	const uint32_t v = blockIdx.y;
-	if (v >= n_variants || w >= Wu) return;
+	if (w >= Wu) return;
+	for (uint32_t v = blockIdx.y; v < n_variants; v += gridDim.y) {
 	uint64_t x = 0, m = 0;
 	if (2 * w + 1 < Wp || 2 * w < Wp) {
 		const uint32_t lo = (2 * w < Wp) ? raw[(size_t)v * Wp + 2 * w] : 0;
@@ -115,29 +117,30 @@ __global__ void k_build_unphased(const uint32_t* __restrict__ raw, const uint32_
 	planes[((size_t)v * P + 0) * Wu + w] = (a0 ^ a1) & keep;
 	planes[((size_t)v * P + 1) * Wu + w] = (a0 & a1) & keep;
 	if (P == 3) planes[((size_t)v * P + 2) * Wu + w] = ms;
+	}
 }
 
 // raw + mask -> phased-with-missing planes (a & ~m, m), 2 rows per variant.
 __global__ void k_build_phased_masked(const uint32_t* __restrict__ raw, const uint32_t* __restrict__ rawmask,
                                       uint32_t Wp, uint32_t n_variants, uint32_t* __restrict__ planes) {
 	const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
-	const uint32_t v = blockIdx.y;
-	if (v >= n_variants || w >= Wp) return;
-	const uint32_t a = raw[(size_t)v * Wp + w], m = rawmask[(size_t)v * Wp + w];
-	planes[((size_t)v * 2 + 0) * Wp + w] = a & ~m;
-	planes[((size_t)v * 2 + 1) * Wp + w] = m;
+	if (w >= Wp) return;
+	for (uint32_t v = blockIdx.y; v < n_variants; v += gridDim.y) {
+		const uint32_t a = raw[(size_t)v * Wp + w], m = rawmask[(size_t)v * Wp + w];
+		planes[((size_t)v * 2 + 0) * Wp + w] = a & ~m;
+		planes[((size_t)v * 2 + 1) * Wp + w] = m;
+	}
 }
 
 // Zero the bits of the raw layout that lie beyond allele 2N (defensive: the
 // reference guarantees it, core.cpp:361).
 __global__ void k_clear_tail(uint32_t* __restrict__ raw, uint32_t Wp, uint32_t n_samples, uint32_t n_variants) {
 	const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
-	const uint32_t v = blockIdx.y;
-	if (v >= n_variants || w >= Wp) return;
+	if (w >= Wp) return;
 	const uint64_t bit0 = (uint64_t)w * 32, nb = 2ull * n_samples;
 	if (bit0 + 32 <= nb) return;
 	const uint32_t keep = bit0 >= nb ? 0u : ((1u << (uint32_t)(nb - bit0)) - 1);
-	raw[(size_t)v * Wp + w] &= keep;
+	for (uint32_t v = blockIdx.y; v < n_variants; v += gridDim.y) raw[(size_t)v * Wp + w] &= keep;
 }
 
 }  // namespace twk

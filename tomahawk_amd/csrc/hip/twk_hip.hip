@@ -126,7 +126,7 @@ int ensure_planes(twk_hip_ctx* c, int kind) {
 		HIPCHK(c, hipMalloc((void**)&ps.rows, bytes));
 		ps.owns_rows = true;
 		HIPCHK(c, hipMemsetAsync(ps.rows, 0, bytes, c->s_compute));
-		const dim3 blk(256), grd((ps.W + 255) / 256, c->M);
+		const dim3 blk(256), grd((ps.W + 255) / 256, std::min<uint32_t>(c->M, 65535u));
 		if (kind == PK_PHASED_MASKED)
 			hipLaunchKernelGGL(k_build_phased_masked, grd, blk, 0, c->s_compute, c->raw, c->rawmask, c->Wp, c->M, ps.rows);
 		else
@@ -332,9 +332,10 @@ int redo_tile_in_strips(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, co
 	return TWK_HIP_OK;
 }
 
-// Rows [0, r) of a triangle of n rows hold r*n - r(r+1)/2 pairs; of an n x m rectangle r*m.
+// Rows [0, r) of a triangle (or trapezoid: nB >= nA columns, col > row) hold r*nB - r(r+1)/2
+// pairs; of an nA x nB rectangle r*nB.
 uint64_t band_pairs_before(uint64_t r, uint64_t nA, uint64_t nB, bool triangle) {
-	return triangle ? r * nA - r * (r + 1) / 2 : r * nB;
+	return triangle ? r * nB - r * (r + 1) / 2 : r * nB;      // triangle: row i pairs with cols (i, nB)
 }
 // First row of shard k: equal-area bands, boundaries on multiples of 64 variants.
 uint32_t band_boundary(uint32_t k, uint32_t n_parts, uint32_t nA, uint32_t nB, bool triangle) {
@@ -461,7 +462,7 @@ int twk_hip_upload_bitvectors(twk_hip_ctx* c, uint32_t first, uint32_t count, co
 	HIPCHK(c, hipSetDevice(c->device));
 	free_planes(c);                                             // derived planes are stale now
 	HIPCHK(c, hipMemcpy2D(c->raw + (size_t)first * c->Wp, (size_t)c->Wp * 4, data, stride64 * 8, w64 * 8, count, hipMemcpyHostToDevice));
-	hipLaunchKernelGGL(k_clear_tail, dim3((c->Wp + 255) / 256, count), dim3(256), 0, c->s_compute,
+	hipLaunchKernelGGL(k_clear_tail, dim3((c->Wp + 255) / 256, std::min<uint32_t>(count, 65535u)), dim3(256), 0, c->s_compute,
 	                   c->raw + (size_t)first * c->Wp, c->Wp, c->N, count);
 	HIPCHK(c, hipGetLastError());
 	if (mask) {
@@ -471,7 +472,7 @@ int twk_hip_upload_bitvectors(twk_hip_ctx* c, uint32_t first, uint32_t count, co
 			HIPCHK(c, hipMemset(c->rawmask, 0, raw_bytes));
 		}
 		HIPCHK(c, hipMemcpy2D(c->rawmask + (size_t)first * c->Wp, (size_t)c->Wp * 4, mask, stride64 * 8, w64 * 8, count, hipMemcpyHostToDevice));
-		hipLaunchKernelGGL(k_clear_tail, dim3((c->Wp + 255) / 256, count), dim3(256), 0, c->s_compute,
+		hipLaunchKernelGGL(k_clear_tail, dim3((c->Wp + 255) / 256, std::min<uint32_t>(count, 65535u)), dim3(256), 0, c->s_compute,
 		                   c->rawmask + (size_t)first * c->Wp, c->Wp, c->N, count);
 		HIPCHK(c, hipGetLastError());
 	}
@@ -493,21 +494,24 @@ int twk_hip_upload_bitvectors(twk_hip_ctx* c, uint32_t first, uint32_t count, co
 	return TWK_HIP_OK;
 }
 
-int twk_hip_generate_synthetic(twk_hip_ctx* c, uint64_t seed) {
+int twk_hip_generate_synthetic(twk_hip_ctx* c, uint64_t seed) { return twk_hip_generate_synthetic_range(c, seed, 0); }
+
+int twk_hip_generate_synthetic_range(twk_hip_ctx* c, uint64_t seed, uint32_t first_variant) {
 	if (!c) return TWK_HIP_E_INVALID;
+	if ((uint64_t)first_variant + (c ? c->M : 0) > 0xFFFFFFFFull) return TWK_HIP_E_INVALID;
 	if (!c->raw) return TWK_HIP_E_STATE;
 	HIPCHK(c, hipSetDevice(c->device));
 	free_planes(c);
 	if (c->rawmask) { (void)hipFree(c->rawmask); c->rawmask = nullptr; }
 	c->any_missing = false;
-	hipLaunchKernelGGL(k_synth, dim3((c->Wp + 255) / 256, c->M), dim3(256), 0, c->s_compute, c->raw, c->Wp, c->N, c->M, seed);
+	hipLaunchKernelGGL(k_synth, dim3((c->Wp + 255) / 256, std::min<uint32_t>(c->M, 65535u)), dim3(256), 0, c->s_compute, c->raw, c->Wp, c->N, c->M, seed, first_variant);
 	HIPCHK(c, hipGetLastError());
 	// metadata: ac = popcount, pos = 1000 + 100 v, one contig, hwe = 1
 	hipLaunchKernelGGL(k_row_popcount, dim3((c->M + 3) / 4), dim3(256), 0, c->s_compute, c->raw, c->Wp, c->M, c->d_ac);
 	HIPCHK(c, hipGetLastError());
 	std::vector<uint32_t> pos(c->M), zero(c->M, 0), ac(c->M);
 	std::vector<double> hwe(c->M, 1.0);
-	for (uint32_t v = 0; v < c->M; ++v) pos[v] = 1000u + 100u * v;
+	for (uint32_t v = 0; v < c->M; ++v) pos[v] = 1000u + 100u * (first_variant + v);
 	HIPCHK(c, hipMemcpyAsync(c->d_pos, pos.data(), (size_t)c->M * 4, hipMemcpyHostToDevice, c->s_compute));
 	HIPCHK(c, hipMemcpyAsync(c->d_an, zero.data(), (size_t)c->M * 4, hipMemcpyHostToDevice, c->s_compute));
 	HIPCHK(c, hipMemcpyAsync(c->d_rid, zero.data(), (size_t)c->M * 4, hipMemcpyHostToDevice, c->s_compute));
@@ -620,20 +624,58 @@ int twk_hip_ld_region(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint32
 	if (!c || !f || !valid_mode(mode) || n_parts == 0 || part >= n_parts) return TWK_HIP_E_INVALID;
 	if (!c->raw) return TWK_HIP_E_STATE;
 	if (nA == 0 || nB == 0 || (uint64_t)a0 + nA > c->M || (uint64_t)b0 + nB > c->M) return TWK_HIP_E_INVALID;
-	if (triangle && (a0 != b0 || nA != nB)) return TWK_HIP_E_INVALID;
+	if (triangle && (a0 != b0 || nB < nA)) return TWK_HIP_E_INVALID;
 	HIPCHK(c, hipSetDevice(c->device));
 	// ---- shard: a contiguous band of rows holding 1/n_parts of the region's pairs ----------
 	// Row i of a triangle has nA-1-i pairs, of a rectangle nB.  Equal-area bands, boundaries
 	// on multiples of 64 variants, derived identically (and without communication) by every rank.
 	// Replaces the reference's square-chunk farm partition (ld_balancing.h:59-78) for GPUs.
-	const uint32_t r0 = band_boundary(part, n_parts, nA, nB, triangle != 0), r1 = band_boundary(part + 1, n_parts, nA, nB, triangle != 0);
+	const bool windowed = (window & TWK_HIP_OPT_WINDOW) != 0;
+	// Window mode: the columns a row can reach, [lo[r], hi[r]) relative to b0 (same contig,
+	// |dpos| <= l_window; variants are sorted by (rid,pos) like every .twk, so both ends only
+	// move forward).  They drive the shard boundaries (equal in-window pairs), the tile edge and
+	// the column range of every row block; the exact test itself stays in the math kernel.
+	std::vector<uint32_t> lo, hi;
+	std::vector<uint64_t> cum;           // cum[r] = in-window pairs of rows [0, r)
+	if (windowed) {
+		lo.resize(nA); hi.resize(nA); cum.assign((size_t)nA + 1, 0);
+		uint32_t l = 0, h = 0;
+		for (uint32_t r = 0; r < nA; ++r) {
+			const twk_hip_variant_meta& R = c->h_meta[a0 + r];
+			auto before = [&](uint32_t j) { const twk_hip_variant_meta& B = c->h_meta[b0 + j];
+				return B.rid < R.rid || (B.rid == R.rid && (uint64_t)B.pos + l_window < R.pos); };
+			auto within = [&](uint32_t j) { const twk_hip_variant_meta& B = c->h_meta[b0 + j];
+				return B.rid < R.rid || (B.rid == R.rid && B.pos <= (uint64_t)R.pos + l_window); };
+			while (l < nB && before(l)) ++l;
+			if (h < l) h = l;
+			while (h < nB && within(h)) ++h;
+			lo[r] = triangle ? std::min(std::max(l, r + 1), nB) : l;
+			hi[r] = std::max(h, lo[r]);
+			cum[r + 1] = cum[r] + (hi[r] - lo[r]);
+		}
+	}
+	auto window_boundary = [&](uint32_t k) -> uint32_t {
+		if (k == 0) return 0;
+		if (k >= n_parts) return nA;
+		const long double target = (long double)cum[nA] * k / n_parts;
+		const uint32_t r = (uint32_t)(std::lower_bound(cum.begin(), cum.end(), (uint64_t)target) - cum.begin());
+		return std::min(nA, (r + 32) / 64 * 64);
+	};
+	const uint32_t r0 = windowed ? window_boundary(part) : band_boundary(part, n_parts, nA, nB, triangle != 0);
+	const uint32_t r1 = windowed ? window_boundary(part + 1) : band_boundary(part + 1, n_parts, nA, nB, triangle != 0);
 
 	// ---- super-tiles of the band --------------------------------------------------------------
 	// Edge S in variants (multiple of 128).  Default: ~16384 plane rows per tile edge so that a
 	// launch holds >= 16 rounds of resident blocks and the partial last round costs < 3 %.
+	// Window mode: about a quarter of the window (in variants), so that the corners a row block
+	// computes outside the window stay near 10 % of its work.
 	const bool two_pass_auto = (mode == TWK_HIP_MODE_AUTO) && c->any_missing;
 	const int Pmax = two_pass_auto ? 3 : planes_per_variant(plane_kind_for(c, mode == TWK_HIP_MODE_PHASED || (mode == TWK_HIP_MODE_AUTO && !c->any_missing)));
 	uint32_t S = tile_variants ? tile_variants : (16384u / (uint32_t)Pmax);
+	if (windowed && !tile_variants && r1 > r0) {
+		const uint64_t wv = (cum[r1] - cum[r0]) / (r1 - r0);              // mean partners per row
+		S = std::min<uint32_t>(S, std::max<uint32_t>(512u, round_up((uint32_t)std::min<uint64_t>(wv / 4, 1u << 20), TILE)));
+	}
 	S = std::max<uint32_t>(TILE, std::min<uint32_t>(S / TILE * TILE, 32768u));
 	S = std::min(S, round_up(std::max(nA, nB), TILE));
 
@@ -684,10 +726,20 @@ int twk_hip_ld_region(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint32
 		const uint32_t h = std::min(S, r1 - x);
 		// triangle: the first tile of the row block starts on the diagonal (rows [x,x+h) x cols [x,x+w),
 		// w >= h, only col > row) and continues into the rectangle to its right in the same launch
-		uint32_t col = triangle ? x : 0;
+		uint32_t col = triangle ? x : 0, col_end = nB;
+		if (windowed) {       // only the columns some row of the block can reach
+			if (!triangle) col = lo[x];
+			col_end = hi[x + h - 1];
+			if (col_end <= col) continue;
+		}
 		const uint32_t sc = choose_col_step(h, col, triangle != 0);
 		bool diag = triangle != 0;
-		for (; col < nB; col += sc, diag = false) push_tile(x, h, col, std::min(sc, nB - col), diag ? 1 : 0);
+		for (; col < col_end; col += sc, diag = false) {
+			uint32_t w = std::min(sc, col_end - col);
+			if (diag && w < h) w = std::min(h, nB - col);            // the diagonal tile must span its own rows
+			push_tile(x, h, col, w, diag ? 1 : 0);
+			if (diag && w > sc) col += w - sc;
+		}
 	}
 
 	uint64_t tot_pairs = 0, tot_recs = 0;
@@ -729,6 +781,7 @@ int twk_hip_ld_region(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint32
 		tot_pairs += pairs_in_tile(c, mine[done]);
 		++done;
 	}
+	if (windowed) tot_pairs = cum[r1] - cum[r0];       // pairs inside the window: the ones the math evaluates
 	if (n_pairs) *n_pairs = tot_pairs;
 	if (n_records) *n_records = tot_recs;
 	return TWK_HIP_OK;

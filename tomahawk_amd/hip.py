@@ -88,6 +88,7 @@ def load_library() -> C.CDLL:
     lib.twk_hip_set_problem.argtypes = [p, C.c_uint32, C.c_uint32]
     lib.twk_hip_upload_bitvectors.argtypes = [p, C.c_uint32, C.c_uint32, p, p, C.c_size_t, p]
     lib.twk_hip_generate_synthetic.argtypes = [p, C.c_uint64]
+    lib.twk_hip_generate_synthetic_range.argtypes = [p, C.c_uint64, C.c_uint32]
     lib.twk_synth_bitvector.restype = C.c_uint32
     lib.twk_synth_bitvector.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, p]
     lib.twk_hip_get_marginals.argtypes = [p, p, p, p, p]
@@ -96,6 +97,9 @@ def load_library() -> C.CDLL:
                                     C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.twk_hip_ld_all.argtypes = [p, C.c_int, C.POINTER(_Filters), C.c_uint32, C.c_uint32, C.c_uint32,
                                    C.c_int32, C.c_uint32, _SINK, p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.twk_hip_ld_region.argtypes = [p, C.c_int, C.POINTER(_Filters), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                      C.c_int32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, C.c_uint32, _SINK, p,
+                                      C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.twk_hip_shard_rows.argtypes = [C.c_uint32, C.c_uint32, C.c_int32, C.c_uint32, C.c_uint32,
                                        C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
     lib.twk_hip_timing_reset.argtypes = [p]
@@ -181,8 +185,10 @@ class HipLd:
         self._check(self._lib.twk_hip_upload_bitvectors(self._ctx, first, data.shape[0], data.ctypes.data, mptr,
                                                         data.shape[1], meta.ctypes.data), "twk_hip_upload_bitvectors")
 
-    def generate_synthetic(self, seed: int = 42):
-        self._check(self._lib.twk_hip_generate_synthetic(self._ctx, seed), "twk_hip_generate_synthetic")
+    def generate_synthetic(self, seed: int = 42, first_variant: int = 0):
+        """Synthetic benchmark input for global variants [first_variant, first_variant + n_variants)."""
+        self._check(self._lib.twk_hip_generate_synthetic_range(self._ctx, seed, first_variant),
+                    "twk_hip_generate_synthetic_range")
 
     def marginals(self):
         M = self.n_variants
@@ -234,6 +240,27 @@ class HipLd:
         self._check(self._lib.twk_hip_ld_all(self._ctx, mode, C.byref(f), part, n_parts, tile_variants,
                                              int(bool(window)), l_window, cb, None, C.byref(npairs), C.byref(nrec)),
                     "twk_hip_ld_all")
+        recs = np.concatenate(chunks) if chunks else np.zeros(0, dtype=RECORD_DTYPE)
+        return recs, npairs.value, nrec.value
+
+    def ld_region(self, mode: int, filters: Filters, a0: int, nA: int, b0: int, nB: int, triangle: bool,
+                  part: int = 0, n_parts: int = 1, tile_variants: int = 0, window: int = 0, l_window: int = 0,
+                  collect: bool = True):
+        """LD over rows [a0,a0+nA) x cols [b0,b0+nB) (triangle: col > row, nB >= nA). Returns (records, n_pairs, n_records)."""
+        chunks = []
+
+        def sink(_user, recs, n):
+            if collect and n:
+                buf = (C.c_char * (n * RECORD_DTYPE.itemsize)).from_address(recs)
+                chunks.append(np.frombuffer(buf, dtype=RECORD_DTYPE).copy())
+            return 0
+
+        cb = _SINK(sink)
+        npairs, nrec = C.c_uint64(0), C.c_uint64(0)
+        f = filters._c()
+        self._check(self._lib.twk_hip_ld_region(self._ctx, mode, C.byref(f), a0, nA, b0, nB, int(bool(triangle)), part,
+                                                n_parts, tile_variants, int(window), l_window, cb, None,
+                                                C.byref(npairs), C.byref(nrec)), "twk_hip_ld_region")
         recs = np.concatenate(chunks) if chunks else np.zeros(0, dtype=RECORD_DTYPE)
         return recs, npairs.value, nrec.value
 
