@@ -40,7 +40,13 @@ CONFIGS = {
     "cfg3": (1_000_000, 50_000, "unphased"),   # BASELINE.json configs[2]: the metric's workload
     "cfg2": (100_000, 10_000, "phased"),       # configs[1]
     "cfg1": (1_000, 1_000, "unphased"),        # configs[0] (plumbing size)
+    # configs[4]: windowed (+-500 kb at 100 bp spacing = 5,000 partners per variant), Fisher P <= 1e-6.
+    # 500 GB of bitvectors: every rank holds only its band of rows plus the halo its window reaches.
+    "cfg5": (10_000_000, 200_000, "unphased"),
 }
+NAMES = {"cfg1": "configs[0]", "cfg2": "configs[1]", "cfg3": "configs[2]", "cfg5": "configs[4]"}
+WINDOW_BP = {"cfg5": 500_000}
+MIN_P = {"cfg5": 1e-6}
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
 VALU_PAIR_PEAK = 256 * 4 * 64 / 6.0 * 2.4e9   # and(2 cyc)+bcnt(4 cyc) per wave64 word pair, 2.4 GHz
 
@@ -95,9 +101,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
     ap.add_argument("--variants", type=int, default=0, help="override the number of variants (debug)")
+    ap.add_argument("--samples", type=int, default=0, help="override the number of samples (debug)")
     ap.add_argument("--tile", type=int, default=0, help="super-tile edge in variants (0 = engine default)")
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--emulate-shard", default="", help="K/N: run shard K of N on this one GPU (validation of the "
+                    "sharded configs on a single-GPU box; the value then covers that shard only)")
     args = ap.parse_args()
 
     import torch
@@ -129,17 +138,46 @@ def main():
     n_samples, n_variants, mode = CONFIGS[args.config]
     if args.variants:
         n_variants = args.variants
+    if args.samples:
+        n_samples = args.samples
     hip_mode = T.MODE_UNPHASED if mode == "unphased" else T.MODE_PHASED
-    filters = T.Filters()                      # reference defaults: r2 >= 0.1, P <= 1
+    filters = T.Filters(minP=MIN_P.get(args.config, 1.0))   # reference defaults: r2 >= 0.1, P <= 1
+    window_bp = WINDOW_BP.get(args.config, 0)
+    shard_rank, shard_world = rank, world
+    if args.emulate_shard:
+        assert world == 1, "--emulate-shard is a single-process facility"
+        shard_rank, shard_world = (int(x) for x in args.emulate_shard.split("/"))
 
     eng = T.HipLd(local_rank)
     t0 = time.time()
-    eng.set_problem(n_samples, n_variants)
-    eng.generate_synthetic(args.seed)          # every rank generates the same bits in its own HBM
+    slab = None
+    if window_bp:
+        # Band of rows with 1/world of the in-window pairs + the halo its last row reaches (positions are
+        # 1000 + 100 v: SURVEY 8(d)); every rank derives the same partition from the positions alone.
+        wv = window_bp // 100
+        cost = np.minimum(wv, n_variants - 1 - np.arange(n_variants, dtype=np.int64))
+        cum = np.concatenate(([0], np.cumsum(cost)))
+        def boundary(k):
+            if k <= 0:
+                return 0
+            if k >= shard_world:
+                return n_variants
+            r = int(np.searchsorted(cum, cum[-1] * k // shard_world, side="left"))
+            return min(n_variants, (r + 32) // 64 * 64)
+        r0, r1 = boundary(shard_rank), boundary(shard_rank + 1)
+        col_end = min(n_variants, r1 + wv)
+        slab = (r0, r1, col_end)
+        eng.set_problem(n_samples, col_end - r0)
+        eng.generate_synthetic(args.seed, first_variant=r0)
+        total_pairs = int(cum[-1])
+        my_expected = int(cum[r1] - cum[r0])
+    else:
+        eng.set_problem(n_samples, n_variants)
+        eng.generate_synthetic(args.seed)          # every rank generates the same bits in its own HBM
+        total_pairs = n_variants * (n_variants - 1) // 2
     torch.cuda.synchronize()
-    log(f"{args.config}: N={n_samples} M={n_variants} {mode}; input resident in HBM after {time.time() - t0:.1f}s")
-
-    total_pairs = n_variants * (n_variants - 1) // 2
+    log(f"{args.config}: N={n_samples} M={n_variants} {mode}{' slab ' + str(slab) if slab else ''}; "
+        f"input resident in HBM after {time.time() - t0:.1f}s")
 
     def barrier():
         torch.cuda.synchronize()
@@ -149,7 +187,13 @@ def main():
 
     def step():
         """One pass of the hot path over this rank's shard + the gather of survivors to rank 0."""
-        recs, npairs, nrec = eng.ld_all(hip_mode, filters, part=rank, n_parts=world, tile_variants=args.tile)
+        if slab:
+            r0, r1, col_end = slab
+            recs, npairs, nrec = eng.ld_region(hip_mode, filters, 0, r1 - r0, 0, col_end - r0, True,
+                                               tile_variants=args.tile, window=1, l_window=window_bp)
+            assert npairs == my_expected, (npairs, my_expected)
+        else:
+            recs, npairs, nrec = eng.ld_all(hip_mode, filters, part=shard_rank, n_parts=shard_world, tile_variants=args.tile)
         if world > 1:
             gather_records(recs, dst=0, device=dev)      # RCCL: all_gather(counts) + gather(payload)
         return npairs, nrec
@@ -175,7 +219,8 @@ def main():
         dist.all_reduce(sums, op=dist.ReduceOp.SUM)
     elapsed_max, count_ms_max, stats_ms_max = (float(x) for x in stats.tolist())
     pairs_all, recs_all, launches_all, row_pairs_all = (float(x) for x in sums.tolist())
-    assert int(round(pairs_all)) == total_pairs * args.steps, (pairs_all, total_pairs * args.steps)
+    if not args.emulate_shard:
+        assert int(round(pairs_all)) == total_pairs * args.steps, (pairs_all, total_pairs * args.steps)
 
     if rank == 0:
         value = pairs_all / elapsed_max
@@ -203,9 +248,11 @@ def main():
             "value": value, "unit": "variant-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[2]: {n_samples} samples x {n_variants} variants, all-vs-all "
-                                   f"{mode} genotype LD (calc {'-u' if mode == 'unphased' else '-p'}, r2>=0.1), "
-                                   f"{total_pairs} pairs/step",
+            "config": {"workload": (f"BASELINE {NAMES[args.config]}: {n_samples} samples x {n_variants} variants, "
+                                    + (f"windowed +-{window_bp} bp" if window_bp else "all-vs-all")
+                                    + f" {mode} genotype LD (calc {'-u' if mode == 'unphased' else '-p'}, r2>=0.1"
+                                    + (f", P<={filters.minP:g}" if filters.minP < 1 else "") + f"), {total_pairs} pairs/step"
+                                    + (f"; EMULATED shard {args.emulate_shard} only" if args.emulate_shard else "")),
                        "n_samples": n_samples, "n_variants": n_variants, "mode": mode, "tile_variants": args.tile,
                        "partition": f"equal-area row bands of the pair triangle over {world} GPU(s), RCCL gather of survivors",
                        "survivors_per_step": recs_all / args.steps},

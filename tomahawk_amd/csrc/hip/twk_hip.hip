@@ -673,8 +673,27 @@ int twk_hip_ld_region(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint32
 	const int Pmax = two_pass_auto ? 3 : planes_per_variant(plane_kind_for(c, mode == TWK_HIP_MODE_PHASED || (mode == TWK_HIP_MODE_AUTO && !c->any_missing)));
 	uint32_t S = tile_variants ? tile_variants : (16384u / (uint32_t)Pmax);
 	if (windowed && !tile_variants && r1 > r0) {
-		const uint64_t wv = (cum[r1] - cum[r0]) / (r1 - r0);              // mean partners per row
-		S = std::min<uint32_t>(S, std::max<uint32_t>(512u, round_up((uint32_t)std::min<uint64_t>(wv / 4, 1u << 20), TILE)));
+		// Search the row-block height: total rounds = sum over row blocks of ceil(blocks / resident),
+		// blocks = the diagonal part + the rectangle out to the farthest reachable column.
+		const uint64_t wv = std::max<uint64_t>(1, (cum[r1] - cum[r0]) / (r1 - r0));   // mean partners per row
+		const uint32_t s_hi = std::min<uint32_t>(S, std::max<uint32_t>(512u, round_up((uint32_t)std::min<uint64_t>(wv, 1u << 20), 64)));
+		const uint32_t s_lo = std::max<uint32_t>(128u, std::min<uint32_t>(s_hi, round_up((uint32_t)std::min<uint64_t>(wv / 8, 1u << 20), 64)));
+		const uint64_t R = c->resident_blocks;
+		auto rb = [&](uint64_t nv) -> uint64_t { return (nv * Pmax + TILE - 1) / TILE; };
+		uint32_t best = s_lo; uint64_t best_cost = ~0ull;
+		for (uint32_t cand = s_lo; cand <= s_hi; cand += 64) {
+			uint64_t cost = 0;
+			for (uint32_t x = r0; x < r1; x += cand) {
+				const uint32_t h = std::min(cand, r1 - x);
+				const uint32_t cs = triangle ? x : lo[x], ce = hi[x + h - 1];
+				if (ce <= cs) continue;
+				const uint64_t ra = rb(h), rbw = rb(std::max<uint32_t>(ce - cs, triangle ? h : 0));
+				const uint64_t blocks = triangle ? ra * (ra + 1) / 2 + ra * (rbw > ra ? rbw - ra : 0) : ra * rbw;
+				cost += (blocks + R - 1) / R;
+			}
+			if (cost < best_cost || (cost == best_cost && cand > best)) { best_cost = cost; best = cand; }
+		}
+		S = best;
 	}
 	S = std::max<uint32_t>(TILE, std::min<uint32_t>(S / TILE * TILE, 32768u));
 	S = std::min(S, round_up(std::max(nA, nB), TILE));
@@ -707,10 +726,13 @@ int twk_hip_ld_region(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint32
 		return diag ? ra * (ra + 1) / 2 + ra * (rb - ra) : ra * rb;
 	};
 	auto choose_col_step = [&](uint32_t h, uint32_t col0, bool first_is_diag) -> uint32_t {
-		// window mode: keep square tiles so that whole out-of-window tiles can be skipped
-		if (tile_variants || (window & TWK_HIP_OPT_WINDOW) || col0 >= nB) return std::max(S, h);
+		if (tile_variants || col0 >= nB) return std::max(S, h);
 		const uint64_t R = c->resident_blocks, ra = rows_of(h);
 		const uint64_t max_rows_b = std::min<uint64_t>(((2ull << 30) / 4) / (ra * TILE), 32768ull * Pmax / TILE);   // blocks
+		// window mode: the column range of a row block is already cut to what it can reach: one launch
+		// (or as few as the 2 GiB bound on C allows)
+		if (window & TWK_HIP_OPT_WINDOW)
+			return std::max<uint32_t>(h, (uint32_t)std::min<uint64_t>(32768ull, max_rows_b * TILE / Pmax / 64 * 64));
 		uint32_t best = std::max(S, h); uint64_t best_cost = ~0ull;
 		for (uint32_t sc = round_up(h, 64); sc <= 32768; sc += 64) {
 			if (rows_of(sc) > max_rows_b) break;
