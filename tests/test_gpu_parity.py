@@ -108,6 +108,43 @@ def test_records_with_missing(hip, mode):
     util.assert_records_match(got, want, variants, exact_counts=False)
 
 
+@pytest.mark.parametrize("window", [0, 1])
+def test_default_mode_regrouped_equals_per_tile_two_pass(hip, window):
+    """Default mode with missing genotypes: the whole-triangle run (plain phased products for every
+    pair + 3-plane products for the pairs that involve a variant with missing data, on the regrouped
+    plane set) gives the records of the per-tile two-pass path (sub-regions), and of the oracle."""
+    N, M, W = 128, 700, 6000
+    al = util.random_alleles(M, N, 77, miss_rate=0.05, miss_variants=0.2, low_ac=3)
+    rid = np.repeat([0, 1], [400, 300]).astype(np.uint32)
+    pos = np.concatenate([np.arange(400) * 100 + 1000, np.arange(300) * 100 + 500])
+    data, mask, variants = util.upload(hip, al, pos=pos, rid=rid)
+    assert 50 < int((variants["an"] > 0).sum()) < 300
+    f = T.Filters(minR2=0.0)
+    kw = dict(window=window, l_window=W)
+    whole, npairs, nrec = hip.ld_all(T.MODE_AUTO, f, **kw)
+    assert nrec == len(whole)
+    key = lambda r: list(zip(r["idxA"].tolist(), r["idxB"].tolist()))
+    assert len(set(key(whole))) == len(whole)                  # every pair at most once
+    assert all(a < b for a, b in key(whole))                   # A is the variant that comes first in the file
+    # (1) sub-regions go through the per-tile two-pass path
+    regs = [hip.ld_region(T.MODE_AUTO, f, 0, 300, 0, 300, True, **kw),
+            hip.ld_region(T.MODE_AUTO, f, 0, 300, 300, 400, False, **kw),
+            hip.ld_region(T.MODE_AUTO, f, 300, 400, 300, 400, True, **kw)]
+    ref = np.concatenate([r[0] for r in regs])
+    assert sum(r[1] for r in regs) == npairs
+    a = np.sort(whole, order=["idxA", "idxB"]); b = np.sort(ref, order=["idxA", "idxB"])
+    assert a.tobytes() == b.tobytes()
+    # (2) shards of the regrouped run partition it
+    parts = [hip.ld_all(T.MODE_AUTO, f, part=k, n_parts=3, **kw) for k in range(3)]
+    assert sum(p[1] for p in parts) == npairs and sum(p[2] for p in parts) == nrec
+    c = np.sort(np.concatenate([p[0] for p in parts]), order=["idxA", "idxB"])
+    assert a.tobytes() == c.tobytes()
+    # (3) the oracle
+    if not window:
+        want = O.all_pairs(data, mask, variants, N, O.settings(minR2=0.0), vector_only=True)
+        util.assert_records_match(whole, want, variants, exact_counts=False)
+
+
 def test_sharded_union_equals_whole(hip):
     """The multi-GPU partition: shards are disjoint and their union is the whole triangle."""
     N, M = 200, 700

@@ -300,7 +300,8 @@ struct TileView {
 	const uint32_t* rowpop;   // popcount of every plane row (global row index)
 	int kind;
 	uint32_t n_samples;
-	uint32_t a0, b0;          // first variant of the tile rows / cols
+	uint32_t a0, b0;          // first variant of the tile rows / cols (index into the plane set)
+	const uint32_t* ids;      // plane-set index -> variant id; null: the plane set is in file order
 };
 
 // 2x2 table (alleleCounts[0],[1],[4],[5]) of local pair (i,j).
@@ -379,8 +380,14 @@ void k_ld_stats(const StatsParams p) {
 	bool keep = false;
 	twk_hip_record rec;
 	if (i < p.nA && j < p.nB) {
-		const uint32_t A = p.tv.a0 + i, B = p.tv.b0 + j;
-		bool todo = A < p.n_variants && B < p.n_variants && (!p.diag || B > A);
+		const uint32_t sA = p.tv.a0 + i, sB = p.tv.b0 + j;       // positions in the plane set
+		bool todo = sA < p.n_variants && sB < p.n_variants && (!p.diag || sB > sA);
+		// A regrouped plane set (ids != null) can meet a pair in either order; the record always
+		// has the variant that comes first in the file as A, like the reference's i < j loops.
+		uint32_t A = sA, B = sB;
+		if (todo && p.tv.ids) { A = p.tv.ids[sA]; B = p.tv.ids[sB]; }
+		const bool flip = A > B;
+		if (flip) { const uint32_t x = A; A = B; B = x; }
 		// ld_engine.cpp:1918 / 2033: nothing to learn from two singletons
 		if (todo && !(p.window & TWK_HIP_OPT_KEEP_LOW_AC) && p.vm.ac[A] + p.vm.ac[B] <= 2) todo = false;
 		if (todo && p.auto_select) {
@@ -395,10 +402,17 @@ void k_ld_stats(const StatsParams p) {
 			if (p.phased_math) {
 				uint64_t c[4];
 				d_cells_phased(p.tv, i, j, c);
+				if (flip) { const uint64_t x = c[1]; c[1] = c[2]; c[2] = x; }
 				keep = d_phased_math(c[0], c[1], c[2], c[3], p.vm, A, B, p.filt, &rec);
 			} else {
 				uint64_t c[9];
 				d_cells_unphased(p.tv, i, j, c);
+				if (flip) {          // transpose the 3x3 table
+					uint64_t x;
+					x = c[1]; c[1] = c[3]; c[3] = x;
+					x = c[2]; c[2] = c[6]; c[6] = x;
+					x = c[5]; c[5] = c[7]; c[7] = x;
+				}
 				keep = d_unphased_math(c, p.vm, A, B, p.filt, &rec);
 			}
 		}

@@ -90,10 +90,12 @@ __device__ __forceinline__ uint32_t compress_even(uint64_t x) {
 // One thread per output word (32 samples) of one variant.
 __global__ void k_build_unphased(const uint32_t* __restrict__ raw, const uint32_t* __restrict__ rawmask,
                                  uint32_t Wp, uint32_t n_samples, uint32_t n_variants,
-                                 uint32_t* __restrict__ planes, uint32_t Wu, int P) {
+                                 uint32_t* __restrict__ planes, uint32_t Wu, int P,
+                                 const uint32_t* __restrict__ ids) {
 	const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
 	if (w >= Wu) return;
-	for (uint32_t v = blockIdx.y; v < n_variants; v += gridDim.y) {
+	for (uint32_t slot = blockIdx.y; slot < n_variants; slot += gridDim.y) {
+	const uint32_t v = ids ? ids[slot] : slot;     // ids: plane-set position -> variant (regrouped set)
 	uint64_t x = 0, m = 0;
 	if (2 * w + 1 < Wp || 2 * w < Wp) {
 		const uint32_t lo = (2 * w < Wp) ? raw[(size_t)v * Wp + 2 * w] : 0;
@@ -114,9 +116,9 @@ __global__ void k_build_unphased(const uint32_t* __restrict__ raw, const uint32_
 	else if (n_samples - s0 < 32) valid = (1u << (n_samples - s0)) - 1;
 	ms &= valid;
 	const uint32_t keep = valid & ~ms;
-	planes[((size_t)v * P + 0) * Wu + w] = (a0 ^ a1) & keep;
-	planes[((size_t)v * P + 1) * Wu + w] = (a0 & a1) & keep;
-	if (P == 3) planes[((size_t)v * P + 2) * Wu + w] = ms;
+	planes[((size_t)slot * P + 0) * Wu + w] = (a0 ^ a1) & keep;
+	planes[((size_t)slot * P + 1) * Wu + w] = (a0 & a1) & keep;
+	if (P == 3) planes[((size_t)slot * P + 2) * Wu + w] = ms;
 	}
 }
 

@@ -33,7 +33,23 @@ struct PlaneSet {
 	uint32_t  rows_alloc = 0;
 	bool      built = false;
 	bool      owns_rows = false;
+	// regrouped set only: position in the set -> variant id (device + host), and how many
+	// variants with missing genotypes lead the set
+	uint32_t* ids = nullptr;
+	std::vector<uint32_t> h_ids;
+	uint32_t  n_front = 0;
 };
+
+// Plane sets a context can hold: one per PlaneKind in file order, plus the masked unphased planes
+// regrouped so that the variants with missing genotypes come first (both groups in file order).
+// Default-mode runs (reference: phased math unless either variant has missing data)
+// then need the expensive 3-plane products only for the pairs that involve the leading group:
+// a triangle over it plus its rectangle against the rest.
+enum { PS_GROUPED = 4, N_PLANE_SETS = 5 };
+inline int set_kind(int set) { return set == PS_GROUPED ? (int)PK_UNPHASED_MASKED : set; }
+// internal modes of the two stages of such a run
+enum { MODE_INT_AUTO_CLEAN = 0x10,     // phased math on the plain planes; pairs without missing data only
+       MODE_INT_GROUPED    = 0x11 };   // unphased math on the regrouped planes; every pair of the tile
 
 struct Slot {                      // one in-flight tile (double buffered)
 	uint32_t* C = nullptr; size_t C_words = 0;
@@ -60,7 +76,7 @@ struct twk_hip_ctx {
 	uint32_t *d_ac = nullptr, *d_an = nullptr, *d_pos = nullptr, *d_rid = nullptr, *d_missing = nullptr;
 	double* d_hwe = nullptr;
 	std::vector<twk_hip_variant_meta> h_meta;
-	PlaneSet planes[4];
+	PlaneSet planes[N_PLANE_SETS];
 	Slot slot[3];                  // [0],[1]: ld_all pipeline; [2]: synchronous single-tile calls
 	twk_hip_record* h_recs = nullptr; unsigned long long h_recs_cap = 0;   // pinned staging
 	twk_hip_timing timing{};
@@ -84,6 +100,7 @@ void free_planes(twk_hip_ctx* c) {
 	for (auto& p : c->planes) {
 		if (p.owns_rows && p.rows) (void)hipFree(p.rows);
 		if (p.rowpop) (void)hipFree(p.rowpop);
+		if (p.ids) (void)hipFree(p.ids);
 		p = PlaneSet();
 	}
 }
@@ -110,9 +127,10 @@ int plane_kind_for(const twk_hip_ctx* c, bool phased) {
 	return c->any_missing ? PK_UNPHASED_MASKED : PK_UNPHASED;
 }
 
-int ensure_planes(twk_hip_ctx* c, int kind) {
-	PlaneSet& ps = c->planes[kind];
+int ensure_planes(twk_hip_ctx* c, int set) {
+	PlaneSet& ps = c->planes[set];
 	if (ps.built) return TWK_HIP_OK;
+	const int kind = set_kind(set);
 	const int P = planes_per_variant(kind);
 	const bool wide = (kind == PK_PHASED || kind == PK_PHASED_MASKED);
 	ps.W = wide ? c->Wp : c->Wu;
@@ -126,13 +144,21 @@ int ensure_planes(twk_hip_ctx* c, int kind) {
 		HIPCHK(c, hipMalloc((void**)&ps.rows, bytes));
 		ps.owns_rows = true;
 		HIPCHK(c, hipMemsetAsync(ps.rows, 0, bytes, c->s_compute));
+		if (set == PS_GROUPED) {
+			ps.h_ids.clear(); ps.h_ids.reserve(c->M);
+			for (uint32_t v = 0; v < c->M; ++v) if (c->h_meta[v].an) ps.h_ids.push_back(v);
+			ps.n_front = (uint32_t)ps.h_ids.size();
+			for (uint32_t v = 0; v < c->M; ++v) if (!c->h_meta[v].an) ps.h_ids.push_back(v);
+			HIPCHK(c, hipMalloc((void**)&ps.ids, (size_t)c->M * 4));
+			HIPCHK(c, hipMemcpyAsync(ps.ids, ps.h_ids.data(), (size_t)c->M * 4, hipMemcpyHostToDevice, c->s_compute));
+		}
 		const dim3 blk(256), grd((ps.W + 255) / 256, std::min<uint32_t>(c->M, 65535u));
 		if (kind == PK_PHASED_MASKED)
 			hipLaunchKernelGGL(k_build_phased_masked, grd, blk, 0, c->s_compute, c->raw, c->rawmask, c->Wp, c->M, ps.rows);
 		else
 			hipLaunchKernelGGL(k_build_unphased, grd, blk, 0, c->s_compute, c->raw,
 			                   kind == PK_UNPHASED_MASKED ? c->rawmask : (const uint32_t*)nullptr,
-			                   c->Wp, c->N, c->M, ps.rows, ps.W, P);
+			                   c->Wp, c->N, c->M, ps.rows, ps.W, P, (const uint32_t*)ps.ids);
 		HIPCHK(c, hipGetLastError());
 	}
 	HIPCHK(c, hipMalloc((void**)&ps.rowpop, (size_t)ps.rows_alloc * 4));
@@ -180,9 +206,9 @@ Geometry tile_geometry(int P, const twk_hip_tile_desc& t) {
 }
 
 // Launch the count kernel for one tile on the compute stream.
-int launch_count(twk_hip_ctx* c, int kind, const twk_hip_tile_desc& t, Slot& s, hipEvent_t e0, hipEvent_t e1, uint64_t* row_pairs) {
-	const PlaneSet& ps = c->planes[kind];
-	const int P = planes_per_variant(kind);
+int launch_count(twk_hip_ctx* c, int set, const twk_hip_tile_desc& t, Slot& s, hipEvent_t e0, hipEvent_t e1, uint64_t* row_pairs) {
+	const PlaneSet& ps = c->planes[set];
+	const int P = planes_per_variant(set_kind(set));
 	const Geometry g = tile_geometry(P, t);
 	if ((uint64_t)t.rowA0 * P + g.rowsA > ps.rows_alloc || (uint64_t)t.rowB0 * P + g.rowsB > ps.rows_alloc) return TWK_HIP_E_INVALID;
 	const int diag = (t.diag && t.rowA0 == t.rowB0) ? 1 : 0;
@@ -196,13 +222,14 @@ int launch_count(twk_hip_ctx* c, int kind, const twk_hip_tile_desc& t, Slot& s, 
 	return TWK_HIP_OK;
 }
 
-StatsParams make_stats(twk_hip_ctx* c, int kind, const twk_hip_tile_desc& t, const Slot& s, bool phased_math,
+StatsParams make_stats(twk_hip_ctx* c, int set, const twk_hip_tile_desc& t, const Slot& s, bool phased_math,
                        int auto_select, const twk_hip_filters& f) {
-	const PlaneSet& ps = c->planes[kind];
+	const PlaneSet& ps = c->planes[set];
+	const int kind = set_kind(set);
 	const int P = planes_per_variant(kind);
 	StatsParams p;
 	p.tv.C = s.C; p.tv.ldc = tile_geometry(P, t).ldc; p.tv.rowpop = ps.rowpop; p.tv.kind = kind;
-	p.tv.n_samples = c->N; p.tv.a0 = t.rowA0; p.tv.b0 = t.rowB0;
+	p.tv.n_samples = c->N; p.tv.a0 = t.rowA0; p.tv.b0 = t.rowB0; p.tv.ids = ps.ids;
 	p.vm = VariantMeta{c->d_ac, c->d_an, c->d_pos, c->d_rid, c->d_missing, c->d_hwe};
 	p.nA = t.nA; p.nB = t.nB; p.n_variants = c->M;
 	p.diag = (t.diag && t.rowA0 == t.rowB0) ? 1 : 0;
@@ -220,25 +247,40 @@ uint64_t pairs_in_tile(const twk_hip_ctx* c, const twk_hip_tile_desc& t) {
 }
 
 // Enqueue everything for one tile into slot s (count [+ second pass], math, counter copy).
+// What a mode runs on a tile: one or two (plane set, math, pair selection) passes.
+struct TilePlan { int set1, set2; bool phased1; int select1; int Pmax; };
+TilePlan plan_for(const twk_hip_ctx* c, int mode) {
+	TilePlan p{PK_PHASED, -1, true, 0, 1};
+	switch (mode) {
+	case TWK_HIP_MODE_PHASED:   p.set1 = plane_kind_for(c, true); break;
+	case TWK_HIP_MODE_UNPHASED: p.set1 = plane_kind_for(c, false); p.phased1 = false; break;
+	case MODE_INT_AUTO_CLEAN:   p.select1 = 1; break;
+	case MODE_INT_GROUPED:      p.set1 = PS_GROUPED; p.phased1 = false; break;
+	default:                    // AUTO on one tile: plain phased (pairs without missing) then masked unphased
+		if (c->any_missing) { p.select1 = 1; p.set2 = PK_UNPHASED_MASKED; }
+		break;
+	}
+	p.Pmax = planes_per_variant(set_kind(p.set1));
+	if (p.set2 >= 0) p.Pmax = std::max(p.Pmax, planes_per_variant(set_kind(p.set2)));
+	return p;
+}
+
 int enqueue_tile(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, const twk_hip_filters& f, Slot& s,
                  unsigned long long capacity) {
-	const bool auto_mode = (mode == TWK_HIP_MODE_AUTO);
-	const bool two_pass = auto_mode && c->any_missing;
-	const bool phased = (mode == TWK_HIP_MODE_PHASED) || (auto_mode && !two_pass);
-	// kinds: single pass -> by mode; auto two-pass -> plain phased (pairs without missing) then masked unphased
-	const int kind1 = two_pass ? (int)PK_PHASED : plane_kind_for(c, phased);
-	const int kind2 = PK_UNPHASED_MASKED;
+	const TilePlan pl = plan_for(c, mode);
+	const bool two_pass = pl.set2 >= 0;
+	const bool phased = pl.phased1;
+	const int kind1 = pl.set1, kind2 = pl.set2;
 	int rc = ensure_planes(c, kind1); if (rc) return rc;
 	if (two_pass) { rc = ensure_planes(c, kind2); if (rc) return rc; }
-	const int Pmax = two_pass ? 3 : planes_per_variant(kind1);
-	const Geometry g = tile_geometry(Pmax, t);
+	const Geometry g = tile_geometry(pl.Pmax, t);
 	rc = ensure_slot(c, s, (size_t)g.rowsA * g.rowsB, capacity); if (rc) return rc;
 	s.two_pass = two_pass;
 
 	HIPCHK(c, hipMemsetAsync(s.n_out, 0, sizeof(unsigned long long), c->s_compute));
 	rc = launch_count(c, kind1, t, s, s.ev_c0, s.ev_c1, &s.row_pairs); if (rc) return rc;
 	{
-		const StatsParams p = make_stats(c, kind1, t, s, two_pass ? true : phased, two_pass ? 1 : 0, f);
+		const StatsParams p = make_stats(c, kind1, t, s, phased, pl.select1, f);
 		hipLaunchKernelGGL(k_ld_stats, dim3((t.nB + 255) / 256, t.nA), dim3(256), 0, c->s_compute, p);
 		HIPCHK(c, hipGetLastError());
 	}
@@ -617,15 +659,18 @@ int twk_hip_ld_all(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint32_t 
 	                         sink, user, n_pairs, n_records);
 }
 
-int twk_hip_ld_region(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint32_t a0, uint32_t nA,
-                      uint32_t b0, uint32_t nB, int32_t triangle, uint32_t part, uint32_t n_parts,
-                      uint32_t tile_variants, int32_t window, uint32_t l_window, twk_hip_record_sink sink,
-                      void* user, uint64_t* n_pairs, uint64_t* n_records) {
-	if (!c || !f || !valid_mode(mode) || n_parts == 0 || part >= n_parts) return TWK_HIP_E_INVALID;
-	if (!c->raw) return TWK_HIP_E_STATE;
-	if (nA == 0 || nB == 0 || (uint64_t)a0 + nA > c->M || (uint64_t)b0 + nB > c->M) return TWK_HIP_E_INVALID;
-	if (triangle && (a0 != b0 || nB < nA)) return TWK_HIP_E_INVALID;
-	HIPCHK(c, hipSetDevice(c->device));
+// One region in one index space: the file order, or (mode MODE_INT_GROUPED) the order of the
+// regrouped plane set.  a0/b0/nA/nB and the tiles are positions in that space.
+static int region_impl(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint32_t a0, uint32_t nA,
+                       uint32_t b0, uint32_t nB, int32_t triangle, uint32_t part, uint32_t n_parts,
+                       uint32_t tile_variants, int32_t window, uint32_t l_window, twk_hip_record_sink sink,
+                       void* user, uint64_t* n_pairs, uint64_t* n_records) {
+	const uint32_t* ids = nullptr;
+	if (mode == MODE_INT_GROUPED) {
+		int rc = ensure_planes(c, PS_GROUPED); if (rc) return rc;
+		ids = c->planes[PS_GROUPED].h_ids.data();
+	}
+	auto meta_at = [&](uint32_t i) -> const twk_hip_variant_meta& { return c->h_meta[ids ? ids[i] : i]; };
 	// ---- shard: a contiguous band of rows holding 1/n_parts of the region's pairs ----------
 	// Row i of a triangle has nA-1-i pairs, of a rectangle nB.  Equal-area bands, boundaries
 	// on multiples of 64 variants, derived identically (and without communication) by every rank.
@@ -641,10 +686,10 @@ int twk_hip_ld_region(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint32
 		lo.resize(nA); hi.resize(nA); cum.assign((size_t)nA + 1, 0);
 		uint32_t l = 0, h = 0;
 		for (uint32_t r = 0; r < nA; ++r) {
-			const twk_hip_variant_meta& R = c->h_meta[a0 + r];
-			auto before = [&](uint32_t j) { const twk_hip_variant_meta& B = c->h_meta[b0 + j];
+			const twk_hip_variant_meta& R = meta_at(a0 + r);
+			auto before = [&](uint32_t j) { const twk_hip_variant_meta& B = meta_at(b0 + j);
 				return B.rid < R.rid || (B.rid == R.rid && (uint64_t)B.pos + l_window < R.pos); };
-			auto within = [&](uint32_t j) { const twk_hip_variant_meta& B = c->h_meta[b0 + j];
+			auto within = [&](uint32_t j) { const twk_hip_variant_meta& B = meta_at(b0 + j);
 				return B.rid < R.rid || (B.rid == R.rid && B.pos <= (uint64_t)R.pos + l_window); };
 			while (l < nB && before(l)) ++l;
 			if (h < l) h = l;
@@ -669,8 +714,7 @@ int twk_hip_ld_region(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint32
 	// launch holds >= 16 rounds of resident blocks and the partial last round costs < 3 %.
 	// Window mode: about a quarter of the window (in variants), so that the corners a row block
 	// computes outside the window stay near 10 % of its work.
-	const bool two_pass_auto = (mode == TWK_HIP_MODE_AUTO) && c->any_missing;
-	const int Pmax = two_pass_auto ? 3 : planes_per_variant(plane_kind_for(c, mode == TWK_HIP_MODE_PHASED || (mode == TWK_HIP_MODE_AUTO && !c->any_missing)));
+	const int Pmax = plan_for(c, mode).Pmax;
 	uint32_t S = tile_variants ? tile_variants : (16384u / (uint32_t)Pmax);
 	if (windowed && !tile_variants && r1 > r0) {
 		// Search the row-block height: total rounds = sum over row blocks of ceil(blocks / resident),
@@ -706,10 +750,10 @@ int twk_hip_ld_region(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint32
 			// Inputs are sorted by (rid, pos) like every .twk: if both tiles lie on one contig and
 			// the gap between them exceeds the window, no pair can qualify (the reference's ticker
 			// skips the rest of the row, ld_balancing.h:191).
-			const twk_hip_variant_meta& firstA = c->h_meta[t.rowA0];
-			const twk_hip_variant_meta& lastA  = c->h_meta[t.rowA0 + t.nA - 1];
-			const twk_hip_variant_meta& firstB = c->h_meta[t.rowB0];
-			const twk_hip_variant_meta& lastB  = c->h_meta[t.rowB0 + t.nB - 1];
+			const twk_hip_variant_meta& firstA = meta_at(t.rowA0);
+			const twk_hip_variant_meta& lastA  = meta_at(t.rowA0 + t.nA - 1);
+			const twk_hip_variant_meta& firstB = meta_at(t.rowB0);
+			const twk_hip_variant_meta& lastB  = meta_at(t.rowB0 + t.nB - 1);
 			if (firstA.rid == lastB.rid && firstB.pos > lastA.pos && firstB.pos - lastA.pos > l_window) return;
 			if (firstA.rid == lastA.rid && firstB.rid == lastB.rid && firstA.rid != firstB.rid) return;
 		}
@@ -807,6 +851,43 @@ int twk_hip_ld_region(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint32
 	if (n_pairs) *n_pairs = tot_pairs;
 	if (n_records) *n_records = tot_recs;
 	return TWK_HIP_OK;
+}
+
+int twk_hip_ld_region(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint32_t a0, uint32_t nA,
+                      uint32_t b0, uint32_t nB, int32_t triangle, uint32_t part, uint32_t n_parts,
+                      uint32_t tile_variants, int32_t window, uint32_t l_window, twk_hip_record_sink sink,
+                      void* user, uint64_t* n_pairs, uint64_t* n_records) {
+	if (!c || !f || !valid_mode(mode) || n_parts == 0 || part >= n_parts) return TWK_HIP_E_INVALID;
+	if (!c->raw) return TWK_HIP_E_STATE;
+	if (nA == 0 || nB == 0 || (uint64_t)a0 + nA > c->M || (uint64_t)b0 + nB > c->M) return TWK_HIP_E_INVALID;
+	if (triangle && (a0 != b0 || nB < nA)) return TWK_HIP_E_INVALID;
+	HIPCHK(c, hipSetDevice(c->device));
+	const bool whole = triangle && a0 == 0 && nA == c->M && nB == c->M;
+	if (!(mode == TWK_HIP_MODE_AUTO && c->any_missing && whole))
+		return region_impl(c, mode, f, a0, nA, b0, nB, triangle, part, n_parts, tile_variants, window, l_window,
+		                   sink, user, n_pairs, n_records);
+	// Default mode over the whole triangle with missing genotypes somewhere: every pair goes through
+	// the cheap one-plane phased products, and only the pairs that involve a variant with missing
+	// data (the leading group G of the regrouped set) through the 3-plane unphased ones:
+	// G x G (triangle) and G x rest (rectangle).  Each stage is sharded on its own.
+	int rc = ensure_planes(c, PS_GROUPED); if (rc) return rc;
+	const uint32_t nG = c->planes[PS_GROUPED].n_front;
+	uint64_t pairs = 0, recs = 0, p2 = 0, r2 = 0;
+	rc = region_impl(c, MODE_INT_AUTO_CLEAN, f, 0, c->M, 0, c->M, 1, part, n_parts, tile_variants, window, l_window,
+	                 sink, user, &pairs, &recs);
+	if (rc == TWK_HIP_OK && nG >= 2) {
+		rc = region_impl(c, MODE_INT_GROUPED, f, 0, nG, 0, nG, 1, part, n_parts, tile_variants, window, l_window,
+		                 sink, user, &p2, &r2);
+		recs += r2;
+	}
+	if (rc == TWK_HIP_OK && nG >= 1 && nG < c->M) {
+		rc = region_impl(c, MODE_INT_GROUPED, f, 0, nG, nG, c->M - nG, 0, part, n_parts, tile_variants, window, l_window,
+		                 sink, user, &p2, &r2);
+		recs += r2;
+	}
+	if (n_pairs) *n_pairs = pairs;          // every pair of the shard is evaluated exactly once
+	if (n_records) *n_records = recs;
+	return rc;
 }
 
 int twk_hip_shard_rows(uint32_t n_rows, uint32_t n_cols, int32_t triangle, uint32_t part, uint32_t n_parts,
