@@ -16,6 +16,10 @@
 //   twkinfo file.twk      -> header + per-variant metadata as read by the
 //                            reference reader (format parity of our writer)
 //   fisher n11 n12 n21 n22 -> kt_fisher_exact left right two (%.17g)
+//   view ... / sort ...   -> the reference's own CLI entry points view() / sort()
+//                            (lib/view.h:62, lib/sort.h:43; header-only, included from
+//                            where they lie) with their own option parsing
+//   twoinfo file.two      -> index of a .two: state, block entries, per-contig entries
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -27,6 +31,8 @@
 #include "two_reader.h"
 #include "twk_reader.h"
 #include "fisher_math.h"
+#include "view.h"      // int view(int, char**)  -- reference CLI function, lib/view.h:62
+#include "sort.h"      // int sort(int, char**)  -- reference CLI function, lib/sort.h:43
 
 // The executable owns these globals in the reference too (lib/main.cpp:4-5,
 // include/tomahawk.h:30-35); the library reads LITERAL_COMMAND_LINE at
@@ -119,6 +125,22 @@ static int do_twkinfo(const char* file) {
 	return 0;
 }
 
+static int do_twoinfo(const char* file) {
+	tomahawk::two_reader rdr;
+	if (!rdr.Open(file)) return 1;
+	printf("#state=%d n=%llu m_ent=%llu\n", (int)rdr.index.state, (unsigned long long)rdr.index.n,
+	       (unsigned long long)rdr.index.m_ent);
+	for (uint64_t i = 0; i < rdr.index.n; ++i) {
+		const tomahawk::IndexEntryOutput& e = rdr.index.ent[i];
+		printf("#block\t%d\t%d\t%u\t%u\t%u\t%u\n", e.rid, e.ridB, e.n, e.minpos, e.maxpos, e.b_unc);
+	}
+	for (uint64_t i = 0; i < rdr.index.m_ent; ++i) {
+		const tomahawk::IndexEntryEntry& e = rdr.index.ent_meta[i];
+		printf("#contig\t%d\t%u\t%u\t%u\t%llu\n", e.rid, e.n, e.minpos, e.maxpos, (unsigned long long)e.nn);
+	}
+	return 0;
+}
+
 int main(int argc, char** argv) {
 	if (argc < 2) { fprintf(stderr, "usage: tomahawk_ref calc|scalc|dump|twkinfo|fisher ...\n"); return 2; }
 	tomahawk::LITERAL_COMMAND_LINE = tomahawk::TOMAHAWK_PROGRAM_NAME;
@@ -128,6 +150,9 @@ int main(int argc, char** argv) {
 	if (cmd == "scalc") return do_calc(argc - 1, argv + 1, true);
 	if (cmd == "dump" && argc == 3) return do_dump(argv[2]);
 	if (cmd == "twkinfo" && argc == 3) return do_twkinfo(argv[2]);
+	if (cmd == "twoinfo" && argc == 3) return do_twoinfo(argv[2]);
+	if (cmd == "view") { optind = 1; return view(argc - 1, argv + 1); }
+	if (cmd == "sort") { optind = 1; return sort(argc - 1, argv + 1); }
 	if (cmd == "fisher" && argc == 6) {
 		double l, r, t;
 		kt_fisher_exact(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), &l, &r, &t);

@@ -15,6 +15,7 @@
 #include "twk_ld.h"
 #include "twk_format.h"
 #include "twk_hip.h"
+#include "twk_two_tools.h"
 
 namespace tomahawk { std::string LITERAL_COMMAND_LINE; }
 
@@ -173,6 +174,133 @@ static int concat(int argc, char** argv) {
 	return 0;
 }
 
+// `tomahawk view` (lib/view.h:28-459): same flags; -h prints the header only and -H drops it,
+// as the reference's option switch has them (view.h:367-368).
+static void view_usage() {
+	program_message();
+	std::cerr <<
+	"About:  Convert binary TWO->LD/TWO, subset and slice TWO data\n\n"
+	"Usage:  tomahawk view [options] -i <in.two>\n\n"
+	"Options:\n"
+	"  -i FILE   input TWO file (required)\n"
+	"  -h/H      (twk/two) header only / no header\n"
+	"  -I STRING filter interval <contig>:pos-pos (TWK/TWO) or linked interval <contig>:pos-pos,<contig>:pos-pos\n\n"
+	"  -o FILE    output file (- for stdout; default: -)\n"
+	"  -O <b|u>   b: compressed TWO, u: uncompressed LD\n\n"
+	"Filter parameters:\n"
+	"  -r,-R --minR2,--maxR2   FLOAT   Pearson's R-squared min/max cut-off value\n"
+	"  -z,-Z --minR,--maxR     FLOAT   Pearson's R min/max cut-off value\n"
+	"  -p,-P --minP,--maxP     FLOAT   Min/max P-value (default: [0,1])\n"
+	"  -d,-D --minD,--maxD     FLOAT   Min/max D value (default: [-1,1])\n"
+	"  -b,-B --minDP,--maxDP   FLOAT   Min/max D' value (default: [0,1])\n"
+	"  -1,-5 --minP1,--maxP1   FLOAT   Min/max REF_REF count (default: [0,inf])\n"
+	"  -2,-6 --minP2,--maxP2   FLOAT   Min/max REF_ALT count (default: [0,inf])\n"
+	"  -3,-7 --minQ1,--maxQ1   FLOAT   Min/max ALT_REF count (default: [0,inf])\n"
+	"  -4,-8 --minQ2,--maxQ1   FLOAT   Min/max ALT_ALT count (default: [0,inf])\n"
+	"  -a,-A --minMHC,--maxMHC FLOAT   Min/max number of non-major haplotype count (default: [0,inf])\n"
+	"  -x,-X --minChi,--maxChi FLOAT   Min/max Chi-squared CV of contingency table (default: [0,inf])\n"
+	"  -m,-M --minMCV,--maxMCV FLOAT   Min/max Chi-squared CV of unphased model (default: [0,inf])\n"
+	"  -f  INT  include FLAG value\n"
+	"  -F  INT  exclude FLAG value\n"
+	"  -u       output only the upper triangular values\n"
+	"  -l       output only the lower triangular values\n"
+	"  -t INT   number of worker threads (default: all; not in the reference)\n";
+}
+
+static int view(int argc, char** argv) {
+	if (argc < 3) { view_usage(); return 0; }
+	static struct option long_options[] = {
+		{"input", required_argument, 0, 'i'}, {"output", optional_argument, 0, 'o'}, {"output-type", optional_argument, 0, 'O'},
+		{"minP", optional_argument, 0, 'p'}, {"maxP", optional_argument, 0, 'P'}, {"minR", optional_argument, 0, 'z'},
+		{"maxR", optional_argument, 0, 'Z'}, {"minR2", optional_argument, 0, 'r'}, {"maxR2", optional_argument, 0, 'R'},
+		{"minDP", optional_argument, 0, 'b'}, {"maxDP", optional_argument, 0, 'B'}, {"minD", optional_argument, 0, 'd'},
+		{"maxD", optional_argument, 0, 'D'}, {"minP1", optional_argument, 0, '1'}, {"minP2", optional_argument, 0, '2'},
+		{"minQ1", optional_argument, 0, '3'}, {"minQ2", optional_argument, 0, '4'}, {"maxP1", optional_argument, 0, '5'},
+		{"maxP2", optional_argument, 0, '6'}, {"maxQ1", optional_argument, 0, '7'}, {"maxQ2", optional_argument, 0, '8'},
+		{"minMHC", optional_argument, 0, 'a'}, {"maxMHC", optional_argument, 0, 'A'}, {"minChi", optional_argument, 0, 'x'},
+		{"maxChi", optional_argument, 0, 'X'}, {"minMCV", optional_argument, 0, 'm'}, {"maxMCV", optional_argument, 0, 'M'},
+		{"flagInclude", optional_argument, 0, 'f'}, {"flagExclude", optional_argument, 0, 'F'},
+		{"upperTriangular", no_argument, 0, 'u'}, {"lowerTriangular", no_argument, 0, 'l'},
+		{"headerOnly", no_argument, 0, 'H'}, {"noHeader", no_argument, 0, 'h'}, {"interval", optional_argument, 0, 'I'},
+		{"threads", required_argument, 0, 't'}, {0, 0, 0, 0}};
+	static const std::regex re_float("^[-+]?[0-9]*\\.?[0-9]+([eE][-+]?[0-9]+)?$"), re_number("^[0-9]+$");   // tomahawk.h:61-62
+	tomahawk::two_view_settings st;
+	tomahawk::TwoFilter& f = st.filter;
+	using F = tomahawk::TwoFilter;
+	int c = 0, long_index = 0;
+	while ((c = getopt_long(argc, argv, "i:HhI:o:O:r:R:z:Z:p:P:d:D:b:B:1:2:3:4:5:6:7:8:x:X:a:A:m:M:f:F:ult:", long_options, &long_index)) != -1) {
+		double* dst = nullptr; F::Bit bit = F::R2;
+		switch (c) {
+		case ':': fprintf(stderr, "%s: option `-%c' requires an argument\n", argv[0], optopt); continue;
+		case '?': default: fprintf(stderr, "%s: option `-%c' is invalid: ignored\n", argv[0], optopt); continue;
+		case 'i': st.in = optarg; continue;
+		case 'o': st.out = optarg; continue;
+		case 'O': if (std::string(optarg).size() != 1) { std::cerr << "illegal O" << std::endl; return 1; } st.mode = optarg[0]; continue;
+		case 'u': f.set(F::UPPER); continue;
+		case 'l': f.set(F::LOWER); continue;
+		case 'h': st.header_only = true; continue;
+		case 'H': st.write_header = false; continue;
+		case 'I': st.ivals.push_back(optarg); continue;
+		case 't': st.n_threads = atoi(optarg); continue;
+		case 'f': case 'F':
+			if (!std::regex_match(std::string(optarg), re_number)) { std::cerr << "not a valid number" << std::endl; return 1; }
+			(c == 'f' ? f.flag_include : f.flag_exclude) = (uint32_t)atof(optarg); f.set(F::FLAGS); continue;
+		case 'p': dst = &f.minP; bit = F::P; break;          case 'P': dst = &f.maxP; bit = F::P; break;
+		case 'z': dst = &f.minR; bit = F::R; break;          case 'Z': dst = &f.maxR; bit = F::R; break;
+		case 'r': dst = &f.minR2; bit = F::R2; break;        case 'R': dst = &f.maxR2; bit = F::R2; break;
+		case 'b': dst = &f.minDprime; bit = F::DPRIME; break; case 'B': dst = &f.maxDprime; bit = F::DPRIME; break;
+		case 'd': dst = &f.minD; bit = F::D; break;          case 'D': dst = &f.maxD; bit = F::D; break;
+		case '1': dst = &f.hA_min; bit = F::HAPA; break;     case '5': dst = &f.hA_max; bit = F::HAPA; break;
+		case '2': dst = &f.hB_min; bit = F::HAPB; break;     case '6': dst = &f.hB_max; bit = F::HAPB; break;
+		case '3': dst = &f.hC_min; bit = F::HAPC; break;     case '7': dst = &f.hC_max; bit = F::HAPC; break;
+		case '4': dst = &f.hD_min; bit = F::HAPD; break;     case '8': dst = &f.hD_max; bit = F::HAPD; break;
+		case 'a': dst = &f.mhc_min; bit = F::MHC; break;     case 'A': dst = &f.mhc_max; bit = F::MHC; break;
+		case 'x': dst = &f.minChi; bit = F::CHI; break;      case 'X': dst = &f.maxChi; bit = F::CHI; break;
+		case 'm': dst = &f.minChiModel; bit = F::CHIMODEL; break; case 'M': dst = &f.maxChiModel; bit = F::CHIMODEL; break;
+		}
+		if (!std::regex_match(std::string(optarg), re_float)) { std::cerr << "not a valid float" << std::endl; return 1; }
+		*dst = atof(optarg); f.set(bit);
+	}
+	if (st.in.empty()) { std::cerr << stamp("ERROR") << "No input value specified..." << std::endl; return 1; }
+	if (!(st.out.empty() || st.out == "-")) program_message();
+	if (st.n_threads <= 0) st.n_threads = 1;
+	return tomahawk::two_view(st);
+}
+
+// `tomahawk sort` (lib/sort.h:28-124)
+static int sort_cmd(int argc, char** argv) {
+	if (argc < 3) {
+		program_message();
+		std::cerr << "About:  Sort TWO files\n\nUsage:  tomahawk sort [options] -i <in.two>\n\nOptions:\n"
+		             "  -i FILE   input TWO file (required)\n  -o FILE   output file (- for stdout; default: -)\n"
+		             "  -m FLOAT  maximum memory usage per thread in GB (default: 0.5)\n"
+		             "  -c INT    compression level 1-20 (default: 1)\n  -t INT    number of threads (default: maximum available)\n\n";
+		return 0;
+	}
+	static struct option long_options[] = {{"input", required_argument, 0, 'i'}, {"output", optional_argument, 0, 'o'},
+		{"memory-usage", optional_argument, 0, 'm'}, {"compression-level", optional_argument, 0, 'c'},
+		{"threads", optional_argument, 0, 't'}, {0, 0, 0, 0}};
+	tomahawk::two_sorter_settings st;
+	int c = 0, long_index = 0;
+	while ((c = getopt_long(argc, argv, "i:o:m:c:t:?", long_options, &long_index)) != -1) {
+		switch (c) {
+		case 'i': st.in = optarg; break;
+		case 'o': st.out = optarg; break;
+		case 'm': st.memory_limit = (float)atof(optarg); break;
+		case 'c': st.c_level = atoi(optarg); break;
+		case 't': st.n_threads = atoi(optarg); break;
+		default: fprintf(stderr, "%s: option `-%c' is invalid: ignored\n", argv[0], optopt); break;
+		}
+	}
+	if (st.in.empty()) { std::cerr << stamp("ERROR") << "No input value specified..." << std::endl; return 1; }
+	if (st.memory_limit <= 0) { std::cerr << stamp("ERROR") << "Cannot set memory limit <= 0..." << std::endl; return 1; }
+	if (st.n_threads <= 0) { std::cerr << stamp("ERROR") << "Cannot set number of threads <= 0..." << std::endl; return 1; }
+	if (st.c_level <= 0) { std::cerr << stamp("ERROR") << "Cannot set the compression level <= 0..." << std::endl; return 1; }
+	program_message();
+	std::cerr << stamp("LOG") << "Calling sort..." << std::endl;
+	return tomahawk::two_sort(st) ? 0 : 1;
+}
+
 // Multi-GPU `calc`: one process per GPU (TWK_HIP_GPUS=n).  The launcher itself never touches
 // HIP: it re-executes this binary n times with TWK_HIP_DEVICE=k, TWK_HIP_PART=k/n and a private
 // part file, waits, and concatenates the parts (the reference's farm mode -c/-C + concat,
@@ -289,9 +417,11 @@ int main(int argc, char** argv) {
 	if (strcmp(argv[1], "calc") == 0) return calc(argc, argv);
 	if (strncmp(argv[1], "concat", 6) == 0) return concat(argc, argv);
 	if (strcmp(argv[1], "calc-single") == 0 || strcmp(argv[1], "scalc") == 0) return scalc(argc, argv);
+	if (strcmp(argv[1], "view") == 0) return view(argc, argv);
+	if (strcmp(argv[1], "sort") == 0) return sort_cmd(argc, argv);
 	if (strcmp(argv[1], "--version") == 0 || strcmp(argv[1], "version") == 0) { program_message(); return 0; }
 	if (strcmp(argv[1], "--help") == 0 || strcmp(argv[1], "help") == 0) { calc_usage(); return 0; }
 	program_message();
-	std::cerr << stamp("ERROR") << "Illegal command: only `calc`, `scalc` and `concat` are provided by the MI355X engine (view/sort/... are the reference's)" << std::endl;
+	std::cerr << stamp("ERROR") << "Illegal command: only `calc`, `scalc`, `concat`, `view` and `sort` are provided by the MI355X engine (import/decay/... are the reference's)" << std::endl;
 	return 1;
 }

@@ -9,6 +9,7 @@
 #include "twk_format.h"
 #include "twk_ld.h"
 #include "twk_hip.h"
+#include "twk_two_tools.h"
 
 using namespace tomahawk;
 
@@ -124,6 +125,59 @@ int twk_file_read_two(const char* path, void* records, uint64_t capacity, uint64
 	uint64_t idx_n = 0;
 	for (const auto& e : rd.index.ent) idx_n += e.n;
 	return idx_n == n ? 0 : -5;
+}
+
+// Write an unsorted .two (the shape calc writes): 106-byte packed records in blocks of
+// `block_records`; n_contigs contigs named "1".."n"; n_samples sample names "S<i>".
+int twk_file_write_two(const char* path, const void* records, uint64_t n_records, uint32_t n_samples,
+                       uint32_t n_contigs, uint32_t block_records, int c_level) {
+	if (!path || (!records && n_records) || block_records == 0) return -1;
+	Header hdr;
+	hdr.literals = "##fileformat=VCFv4.2\n##source=tomahawk_amd synthetic writer\n";
+	for (uint32_t s = 0; s < n_samples; ++s) hdr.samples.push_back("S" + std::to_string(s));
+	for (uint32_t c = 0; c < n_contigs; ++c) { Contig k; k.idx = c; k.name = std::to_string(c + 1); k.n_bases = 250000000; hdr.contigs.push_back(k); }
+	TwoWriter w;
+	if (!w.open(path, hdr, c_level)) return -2;
+	const TwoRecord* r = (const TwoRecord*)records;
+	for (uint64_t i = 0; i < n_records; i += block_records)
+		if (!w.write_block(r + i, (uint32_t)std::min<uint64_t>(block_records, n_records - i))) return -3;
+	return w.close() ? 0 : -3;
+}
+
+// Index of a .two.  Two-call pattern: entries [n][6] = rid, ridB, n, minpos, maxpos, b_unc (as int64);
+// contigs [m][5] = rid, n, minpos, maxpos, nn.  counts = [state, n, m].
+int twk_file_two_index(const char* path, int64_t* entries, uint64_t cap_entries, int64_t* contigs, uint64_t cap_contigs,
+                       uint64_t* counts) {
+	TwoReader rd;
+	if (!path || !rd.open(path)) return -2;
+	if (counts) { counts[0] = rd.index.state; counts[1] = rd.index.ent.size(); counts[2] = rd.index.meta.size(); }
+	if (entries) {
+		if (cap_entries < rd.index.ent.size()) return -4;
+		for (size_t i = 0; i < rd.index.ent.size(); ++i) {
+			const IndexEntryOutput& e = rd.index.ent[i];
+			int64_t* o = entries + i * 6;
+			o[0] = e.rid; o[1] = e.ridB; o[2] = e.n; o[3] = e.minpos; o[4] = e.maxpos; o[5] = e.b_unc;
+		}
+	}
+	if (contigs) {
+		if (cap_contigs < rd.index.meta.size()) return -4;
+		for (size_t i = 0; i < rd.index.meta.size(); ++i) {
+			const IndexEntryEntry& e = rd.index.meta[i];
+			int64_t* o = contigs + i * 5;
+			o[0] = e.rid; o[1] = e.n; o[2] = e.minpos; o[3] = e.maxpos; o[4] = (int64_t)e.nn;
+		}
+	}
+	return 0;
+}
+
+// two_reader::Sort through a flat argument list (lib/sort.h:93-123).
+int twk_two_sort(const char* in, const char* out, double memory_limit_gb, int c_level, int n_threads) {
+	two_sorter_settings s;
+	s.in = in ? in : ""; s.out = out ? out : "-";
+	if (memory_limit_gb > 0) s.memory_limit = (float)memory_limit_gb;
+	if (c_level > 0) s.c_level = c_level;
+	if (n_threads > 0) s.n_threads = n_threads;
+	return two_sort(s) ? 0 : 1;
 }
 
 // Header literals of a .two / .twk (NUL terminated, truncated to cap).

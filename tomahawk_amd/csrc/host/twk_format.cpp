@@ -367,6 +367,12 @@ bool TwoWriter::pack(const TwoRecord* recs, uint32_t n, int c_level, Packed& out
 	return true;
 }
 
+bool TwoWriter::pack_generic(const TwoRecord* recs, uint32_t n, int c_level, bool sorted, Packed& out) {
+	if (!pack(recs, n, c_level, out)) return false;
+	if (!sorted) { out.entry.rid = -1; out.entry.ridB = -1; out.entry.minpos = 0; out.entry.maxpos = 0; }   // writer.h:377-382
+	return true;
+}
+
 bool TwoWriter::write_packed(const Packed& p) {
 	IndexEntryOutput e = p.entry;
 	e.foff = off_;
@@ -374,6 +380,11 @@ bool TwoWriter::write_packed(const Packed& p) {
 	if (!put(&marker, 1) || !put(&unc, 4) || !put(&cmp, 4) || !put(p.z.data(), p.z.size())) return false;
 	e.fend = off_;
 	index_.ent.push_back(e);
+	if (index_.state == 2 && e.rid >= 0 && (size_t)e.rid < index_.meta.size()) {      // index.cpp:70-88
+		IndexEntryEntry& m = index_.meta[e.rid];
+		if (m.n == 0) { m.minpos = e.minpos; m.foff = e.foff; m.rid = e.rid; }
+		m.n += e.n; m.maxpos = e.maxpos; m.fend = e.fend; ++m.nn;
+	}
 	n_records += e.n; ++n_blocks;
 	return true;
 }
@@ -424,6 +435,23 @@ bool TwoReader::next_block(std::vector<TwoRecord>& recs) { // two_reader.cpp:11-
 	if (!in_.good() || !zstd_decompress(z.data(), cmp, b.v, unc)) { error = "bad block"; return false; }
 	uint32_t n = 0, m = 0;
 	if (!b.get(n) || !b.get(m) || (size_t)n * sizeof(TwoRecord) + 8 > b.size()) { error = "bad block payload"; return false; }
+	recs.resize(n);
+	b.get_bytes(recs.data(), (size_t)n * sizeof(TwoRecord));
+	return true;
+}
+
+bool TwoReader::read_block_at(std::ifstream& in, uint64_t foff, std::vector<TwoRecord>& recs) {
+	in.clear();
+	in.seekg((std::streamoff)foff);
+	uint8_t marker = 0; uint32_t unc = 0, cmp = 0;
+	in.read((char*)&marker, 1); in.read((char*)&unc, 4); in.read((char*)&cmp, 4);
+	if (!in.good() || marker != 1) return false;
+	std::vector<uint8_t> z(cmp);
+	in.read((char*)z.data(), cmp);
+	ByteBuf b;
+	if (!in.good() || !zstd_decompress(z.data(), cmp, b.v, unc)) return false;
+	uint32_t n = 0, m = 0;
+	if (!b.get(n) || !b.get(m) || (size_t)n * sizeof(TwoRecord) + 8 > b.size()) return false;
 	recs.resize(n);
 	b.get_bytes(recs.data(), (size_t)n * sizeof(TwoRecord));
 	return true;

@@ -158,6 +158,12 @@ public:
 	// pack() is thread-safe and touches no writer state; write_packed() appends in call order.
 	struct Packed { std::vector<uint8_t> z; IndexEntryOutput entry; uint32_t b_unc = 0; };
 	static bool pack(const TwoRecord* recs, uint32_t n, int c_level, Packed& out);
+	// The generic .two block of view -O b and sort (twk_two_writer_t::WriteBlockCompressedTWO,
+	// writer.h:346-396): the index entry carries contigs and positions only in a sorted file.
+	static bool pack_generic(const TwoRecord* recs, uint32_t n, int c_level, bool sorted, Packed& out);
+	// Index state (0 unsorted, 2 sorted: index.h:103-105).  In a sorted file every block also
+	// extends the per-contig entry of its ridA (writer.h:384-386, index.cpp:70-88).
+	void set_state(uint8_t s) { index_.state = s; }
 	bool write_packed(const Packed& p);
 	// Append an already compressed block under the given index entry (concat, lib/concat.h:160-175).
 	bool write_raw(uint32_t b_unc, const std::vector<uint8_t>& z, IndexEntryOutput entry);
@@ -181,6 +187,9 @@ public:
 	bool next_block(std::vector<TwoRecord>& recs);
 	// Next block as stored (still compressed): twk1_two_iterator::NextBlockRaw (two_reader.cpp:11-44).
 	bool next_block_raw(uint32_t& b_unc, std::vector<uint8_t>& z);
+	// Block at file offset `foff` (an index entry's foff) through a caller-owned stream, so that
+	// worker threads can decode different blocks of one file at once.
+	static bool read_block_at(std::ifstream& in, uint64_t foff, std::vector<TwoRecord>& recs);
 	std::string error;
 private:
 	std::ifstream in_;

@@ -33,6 +33,9 @@ def lib():
                                                    C.c_int, C.c_int]
         L.twk_file_read_twk.argtypes = [C.c_char_p, p, p, p, p, p, p]
         L.twk_file_read_two.argtypes = [C.c_char_p, p, C.c_uint64, p, p]
+        L.twk_file_write_two.argtypes = [C.c_char_p, p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
+        L.twk_file_two_index.argtypes = [C.c_char_p, p, C.c_uint64, p, C.c_uint64, p]
+        L.twk_two_sort.argtypes = [C.c_char_p, C.c_char_p, C.c_double, C.c_int, C.c_int]
         L.twk_file_header_literals.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_size_t]
         L.twk_ld_compute.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, p, p]
@@ -90,6 +93,35 @@ def read_two(path):
         if rc != 0:
             raise RuntimeError(f"twk_file_read_two failed: {rc}")
     return recs, dict(n_samples=info[0], n_contigs=info[1], n_blocks=info[2], state=info[3])
+
+
+def write_two(path, recs, n_samples=1, n_contigs=1, block_records=10000, c_level=1):
+    """Unsorted .two from TWO_DTYPE records (the shape `calc` writes)."""
+    recs = np.ascontiguousarray(recs, dtype=TWO_DTYPE)
+    rc = lib().twk_file_write_two(path.encode(), recs.ctypes.data, len(recs), n_samples, n_contigs, block_records, c_level)
+    if rc != 0:
+        raise RuntimeError(f"twk_file_write_two failed: {rc}")
+
+
+def two_index(path):
+    """Index of a .two: (state, entries [n,6] = rid, ridB, n, minpos, maxpos, b_unc; contigs [m,5] = rid, n, minpos, maxpos, nn)."""
+    cnt = (C.c_uint64 * 3)()
+    rc = lib().twk_file_two_index(path.encode(), None, 0, None, 0, cnt)
+    if rc != 0:
+        raise RuntimeError(f"twk_file_two_index failed: {rc}")
+    ent = np.zeros((cnt[1], 6), dtype=np.int64)
+    ctg = np.zeros((cnt[2], 5), dtype=np.int64)
+    rc = lib().twk_file_two_index(path.encode(), ent.ctypes.data, cnt[1], ctg.ctypes.data, cnt[2], cnt)
+    if rc != 0:
+        raise RuntimeError(f"twk_file_two_index failed: {rc}")
+    return int(cnt[0]), ent, ctg
+
+
+def sort_two(path_in, path_out, memory_limit_gb=0.5, c_level=1, n_threads=0):
+    """`tomahawk sort` (two_reader::Sort): sorted .two with a sorted index."""
+    rc = lib().twk_two_sort(path_in.encode(), path_out.encode(), memory_limit_gb, c_level, n_threads)
+    if rc != 0:
+        raise RuntimeError(f"twk_two_sort failed: {rc}")
 
 
 def header_literals(path, is_two=True):
