@@ -120,6 +120,8 @@ def test_cli_usage_and_errors():
     r = subprocess.run([hostlib.CLI_PATH, "scalc", "-i", "/nonexistent.twk", "-o", "/tmp/x", "-w", "0"], capture_output=True, text=True)
     assert r.returncode == 1 and "non-positive window" in r.stderr
     r = subprocess.run([hostlib.CLI_PATH, "view"], capture_output=True, text=True)
+    assert r.returncode == 0 and "Usage:  tomahawk view" in r.stderr            # usage, like view.h:63-66
+    r = subprocess.run([hostlib.CLI_PATH, "decay"], capture_output=True, text=True)
     assert r.returncode == 1 and "Illegal command" in r.stderr
 
 
