@@ -10,6 +10,7 @@ PKG      := tomahawk_amd
 LIBDIR   := $(PKG)/lib
 BINDIR   := $(PKG)/bin
 ZSTD_LIB ?= /usr/lib/x86_64-linux-gnu/libzstd.so.1
+ZLIB     ?= /usr/lib/x86_64-linux-gnu/libz.so.1
 
 HIP_SRC  := $(PKG)/csrc/hip/twk_hip.hip
 HIP_DEPS := $(wildcard $(PKG)/csrc/hip/*.h) include/twk_hip.h
@@ -32,7 +33,7 @@ $(LIBDIR)/libtwk_hip.so: $(HIP_SRC) $(HIP_DEPS)
 host: $(LIBDIR)/libtomahawk_amd.so
 $(LIBDIR)/libtomahawk_amd.so: $(HOST_LIB_SRC) $(HOST_DEPS) $(LIBDIR)/libtwk_hip.so
 	@mkdir -p $(LIBDIR)
-	$(CXX) $(CXXFLAGS) -shared $(HOST_LIB_SRC) -o $@ -L$(LIBDIR) -ltwk_hip $(ZSTD_LIB) -Wl,-rpath,'$$ORIGIN'
+	$(CXX) $(CXXFLAGS) -shared $(HOST_LIB_SRC) -o $@ -L$(LIBDIR) -ltwk_hip $(ZSTD_LIB) $(ZLIB) -Wl,-rpath,'$$ORIGIN'
 
 cli: $(BINDIR)/tomahawk
 $(BINDIR)/tomahawk: $(PKG)/csrc/host/calc_main.cpp $(LIBDIR)/libtomahawk_amd.so

@@ -134,6 +134,10 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=dev)
+        # RCCL sets up its rings and the point-to-point channels of gather() lazily on first use:
+        # do that once here, outside any step (one empty-ish gather + a barrier).
+        gather_records(np.zeros(1, dtype=T.RECORD_DTYPE), dst=0, device=dev)
+        dist.barrier()
 
     n_samples, n_variants, mode = CONFIGS[args.config]
     if args.variants:

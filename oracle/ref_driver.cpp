@@ -20,6 +20,7 @@
 //                            (lib/view.h:62, lib/sort.h:43; header-only, included from
 //                            where they lie) with their own option parsing
 //   twoinfo file.two      -> index of a .two: state, block entries, per-contig entries
+//   hwe hom1 het hom2     -> twk1_t::calculateHardyWeinberg (core.cpp:103-201) on three runs (%.17g)
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -141,6 +142,18 @@ static int do_twoinfo(const char* file) {
 	return 0;
 }
 
+static int do_hwe(uint32_t hom1, uint32_t het, uint32_t hom2) {
+	tomahawk::twk1_t rec;
+	tomahawk::twk1_igt_t<uint32_t>* gt = new tomahawk::twk1_igt_t<uint32_t>;
+	gt->data = new uint32_t[3];
+	gt->n = 3; gt->miss = 0;
+	gt->data[0] = hom1 << 2 | 0; gt->data[1] = het << 2 | 1; gt->data[2] = hom2 << 2 | 3;   // RLE words: len << 2 | (a << 1 | b)
+	rec.gt = gt;
+	rec.calculateHardyWeinberg();
+	printf("%.17g\n", rec.hwe);
+	return 0;
+}
+
 int main(int argc, char** argv) {
 	if (argc < 2) { fprintf(stderr, "usage: tomahawk_ref calc|scalc|dump|twkinfo|fisher ...\n"); return 2; }
 	tomahawk::LITERAL_COMMAND_LINE = tomahawk::TOMAHAWK_PROGRAM_NAME;
@@ -151,6 +164,7 @@ int main(int argc, char** argv) {
 	if (cmd == "dump" && argc == 3) return do_dump(argv[2]);
 	if (cmd == "twkinfo" && argc == 3) return do_twkinfo(argv[2]);
 	if (cmd == "twoinfo" && argc == 3) return do_twoinfo(argv[2]);
+	if (cmd == "hwe" && argc == 5) return do_hwe((uint32_t)atoi(argv[2]), (uint32_t)atoi(argv[3]), (uint32_t)atoi(argv[4]));
 	if (cmd == "view") { optind = 1; return view(argc - 1, argv + 1); }
 	if (cmd == "sort") { optind = 1; return sort(argc - 1, argv + 1); }
 	if (cmd == "fisher" && argc == 6) {

@@ -207,3 +207,32 @@ def test_cli_multi_process_shards_equal_single(tmp_path):
     key = lambda m: m[np.lexsort((m[:, 4], m[:, 2]))]
     assert len(whole) > 0 and np.array_equal(key(whole), key(multi))
     assert "Merged 3 GPU shards" in log and not [f for f in os.listdir(tmp_path) if ".part" in f]
+
+
+def test_cli_full_chain_import_calc_sort_view(tmp_path):
+    """VCF -> import -> calc (default mode, missing genotypes) -> sort -> view: the chain a user of the reference runs."""
+    from tests.test_import import write_vcf
+    N, M = 96, 300
+    al = util.random_alleles(M, N, 5, miss_rate=0.04, miss_variants=0.2)
+    pos = 500 + 25 * np.arange(M)
+    vcf, twk, direct = str(tmp_path / "in.vcf.gz"), str(tmp_path / "in.twk"), str(tmp_path / "direct.twk")
+    write_vcf(vcf, al, pos, np.zeros(M, int), gz=True)
+    cnt = hostlib.import_vcf(vcf, twk, threshold_miss=0.5, remove_univariate=False, block_size=64)
+    assert cnt["written"] == M
+    hostlib.write_twk(direct, al, pos - 1, np.zeros(M, np.uint32), np.ones(M, np.uint8), n_contigs=2, block_size=64)
+    outs = []
+    for src in (twk, direct):
+        out = str(tmp_path / (os.path.basename(src) + ".two"))
+        r = subprocess.run([hostlib.CLI_PATH, "calc", "-i", src, "-o", out, "-r", "0.05"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        outs.append(out)
+    a, b = (hostlib.read_two(o)[0] for o in outs)
+    assert len(a) > 0 and a.tobytes() == b.tobytes()           # imported file == directly written genotypes, record for record
+    srt = str(tmp_path / "sorted.two")
+    r = subprocess.run([hostlib.CLI_PATH, "sort", "-i", outs[0], "-o", srt], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([hostlib.CLI_PATH, "view", "-i", srt, "-H", "-I", "20:1000-3000", "-u"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    rows = [l.split("\t") for l in r.stdout.splitlines()[1:]]
+    sel = a[(a["packA"] >> 2 >= 1000) & (a["packA"] >> 2 <= 3000) & ((a["packA"] >> 2) < (a["packB"] >> 2))]
+    assert len(rows) == len(sel) > 0 and all(row[1] == "20" and 1001 <= int(row[2]) <= 3001 for row in rows)

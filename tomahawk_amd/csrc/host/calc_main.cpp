@@ -16,6 +16,7 @@
 #include "twk_format.h"
 #include "twk_hip.h"
 #include "twk_two_tools.h"
+#include "twk_import.h"
 
 namespace tomahawk { std::string LITERAL_COMMAND_LINE; }
 
@@ -267,6 +268,56 @@ static int view(int argc, char** argv) {
 	return tomahawk::two_view(st);
 }
 
+// `tomahawk import` (lib/import.h:28-131): VCF text (plain / gzip) -> .twk
+static int import_cmd(int argc, char** argv) {
+	if (argc < 3) {
+		program_message();
+		std::cerr << "About:  Convert VCF->TWK\n\nUsage:  tomahawk import [options] -i <in.vcf[.gz]> -o <out.twk>\n\nOptions:\n"
+		             "  -i FILE  input VCF, plain or gzip/bgzip text (required; BCF is not read)\n  -o FILE  output file prefix (required)\n"
+		             "  -n FLOAT missingness fraction in range [0,1] (default: 0.9)\n  -H FLOAT Hardy-Weinberg P-value cutoff (default: 0)\n"
+		             "  -r       do not filter out univariate sites\n  -f       flip reference and alternative alleles when the major allele is the alternative (no effect, as in the reference)\n"
+		             "  -b INT   number of variants per block (default: 500)\n  -L INT   compression level 1-20 (default: 1)\n"
+		             "  -t INT   parser threads (default: all; not in the reference)\n\n";
+		return 1;
+	}
+	static struct option long_options[] = {{"input", required_argument, 0, 'i'}, {"output", optional_argument, 0, 'o'},
+		{"filter-univariate", optional_argument, 0, 'r'}, {"flip", optional_argument, 0, 'f'}, {"missingness", optional_argument, 0, 'n'},
+		{"compression-level", optional_argument, 0, 'L'}, {"block-size", optional_argument, 0, 'b'}, {"hwe", optional_argument, 0, 'H'},
+		{"threads", required_argument, 0, 't'}, {0, 0, 0, 0}};
+	tomahawk::twk_vimport_settings st;
+	int c = 0, option_index = 0;
+	while ((c = getopt_long(argc, argv, "i:o:rfn:b:L:H:t:?", long_options, &option_index)) != -1) {
+		switch (c) {
+		case 'i': st.input = optarg; break;
+		case 'o': st.output = optarg; break;
+		case 'n':
+			st.threshold_miss = (float)atof(optarg);
+			if (st.threshold_miss < 0) { std::cerr << stamp("ERROR") << "Cannot set missingness filter to < 0..." << std::endl; return 1; }
+			if (st.threshold_miss > 1) { std::cerr << stamp("ERROR") << "Cannot set missingness filter to > 1..." << std::endl; return 1; }
+			break;
+		case 'H':
+			st.hwe = atof(optarg);
+			if (st.hwe < 0) { std::cerr << stamp("ERROR") << "Cannot set Hardy-Weinberg filter to < 0..." << std::endl; return 1; }
+			if (st.hwe > 1) { std::cerr << stamp("ERROR") << "Cannot set Hardy-Weinberg filter to > 1..." << std::endl; return 1; }
+			break;
+		case 'r': st.remove_univariate = false; break;
+		case 'f': st.flip_major_minor = false; break;          // import.h:92-94
+		case 'b': st.block_size = (uint32_t)atoi(optarg); break;
+		case 'L': st.c_level = (uint8_t)atoi(optarg); break;
+		case 't': st.n_threads = atoi(optarg); break;
+		default: std::cerr << stamp("ERROR") << "Unrecognized option: " << (char)c << std::endl; return 1;
+		}
+	}
+	if (st.input.empty()) { std::cerr << stamp("ERROR") << "No input value specified..." << std::endl; return 1; }
+	if (st.output.empty()) { std::cerr << stamp("ERROR") << "No output value specified..." << std::endl; return 1; }
+	if (st.block_size == 0) { std::cerr << stamp("ERROR") << "Cannot set the block size to 0..." << std::endl; return 1; }
+	program_message();
+	std::cerr << stamp("LOG") << "Calling import..." << std::endl;
+	tomahawk::twk_variant_importer importer;
+	if (!importer.Import(st)) { std::cerr << "failed import" << std::endl; return 1; }
+	return 0;
+}
+
 // `tomahawk sort` (lib/sort.h:28-124)
 static int sort_cmd(int argc, char** argv) {
 	if (argc < 3) {
@@ -419,9 +470,10 @@ int main(int argc, char** argv) {
 	if (strcmp(argv[1], "calc-single") == 0 || strcmp(argv[1], "scalc") == 0) return scalc(argc, argv);
 	if (strcmp(argv[1], "view") == 0) return view(argc, argv);
 	if (strcmp(argv[1], "sort") == 0) return sort_cmd(argc, argv);
+	if (strcmp(argv[1], "import") == 0) return import_cmd(argc, argv);
 	if (strcmp(argv[1], "--version") == 0 || strcmp(argv[1], "version") == 0) { program_message(); return 0; }
 	if (strcmp(argv[1], "--help") == 0 || strcmp(argv[1], "help") == 0) { calc_usage(); return 0; }
 	program_message();
-	std::cerr << stamp("ERROR") << "Illegal command: only `calc`, `scalc`, `concat`, `view` and `sort` are provided by the MI355X engine (import/decay/... are the reference's)" << std::endl;
+	std::cerr << stamp("ERROR") << "Illegal command: only `import`, `calc`, `scalc`, `concat`, `view` and `sort` are provided by the MI355X engine (aggregate/decay/... are the reference's)" << std::endl;
 	return 1;
 }

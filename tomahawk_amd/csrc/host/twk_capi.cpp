@@ -10,6 +10,7 @@
 #include "twk_ld.h"
 #include "twk_hip.h"
 #include "twk_two_tools.h"
+#include "twk_import.h"
 
 using namespace tomahawk;
 
@@ -179,6 +180,30 @@ int twk_two_sort(const char* in, const char* out, double memory_limit_gb, int c_
 	if (n_threads > 0) s.n_threads = n_threads;
 	return two_sort(s) ? 0 : 1;
 }
+
+// twk_variant_importer::Import through a flat argument list (lib/import.h:46-128).
+// counters (may be NULL): [0..8] sites dropped per reason (genotype_encoder.h:25-35), [9] duplicates,
+// [10] sites read, [11] variants written.
+int twk_import_vcf(const char* in, const char* out, double threshold_miss, double hwe, int remove_univariate,
+                   uint32_t block_size, int c_level, int n_threads, uint64_t* counters) {
+	twk_vimport_settings s;
+	s.input = in ? in : "-"; s.output = out ? out : "-";
+	if (threshold_miss >= 0) s.threshold_miss = (float)threshold_miss;
+	if (hwe >= 0) s.hwe = hwe;
+	s.remove_univariate = remove_univariate != 0;
+	if (block_size) s.block_size = block_size;
+	if (c_level > 0) s.c_level = (uint8_t)c_level;
+	s.n_threads = n_threads;
+	twk_variant_importer imp;
+	const bool ok = imp.Import(s);
+	if (counters) {
+		for (int i = 0; i < 9; ++i) counters[i] = imp.filtered[i];
+		counters[9] = imp.n_duplicates; counters[10] = imp.n_sites; counters[11] = imp.n_written;
+	}
+	return ok ? 0 : 1;
+}
+
+double twk_hwe_exact(uint64_t hom1, uint64_t het, uint64_t hom2) { return hardy_weinberg_exact(hom1, het, hom2); }
 
 // Header literals of a .two / .twk (NUL terminated, truncated to cap).
 int twk_file_header_literals(const char* path, int is_two, char* out, size_t cap) {

@@ -244,13 +244,17 @@ bool TwkWriter::open(const std::string& path, const Header& hdr, int c_level) {
 }
 bool TwkWriter::write_block(const Block& blk) {
 	if (blk.rcds.empty()) return true;
+	return write_block(blk, c_level_, blk.rcds.front().pos + 1);
+}
+bool TwkWriter::write_block(const Block& blk, int c_level, uint32_t minpos) {
+	if (blk.rcds.empty()) return true;
 	ByteBuf b; blk.serialize(b);
 	if (b.size() >= (1ull << 32)) return false; // b_unc is u32 (core.cpp:266-271)
 	std::vector<uint8_t> z;
-	if (!zstd_compress(b.v.data(), b.v.size(), z, c_level_)) return false;
+	if (!zstd_compress(b.v.data(), b.v.size(), z, c_level)) return false;
 	IndexEntry e;
 	e.rid = (int32_t)blk.rid; e.n = (uint32_t)blk.rcds.size();
-	e.minpos = blk.rcds.front().pos + 1; e.maxpos = blk.rcds.back().pos + 1; // core.cpp:221-222
+	e.minpos = minpos; e.maxpos = blk.rcds.back().pos + 1; // core.cpp:221-222
 	e.foff = (uint64_t)out_.tellp();
 	const uint8_t marker = 1; const uint32_t unc = (uint32_t)b.size(), cmp = (uint32_t)z.size();
 	out_.write((const char*)&marker, 1); out_.write((const char*)&unc, 4); out_.write((const char*)&cmp, 4);

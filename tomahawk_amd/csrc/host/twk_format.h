@@ -115,7 +115,12 @@ public:
 	bool open(const std::string& path, const Header& hdr, int c_level = 1);
 	// Append a block (one contig per block, importer.cpp:192-260).
 	bool write_block(const Block& blk);
+	// The same with an explicit zstd level and index minpos (the importer's first block records
+	// the 0-based position, importer.cpp:262-264; full blocks are compressed at level 10, :232).
+	bool write_block(const Block& blk, int c_level, uint32_t minpos);
 	bool close();
+	uint64_t n_variants() const { uint64_t n = 0; for (const auto& e : index_.ent) n += e.n; return n; }
+	size_t n_blocks() const { return index_.ent.size(); }
 private:
 	std::ofstream out_;
 	TwkIndex index_;

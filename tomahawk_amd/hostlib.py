@@ -36,6 +36,9 @@ def lib():
         L.twk_file_write_two.argtypes = [C.c_char_p, p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
         L.twk_file_two_index.argtypes = [C.c_char_p, p, C.c_uint64, p, C.c_uint64, p]
         L.twk_two_sort.argtypes = [C.c_char_p, C.c_char_p, C.c_double, C.c_int, C.c_int]
+        L.twk_import_vcf.argtypes = [C.c_char_p, C.c_char_p, C.c_double, C.c_double, C.c_int, C.c_uint32, C.c_int, C.c_int, p]
+        L.twk_hwe_exact.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
+        L.twk_hwe_exact.restype = C.c_double
         L.twk_file_header_literals.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_size_t]
         L.twk_ld_compute.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, p, p]
@@ -122,6 +125,25 @@ def sort_two(path_in, path_out, memory_limit_gb=0.5, c_level=1, n_threads=0):
     rc = lib().twk_two_sort(path_in.encode(), path_out.encode(), memory_limit_gb, c_level, n_threads)
     if rc != 0:
         raise RuntimeError(f"twk_two_sort failed: {rc}")
+
+
+IMPORT_COUNTERS = ("invariant", "missing_threshold", "insufficient_samples", "mixed_ploidy", "no_genotypes", "no_format",
+                   "not_biallelic", "not_snp", "hwe", "duplicates", "sites", "written")
+
+
+def import_vcf(path_in, path_out, threshold_miss=0.9, hwe=0.0, remove_univariate=True, block_size=500, c_level=1,
+               n_threads=0):
+    """`tomahawk import` (twk_variant_importer::Import): VCF text (plain / gzip) -> .twk. Returns the site counters."""
+    cnt = (C.c_uint64 * 12)()
+    rc = lib().twk_import_vcf(path_in.encode(), path_out.encode(), threshold_miss, hwe, int(remove_univariate), block_size,
+                              c_level, n_threads, cnt)
+    if rc != 0:
+        raise RuntimeError(f"twk_import_vcf failed: {rc}")
+    return dict(zip(IMPORT_COUNTERS, (int(x) for x in cnt)))
+
+
+def hwe_exact(hom1, het, hom2):
+    return float(lib().twk_hwe_exact(hom1, het, hom2))
 
 
 def header_literals(path, is_two=True):
