@@ -248,21 +248,30 @@ bool TwkWriter::write_block(const Block& blk) {
 }
 bool TwkWriter::write_block(const Block& blk, int c_level, uint32_t minpos) {
 	if (blk.rcds.empty()) return true;
+	Packed p;
+	return pack(blk, c_level, minpos, p) && write_packed(p);
+}
+bool TwkWriter::pack(const Block& blk, int c_level, uint32_t minpos, Packed& out) {
 	ByteBuf b; blk.serialize(b);
 	if (b.size() >= (1ull << 32)) return false; // b_unc is u32 (core.cpp:266-271)
-	std::vector<uint8_t> z;
-	if (!zstd_compress(b.v.data(), b.v.size(), z, c_level)) return false;
-	IndexEntry e;
+	if (!zstd_compress(b.v.data(), b.v.size(), out.z, c_level)) return false;
+	IndexEntry& e = out.entry;
+	e = IndexEntry();
 	e.rid = (int32_t)blk.rid; e.n = (uint32_t)blk.rcds.size();
 	e.minpos = minpos; e.maxpos = blk.rcds.back().pos + 1; // core.cpp:221-222
+	e.b_unc = (uint32_t)b.size(); e.b_cmp = (uint32_t)out.z.size();
+	return true;
+}
+bool TwkWriter::write_packed(const Packed& p) {
+	IndexEntry e = p.entry;
 	e.foff = (uint64_t)out_.tellp();
-	const uint8_t marker = 1; const uint32_t unc = (uint32_t)b.size(), cmp = (uint32_t)z.size();
+	const uint8_t marker = 1; const uint32_t unc = e.b_unc, cmp = e.b_cmp;
 	out_.write((const char*)&marker, 1); out_.write((const char*)&unc, 4); out_.write((const char*)&cmp, 4);
-	out_.write((const char*)z.data(), z.size());
-	e.fend = (uint64_t)out_.tellp(); e.b_unc = unc; e.b_cmp = cmp;
+	out_.write((const char*)p.z.data(), p.z.size());
+	e.fend = (uint64_t)out_.tellp();
 	index_.ent.push_back(e);
-	if (blk.rid < index_.meta.size()) { // IndexEntryEntry::operator+= (index.cpp:69-86)
-		IndexEntryEntry& m = index_.meta[blk.rid];
+	if (e.rid >= 0 && (size_t)e.rid < index_.meta.size()) { // IndexEntryEntry::operator+= (index.cpp:69-86)
+		IndexEntryEntry& m = index_.meta[e.rid];
 		if (m.n == 0) { m.minpos = e.minpos; m.foff = e.foff; m.rid = e.rid; }
 		m.n += e.n; m.maxpos = e.maxpos; m.fend = e.fend; ++m.nn;
 	}

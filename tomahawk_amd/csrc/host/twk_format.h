@@ -118,6 +118,11 @@ public:
 	// The same with an explicit zstd level and index minpos (the importer's first block records
 	// the 0-based position, importer.cpp:262-264; full blocks are compressed at level 10, :232).
 	bool write_block(const Block& blk, int c_level, uint32_t minpos);
+	// In two steps, so that blocks can be compressed on worker threads: pack() touches no writer
+	// state; write_packed() appends in call order.
+	struct Packed { std::vector<uint8_t> z; IndexEntry entry; };
+	static bool pack(const Block& blk, int c_level, uint32_t minpos, Packed& out);
+	bool write_packed(const Packed& p);
 	bool close();
 	uint64_t n_variants() const { uint64_t n = 0; for (const auto& e : index_.ent) n += e.n; return n; }
 	size_t n_blocks() const { return index_.ent.size(); }

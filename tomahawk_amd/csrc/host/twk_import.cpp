@@ -328,12 +328,36 @@ bool twk_variant_importer::Import(void) {
 	std::memset(filtered, 0, sizeof(filtered));
 	n_sites = n_written = n_duplicates = 0;
 	uint64_t n_malformed = 0;
+	// Finished blocks wait here until the end of the round, are compressed on the parser threads
+	// and written in order (the reference compresses inline on its one thread).
+	struct Pending { Block blk; int level; uint32_t minpos; TwkWriter::Packed packed; };
+	std::vector<Pending> pending;
 	auto flush = [&](int level) -> bool {
-		if (!open_writer()) return false;
-		const bool ok = w.write_block(block, level, block_minpos);
+		pending.emplace_back();
+		pending.back().blk.rid = block.rid; pending.back().blk.rcds.swap(block.rcds);
+		pending.back().level = level; pending.back().minpos = block_minpos;
 		block.rcds.clear();
 		first_block = false;
-		return ok;
+		return true;
+	};
+	auto write_pending = [&]() -> bool {
+		if (pending.empty()) return true;
+		if (!open_writer()) return false;
+		std::atomic<size_t> nxt{0};
+		std::atomic<bool> ok{true};
+		auto work = [&]() {
+			for (;;) { const size_t i = nxt.fetch_add(1); if (i >= pending.size()) return;
+				if (!TwkWriter::pack(pending[i].blk, pending[i].level, pending[i].minpos, pending[i].packed)) ok = false; }
+		};
+		std::vector<std::thread> th;
+		const int nt = (int)std::min<size_t>((size_t)T, pending.size());
+		for (int t = 1; t < nt; ++t) th.emplace_back(work);
+		work();
+		for (auto& x : th) x.join();
+		if (!ok) return false;
+		for (auto& pb : pending) if (!w.write_packed(pb.packed)) return false;
+		pending.clear();
+		return true;
 	};
 
 	read_round(lines);
@@ -378,10 +402,12 @@ bool twk_variant_importer::Import(void) {
 			block.rcds.push_back(std::move(sv.v));
 			++n_written;
 		}
+		if (!write_pending()) { std::cerr << "failed to compress" << std::endl; return false; }
 		lines.swap(next_lines);
 	}
 	if (in.bad()) { std::cerr << stamp("ERROR") << "Failed to parse VCF record: read error" << std::endl; return false; }
 	if (!block.rcds.empty() && !flush(settings.c_level)) return false;
+	if (!write_pending()) { std::cerr << "failed to compress" << std::endl; return false; }
 	if (!open_writer() || !w.close()) { std::cerr << "failed to compress" << std::endl; return false; }
 
 	const uint64_t n_out = w.n_variants();
