@@ -129,8 +129,12 @@ def main():
 
     if not torch.cuda.is_available() or T.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one GPU per rank: LOCAL_RANK indexes the visible devices, unless the launcher already narrowed
+    # visibility to one device per process
+    n_vis = torch.cuda.device_count()
+    dev_index = local_rank if local_rank < n_vis else local_rank % max(n_vis, 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=dev)
@@ -152,7 +156,7 @@ def main():
         assert world == 1, "--emulate-shard is a single-process facility"
         shard_rank, shard_world = (int(x) for x in args.emulate_shard.split("/"))
 
-    eng = T.HipLd(local_rank)
+    eng = T.HipLd(dev_index)
     t0 = time.time()
     slab = None
     if window_bp:
