@@ -245,6 +245,31 @@ def test_degenerate_shapes(hip, N, M):
         util.assert_records_match(got, want, variants)
 
 
+def test_randomised_shapes_counts_bitexact(hip):
+    """Sweep of random shapes (sample counts around the 32/64/128-bit and KC = 32-word boundaries, row
+    counts around the 128-row tile): every contingency cell of every pair equals the oracle's."""
+    rng = np.random.default_rng(2026)
+    specials = [31, 32, 33, 63, 64, 65, 127, 128, 129, 511, 512, 513, 1023, 1024, 1025, 2047, 2049]
+    for it in range(24):
+        N = int(rng.choice(specials)) if it % 2 == 0 else int(rng.integers(1, 700))
+        M = int(rng.choice([2, 3, 64, 127, 128, 129, 130, 255, 257])) if it % 3 == 0 else int(rng.integers(2, 200))
+        miss = it % 4 == 1
+        al = util.random_alleles(M, N, 1000 + it, maf_lo=0.02, maf_hi=0.98,
+                                 miss_rate=0.2 if miss else 0.0, miss_variants=0.5 if miss else 0.0)
+        data, mask, variants = util.upload(hip, al)
+        a0 = int(rng.integers(0, M)); b0 = int(rng.integers(0, M))
+        nA = int(rng.integers(1, M - a0 + 1)); nB = int(rng.integers(1, M - b0 + 1))
+        for mode, counter in ((T.MODE_PHASED, O.count_phased), (T.MODE_UNPHASED, O.count_unphased)):
+            got = hip.count_tile(mode, a0, nA, b0, nB)
+            for i in rng.choice(nA, size=min(nA, 6), replace=False):
+                for j in rng.choice(nB, size=min(nB, 6), replace=False):
+                    A, B = a0 + int(i), b0 + int(j)
+                    mA = mask[A] if mask is not None and variants["gt_missing"][A] else None
+                    mB = mask[B] if mask is not None and variants["gt_missing"][B] else None
+                    want = counter(data[A], mA, data[B], mB, N)
+                    assert np.array_equal(got[i, j], want), (it, N, M, mode, A, B)
+
+
 def test_invalid_arguments_are_rejected(hip):
     hip.set_problem(10, 20)
     hip.generate_synthetic(1)
