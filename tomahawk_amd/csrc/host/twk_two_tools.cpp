@@ -10,6 +10,7 @@
 #include <cstring>
 #include <functional>
 #include <iostream>
+#include <memory>
 #include <mutex>
 #include <queue>
 #include <regex>
@@ -164,29 +165,34 @@ template <class Slot>
 bool ordered_parallel(size_t n, int T, const std::function<bool(size_t, Slot&)>& produce,
                       const std::function<bool(size_t, Slot&)>& consume) {
 	if (n == 0) return true;
-	T = std::max(1, std::min<int>(T, (int)std::min<size_t>(n, 1024)));
+	const int hw = (int)std::max(1u, std::thread::hardware_concurrency());
+	T = std::max(1, std::min<int>(std::min(T, hw), (int)std::min<size_t>(n, 1024)));   // more threads than cores only starves the consumer
 	const size_t window = (size_t)T * 4;
+	const size_t wake_every = std::max<size_t>(1, window / 4);
 	std::vector<Slot> slots(window);
-	std::vector<char> ready(window, 0);
+	std::unique_ptr<std::atomic<int>[]> ready(new std::atomic<int>[window]);
+	for (size_t i = 0; i < window; ++i) ready[i].store(0);
+	std::atomic<size_t> next{0}, consumed{0};
+	std::atomic<bool> failed{false};
+	// Two condition variables, each with at most a handful of sleepers: workers that ran a whole
+	// window ahead of the consumer (rare), and the one consumer.  No broadcast per item.
 	std::mutex mu; std::condition_variable cv_ready, cv_room;
-	size_t next = 0, consumed = 0;
-	bool failed = false;
+	std::atomic<int> room_waiters{0};
 	auto worker = [&]() {
 		for (;;) {
-			size_t i;
-			{
+			const size_t i = next.fetch_add(1);
+			if (i >= n || failed.load()) return;
+			if (i >= consumed.load() + window) {
 				std::unique_lock<std::mutex> lk(mu);
-				cv_room.wait(lk, [&] { return failed || next >= n || next < consumed + window; });
-				if (failed || next >= n) return;
-				i = next++;
+				++room_waiters;
+				cv_room.wait(lk, [&] { return failed.load() || i < consumed.load() + window; });
+				--room_waiters;
+				if (failed.load()) return;
 			}
 			const bool ok = produce(i, slots[i % window]);
-			{
-				std::lock_guard<std::mutex> lk(mu);
-				if (!ok) failed = true;
-				ready[i % window] = 1;
-			}
-			cv_ready.notify_all();
+			if (!ok) failed.store(true);
+			ready[i % window].store(1);      // seq_cst with the load of `consumed` below (store-load pairing with the consumer)
+			if (i == consumed.load() || !ok) { std::lock_guard<std::mutex> lk(mu); cv_ready.notify_one(); }
 			if (!ok) { cv_room.notify_all(); return; }
 		}
 	};
@@ -194,23 +200,27 @@ bool ordered_parallel(size_t n, int T, const std::function<bool(size_t, Slot&)>&
 	for (int t = 0; t < T; ++t) th.emplace_back(worker);
 	bool ok = true;
 	for (size_t i = 0; i < n && ok; ++i) {
-		{
+		if (!ready[i % window].load()) {
 			std::unique_lock<std::mutex> lk(mu);
-			cv_ready.wait(lk, [&] { return failed || ready[i % window]; });
-			if (failed) { ok = false; break; }
+			cv_ready.wait(lk, [&] { return failed.load() || ready[i % window].load() != 0; });
 		}
+		if (failed.load()) { ok = false; break; }
 		if (!consume(i, slots[i % window])) ok = false;
+		ready[i % window].store(0);
 		{
-			std::lock_guard<std::mutex> lk(mu);
-			ready[i % window] = 0; consumed = i + 1;
-			if (!ok) failed = true;
+			std::lock_guard<std::mutex> lk(mu);      // orders `consumed` against a worker about to sleep
+			consumed.store(i + 1);
 		}
-		cv_room.notify_all();
+		// Workers that ran a whole window ahead are woken in batches: the worker holding item j sleeps
+		// only while j >= consumed + window and is woken by consumed = j - window + wake_every at the
+		// latest, long before the consumer needs item j.
+		if (room_waiters.load() > 0 && (i + 1) % wake_every == 0) cv_room.notify_all();
 	}
-	{ std::lock_guard<std::mutex> lk(mu); if (!ok) failed = true; }
+	if (!ok) failed.store(true);
+	{ std::lock_guard<std::mutex> lk(mu); }
 	cv_room.notify_all();
 	for (auto& t : th) t.join();
-	return ok && !failed;
+	return ok && !failed.load();
 }
 
 // twk1_two_t::PrintLD (core.cpp:520-525): default ostream formatting of doubles is %g.
