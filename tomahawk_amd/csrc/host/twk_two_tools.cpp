@@ -336,29 +336,60 @@ inline SortKey key_of(const TwoRecord& r, uint32_t idx) {
 	return SortKey{(uint64_t)r.ridA << 32 | r.ridB, (uint64_t)r.Apos() << 32 | r.Bpos(), idx};
 }
 
-// Sort keys on T threads: sorted chunks, then pairwise merges level by level.
+// Sort keys on T threads: T sorted chunks, then a partitioned T-way merge -- splitters from a sample
+// cut the key space into T ranges, and every thread merges its range of all chunks into place in a
+// second buffer.  Stable: equal keys keep their input order (chunks are in input order, ties in the
+// merge go to the lower chunk, and equal keys never straddle a splitter).
 void parallel_sort(std::vector<SortKey>& k, int T) {
 	const size_t n = k.size();
-	T = std::max(1, std::min<int>(T, (int)(n / 65536 + 1)));
+	T = std::max(1, std::min<int>(T, (int)(n / 8192 + 1)));
+	T = std::min<int>(T, (int)std::max(1u, std::thread::hardware_concurrency()));
 	if (T == 1) { std::stable_sort(k.begin(), k.end()); return; }
 	std::vector<size_t> cut(T + 1);
 	for (int t = 0; t <= T; ++t) cut[t] = n * (size_t)t / T;
-	{
+	auto run = [&](const std::function<void(int)>& f) {
 		std::vector<std::thread> th;
-		for (int t = 0; t < T; ++t) th.emplace_back([&, t] { std::stable_sort(k.begin() + cut[t], k.begin() + cut[t + 1]); });
+		for (int t = 0; t < T; ++t) th.emplace_back(f, t);
 		for (auto& x : th) x.join();
+	};
+	run([&](int t) { std::stable_sort(k.begin() + cut[t], k.begin() + cut[t + 1]); });
+	// splitters: 64 evenly spaced keys per chunk, sorted, T-quantiles
+	std::vector<SortKey> sample;
+	for (int t = 0; t < T; ++t) {
+		const size_t len = cut[t + 1] - cut[t];
+		for (size_t j = 0; j < 64 && len; ++j) sample.push_back(k[cut[t] + len * j / 64]);
 	}
-	while (cut.size() > 2) {
-		std::vector<size_t> nc;
-		std::vector<std::thread> th;
-		for (size_t i = 0; i + 2 < cut.size(); i += 2) {
-			th.emplace_back([&, i] { std::inplace_merge(k.begin() + cut[i], k.begin() + cut[i + 1], k.begin() + cut[i + 2]); });
+	std::sort(sample.begin(), sample.end());
+	std::vector<SortKey> split(T - 1);
+	for (int p = 1; p < T; ++p) split[p - 1] = sample[sample.size() * (size_t)p / T];
+	// bounds[p][t] = first element of chunk t that belongs to partition >= p
+	std::vector<std::vector<size_t>> bounds(T + 1, std::vector<size_t>(T));
+	for (int t = 0; t < T; ++t) { bounds[0][t] = cut[t]; bounds[T][t] = cut[t + 1]; }
+	run([&](int t) {
+		for (int p = 1; p < T; ++p)
+			bounds[p][t] = (size_t)(std::lower_bound(k.begin() + cut[t], k.begin() + cut[t + 1], split[p - 1]) - k.begin());
+	});
+	std::vector<size_t> out_off(T + 1, 0);
+	for (int p = 0; p < T; ++p) { size_t m = 0; for (int t = 0; t < T; ++t) m += bounds[p + 1][t] - bounds[p][t]; out_off[p + 1] = out_off[p] + m; }
+	std::vector<SortKey> out(n);
+	run([&](int p) {
+		struct Head { SortKey key; int chunk; };
+		auto after = [](const Head& a, const Head& b) { return b.key < a.key || (!(a.key < b.key) && b.chunk < a.chunk); };
+		std::vector<Head> heap;
+		std::vector<size_t> pos(T), end(T);
+		for (int t = 0; t < T; ++t) { pos[t] = bounds[p][t]; end[t] = bounds[p + 1][t]; if (pos[t] < end[t]) heap.push_back(Head{k[pos[t]], t}); }
+		std::make_heap(heap.begin(), heap.end(), after);
+		size_t o = out_off[p];
+		while (!heap.empty()) {
+			std::pop_heap(heap.begin(), heap.end(), after);
+			Head h = heap.back();
+			out[o++] = h.key;
+			const int t = h.chunk;
+			if (++pos[t] < end[t]) { heap.back() = Head{k[pos[t]], t}; std::push_heap(heap.begin(), heap.end(), after); }
+			else heap.pop_back();
 		}
-		for (auto& x : th) x.join();
-		for (size_t i = 0; i < cut.size(); i += 2) nc.push_back(cut[i]);
-		if (nc.back() != n) nc.push_back(n);
-		cut.swap(nc);
-	}
+	});
+	k.swap(out);
 }
 
 // Records of index blocks [b0, b1) into `recs` (sized), decoded on T threads.
@@ -463,6 +494,7 @@ bool two_sort(two_sorter_settings& st) {
 	if (runs.size() == 1) {
 		std::vector<TwoRecord> recs;
 		if (!load_range(st.in, idx, 0, idx.ent.size(), recs, T)) { std::cerr << stamp("ERROR") << "Failed to read input blocks..." << std::endl; return false; }
+		std::cerr << stamp("LOG") << "Decoded " << pretty(recs.size()) << " records. " << elapsed_string(std::chrono::duration<double>(clock::now() - t0).count()) << std::endl;
 		std::vector<SortKey> keys(recs.size());
 		{
 			std::vector<std::thread> th;
