@@ -11,6 +11,7 @@
 #include <ctime>
 #include <unistd.h>
 #include <sys/wait.h>
+#include <malloc.h>
 
 #include "twk_ld.h"
 #include "twk_format.h"
@@ -462,6 +463,10 @@ static int scalc(int argc, char** argv) {
 
 int main(int argc, char** argv) {
 	if (argc == 1) { program_message(); std::cerr << "Usage: tomahawk calc [options] -i <in.twk> -o <output.two>" << std::endl; return 1; }
+	// The host tools allocate and free MB-sized block buffers on hundreds of threads; served by
+	// mmap/munmap (glibc's default above 128 KiB) that serialises on the address-space lock.
+	mallopt(M_MMAP_THRESHOLD, 1 << 30);
+	mallopt(M_TRIM_THRESHOLD, 1 << 30);
 	g_argv.assign(argv, argv + argc);
 	tomahawk::LITERAL_COMMAND_LINE = "tomahawk";
 	for (int i = 1; i < argc; ++i) tomahawk::LITERAL_COMMAND_LINE += " " + std::string(argv[i]);

@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <charconv>
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
@@ -166,7 +167,9 @@ bool ordered_parallel(size_t n, int T, const std::function<bool(size_t, Slot&)>&
                       const std::function<bool(size_t, Slot&)>& consume) {
 	if (n == 0) return true;
 	const int hw = (int)std::max(1u, std::thread::hardware_concurrency());
-	T = std::max(1, std::min<int>(std::min(T, hw), (int)std::min<size_t>(n, 1024)));   // more threads than cores only starves the consumer
+	// more threads than cores only starves the consumer; beyond ~64 the single consumer (file
+	// write) or the memory system is the limit and extra workers cost more than they add
+	T = std::max(1, std::min<int>(std::min(std::min(T, hw), 64), (int)std::min<size_t>(n, 1024)));
 	const size_t window = (size_t)T * 4;
 	const size_t wake_every = std::max<size_t>(1, window / 4);
 	std::vector<Slot> slots(window);
@@ -223,14 +226,26 @@ bool ordered_parallel(size_t n, int T, const std::function<bool(size_t, Slot&)>&
 	return ok && !failed.load();
 }
 
-// twk1_two_t::PrintLD (core.cpp:520-525): default ostream formatting of doubles is %g.
+// twk1_two_t::PrintLD (core.cpp:520-525): default ostream formatting of doubles is %g, i.e.
+// std::to_chars(general, precision 6) -- same digits, no locale, no format parsing.
 void append_text(std::string& out, const TwoRecord& r, const Header& hdr) {
-	auto name = [&](uint32_t rid) -> const char* { return rid < hdr.contigs.size() ? hdr.contigs[rid].name.c_str() : "."; };
-	char buf[512];
-	const int n = snprintf(buf, sizeof(buf), "%u\t%s\t%u\t%s\t%u\t%g\t%g\t%g\t%g\t%g\t%g\t%g\t%g\t%g\t%g\t%g\n",
-	                       (unsigned)r.controller, name(r.ridA), r.Apos() + 1, name(r.ridB), r.Bpos() + 1,
-	                       r.cnt[0], r.cnt[1], r.cnt[2], r.cnt[3], r.D, r.Dprime, r.R, r.R2, r.P, r.ChiSqFisher, r.ChiSqModel);
-	if (n > 0) out.append(buf, (size_t)std::min<int>(n, (int)sizeof(buf) - 1));
+	char buf[640];
+	char* p = buf; char* const end = buf + sizeof(buf);
+	auto put_u = [&](uint32_t v) { p = std::to_chars(p, end, v).ptr; *p++ = '\t'; };
+	auto put_d = [&](double v, char sep) { p = std::to_chars(p, end, v, std::chars_format::general, 6).ptr; *p++ = sep; };
+	auto put_name = [&](uint32_t rid) {
+		if (rid < hdr.contigs.size()) {
+			const std::string& n = hdr.contigs[rid].name;
+			if (n.size() > 128) { out.append(buf, (size_t)(p - buf)); out.append(n); p = buf; }
+			else { std::memcpy(p, n.data(), n.size()); p += n.size(); }
+		} else *p++ = '.';
+		*p++ = '\t';
+	};
+	put_u(r.controller); put_name(r.ridA); put_u(r.Apos() + 1); put_name(r.ridB); put_u(r.Bpos() + 1);
+	put_d(r.cnt[0], '\t'); put_d(r.cnt[1], '\t'); put_d(r.cnt[2], '\t'); put_d(r.cnt[3], '\t');
+	put_d(r.D, '\t'); put_d(r.Dprime, '\t'); put_d(r.R, '\t'); put_d(r.R2, '\t'); put_d(r.P, '\t');
+	put_d(r.ChiSqFisher, '\t'); put_d(r.ChiSqModel, '\n');
+	out.append(buf, (size_t)(p - buf));
 }
 }  // namespace
 
@@ -281,12 +296,12 @@ int two_view(two_view_settings& st) {
 	if (use_blocks) blocks = ivals.blocks;
 	else { blocks.resize(rd.index.ent.size()); for (size_t i = 0; i < blocks.size(); ++i) blocks[i] = (uint32_t)i; }
 
-	struct Slot { std::string text; std::vector<TwoRecord> keep; std::ifstream in; };
+	struct Slot { std::string text; std::vector<TwoRecord> keep, recs; std::ifstream in; };
 	const bool want_ivals = !ivals.empty();
 	const Header& hdr = rd.hdr;
 	auto produce = [&](size_t i, Slot& s) -> bool {
 		if (!s.in.is_open()) { s.in.open(st.in, std::ios::binary); if (!s.in.good()) return false; }
-		std::vector<TwoRecord> recs;
+		std::vector<TwoRecord>& recs = s.recs;
 		if (!TwoReader::read_block_at(s.in, rd.index.ent[blocks[i]].foff, recs)) return false;
 		s.text.clear(); s.keep.clear();
 		if (st.mode == 'u') s.text.reserve(recs.size() * 128);
@@ -327,6 +342,20 @@ int two_view(two_view_settings& st) {
 
 // ---- sort (lib/two_reader.cpp:168-416) -------------------------------------------------------------
 namespace {
+// Large scratch arrays without the single-threaded zero fill of std::vector (6.8 GB of records for a
+// 64 M record file): memory is first touched by the threads that fill it.
+template <class T> struct Raw {
+	std::unique_ptr<T[]> p; size_t n = 0;
+	void alloc(size_t m) { p.reset(new T[m]); n = m; }
+	size_t size() const { return n; }
+	T* data() { return p.get(); }
+	T* begin() { return p.get(); }
+	T* end() { return p.get() + n; }
+	T& operator[](size_t i) { return p[i]; }
+	const T& operator[](size_t i) const { return p[i]; }
+	void swap(Raw& o) { p.swap(o.p); std::swap(n, o.n); }
+};
+
 struct SortKey {
 	uint64_t hi, lo;       // (ridA, ridB), (Apos, Bpos): twk1_two_t::operator< (core.cpp:458-468)
 	uint32_t idx;
@@ -340,7 +369,7 @@ inline SortKey key_of(const TwoRecord& r, uint32_t idx) {
 // cut the key space into T ranges, and every thread merges its range of all chunks into place in a
 // second buffer.  Stable: equal keys keep their input order (chunks are in input order, ties in the
 // merge go to the lower chunk, and equal keys never straddle a splitter).
-void parallel_sort(std::vector<SortKey>& k, int T) {
+void parallel_sort(Raw<SortKey>& k, int T) {
 	const size_t n = k.size();
 	T = std::max(1, std::min<int>(T, (int)(n / 8192 + 1)));
 	T = std::min<int>(T, (int)std::max(1u, std::thread::hardware_concurrency()));
@@ -371,7 +400,7 @@ void parallel_sort(std::vector<SortKey>& k, int T) {
 	});
 	std::vector<size_t> out_off(T + 1, 0);
 	for (int p = 0; p < T; ++p) { size_t m = 0; for (int t = 0; t < T; ++t) m += bounds[p + 1][t] - bounds[p][t]; out_off[p + 1] = out_off[p] + m; }
-	std::vector<SortKey> out(n);
+	Raw<SortKey> out; out.alloc(n);
 	run([&](int p) {
 		struct Head { SortKey key; int chunk; };
 		auto after = [](const Head& a, const Head& b) { return b.key < a.key || (!(a.key < b.key) && b.chunk < a.chunk); };
@@ -393,10 +422,10 @@ void parallel_sort(std::vector<SortKey>& k, int T) {
 }
 
 // Records of index blocks [b0, b1) into `recs` (sized), decoded on T threads.
-bool load_range(const std::string& path, const TwoIndex& idx, size_t b0, size_t b1, std::vector<TwoRecord>& recs, int T) {
+bool load_range(const std::string& path, const TwoIndex& idx, size_t b0, size_t b1, Raw<TwoRecord>& recs, int T) {
 	std::vector<uint64_t> off(b1 - b0 + 1, 0);
 	for (size_t b = b0; b < b1; ++b) off[b - b0 + 1] = off[b - b0] + idx.ent[b].n;
-	recs.resize(off.back());
+	recs.alloc(off.back());
 	std::atomic<size_t> next{b0};
 	std::atomic<bool> ok{true};
 	auto worker = [&]() {
@@ -492,10 +521,10 @@ bool two_sort(two_sorter_settings& st) {
 
 	const auto t0 = clock::now();
 	if (runs.size() == 1) {
-		std::vector<TwoRecord> recs;
+		Raw<TwoRecord> recs;
 		if (!load_range(st.in, idx, 0, idx.ent.size(), recs, T)) { std::cerr << stamp("ERROR") << "Failed to read input blocks..." << std::endl; return false; }
 		std::cerr << stamp("LOG") << "Decoded " << pretty(recs.size()) << " records. " << elapsed_string(std::chrono::duration<double>(clock::now() - t0).count()) << std::endl;
-		std::vector<SortKey> keys(recs.size());
+		Raw<SortKey> keys; keys.alloc(recs.size());
 		{
 			std::vector<std::thread> th;
 			for (int t = 0; t < T; ++t) th.emplace_back([&, t] {
@@ -523,9 +552,9 @@ bool two_sort(two_sorter_settings& st) {
 		const std::string tmp_base = (to_stdout ? std::string("/tmp/twk_sort") : st.out) + "_" + std::to_string((unsigned)getpid());
 		std::vector<std::string> tmp_names; std::vector<uint64_t> run_n;
 		for (size_t r = 0; r < runs.size(); ++r) {
-			std::vector<TwoRecord> recs;
+			Raw<TwoRecord> recs;
 			if (!load_range(st.in, idx, runs[r].first, runs[r].second, recs, T)) { std::cerr << stamp("ERROR") << "Failed to read input blocks..." << std::endl; return false; }
-			std::vector<SortKey> keys(recs.size());
+			Raw<SortKey> keys; keys.alloc(recs.size());
 			for (size_t i = 0; i < recs.size(); ++i) keys[i] = key_of(recs[i], (uint32_t)i);
 			parallel_sort(keys, T);
 			const std::string name = tmp_base + "_run" + std::to_string(r) + ".tmp";
