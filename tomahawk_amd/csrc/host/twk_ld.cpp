@@ -27,6 +27,7 @@
 
 #include "twk_format.h"
 #include "twk_hip.h"
+#include "twk_parallel.h"
 #include "twk_util.h"
 
 #ifndef TWK_AMD_VERSION
@@ -93,100 +94,77 @@ public:
 	// per-variant (rid,pos) of the uploaded selection
 	std::vector<uint32_t> rid, pos;
 
-	// output state: one forward and one reverse block (ld_engine.h:321)
-	std::vector<TwoRecord> blk_f, blk_r;
+	// Output state.  The reference keeps one forward and one reverse block per thread
+	// (ld_engine.h:321) and flushes both when the forward block is full or the contig pair of
+	// the next record differs from the block's first (ld_engine.cpp:1270-1281).  Here the
+	// survivors of one tile arrive together: they are put in (row, col) order with a parallel
+	// key sort, cut into blocks by that same rule, and the blocks are expanded to forward +
+	// reverse records and compressed on worker threads while this thread writes them in order.
+	// The last, still open block carries over to the next tile.
 	TwoWriter writer;
 	uint32_t b_size = 10000;
+	int c_level = 1, n_workers = 1;
 	bool write_failed = false;
-	std::vector<twk_hip_record> sort_buf;
+	std::vector<twk_hip_record> carry;            // records of the open block (< b_size), in order
 
-	// Block compression runs on worker threads (the reference compresses on its n_threads LD
-	// threads, ld_engine.cpp:1742-1802); blocks are appended to the file in submission order.
-	struct Job { std::vector<TwoRecord> recs; TwoWriter::Packed packed; bool done = false, ok = true; };
-	std::deque<std::shared_ptr<Job>> pending;     // submission order
-	std::deque<std::shared_ptr<Job>> todo;        // not yet picked by a worker
-	std::vector<std::thread> workers;
-	std::mutex mu;
-	std::condition_variable cv_work, cv_done;
-	bool stopping = false;
-	int c_level = 1;
-
-	void start_workers(int n, int level) {
-		c_level = level; stopping = false;
-		for (int i = 0; i < std::max(1, n); ++i) workers.emplace_back([this] {
-			for (;;) {
-				std::shared_ptr<Job> j;
-				{
-					std::unique_lock<std::mutex> lk(mu);
-					cv_work.wait(lk, [this] { return stopping || !todo.empty(); });
-					if (todo.empty()) return;
-					j = todo.front(); todo.pop_front();
-				}
-				const bool ok = TwoWriter::pack(j->recs.data(), (uint32_t)j->recs.size(), c_level, j->packed);
-				{ std::lock_guard<std::mutex> lk(mu); j->ok = ok; j->done = true; }
-				cv_done.notify_all();
-			}
-		});
-	}
-	// write every finished block at the head of the queue; wait == true drains everything
-	bool drain(bool wait) {
-		std::unique_lock<std::mutex> lk(mu);
-		for (;;) {
-			while (!pending.empty() && pending.front()->done) {
-				auto j = pending.front(); pending.pop_front();
-				lk.unlock();
-				const bool ok = j->ok && writer.write_packed(j->packed);
-				lk.lock();
-				if (!ok) return false;
-			}
-			if (!wait || pending.empty()) return true;
-			cv_done.wait(lk, [this] { return pending.front()->done; });
-		}
-	}
-	void stop_workers() {
-		{ std::lock_guard<std::mutex> lk(mu); stopping = true; }
-		cv_work.notify_all();
-		for (auto& t : workers) t.join();
-		workers.clear();
-	}
-	bool submit(std::vector<TwoRecord>& blk) {
-		if (blk.empty()) return true;
-		auto j = std::make_shared<Job>();
-		j->recs.swap(blk);
-		{
-			std::unique_lock<std::mutex> lk(mu);
-			pending.push_back(j); todo.push_back(j);
-		}
-		cv_work.notify_one();
-		// bound the memory in flight: ~256 blocks of <= b_size records
-		while (true) {
-			{ std::lock_guard<std::mutex> lk(mu); if (pending.size() < 256) break; }
-			if (!drain(false)) return false;
-			std::unique_lock<std::mutex> lk(mu);
-			if (pending.size() >= 256) cv_done.wait(lk, [this] { return pending.front()->done; });
-		}
-		return drain(false);
-	}
-
-	bool flush() { // CompressBlock (ld_engine.cpp:1804-1810): forward, then reverse
-		return submit(blk_f) && submit(blk_r);
-	}
-
-	bool add(const twk_hip_record& r) {
-		TwoRecord f;
+	void expand(const twk_hip_record& r, TwoRecord& f, TwoRecord& v) const {
 		f.controller = (uint16_t)r.flags;
 		f.ridA = rid[r.idxA]; f.ridB = rid[r.idxB];
 		f.packA = pos[r.idxA] << 2; f.packB = pos[r.idxB] << 2;
 		std::memcpy(f.cnt, r.cnt, sizeof(f.cnt));
 		f.D = r.D; f.Dprime = r.Dprime; f.R = r.R; f.R2 = r.R2; f.P = r.P;
 		f.ChiSqFisher = r.ChiSqFisher; f.ChiSqModel = r.ChiSqModel;
-		// flush rule of ld_engine.cpp:1270-1281
-		if (!blk_f.empty() && (blk_f.size() == b_size || blk_f.front().ridA != f.ridA || blk_r.front().ridA != f.ridB))
-			if (!flush()) return false;
-		blk_f.push_back(f);
-		TwoRecord v = f;                 // reverse copy swaps (rid,pos) only; cnt is NOT transposed (:1292-1298)
+		v = f;                           // reverse copy swaps (rid,pos) only; cnt is NOT transposed (:1292-1298)
 		std::swap(v.ridA, v.ridB); std::swap(v.packA, v.packB);
-		blk_r.push_back(v);
+	}
+
+	// Write the survivors `recs[0..n)` (any order) behind the carried block; final: close the open block too.
+	bool emit(const twk_hip_record* recs, uint64_t n, bool final) {
+		// (row, col) order: the file is deterministic (the reference's order is thread-timing dependent)
+		par::Raw<par::SortKey> keys;
+		keys.alloc(n);
+		{
+			const int T = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)n_workers, n / 65536 + 1));
+			std::vector<std::thread> th;
+			for (int t = 0; t < T; ++t) th.emplace_back([&, t] {
+				for (uint64_t i = n * (uint64_t)t / T, e = n * (uint64_t)(t + 1) / T; i < e; ++i)
+					keys[i] = par::SortKey{0, (uint64_t)recs[i].idxA << 32 | recs[i].idxB, (uint32_t)i};
+			});
+			for (auto& x : th) x.join();
+		}
+		par::parallel_sort(keys, n_workers);
+		// the sequence is carry[0..nc) followed by recs[keys[.].idx]
+		const uint64_t nc = carry.size(), total = nc + n;
+		auto at = [&](uint64_t i) -> const twk_hip_record& { return i < nc ? carry[i] : recs[keys[i - nc].idx]; };
+		// cuts by the flush rule: a block ends when it holds b_size records or the next record's
+		// (ridA, ridB) differs from its first record's
+		std::vector<uint64_t> cut{0};
+		if (total) {
+			uint32_t fa = rid[at(0).idxA], fb = rid[at(0).idxB];
+			for (uint64_t i = 1; i < total; ++i) {
+				const twk_hip_record& r = at(i);
+				const uint32_t ra = rid[r.idxA], rb = rid[r.idxB];
+				if (i - cut.back() == b_size || ra != fa || rb != fb) { cut.push_back(i); fa = ra; fb = rb; }
+			}
+		}
+		// the block after the last cut stays open unless this is the end
+		const size_t n_closed = total ? (final ? cut.size() : cut.size() - 1) : 0;
+		if (final && total) cut.push_back(total);
+		struct Slot { std::vector<TwoRecord> f, v; TwoWriter::Packed pf, pv; };
+		const int level = c_level;
+		std::function<bool(size_t, Slot&)> produce = [&](size_t b, Slot& s) -> bool {
+			const uint64_t lo = cut[b], hi = cut[b + 1];
+			s.f.resize(hi - lo); s.v.resize(hi - lo);
+			for (uint64_t i = lo; i < hi; ++i) expand(at(i), s.f[i - lo], s.v[i - lo]);
+			return TwoWriter::pack(s.f.data(), (uint32_t)s.f.size(), level, s.pf) && TwoWriter::pack(s.v.data(), (uint32_t)s.v.size(), level, s.pv);
+		};
+		std::function<bool(size_t, Slot&)> consume = [&](size_t, Slot& s) -> bool {   // CompressBlock (:1804-1810): forward, then reverse
+			return writer.write_packed(s.pf) && writer.write_packed(s.pv);
+		};
+		if (n_closed && !par::ordered_parallel<Slot>(n_closed, n_workers, produce, consume)) return false;
+		std::vector<twk_hip_record> next;
+		if (!final && total) { next.reserve(total - cut.back()); for (uint64_t i = cut.back(); i < total; ++i) next.push_back(at(i)); }
+		carry.swap(next);
 		return true;
 	}
 
@@ -194,14 +172,7 @@ public:
 
 	static int sink(void* user, const twk_hip_record* recs, uint64_t n) {
 		auto* self = static_cast<twk_ld_impl*>(user);
-		// Survivors of a tile arrive in device-compaction order; restore (row, col) order so that
-		// the file is deterministic (the reference's order is thread-timing dependent anyway).
-		self->sort_buf.assign(recs, recs + n);
-		std::sort(self->sort_buf.begin(), self->sort_buf.end(), [](const twk_hip_record& a, const twk_hip_record& b) {
-			return a.idxA != b.idxA ? a.idxA < b.idxA : a.idxB < b.idxB;
-		});
-		for (const auto& r : self->sort_buf)
-			if (!self->add(r)) { self->write_failed = true; return 1; }
+		if (!self->emit(recs, n, false)) { self->write_failed = true; return 1; }
 		self->n_records += 2 * n;
 		return 0;
 	}
@@ -377,9 +348,8 @@ bool twk_ld::twk_ld_impl::run(twk_ld_settings& settings, const Header& hdr, twk_
 	const RunSpec& spec = *static_cast<const RunSpec*>(spec_);
 	if (!open_output(settings, hdr, writer)) return false;
 	b_size = (uint32_t)std::max(2, settings.b_size);
-	blk_f.clear(); blk_r.clear(); write_failed = false; n_records = 0; n_pairs = 0;
-	start_workers(std::min(std::max(1, settings.n_threads), 64), settings.c_level);
-	struct StopGuard { twk_ld_impl* s; ~StopGuard() { s->stop_workers(); } } stop_guard{this};
+	carry.clear(); write_failed = false; n_records = 0; n_pairs = 0;
+	c_level = settings.c_level; n_workers = std::min(std::max(1, settings.n_threads), 64);
 	const int mode = settings.single ? TWK_HIP_MODE_AUTO
 	               : settings.force_phased ? TWK_HIP_MODE_PHASED : (settings.forced_unphased ? TWK_HIP_MODE_UNPHASED : TWK_HIP_MODE_AUTO);
 	twk_hip_filters f{settings.minR2, settings.maxR2, settings.minDprime, settings.maxDprime, settings.minP};
@@ -403,7 +373,7 @@ bool twk_ld::twk_ld_impl::run(twk_ld_settings& settings, const Header& hdr, twk_
 	}
 	if (write_failed) { std::cerr << stamp("ERROR", "WRITER") << "Failed to write output block!" << std::endl; return false; }
 	if (!hip_ok(ctx, rc, "twk_hip_ld_region")) return false;
-	if (!flush() || !drain(true)) { std::cerr << stamp("ERROR", "WRITER") << "Failed to write output block!" << std::endl; return false; }
+	if (!emit(nullptr, 0, true)) { std::cerr << stamp("ERROR", "WRITER") << "Failed to write output block!" << std::endl; return false; }
 	const double sec = std::chrono::duration<double>(clock::now() - t0).count();
 	std::cerr << stamp("PROGRESS") << "Finished in " << elapsed_string(sec) << ". Variants: " << pretty(n_pairs) << ", genotypes: "
 	          << pretty(n_pairs * n_samples) << ", output: " << pretty(n_records) << std::endl;
