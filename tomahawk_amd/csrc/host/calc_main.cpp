@@ -461,7 +461,7 @@ static int scalc(int argc, char** argv) {
 	return ld.ComputeSingle(settings, true, true) ? 0 : 1;
 }
 
-int main(int argc, char** argv) {
+static int run_main(int argc, char** argv) {
 	if (argc == 1) { program_message(); std::cerr << "Usage: tomahawk calc [options] -i <in.twk> -o <output.two>" << std::endl; return 1; }
 	// The host tools allocate and free MB-sized block buffers on hundreds of threads; served by
 	// mmap/munmap (glibc's default above 128 KiB) that serialises on the address-space lock.
@@ -480,5 +480,16 @@ int main(int argc, char** argv) {
 	if (strcmp(argv[1], "--help") == 0 || strcmp(argv[1], "help") == 0) { calc_usage(); return 0; }
 	program_message();
 	std::cerr << stamp("ERROR") << "Illegal command: only `import`, `calc`, `scalc`, `concat`, `view` and `sort` are provided by the MI355X engine (aggregate/decay/... are the reference's)" << std::endl;
+	return 1;
+}
+
+int main(int argc, char** argv) {
+	try {
+		return run_main(argc, argv);
+	} catch (const std::bad_alloc&) {
+		std::cerr << stamp("ERROR") << "Out of memory (or a corrupt file declaring an absurd size)..." << std::endl;
+	} catch (const std::exception& e) {
+		std::cerr << stamp("ERROR") << e.what() << std::endl;
+	}
 	return 1;
 }

@@ -14,6 +14,9 @@
 
 using namespace tomahawk;
 
+// No C++ exception may cross the C boundary (ctypes callers would abort): every entry point is a
+// function-try-block that turns one into -9.
+
 extern "C" {
 
 // Write a .twk from dense genotypes.  alleles: int8 [n_variants][2*n_samples] in {0,1,2};
@@ -21,7 +24,7 @@ extern "C" {
 // n_contigs contigs named "1".."n"; block_size variants per block (one contig per block).
 int twk_file_write_twk(const char* path, uint32_t n_samples, uint32_t n_variants, const int8_t* alleles,
                        const uint32_t* pos, const uint32_t* rid, const uint8_t* phased, const double* hwe,
-                       uint32_t n_contigs, uint32_t block_size, int c_level) {
+                       uint32_t n_contigs, uint32_t block_size, int c_level) try {
 	if (!path || !alleles || !pos || !rid || !phased || n_samples == 0 || block_size == 0) return -1;
 	Header hdr;
 	hdr.literals = "##fileformat=VCFv4.2\n##source=tomahawk_amd synthetic writer";
@@ -41,12 +44,12 @@ int twk_file_write_twk(const char* path, uint32_t n_samples, uint32_t n_variants
 	}
 	if (!blk.rcds.empty() && !w.write_block(blk)) return -3;
 	return w.close() ? 0 : -3;
-}
+} catch (...) { return -9; }
 
 // Write the first n_variants of the synthetic benchmark input as a .twk:
 // the CPU-baseline sample shares its bits with twk_hip_generate_synthetic().
 int twk_file_write_synthetic_twk(const char* path, uint32_t n_samples, uint32_t n_variants, uint64_t seed,
-                                 int phased, uint32_t block_size, int c_level, int n_threads) {
+                                 int phased, uint32_t block_size, int c_level, int n_threads) try {
 	if (!path || n_samples == 0 || n_variants == 0 || block_size == 0) return -1;
 	Header hdr;
 	hdr.literals = "##fileformat=VCFv4.2\n##source=tomahawk_amd synthetic benchmark input seed=" + std::to_string(seed);
@@ -76,12 +79,12 @@ int twk_file_write_synthetic_twk(const char* path, uint32_t n_samples, uint32_t 
 		if (!w.write_block(blk)) return -3;
 	}
 	return w.close() ? 0 : -3;
-}
+} catch (...) { return -9; }
 
 // Read a whole .twk: two-call pattern (first with data == NULL to get the sizes).
 // meta: twk_hip_variant_meta[n_variants]; extra (may be NULL): uint32 [n_variants][4] = n_het, n_hom, gt_phase, n_runs.
 int twk_file_read_twk(const char* path, uint32_t* n_samples, uint32_t* n_variants, uint64_t* data, uint64_t* mask,
-                      twk_hip_variant_meta* meta, uint32_t* extra) {
+                      twk_hip_variant_meta* meta, uint32_t* extra) try {
 	TwkReader rd;
 	if (!path || !rd.open(path)) return -2;
 	uint32_t M = 0;
@@ -103,11 +106,11 @@ int twk_file_read_twk(const char* path, uint32_t* n_samples, uint32_t* n_variant
 		}
 	}
 	return 0;
-}
+} catch (...) { return -9; }
 
 // Read a whole .two: records are the 106-byte packed twk1_two_t.  Two-call pattern.
 // info (may be NULL): [n_samples, n_contigs, n_index_blocks, index_state].
-int twk_file_read_two(const char* path, void* records, uint64_t capacity, uint64_t* n_records, uint64_t* info) {
+int twk_file_read_two(const char* path, void* records, uint64_t capacity, uint64_t* n_records, uint64_t* info) try {
 	TwoReader rd;
 	if (!path || !rd.open(path)) return -2;
 	if (info) { info[0] = rd.hdr.samples.size(); info[1] = rd.hdr.contigs.size(); info[2] = rd.index.ent.size(); info[3] = rd.index.state; }
@@ -126,12 +129,12 @@ int twk_file_read_two(const char* path, void* records, uint64_t capacity, uint64
 	uint64_t idx_n = 0;
 	for (const auto& e : rd.index.ent) idx_n += e.n;
 	return idx_n == n ? 0 : -5;
-}
+} catch (...) { return -9; }
 
 // Write an unsorted .two (the shape calc writes): 106-byte packed records in blocks of
 // `block_records`; n_contigs contigs named "1".."n"; n_samples sample names "S<i>".
 int twk_file_write_two(const char* path, const void* records, uint64_t n_records, uint32_t n_samples,
-                       uint32_t n_contigs, uint32_t block_records, int c_level) {
+                       uint32_t n_contigs, uint32_t block_records, int c_level) try {
 	if (!path || (!records && n_records) || block_records == 0) return -1;
 	Header hdr;
 	hdr.literals = "##fileformat=VCFv4.2\n##source=tomahawk_amd synthetic writer\n";
@@ -143,12 +146,12 @@ int twk_file_write_two(const char* path, const void* records, uint64_t n_records
 	for (uint64_t i = 0; i < n_records; i += block_records)
 		if (!w.write_block(r + i, (uint32_t)std::min<uint64_t>(block_records, n_records - i))) return -3;
 	return w.close() ? 0 : -3;
-}
+} catch (...) { return -9; }
 
 // Index of a .two.  Two-call pattern: entries [n][6] = rid, ridB, n, minpos, maxpos, b_unc (as int64);
 // contigs [m][5] = rid, n, minpos, maxpos, nn.  counts = [state, n, m].
 int twk_file_two_index(const char* path, int64_t* entries, uint64_t cap_entries, int64_t* contigs, uint64_t cap_contigs,
-                       uint64_t* counts) {
+                       uint64_t* counts) try {
 	TwoReader rd;
 	if (!path || !rd.open(path)) return -2;
 	if (counts) { counts[0] = rd.index.state; counts[1] = rd.index.ent.size(); counts[2] = rd.index.meta.size(); }
@@ -169,23 +172,23 @@ int twk_file_two_index(const char* path, int64_t* entries, uint64_t cap_entries,
 		}
 	}
 	return 0;
-}
+} catch (...) { return -9; }
 
 // two_reader::Sort through a flat argument list (lib/sort.h:93-123).
-int twk_two_sort(const char* in, const char* out, double memory_limit_gb, int c_level, int n_threads) {
+int twk_two_sort(const char* in, const char* out, double memory_limit_gb, int c_level, int n_threads) try {
 	two_sorter_settings s;
 	s.in = in ? in : ""; s.out = out ? out : "-";
 	if (memory_limit_gb > 0) s.memory_limit = (float)memory_limit_gb;
 	if (c_level > 0) s.c_level = c_level;
 	if (n_threads > 0) s.n_threads = n_threads;
 	return two_sort(s) ? 0 : 1;
-}
+} catch (...) { return -9; }
 
 // twk_variant_importer::Import through a flat argument list (lib/import.h:46-128).
 // counters (may be NULL): [0..8] sites dropped per reason (genotype_encoder.h:25-35), [9] duplicates,
 // [10] sites read, [11] variants written.
 int twk_import_vcf(const char* in, const char* out, double threshold_miss, double hwe, int remove_univariate,
-                   uint32_t block_size, int c_level, int n_threads, uint64_t* counters) {
+                   uint32_t block_size, int c_level, int n_threads, uint64_t* counters) try {
 	twk_vimport_settings s;
 	s.input = in ? in : "-"; s.output = out ? out : "-";
 	if (threshold_miss >= 0) s.threshold_miss = (float)threshold_miss;
@@ -201,23 +204,23 @@ int twk_import_vcf(const char* in, const char* out, double threshold_miss, doubl
 		counters[9] = imp.n_duplicates; counters[10] = imp.n_sites; counters[11] = imp.n_written;
 	}
 	return ok ? 0 : 1;
-}
+} catch (...) { return -9; }
 
 double twk_hwe_exact(uint64_t hom1, uint64_t het, uint64_t hom2) { return hardy_weinberg_exact(hom1, het, hom2); }
 
 // Header literals of a .two / .twk (NUL terminated, truncated to cap).
-int twk_file_header_literals(const char* path, int is_two, char* out, size_t cap) {
+int twk_file_header_literals(const char* path, int is_two, char* out, size_t cap) try {
 	Header h;
 	if (is_two) { TwoReader r; if (!r.open(path)) return -2; h = r.hdr; }
 	else { TwkReader r; if (!r.open(path)) return -2; h = r.hdr; }
 	if (out && cap) { std::strncpy(out, h.literals.c_str(), cap - 1); out[cap - 1] = 0; }
 	return 0;
-}
+} catch (...) { return -9; }
 
 // twk_ld::Compute through a flat argument list (what calc.h:96-238 builds).
 int twk_ld_compute(const char* in, const char* out, int force_phased, int force_unphased, double minR2, double minP,
                    double minDprime, int window, int l_window, int n_chunks, int c_chunk, int n_threads, int c_level,
-                   int b_size, uint64_t* n_pairs, uint64_t* n_records) {
+                   int b_size, uint64_t* n_pairs, uint64_t* n_records) try {
 	twk_ld_settings s;
 	s.in = in ? in : ""; s.out = out ? out : "-";
 	s.force_phased = force_phased != 0; s.forced_unphased = force_unphased != 0;
@@ -231,6 +234,6 @@ int twk_ld_compute(const char* in, const char* out, int force_phased, int force_
 	if (n_pairs) *n_pairs = ld.n_pairs();
 	if (n_records) *n_records = ld.n_records();
 	return ok ? 0 : 1;
-}
+} catch (...) { return -9; }
 
 }  // extern "C"

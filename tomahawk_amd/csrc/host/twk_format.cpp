@@ -13,6 +13,7 @@ size_t ZSTD_compressBound(size_t srcSize);
 unsigned ZSTD_isError(size_t code);
 const char* ZSTD_getErrorName(size_t code);
 const char* ZSTD_versionString(void);
+unsigned long long ZSTD_getFrameContentSize(const void* src, size_t srcSize);
 }
 
 namespace tomahawk {
@@ -29,6 +30,9 @@ bool zstd_compress(const uint8_t* src, size_t n, std::vector<uint8_t>& dst, int 
 	return true;
 }
 bool zstd_decompress(const uint8_t* src, size_t n, std::vector<uint8_t>& dst, size_t n_unc) {
+	// one-shot frames record their content size: a declared size that disagrees is a corrupt file,
+	// found before anything is allocated for it
+	if (ZSTD_getFrameContentSize(src, n) != (unsigned long long)n_unc) { std::cerr << "[zstd] decompress failed" << std::endl; return false; }
 	dst.resize(n_unc);
 	const size_t r = ZSTD_decompress(dst.data(), n_unc, src, n);
 	if (ZSTD_isError(r) || r != n_unc) { std::cerr << "[zstd] decompress failed" << std::endl; return false; }
@@ -51,14 +55,14 @@ void Header::serialize(ByteBuf& b) const {
 }
 bool Header::deserialize(ByteBuf& b) {
 	uint32_t n = 0;
-	if (!b.get_str(fileformat) || !b.get_str(literals) || !b.get(n)) return false;
+	if (!b.get_str(fileformat) || !b.get_str(literals) || !b.get(n) || n > b.remaining() / 4) return false;
 	samples.resize(n);
 	for (auto& s : samples) if (!b.get_str(s)) return false;
-	if (!b.get(n)) return false;
+	if (!b.get(n) || n > b.remaining() / 24) return false;
 	contigs.resize(n);
 	for (auto& c : contigs) {
 		uint32_t ne = 0;
-		if (!b.get(c.idx) || !b.get_str(c.name) || !b.get_str(c.description) || !b.get(c.n_bases) || !b.get(ne)) return false;
+		if (!b.get(c.idx) || !b.get_str(c.name) || !b.get_str(c.description) || !b.get(c.n_bases) || !b.get(ne) || ne > b.remaining() / 8) return false;
 		c.extra.resize(ne);
 		for (auto& e : c.extra) if (!b.get_str(e.first) || !b.get_str(e.second)) return false;
 	}
@@ -91,6 +95,7 @@ void TwkIndex::serialize(ByteBuf& b) const {
 bool TwkIndex::deserialize(ByteBuf& b) {
 	uint64_t marker = 0, n = 0, m = 0, me = 0;
 	if (!b.get(marker) || marker != TWK_INDEX_START_MARKER || !b.get(n) || !b.get(m) || !b.get(me)) return false;
+	if (n > b.remaining() / 40 || me > b.remaining() / 44) return false;
 	ent.resize(n); meta.resize(me);
 	for (auto& e : ent) if (!get_entry(b, e)) return false;
 	for (auto& e : meta) if (!get_meta(b, e)) return false;
@@ -106,6 +111,7 @@ void TwoIndex::serialize(ByteBuf& b) const {
 bool TwoIndex::deserialize(ByteBuf& b) {
 	uint64_t marker = 0, n = 0, m = 0, me = 0;
 	if (!b.get(marker) || marker != TWK_INDEX_START_MARKER || !b.get(state) || !b.get(n) || !b.get(m) || !b.get(me)) return false;
+	if (n > b.remaining() / 44 || me > b.remaining() / 44) return false;
 	ent.resize(n); meta.resize(me);
 	for (auto& e : ent) if (!get_entry(b, e) || !b.get(e.ridB)) return false;
 	for (auto& e : meta) if (!get_meta(b, e)) return false;
@@ -135,6 +141,7 @@ bool Variant::deserialize(ByteBuf& b) { // core.cpp:75-101
 	const uint32_t n = n_write >> 1;
 	// (n_write & 1) is the container's own miss bit; it equals gt_missing in valid files.
 	gt_missing = n_write & 1;
+	if (n > b.remaining() / gt_ptype) return false;
 	runs.resize(n);
 	for (uint32_t i = 0; i < n; ++i) {
 		if (gt_ptype == 1) { uint8_t x; if (!b.get(x)) return false; runs[i] = x; }
@@ -216,7 +223,7 @@ void Block::serialize(ByteBuf& b) const { // core.cpp:245-251
 }
 bool Block::deserialize(ByteBuf& b) {
 	uint32_t n = 0, m = 0;
-	if (!b.get(n) || !b.get(m) || !b.get(rid)) return false;
+	if (!b.get(n) || !b.get(m) || !b.get(rid) || n > b.remaining() / 38) return false;
 	rcds.resize(n);
 	for (auto& r : rcds) if (!r.deserialize(b)) return false;
 	return true;

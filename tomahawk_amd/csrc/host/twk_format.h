@@ -33,6 +33,7 @@ public:
 	bool get_bytes(void* p, size_t n) { if (rd + n > v.size()) return false; if (n) std::memcpy(p, &v[rd], n); rd += n; return true; }
 	bool get_str(std::string& s) { uint32_t n; if (!get(n) || rd + n > v.size()) return false; s.assign((const char*)&v[rd], n); rd += n; return true; }
 	size_t size() const { return v.size(); }
+	size_t remaining() const { return v.size() - rd; }     // bytes not read yet: bounds every count a file declares
 	void clear() { v.clear(); rd = 0; }
 };
 
