@@ -134,3 +134,28 @@ def test_view_and_sort_live_against_reference(tmp_path):
     for path, args in [(src, []), (src, ["-u", "-r", "0.05"]), (src, ["-a", "10", "-A", "40"]), (ref, ["-I", "1:1000-1500,1:3000-4000"]),
                        (mine, ["-I", "1:1200-1300", "-I", "1:1250-2000", "-H"]), (mine, ["-I", "1", "-l"])]:
         assert strip_dated(view(path, args)) == strip_dated(view(path, args, binary=O.REF_BIN)), args
+
+
+def test_corrupt_files_fail_cleanly(tmp_path):
+    """Byte flips, truncations and absurd sizes: exit code 0 or 1, never a crash or a runaway allocation."""
+    import random
+    src = open(os.path.join(GOLD, "ref_n64_small_p.two"), "rb").read()
+    rnd = random.Random(5)
+    path = str(tmp_path / "fz.two")
+    for it in range(45):
+        b = bytearray(src)
+        if it % 3 == 0:
+            for _ in range(rnd.randint(1, 5)):
+                b[rnd.randrange(len(b))] = rnd.randrange(256)
+        elif it % 3 == 1:
+            b = b[: rnd.randrange(4, len(b))]
+        else:
+            i = rnd.randrange(len(b) - 8)
+            b[i:i + 4] = b"\xff\xff\xff\x7f"
+        open(path, "wb").write(b)
+        p = subprocess.run([H.CLI_PATH, "view", "-i", path, "-H", "-t", "2"], capture_output=True, timeout=60)
+        assert p.returncode in (0, 1), (it, p.returncode, p.stderr[-200:])
+        try:
+            H.read_two(path)
+        except RuntimeError:
+            pass
