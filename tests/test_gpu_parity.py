@@ -270,6 +270,23 @@ def test_randomised_shapes_counts_bitexact(hip):
                     assert np.array_equal(got[i, j], want), (it, N, M, mode, A, B)
 
 
+def test_fisher_p_values_large_tables(hip):
+    """Fisher's P at a sample count where the reference walks ~1e5 tail terms per record and the device
+    starts its walk at a verified e^-50 point instead: same P (1e-6), from P ~ 1 down to the underflow region."""
+    N, M = 60000, 48
+    rng = np.random.default_rng(12)
+    al = util.random_alleles(M, N, 12)
+    for k, noise in enumerate([0.0005, 0.05, 0.3, 0.45, 0.47, 0.48, 0.485, 0.49]):     # partners in LD with variant 0..7
+        flip = rng.random((N, 2)) < noise
+        al[M - 1 - k] = np.where(flip, 1 - al[k], al[k])
+    data, mask, variants = util.upload(hip, al)
+    got, _, _ = hip.ld_all(T.MODE_PHASED, T.Filters(minR2=0.0))
+    want = O.all_pairs(data, mask, variants, N, O.settings(minR2=0.0, phased=True), vector_only=True)
+    util.assert_records_match(got, want, variants)
+    P = np.sort(want["P"])
+    assert P[0] < 1e-250 and (P > 0.5).sum() > 100 and ((P > 1e-200) & (P < 1e-6)).sum() >= 2       # the whole range is exercised
+
+
 def test_invalid_arguments_are_rejected(hip):
     hip.set_problem(10, 20)
     hip.generate_synthetic(1)

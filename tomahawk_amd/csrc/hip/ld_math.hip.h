@@ -76,12 +76,40 @@ __device__ inline double d_fisher_two(int n11, int n12, int n21, int n22) {
 	if (min < 0) min = 0;
 	if (min == max) return 1.;
 	q = d_hypergeo_acc(n11, n1_, n_1, n, &aux);
-	p = d_hypergeo_acc(min, 0, 0, 0, &aux);
-	for (left = 0., i = min + 1; p < 0.99999999 * q && i <= max; ++i)
+	// The reference walks both tails from the ends of the support (min, max) inwards until the
+	// terms reach q: up to min(n1_, n_1) steps per record, almost all of them over terms that are
+	// zero or tens of orders of magnitude below q.  Start each walk closer in instead, at a point
+	// that is *verified* (one log-pmf evaluation) to lie below q by a factor e^-50: the pmf is
+	// monotone out there, so everything skipped sums to < (max - min) * 2e-22 * q, i.e. < 1e-15
+	// of the result (P >= q) -- far inside the 1e-6 bar; the walk itself, its re-synchronisation
+	// every 11th step and its stopping rule are unchanged.
+	int i0 = min, j0 = max;
+	if (q > 0 && max - min > 64) {
+		const double lq = log(q), nn = (double)n;
+		const double mean = (double)n1_ * (double)n_1 / nn;
+		const double sd = sqrt(mean * ((nn - n1_) / nn) * ((nn - n_1) / (nn - 1.0)));
+		const double lden = d_lbinom(n, n_1);
+		double D = fabs((double)n11 - mean) + 12.0 * sd + 16.0;
+		for (int t = 0; t < 3; ++t, D *= 2.0) {
+			const double sf = floor(mean - D);
+			if (sf <= (double)min) break;
+			const int s = (int)sf;
+			if (d_lbinom(n1_, s) + d_lbinom(n - n1_, n_1 - s) - lden <= lq - 50.0) { i0 = s; break; }
+		}
+		D = fabs((double)n11 - mean) + 12.0 * sd + 16.0;
+		for (int t = 0; t < 3; ++t, D *= 2.0) {
+			const double sf = ceil(mean + D);
+			if (sf >= (double)max) break;
+			const int s = (int)sf;
+			if (d_lbinom(n1_, s) + d_lbinom(n - n1_, n_1 - s) - lden <= lq - 50.0) { j0 = s; break; }
+		}
+	}
+	p = d_hypergeo_acc(i0, 0, 0, 0, &aux);
+	for (left = 0., i = i0 + 1; p < 0.99999999 * q && i <= max; ++i)
 		left += p, p = d_hypergeo_acc(i, 0, 0, 0, &aux);
 	if (p < 1.00000001 * q) left += p;
-	p = d_hypergeo_acc(max, 0, 0, 0, &aux);
-	for (right = 0., j = max - 1; p < 0.99999999 * q && j >= 0; --j)
+	p = d_hypergeo_acc(j0, 0, 0, 0, &aux);
+	for (right = 0., j = j0 - 1; p < 0.99999999 * q && j >= 0; --j)
 		right += p, p = d_hypergeo_acc(j, 0, 0, 0, &aux);
 	if (p < 1.00000001 * q) right += p;
 	double two = left + right;
