@@ -38,6 +38,10 @@ CASES = {
     "n64_missing":  (64, 70, 104, dict(miss_rate=0.1, miss_variants=0.35, low_ac=4), 1, 30),
     "n128_missing": (128, 80, 105, dict(miss_rate=0.06, miss_variants=0.3, low_ac=4), 1, 30),
     "n64_scalc":    (64, 300, 106, dict(miss_rate=0.1, miss_variants=0.1), 1, 64),
+    # haplotype mosaics: strong LD, identical and complementary variants, D' = 1 pairs, double roots of the cubic
+    "n64_ld":       (64, 90, 107, dict(mosaic=True), 1, 30),
+    "n500_ld":      (500, 100, 108, dict(mosaic=True, switch=0.01), 1, 40),
+    "n128_ld_miss": (128, 80, 109, dict(mosaic=True, miss_rate=0.05, miss_variants=0.3), 1, 30),
 }
 
 
@@ -60,8 +64,12 @@ def forward_only(rec):
 def main():
     assert O.have_ref(), "build the reference first: make -C oracle ref"
     tmp = tempfile.mkdtemp(prefix="twk_golden_")
+    only = set(sys.argv[1:])            # optional: names of the cases to (re)generate
     for name, (N, M, seed, kw, n_contigs, bsize) in CASES.items():
-        al = util.random_alleles(M, N, seed, **kw)
+        if only and name not in only:
+            continue
+        kw = dict(kw)
+        al = util.mosaic_alleles(M, N, seed, **kw) if kw.pop("mosaic", False) else util.random_alleles(M, N, seed, **kw)
         rid = np.sort(np.arange(M) * n_contigs // M).astype(np.uint32)
         pos = np.zeros(M, dtype=np.uint32)
         for r in range(n_contigs):

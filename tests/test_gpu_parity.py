@@ -287,6 +287,23 @@ def test_fisher_p_values_large_tables(hip):
     assert P[0] < 1e-250 and (P > 0.5).sum() > 100 and ((P > 1e-200) & (P < 1e-6)).sum() >= 2       # the whole range is exercised
 
 
+@pytest.mark.parametrize("N,seed,founders,switch,mut,miss", [(64, 5001, 4, 0.02, 0.002, False), (250, 5004, 7, 0.02, 0.002, False),
+                                                            (128, 5003, 6, 0.005, 0.0, True), (1000, 5006, 3, 0.005, 0.0, False)])
+def test_haplotype_block_data_all_modes(hip, N, seed, founders, switch, mut, miss):
+    """Real LD structure (mosaics of a few founder haplotypes): identical / complementary variants, D' = 1,
+    double roots of the unphased cubic.  Pair sets and records equal the oracle's in every mode."""
+    M = 140
+    al = util.mosaic_alleles(M, N, seed, n_founders=founders, switch=switch, mut=mut,
+                             miss_rate=0.05 if miss else 0.0, miss_variants=0.3 if miss else 0.0)
+    data, mask, variants = util.upload(hip, al)
+    for mode, ph in ((T.MODE_UNPHASED, False), (T.MODE_PHASED, True), (T.MODE_AUTO, None)):
+        st = O.settings(minR2=0.0, phased=bool(ph), unphased=(ph is False))
+        want = O.all_pairs(data, mask, variants, N, st, vector_only=True)
+        got, _, _ = hip.ld_all(mode, T.Filters(minR2=0.0))
+        assert len(want) > 1000
+        util.assert_records_match(got, want, variants, exact_counts=(ph is True and not miss))
+
+
 def test_invalid_arguments_are_rejected(hip):
     hip.set_problem(10, 20)
     hip.generate_synthetic(1)

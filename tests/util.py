@@ -27,6 +27,36 @@ def random_alleles(M, N, seed, maf_lo=0.05, maf_hi=0.5, miss_rate=0.0, miss_vari
     return al
 
 
+def mosaic_alleles(M, N, seed, n_founders=6, switch=0.03, mut=0.004, miss_rate=0.0, miss_variants=0.0):
+    """Genotypes with real LD structure: every haplotype is a mosaic of a few founder haplotypes (switching
+    founder with probability `switch` per variant) plus rare mutations - long runs of perfectly or almost
+    perfectly correlated variants, identical variants, D' = 1 pairs, the cases iid data never produces."""
+    rng = np.random.default_rng(seed)
+    founders = (rng.random((n_founders, M)) < rng.uniform(0.1, 0.6, size=M)[None, :]).astype(np.int8)
+    H = 2 * N
+    src = rng.integers(0, n_founders, size=H)
+    hap = np.empty((H, M), dtype=np.int8)
+    cur = src.copy()
+    for v in range(M):
+        sw = rng.random(H) < switch
+        cur = np.where(sw, rng.integers(0, n_founders, size=H), cur)
+        hap[:, v] = founders[cur, v]
+    hap ^= (rng.random((H, M)) < mut).astype(np.int8)
+    for v in range(M):                       # keep every site polymorphic (the importer drops invariant sites)
+        ac = int(hap[:, v].sum())
+        if ac < 2 or ac > H - 2:
+            hap[rng.choice(H, size=3, replace=False), v] = 1 if ac < 2 else 0
+    al = hap.T.reshape(M, N, 2).copy()
+    if miss_variants > 0:
+        which = rng.random(M) < miss_variants
+        for v in np.nonzero(which)[0]:
+            ms = rng.random(N) < miss_rate
+            if not ms.any():
+                ms[rng.integers(N)] = True
+            al[v, ms, :] = 2
+    return al
+
+
 def to_hip_meta(variants):
     m = np.zeros(len(variants), dtype=META_DTYPE)
     for k in ("ac", "an", "pos", "rid", "hwe"):

@@ -194,6 +194,18 @@ __device__ inline double d_chisq_unphased(const double o[9], double total, doubl
 	return s;
 }
 
+// x^3 correctly rounded (double-double through FMA).  The reference writes pow(x, 3.0); glibc's pow is
+// correctly rounded in all but ~1e-5 of the cases, the device's pow() is only good to an ulp - and the sign
+// of yN^2 - h2 (one or three real roots) is decided at that level when the cubic has a double root, which
+// real haplotype-block data produces all the time (identical or complementary variants).
+__device__ inline double d_cube(double x) {
+	const double hi = x * x;
+	const double lo = fma(x, x, -hi);            // x^2 = hi + lo exactly
+	const double p = hi * x;
+	const double e = fma(hi, x, -p);             // hi * x = p + e exactly
+	return p + (e + lo * x);
+}
+
 // ---- ChooseF11Calculate: ld_engine.cpp:1590-1740 ---------------------------------------------
 __device__ inline bool d_choose_f11(double total, double target, double p, double q, uint32_t pre_flags,
                                     const VariantMeta& vm, uint32_t A, uint32_t B,
@@ -253,18 +265,18 @@ __device__ inline bool d_unphased_math(const uint64_t c[9], const VariantMeta& v
 
 	const double xN  = -b / (3.0 * a);
 	const double d2  = ((b * b) - 3.0 * a * cc) / (9 * (a * a));
-	const double yN  = a * pow(xN, 3.0) + b * (xN * xN) + cc * xN + dee;
+	const double yN  = a * d_cube(xN) + b * (xN * xN) + cc * xN + dee;
 	const double yN2 = yN * yN;
-	const double h2  = 4 * (a * a) * pow(d2, 3.0);
+	const double h2  = 4 * (a * a) * d_cube(d2);
 	const double diff = yN2 - h2;
 	const double lo = minhap - TWK_D_ROUNDING_ERR, hi = maxhap + TWK_D_ROUNDING_ERR;
 	const double o[9] = { (double)a0, (double)a14, (double)a5, (double)a1664, dh, (double)a2169,
 	                      (double)a80, (double)a8184, (double)a85 };
 
 	if (diff < 0) {
-		const double h = pow(h2, 0.5);
+		const double h = sqrt(h2);                  // pow(h2, 0.5): correctly rounded either way
 		const double theta = acos(-yN / h) / 3.0;
-		const double delta = pow(d2, 0.5);
+		const double delta = sqrt(d2);
 		const double alpha = xN + 2.0 * delta * cos(theta);
 		const double beta  = xN + 2.0 * delta * cos(2.0 * M_PI / 3.0 + theta);
 		const double gamma = xN + 2.0 * delta * cos(4.0 * M_PI / 3.0 + theta);
@@ -284,7 +296,7 @@ __device__ inline bool d_unphased_math(const uint64_t c[9], const VariantMeta& v
 		if (possible == 0) return false;
 		return d_choose_f11(total, chosen, P, Q, possible > 1 ? (1u << 5) : 0u, vm, A, B, f, rec);
 	} else if (diff > 0) {
-		const double sq = pow(yN2 - h2, 0.5);
+		const double sq = sqrt(yN2 - h2);
 		const double t1 = 1.0 / (2.0 * a) * (-yN + sq);
 		const double t2 = 1.0 / (2.0 * a) * (-yN - sq);
 		const double number1 = t1 < 0 ? -pow(-t1, 1.0 / 3.0) : pow(t1, 1.0 / 3.0);
