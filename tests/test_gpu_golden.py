@@ -27,17 +27,6 @@ def golden_as_oracle_records(mat):
     return r
 
 
-def normalise_orientation(recs, cnt_field="cnt"):
-    """cnt[1]/cnt[2] orientation depends on which CPU kernel the reference picked for a pair with
-    missing data (run-length vs vector); the statistics do not.  Sort the two."""
-    recs = recs.copy()
-    c = recs[cnt_field]
-    lo, hi = np.minimum(c[:, 1], c[:, 2]), np.maximum(c[:, 1], c[:, 2])
-    c[:, 1], c[:, 2] = lo, hi
-    recs[cnt_field] = c
-    return recs
-
-
 @pytest.mark.parametrize("tag", ["p", "u", "d"])
 @pytest.mark.parametrize("name", CASES)
 def test_hip_equals_reference_records(hip, name, tag):
@@ -51,8 +40,8 @@ def test_hip_equals_reference_records(hip, name, tag):
     M = al.shape[0]
     assert npairs == M * (M - 1) // 2
     want = golden_as_oracle_records(z["rec_" + tag])
-    if (al == 2).any():
-        got, want = normalise_orientation(got), normalise_orientation(want)
+    # includes which off-diagonal count sits in cnt[1] for pairs the reference ran through its run-length
+    # kernel (missing data + low allele counts): the device mirrors that choice
     util.assert_records_match(got, want, variants)
 
 
@@ -92,8 +81,6 @@ def test_cli_calc_end_to_end(tmp_path, name, flag, tag):
     for i, f in enumerate(("D", "Dprime", "R", "R2", "P", "ChiSqFisher", "ChiSqModel")):
         got[f] = fwd[:, 9 + i]
     w = golden_as_oracle_records(want)
-    if (al == 2).any():
-        got, w = normalise_orientation(got), normalise_orientation(w)
     util.assert_records_match(got, w, variants)
     lit = hostlib.header_literals(out + ".two")
     assert "##tomahawk_calcCommand=tomahawk calc -i" in lit and "##tomahawk_calcVersion=" in lit
@@ -128,6 +115,17 @@ def test_cli_interval_slicing(tmp_path, ival, flag, tag):
     util.assert_records_match(_fwd_records(fwd, variants), golden_as_oracle_records(z["rec_" + tag]), variants)
     r = subprocess.run([hostlib.CLI_PATH, "calc", "-i", twk, "-o", out, "-I", "7"], capture_output=True, text=True)
     assert r.returncode == 1 and "Contig does not exist" in r.stderr
+
+
+def normalise_orientation(recs, cnt_field="cnt"):
+    """scalc pairs the target with neighbours on both sides; which of the two is 'A' for the count slots
+    follows the reference's target-first loop, not file order: compare cnt[1]/cnt[2] as a set there."""
+    recs = recs.copy()
+    c = recs[cnt_field]
+    lo, hi = np.minimum(c[:, 1], c[:, 2]), np.maximum(c[:, 1], c[:, 2])
+    c[:, 1], c[:, 2] = lo, hi
+    recs[cnt_field] = c
+    return recs
 
 
 def test_cli_scalc_single_site(tmp_path):

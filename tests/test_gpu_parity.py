@@ -73,7 +73,7 @@ def test_records_match_oracle(hip, mode, phased, N, M, seed):
     al = util.random_alleles(M, N, seed, low_ac=6)
     data, mask, variants = util.upload(hip, al, phase=int(phased))
     st = O.settings(minR2=0.0, phased=phased, unphased=not phased)
-    want = O.all_pairs(data, mask, variants, N, st, vector_only=True)
+    want = O.all_pairs(data, mask, variants, N, st, vector_only=False)
     got, npairs, nrec = hip.ld_all(mode, T.Filters(minR2=0.0))
     assert npairs == M * (M - 1) // 2
     assert nrec == len(got) == len(want)
@@ -103,7 +103,7 @@ def test_records_with_missing(hip, mode):
     al = util.random_alleles(M, N, 31, miss_rate=0.08, miss_variants=0.3, low_ac=4)
     data, mask, variants = util.upload(hip, al)
     st = O.settings(minR2=0.0, phased=(mode == T.MODE_PHASED), unphased=(mode == T.MODE_UNPHASED))
-    want = O.all_pairs(data, mask, variants, N, st, vector_only=True)
+    want = O.all_pairs(data, mask, variants, N, st, vector_only=False)
     got, _, _ = hip.ld_all(mode, T.Filters(minR2=0.0))
     util.assert_records_match(got, want, variants, exact_counts=False)
 
@@ -141,7 +141,7 @@ def test_default_mode_regrouped_equals_per_tile_two_pass(hip, window):
     assert a.tobytes() == c.tobytes()
     # (3) the oracle
     if not window:
-        want = O.all_pairs(data, mask, variants, N, O.settings(minR2=0.0), vector_only=True)
+        want = O.all_pairs(data, mask, variants, N, O.settings(minR2=0.0), vector_only=False)
         util.assert_records_match(whole, want, variants, exact_counts=False)
 
 
@@ -281,7 +281,7 @@ def test_fisher_p_values_large_tables(hip):
         al[M - 1 - k] = np.where(flip, 1 - al[k], al[k])
     data, mask, variants = util.upload(hip, al)
     got, _, _ = hip.ld_all(T.MODE_PHASED, T.Filters(minR2=0.0))
-    want = O.all_pairs(data, mask, variants, N, O.settings(minR2=0.0, phased=True), vector_only=True)
+    want = O.all_pairs(data, mask, variants, N, O.settings(minR2=0.0, phased=True), vector_only=False)
     util.assert_records_match(got, want, variants)
     P = np.sort(want["P"])
     assert P[0] < 1e-250 and (P > 0.5).sum() > 100 and ((P > 1e-200) & (P < 1e-6)).sum() >= 2       # the whole range is exercised
@@ -298,7 +298,7 @@ def test_haplotype_block_data_all_modes(hip, N, seed, founders, switch, mut, mis
     data, mask, variants = util.upload(hip, al)
     for mode, ph in ((T.MODE_UNPHASED, False), (T.MODE_PHASED, True), (T.MODE_AUTO, None)):
         st = O.settings(minR2=0.0, phased=bool(ph), unphased=(ph is False))
-        want = O.all_pairs(data, mask, variants, N, st, vector_only=True)
+        want = O.all_pairs(data, mask, variants, N, st, vector_only=False)
         got, _, _ = hip.ld_all(mode, T.Filters(minR2=0.0))
         assert len(want) > 1000
         util.assert_records_match(got, want, variants, exact_counts=(ph is True and not miss))

@@ -110,9 +110,8 @@ def assert_records_match(gpu_recs, orc_recs, variants, n_samples=None, rtol=1e-6
         total = float(np.sum(w["cnt"]))
         if phased_math:
             floors = dict(D=0.0, Dprime=0.0, R=0.0, R2=0.0, ChiSqFisher=0.0, ChiSqModel=0.0)
-            if exact_counts or True:
-                if not np.array_equal(g["cnt"], w["cnt"]):
-                    bad.append((k, "cnt", g["cnt"].tolist(), w["cnt"].tolist()))
+            if not np.array_equal(g["cnt"], w["cnt"]):          # integer counts, slot for slot (`exact_counts` is historical)
+                bad.append((k, "cnt", g["cnt"].tolist(), w["cnt"].tolist()))
         else:
             floors = dict(D=1e-8, Dprime=1e-6, R=1e-6, R2=1e-8, ChiSqFisher=1e-8 * total, ChiSqModel=0.0)
             if not np.allclose(g["cnt"], w["cnt"], rtol=rtol, atol=1e-8 * total):

@@ -443,6 +443,15 @@ void k_ld_stats(const StatsParams p) {
 				uint64_t c[4];
 				d_cells_phased(p.tv, i, j, c);
 				if (flip) { const uint64_t x = c[1]; c[1] = c[2]; c[2] = x; }
+				// Which of the two off-diagonal counts is stored in cnt[1] depends on the CPU kernel the
+				// reference picks for the pair: its run-length kernel - taken when either
+				// variant has missing genotypes and ac_A + ac_B is below a sample-count dependent
+				// threshold (ld_engine.cpp:1910, :1925-1926) - has (A ref, B alt) there, the vector
+				// kernels (A alt, B ref).  The statistics are symmetric in the two; mirror the slot.
+				if ((p.vm.missing[A] || p.vm.missing[B]) &&
+				    p.vm.ac[A] + p.vm.ac[B] < (uint32_t)(0.0047 * p.tv.n_samples + 5.2913)) {
+					const uint64_t x = c[1]; c[1] = c[2]; c[2] = x;
+				}
 				keep = d_phased_math(c[0], c[1], c[2], c[3], p.vm, A, B, p.filt, &rec);
 			} else {
 				uint64_t c[9];
