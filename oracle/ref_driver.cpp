@@ -16,7 +16,7 @@
 //   twkinfo file.twk      -> header + per-variant metadata as read by the
 //                            reference reader (format parity of our writer)
 //   fisher n11 n12 n21 n22 -> kt_fisher_exact left right two (%.17g)
-//   view ... / sort ...   -> the reference's own CLI entry points view() / sort()
+//   view ... / sort ... / concat ... -> the reference's own CLI entry points view() / sort() / concat()
 //                            (lib/view.h:62, lib/sort.h:43; header-only, included from
 //                            where they lie) with their own option parsing
 //   twoinfo file.two      -> index of a .two: state, block entries, per-contig entries
@@ -34,6 +34,7 @@
 #include "fisher_math.h"
 #include "view.h"      // int view(int, char**)  -- reference CLI function, lib/view.h:62
 #include "sort.h"      // int sort(int, char**)  -- reference CLI function, lib/sort.h:43
+#include "concat.h"    // int concat(int, char**) -- reference CLI function, lib/concat.h:63
 
 // The executable owns these globals in the reference too (lib/main.cpp:4-5,
 // include/tomahawk.h:30-35); the library reads LITERAL_COMMAND_LINE at
@@ -167,6 +168,7 @@ int main(int argc, char** argv) {
 	if (cmd == "hwe" && argc == 5) return do_hwe((uint32_t)atoi(argv[2]), (uint32_t)atoi(argv[3]), (uint32_t)atoi(argv[4]));
 	if (cmd == "view") { optind = 1; return view(argc - 1, argv + 1); }
 	if (cmd == "sort") { optind = 1; return sort(argc - 1, argv + 1); }
+	if (cmd == "concat") { optind = 1; return concat(argc - 1, argv + 1); }
 	if (cmd == "fisher" && argc == 6) {
 		double l, r, t;
 		kt_fisher_exact(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), &l, &r, &t);

@@ -159,3 +159,24 @@ def test_corrupt_files_fail_cleanly(tmp_path):
             H.read_two(path)
         except RuntimeError:
             pass
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="compiled reference (oracle/_ref) not available")
+def test_concat_live_against_reference(tmp_path):
+    """`concat`: same record stream and index entries as the reference's concat()."""
+    parts = []
+    for k, n in enumerate((1000, 700, 10)):
+        g = np.random.default_rng(k)
+        r = np.zeros(n, dtype=H.TWO_DTYPE)
+        r["controller"] = g.integers(1, 100, n); r["ridA"] = g.integers(0, 2, n); r["ridB"] = r["ridA"]
+        r["packA"] = g.integers(0, 1000, n).astype(np.uint32) << 2; r["packB"] = g.integers(0, 1000, n).astype(np.uint32) << 2
+        r["R2"] = g.random(n)
+        parts.append(str(tmp_path / f"p{k}.two"))
+        H.write_two(parts[-1], r, n_samples=5, n_contigs=2, block_records=300)
+    args = [x for p in parts for x in ("-i", p)]
+    mine, ref = str(tmp_path / "mine.two"), str(tmp_path / "ref.two")
+    subprocess.run([H.CLI_PATH, "concat"] + args + ["-o", mine], check=True, capture_output=True)
+    subprocess.run([O.REF_BIN, "concat"] + args + ["-o", ref], check=True, capture_output=True)
+    assert H.read_two(mine)[0].tobytes() == H.read_two(ref)[0].tobytes()
+    a, b = H.two_index(mine), H.two_index(ref)
+    assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
