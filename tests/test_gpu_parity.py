@@ -304,6 +304,22 @@ def test_haplotype_block_data_all_modes(hip, N, seed, founders, switch, mut, mis
         util.assert_records_match(got, want, variants, exact_counts=(ph is True and not miss))
 
 
+@pytest.mark.parametrize("N,seed,miss", [(64, 901, True), (7, 903, False), (320, 904, False), (33, 915, True), (2504, 908, False)])
+def test_hostile_genotypes_all_modes(hip, N, seed, miss):
+    """Allele frequencies at the extremes, all-het / complementary / identical variants, 30-95 % missing
+    samples (the compiled reference and the oracle agree bit for bit on such data, 146 k records checked).
+    N = 33 / seed 915 contains the one table found where glibc's pow(d2, 3) is not correctly rounded and the
+    double-root pair goes the other way: allowed through double_root_vetter, nothing else is."""
+    al = util.extreme_alleles(70, N, seed, miss)
+    data, mask, variants = util.upload(hip, al)
+    vet = util.double_root_vetter(data, mask, variants, N)
+    for mode, ph in ((T.MODE_UNPHASED, False), (T.MODE_PHASED, True), (T.MODE_AUTO, None)):
+        st = O.settings(minR2=0.0, phased=bool(ph), unphased=(ph is False))
+        want = O.all_pairs(data, mask, variants, N, st, vector_only=False)
+        got, _, _ = hip.ld_all(mode, T.Filters(minR2=0.0))
+        util.assert_records_match(got, want, variants, double_root=vet)
+
+
 def test_invalid_arguments_are_rejected(hip):
     hip.set_problem(10, 20)
     hip.generate_synthetic(1)

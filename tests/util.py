@@ -57,6 +57,28 @@ def mosaic_alleles(M, N, seed, n_founders=6, switch=0.03, mut=0.004, miss_rate=0
     return al
 
 
+def extreme_alleles(M, N, seed, miss=False):
+    """Hostile genotypes: allele frequencies at the extremes (0.05 % .. 2 % and 98 % .. 99.95 %), an all-het
+    variant, complementary and identical variants, and (miss) variants with 30 % / 70 % / 95 % missing samples.
+    Every site stays polymorphic with >= 4 called alleles (the reference asserts on monomorphic sites)."""
+    rng = np.random.default_rng(seed)
+    p = np.concatenate([rng.uniform(0.0005, 0.02, M // 3), rng.uniform(0.98, 0.9995, M // 3), rng.uniform(0.3, 0.7, M - 2 * (M // 3))])
+    rng.shuffle(p)
+    al = (rng.random((M, N, 2)) < p[:, None, None]).astype(np.int8)
+    al[1, :, 0] = 0; al[1, :, 1] = 1
+    al[2] = 1 - al[3]
+    al[4] = al[5]
+    if miss:
+        for v in range(0, M, 3):
+            ms = rng.random(N) < rng.choice([0.3, 0.7, 0.95])
+            al[v, ms, :] = 2
+    for v in range(M):
+        nz = al[v][al[v] != 2]
+        if (nz == 1).sum() == 0 or (nz == 0).sum() == 0 or len(nz) < 4:
+            al[v, :2, :] = [[0, 1], [1, 0]]
+    return al
+
+
 def to_hip_meta(variants):
     m = np.zeros(len(variants), dtype=META_DTYPE)
     for k in ("ac", "an", "pos", "rid", "hwe"):
@@ -79,7 +101,36 @@ def records_by_pair(recs, key_a, key_b):
     return {(int(r[key_a]), int(r[key_b])): r for r in recs}
 
 
-def assert_records_match(gpu_recs, orc_recs, variants, n_samples=None, rtol=1e-6, p_floor=1e-290, exact_counts=True):
+def double_root_vetter(data, mask, variants, n_samples):
+    """-> f(A, B): True when the unphased cubic of pair (A, B) sits on a double root, i.e. yN^2 and h2 agree to
+    a few ulps.  There the reference's branch (three real roots / one) is decided by the last bit of its
+    libm's pow(d2, 3.0) - glibc's is not always correctly rounded - and whether the pair is reported at all
+    depends on it (ld_engine.cpp:1429-1558).  Such pairs may legitimately differ; nothing else may."""
+    def vet(A, B):
+        mA = mask[A] if mask is not None and variants["gt_missing"][A] else None
+        mB = mask[B] if mask is not None and variants["gt_missing"][B] else None
+        c = [float(x) for x in O.count_unphased(data[A], mA, data[B], mB, n_samples)]
+        a0, a14, a5, a1664, hets, a2169, a80, a8184, a85 = c
+        total = sum(c)
+        if total == 0 or hets == 0:
+            return False
+        P = ((a0 + a14 + a5) * 2.0 + (a1664 + hets + a2169)) / (2.0 * total)
+        Q = ((a0 + a1664 + a80) * 2.0 + (a14 + hets + a8184)) / (2.0 * total)
+        n11 = 2 * a0 + a14 + a1664
+        dee = -n11 * P * Q
+        cc = -n11 * (1 - 2 * P - 2 * Q) - hets * (1 - P - Q) + 2 * total * P * Q
+        b = 2 * total * (1 - 2 * P - 2 * Q) - 2 * n11 - hets
+        a = 4 * total
+        xN = -b / (3 * a)
+        d2 = (b * b - 3 * a * cc) / (9 * a * a)
+        yN = a * xN ** 3 + b * xN * xN + cc * xN + dee
+        yN2, h2 = yN * yN, 4 * a * a * d2 ** 3
+        return abs(yN2 - h2) <= 16 * np.spacing(max(yN2, h2))
+    return vet
+
+
+def assert_records_match(gpu_recs, orc_recs, variants, n_samples=None, rtol=1e-6, p_floor=1e-290, exact_counts=True,
+                         double_root=None):
     """gpu_recs: tomahawk_amd.RECORD_DTYPE (variant indices); orc_recs: oracle RECORD_DTYPE (rid/pos).
 
     Bar (BASELINE.json north_star): counts bit-exact, statistics within 1e-6 relative.
@@ -99,6 +150,13 @@ def assert_records_match(gpu_recs, orc_recs, variants, n_samples=None, rtol=1e-6
     assert len(got) == len(gpu_recs), "duplicate pairs in GPU output"
     missing = set(want) - set(got)
     extra = set(got) - set(want)
+    if double_root is not None and (missing or extra):
+        # pairs on a double root of the cubic may be reported by one side only (see double_root_vetter)
+        vetted = {k for k in missing | extra if double_root(*k)}
+        assert len(vetted) <= max(1, len(want) // 2000), f"too many double-root differences: {sorted(vetted)[:8]}"
+        missing -= vetted; extra -= vetted
+        for k in vetted:
+            want.pop(k, None); got.pop(k, None)
     assert not missing and not extra, f"pair sets differ: missing {sorted(missing)[:5]} extra {sorted(extra)[:5]}"
     ties, bad = [], []
     for k, w in want.items():

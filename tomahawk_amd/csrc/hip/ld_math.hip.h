@@ -273,6 +273,14 @@ __device__ inline bool d_unphased_math(const uint64_t c[9], const VariantMeta& v
 	const double o[9] = { (double)a0, (double)a14, (double)a5, (double)a1664, dh, (double)a2169,
 	                      (double)a80, (double)a8184, (double)a85 };
 
+	// Double roots (small tables in perfect LD) make yN^2 and h2 agree to the last bit, and the sign of
+	// `diff` - three real roots or one, and the one-root formula cannot see a double root - is then
+	// decided by the rounding of pow(d2, 3.0).  glibc's pow is within 0.52 ulp, i.e. correctly rounded
+	// except when the exact cube lies within ~0.02 ulp of a rounding midpoint; d_cube is correctly
+	// rounded always, so the two agree on all but a few per cent of these knife-edge pairs (measured:
+	// one table in 2e5 hostile records).  Treating the knife edge as "three roots" instead was tried and
+	// is worse: the reference drops most such pairs (diff >= 0 by a hair, simple root inadmissible), and
+	// following its sign reproduces that.
 	if (diff < 0) {
 		const double h = sqrt(h2);                  // pow(h2, 0.5): correctly rounded either way
 		const double theta = acos(-yN / h) / 3.0;
