@@ -204,6 +204,13 @@ typedef struct {
 	uint64_t variant_pairs; /* variant pairs evaluated by the math kernel        */
 	uint64_t words_per_row; /* 32-bit words contracted per row pair (unpadded)   */
 } twk_hip_timing;
+/* Progress of twk_hip_ld_all / twk_hip_ld_region: `cb` runs on the calling thread after every tile
+ * with the variant pairs finished so far in the current call and the tile counts.  Replaces the
+ * counters the reference's ticker thread polls every 30 s (lib/ld/ld_progress.h:40-86: n_var, n_out).
+ * cb == NULL switches it off. */
+typedef void (*twk_hip_progress_cb)(void* user, uint64_t pairs_done, uint32_t tiles_done, uint32_t tiles_total);
+int twk_hip_set_progress(twk_hip_ctx* ctx, twk_hip_progress_cb cb, void* user);
+
 int twk_hip_timing_reset(twk_hip_ctx* ctx);
 int twk_hip_timing_get(twk_hip_ctx* ctx, twk_hip_timing* out);
 

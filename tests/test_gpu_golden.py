@@ -188,7 +188,9 @@ def test_cli_multi_process_shards_equal_single(tmp_path):
         r = subprocess.run([hostlib.CLI_PATH, "calc", "-i", twk, "-o", out, "-r", "0.02", "-u"], capture_output=True, text=True, env=env)
         assert r.returncode == 0, r.stderr
         return hostlib.two_as_matrix(hostlib.read_two(out)[0]), r.stderr
-    whole, _ = run({}, str(tmp_path / "w.two"))
+    whole, log0 = run({"TWK_HIP_PROGRESS_SECONDS": "0"}, str(tmp_path / "w.two"))
+    prog = [l for l in log0.splitlines() if "[PROGRESS]" in l]
+    assert "Time elapsed" in prog[0] and "Est. Time left" in prog[0] and "%" in prog[1]          # ticker lines (ld_progress.h:48-75)
     # three workers; every worker is pinned to device 0 because the box has one GPU
     multi, log = run({"TWK_HIP_GPUS": "3", "TWK_HIP_FORCE_DEVICE": "0"}, str(tmp_path / "m.two"))
     key = lambda m: m[np.lexsort((m[:, 4], m[:, 2]))]

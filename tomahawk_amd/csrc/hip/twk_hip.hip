@@ -80,6 +80,8 @@ struct twk_hip_ctx {
 	Slot slot[3];                  // [0],[1]: ld_all pipeline; [2]: synchronous single-tile calls
 	twk_hip_record* h_recs = nullptr; unsigned long long h_recs_cap = 0;   // pinned staging
 	twk_hip_timing timing{};
+	twk_hip_progress_cb progress_cb = nullptr; void* progress_user = nullptr;
+	bool progress_muted = false;       // second stage of a default-mode run: its pairs were already counted
 	uint32_t resident_blocks = 512;   // count-kernel blocks the chip holds at once (2 per CU)
 	char err[512] = {0};
 };
@@ -846,6 +848,7 @@ static int region_impl(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint3
 		}
 		tot_pairs += pairs_in_tile(c, mine[done]);
 		++done;
+		if (c->progress_cb && !c->progress_muted) c->progress_cb(c->progress_user, tot_pairs, (uint32_t)done, (uint32_t)n);
 	}
 	if (windowed) tot_pairs = cum[r1] - cum[r0];       // pairs inside the window: the ones the math evaluates
 	if (n_pairs) *n_pairs = tot_pairs;
@@ -875,6 +878,8 @@ int twk_hip_ld_region(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint32
 	uint64_t pairs = 0, recs = 0, p2 = 0, r2 = 0;
 	rc = region_impl(c, MODE_INT_AUTO_CLEAN, f, 0, c->M, 0, c->M, 1, part, n_parts, tile_variants, window, l_window,
 	                 sink, user, &pairs, &recs);
+	struct Mute { twk_hip_ctx* c; ~Mute() { c->progress_muted = false; } } mute{c};
+	c->progress_muted = true;
 	if (rc == TWK_HIP_OK && nG >= 2) {
 		rc = region_impl(c, MODE_INT_GROUPED, f, 0, nG, 0, nG, 1, part, n_parts, tile_variants, window, l_window,
 		                 sink, user, &p2, &r2);
@@ -898,6 +903,12 @@ int twk_hip_shard_rows(uint32_t n_rows, uint32_t n_cols, int32_t triangle, uint3
 	if (row_begin) *row_begin = r0;
 	if (row_end) *row_end = r1;
 	if (n_pairs) *n_pairs = band_pairs_before(r1, n_rows, n_cols, triangle != 0) - band_pairs_before(r0, n_rows, n_cols, triangle != 0);
+	return TWK_HIP_OK;
+}
+
+int twk_hip_set_progress(twk_hip_ctx* c, twk_hip_progress_cb cb, void* user) {
+	if (!c) return TWK_HIP_E_INVALID;
+	c->progress_cb = cb; c->progress_user = user;
 	return TWK_HIP_OK;
 }
 

@@ -363,9 +363,39 @@ bool twk_ld::twk_ld_impl::run(twk_ld_settings& settings, const Header& hdr, twk_
 	const auto t0 = clock::now();
 	uint64_t np = 0, nr = 0;
 	int rc = TWK_HIP_OK;
+	// Progress lines like the reference's ticker (ld_progress.h:40-86), every 30 s, driven by the
+	// engine's per-tile callback instead of a polling thread.
+	struct Progress {
+		twk_ld_impl* self; clock::time_point t0, last; uint64_t base = 0, total = 0; uint32_t n_s = 0; bool header = false;
+		double every = 30.0;
+		static void cb(void* u, uint64_t pairs_done, uint32_t, uint32_t) {
+			Progress& p = *static_cast<Progress*>(u);
+			const auto now = clock::now();
+			if (std::chrono::duration<double>(now - p.last).count() < p.every) return;
+			p.last = now;
+			if (!p.header) {
+				std::cerr << stamp("PROGRESS") << std::setw(12) << "Time elapsed" << std::setw(15) << "Variants" << std::setw(20) << "Genotypes"
+				          << std::setw(15) << "Output" << std::setw(10) << "Progress" << "\tEst. Time left" << std::endl;
+				p.header = true;
+			}
+			const double sec = std::chrono::duration<double>(now - p.t0).count();
+			const uint64_t done = p.base + pairs_done;
+			const double frac = p.total ? (double)done / (double)p.total : 0.0;
+			std::cerr << stamp("PROGRESS") << std::setw(12) << elapsed_string(sec) << std::setw(15) << pretty(done)
+			          << std::setw(20) << pretty(done * p.n_s) << std::setw(15) << pretty(p.self->n_records)
+			          << std::setw(10) << frac * 100 << "%\t" << (frac > 0 ? elapsed_string(sec * (1 - frac) / frac) : std::string("-")) << std::endl;
+		}
+	} progress;
+	progress.self = this; progress.t0 = progress.last = t0; progress.n_s = n_samples;
+	if (const char* e = std::getenv("TWK_HIP_PROGRESS_SECONDS")) progress.every = std::atof(e);      // test hook
+	progress.total = (spec.triangleA && spec.nA > 1 ? (uint64_t)spec.nA * (spec.nA - 1) / 2 : 0) + (spec.rectAB ? (uint64_t)spec.nA * spec.nB : 0);
+	if (n_parts > 1) progress.total /= n_parts;
+	twk_hip_set_progress(ctx, &Progress::cb, &progress);
+	struct ProgressOff { twk_hip_ctx* c; ~ProgressOff() { twk_hip_set_progress(c, nullptr, nullptr); } } progress_off{ctx};
 	if (spec.triangleA && spec.nA > 1) {
 		rc = twk_hip_ld_region(ctx, mode, &f, 0, spec.nA, 0, spec.nA, 1, part, n_parts, 0, spec.options, spec.l_window, sink, this, &np, &nr);
 		n_pairs += np;
+		progress.base = n_pairs;
 	}
 	if (rc == TWK_HIP_OK && spec.rectAB && spec.nA && spec.nB) {
 		rc = twk_hip_ld_region(ctx, mode, &f, 0, spec.nA, spec.nA, spec.nB, 0, part, n_parts, 0, spec.options, spec.l_window, sink, this, &np, &nr);
