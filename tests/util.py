@@ -129,7 +129,7 @@ def double_root_vetter(data, mask, variants, n_samples):
     return vet
 
 
-def assert_records_match(gpu_recs, orc_recs, variants, n_samples=None, rtol=1e-6, p_floor=1e-290, exact_counts=True,
+def assert_records_match(gpu_recs, orc_recs, variants, n_samples=None, rtol=1e-6, p_floor=1e-290,
                          double_root=None):
     """gpu_recs: tomahawk_amd.RECORD_DTYPE (variant indices); orc_recs: oracle RECORD_DTYPE (rid/pos).
 
@@ -168,7 +168,7 @@ def assert_records_match(gpu_recs, orc_recs, variants, n_samples=None, rtol=1e-6
         total = float(np.sum(w["cnt"]))
         if phased_math:
             floors = dict(D=0.0, Dprime=0.0, R=0.0, R2=0.0, ChiSqFisher=0.0, ChiSqModel=0.0)
-            if not np.array_equal(g["cnt"], w["cnt"]):          # integer counts, slot for slot (`exact_counts` is historical)
+            if not np.array_equal(g["cnt"], w["cnt"]):          # integer counts, slot for slot
                 bad.append((k, "cnt", g["cnt"].tolist(), w["cnt"].tolist()))
         else:
             floors = dict(D=1e-8, Dprime=1e-6, R=1e-6, R2=1e-8, ChiSqFisher=1e-8 * total, ChiSqModel=0.0)
