@@ -462,7 +462,18 @@ static int scalc(int argc, char** argv) {
 }
 
 static int run_main(int argc, char** argv) {
-	if (argc == 1) { program_message(); std::cerr << "Usage: tomahawk calc [options] -i <in.twk> -o <output.two>" << std::endl; return 1; }
+	if (argc == 1) {           // reference: lib/main.cpp:28-60 lists its commands
+		program_message();
+		std::cerr << "Usage: tomahawk <command> [options]\n\n"
+		             "Commands:\n"
+		             "  import   convert VCF text (plain / gzip) to .twk\n"
+		             "  calc     calculate linkage disequilibrium: tomahawk calc [options] -i <in.twk> -o <output.two>\n"
+		             "  scalc    linkage disequilibrium of one site against its neighbourhood\n"
+		             "  sort     sort a .two file\n"
+		             "  view     convert, filter and slice .two files\n"
+		             "  concat   concatenate .two files from the same set of samples\n" << std::endl;
+		return 1;
+	}
 	// The host tools allocate and free MB-sized block buffers on hundreds of threads; served by
 	// mmap/munmap (glibc's default above 128 KiB) that serialises on the address-space lock.
 	mallopt(M_MMAP_THRESHOLD, 1 << 30);
