@@ -198,3 +198,33 @@ def test_reference_reader_accepts_imported_file(tmp_path):
     for hom1, het, hom2 in [(17, 30, 9), (400, 90, 20), (3, 0, 2), (0, 25, 0)]:
         ref = float(subprocess.run([O.REF_BIN, "hwe", str(hom1), str(het), str(hom2)], capture_output=True, text=True).stdout)
         assert H.hwe_exact(hom1, het, hom2) == ref
+
+
+def test_import_input_variants(tmp_path):
+    """CRLF line ends, a contig the header does not declare, stdin input, a header-only file."""
+    N = 10
+    rng = np.random.default_rng(8)
+    rows = []
+    for v in range(12):
+        g = rng.integers(0, 2, (N, 2))
+        rows.append(f"{'chrA' if v < 6 else 'chrB'}\t{100 + 10 * v}\t.\tA\tC\t.\t.\t.\tGT\t" + "\t".join(f"{a}|{b}" for a, b in g))
+    head = ["##fileformat=VCFv4.2", "##contig=<ID=chrA,length=1000>", '##FORMAT=<ID=GT,Number=1,Type=String,Description="Genotype">',
+            "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(f"S{i}" for i in range(N))]
+    vcf = str(tmp_path / "crlf.vcf")
+    open(vcf, "wb").write(("\r\n".join(head + rows) + "\r\n").encode())
+    out = str(tmp_path / "o.twk")
+    cnt = H.import_vcf(vcf, out, remove_univariate=False, threshold_miss=0.0)
+    assert cnt["written"] == 12 and cnt["sites"] == 12
+    _, _, _, meta, _ = read_back(out)
+    assert meta["rid"].tolist() == [0] * 6 + [1] * 6                         # chrB appended behind the declared contigs
+    # the same through stdin
+    p = subprocess.run([H.CLI_PATH, "import", "-i", "-", "-o", str(tmp_path / "stdin.twk"), "-r", "-n", "0"],
+                       input=open(vcf, "rb").read(), capture_output=True)
+    assert p.returncode == 0, p.stderr.decode()
+    assert read_back(str(tmp_path / "stdin.twk"))[3]["pos"].tolist() == meta["pos"].tolist()
+    # header only: a valid, empty .twk
+    open(vcf, "w").write("\n".join(head) + "\n")
+    cnt = H.import_vcf(vcf, out)
+    assert cnt["sites"] == 0 and cnt["written"] == 0
+    n, data, _, _, _ = read_back(out)
+    assert n == N and len(data) == 0

@@ -95,7 +95,7 @@ void TwkIndex::serialize(ByteBuf& b) const {
 bool TwkIndex::deserialize(ByteBuf& b) {
 	uint64_t marker = 0, n = 0, m = 0, me = 0;
 	if (!b.get(marker) || marker != TWK_INDEX_START_MARKER || !b.get(n) || !b.get(m) || !b.get(me)) return false;
-	if (n > b.remaining() / 40 || me > b.remaining() / 44) return false;
+	if (n > b.remaining() / 40 || me > b.remaining() / 40 || n * 40 + me * 40 > b.remaining()) return false;   // 40-byte entries
 	ent.resize(n); meta.resize(me);
 	for (auto& e : ent) if (!get_entry(b, e)) return false;
 	for (auto& e : meta) if (!get_meta(b, e)) return false;
@@ -111,7 +111,7 @@ void TwoIndex::serialize(ByteBuf& b) const {
 bool TwoIndex::deserialize(ByteBuf& b) {
 	uint64_t marker = 0, n = 0, m = 0, me = 0;
 	if (!b.get(marker) || marker != TWK_INDEX_START_MARKER || !b.get(state) || !b.get(n) || !b.get(m) || !b.get(me)) return false;
-	if (n > b.remaining() / 44 || me > b.remaining() / 44) return false;
+	if (n > b.remaining() / 44 || me > b.remaining() / 40 || n * 44 + me * 40 > b.remaining()) return false;   // 44- and 40-byte entries
 	ent.resize(n); meta.resize(me);
 	for (auto& e : ent) if (!get_entry(b, e) || !b.get(e.ridB)) return false;
 	for (auto& e : meta) if (!get_meta(b, e)) return false;
