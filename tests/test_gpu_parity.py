@@ -320,6 +320,21 @@ def test_hostile_genotypes_all_modes(hip, N, seed, miss):
         util.assert_records_match(got, want, variants, double_root=vet)
 
 
+def test_records_at_the_headline_sample_count(hip):
+    """Record-level parity (not only table properties) at N ~ 1 M: haplotype-block genotypes with missing
+    samples, N not a multiple of anything, every mode, against the scalar oracle."""
+    N, M = 1_000_003, 14
+    al = util.mosaic_alleles(M, N, 2, n_founders=5, switch=0.05, mut=0.01, miss_rate=0.01, miss_variants=0.3)
+    data, mask, variants = util.upload(hip, al)
+    vet = util.double_root_vetter(data, mask, variants, N)
+    for mode, ph in ((T.MODE_UNPHASED, False), (T.MODE_PHASED, True), (T.MODE_AUTO, None)):
+        st = O.settings(minR2=0.0, phased=bool(ph), unphased=(ph is False))
+        want = O.all_pairs(data, mask, variants, N, st, vector_only=False)
+        got, npairs, _ = hip.ld_all(mode, T.Filters(minR2=0.0))
+        assert npairs == M * (M - 1) // 2 and len(want) > 60
+        util.assert_records_match(got, want, variants, double_root=vet)
+
+
 def test_invalid_arguments_are_rejected(hip):
     hip.set_problem(10, 20)
     hip.generate_synthetic(1)
