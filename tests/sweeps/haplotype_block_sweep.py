@@ -1,0 +1,25 @@
+import sys, numpy as np
+sys.path.insert(0, '.')
+import tomahawk_amd as T
+from oracle import oracle as O
+from tests import util
+hip = T.HipLd(0)
+bad = 0; total = 0
+for it in range(40):
+    N = [33, 64, 100, 128, 250, 500, 1000, 2504][it % 8]
+    M = 140
+    miss = (it % 5 == 3)
+    al = util.mosaic_alleles(M, N, 5000 + it, n_founders=3 + it % 6, switch=[0.005, 0.02, 0.05][it % 3], mut=[0.0, 0.002, 0.01][it % 3],
+                             miss_rate=0.05 if miss else 0.0, miss_variants=0.3 if miss else 0.0)
+    data, mask, variants = util.upload(hip, al)
+    for mode, ph in ((T.MODE_UNPHASED, False), (T.MODE_PHASED, True), (T.MODE_AUTO, None)):
+        st = O.settings(minR2=0.0, phased=bool(ph), unphased=(ph is False))
+        want = O.all_pairs(data, mask, variants, N, st, vector_only=False)
+        got, _, _ = hip.ld_all(mode, T.Filters(minR2=0.0))
+        total += len(want)
+        try:
+            util.assert_records_match(got, want, variants)
+        except AssertionError as e:
+            bad += 1
+            print("MISMATCH it", it, "N", N, "mode", mode, "miss", miss, str(e)[:300], flush=True)
+print("records compared", total, "failing datasets", bad)
