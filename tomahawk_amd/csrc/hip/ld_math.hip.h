@@ -145,6 +145,15 @@ __device__ inline bool d_phased_math(uint64_t c0, uint64_t c1, uint64_t c4, uint
 	if (total < TWK_D_MIN_ALLELES) return false;
 	if (c0 < c5) { if (c4 + c1 + c0 < 5) return false; }
 	else         { if (c5 + c4 + c1 < 5) return false; }
+	// Screen before the nine divisions below: r2 = (c0 c5 - c1 c4)^2 / ((c0+c4)(c1+c5)(c0+c1)(c4+c5)) exactly
+	// (the products are integers below 2^53).  A pair whose exact r2 is below the cut-off by more than a
+	// part in 1e6 cannot pass the rounded test further down either (its D carries an absolute error of
+	// ~4e-16 against |D| > 1e-8 at any cut-off worth the name), and nothing else below has an effect.
+	if (f.minR2 > 1e-6) {
+		const double dn = (double)c0 * (double)c5 - (double)c1 * (double)c4;
+		const double den = ((double)c0 + (double)c4) * ((double)c1 + (double)c5) * (((double)c0 + (double)c1) * ((double)c4 + (double)c5));
+		if (dn * dn < f.minR2 * (1.0 - 1e-6) * den) return false;
+	}
 	const double T = (double)total;
 	const double pA = (double)c0 / T, qA = (double)c1 / T, pB = (double)c4 / T, qB = (double)c5 / T;
 	const double D = pA * qB - qA * pB;
