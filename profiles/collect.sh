@@ -1,0 +1,67 @@
+#!/bin/bash
+# Collect the measurements behind DESIGN.md on a GPU box (run through gpurun from the repo root):
+#   profiles/collect.sh <tag> <stage>...      e.g.  profiles/collect.sh r02 microbench cfg2 cfg5 cfg3
+# Raw outputs land in gpurun_out/<tag>/ ; the ones quoted in DESIGN.md are then copied to profiles/<tag>_*.
+# rocprofv3 is always given the python3 / tool binary itself after `--` (no shell hop), counters in their
+# own passes.
+set -u
+TAG=${1:?tag}; shift
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+cd /tmp
+
+stats() {   # stats <name> <bench args...>: kernel trace + stats of one bench run, CSV summary kept
+	local name=$1; shift
+	rm -rf /tmp/prof_$name
+	timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -o $name -- \
+		python3 $R/bench.py --no-cpu-baseline "$@" > $OUT/${name}_under_rocprof.json 2> $OUT/${name}_under_rocprof.log < /dev/null
+	echo "$name stats rc=$?"
+	local f; f=$(find /tmp/prof_$name -name "*kernel_stats.csv" | head -1)
+	[ -n "$f" ] && cp "$f" $OUT/${name}_kernel_stats.csv && head -5 "$f" | cut -c1-220
+}
+pmc() {     # pmc <name> <counter list> <bench args...>: one counter pass, per-kernel sums
+	local name=$1 ctr=$2; shift 2
+	rm -rf /tmp/pmc_$name
+	timeout 900 rocprofv3 --pmc $ctr --output-format csv -d /tmp/pmc_$name -o $name -- \
+		python3 $R/bench.py --no-cpu-baseline "$@" > $OUT/${name}_pmc.json 2> $OUT/${name}_pmc.log < /dev/null
+	echo "$name pmc rc=$?"
+	local f; f=$(find /tmp/pmc_$name -name "*counter_collection.csv" | head -1)
+	[ -n "$f" ] && python3 $R/profiles/sum_counters.py "$f" > $OUT/${name}_pmc_sums.json && cat $OUT/${name}_pmc_sums.json | head -60
+}
+
+for stage in "$@"; do
+	case $stage in
+	microbench)   # the instruction-rate evidence behind the VALU ceiling
+		for t in valu_rate issue_test2 hbm_read_bw; do
+			echo "== $t"; timeout 300 $R/build/$t > $OUT/microbench_$t.txt 2>&1; cat $OUT/microbench_$t.txt
+		done
+		echo "== count_microbench (kernel alone, full K of N = 1M unphased planes: 4096 rows x 31264 words)"
+		timeout 300 $R/build/count_microbench 4096 31264 3 > $OUT/microbench_count_microbench.txt 2>&1; cat $OUT/microbench_count_microbench.txt
+		echo "== count_microbench (configs[1] rows: 10112 rows x 6272 words)"
+		timeout 300 $R/build/count_microbench 10112 6272 3 >> $OUT/microbench_count_microbench.txt 2>&1; tail -3 $OUT/microbench_count_microbench.txt
+		;;
+	cfg3)  timeout 600 python3 $R/bench.py --steps 2 --warmup 1 > $OUT/bench_cfg3.json 2> $OUT/bench_cfg3.log; cat $OUT/bench_cfg3.json ;;
+	cfg3_stats) stats cfg3 --steps 2 --warmup 1 ;;
+	cfg3_pmc)
+		pmc cfg3_fetch FETCH_SIZE --steps 1 --warmup 0 --variants 16384
+		pmc cfg3_write WRITE_SIZE --steps 1 --warmup 0 --variants 16384
+		pmc cfg3_sq "SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" --steps 1 --warmup 0 --variants 16384
+		;;
+	cfg2)
+		timeout 600 python3 $R/bench.py --config cfg2 --steps 20 --warmup 3 > $OUT/bench_cfg2.json 2> $OUT/bench_cfg2.log; cat $OUT/bench_cfg2.json
+		stats cfg2 --config cfg2 --steps 20 --warmup 3
+		pmc cfg2_sq "SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" --config cfg2 --steps 5 --warmup 1
+		;;
+	cfg5)
+		timeout 900 python3 $R/bench.py --config cfg5 --emulate-shard 3/8 --steps 1 --warmup 0 > $OUT/bench_cfg5_shard3of8.json 2> $OUT/bench_cfg5_shard3of8.log; cat $OUT/bench_cfg5_shard3of8.json
+		;;
+	cfg5_prof)
+		stats cfg5_shard3of8 --config cfg5 --emulate-shard 3/8 --steps 1 --warmup 0
+		pmc cfg5_sq "SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" --config cfg5 --emulate-shard 3/8 --steps 1 --warmup 0
+		;;
+	shards)  timeout 1200 python3 $R/tests/sweeps/shard_timings.py > $OUT/shard_timings.txt 2>&1; tail -20 $OUT/shard_timings.txt ;;
+	*) echo "unknown stage $stage" ;;
+	esac
+done

@@ -1,0 +1,217 @@
+"""GPU parity at the sample counts and launch shapes of BASELINE.json's single-GPU configs that the small
+cases in test_gpu_parity.py do not reach, record for record against the scalar oracle:
+
+  configs[1]  N = 100,000 phased, several 128-row tiles (diagonal + rectangle launches)
+  configs[2]  N ~ 1,000,000 unphased: Fisher's tail-start shortcut on the cubic path's rounded tables
+  configs[4]  N = 10,000,000, windowed, Fisher P <= 1e-6, missing samples, every mode
+
+plus the two review findings of round 1 on window mode over the regrouped plane set and on the r2 screen.
+"""
+import numpy as np
+import pytest
+
+import tomahawk_amd as T
+from oracle import oracle as O
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _in_window(want, W):
+    d = np.abs(want["Apos"].astype(np.int64) - want["Bpos"].astype(np.int64))
+    return want[(want["ridA"] == want["ridB"]) & (d <= W)]
+
+
+def test_config2_phased_100k_samples_multi_tile(hip):
+    """configs[1]'s sample count with enough variants for several row / column tiles: the default launch
+    (one diagonal super-tile of 3 x 3 blocks) and 128-variant super-tiles (diagonal + rectangle launches,
+    two-deep pipeline) both equal the oracle, counts bit-exact."""
+    N, M = 100_000, 333
+    al = util.mosaic_alleles(M, N, 71, n_founders=8, switch=0.02, mut=0.003)
+    data, mask, variants = util.upload(hip, al)
+    want = O.all_pairs(data, mask, variants, N, O.settings(minR2=0.0, phased=True), vector_only=False)
+    assert len(want) > 50_000
+    for tile in (0, 128):
+        got, npairs, nrec = hip.ld_all(T.MODE_PHASED, T.Filters(minR2=0.0), tile_variants=tile)
+        assert npairs == M * (M - 1) // 2 and nrec == len(got)
+        util.assert_records_match(got, want, variants)
+    # the default filter (r2 >= 0.1) keeps the same pairs as the oracle's
+    want01 = O.all_pairs(data, mask, variants, N, O.settings(minR2=0.1, phased=True), vector_only=False)
+    got01, _, _ = hip.ld_all(T.MODE_PHASED, T.Filters(minR2=0.1), tile_variants=128)
+    assert 100 < len(want01) < len(want)
+    util.assert_records_match(got01, want01, variants)
+    # raw 2x2 tables of a rectangle that crosses tile boundaries
+    c = hip.count_tile(T.MODE_PHASED, 100, 150, 120, 213)
+    for i, j in [(0, 0), (149, 212), (27, 8), (28, 136), (140, 9)]:
+        assert np.array_equal(c[i, j], O.count_phased(data[100 + i], None, data[120 + j], None, N)), (i, j)
+
+
+def test_fisher_shortcut_unphased_1m_samples(hip):
+    """Fisher's exact test behind UnphasedMath at N = 1 M: tables are round()ed expected haplotype counts
+    near 2e6 (ld_engine.cpp:1656), the reference walks ~1e6 tail terms per record, the device starts at
+    a verified e^-50 point.  P must agree from ~1 down to the underflow region."""
+    N, M = 1_000_000, 26
+    rng = np.random.default_rng(99)
+    al = util.random_alleles(M, N, 99, maf_lo=0.1, maf_hi=0.5)
+    for k, noise in enumerate([0.0003, 0.02, 0.2, 0.4, 0.45, 0.47, 0.48, 0.485, 0.49, 0.495, 0.497, 0.499]):
+        flip = rng.random((N, 2)) < noise
+        al[M - 1 - k] = np.where(flip, 1 - al[k], al[k])
+    data, mask, variants = util.upload(hip, al, phase=0)
+    vet = util.double_root_vetter(data, mask, variants, N)
+    want = O.all_pairs(data, mask, variants, N, O.settings(minR2=0.0, unphased=True), vector_only=False)
+    got, npairs, _ = hip.ld_all(T.MODE_UNPHASED, T.Filters(minR2=0.0))
+    assert npairs == M * (M - 1) // 2 and len(want) > 300
+    assert (want["controller"] & 1).sum() == 0            # every record came through the cubic, none through PhasedMath
+    util.assert_records_match(got, want, variants, double_root=vet)
+    P = np.sort(want["P"])
+    assert P[0] < 1e-250 and (P > 0.3).sum() > 50 and ((P > 1e-200) & (P < 1e-6)).sum() >= 2
+    # and the P cut-off drops the same records
+    want_p = O.all_pairs(data, mask, variants, N, O.settings(minR2=0.0, minP=1e-6, unphased=True), vector_only=False)
+    got_p, _, _ = hip.ld_all(T.MODE_UNPHASED, T.Filters(minR2=0.0, minP=1e-6))
+    assert 0 < len(want_p) < len(want)
+    util.assert_records_match(got_p, want_p, variants, double_root=vet)
+
+
+@pytest.fixture(scope="module")
+def ten_million():
+    """configs[4]'s sample count: 14 haplotype-block variants, 10,000,000 diploid samples, a third of the
+    variants with 0.5 % missing samples.  Counts reach 2e7 (the int arguments of kt_fisher_exact,
+    fisher_math.cpp:231), a row is 19,532 K-chunks of the count kernel."""
+    N, M = 10_000_000, 14
+    rng = np.random.default_rng(4)
+    founders = (rng.random((5, M)) < rng.uniform(0.15, 0.6, size=M)[None, :]).astype(np.int8)
+    al = np.empty((M, N, 2), dtype=np.int8)
+    cur = rng.integers(0, 5, size=2 * N).astype(np.int8)
+    for v in range(M):
+        sw = rng.random(2 * N) < 0.06
+        cur = np.where(sw, rng.integers(0, 5, size=2 * N), cur).astype(np.int8)
+        h = founders[cur, v] ^ (rng.random(2 * N) < 0.008)
+        al[v] = h.reshape(N, 2)
+    for v in (1, 4, 7, 12):
+        ms = rng.random(N) < 0.005
+        al[v, ms, :] = 2
+    al[9, 17, 0] = 2                                     # one half-missing genotype (an = 1)
+    data, mask = O.bitvectors_from_alleles(al)
+    variants = O.variants_from_alleles(al)
+    return N, M, data, mask, variants
+
+
+@pytest.mark.parametrize("mode,ph", [(T.MODE_UNPHASED, False), (T.MODE_PHASED, True), (T.MODE_AUTO, None)])
+def test_config5_ten_million_samples_all_modes(hip, ten_million, mode, ph):
+    N, M, data, mask, variants = ten_million
+    hip.set_problem(N, M)
+    hip.upload(data, util.to_hip_meta(variants), mask)
+    vet = util.double_root_vetter(data, mask, variants, N)
+    st = O.settings(minR2=0.0, phased=bool(ph), unphased=(ph is False))
+    want = O.all_pairs(data, mask, variants, N, st, vector_only=False)
+    got, npairs, _ = hip.ld_all(mode, T.Filters(minR2=0.0))
+    assert npairs == M * (M - 1) // 2 and len(want) > 60
+    assert want["cnt"].max() > 1e7
+    util.assert_records_match(got, want, variants, double_root=vet)
+    # configs[4] as specified: window + Fisher cut-off (positions 1000 + 100 v: +-4 partners at 400 bp)
+    W = 400
+    st = O.settings(minR2=0.0, minP=1e-6, phased=bool(ph), unphased=(ph is False))
+    want_w = _in_window(O.all_pairs(data, mask, variants, N, st, vector_only=False), W)
+    got_w, npw, _ = hip.ld_all(mode, T.Filters(minR2=0.0, minP=1e-6), window=T.OPT_WINDOW, l_window=W)
+    assert npw == sum(min(4, M - 1 - i) for i in range(M))
+    assert 10 < len(want_w) < len(want)
+    util.assert_records_match(got_w, want_w, variants, double_root=vet)
+    # raw cells, bit-exact, on the widest rows the engine sees
+    if mode != T.MODE_AUTO:
+        counter = O.count_phased if ph else O.count_unphased
+        c = hip.count_tile(mode, 0, M, 0, M)
+        for i, j in [(0, 13), (1, 4), (4, 12), (9, 1), (6, 5)]:
+            mi = mask[i] if variants["gt_missing"][i] else None
+            mj = mask[j] if variants["gt_missing"][j] else None
+            assert np.array_equal(c[i, j], counter(data[i], mi, data[j], mj, N)), (i, j)
+
+
+@pytest.mark.parametrize("tile", [0, 128])
+def test_window_mode_regrouped_rows_straddle_contigs(hip, tile):
+    """Default mode + missing data + `-w` on several contigs: the rows of the regrouped rectangle (variants
+    with missing data) straddle contig boundaries and later contigs start at small positions again, so a
+    column tile can lie wholly *before* the row tile's reach.  Every same-contig pair with |dpos| <= w must
+    still come out (round-1 review: a tile skip assumed columns always follow rows)."""
+    N, W = 128, 6000
+    sizes = [350, 300, 250, 120]
+    M = sum(sizes)
+    al = util.random_alleles(M, N, 78, miss_rate=0.05, miss_variants=0.3, low_ac=3)
+    rid = np.repeat(np.arange(len(sizes)), sizes).astype(np.uint32)
+    pos = np.concatenate([np.arange(n) * 100 + off for n, off in zip(sizes, (1000, 500, 200, 50))])
+    data, mask, variants = util.upload(hip, al, pos=pos, rid=rid)
+    f = T.Filters(minR2=0.0)
+    everything, _, _ = hip.ld_all(T.MODE_AUTO, f)
+    d = np.abs(pos[everything["idxA"]].astype(np.int64) - pos[everything["idxB"]].astype(np.int64))
+    want = everything[(rid[everything["idxA"]] == rid[everything["idxB"]]) & (d <= W)]
+    got, npairs, nrec = hip.ld_all(T.MODE_AUTO, f, tile_variants=tile, window=T.OPT_WINDOW, l_window=W)
+    assert nrec == len(got)
+    a = np.sort(want, order=["idxA", "idxB"]); b = np.sort(got, order=["idxA", "idxB"])
+    assert len(a) == len(b) and a.tobytes() == b.tobytes()
+    # the pair count reported for window mode is the number of in-window pairs
+    same = rid[:, None] == rid[None, :]
+    near = np.abs(pos[:, None].astype(np.int64) - pos[None, :].astype(np.int64)) <= W
+    assert npairs == int(np.triu(same & near, 1).sum())
+    # shards still partition it
+    parts = [hip.ld_all(T.MODE_AUTO, f, part=k, n_parts=3, tile_variants=tile, window=T.OPT_WINDOW, l_window=W) for k in range(3)]
+    c = np.sort(np.concatenate([p[0] for p in parts]), order=["idxA", "idxB"])
+    assert a.tobytes() == c.tobytes()
+
+
+@pytest.mark.parametrize("N,M,seed", [(64, 120, 301), (1_000_000, 12, 302)])
+def test_r2_screen_agrees_at_the_cutoff(hip, N, M, seed):
+    """PhasedMath's integer screen (ld_math.hip.h) against the reference's rounded test, with the r2 cut-off
+    placed exactly on, one ulp below and one ulp above the r2 of existing pairs: the survivors must be
+    exactly the records whose (unscreened, minR2 = 0) R2 is >= the cut-off."""
+    al = util.mosaic_alleles(M, N, seed, n_founders=5, switch=0.03, mut=0.004)
+    util.upload(hip, al)
+    base, _, _ = hip.ld_all(T.MODE_PHASED, T.Filters(minR2=0.0))
+    r2 = np.unique(base["R2"])
+    r2 = r2[(r2 > 1e-5) & (r2 < 1.0)]
+    picks = r2[:: max(1, len(r2) // 9)][:9]
+    assert len(picks) >= 5
+    keys = lambda r: set(zip(r["idxA"].tolist(), r["idxB"].tolist()))
+    for x in picks:
+        for cut in (np.nextafter(x, 0.0), x, np.nextafter(x, 1.0)):
+            got, _, _ = hip.ld_all(T.MODE_PHASED, T.Filters(minR2=float(cut)))
+            want = base[base["R2"] >= cut]
+            assert keys(got) == keys(want), (x, cut)
+
+
+def test_option_bits_pass_through_unchanged(hip):
+    """ld_all / ld_tile hand the TWK_HIP_OPT_* bits to the C ABI as given: OPT_KEEP_LOW_AC alone keeps the
+    singleton pairs and does not switch window mode on."""
+    N, M = 64, 40
+    al = util.random_alleles(M, N, 17, low_ac=8)
+    al[:8] = 0
+    for v in range(8):
+        al[v, v, 0] = 1                                   # eight singletons: ac_A + ac_B = 2 for their pairs
+    util.upload(hip, al)
+    f = T.Filters(minR2=0.0)
+    plain, _, _ = hip.ld_all(T.MODE_PHASED, f)
+    keep, _, _ = hip.ld_all(T.MODE_PHASED, f, window=T.OPT_KEEP_LOW_AC, l_window=1)
+    win, _, _ = hip.ld_all(T.MODE_PHASED, f, window=T.OPT_WINDOW, l_window=1)
+    keys = lambda r: set(zip(r["idxA"].tolist(), r["idxB"].tolist()))
+    assert keys(plain) <= keys(keep)
+    assert not any(a < 8 and b < 8 for a, b in keys(plain))
+    # singleton x singleton tables have < 5 observations off the main cell: PhasedMath drops them anyway,
+    # but the pairs with the other variants are unaffected and l_window = 1 did not filter anything
+    assert len(keep) >= len(plain) > len(win)
+    t_keep, _ = hip.ld_tile(T.MODE_PHASED, 0, M, 0, M, True, f, window=T.OPT_KEEP_LOW_AC, l_window=1)
+    assert keys(t_keep) == keys(keep)
+
+
+def test_inconsistent_missing_flags_are_rejected_without_side_effects(hip):
+    """gt_missing without missing alleles (or the reverse) cannot come from the reference's importer; the
+    upload refuses it before touching device state (round-1 review)."""
+    N, M = 64, 20
+    al = util.random_alleles(M, N, 19, miss_rate=0.1, miss_variants=0.5)
+    data, mask, variants = util.upload(hip, al)
+    before, _, _ = hip.ld_all(T.MODE_AUTO, T.Filters(minR2=0.0))
+    bad = util.to_hip_meta(variants)
+    k = int(np.nonzero(bad["missing"])[0][0])
+    bad["an"][k] = 0
+    with pytest.raises(T.HipError) as e:
+        hip.upload(np.zeros_like(data), bad, mask)
+    assert e.value.code == -1
+    after, _, _ = hip.ld_all(T.MODE_AUTO, T.Filters(minR2=0.0))
+    assert before.tobytes() == after.tobytes()

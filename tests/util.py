@@ -5,6 +5,9 @@ from oracle import oracle as O
 import tomahawk_amd as T
 from tomahawk_amd.hip import META_DTYPE
 
+import os as _os
+_STATS_PATH = _os.environ.get("TWK_PARITY_STATS", "")     # tests/sweeps: record the observed deviations
+
 
 def random_alleles(M, N, seed, maf_lo=0.05, maf_hi=0.5, miss_rate=0.0, miss_variants=0.0, low_ac=0):
     """int8 [M, N, 2] genotypes; a fraction `miss_variants` of variants gets `miss_rate` missing samples;
@@ -159,9 +162,17 @@ def assert_records_match(gpu_recs, orc_recs, variants, n_samples=None, rtol=1e-6
             want.pop(k, None); got.pop(k, None)
     assert not missing and not extra, f"pair sets differ: missing {sorted(missing)[:5]} extra {sorted(extra)[:5]}"
     ties, bad = [], []
+    dev = {}                                     # largest deviations seen on cubic-path records (TWK_PARITY_STATS)
     for k, w in want.items():
         g = got[k]
         phased_math = bool(int(w["controller"]) & 1)
+        if not phased_math and _STATS_PATH:
+            tot = float(np.sum(w["cnt"]))
+            for f in ("D", "Dprime", "R", "R2"):
+                dev[f] = max(dev.get(f, 0.0), abs(float(g[f]) - float(w[f])))
+            dev["cnt/total"] = max(dev.get("cnt/total", 0.0), float(np.max(np.abs(g["cnt"] - w["cnt"]))) / tot)
+            dev["ChiSqFisher/total"] = max(dev.get("ChiSqFisher/total", 0.0), abs(float(g["ChiSqFisher"]) - float(w["ChiSqFisher"])) / tot)
+            dev["n"] = dev.get("n", 0) + 1
         if (int(g["flags"]) ^ int(w["controller"])) & ~(1 << 5):   # bit 5 (multiple roots) checked below
             bad.append((k, "flags", int(g["flags"]), int(w["controller"])))
             continue
@@ -181,13 +192,30 @@ def assert_records_match(gpu_recs, orc_recs, variants, n_samples=None, rtol=1e-6
             if not np.isclose(g[f], w[f], rtol=rtol, atol=atol):
                 bad.append((k, f, float(g[f]), float(w[f])))
         # Fisher P underflows to exactly 0 for strong associations: absolute floor.
-        # UnphasedMath runs Fisher on round(expected counts) (ld_engine.cpp:1656): when an expected
-        # count is a half-integer up to rounding error, round() is decided by the last ulp of the
-        # cubic root and either neighbouring table is a faithful answer.
-        frac = np.abs(np.asarray(w["cnt"]) - np.floor(w["cnt"]) - 0.5)
-        if not phased_math and (frac < 1e-6).any():
-            ties.append((k, "round"))
-        elif not np.isclose(g["P"], w["P"], rtol=rtol, atol=p_floor):
-            bad.append((k, "P", float(g["P"]), float(w["P"])))
+        # UnphasedMath runs Fisher on round(expected counts) (ld_engine.cpp:1656).  The expected counts
+        # are only as good as the cubic root (above), so when one of them lies within that error of a
+        # half-integer the two sides may round to neighbouring tables - at N = 1e7 an error of 1e-8 in
+        # haplotype frequency is 0.2 counts.  Such a record is not skipped: the device's P must then be
+        # Fisher's P of the device's *own* rounded table (computed by the oracle), and that table must
+        # be the oracle's up to one count per cell.
+        if not np.isclose(g["P"], w["P"], rtol=rtol, atol=p_floor):
+            gt = [int(np.floor(float(x) + 0.5)) for x in g["cnt"]]       # C round(): halves away from zero
+            wt = [int(np.floor(float(x) + 0.5)) for x in w["cnt"]]
+            neighbour = (not phased_math) and gt != wt and max(abs(a - b) for a, b in zip(gt, wt)) <= 1
+            # ... and every cell that rounds differently must sit on a half-integer within the cubic's tolerance
+            for a, b, x in zip(gt, wt, w["cnt"]):
+                if a != b and abs(float(x) - np.floor(float(x)) - 0.5) > 1e-8 * total + rtol * float(x):
+                    neighbour = False
+            own = O.fisher(gt[0], gt[2], gt[1], gt[3])[2] if neighbour else None
+            if neighbour and np.isclose(g["P"], own, rtol=rtol, atol=p_floor):
+                ties.append((k, "round"))
+            else:
+                bad.append((k, "P", float(g["P"]), float(w["P"]), own))
+    if _STATS_PATH and dev:
+        import json, os
+        dev.update(test=os.environ.get("PYTEST_CURRENT_TEST", ""), n_samples=n_samples, records=len(want), ties=len(ties))
+        with open(_STATS_PATH, "a") as fh:
+            fh.write(json.dumps(dev) + "\n")
     assert not bad, f"{len(bad)} field mismatches of {len(want)} records, first: {bad[:8]}"
-    assert len(ties) <= max(2, len(want) // 50), f"too many rounding ties: {len(ties)} of {len(want)}: {ties[:5]}"
+    roots = [t for t in ties if t[1] == "roots"]
+    assert len(roots) <= max(2, len(want) // 50), f"too many root-multiplicity ties: {len(roots)} of {len(want)}: {roots[:5]}"

@@ -145,10 +145,15 @@ __device__ inline bool d_phased_math(uint64_t c0, uint64_t c1, uint64_t c4, uint
 	if (total < TWK_D_MIN_ALLELES) return false;
 	if (c0 < c5) { if (c4 + c1 + c0 < 5) return false; }
 	else         { if (c5 + c4 + c1 < 5) return false; }
-	// Screen before the nine divisions below: r2 = (c0 c5 - c1 c4)^2 / ((c0+c4)(c1+c5)(c0+c1)(c4+c5)) exactly
-	// (the products are integers below 2^53).  A pair whose exact r2 is below the cut-off by more than a
-	// part in 1e6 cannot pass the rounded test further down either (its D carries an absolute error of
-	// ~4e-16 against |D| > 1e-8 at any cut-off worth the name), and nothing else below has an effect.
+	// Screen before the nine divisions below: r2 = (c0 c5 - c1 c4)^2 / ((c0+c4)(c1+c5)(c0+c1)(c4+c5)).  The
+	// products and sums below are evaluated in FP64: c0*c5 and c1*c4 are exact while the cells stay below
+	// 2^26 (N < 16.7 M haplotypes), the denominator is not, and at the largest sample counts set_problem
+	// accepts neither is - each operation carries <= 1 ulp, so dn^2 and den are good to ~1e-15 relative.
+	// The screen only rejects a pair whose r2 computed this way lies more than a part in 1e6 below the
+	// cut-off: nine orders of magnitude more than the rounding error of either evaluation, so such a pair
+	// cannot pass the reference's (rounded) test further down, and nothing else below has an effect.  Pairs
+	// inside the band minR2 * (1 +- 1e-6) always go through the reference's formula
+	// (tests: test_r2_screen_agrees_at_the_cutoff).
 	if (f.minR2 > 1e-6) {
 		const double dn = (double)c0 * (double)c5 - (double)c1 * (double)c4;
 		const double den = ((double)c0 + (double)c4) * ((double)c1 + (double)c5) * (((double)c0 + (double)c1) * ((double)c4 + (double)c5));

@@ -503,6 +503,14 @@ int twk_hip_upload_bitvectors(twk_hip_ctx* c, uint32_t first, uint32_t count, co
 	if (!c->raw) return TWK_HIP_E_STATE;
 	const size_t w64 = ((size_t)2 * c->N + 63) / 64;
 	if (stride64 < w64 || (uint64_t)first + count > c->M) return TWK_HIP_E_INVALID;
+	// Validate everything before any device or context state changes.  A variant's missing-data
+	// flags must agree: the reference picks the pair math from `an` (ld_engine.cpp:2775) and builds
+	// the mask from `gt_missing` (core.cpp:356-358); both come from the same genotypes in any .twk
+	// its importer writes, and the plane selection here relies on that.
+	for (uint32_t i = 0; i < count; ++i) {
+		if (meta[i].missing && !mask) return TWK_HIP_E_INVALID;
+		if ((meta[i].an != 0) != (meta[i].missing != 0)) return TWK_HIP_E_INVALID;
+	}
 	HIPCHK(c, hipSetDevice(c->device));
 	free_planes(c);                                             // derived planes are stale now
 	HIPCHK(c, hipMemcpy2D(c->raw + (size_t)first * c->Wp, (size_t)c->Wp * 4, data, stride64 * 8, w64 * 8, count, hipMemcpyHostToDevice));
@@ -526,7 +534,7 @@ int twk_hip_upload_bitvectors(twk_hip_ctx* c, uint32_t first, uint32_t count, co
 		ac[i] = meta[i].ac; an[i] = meta[i].an; pos[i] = meta[i].pos; rid[i] = meta[i].rid;
 		miss[i] = meta[i].missing ? 1 : 0; hwe[i] = meta[i].hwe;
 		c->h_meta[first + i] = meta[i];
-		if (meta[i].missing) { if (!mask) return TWK_HIP_E_INVALID; c->any_missing = true; }
+		if (meta[i].missing) c->any_missing = true;
 	}
 	HIPCHK(c, hipMemcpy(c->d_ac + first, ac.data(), (size_t)count * 4, hipMemcpyHostToDevice));
 	HIPCHK(c, hipMemcpy(c->d_an + first, an.data(), (size_t)count * 4, hipMemcpyHostToDevice));
@@ -749,15 +757,21 @@ static int region_impl(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint3
 		twk_hip_tile_desc t{};
 		t.rowA0 = a0 + ra; t.nA = na; t.rowB0 = b0 + cb; t.nB = nb_; t.diag = diag; t.window = window; t.l_window = l_window;
 		if ((window & TWK_HIP_OPT_WINDOW) && !diag) {
-			// Inputs are sorted by (rid, pos) like every .twk: if both tiles lie on one contig and
-			// the gap between them exceeds the window, no pair can qualify (the reference's ticker
-			// skips the rest of the row, ld_balancing.h:191).
+			// Each axis of a tile is sorted by (rid, pos) (file order, or one group of the regrouped set),
+			// but the two axes are in no particular order relative to each other (regrouped rectangle: the
+			// rows are the variants with missing data, the columns the rest).  A tile can only be skipped
+			// when both of its axes lie on one contig each and either the contigs differ or the position
+			// intervals are more than the window apart, in whichever direction (the reference's ticker
+			// skips the rest of a row on the same grounds, ld_balancing.h:191).
 			const twk_hip_variant_meta& firstA = meta_at(t.rowA0);
 			const twk_hip_variant_meta& lastA  = meta_at(t.rowA0 + t.nA - 1);
 			const twk_hip_variant_meta& firstB = meta_at(t.rowB0);
 			const twk_hip_variant_meta& lastB  = meta_at(t.rowB0 + t.nB - 1);
-			if (firstA.rid == lastB.rid && firstB.pos > lastA.pos && firstB.pos - lastA.pos > l_window) return;
-			if (firstA.rid == lastA.rid && firstB.rid == lastB.rid && firstA.rid != firstB.rid) return;
+			if (firstA.rid == lastA.rid && firstB.rid == lastB.rid) {
+				if (firstA.rid != firstB.rid) return;
+				if ((uint64_t)firstB.pos > (uint64_t)lastA.pos + l_window) return;      // columns wholly after the rows' reach
+				if ((uint64_t)firstA.pos > (uint64_t)lastB.pos + l_window) return;      // columns wholly before it
+			}
 		}
 		mine.push_back(t);
 	};

@@ -15,6 +15,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libtwk_hip.so")
 
 MODE_PHASED, MODE_UNPHASED, MODE_AUTO = 1, 2, 3
+# option bits of twk_hip_tile_desc.window / the `window` argument of ld_all / ld_region (TWK_HIP_OPT_*)
+OPT_WINDOW, OPT_KEEP_LOW_AC = 1, 2
 E_OVERFLOW = -4
 
 # twk_hip_record (include/twk_hip.h): 104 bytes
@@ -200,7 +202,7 @@ class HipLd:
     # ---- compute ----
     @staticmethod
     def _tile(a0, nA, b0, nB, diag, window=0, l_window=0) -> _Tile:
-        return _Tile(a0, nA, b0, nB, int(bool(diag)), int(bool(window)), l_window, 0)
+        return _Tile(a0, nA, b0, nB, int(bool(diag)), int(window), l_window, 0)
 
     def count_tile(self, mode: int, a0: int, nA: int, b0: int, nB: int, diag: bool = False) -> np.ndarray:
         ncell = 4 if mode == MODE_PHASED else 9
@@ -225,7 +227,8 @@ class HipLd:
 
     def ld_all(self, mode: int, filters: Filters, part: int = 0, n_parts: int = 1, tile_variants: int = 0,
                window: int = 0, l_window: int = 0, collect: bool = True):
-        """All-vs-all over shard `part` of `n_parts`. Returns (records, n_pairs, n_records)."""
+        """All-vs-all over shard `part` of `n_parts`. Returns (records, n_pairs, n_records).
+        `window` carries the TWK_HIP_OPT_* bits unchanged (OPT_WINDOW = 1, OPT_KEEP_LOW_AC = 2)."""
         chunks = []
 
         def sink(_user, recs, n):
@@ -238,7 +241,7 @@ class HipLd:
         npairs, nrec = C.c_uint64(0), C.c_uint64(0)
         f = filters._c()
         self._check(self._lib.twk_hip_ld_all(self._ctx, mode, C.byref(f), part, n_parts, tile_variants,
-                                             int(bool(window)), l_window, cb, None, C.byref(npairs), C.byref(nrec)),
+                                             int(window), l_window, cb, None, C.byref(npairs), C.byref(nrec)),
                     "twk_hip_ld_all")
         recs = np.concatenate(chunks) if chunks else np.zeros(0, dtype=RECORD_DTYPE)
         return recs, npairs.value, nrec.value
