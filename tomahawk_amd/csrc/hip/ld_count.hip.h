@@ -235,6 +235,157 @@ void k_count_tile_t(const uint32_t* __restrict__ rows, uint32_t W, uint32_t rowA
 		for (int u = 0; u < TB; ++u) Cblk[(size_t)(8 * t) * ldc + 8 * u] = acc[t][u];
 }
 
+// ---- persistent work-list form of the same contraction ------------------------------------
+// One launch = a list of 128 x 128 tiles of one super-tile (only the tiles that hold wanted pairs:
+// on/above the diagonal, inside the window band, ...) run by P persistent blocks, P = the number
+// of blocks the chip holds at once (2 per CU).  A plain 2-D grid of T tiles takes ceil(T / P)
+// rounds of equal-length blocks, so the partial last round is pure loss - up to 12 % of a
+// configs[1]-sized launch (3160 tiles = 6.17 rounds), 19 % of a thin window-mode row block.  Here
+//   * the first floor(T / P) * P tiles are done data-parallel, tile r*P + b by block b in round r
+//     (full K range, plain stores - exactly the 2-D grid's work, phases aligned across blocks);
+//   * the K iterations of the remaining T mod P tiles are cut into P equal contiguous ranges
+//     ("stream-K"): block b contracts chunks [c0, c1) of one or more of those tiles and adds its
+//     partial counts with atomics into tiles that a small kernel zeroed beforehand.
+// So every block runs the same number of K chunks to within one, whatever T is.  The software
+// pipeline (LDS-DMA of chunk i+1 behind the contraction of chunk i) runs across tile switches.
+struct CountWork {
+	const uint32_t* rows; uint32_t W;      // plane rows, row pitch in words (multiple of KC)
+	uint32_t rowA0, rowB0;                 // first plane row of the super-tile's row / column axis
+	const uint32_t* tiles;                 // [n_tiles]: (tile row << 16) | tile column, within the super-tile
+	uint32_t n_tiles;
+	uint32_t n_rounds;                     // data-parallel rounds: tiles [0, n_rounds * gridDim.x)
+	uint32_t* C; uint32_t ldc;             // counts of the super-tile
+};
+
+// The segments (tile, first chunk, end chunk) of block b, in order.
+struct SegIter {
+	uint32_t round, n_rounds, P, b, n_tiles, nchunks;
+	unsigned long long it, it_end;         // position in the stream-K iteration space of the tail tiles
+	__device__ __forceinline__ void init(const CountWork& w, uint32_t nch, uint32_t nblocks, uint32_t blk) {
+		round = 0; n_rounds = w.n_rounds; P = nblocks; b = blk; n_tiles = w.n_tiles; nchunks = nch;
+		const unsigned long long tail = (unsigned long long)(n_tiles - n_rounds * P) * nchunks;
+		it = tail * b / P; it_end = tail * (b + 1) / P;
+	}
+	// -> false when the block is out of work
+	__device__ __forceinline__ bool next(uint32_t& tile, uint32_t& c0, uint32_t& c1) {
+		if (round < n_rounds) { tile = round * P + b; c0 = 0; c1 = nchunks; ++round; return true; }
+		if (it >= it_end) return false;
+		const uint32_t t = (uint32_t)(it / nchunks);
+		c0 = (uint32_t)(it - (unsigned long long)t * nchunks);
+		const unsigned long long left = it_end - it;
+		c1 = (left < (unsigned long long)(nchunks - c0)) ? c0 + (uint32_t)left : nchunks;
+		tile = n_rounds * P + t;
+		it += c1 - c0;
+		return true;
+	}
+};
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64, NW / 2)
+void k_count_list_t(const CountWork w) {
+	constexpr int WC = NW / 2;
+	constexpr int TB = 16 / WC;
+	constexpr int NSEG = 32 / NW;
+	__shared__ __attribute__((aligned(16))) uint32_t lds[2 * 2 * TILE * KC];
+
+	const int tid  = threadIdx.x;
+	const int lane = tid & 63;
+	const int wave = tid >> 6;
+	const int wr = wave / WC, wc = wave % WC;
+	const int li = lane >> 3, lj = lane & 7;
+	const uint32_t nchunks = w.W / KC;
+
+	SegIter segs;
+	segs.init(w, nchunks, gridDim.x, blockIdx.x);
+	uint32_t tile, c, c_end;
+	if (!segs.next(tile, c, c_end)) return;
+
+	uint32_t acc[8][TB];
+#pragma unroll
+	for (int t = 0; t < 8; ++t)
+#pragma unroll
+		for (int u = 0; u < TB; ++u) acc[t][u] = 0;
+
+	uint32_t offA[8], offB[8];
+#pragma unroll
+	for (int k = 0; k < 8; ++k) {
+		offA[k] = (uint32_t)((wr * 64 + li) * (KC * 4) + (((li >> 1) ^ k) << 4));
+		offB[k] = (uint32_t)(LDS_TILE_BYTES + (wc * 8 * TB + lj) * (KC * 4) + (((lj >> 1) ^ k) << 4));
+	}
+	const char* lds_b = reinterpret_cast<const char*>(lds);
+
+	const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+	const bool st_isB = wave_u >= NW / 2;
+	const int st_seg0 = (wave_u % (NW / 2)) * NSEG;
+	const uint32_t lds_base = (uint32_t)(uintptr_t)(lptr_t*)lds;
+	const uint32_t st_lds = lds_base + (st_isB ? (uint32_t)LDS_TILE_BYTES : 0u);
+	// first plane row this wave stages for a tile: the A rows (first half of the waves) or the B rows
+	auto stage_row0 = [&](uint32_t tl) -> uint32_t {
+		const uint32_t yx = w.tiles[tl];
+		return st_isB ? w.rowB0 + (yx & 0xFFFFu) * TILE : w.rowA0 + (yx >> 16) * TILE;
+	};
+
+	stage_rows(w.rows, w.W, stage_row0(tile), c, st_lds, st_seg0, NSEG, lane);
+	const uint32_t c_first = c;
+	uint32_t seg_c0 = c_first;
+	int buf = 0;
+	for (;;) {
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__syncthreads();
+		// prefetch the chunk after this one: same tile, or the first chunk of the next segment
+		uint32_t n_tile = tile, n_c = c + 1, n_end = c_end;
+		bool more = true;
+		if (n_c == c_end) more = segs.next(n_tile, n_c, n_end);
+		if (more) stage_rows(w.rows, w.W, stage_row0(n_tile), n_c, st_lds + (buf ^ 1) * (2 * LDS_TILE_BYTES), st_seg0, NSEG, lane);
+
+		const char* base = lds_b + buf * (2 * LDS_TILE_BYTES);
+#pragma unroll
+		for (int q = 0; q < 8; ++q) {
+			uint4 a[8];
+#pragma unroll
+			for (int t = 0; t < 8; ++t)
+				a[t] = *reinterpret_cast<const uint4*>(base + offA[q ^ ((t & 1) << 2)] + t * 8 * (KC * 4));
+#pragma unroll
+			for (int u = 0; u < TB; ++u) {
+				const uint4 b = *reinterpret_cast<const uint4*>(base + offB[q ^ ((u & 1) << 2)] + u * 8 * (KC * 4));
+				contract_slot<TB>(acc, u, a, b);
+			}
+		}
+
+		if (c + 1 == c_end) {          // segment done: write (whole tile) or add (part of a tile's K range)
+			const uint32_t yx = w.tiles[tile];
+			uint32_t* Cblk = w.C + (size_t)((yx >> 16) * TILE + wr * 64 + li) * w.ldc + (yx & 0xFFFFu) * TILE + wc * 8 * TB + lj;
+			if (seg_c0 == 0 && c_end == nchunks) {
+#pragma unroll
+				for (int t = 0; t < 8; ++t)
+#pragma unroll
+					for (int u = 0; u < TB; ++u) { Cblk[(size_t)(8 * t) * w.ldc + 8 * u] = acc[t][u]; acc[t][u] = 0; }
+			} else {
+#pragma unroll
+				for (int t = 0; t < 8; ++t)
+#pragma unroll
+					for (int u = 0; u < TB; ++u) { atomicAdd(&Cblk[(size_t)(8 * t) * w.ldc + 8 * u], acc[t][u]); acc[t][u] = 0; }
+			}
+			if (!more) break;
+			seg_c0 = n_c;
+		}
+		tile = n_tile; c = n_c; c_end = n_end;
+		buf ^= 1;
+	}
+}
+
+// Zero the tiles [first, n_tiles) of the list (the ones whose K range is shared between blocks).
+__global__ __launch_bounds__(256)
+void k_zero_tiles(const uint32_t* __restrict__ tiles, uint32_t first, uint32_t* __restrict__ C, uint32_t ldc) {
+	const uint32_t yx = tiles[first + blockIdx.x];
+	uint32_t* Cblk = C + (size_t)((yx >> 16) * TILE) * ldc + (yx & 0xFFFFu) * TILE;
+	const uint4 z = make_uint4(0, 0, 0, 0);
+	for (int i = threadIdx.x; i < TILE * TILE / 4; i += 256) {
+		const int r = i / (TILE / 4), q = i % (TILE / 4);
+		*reinterpret_cast<uint4*>(Cblk + (size_t)r * ldc + q * 4) = z;
+	}
+}
+
 #ifndef TWK_COUNT_NW
 #define TWK_COUNT_NW 8
 #endif

@@ -60,7 +60,12 @@ struct Slot {                      // one in-flight tile (double buffered)
 	bool two_pass = false;
 	double minP = 1.0;
 	uint64_t row_pairs = 0, row_pairs_b = 0;
+	// work lists of the (up to two) count launches of the tile: pinned host copy + device copy
+	uint32_t* h_tiles[2] = {nullptr, nullptr}; uint32_t* d_tiles[2] = {nullptr, nullptr}; size_t tiles_cap[2] = {0, 0};
 };
+
+// Window mode: row variant a0 + r of a region reaches the columns [b0 + lo[r], b0 + hi[r]).
+struct ColRange { const uint32_t* lo = nullptr; const uint32_t* hi = nullptr; uint32_t a0 = 0, b0 = 0; };
 
 }  // namespace
 
@@ -111,6 +116,11 @@ void free_slots(twk_hip_ctx* c) {
 		if (s.C) (void)hipFree(s.C);
 		if (s.out) (void)hipFree(s.out);
 		s.C = nullptr; s.C_words = 0; s.out = nullptr; s.capacity = 0;
+		for (int k = 0; k < 2; ++k) {
+			if (s.h_tiles[k]) (void)hipHostFree(s.h_tiles[k]);
+			if (s.d_tiles[k]) (void)hipFree(s.d_tiles[k]);
+			s.h_tiles[k] = s.d_tiles[k] = nullptr; s.tiles_cap[k] = 0;
+		}
 	}
 }
 void free_problem(twk_hip_ctx* c) {
@@ -207,20 +217,90 @@ Geometry tile_geometry(int P, const twk_hip_tile_desc& t) {
 	return g;
 }
 
-// Launch the count kernel for one tile on the compute stream.
-int launch_count(twk_hip_ctx* c, int set, const twk_hip_tile_desc& t, Slot& s, hipEvent_t e0, hipEvent_t e1, uint64_t* row_pairs) {
+// The 128 x 128 tiles of a super-tile that hold wanted pairs, as (tile row << 16 | tile column):
+// on or above the diagonal (diag), and in window mode only those some row of the tile can reach.
+// Order: 8 x 8 patches of tiles, patch by patch; then, for the data-parallel rounds of the launch
+// (P blocks, block b on XCD b mod 8 in dispatch order), interleaved so that the 64 tiles one XCD
+// works on at a time are one patch (8 row tiles + 8 column tiles through its L2 per K step).
+void build_tile_list(const twk_hip_tile_desc& t, int P, const Geometry& g, bool diag, const ColRange* cr,
+                     uint32_t n_blocks, std::vector<uint32_t>& out) {
+	std::vector<uint32_t> x0(g.gy, 0), x1(g.gy, g.gx);
+	for (uint32_t by = 0; by < g.gy; ++by) {
+		if (diag) x0[by] = by;
+		if (cr && cr->lo) {
+			const uint32_t v0 = t.rowA0 + (by * TILE) / P;
+			const uint32_t v1 = std::min<uint64_t>((uint64_t)t.rowA0 + t.nA, (uint64_t)t.rowA0 + ((uint64_t)(by + 1) * TILE + P - 1) / P);   // exclusive
+			if (v0 >= v1) { x1[by] = x0[by]; continue; }
+			const uint64_t c_lo = (uint64_t)cr->b0 + cr->lo[v0 - cr->a0], c_hi = (uint64_t)cr->b0 + cr->hi[v1 - 1 - cr->a0];   // variants [c_lo, c_hi)
+			const uint64_t lo = std::max<uint64_t>(c_lo, t.rowB0), hi = std::min<uint64_t>(c_hi, (uint64_t)t.rowB0 + t.nB);
+			if (hi <= lo) { x1[by] = x0[by]; continue; }
+			x0[by] = std::max<uint32_t>(x0[by], (uint32_t)(((lo - t.rowB0) * P) / TILE));
+			x1[by] = std::min<uint32_t>(x1[by], (uint32_t)(((hi - t.rowB0) * P + TILE - 1) / TILE));
+			if (x1[by] < x0[by]) x1[by] = x0[by];
+		}
+	}
+	std::vector<uint32_t> seq;
+	seq.reserve((size_t)g.gx * g.gy);
+	for (uint32_t py = 0; py < g.gy; py += 8)
+		for (uint32_t px = 0; px < g.gx; px += 8)
+			for (uint32_t y = py; y < std::min(py + 8, g.gy); ++y)
+				for (uint32_t x = std::max(px, x0[y]); x < std::min(px + 8, x1[y]); ++x) seq.push_back(y << 16 | x);
+	const size_t T = seq.size(), rounds = n_blocks ? T / n_blocks : 0;
+	out.resize(T);
+	if (n_blocks % 8 == 0 && n_blocks >= 8) {
+		const size_t per = n_blocks / 8;                       // blocks (and tiles per round) of one XCD
+		for (size_t r = 0; r < rounds; ++r)
+			for (size_t k = 0; k < 8; ++k)
+				for (size_t j = 0; j < per; ++j) out[r * n_blocks + 8 * j + k] = seq[(r * 8 + k) * per + j];
+		for (size_t i = rounds * n_blocks; i < T; ++i) out[i] = seq[i];
+	} else {
+		out = seq;
+	}
+}
+
+// Launch the count kernel for one tile on the compute stream (which: first or second launch of the slot).
+int launch_count(twk_hip_ctx* c, int set, const twk_hip_tile_desc& t, Slot& s, int which, hipEvent_t e0, hipEvent_t e1,
+                 uint64_t* row_pairs, const ColRange* cr = nullptr) {
 	const PlaneSet& ps = c->planes[set];
 	const int P = planes_per_variant(set_kind(set));
 	const Geometry g = tile_geometry(P, t);
 	if ((uint64_t)t.rowA0 * P + g.rowsA > ps.rows_alloc || (uint64_t)t.rowB0 * P + g.rowsB > ps.rows_alloc) return TWK_HIP_E_INVALID;
-	const int diag = (t.diag && t.rowA0 == t.rowB0) ? 1 : 0;
+	if (g.gx > 0xFFFFu || g.gy > 0xFFFFu) return TWK_HIP_E_INVALID;
+	const bool diag = t.diag && t.rowA0 == t.rowB0;
+	const uint32_t n_blocks = c->resident_blocks;
+	std::vector<uint32_t> list;
+	build_tile_list(t, P, g, diag, cr, n_blocks, list);
+	const size_t T = list.size();
+	if (s.tiles_cap[which] < T) {
+		if (s.h_tiles[which]) (void)hipHostFree(s.h_tiles[which]);
+		if (s.d_tiles[which]) (void)hipFree(s.d_tiles[which]);
+		s.h_tiles[which] = s.d_tiles[which] = nullptr; s.tiles_cap[which] = 0;
+		const size_t cap = std::max<size_t>(T, 4096);
+		HIPCHK(c, hipHostMalloc((void**)&s.h_tiles[which], cap * 4, hipHostMallocDefault));
+		HIPCHK(c, hipMalloc((void**)&s.d_tiles[which], cap * 4));
+		s.tiles_cap[which] = cap;
+	}
+	if (T) {
+		std::memcpy(s.h_tiles[which], list.data(), T * 4);
+		HIPCHK(c, hipMemcpyAsync(s.d_tiles[which], s.h_tiles[which], T * 4, hipMemcpyHostToDevice, c->s_compute));
+	}
 	HIPCHK(c, hipEventRecord(e0, c->s_compute));
-	hipLaunchKernelGGL((k_count_tile_t<COUNT_NW>), dim3(g.gx, g.gy), dim3(COUNT_THREADS), 0, c->s_compute, ps.rows, ps.W,
-	                   t.rowA0 * P, t.rowB0 * P, diag, s.C, g.ldc);
-	HIPCHK(c, hipGetLastError());
+	if (T) {
+		CountWork w;
+		w.rows = ps.rows; w.W = ps.W; w.rowA0 = t.rowA0 * P; w.rowB0 = t.rowB0 * P;
+		w.tiles = s.d_tiles[which]; w.n_tiles = (uint32_t)T; w.n_rounds = (uint32_t)(T / n_blocks);
+		w.C = s.C; w.ldc = g.ldc;
+		const uint32_t first_tail = w.n_rounds * n_blocks;
+		if (first_tail < T) {
+			hipLaunchKernelGGL(k_zero_tiles, dim3((uint32_t)T - first_tail), dim3(256), 0, c->s_compute, w.tiles, first_tail, w.C, w.ldc);
+			HIPCHK(c, hipGetLastError());
+		}
+		hipLaunchKernelGGL((k_count_list_t<COUNT_NW>), dim3(std::min<uint32_t>(n_blocks, std::max<uint32_t>(1, (uint32_t)std::min<uint64_t>((uint64_t)T * (ps.W / KC), 0xFFFFFFFFull)))),
+		                   dim3(COUNT_THREADS), 0, c->s_compute, w);
+		HIPCHK(c, hipGetLastError());
+	}
 	HIPCHK(c, hipEventRecord(e1, c->s_compute));
-	const uint64_t tiles = diag ? (uint64_t)g.gy * (g.gy + 1) / 2 + (uint64_t)g.gy * (g.gx - g.gy) : (uint64_t)g.gx * g.gy;
-	*row_pairs = tiles * TILE * TILE;
+	*row_pairs = (uint64_t)T * TILE * TILE;
 	return TWK_HIP_OK;
 }
 
@@ -268,7 +348,7 @@ TilePlan plan_for(const twk_hip_ctx* c, int mode) {
 }
 
 int enqueue_tile(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, const twk_hip_filters& f, Slot& s,
-                 unsigned long long capacity) {
+                 unsigned long long capacity, const ColRange* cr = nullptr) {
 	const TilePlan pl = plan_for(c, mode);
 	const bool two_pass = pl.set2 >= 0;
 	const bool phased = pl.phased1;
@@ -280,14 +360,14 @@ int enqueue_tile(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, const twk
 	s.two_pass = two_pass;
 
 	HIPCHK(c, hipMemsetAsync(s.n_out, 0, sizeof(unsigned long long), c->s_compute));
-	rc = launch_count(c, kind1, t, s, s.ev_c0, s.ev_c1, &s.row_pairs); if (rc) return rc;
+	rc = launch_count(c, kind1, t, s, 0, s.ev_c0, s.ev_c1, &s.row_pairs, cr); if (rc) return rc;
 	{
 		const StatsParams p = make_stats(c, kind1, t, s, phased, pl.select1, f);
 		hipLaunchKernelGGL(k_ld_stats, dim3((t.nB + 255) / 256, t.nA), dim3(256), 0, c->s_compute, p);
 		HIPCHK(c, hipGetLastError());
 	}
 	if (two_pass) {
-		rc = launch_count(c, kind2, t, s, s.ev_c0b, s.ev_c1b, &s.row_pairs_b); if (rc) return rc;
+		rc = launch_count(c, kind2, t, s, 1, s.ev_c0b, s.ev_c1b, &s.row_pairs_b, cr); if (rc) return rc;
 		const StatsParams p = make_stats(c, kind2, t, s, false, 2, f);
 		hipLaunchKernelGGL(k_ld_stats, dim3((t.nB + 255) / 256, t.nA), dim3(256), 0, c->s_compute, p);
 		HIPCHK(c, hipGetLastError());
@@ -630,7 +710,7 @@ int twk_hip_count_tile(twk_hip_ctx* c, int mode, const twk_hip_tile_desc* t, uin
 	const Geometry g = tile_geometry(planes_per_variant(kind), *t);
 	rc = ensure_slot(c, s, (size_t)g.rowsA * g.rowsB, 1); if (rc) return rc;
 	uint64_t rp = 0;
-	rc = launch_count(c, kind, *t, s, s.ev_c0, s.ev_c1, &rp); if (rc) return rc;
+	rc = launch_count(c, kind, *t, s, 0, s.ev_c0, s.ev_c1, &rp); if (rc) return rc;
 	const int ncell = phased ? 4 : 9;
 	const size_t n = (size_t)t->nA * t->nB * ncell;
 	unsigned long long* d_cells = nullptr;
@@ -839,10 +919,12 @@ static int region_impl(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint3
 	int rc = TWK_HIP_OK;
 	size_t issued = 0, done = 0;
 	const size_t n = mine.size();
+	ColRange col_range;
+	if (windowed) { col_range.lo = lo.data(); col_range.hi = hi.data(); col_range.a0 = a0; col_range.b0 = b0; }
 	// two-deep software pipeline over the tiles of this shard
 	while (done < n) {
 		while (issued < n && issued < done + 2) {
-			rc = enqueue_tile(c, mode, mine[issued], *f, c->slot[issued & 1], cap_default);
+			rc = enqueue_tile(c, mode, mine[issued], *f, c->slot[issued & 1], cap_default, windowed ? &col_range : nullptr);
 			if (rc) return rc;
 			++issued;
 		}
