@@ -14,11 +14,19 @@ gathered to rank 0 over RCCL inside the timed region, and `value` is total pairs
 time: total work is fixed, so "scaling" is "strong".
 
 The JSON line also carries
-  roofline     the dominant kernel (k_count_tile), timed live with HIP events on the engine's own
-               stream: achieved = variant pairs of the launches x N/4 bytes per pair (one partner
-               bitvector) / kernel time, against the 8 TB/s HBM peak.  The kernel tiles
-               128 x 128 plane rows through LDS, so a streamed row is reused 128x and `frac` exceeds
-               1: the binding limit is VALU issue (v_and_b32 + v_bcnt_u32_b32), reported under "valu".
+  roofline     the dominant kernel (twk::k_count_list_t), timed live with HIP events on the engine's
+               own stream.  The kernel tiles 128 x 128 plane rows through LDS, so each streamed row is
+               reused 128x and HBM is not what binds it: the binding unit is the VALU (v_and_b32 +
+               v_bcnt_u32_b32 per 32-bit word pair, no MFMA as the north star requires).  bound="valu":
+               achieved = algorithmic lane-ops (2*ceil(2N/32) per pair phased,
+               8*ceil(N/32) unphased) x variant pairs of the launches / kernel time, against the
+               SIMD lane peak 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz = 78.6 T lane-ops/s.
+               `and_bcnt_ceiling_frac` prices the same work against what the two instructions can
+               issue at best (v_and_b32 2 cycles + v_bcnt_u32_b32 4 cycles per wave64: 2.62e13 word
+               pairs/s; microbenchmarks under profiles/).  `hbm_algorithmic` keeps SURVEY 8(d)'s
+               HBM-read accounting (N/4 bytes per pair against 8 TB/s; > 1 by construction because
+               of the LDS reuse).  `traffic` (HBM bytes per launch) needs rocprofv3 counter passes and
+               is not measured inside this run: null here, the per-round figure is in profiles/.
   cpu_baseline the compiled reference (oracle/_ref, SSE4.2) on this box's host cores, on the first
                M_s variants of the same synthetic input (rank 0, N=1 only).
 """
@@ -48,6 +56,7 @@ NAMES = {"cfg1": "configs[0]", "cfg2": "configs[1]", "cfg3": "configs[2]", "cfg5
 WINDOW_BP = {"cfg5": 500_000}
 MIN_P = {"cfg5": 1e-6}
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
+VALU_LANE_PEAK = 256 * 4 * 32 * 2.4e9         # SIMD-32 lane-ops/s (MI355X_MICROARCH.md: v_fma_f32 wave64 = 2 cycles)
 VALU_PAIR_PEAK = 256 * 4 * 64 / 6.0 * 2.4e9   # and(2 cyc)+bcnt(4 cyc) per wave64 word pair, 2.4 GHz
 
 
@@ -233,24 +242,18 @@ def main():
     if rank == 0:
         value = pairs_all / elapsed_max
         bytes_per_pair = n_samples / 4.0                    # one partner bitvector: 8*ceil(2N/64) = N/4 bytes
+        # algorithmic integer work per variant pair: one AND + one popcount per 32-bit word
+        lane_ops_per_pair = 2 * ((2 * n_samples + 31) // 32) if mode == "phased" else 8 * ((n_samples + 31) // 32)
         # dominant kernel on rank 0: its own launches, its own HIP-event time
         k_pairs = my_pairs
         k_ms = tm["count_ms"]
-        achieved = k_pairs * bytes_per_pair / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        k_s = k_ms * 1e-3
+        lane_ops_per_s = k_pairs * lane_ops_per_pair / k_s if k_ms > 0 else 0.0
+        hbm_alg = k_pairs * bytes_per_pair / k_s / 1e9 if k_ms > 0 else 0.0
         words = tm["words_per_row"]
-        word_pairs_per_s = tm["row_pairs"] * words / (k_ms * 1e-3) if k_ms > 0 else 0.0
-        # HBM bytes per launch: PMC-measured bytes per plane-row pair (profiles/r*_pmc_hbm_traffic.json,
-        # FETCH_SIZE x2-corrected per MI355X_MICROARCH.md + WRITE_SIZE) x the row pairs of a launch.
-        traffic, traffic_src = None, None
-        try:
-            pm = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_hbm_traffic.json"))
-            if pm and n_samples == 1_000_000 and mode == "unphased" and tm["count_launches"]:
-                k = json.load(open(os.path.join(ROOT, "profiles", pm[-1])))["k_count_tile"]
-                per_rp = k["hbm_read_bytes_per_row_pair"] + k["write_bytes_per_launch"] * k["launches"] / k["plane_row_pairs"]
-                traffic = per_rp * tm["row_pairs"] / tm["count_launches"]
-                traffic_src = f"profiles/{pm[-1]} (rocprofv3 --pmc, separate pass; scaled by plane-row pairs per launch)"
-        except Exception:
-            pass
+        # what the kernel actually contracted (whole 128 x 128 tiles: includes the lower half of diagonal
+        # tiles, row padding and, in window mode, the tile corners outside the window)
+        word_pairs_per_s = tm["row_pairs"] * words / k_s if k_ms > 0 else 0.0
         out = {
             "metric": "variant-pairs/sec all-vs-all LD, 1M samples; achieved HBM GB/s vs roofline",
             "value": value, "unit": "variant-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -262,19 +265,28 @@ def main():
                                     + (f", P<={filters.minP:g}" if filters.minP < 1 else "") + f"), {total_pairs} pairs/step"
                                     + (f"; EMULATED shard {args.emulate_shard} only" if args.emulate_shard else "")),
                        "n_samples": n_samples, "n_variants": n_variants, "mode": mode, "tile_variants": args.tile,
-                       "partition": f"equal-area row bands of the pair triangle over {world} GPU(s), RCCL gather of survivors",
+                       "partition": f"equal-area row bands of the pair triangle over {world} GPU(s), RCCL gather of survivors, "
+                                    "rank 0 writes the .two file",
                        "survivors_per_step": recs_all / args.steps},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "twk::k_count_tile", "launches": int(tm["count_launches"]),
+            "roofline": {"bound": "valu", "achieved": lane_ops_per_s / 1e12, "peak": VALU_LANE_PEAK / 1e12,
+                         "unit": "Tlane-op/s", "frac": lane_ops_per_s / VALU_LANE_PEAK,
+                         "and_bcnt_ceiling_frac": (lane_ops_per_s / 2) / VALU_PAIR_PEAK,
+                         "traffic": None,
+                         "traffic_note": "HBM bytes need rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE, separate runs); "
+                                         "see profiles/ for the round's figure",
+                         "kernel": "twk::k_count_list_t", "launches": int(tm["count_launches"]),
                          "avg_launch_ms": k_ms / max(tm["count_launches"], 1),
-                         "algorithmic_bytes_per_pair": bytes_per_pair,
-                         "note": "algorithmic bytes = one partner bitvector per pair (SURVEY 8(d)); rows are reused "
-                                 "128x from LDS so frac > 1; real limit is VALU issue, see valu"},
-            "valu": {"word_pairs_per_s": word_pairs_per_s, "peak_word_pairs_per_s": VALU_PAIR_PEAK,
-                     "frac": word_pairs_per_s / VALU_PAIR_PEAK, "words_per_row": int(words),
-                     "note": "32-bit AND+popcount word pairs; peak = 256 CU x 4 SIMD x 64 lanes / 6 cycles x 2.4 GHz "
-                             "(v_and_b32 2 cycles + v_bcnt_u32_b32 4 cycles per wave64)"},
+                         "algorithmic_lane_ops_per_pair": lane_ops_per_pair,
+                         "executed_word_pairs_per_s": word_pairs_per_s,
+                         "executed_frac_of_and_bcnt_ceiling": word_pairs_per_s / VALU_PAIR_PEAK,
+                         "words_per_row": int(words),
+                         "hbm_algorithmic": {"achieved": hbm_alg, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                             "frac": hbm_alg / HBM_PEAK_GBS, "bytes_per_pair": bytes_per_pair,
+                                             "note": "SURVEY 8(d): one partner bitvector per pair; rows are reused 128x "
+                                                     "from LDS, so this exceeds 1 and does not bound the kernel"},
+                         "note": "integer AND+popcount: bound by VALU issue. peak = 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz; "
+                                 "and+bcnt ceiling = 64 lanes / (2 + 4 cycles) per SIMD = 2.62e13 word pairs/s "
+                                 "(v_bcnt_u32_b32 is half rate: profiles/*microbench_valu_rate.txt)"},
             "kernel_ms": {"count": count_ms_max, "math": stats_ms_max, "wall": elapsed_max * 1e3},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -124,6 +124,43 @@ __device__ __forceinline__ void and_bcnt8(uint32_t& c0, uint32_t& c1, uint32_t& 
 	    : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7), "v"(b));
 }
 
+// Same, volatile (stays where it is written relative to the other volatile asm of the hand-scheduled
+// loop) and with two alternating temporaries instead of eight: the loop is at the 128-VGPR limit of
+// 4 waves/SIMD, and in-order issue makes the reuse safe (the bcnt that reads a temporary is issued
+// before the next v_and that overwrites it).
+__device__ __forceinline__ void and_bcnt8v(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t& c4,
+                                           uint32_t& c5, uint32_t& c6, uint32_t& c7, uint32_t a0, uint32_t a1,
+                                           uint32_t a2, uint32_t a3, uint32_t a4, uint32_t a5,
+                                           uint32_t a6, uint32_t a7, uint32_t b) {
+	uint32_t t0, t1;
+	asm volatile("v_and_b32 %8, %10, %18\n\t"
+	    "s_nop 0\n\t"
+	    "v_bcnt_u32_b32 %0, %8, %0\n\t"
+	    "v_and_b32 %9, %11, %18\n\t"
+	    "s_nop 0\n\t"
+	    "v_bcnt_u32_b32 %1, %9, %1\n\t"
+	    "v_and_b32 %8, %12, %18\n\t"
+	    "s_nop 0\n\t"
+	    "v_bcnt_u32_b32 %2, %8, %2\n\t"
+	    "v_and_b32 %9, %13, %18\n\t"
+	    "s_nop 0\n\t"
+	    "v_bcnt_u32_b32 %3, %9, %3\n\t"
+	    "v_and_b32 %8, %14, %18\n\t"
+	    "s_nop 0\n\t"
+	    "v_bcnt_u32_b32 %4, %8, %4\n\t"
+	    "v_and_b32 %9, %15, %18\n\t"
+	    "s_nop 0\n\t"
+	    "v_bcnt_u32_b32 %5, %9, %5\n\t"
+	    "v_and_b32 %8, %16, %18\n\t"
+	    "s_nop 0\n\t"
+	    "v_bcnt_u32_b32 %6, %8, %6\n\t"
+	    "v_and_b32 %9, %17, %18\n\t"
+	    "s_nop 0\n\t"
+	    "v_bcnt_u32_b32 %7, %9, %7"
+	    : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7), "=&v"(t0), "=&v"(t1)
+	    : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7), "v"(b));
+}
+
 // acc[t][u] += popc(a[t] & b) over the four words of a 16-byte slot, t = 0..7.
 template <int TB>
 __device__ __forceinline__ void contract_slot(uint32_t (&acc)[8][TB], int u, const uint4 (&a)[8], const uint4& b) {
@@ -235,58 +272,134 @@ void k_count_tile_t(const uint32_t* __restrict__ rows, uint32_t W, uint32_t rowA
 		for (int u = 0; u < TB; ++u) Cblk[(size_t)(8 * t) * ldc + 8 * u] = acc[t][u];
 }
 
+// LDS-DMA with a scalar base: HBM (sbase + 32-bit per-lane byte offset voff) -> LDS (lds_byte + 16 * lane).
+// The lane part of the address is the same for every segment of the same parity, so the list kernel
+// keeps two offset VGPRs for all its DMAs and does the rest of the address arithmetic on the scalar unit.
+__device__ __forceinline__ void glds16s(const void* sbase, uint32_t voff, uint32_t lds_byte) {
+	uint32_t keep;
+	asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+	             "global_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+	             : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte) : "memory");
+}
+// One chunk of one 128-row operand tile, this wave's `n` segments from `seg0` on.  voff_even / voff_odd:
+// (lr * W + src_slot * 4) * 4 for even / odd segments, lr = lane >> 3, src_slot = (lane & 7) ^ (lr >> 1)
+// [^ 4 for odd segments]: the source-side swizzle of stage_rows, (r >> 1) & 7 with r = seg * 8 + lr.
+__device__ __forceinline__ void stage_rows_s(const uint32_t* __restrict__ rows, size_t W, uint32_t row0, uint32_t chunk,
+                                             uint32_t lds_tile_byte, int seg0, int n, uint32_t voff_even, uint32_t voff_odd) {
+	const uint32_t* base = rows + (size_t)row0 * W + (size_t)chunk * KC;
+#pragma unroll
+	for (int i = 0; i < n; ++i) {
+		const int seg = seg0 + i;
+		glds16s(base + (size_t)(seg * 8) * W, (seg & 1) ? voff_odd : voff_even, lds_tile_byte + seg * 8 * KC * 4);
+	}
+}
+
+// One ds_read_b64 through asm (see k_count_list_t for why): 64 lanes x 8 B from LDS byte address
+// `addr` + OFF.
+template <int OFF>
+__device__ __forceinline__ uint2 lds_read8(uint32_t addr) {
+	uint2 v;
+	asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+	return v;
+}
+// The 8 + TB reads of one half-slot.  addrA0 / addrA1: LDS byte address of this lane's A row for even / odd
+// t (the slot swizzle differs by 4 between them, see the offA table); likewise addrB0 / addrB1; row t is
+// 8 * t rows = t * 1024 bytes further on; HALF selects the upper 8 bytes of the 16-byte slot.
+template <int TB, int T = 0>
+__device__ __forceinline__ void read_half_a(uint2 (&ra)[8], uint32_t addrA0, uint32_t addrA1, int half) {
+	if constexpr (T < 8) {
+		ra[T] = half ? lds_read8<T * 8 * (KC * 4) + 8>((T & 1) ? addrA1 : addrA0) : lds_read8<T * 8 * (KC * 4)>((T & 1) ? addrA1 : addrA0);
+		read_half_a<TB, T + 1>(ra, addrA0, addrA1, half);
+	}
+}
+template <int TB, int U = 0>
+__device__ __forceinline__ void read_half_b(uint2 (&rb)[TB], uint32_t addrB0, uint32_t addrB1, int half) {
+	if constexpr (U < TB) {
+		rb[U] = half ? lds_read8<U * 8 * (KC * 4) + 8>((U & 1) ? addrB1 : addrB0) : lds_read8<U * 8 * (KC * 4)>((U & 1) ? addrB1 : addrB0);
+		read_half_b<TB, U + 1>(rb, addrB0, addrB1, half);
+	}
+}
+template <int TB>
+__device__ __forceinline__ void read_half(uint2 (&ra)[8], uint2 (&rb)[TB], uint32_t addrA0, uint32_t addrA1,
+                                          uint32_t addrB0, uint32_t addrB1, int half) {
+	read_half_a<TB>(ra, addrA0, addrA1, half);
+	read_half_b<TB>(rb, addrB0, addrB1, half);
+}
+// acc[t][u] += popc(a[t] & b) over the two words of a half-slot, t = 0..7 (volatile: keeps its place
+// between the hand-placed LDS reads and waits).
+template <int TB>
+__device__ __forceinline__ void contract_half(uint32_t (&acc)[8][TB], int u, const uint2 (&a)[8], const uint2& b) {
+	and_bcnt8v(acc[0][u], acc[1][u], acc[2][u], acc[3][u], acc[4][u], acc[5][u], acc[6][u], acc[7][u],
+	           a[0].x, a[1].x, a[2].x, a[3].x, a[4].x, a[5].x, a[6].x, a[7].x, b.x);
+	and_bcnt8v(acc[0][u], acc[1][u], acc[2][u], acc[3][u], acc[4][u], acc[5][u], acc[6][u], acc[7][u],
+	           a[0].y, a[1].y, a[2].y, a[3].y, a[4].y, a[5].y, a[6].y, a[7].y, b.y);
+}
+
 // ---- persistent work-list form of the same contraction ------------------------------------
 // One launch = a list of 128 x 128 tiles of one super-tile (only the tiles that hold wanted pairs:
 // on/above the diagonal, inside the window band, ...) run by P persistent blocks, P = the number
-// of blocks the chip holds at once (2 per CU).  A plain 2-D grid of T tiles takes ceil(T / P)
-// rounds of equal-length blocks, so the partial last round is pure loss - up to 12 % of a
-// configs[1]-sized launch (3160 tiles = 6.17 rounds), 19 % of a thin window-mode row block.  Here
-//   * the first floor(T / P) * P tiles are done data-parallel, tile r*P + b by block b in round r
-//     (full K range, plain stores - exactly the 2-D grid's work, phases aligned across blocks);
-//   * the K iterations of the remaining T mod P tiles are cut into P equal contiguous ranges
-//     ("stream-K"): block b contracts chunks [c0, c1) of one or more of those tiles and adds its
-//     partial counts with atomics into tiles that a small kernel zeroed beforehand.
-// So every block runs the same number of K chunks to within one, whatever T is.  The software
-// pipeline (LDS-DMA of chunk i+1 behind the contraction of chunk i) runs across tile switches.
+// of blocks the chip holds at once (2 per CU), which pull *units* of work from an atomic ticket:
+//   * a unit is a K-range [c0, c1) of one tile; whole tiles (full K range) are stored plainly, parts
+//     of a tile are added with atomics into a tile that a small kernel zeroed beforehand;
+//   * the host (build_count_units) hands out whole tiles while more than ~2 rounds of work remain
+//     and ever shorter K-ranges after that, so the launch ends within a few short units of balance.
+// Why not a plain 2-D grid: T tiles take ceil(T / P) rounds and the partial last round is pure loss
+// (12 % of a configs[1]-sized launch, more for thin window-mode row blocks).  Why not a static equal
+// split (stream-K): the two blocks of a CU do NOT run at the same speed - the issue arbiter favours
+// the older waves, so the block that arrived first runs ~1.5x faster than its mate (measured: with
+// equal static shares half of the blocks finish at 55 % of the kernel time, and their mates then
+// run alone at 78 % of the CU's rate).  With tickets the fast block simply takes more units.
+// The software pipeline (LDS-DMA of chunk i+1 behind the contraction of chunk i) runs across units;
+// the next unit's ticket is drawn by thread 0 at the first chunk of a unit and handed to the other
+// waves through a two-slot LDS mailbox behind the next chunk barrier, so no extra synchronisation
+// is paid (units of a single chunk excepted).
+struct CountUnit { uint32_t tile, c0, c1, _pad; };     // chunks [c0, c1) of tiles[tile]
 struct CountWork {
 	const uint32_t* rows; uint32_t W;      // plane rows, row pitch in words (multiple of KC)
 	uint32_t rowA0, rowB0;                 // first plane row of the super-tile's row / column axis
 	const uint32_t* tiles;                 // [n_tiles]: (tile row << 16) | tile column, within the super-tile
-	uint32_t n_tiles;
-	uint32_t n_rounds;                     // data-parallel rounds: tiles [0, n_rounds * gridDim.x)
+	const CountUnit* units;                // [n_units], in the order they are handed out
+	uint32_t n_units;
 	uint32_t* C; uint32_t ldc;             // counts of the super-tile
+	uint32_t* ticket;                      // zeroed before the launch
 };
 
-// The segments (tile, first chunk, end chunk) of block b, in order.
-struct SegIter {
-	uint32_t round, n_rounds, P, b, n_tiles, nchunks;
-	unsigned long long it, it_end;         // position in the stream-K iteration space of the tail tiles
-	__device__ __forceinline__ void init(const CountWork& w, uint32_t nch, uint32_t nblocks, uint32_t blk) {
-		round = 0; n_rounds = w.n_rounds; P = nblocks; b = blk; n_tiles = w.n_tiles; nchunks = nch;
-		const unsigned long long tail = (unsigned long long)(n_tiles - n_rounds * P) * nchunks;
-		it = tail * b / P; it_end = tail * (b + 1) / P;
+// The unit table of a launch (host side; shared by the engine and the dev tools).  Guided self-scheduling:
+// a unit is never longer than 1/share_div of an even share of the work still to be handed out, so whole
+// tiles go out only while more than tail_rounds (= share_div) rounds of work remain, and after that
+// K-ranges that shrink with the remainder down to `min_chunks` chunks.  The launch then ends within a few
+// of the shortest units of perfect balance however unequal the blocks' speeds are (measured: finish
+// times of the 512 blocks within 0.14 ms of each other on a 21 ms launch).  Returns the index of the
+// first tile that is split (tiles from there on must be zeroed before the launch); n_tiles if none.
+template <class Vec>
+inline uint32_t build_count_units(uint32_t n_tiles, uint32_t nchunks, uint32_t n_blocks, uint32_t min_chunks, Vec& units,
+                                  uint32_t share_div = 8, uint32_t tail_rounds = 8) {
+	units.clear();
+	const uint32_t tail = (uint32_t)(n_tiles < (unsigned long long)tail_rounds * n_blocks ? n_tiles : (unsigned long long)tail_rounds * n_blocks);
+	uint32_t first_split = n_tiles - tail;
+	if (nchunks < 2 * min_chunks) first_split = n_tiles;             // rows too short to be worth splitting
+	for (uint32_t t = 0; t < first_split; ++t) units.push_back(CountUnit{t, 0, nchunks, 0});
+	for (uint32_t t = first_split; t < n_tiles; ++t) {
+		const unsigned long long rem = (unsigned long long)(n_tiles - t) * nchunks;      // chunks left, this tile included
+		unsigned long long target = rem / ((unsigned long long)share_div * n_blocks);
+		if (target < min_chunks) target = min_chunks;
+		uint32_t S = (uint32_t)((nchunks + target - 1) / target);
+		if (S < 1) S = 1;
+		if (S > nchunks) S = nchunks;
+		for (uint32_t k = 0; k < S; ++k)
+			units.push_back(CountUnit{t, (uint32_t)((unsigned long long)nchunks * k / S), (uint32_t)((unsigned long long)nchunks * (k + 1) / S), 0});
 	}
-	// -> false when the block is out of work
-	__device__ __forceinline__ bool next(uint32_t& tile, uint32_t& c0, uint32_t& c1) {
-		if (round < n_rounds) { tile = round * P + b; c0 = 0; c1 = nchunks; ++round; return true; }
-		if (it >= it_end) return false;
-		const uint32_t t = (uint32_t)(it / nchunks);
-		c0 = (uint32_t)(it - (unsigned long long)t * nchunks);
-		const unsigned long long left = it_end - it;
-		c1 = (left < (unsigned long long)(nchunks - c0)) ? c0 + (uint32_t)left : nchunks;
-		tile = n_rounds * P + t;
-		it += c1 - c0;
-		return true;
-	}
-};
+	return first_split;
+}
 
-template <int NW>
+template <int NW, int EXPERIMENT = 0>      // EXPERIMENT == 5: the dev tool's finish-time probe (overwrites C)
 __global__ __launch_bounds__(NW * 64, NW / 2)
 void k_count_list_t(const CountWork w) {
 	constexpr int WC = NW / 2;
 	constexpr int TB = 16 / WC;
 	constexpr int NSEG = 32 / NW;
 	__shared__ __attribute__((aligned(16))) uint32_t lds[2 * 2 * TILE * KC];
+	__shared__ uint32_t mbox[2];
 
 	const int tid  = threadIdx.x;
 	const int lane = tid & 63;
@@ -294,11 +407,27 @@ void k_count_list_t(const CountWork w) {
 	const int wr = wave / WC, wc = wave % WC;
 	const int li = lane >> 3, lj = lane & 7;
 	const uint32_t nchunks = w.W / KC;
+	const uint32_t n_units = w.n_units;
 
-	SegIter segs;
-	segs.init(w, nchunks, gridDim.x, blockIdx.x);
+	// unit id -> (tile, first chunk, end chunk); wave-uniform (scalar loads)
+	auto decode = [&](uint32_t u, uint32_t& tl, uint32_t& c0, uint32_t& c1) {
+		const CountUnit cu = w.units[u];
+		tl = __builtin_amdgcn_readfirstlane(cu.tile); c0 = __builtin_amdgcn_readfirstlane(cu.c0); c1 = __builtin_amdgcn_readfirstlane(cu.c1);
+	};
+
+	// the first ticket of the block
+	uint32_t fetched = 0;                       // thread 0: the ticket in flight (the next unit)
+	if (tid == 0) mbox[0] = atomicAdd(w.ticket, 1u);
+	__syncthreads();
+	uint32_t unit = __builtin_amdgcn_readfirstlane(mbox[0]);
+	if (unit >= n_units) return;
+	uint32_t unit_next = 0xFFFFFFFFu;
+	uint32_t n_started = 0;                     // units this block has started (mailbox slot parity)
+	bool unit_start = true;                     // this iteration is the first of its unit
+	bool want_next = false;                     // unit_next is to be picked up from the mailbox behind the next barrier
+
 	uint32_t tile, c, c_end;
-	if (!segs.next(tile, c, c_end)) return;
+	decode(unit, tile, c, c_end);
 
 	uint32_t acc[8][TB];
 #pragma unroll
@@ -312,7 +441,6 @@ void k_count_list_t(const CountWork w) {
 		offA[k] = (uint32_t)((wr * 64 + li) * (KC * 4) + (((li >> 1) ^ k) << 4));
 		offB[k] = (uint32_t)(LDS_TILE_BYTES + (wc * 8 * TB + lj) * (KC * 4) + (((lj >> 1) ^ k) << 4));
 	}
-	const char* lds_b = reinterpret_cast<const char*>(lds);
 
 	const int wave_u = __builtin_amdgcn_readfirstlane(wave);
 	const bool st_isB = wave_u >= NW / 2;
@@ -321,39 +449,74 @@ void k_count_list_t(const CountWork w) {
 	const uint32_t st_lds = lds_base + (st_isB ? (uint32_t)LDS_TILE_BYTES : 0u);
 	// first plane row this wave stages for a tile: the A rows (first half of the waves) or the B rows
 	auto stage_row0 = [&](uint32_t tl) -> uint32_t {
-		const uint32_t yx = w.tiles[tl];
+		const uint32_t yx = __builtin_amdgcn_readfirstlane(w.tiles[tl]);     // wave-uniform: lives in an SGPR
 		return st_isB ? w.rowB0 + (yx & 0xFFFFu) * TILE : w.rowA0 + (yx >> 16) * TILE;
 	};
 
-	stage_rows(w.rows, w.W, stage_row0(tile), c, st_lds, st_seg0, NSEG, lane);
-	const uint32_t c_first = c;
-	uint32_t seg_c0 = c_first;
+	const uint32_t lr = (uint32_t)lane >> 3, ls = (uint32_t)lane & 7u;
+	const uint32_t voff_even = (lr * w.W + ((ls ^ (lr >> 1)) << 2)) << 2;
+	const uint32_t voff_odd  = (lr * w.W + ((ls ^ (lr >> 1) ^ 4u) << 2)) << 2;
+	uint32_t st_row0 = stage_row0(tile);
+	stage_rows_s(w.rows, w.W, st_row0, c, st_lds, st_seg0, NSEG, voff_even, voff_odd);
+	uint32_t seg_c0 = c;
 	int buf = 0;
 	for (;;) {
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		// the ticket fetched one iteration ago has arrived with everything else: publish it
+		if (want_next && tid == 0) mbox[n_started & 1u] = fetched;
 		__syncthreads();
-		// prefetch the chunk after this one: same tile, or the first chunk of the next segment
+		if (want_next) { unit_next = __builtin_amdgcn_readfirstlane(mbox[n_started & 1u]); want_next = false; }
+		if (unit_start) {
+			// First chunk of a unit: thread 0 draws the ticket of the next unit.  It is needed when the
+			// last chunk of this unit is contracted (to stage the next unit's first chunk behind it); with
+			// two or more chunks it travels through the mailbox at the next barrier for free, a one-chunk
+			// unit has to wait for it here.  A block thus never holds more than its current and next unit,
+			// which keeps the slow block of a CU from sitting on big units drawn long ago.
+			++n_started;
+			if (tid == 0) fetched = atomicAdd(w.ticket, 1u);
+			if (c + 1 == c_end) {
+				if (tid == 0) mbox[n_started & 1u] = fetched;
+				__syncthreads();
+				unit_next = __builtin_amdgcn_readfirstlane(mbox[n_started & 1u]);
+			} else {
+				want_next = true;
+			}
+			unit_start = false;
+		}
+		// prefetch the chunk after this one: same unit, or the first chunk of the next unit
 		uint32_t n_tile = tile, n_c = c + 1, n_end = c_end;
 		bool more = true;
-		if (n_c == c_end) more = segs.next(n_tile, n_c, n_end);
-		if (more) stage_rows(w.rows, w.W, stage_row0(n_tile), n_c, st_lds + (buf ^ 1) * (2 * LDS_TILE_BYTES), st_seg0, NSEG, lane);
-
-		const char* base = lds_b + buf * (2 * LDS_TILE_BYTES);
+		if (n_c == c_end) {
+			more = unit_next < n_units;
+			if (more) { decode(unit_next, n_tile, n_c, n_end); st_row0 = stage_row0(n_tile); }
+		}
+		if (more) stage_rows_s(w.rows, w.W, st_row0, n_c, st_lds + (buf ^ 1) * (2 * LDS_TILE_BYTES), st_seg0, NSEG, voff_even, voff_odd);
+		// The chunk in 16 half-slots of 8 bytes per row.  The 12 LDS reads of half-slot h + 1 (8 A rows,
+		// TB B rows, ds_read_b64) are issued before the contraction of half-slot h, into the other
+		// register set, so the contraction never waits for LDS except at the first half-slot of a chunk.
+		// hipcc will not keep such a schedule by itself (it sinks the reads to their uses to save
+		// registers: -10 %), so reads, waits and contraction are volatile asm in program order and the
+		// outstanding-read count is tracked by hand (LDS returns in order: lgkmcnt(12) = "everything but
+		// the 12 reads just issued has arrived").
+		const uint32_t bufbase = lds_base + (uint32_t)buf * (2 * LDS_TILE_BYTES);
+		uint2 ra[2][8], rb[2][TB];
+		read_half<TB>(ra[0], rb[0], bufbase + offA[0], bufbase + offA[4], bufbase + offB[0], bufbase + offB[4], 0);
 #pragma unroll
-		for (int q = 0; q < 8; ++q) {
-			uint4 a[8];
-#pragma unroll
-			for (int t = 0; t < 8; ++t)
-				a[t] = *reinterpret_cast<const uint4*>(base + offA[q ^ ((t & 1) << 2)] + t * 8 * (KC * 4));
-#pragma unroll
-			for (int u = 0; u < TB; ++u) {
-				const uint4 b = *reinterpret_cast<const uint4*>(base + offB[q ^ ((u & 1) << 2)] + u * 8 * (KC * 4));
-				contract_slot<TB>(acc, u, a, b);
+		for (int h = 0; h < 16; ++h) {
+			if (h + 1 < 16) {
+				const int q = (h + 1) >> 1;
+				read_half<TB>(ra[(h + 1) & 1], rb[(h + 1) & 1], bufbase + offA[q], bufbase + offA[q ^ 4], bufbase + offB[q],
+				              bufbase + offB[q ^ 4], (h + 1) & 1);
+				asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+			} else {
+				asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 			}
+#pragma unroll
+			for (int u = 0; u < TB; ++u) contract_half<TB>(acc, u, ra[h & 1], rb[h & 1][u]);
 		}
 
-		if (c + 1 == c_end) {          // segment done: write (whole tile) or add (part of a tile's K range)
-			const uint32_t yx = w.tiles[tile];
+		if (c + 1 == c_end) {          // unit done: write (whole tile) or add (part of a tile's K range)
+			const uint32_t yx = __builtin_amdgcn_readfirstlane(w.tiles[tile]);
 			uint32_t* Cblk = w.C + (size_t)((yx >> 16) * TILE + wr * 64 + li) * w.ldc + (yx & 0xFFFFu) * TILE + wc * 8 * TB + lj;
 			if (seg_c0 == 0 && c_end == nchunks) {
 #pragma unroll
@@ -366,15 +529,24 @@ void k_count_list_t(const CountWork w) {
 #pragma unroll
 					for (int u = 0; u < TB; ++u) { atomicAdd(&Cblk[(size_t)(8 * t) * w.ldc + 8 * u], acc[t][u]); acc[t][u] = 0; }
 			}
-			if (!more) break;
-			seg_c0 = n_c;
+			if (!more) {
+				if (EXPERIMENT == 5 && tid == 0) {      // probe: when did this block finish, and on which XCD / CU?
+					uint32_t xcc, hwid;
+					asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+					asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+					unsigned long long* o = reinterpret_cast<unsigned long long*>(w.C) + 2 * (size_t)blockIdx.x;
+					o[0] = wall_clock64(); o[1] = ((unsigned long long)xcc << 32) | hwid;
+				}
+				break;
+			}
+			unit = unit_next; seg_c0 = n_c; unit_start = true;          // the next unit starts
 		}
 		tile = n_tile; c = n_c; c_end = n_end;
 		buf ^= 1;
 	}
 }
 
-// Zero the tiles [first, n_tiles) of the list (the ones whose K range is shared between blocks).
+// Zero the tiles [first, n_tiles) of the list (the ones whose K range is split into several units).
 __global__ __launch_bounds__(256)
 void k_zero_tiles(const uint32_t* __restrict__ tiles, uint32_t first, uint32_t* __restrict__ C, uint32_t ldc) {
 	const uint32_t yx = tiles[first + blockIdx.x];

@@ -88,6 +88,7 @@ struct twk_hip_ctx {
 	twk_hip_progress_cb progress_cb = nullptr; void* progress_user = nullptr;
 	bool progress_muted = false;       // second stage of a default-mode run: its pairs were already counted
 	uint32_t resident_blocks = 512;   // count-kernel blocks the chip holds at once (2 per CU)
+	uint32_t* tickets = nullptr;      // [6] work tickets of the count launches: one per (slot, launch)
 	char err[512] = {0};
 };
 
@@ -219,11 +220,10 @@ Geometry tile_geometry(int P, const twk_hip_tile_desc& t) {
 
 // The 128 x 128 tiles of a super-tile that hold wanted pairs, as (tile row << 16 | tile column):
 // on or above the diagonal (diag), and in window mode only those some row of the tile can reach.
-// Order: 8 x 8 patches of tiles, patch by patch; then, for the data-parallel rounds of the launch
-// (P blocks, block b on XCD b mod 8 in dispatch order), interleaved so that the 64 tiles one XCD
-// works on at a time are one patch (8 row tiles + 8 column tiles through its L2 per K step).
+// Order: 8 x 8 patches of tiles, patch by patch - the blocks pull consecutive tickets, so the ~P tiles in
+// flight at any time are a few neighbouring patches (shared row / column tiles meet in L2 and the MALL).
 void build_tile_list(const twk_hip_tile_desc& t, int P, const Geometry& g, bool diag, const ColRange* cr,
-                     uint32_t n_blocks, std::vector<uint32_t>& out) {
+                     std::vector<uint32_t>& out) {
 	std::vector<uint32_t> x0(g.gy, 0), x1(g.gy, g.gx);
 	for (uint32_t by = 0; by < g.gy; ++by) {
 		if (diag) x0[by] = by;
@@ -245,17 +245,7 @@ void build_tile_list(const twk_hip_tile_desc& t, int P, const Geometry& g, bool 
 		for (uint32_t px = 0; px < g.gx; px += 8)
 			for (uint32_t y = py; y < std::min(py + 8, g.gy); ++y)
 				for (uint32_t x = std::max(px, x0[y]); x < std::min(px + 8, x1[y]); ++x) seq.push_back(y << 16 | x);
-	const size_t T = seq.size(), rounds = n_blocks ? T / n_blocks : 0;
-	out.resize(T);
-	if (n_blocks % 8 == 0 && n_blocks >= 8) {
-		const size_t per = n_blocks / 8;                       // blocks (and tiles per round) of one XCD
-		for (size_t r = 0; r < rounds; ++r)
-			for (size_t k = 0; k < 8; ++k)
-				for (size_t j = 0; j < per; ++j) out[r * n_blocks + 8 * j + k] = seq[(r * 8 + k) * per + j];
-		for (size_t i = rounds * n_blocks; i < T; ++i) out[i] = seq[i];
-	} else {
-		out = seq;
-	}
+	out.swap(seq);
 }
 
 // Launch the count kernel for one tile on the compute stream (which: first or second launch of the slot).
@@ -269,34 +259,46 @@ int launch_count(twk_hip_ctx* c, int set, const twk_hip_tile_desc& t, Slot& s, i
 	const bool diag = t.diag && t.rowA0 == t.rowB0;
 	const uint32_t n_blocks = c->resident_blocks;
 	std::vector<uint32_t> list;
-	build_tile_list(t, P, g, diag, cr, n_blocks, list);
+	build_tile_list(t, P, g, diag, cr, list);
 	const size_t T = list.size();
-	if (s.tiles_cap[which] < T) {
+	// units of work: see build_count_units (ld_count.hip.h)
+	const uint32_t nchunks = ps.W / KC;
+	uint32_t min_chunks = 8;
+	if (const char* e = std::getenv("TWK_HIP_COUNT_MIN_CHUNKS")) {      // test hook: split short rows too
+		const unsigned long v = std::strtoul(e, nullptr, 10);
+		if (v) min_chunks = (uint32_t)v;
+	}
+	std::vector<CountUnit> units;
+	const uint32_t first_split = T ? build_count_units((uint32_t)T, nchunks, n_blocks, min_chunks, units) : 0;
+	const size_t T4 = (T + 3) / 4 * 4, words = T4 + units.size() * 4;       // [tiles | pad | units], units 16-byte aligned
+	if (s.tiles_cap[which] < words) {
 		if (s.h_tiles[which]) (void)hipHostFree(s.h_tiles[which]);
 		if (s.d_tiles[which]) (void)hipFree(s.d_tiles[which]);
 		s.h_tiles[which] = s.d_tiles[which] = nullptr; s.tiles_cap[which] = 0;
-		const size_t cap = std::max<size_t>(T, 4096);
+		const size_t cap = std::max<size_t>(words, 16384);
 		HIPCHK(c, hipHostMalloc((void**)&s.h_tiles[which], cap * 4, hipHostMallocDefault));
 		HIPCHK(c, hipMalloc((void**)&s.d_tiles[which], cap * 4));
 		s.tiles_cap[which] = cap;
 	}
 	if (T) {
 		std::memcpy(s.h_tiles[which], list.data(), T * 4);
-		HIPCHK(c, hipMemcpyAsync(s.d_tiles[which], s.h_tiles[which], T * 4, hipMemcpyHostToDevice, c->s_compute));
+		std::memcpy(s.h_tiles[which] + T4, units.data(), units.size() * sizeof(CountUnit));
+		HIPCHK(c, hipMemcpyAsync(s.d_tiles[which], s.h_tiles[which], words * 4, hipMemcpyHostToDevice, c->s_compute));
 	}
 	HIPCHK(c, hipEventRecord(e0, c->s_compute));
 	if (T) {
-		CountWork w;
+		CountWork w{};
 		w.rows = ps.rows; w.W = ps.W; w.rowA0 = t.rowA0 * P; w.rowB0 = t.rowB0 * P;
-		w.tiles = s.d_tiles[which]; w.n_tiles = (uint32_t)T; w.n_rounds = (uint32_t)(T / n_blocks);
+		w.tiles = s.d_tiles[which];
+		w.units = reinterpret_cast<const CountUnit*>(s.d_tiles[which] + T4); w.n_units = (uint32_t)units.size();
 		w.C = s.C; w.ldc = g.ldc;
-		const uint32_t first_tail = w.n_rounds * n_blocks;
-		if (first_tail < T) {
-			hipLaunchKernelGGL(k_zero_tiles, dim3((uint32_t)T - first_tail), dim3(256), 0, c->s_compute, w.tiles, first_tail, w.C, w.ldc);
+		w.ticket = c->tickets + ((&s - c->slot) * 2 + which);
+		HIPCHK(c, hipMemsetAsync(w.ticket, 0, 4, c->s_compute));
+		if (first_split < T) {
+			hipLaunchKernelGGL(k_zero_tiles, dim3((uint32_t)T - first_split), dim3(256), 0, c->s_compute, w.tiles, first_split, w.C, w.ldc);
 			HIPCHK(c, hipGetLastError());
 		}
-		hipLaunchKernelGGL((k_count_list_t<COUNT_NW>), dim3(std::min<uint32_t>(n_blocks, std::max<uint32_t>(1, (uint32_t)std::min<uint64_t>((uint64_t)T * (ps.W / KC), 0xFFFFFFFFull)))),
-		                   dim3(COUNT_THREADS), 0, c->s_compute, w);
+		hipLaunchKernelGGL((k_count_list_t<COUNT_NW>), dim3(std::min(n_blocks, w.n_units)), dim3(COUNT_THREADS), 0, c->s_compute, w);
 		HIPCHK(c, hipGetLastError());
 	}
 	HIPCHK(c, hipEventRecord(e1, c->s_compute));
@@ -526,6 +528,7 @@ int twk_hip_ctx_create(int device, twk_hip_ctx** out) {
 	}
 	if (hipStreamCreateWithFlags(&c->s_compute, hipStreamNonBlocking) != hipSuccess) return fail(TWK_HIP_E_DEVICE);
 	if (hipStreamCreateWithFlags(&c->s_copy, hipStreamNonBlocking) != hipSuccess) return fail(TWK_HIP_E_DEVICE);
+	if (hipMalloc((void**)&c->tickets, 6 * sizeof(uint32_t)) != hipSuccess) return fail(TWK_HIP_E_NOMEM);
 	for (auto& s : c->slot) {
 		hipEvent_t* evs[] = {&s.ev_c0, &s.ev_c1, &s.ev_s1, &s.ev_c0b, &s.ev_c1b};
 		for (auto* e : evs) if (hipEventCreate(e) != hipSuccess) return fail(TWK_HIP_E_DEVICE);
@@ -548,6 +551,7 @@ int twk_hip_ctx_destroy(twk_hip_ctx* c) {
 		if (s.h_n_out) (void)hipHostFree(s.h_n_out);
 	}
 	if (c->h_recs) (void)hipHostFree(c->h_recs);
+	if (c->tickets) (void)hipFree(c->tickets);
 	if (c->s_compute) (void)hipStreamDestroy(c->s_compute);
 	if (c->s_copy) (void)hipStreamDestroy(c->s_copy);
 	delete c;

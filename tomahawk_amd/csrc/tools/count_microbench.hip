@@ -10,18 +10,13 @@
 #include "../hip/ld_count.hip.h"
 #define CK(x) do{hipError_t e=(x); if(e!=hipSuccess){fprintf(stderr,"HIP %s @%d: %s\n",#x,__LINE__,hipGetErrorString(e)); exit(1);} }while(0)
 
-static std::vector<uint32_t> make_list(uint32_t g, int diag, uint32_t P, bool patch) {
+static std::vector<uint32_t> make_list(uint32_t g, int diag, bool patch) {
 	std::vector<uint32_t> seq;
 	if (!patch) { for (uint32_t y = 0; y < g; ++y) for (uint32_t x = diag ? y : 0; x < g; ++x) seq.push_back(y << 16 | x); return seq; }
 	for (uint32_t py = 0; py < g; py += 8) for (uint32_t px = 0; px < g; px += 8)
 		for (uint32_t y = py; y < std::min(py + 8, g); ++y) for (uint32_t x = std::max(px, diag ? y : 0u); x < std::min(px + 8, g); ++x) seq.push_back(y << 16 | x);
-	std::vector<uint32_t> out(seq.size());
-	const size_t T = seq.size(), rounds = T / P, per = P / 8;
-	for (size_t r = 0; r < rounds; ++r) for (size_t k = 0; k < 8; ++k) for (size_t j = 0; j < per; ++j) out[r * P + 8 * j + k] = seq[(r * 8 + k) * per + j];
-	for (size_t i = rounds * P; i < T; ++i) out[i] = seq[i];
-	return out;
+	return seq;
 }
-
 int main(int argc,char**argv){
   uint32_t R = argc>1? atoi(argv[1]) : 4096;     // rows (multiple of 128)
   uint32_t W = argc>2? atoi(argv[2]) : 3136;     // words per row (multiple of 32)
@@ -29,7 +24,8 @@ int main(int argc,char**argv){
   uint32_t P = argc>4? atoi(argv[4]) : 512;      // persistent blocks
   size_t nw=(size_t)R*W;
   std::vector<uint32_t> h(nw); std::mt19937 rng(1); for(auto&x:h) x=rng();
-  uint32_t *d,*C,*dl; CK(hipMalloc(&d,nw*4)); CK(hipMalloc(&C,(size_t)R*R*4)); CK(hipMalloc(&dl,(size_t)(R/128)*(R/128)*4));
+  uint32_t *d,*C,*dl; twk::CountUnit* du; CK(hipMalloc(&d,nw*4)); CK(hipMalloc(&C,(size_t)R*R*4)); CK(hipMalloc(&dl,(size_t)(R/128)*(R/128)*4)); CK(hipMalloc(&du,(size_t)(R/128)*(R/128)*64*16+65536));
+  const uint32_t min_chunks = getenv("MINCHUNKS")? atoi(getenv("MINCHUNKS")) : 8; uint32_t first_split=0; std::vector<twk::CountUnit> units;
   CK(hipMemcpy(d,h.data(),nw*4,hipMemcpyHostToDevice)); CK(hipMemset(C,0xff,(size_t)R*R*4));
   dim3 grid(R/128,R/128), block(twk::COUNT_THREADS);
   hipEvent_t e0,e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -40,26 +36,50 @@ int main(int argc,char**argv){
     for(int s=0;s<2000;++s){ uint32_t i=r2()%R,j=r2()%R; if(diag && j/128<i/128) continue; uint32_t ref=0; for(uint32_t k=0;k<W;++k) ref+=__builtin_popcount(h[(size_t)i*W+k]&h[(size_t)j*W+k]); if(ref!=hc[(size_t)i*R+j]){ if(bad<5) printf("MISMATCH %s (%u,%u) ref %u got %u\n",what,i,j,ref,hc[(size_t)i*R+j]); ++bad; } }
     printf("check %s: %d mismatches\n",what,bad); bad_total+=bad;
   };
+  if(const char* gy=getenv("GRIDY")){   // probe: the 2-D grid kernel over gy tile rows only (e.g. 16 x 32 = 512 tiles = one round)
+    const uint32_t ny=atoi(gy); dim3 g2(R/128,ny);
+    hipLaunchKernelGGL((twk::k_count_tile_t<twk::COUNT_NW>),g2,block,0,0,d,W,0u,0u,0,C,R); CK(hipDeviceSynchronize());
+    float best=1e30f;
+    for(int i=0;i<reps;++i){ CK(hipEventRecord(e0)); hipLaunchKernelGGL((twk::k_count_tile_t<twk::COUNT_NW>),g2,block,0,0,d,W,0u,0u,0,C,R); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms,e0,e1)); if(ms<best)best=ms; }
+    const double tiles=(double)(R/128)*ny, wordops=tiles*128*128*W;
+    printf("grid %ux%u tiles=%.0f best %.3f ms  word-pairs/s %.3e (%.1f%% of the and+bcnt ceiling)\n",R/128,ny,tiles,best,wordops/best*1e3,wordops/best*1e3/2.6214e13*100);
+    return 0;
+  }
+  uint32_t* tick; CK(hipMalloc(&tick,4));
+  if(getenv("FINISH")){   // probe: per-block finish times of the static list kernel (2 full rounds), by XCD
+    std::vector<uint32_t> list=make_list(R/128,0,true); CK(hipMemcpy(dl,list.data(),list.size()*4,hipMemcpyHostToDevice));
+    twk::CountWork w{}; w.rows=d; w.W=W; w.tiles=dl; w.C=C; w.ldc=R; w.ticket=tick; first_split=twk::build_count_units((uint32_t)list.size(),W/twk::KC,P,min_chunks,units,getenv("SHAREDIV")?atoi(getenv("SHAREDIV")):8,getenv("TAILROUNDS")?atoi(getenv("TAILROUNDS")):8); CK(hipMemcpy(du,units.data(),units.size()*16,hipMemcpyHostToDevice)); w.units=du; w.n_units=(uint32_t)units.size();
+    for(int rep=0;rep<2;++rep){ CK(hipMemset(tick,0,4)); if(first_split<list.size()) hipLaunchKernelGGL(twk::k_zero_tiles,dim3((uint32_t)list.size()-first_split),dim3(256),0,0,w.tiles,first_split,C,R); hipLaunchKernelGGL((twk::k_count_list_t<twk::COUNT_NW,5>),dim3(P),block,0,0,w); CK(hipDeviceSynchronize()); }
+    std::vector<unsigned long long> o(2*P); CK(hipMemcpy(o.data(),C,o.size()*8,hipMemcpyDeviceToHost));
+    unsigned long long t0=~0ull,t1=0; for(uint32_t b=0;b<P;++b){ t0=std::min(t0,o[2*b]); t1=std::max(t1,o[2*b]); }
+    printf("finish-time spread over %u blocks: %.1f us (wall_clock64 ticks at 100 MHz)\n",P,(t1-t0)/100.0);
+    for(int x=0;x<8;++x){ double mn=1e30,mx=0,sum=0; int n=0; for(uint32_t b=0;b<P;++b) if((int)(o[2*b+1]>>32&15)==x){ double t=(o[2*b]-t0)/100.0; mn=std::min(mn,t); mx=std::max(mx,t); sum+=t; ++n; }
+      printf("  XCD %d: %3d blocks, finish offset min %.1f mean %.1f max %.1f us\n",x,n,mn,n?sum/n:0,mx); }
+    // same-CU pairs
+    printf("  first 16 blocks: "); for(uint32_t b=0;b<16;++b) printf("[b%u xcc%llu hw%05llx t%.0f] ",b,o[2*b+1]>>32&15,o[2*b+1]&0xFFFFF,(o[2*b]-t0)/100.0); printf("\n");
+    return 0;
+  }
   for(int diag=0; diag<2; ++diag){
     double tiles = diag? (double)(R/128)*(R/128+1)/2 : (double)(R/128)*(R/128);
     double wordops = tiles*128*128*W;
-    for(int mode=0; mode<3; ++mode){     // 0 grid, 1 list row-major, 2 list patch order
+    for(int mode=0; mode<3; ++mode){     // 0 grid, 1 list row-major, 2 list patch order, 3.. timing probes
       std::vector<uint32_t> list; twk::CountWork w{};
-      if(mode){ list=make_list(R/128,diag,P,mode==2); CK(hipMemcpy(dl,list.data(),list.size()*4,hipMemcpyHostToDevice));
-        w.rows=d; w.W=W; w.rowA0=0; w.rowB0=0; w.tiles=dl; w.n_tiles=(uint32_t)list.size(); w.n_rounds=(uint32_t)(list.size()/P); w.C=C; w.ldc=R; }
+      if(mode){ list=make_list(R/128,diag,mode>=2); CK(hipMemcpy(dl,list.data(),list.size()*4,hipMemcpyHostToDevice));
+        w.rows=d; w.W=W; w.rowA0=0; w.rowB0=0; w.tiles=dl; w.C=C; w.ldc=R; w.ticket=tick; first_split=twk::build_count_units((uint32_t)list.size(),W/twk::KC,P,min_chunks,units,getenv("SHAREDIV")?atoi(getenv("SHAREDIV")):8,getenv("TAILROUNDS")?atoi(getenv("TAILROUNDS")):8); CK(hipMemcpy(du,units.data(),units.size()*16,hipMemcpyHostToDevice)); w.units=du; w.n_units=(uint32_t)units.size(); }
       auto launch=[&](){
         if(!mode){ hipLaunchKernelGGL((twk::k_count_tile_t<twk::COUNT_NW>),grid,block,0,0,d,W,0u,0u,diag,C,R); return; }
-        const uint32_t first=w.n_rounds*P;
-        if(first<w.n_tiles) hipLaunchKernelGGL(twk::k_zero_tiles,dim3(w.n_tiles-first),dim3(256),0,0,w.tiles,first,C,R);
+        CK(hipMemsetAsync(tick,0,4,0));
+        if(first_split<list.size()) hipLaunchKernelGGL(twk::k_zero_tiles,dim3((uint32_t)list.size()-first_split),dim3(256),0,0,w.tiles,first_split,C,R);
         hipLaunchKernelGGL((twk::k_count_list_t<twk::COUNT_NW>),dim3(P),block,0,0,w);
       };
+      static const char* names[]={"grid","list","list/patch"};
       CK(hipMemset(C,0xff,(size_t)R*R*4));
       launch(); CK(hipDeviceSynchronize());
-      check(mode==0?"grid":mode==1?"list":"list/patch",diag);
+      check(names[mode],diag);
       float best=1e30f;
       for(int i=0;i<reps;++i){ CK(hipEventRecord(e0)); launch(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms,e0,e1)); if(ms<best)best=ms; }
-      printf("%-10s diag=%d R=%u W=%u P=%u tiles=%.0f best %.3f ms  word-pairs/s %.3e  VALU lane-ops/s %.3e (%.1f%% of 7.86e13; %.1f%% of the and+bcnt ceiling 2.62e13)\n",
-             mode==0?"grid":mode==1?"list":"list/patch",diag,R,W,P,tiles,best,wordops/best*1e3,2*wordops/best*1e3,2*wordops/best*1e3/7.864e13*100,wordops/best*1e3/2.6214e13*100);
+      printf("%-10s diag=%d R=%u W=%u P=%u tiles=%.0f whole=%u units=%u best %.3f ms  word-pairs/s %.3e  VALU lane-ops/s %.3e (%.1f%% of 7.86e13; %.1f%% of the and+bcnt ceiling 2.62e13)\n",
+             names[mode],diag,R,W,P,tiles,mode?first_split:0u,mode?w.n_units:0u,best,wordops/best*1e3,2*wordops/best*1e3,2*wordops/best*1e3/7.864e13*100,wordops/best*1e3/2.6214e13*100);
     }
   }
   return bad_total!=0;
