@@ -9,9 +9,10 @@ Workload (config.workload): BASELINE.json configs[2] -- 1,000,000 diploid sample
 variants, all-vs-all *unphased* genotype LD (`calc -u`, default filters r2 >= 0.1), synthetic iid
 genotypes generated directly in HBM (bit-identical host twin feeds the CPU baseline).
 A step is one pass over the whole upper triangle: 1,249,975,000 variant pairs.  With N GPUs the
-triangle is cut into equal-area row bands, one per rank (no data-path collective), survivors are
-gathered to rank 0 over RCCL inside the timed region, and `value` is total pairs / max-over-ranks
-time: total work is fixed, so "scaling" is "strong".
+triangle is cut into equal-area row bands, one per rank (no data-path collective); inside the timed
+region the survivors are gathered to rank 0 over RCCL (counts all-gather + grouped send/recv of exact
+sizes) and rank 0 packs them into a real .two file; `value` is total pairs / max-over-ranks time:
+total work is fixed, so "scaling" is "strong".
 
 The JSON line also carries
   roofline     the dominant kernel (twk::k_count_list_t), timed live with HIP events on the engine's
@@ -202,31 +203,57 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def step():
-        """One pass of the hot path over this rank's shard + the gather of survivors to rank 0."""
+    # Rank 0 is the writer rank: it packs the survivors of all ranks into a real .two file (forward + reverse
+    # blocks, the reference's flush rule, index) inside the timed region.  The files are created - header
+    # only - before the clock starts, one per step.
+    from tomahawk_amd import hostlib
+    out_dir = tempfile.mkdtemp(prefix="twk_bench_") if rank == 0 else None
+    all_pos = 1000 + 100 * np.arange(n_variants, dtype=np.uint32)
+    all_rid = np.zeros(n_variants, dtype=np.uint32)
+
+    def open_stream(i):
+        if rank != 0:
+            return None
+        return hostlib.TwoStream(os.path.join(out_dir, f"step{i}.two"), n_samples, all_rid, all_pos,
+                                 n_threads=min(os.cpu_count() or 1, 32))
+
+    written = {"records": 0}
+
+    def step(stream):
+        """One pass of the hot path over this rank's shard + the gather of survivors to rank 0 + the .two blocks."""
         if slab:
             r0, r1, col_end = slab
             recs, npairs, nrec = eng.ld_region(hip_mode, filters, 0, r1 - r0, 0, col_end - r0, True,
                                                tile_variants=args.tile, window=1, l_window=window_bp)
             assert npairs == my_expected, (npairs, my_expected)
+            if len(recs):                                # slab-local variant indices -> global
+                recs["idxA"] += r0; recs["idxB"] += r0
         else:
             recs, npairs, nrec = eng.ld_all(hip_mode, filters, part=shard_rank, n_parts=shard_world, tile_variants=args.tile)
         if world > 1:
-            gather_records(recs, dst=0, device=dev)      # RCCL: all_gather(counts) + gather(payload)
+            recs = gather_records(recs, dst=0, device=dev)      # RCCL: all_gather(counts) + grouped send/recv of exact sizes
+        if rank == 0:
+            stream.append(recs)
+            written["records"] += stream.close()
         return npairs, nrec
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        step(open_stream(f"w{i}"))
+    streams = [open_stream(i) for i in range(args.steps)]
+    written["records"] = 0
     barrier()
     eng.timing_reset()
     t0 = time.perf_counter()
     my_pairs = my_recs = 0
-    for _ in range(args.steps):
-        p, r = step()
+    for i in range(args.steps):
+        p, r = step(streams[i])
         my_pairs += p
         my_recs += r
     barrier()
     elapsed = time.perf_counter() - t0
+    if rank == 0:
+        import shutil
+        shutil.rmtree(out_dir, ignore_errors=True)
     tm = eng.timing()
 
     stats = torch.tensor([elapsed, tm["count_ms"], tm["stats_ms"]], dtype=torch.float64, device=dev)
@@ -267,7 +294,8 @@ def main():
                        "n_samples": n_samples, "n_variants": n_variants, "mode": mode, "tile_variants": args.tile,
                        "partition": f"equal-area row bands of the pair triangle over {world} GPU(s), RCCL gather of survivors, "
                                     "rank 0 writes the .two file",
-                       "survivors_per_step": recs_all / args.steps},
+                       "survivors_per_step": recs_all / args.steps,
+                       "two_records_written_per_step": written["records"] / args.steps},
             "roofline": {"bound": "valu", "achieved": lane_ops_per_s / 1e12, "peak": VALU_LANE_PEAK / 1e12,
                          "unit": "Tlane-op/s", "frac": lane_ops_per_s / VALU_LANE_PEAK,
                          "and_bcnt_ceiling_frac": (lane_ops_per_s / 2) / VALU_PAIR_PEAK,

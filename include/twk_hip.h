@@ -107,6 +107,12 @@ const char* twk_hip_last_error(const twk_hip_ctx* ctx);
 int twk_hip_ctx_create(int device, twk_hip_ctx** out);
 int twk_hip_ctx_destroy(twk_hip_ctx* ctx);
 
+/* Page-locked host memory for upload staging (hipHostMalloc / hipHostFree): uploads from it run at
+ * full PCIe rate and without a bounce copy.  No reference counterpart (the reference never leaves
+ * host memory). */
+int twk_hip_host_alloc(size_t bytes, void** out);
+int twk_hip_host_free(void* p);
+
 /* ---- input ------------------------------------------------------------ */
 /* Declare the problem: n_samples diploid samples, n_variants variants.
  * Replaces twk_ld_engine::SetSamples (ld_engine.cpp:55-71) + the ldd block
@@ -123,6 +129,33 @@ int twk_hip_set_problem(twk_hip_ctx* ctx, uint32_t n_samples, uint32_t n_variant
 int twk_hip_upload_bitvectors(twk_hip_ctx* ctx, uint32_t first, uint32_t count,
                               const uint64_t* data, const uint64_t* mask, size_t stride64,
                               const twk_hip_variant_meta* meta);
+
+/* The same upload with the expansion done on the device: `bytes` holds the run-length genotype words of
+ * `count` variants exactly as they are stored in a .twk block (twk1_t::gt, include/core.h:195-205:
+ * 1, 2 or 4 bytes per run, little endian, run = length << (2+2m) | A << (1+m) | B with m = 1 and two bits
+ * per allele when the variant has missing genotypes), desc[i] says where variant first+i's runs start.
+ * A HIP kernel does what twk_igt_vec::Build does on the reference's unpack threads
+ * (lib/core.cpp:349-391, lib/ld/ld_unpacker.h:44-123): bitvector + mask, padding bits zero - so the
+ * PCIe link carries the compressed genotypes, not N/4 bytes per variant.  `bytes` may be pageable or
+ * pinned host memory and is free for reuse when the call returns.  Runs that do not add up to the
+ * problem's sample count fail with TWK_HIP_E_INVALID (found on the device: the rows of this call are
+ * then undefined). */
+typedef struct {
+	uint64_t offset;   /* byte offset of the variant's first run word in `bytes` */
+	uint32_t n_runs;
+	uint8_t  width;    /* bytes per run word: 1, 2 or 4 (twk1_t.gt_ptype)        */
+	uint8_t  missing;  /* twk1_t.gt_missing: two bits per allele in the run word */
+	uint16_t _pad;
+} twk_hip_rle_desc;
+int twk_hip_upload_rle(twk_hip_ctx* ctx, uint32_t first, uint32_t count, const void* bytes, size_t n_bytes,
+                       const twk_hip_rle_desc* desc, const twk_hip_variant_meta* meta);
+
+/* Read variants [first, first+count) back in the reference layout (twk_igt_vec::data / ::mask,
+ * include/core.h:724-753): the inverse of twk_hip_upload_bitvectors, whatever way the rows were put
+ * there (bitvectors, run-length words, the synthetic generator).  mask may be NULL; variants without
+ * missing genotypes get an all-zero mask.  Parity tests of the device-side T1 use it. */
+int twk_hip_download_bitvectors(twk_hip_ctx* ctx, uint32_t first, uint32_t count,
+                                uint64_t* data, uint64_t* mask, size_t stride64);
 
 /* Fill the whole problem with the synthetic benchmark input of SURVEY 8(d)
  * directly in HBM (iid alleles, per-variant ALT frequency U(0.05,0.5), one

@@ -1,5 +1,5 @@
-import sys, time
-sys.path.insert(0, '.')
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import tomahawk_amd as T
 hip = T.HipLd(0)
 hip.set_problem(1_000_000, 50_000)

@@ -216,3 +216,93 @@ def test_inconsistent_missing_flags_are_rejected_without_side_effects(hip):
     after, _, _ = hip.ld_all(T.MODE_AUTO, T.Filters(minR2=0.0))
     order = ["idxA", "idxB"]                    # survivors are compacted in no particular order
     assert np.sort(before, order=order).tobytes() == np.sort(after, order=order).tobytes()
+
+
+# ---- T1 on the device: run-length genotypes -> bitvector + mask -------------------------------------------------
+def _rle_encode(al, width, missing):
+    """Run words of one variant (al int8 [N, 2] in {0,1,2}) the way a .twk stores them: length << (2+2m) | A << (1+m) | B,
+    `width` bytes each, runs split at the longest length the word can hold (lib/genotype_encoder.h:277-343)."""
+    m = 1 if missing else 0
+    limit = (1 << (8 * width - 2 - 2 * m)) - 1
+    code = (al[:, 0].astype(np.int64) << (m + 1)) | al[:, 1].astype(np.int64)
+    starts = np.concatenate(([0], np.nonzero(np.diff(code))[0] + 1, [len(code)]))
+    words, lens, As, Bs = [], [], [], []
+    for s0, s1 in zip(starts[:-1], starts[1:]):
+        left = int(s1 - s0)
+        while left:
+            ln = min(left, limit)
+            words.append(ln << (2 + 2 * m) | int(code[s0]))
+            lens.append(ln); As.append(int(al[s0, 0])); Bs.append(int(al[s0, 1]))
+            left -= ln
+    raw = np.array(words, dtype={1: "<u1", 2: "<u2", 4: "<u4"}[width]).view(np.uint8)
+    return raw, np.array(lens, np.uint32), np.array(As, np.uint8), np.array(Bs, np.uint8)
+
+
+@pytest.mark.parametrize("N", [1, 15, 16, 17, 127, 128, 129, 1000, 4099, 200_003])
+def test_rle_inflate_kernel_equals_the_oracle(hip, N):
+    """twk_hip_upload_rle (HIP kernel) against orc_build_bitvector (twk_igt_vec::Build, core.cpp:349-391), bit for
+    bit, data and mask: every run-word width, with and without missing genotypes, all-ref / all-alt / alternating
+    variants, long runs that are split at the word's length limit, sample counts around the word boundaries."""
+    rng = np.random.default_rng(N)
+    M = 24
+    al = util.random_alleles(M, N, 500 + N, maf_lo=0.01, maf_hi=0.6, miss_rate=0.1, miss_variants=0.4)
+    al[0] = 0; al[1] = 1                                  # one run each (split at the limit of narrow words)
+    al[2, :, 0] = 0; al[2, :, 1] = 1                        # all het
+    al[3] = (np.arange(N)[:, None] % 2).astype(np.int8)     # alternates every sample: N runs
+    if N > 3:
+        al[4] = 0; al[4, N // 2] = (2, 1)                   # a single half-missing genotype
+        blocks = (np.arange(N) // max(1, N // 7)) % 3       # a handful of long runs incl. missing ones
+        al[5, :, 0] = blocks; al[5, :, 1] = blocks
+    variants = O.variants_from_alleles(al)
+    chunks, desc, want_d, want_m = [], np.zeros(M, dtype=T.RLE_DESC_DTYPE), [], []
+    off = 3                                                  # run words need no alignment
+    for v in range(M):
+        missing = bool((al[v] == 2).any())
+        width = int(rng.choice([1, 2, 4]))
+        raw, lens, As, Bs = _rle_encode(al[v], width, missing)
+        chunks.append((off, raw))
+        desc[v] = (off, len(lens), width, int(missing), 0)
+        off += raw.size + int(rng.integers(0, 5))
+        d = np.zeros(O.words64(N), np.uint64); mk = np.zeros(O.words64(N), np.uint64)
+        assert O.lib().orc_build_bitvector(lens.ctypes.data, As.ctypes.data, Bs.ctypes.data, len(lens), N, d.ctypes.data, mk.ctypes.data) == 0
+        want_d.append(d); want_m.append(mk)
+    buf = np.zeros(off + 8, np.uint8)
+    for o, raw in chunks:
+        buf[o:o + raw.size] = raw
+    hip.set_problem(N, M + 3)
+    hip.upload_rle(buf, desc, util.to_hip_meta(variants), first=2)          # into the middle of the problem
+    data, mask = hip.download(2, M)
+    assert np.array_equal(data, np.array(want_d)) and np.array_equal(mask, np.array(want_m))
+    # the same rows through the bitvector upload give the same engine state
+    d2, m2 = O.bitvectors_from_alleles(al)
+    assert np.array_equal(data, d2) and (m2 is None or np.array_equal(mask, m2))
+    # corrupt runs (lengths do not add up) are refused
+    bad = desc.copy(); bad["n_runs"][3] -= 1
+    if N > 1:
+        with pytest.raises(T.HipError) as e:
+            hip.upload_rle(buf, bad, util.to_hip_meta(variants), first=2)
+        assert e.value.code == -1
+    bad = desc.copy(); bad["offset"][0] = buf.size                             # runs beyond the buffer
+    with pytest.raises(T.HipError):
+        hip.upload_rle(buf, bad, util.to_hip_meta(variants), first=2)
+
+
+def test_split_units_on_short_rows(hip, monkeypatch):
+    """The count kernel's split-unit path (K-ranges of a tile added with atomics) is only taken on long rows by
+    default; forced onto short ones, every cell still equals the oracle's."""
+    N, M = 3000, 300                                  # unphased planes: 94 words -> 3 chunks of 32
+    al = util.random_alleles(M, N, 8, miss_rate=0.05, miss_variants=0.3)
+    data, mask, variants = util.upload(hip, al)
+    monkeypatch.setenv("TWK_HIP_COUNT_MIN_CHUNKS", "1")
+    for mode, counter in ((T.MODE_PHASED, O.count_phased), (T.MODE_UNPHASED, O.count_unphased)):
+        got = hip.count_tile(mode, 0, M, 0, M)
+        rng = np.random.default_rng(3)
+        for i, j in zip(rng.integers(0, M, 60), rng.integers(0, M, 60)):
+            mi = mask[i] if variants["gt_missing"][i] else None
+            mj = mask[j] if variants["gt_missing"][j] else None
+            assert np.array_equal(got[i, j], counter(data[i], mi, data[j], mj, N)), (mode, i, j)
+    whole, _, _ = hip.ld_all(T.MODE_AUTO, T.Filters(minR2=0.0))
+    monkeypatch.delenv("TWK_HIP_COUNT_MIN_CHUNKS")
+    plain, _, _ = hip.ld_all(T.MODE_AUTO, T.Filters(minR2=0.0))
+    order = ["idxA", "idxB"]
+    assert np.sort(whole, order=order).tobytes() == np.sort(plain, order=order).tobytes()

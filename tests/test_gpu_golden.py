@@ -176,26 +176,44 @@ def test_cli_window_mode(tmp_path):
     assert 0 < len(win) < len(whole) and np.array_equal(key(win), key(sel))
 
 
-def test_cli_multi_process_shards_equal_single(tmp_path):
-    """TWK_HIP_GPUS=n: one worker process per shard (here all on GPU 0), parts concatenated."""
+def test_cli_multi_gpu_driver_threads_equal_single(tmp_path):
+    """TWK_HIP_GPUS=n: one driver thread and one engine context per GPU (here all on GPU 0), one shared
+    writer; TWK_HIP_PART=k/n: this process's share of a multi-node run, merged with concat."""
     N, M = 80, 500
-    al = util.random_alleles(M, N, 77)
+    al = util.random_alleles(M, N, 77, miss_rate=0.05, miss_variants=0.2)
     pos = (1000 + 10 * np.arange(M)).astype(np.uint32)
     twk = str(tmp_path / "in.twk")
     hostlib.write_twk(twk, al, pos, np.zeros(M, np.uint32), np.ones(M, np.uint8), block_size=50)
-    def run(env_extra, out):
+    def run(env_extra, out, extra=()):
         env = dict(os.environ, **env_extra)
-        r = subprocess.run([hostlib.CLI_PATH, "calc", "-i", twk, "-o", out, "-r", "0.02", "-u"], capture_output=True, text=True, env=env)
+        r = subprocess.run([hostlib.CLI_PATH, "calc", "-i", twk, "-o", out, "-r", "0.02"] + list(extra), capture_output=True, text=True, env=env)
         assert r.returncode == 0, r.stderr
         return hostlib.two_as_matrix(hostlib.read_two(out)[0]), r.stderr
     whole, log0 = run({"TWK_HIP_PROGRESS_SECONDS": "0"}, str(tmp_path / "w.two"))
     prog = [l for l in log0.splitlines() if "[PROGRESS]" in l]
     assert "Time elapsed" in prog[0] and "Est. Time left" in prog[0] and "%" in prog[1]          # ticker lines (ld_progress.h:48-75)
-    # three workers; every worker is pinned to device 0 because the box has one GPU
-    multi, log = run({"TWK_HIP_GPUS": "3", "TWK_HIP_FORCE_DEVICE": "0"}, str(tmp_path / "m.two"))
     key = lambda m: m[np.lexsort((m[:, 4], m[:, 2]))]
-    assert len(whole) > 0 and np.array_equal(key(whole), key(multi))
-    assert "Merged 3 GPU shards" in log and not [f for f in os.listdir(tmp_path) if ".part" in f]
+    assert len(whole) > 0
+    for mode in ((), ("-u",), ("-p",)):
+        one, _ = run({}, str(tmp_path / "one.two"), mode)
+        # three contexts; every one is pinned to device 0 because the box has one GPU
+        multi, log = run({"TWK_HIP_GPUS": "3", "TWK_HIP_FORCE_DEVICE": "0", "TWK_HIP_PROGRESS_SECONDS": "0"}, str(tmp_path / "m.two"), mode)
+        assert len(one) > 0 and np.array_equal(key(one), key(multi))
+        assert "Using 3 GPUs" in log and "GPU 2: count kernel" in log
+    # farm mode: two processes x two GPUs each = four shards, outputs merged with concat
+    parts = []
+    for k in range(2):
+        out = str(tmp_path / f"farm{k}.two")
+        run({"TWK_HIP_GPUS": "2", "TWK_HIP_FORCE_DEVICE": "0", "TWK_HIP_PART": f"{k}/2"}, out)
+        parts.append(out)
+    cat = str(tmp_path / "cat.two")
+    r = subprocess.run([hostlib.CLI_PATH, "concat", "-i", parts[0], "-i", parts[1], "-o", cat], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert np.array_equal(key(whole), key(hostlib.two_as_matrix(hostlib.read_two(cat)[0])))
+    # more GPUs than the box has is an error, not a silent fallback
+    r = subprocess.run([hostlib.CLI_PATH, "calc", "-i", twk, "-o", str(tmp_path / "x.two")], capture_output=True, text=True,
+                       env=dict(os.environ, TWK_HIP_GPUS="64"))
+    assert r.returncode != 0 and "device(s) are visible" in r.stderr
 
 
 def test_cli_full_chain_import_calc_sort_view(tmp_path):

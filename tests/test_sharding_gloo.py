@@ -47,51 +47,70 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, M, q):
+def _worker(rank, world, port, M, q, two_path):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from tomahawk_amd.dist import gather_records
+    from tomahawk_amd import hostlib
     r0, r1, n = T.shard_rows(M, rank, world)
-    # stand-in survivors: every 7th pair of this rank's band (no device in this test)
-    recs = np.zeros(0, dtype=T.RECORD_DTYPE)
+    # stand-in survivors: every 7th pair of this rank's band (no device in this test); ragged on purpose:
+    # the middle rank has none at all, the last one five
     ij = [(i, j) for i in range(r0, r1) for j in range(i + 1, M)][::7]
-    if rank == 1:
-        ij = ij[:5]                                         # ragged: very different counts per rank
+    if rank == world - 1:
+        ij = ij[:5]
+    elif rank != 0:
+        ij = []
     recs = np.zeros(len(ij), dtype=T.RECORD_DTYPE)
     recs["idxA"] = [p[0] for p in ij]; recs["idxB"] = [p[1] for p in ij]
     recs["R2"] = recs["idxA"] * 1e-3 + recs["idxB"] * 1e-6
+    recs["flags"] = 3
     got = gather_records(recs, dst=0)
     empty = gather_records(np.zeros(0, dtype=T.RECORD_DTYPE), dst=0)
     if rank == 0:
-        q.put((got["idxA"].tolist(), got["idxB"].tolist(), got["R2"].tolist(), len(empty), (r0, r1, n)))
+        # the writer rank packs what it gathered into a real .two (forward + reverse blocks, flush rule, index)
+        w = hostlib.TwoStream(two_path, 10, np.zeros(M, dtype=np.uint32), 1000 + 100 * np.arange(M, dtype=np.uint32), b_size=500)
+        w.append(got[: len(got) // 2]); w.append(got[len(got) // 2:])
+        n_written = w.close()
+        q.put((got["idxA"].tolist(), got["idxB"].tolist(), got["R2"].tolist(), len(empty), (r0, r1, n), n_written))
     else:
         assert got is None and empty is None
-        q.put((len(ij), (r0, r1, n)))
+        q.put((rank, len(ij), (r0, r1, n)))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_gather_records_world2_gloo():
-    M, world = 300, 2
+def test_gather_records_world3_gloo_and_writer_rank(tmp_path):
+    from tomahawk_amd import hostlib
+    M, world = 300, 3
+    two_path = str(tmp_path / "gathered.two")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, M, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, M, q, two_path)) for r in range(world)]
     for p in procs:
         p.start()
     outs = [q.get(timeout=120) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    root = next(o for o in outs if len(o) == 5)
-    other = next(o for o in outs if len(o) == 2)
-    idxA, idxB, r2, n_empty, band0 = root
-    n1, band1 = other
-    assert n_empty == 0 and n1 == 5
-    assert band0[1] == band1[0] and band0[2] + band1[2] == M * (M - 1) // 2
-    # rank order is preserved; rank 0's records all lie in its band, rank 1's in the other
-    n0 = len(idxA) - n1
-    assert all(band0[0] <= a < band0[1] for a in idxA[:n0]) and all(band1[0] <= a < band1[1] for a in idxA[n0:])
+    root = next(o for o in outs if len(o) == 6)
+    others = sorted(o for o in outs if len(o) == 3)
+    idxA, idxB, r2, n_empty, band0, n_written = root
+    (_, n1, band1), (_, n2, band2) = others
+    assert n_empty == 0 and n1 == 0 and n2 == 5
+    assert band0[1] == band1[0] and band1[1] == band2[0] and band0[2] + band1[2] + band2[2] == M * (M - 1) // 2
+    # rank order is preserved; rank 0's records all lie in its band, the last rank's in its own
+    n0 = len(idxA) - n2
+    assert n0 > 100
+    assert all(band0[0] <= a < band0[1] for a in idxA[:n0]) and all(band2[0] <= a < band2[1] for a in idxA[n0:])
     assert all(a < b for a, b in zip(idxA, idxB))
     np.testing.assert_allclose(r2, np.array(idxA) * 1e-3 + np.array(idxB) * 1e-6)
+    # the .two the writer rank produced: every gathered pair once forward and once reversed
+    recs, info = hostlib.read_two(two_path)
+    assert n_written == len(recs) == 2 * len(idxA) and info["n_samples"] == 10
+    fwd = {(1000 + 100 * a, 1000 + 100 * b) for a, b in zip(idxA, idxB)}
+    seen = {(int(r["packA"]) >> 2, int(r["packB"]) >> 2) for r in recs}
+    assert seen == fwd | {(b, a) for a, b in fwd}
+    state, ent, _ = hostlib.two_index(two_path)
+    assert state == 0 and int(ent[:, 2].sum()) == len(recs) and ent[:, 2].max() <= 500

@@ -145,4 +145,120 @@ __global__ void k_clear_tail(uint32_t* __restrict__ raw, uint32_t Wp, uint32_t n
 	for (uint32_t v = blockIdx.y; v < n_variants; v += gridDim.y) raw[(size_t)v * Wp + w] &= keep;
 }
 
+// ---- T1 on the device: run-length genotypes -> bitvector + mask ---------------------------------
+// Device counterpart of twk_igt_vec::Build (lib/core.cpp:349-391): the variant's run words exactly as
+// they sit in a .twk block (twk1_t::gt, 1 / 2 / 4 bytes per run, little endian; lib/core.h:195-205,
+// lib/genotype_encoder.h:277-343) are expanded to the raw layout (bit 2s / 2s+1 = first / second allele
+// of sample s is ALT) and, for variants with missing genotypes, the mask (both bits of a sample set when
+// either allele is missing, core.cpp:379-380).  A run word is  length << (2 + 2m) | A << (1 + m) | B
+// with m = 1 and two bits per allele (0 ref, 1 alt, 2 missing) when the variant has missing genotypes,
+// m = 0 and one bit per allele otherwise.
+//
+// One 256-thread block per variant, two phases:
+//   1. every thread sums the lengths of groups of 32 runs, a block scan turns the sums into the first
+//      sample of every group (scratch: one u32 per group);
+//   2. every thread produces spans of 8 output words (128 samples): binary search for the group that
+//      holds the span's first sample, walk the runs, OR the allele patterns in, store.
+// Output-centric, so no atomics, every row word is written exactly once (zero where nothing is ALT) and
+// the padding beyond 2N bits is zero.  status[0] is set to 1 if any variant's runs do not add up to
+// n_samples (corrupt input).
+struct RleDesc {
+	unsigned long long off;     // byte offset of the variant's first run word in `bytes`
+	uint32_t n_runs;
+	uint32_t width_missing;     // bits 0-7: bytes per run word (1, 2, 4); bit 8: variant has missing genotypes
+};
+constexpr int RLE_GROUP = 32;          // runs per scan group
+constexpr int RLE_SPAN_WORDS = 8;      // 32-bit output words per paint step of a thread
+
+__device__ __forceinline__ uint32_t rle_word(const uint8_t* __restrict__ p, uint32_t i, uint32_t width) {
+	p += (size_t)i * width;
+	if (width == 1) return p[0];
+	if (width == 2) return (uint32_t)p[0] | (uint32_t)p[1] << 8;
+	return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24;
+}
+
+__global__ __launch_bounds__(256)
+void k_inflate_rle(const uint8_t* __restrict__ bytes, const RleDesc* __restrict__ desc,
+                   const unsigned long long* __restrict__ group_base,   // first scratch slot of every variant
+                   uint32_t* __restrict__ scratch, uint32_t* __restrict__ raw, uint32_t* __restrict__ rawmask,
+                   uint32_t Wp, uint32_t n_samples, uint32_t first_row, int* __restrict__ status) {
+	const uint32_t v = blockIdx.x;
+	const RleDesc d = desc[v];
+	const uint32_t width = d.width_missing & 0xFFu, m = (d.width_missing >> 8) & 1u;
+	const uint32_t shift = 2 + 2 * m, amask = (1u << (1 + m)) - 1;
+	const uint8_t* runs = bytes + d.off;
+	const uint32_t n_groups = (d.n_runs + RLE_GROUP - 1) / RLE_GROUP;
+	uint32_t* gstart = scratch + group_base[v];                  // first sample of every group
+	__shared__ uint32_t warp_sum[4];
+	__shared__ uint32_t carry_s;
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	if (tid == 0) carry_s = 0;
+	__syncthreads();
+	// ---- phase 1: exclusive scan of the group sums -------------------------------------------
+	for (uint32_t g0 = 0; g0 < n_groups; g0 += 256) {
+		const uint32_t g = g0 + tid;
+		uint32_t sum = 0;
+		if (g < n_groups) {
+			const uint32_t r1 = min(d.n_runs, (g + 1) * RLE_GROUP);
+			for (uint32_t r = g * RLE_GROUP; r < r1; ++r) sum += rle_word(runs, r, width) >> shift;
+		}
+		uint32_t inc = sum;                                     // inclusive scan within the wave
+		for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+		if (lane == 63) warp_sum[wv] = inc;
+		__syncthreads();
+		uint32_t before = carry_s;
+		for (int k = 0; k < wv; ++k) before += warp_sum[k];
+		if (g < n_groups) gstart[g] = before + inc - sum;
+		__syncthreads();
+		if (tid == 255) carry_s = before + inc;
+		__syncthreads();
+	}
+	const uint32_t total = carry_s;
+	if (total != n_samples) { if (tid == 0) status[0] = 1; }
+	// ---- phase 2: paint -----------------------------------------------------------------------------
+	uint32_t* row = raw + (size_t)(first_row + v) * Wp;
+	uint32_t* mrow = rawmask ? rawmask + (size_t)(first_row + v) * Wp : nullptr;
+	const uint32_t n_spans = (Wp + RLE_SPAN_WORDS - 1) / RLE_SPAN_WORDS;
+	const uint32_t live = min(total, n_samples);                // samples the runs actually describe
+	for (uint32_t sp = tid; sp < n_spans; sp += 256) {
+		uint32_t out[RLE_SPAN_WORDS], outm[RLE_SPAN_WORDS];
+#pragma unroll
+		for (int k = 0; k < RLE_SPAN_WORDS; ++k) { out[k] = 0; outm[k] = 0; }
+		const uint32_t s0 = sp * (RLE_SPAN_WORDS * 16);          // first sample of the span
+		const uint32_t s1 = min(live, s0 + RLE_SPAN_WORDS * 16);
+		if (s0 < s1 && n_groups) {
+			// largest group g with gstart[g] <= s0
+			uint32_t lo = 0, hi = n_groups;                     // invariant: gstart[lo] <= s0 (gstart[0] = 0)
+			while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (gstart[mid] <= s0) lo = mid; else hi = mid; }
+			uint32_t r = lo * RLE_GROUP, cur = gstart[lo];      // run r starts at sample cur
+			while (r < d.n_runs && cur < s1) {
+				const uint32_t wd = rle_word(runs, r, width);
+				const uint32_t len = wd >> shift, a = (wd >> (1 + m)) & amask, b = wd & amask;
+				const uint32_t e = cur + len;
+				if (e > s0 && (a | b)) {
+					const uint32_t p0 = max(cur, s0) - s0, p1 = min(e, s1) - s0;       // samples [p0, p1) of the span
+					const uint32_t pat = (a == 1 ? 0x55555555u : 0u) | (b == 1 ? 0xAAAAAAAAu : 0u);
+					const uint32_t miss = (a == 2 || b == 2) ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+					for (int k = 0; k < RLE_SPAN_WORDS; ++k) {
+						const uint32_t w0 = k * 16, w1 = w0 + 16;
+						if (p1 > w0 && p0 < w1) {
+							const uint32_t lo_s = max(p0, w0) - w0, hi_s = min(p1, w1) - w0;       // samples [lo_s, hi_s) of word k
+							const uint32_t bits = (hi_s - lo_s) * 2;
+							const uint32_t rng = (bits == 32 ? 0xFFFFFFFFu : ((1u << bits) - 1u)) << (lo_s * 2);
+							out[k] |= pat & rng; outm[k] |= miss & rng;
+						}
+					}
+				}
+				cur = e; ++r;
+			}
+		}
+#pragma unroll
+		for (int k = 0; k < RLE_SPAN_WORDS; ++k) {
+			const uint32_t w = sp * RLE_SPAN_WORDS + k;
+			if (w < Wp) { row[w] = out[k]; if (mrow) mrow[w] = outm[k]; }
+		}
+	}
+}
+
 }  // namespace twk

@@ -89,6 +89,11 @@ struct twk_hip_ctx {
 	bool progress_muted = false;       // second stage of a default-mode run: its pairs were already counted
 	uint32_t resident_blocks = 512;   // count-kernel blocks the chip holds at once (2 per CU)
 	uint32_t* tickets = nullptr;      // [6] work tickets of the count launches: one per (slot, launch)
+	// staging of twk_hip_upload_rle (grow-only): run bytes, descriptors + scratch offsets, scan scratch, status word
+	uint8_t* d_rle = nullptr; size_t d_rle_cap = 0;
+	uint8_t* d_rle_desc = nullptr; size_t d_rle_desc_cap = 0;
+	uint32_t* d_rle_scratch = nullptr; size_t d_rle_scratch_cap = 0;
+	int* d_status = nullptr;
 	char err[512] = {0};
 };
 
@@ -476,6 +481,25 @@ uint32_t band_boundary(uint32_t k, uint32_t n_parts, uint32_t nA, uint32_t nB, b
 	return std::min(nA, (lo + 32) / 64 * 64);
 }
 
+// Per-variant metadata of variants [first, first + count): device SoA + host mirror (synchronous copies).
+int upload_meta(twk_hip_ctx* c, uint32_t first, uint32_t count, const twk_hip_variant_meta* meta) {
+	std::vector<uint32_t> ac(count), an(count), pos(count), rid(count), miss(count);
+	std::vector<double> hwe(count);
+	for (uint32_t i = 0; i < count; ++i) {
+		ac[i] = meta[i].ac; an[i] = meta[i].an; pos[i] = meta[i].pos; rid[i] = meta[i].rid;
+		miss[i] = meta[i].missing ? 1 : 0; hwe[i] = meta[i].hwe;
+		c->h_meta[first + i] = meta[i];
+		if (meta[i].missing) c->any_missing = true;
+	}
+	HIPCHK(c, hipMemcpy(c->d_ac + first, ac.data(), (size_t)count * 4, hipMemcpyHostToDevice));
+	HIPCHK(c, hipMemcpy(c->d_an + first, an.data(), (size_t)count * 4, hipMemcpyHostToDevice));
+	HIPCHK(c, hipMemcpy(c->d_pos + first, pos.data(), (size_t)count * 4, hipMemcpyHostToDevice));
+	HIPCHK(c, hipMemcpy(c->d_rid + first, rid.data(), (size_t)count * 4, hipMemcpyHostToDevice));
+	HIPCHK(c, hipMemcpy(c->d_missing + first, miss.data(), (size_t)count * 4, hipMemcpyHostToDevice));
+	HIPCHK(c, hipMemcpy(c->d_hwe + first, hwe.data(), (size_t)count * 8, hipMemcpyHostToDevice));
+	return TWK_HIP_OK;
+}
+
 bool valid_mode(int m) { return m == TWK_HIP_MODE_PHASED || m == TWK_HIP_MODE_UNPHASED || m == TWK_HIP_MODE_AUTO; }
 bool valid_tile(const twk_hip_ctx* c, const twk_hip_tile_desc* t) {
 	if (!t || t->nA == 0 || t->nB == 0 || t->nA > 32768 || t->nB > 32768) return false;
@@ -552,10 +576,24 @@ int twk_hip_ctx_destroy(twk_hip_ctx* c) {
 	}
 	if (c->h_recs) (void)hipHostFree(c->h_recs);
 	if (c->tickets) (void)hipFree(c->tickets);
+	if (c->d_rle) (void)hipFree(c->d_rle);
+	if (c->d_rle_desc) (void)hipFree(c->d_rle_desc);
+	if (c->d_rle_scratch) (void)hipFree(c->d_rle_scratch);
+	if (c->d_status) (void)hipFree(c->d_status);
 	if (c->s_compute) (void)hipStreamDestroy(c->s_compute);
 	if (c->s_copy) (void)hipStreamDestroy(c->s_copy);
 	delete c;
 	return TWK_HIP_OK;
+}
+
+int twk_hip_host_alloc(size_t bytes, void** out) {
+	if (!out || bytes == 0) return TWK_HIP_E_INVALID;
+	*out = nullptr;
+	return hipHostMalloc(out, bytes, hipHostMallocDefault) == hipSuccess ? TWK_HIP_OK : TWK_HIP_E_NOMEM;
+}
+int twk_hip_host_free(void* p) {
+	if (!p) return TWK_HIP_OK;
+	return hipHostFree(p) == hipSuccess ? TWK_HIP_OK : TWK_HIP_E_DEVICE;
 }
 
 int twk_hip_set_problem(twk_hip_ctx* c, uint32_t n_samples, uint32_t n_variants) {
@@ -612,21 +650,82 @@ int twk_hip_upload_bitvectors(twk_hip_ctx* c, uint32_t first, uint32_t count, co
 		                   c->rawmask + (size_t)first * c->Wp, c->Wp, c->N, count);
 		HIPCHK(c, hipGetLastError());
 	}
-	std::vector<uint32_t> ac(count), an(count), pos(count), rid(count), miss(count);
-	std::vector<double> hwe(count);
-	for (uint32_t i = 0; i < count; ++i) {
-		ac[i] = meta[i].ac; an[i] = meta[i].an; pos[i] = meta[i].pos; rid[i] = meta[i].rid;
-		miss[i] = meta[i].missing ? 1 : 0; hwe[i] = meta[i].hwe;
-		c->h_meta[first + i] = meta[i];
-		if (meta[i].missing) c->any_missing = true;
-	}
-	HIPCHK(c, hipMemcpy(c->d_ac + first, ac.data(), (size_t)count * 4, hipMemcpyHostToDevice));
-	HIPCHK(c, hipMemcpy(c->d_an + first, an.data(), (size_t)count * 4, hipMemcpyHostToDevice));
-	HIPCHK(c, hipMemcpy(c->d_pos + first, pos.data(), (size_t)count * 4, hipMemcpyHostToDevice));
-	HIPCHK(c, hipMemcpy(c->d_rid + first, rid.data(), (size_t)count * 4, hipMemcpyHostToDevice));
-	HIPCHK(c, hipMemcpy(c->d_missing + first, miss.data(), (size_t)count * 4, hipMemcpyHostToDevice));
-	HIPCHK(c, hipMemcpy(c->d_hwe + first, hwe.data(), (size_t)count * 8, hipMemcpyHostToDevice));
+	int rc = upload_meta(c, first, count, meta); if (rc) return rc;
 	HIPCHK(c, hipStreamSynchronize(c->s_compute));
+	return TWK_HIP_OK;
+}
+
+int twk_hip_upload_rle(twk_hip_ctx* c, uint32_t first, uint32_t count, const void* bytes, size_t n_bytes,
+                       const twk_hip_rle_desc* desc, const twk_hip_variant_meta* meta) {
+	if (!c || !bytes || !desc || !meta || count == 0) return TWK_HIP_E_INVALID;
+	if (!c->raw) return TWK_HIP_E_STATE;
+	if ((uint64_t)first + count > c->M) return TWK_HIP_E_INVALID;
+	// validate before anything changes (same rules as twk_hip_upload_bitvectors)
+	bool any_mask = false;
+	std::vector<RleDesc> dd(count);
+	std::vector<unsigned long long> gbase(count);
+	unsigned long long groups = 0;
+	for (uint32_t i = 0; i < count; ++i) {
+		const twk_hip_rle_desc& d = desc[i];
+		if (d.width != 1 && d.width != 2 && d.width != 4) return TWK_HIP_E_INVALID;
+		if (d.offset > n_bytes || (uint64_t)d.n_runs * d.width > n_bytes - d.offset) return TWK_HIP_E_INVALID;
+		if ((meta[i].missing != 0) != (d.missing != 0)) return TWK_HIP_E_INVALID;
+		if ((meta[i].an != 0) != (meta[i].missing != 0)) return TWK_HIP_E_INVALID;
+		if (d.missing) any_mask = true;
+		dd[i].off = d.offset; dd[i].n_runs = d.n_runs; dd[i].width_missing = (uint32_t)d.width | (d.missing ? 256u : 0u);
+		gbase[i] = groups;
+		groups += ((unsigned long long)d.n_runs + RLE_GROUP - 1) / RLE_GROUP;
+	}
+	HIPCHK(c, hipSetDevice(c->device));
+	free_planes(c);                                             // derived planes are stale now
+	auto grow = [&](void** p, size_t* cap, size_t need) -> hipError_t {
+		if (*cap >= need) return hipSuccess;
+		if (*p) (void)hipFree(*p);
+		*p = nullptr; *cap = 0;
+		const size_t want = need + need / 4;
+		const hipError_t e = hipMalloc(p, want);
+		if (e == hipSuccess) *cap = want;
+		return e;
+	};
+	const size_t desc_bytes = (size_t)count * (sizeof(RleDesc) + sizeof(unsigned long long));
+	HIPCHK(c, grow((void**)&c->d_rle, &c->d_rle_cap, n_bytes + 16));
+	HIPCHK(c, grow((void**)&c->d_rle_desc, &c->d_rle_desc_cap, desc_bytes));
+	HIPCHK(c, grow((void**)&c->d_rle_scratch, &c->d_rle_scratch_cap, (size_t)std::max<unsigned long long>(groups, 1) * 4));
+	if (!c->d_status) HIPCHK(c, hipMalloc((void**)&c->d_status, sizeof(int)));
+	if (any_mask && !c->rawmask) {
+		const size_t raw_bytes = (size_t)c->M_alloc * c->Wp * 4;
+		HIPCHK(c, hipMalloc((void**)&c->rawmask, raw_bytes));
+		HIPCHK(c, hipMemsetAsync(c->rawmask, 0, raw_bytes, c->s_compute));
+	}
+	RleDesc* d_desc = reinterpret_cast<RleDesc*>(c->d_rle_desc);
+	unsigned long long* d_gbase = reinterpret_cast<unsigned long long*>(c->d_rle_desc + (size_t)count * sizeof(RleDesc));
+	HIPCHK(c, hipMemsetAsync(c->d_status, 0, sizeof(int), c->s_compute));
+	HIPCHK(c, hipMemcpyAsync(c->d_rle, bytes, n_bytes, hipMemcpyHostToDevice, c->s_compute));
+	HIPCHK(c, hipMemcpyAsync(d_desc, dd.data(), (size_t)count * sizeof(RleDesc), hipMemcpyHostToDevice, c->s_compute));
+	HIPCHK(c, hipMemcpyAsync(d_gbase, gbase.data(), (size_t)count * sizeof(unsigned long long), hipMemcpyHostToDevice, c->s_compute));
+	hipLaunchKernelGGL(k_inflate_rle, dim3(count), dim3(256), 0, c->s_compute, c->d_rle, d_desc, d_gbase, c->d_rle_scratch,
+	                   c->raw, c->rawmask, c->Wp, c->N, first, c->d_status);
+	HIPCHK(c, hipGetLastError());
+	int status = 0;
+	HIPCHK(c, hipMemcpyAsync(&status, c->d_status, sizeof(int), hipMemcpyDeviceToHost, c->s_compute));
+	int rc = upload_meta(c, first, count, meta); if (rc) return rc;
+	HIPCHK(c, hipStreamSynchronize(c->s_compute));
+	if (status) { snprintf(c->err, sizeof(c->err), "run lengths of an uploaded variant do not add up to %u samples", c->N); return TWK_HIP_E_INVALID; }
+	return TWK_HIP_OK;
+}
+
+int twk_hip_download_bitvectors(twk_hip_ctx* c, uint32_t first, uint32_t count, uint64_t* data, uint64_t* mask, size_t stride64) {
+	if (!c || !data || count == 0) return TWK_HIP_E_INVALID;
+	if (!c->raw) return TWK_HIP_E_STATE;
+	const size_t w64 = ((size_t)2 * c->N + 63) / 64;
+	if (stride64 < w64 || (uint64_t)first + count > c->M) return TWK_HIP_E_INVALID;
+	HIPCHK(c, hipSetDevice(c->device));
+	HIPCHK(c, hipStreamSynchronize(c->s_compute));
+	HIPCHK(c, hipMemcpy2D(data, stride64 * 8, c->raw + (size_t)first * c->Wp, (size_t)c->Wp * 4, w64 * 8, count, hipMemcpyDeviceToHost));
+	if (mask) {
+		if (c->rawmask) HIPCHK(c, hipMemcpy2D(mask, stride64 * 8, c->rawmask + (size_t)first * c->Wp, (size_t)c->Wp * 4, w64 * 8, count, hipMemcpyDeviceToHost));
+		else for (uint32_t i = 0; i < count; ++i) std::memset(mask + (size_t)i * stride64, 0, w64 * 8);
+	}
 	return TWK_HIP_OK;
 }
 

@@ -28,7 +28,6 @@ static void program_message() {
 }
 
 static std::vector<std::string> g_argv;     // argv as given (getopt_long permutes the live one)
-static int launch_multi_gpu(int n_gpus, const std::string& out_final);
 
 static void calc_usage() {
 	program_message();
@@ -52,8 +51,9 @@ static void calc_usage() {
 	"  -P FLOAT  Fisher's exact test / Chi-squared cutoff P-value (default: 1)\n"
 	"  -r FLOAT  Pearson's R-squared minimum cut-off value (default: 0.1)\n"
 	"  -k INT    compression level to use (default: 1, max = 22).\n"
-	"Environment: TWK_HIP_DEVICE=<n> selects the GPU (default 0); TWK_HIP_GPUS=<n> runs one worker\n"
-	"             process per GPU on n GPUs (equal-area row bands) and concatenates their output.\n" << std::endl;
+	"Environment: TWK_HIP_DEVICE=<n> selects the GPU (default 0); TWK_HIP_GPUS=<n> uses GPUs 0..n-1, one\n"
+	"             driver thread each (equal-area row bands, one shared output file); TWK_HIP_PART=k/n makes\n"
+	"             this process compute share k of n of a multi-node run (merge the outputs with concat).\n" << std::endl;
 }
 
 static std::string stamp(const char* t) { return std::string("[") + t + "] "; }
@@ -121,12 +121,6 @@ static int calc(int argc, char** argv) {
 	}
 	if (settings.in.empty()) { std::cerr << stamp("ERROR") << "No input value specified..." << std::endl; return 1; }
 	if (settings.out.empty()) { std::cerr << stamp("ERROR") << "No output value specified..." << std::endl; return 1; }
-	if (const char* g = std::getenv("TWK_HIP_GPUS")) {
-		const int n = atoi(g);
-		if (n > 1) {
-			return launch_multi_gpu(n, settings.out);
-		}
-	}
 	program_message();
 	std::cerr << stamp("LOG") << "Calling calc..." << std::endl;
 	tomahawk::twk_ld ld;
@@ -351,52 +345,6 @@ static int sort_cmd(int argc, char** argv) {
 	program_message();
 	std::cerr << stamp("LOG") << "Calling sort..." << std::endl;
 	return tomahawk::two_sort(st) ? 0 : 1;
-}
-
-// Multi-GPU `calc`: one process per GPU (TWK_HIP_GPUS=n).  The launcher itself never touches
-// HIP: it re-executes this binary n times with TWK_HIP_DEVICE=k, TWK_HIP_PART=k/n and a private
-// part file, waits, and concatenates the parts (the reference's farm mode -c/-C + concat,
-// docs/job-balancing.md, with row bands instead of square chunks).
-static int launch_multi_gpu(int n_gpus, const std::string& out_final) {
-	std::vector<std::string> parts;
-	std::vector<pid_t> pids;
-	const std::string base = (out_final == "-" || out_final.empty()) ? std::string("/tmp/twk_calc_") + std::to_string(getpid()) : out_final;
-	for (int k = 0; k < n_gpus; ++k) {
-		const std::string part = base + ".part" + std::to_string(k) + ".two";
-		parts.push_back(part);
-		std::vector<std::string> args = g_argv;
-		bool replaced = false;
-		for (size_t i = 1; i + 1 < args.size(); ++i) if (args[i] == "-o" || args[i] == "--output") { args[i + 1] = part; replaced = true; }
-		if (!replaced) { args.push_back("-o"); args.push_back(part); }
-		const pid_t pid = fork();
-		if (pid < 0) { std::cerr << stamp("ERROR") << "fork failed" << std::endl; return 1; }
-		if (pid == 0) {
-			setenv("TWK_HIP_DEVICE", std::to_string(k).c_str(), 1);
-			setenv("TWK_HIP_PART", (std::to_string(k) + "/" + std::to_string(n_gpus)).c_str(), 1);
-			unsetenv("TWK_HIP_GPUS");
-			std::vector<char*> av;
-			for (auto& a : args) av.push_back(const_cast<char*>(a.c_str()));
-			av.push_back(nullptr);
-			execv("/proc/self/exe", av.data());
-			_exit(127);
-		}
-		pids.push_back(pid);
-	}
-	bool ok = true;
-	for (pid_t pid : pids) { int st = 0; if (waitpid(pid, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) ok = false; }
-	if (!ok) { std::cerr << stamp("ERROR") << "A GPU worker failed; part files are left in place" << std::endl; return 1; }
-	std::string err;
-	const std::string note = "\n##tomahawk_calcGPUs=" + std::to_string(n_gpus);
-	std::string out = out_final.empty() ? "-" : out_final;
-	if (out != "-") {
-		const size_t sl = out.find_last_of("/\\"), dot = out.rfind('.');
-		const std::string ext = (dot == std::string::npos || (sl != std::string::npos && dot < sl)) ? "" : out.substr(dot + 1);
-		if (!(ext.size() == 3 && strncasecmp(ext.c_str(), "two", 3) == 0)) out += ".two";
-	}
-	if (!tomahawk::two_concat(parts, out, note, err)) { std::cerr << stamp("ERROR") << err << std::endl; return 1; }
-	for (const auto& p : parts) unlink(p.c_str());
-	std::cerr << stamp("LOG") << "Merged " << n_gpus << " GPU shards into " << out << std::endl;
-	return 0;
 }
 
 // `tomahawk scalc` (lib/scalc.h:50-194): one site against its neighbourhood.

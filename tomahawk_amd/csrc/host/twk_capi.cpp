@@ -2,6 +2,7 @@
 // (ctypes-friendly; plain pointers and sizes).
 #include <cstdint>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -11,6 +12,7 @@
 #include "twk_hip.h"
 #include "twk_two_tools.h"
 #include "twk_import.h"
+#include "twk_record_sink.h"
 
 using namespace tomahawk;
 
@@ -234,6 +236,52 @@ int twk_ld_compute(const char* in, const char* out, int force_phased, int force_
 	if (n_pairs) *n_pairs = ld.n_pairs();
 	if (n_records) *n_records = ld.n_records();
 	return ok ? 0 : 1;
+} catch (...) { return -9; }
+
+// The writer side of a calc run on its own: survivor records as the engine hands them out
+// (twk_hip_record, variant indices into rid[] / pos[]) -> forward + reverse twk1_two_t blocks with the
+// reference's flush rule -> a .two file (twk_record_sink.h).  This is what rank 0 of a multi-process
+// run does with the records it gathered from the other ranks (bench.py); `tomahawk calc` uses the same
+// classes directly.  Header: n_contigs contigs "1".."n", sample names "S<i>".
+namespace {
+struct TwoStream {
+	TwoOutput out;
+	std::vector<uint32_t> rid, pos;
+	std::unique_ptr<RecordEmitter> emitter;
+};
+}
+void* twk_two_stream_open(const char* path, uint32_t n_samples, uint32_t n_contigs, const uint32_t* rid, const uint32_t* pos,
+                          uint32_t n_variants, int c_level, uint32_t b_size, int n_threads) try {
+	if (!path || !rid || !pos || n_variants == 0 || b_size < 2) return nullptr;
+	std::unique_ptr<TwoStream> st(new TwoStream);
+	Header hdr;
+	hdr.literals = "##fileformat=VCFv4.2\n##source=tomahawk_amd record stream\n";
+	for (uint32_t s = 0; s < n_samples; ++s) hdr.samples.push_back("S" + std::to_string(s));
+	for (uint32_t c = 0; c < n_contigs; ++c) { Contig k; k.idx = c; k.name = std::to_string(c + 1); k.n_bases = 250000000; hdr.contigs.push_back(k); }
+	st->rid.assign(rid, rid + n_variants); st->pos.assign(pos, pos + n_variants);
+	for (uint32_t v = 0; v < n_variants; ++v) if (st->rid[v] >= n_contigs) return nullptr;
+	if (!st->out.writer.open(path, hdr, c_level > 0 ? c_level : 1)) return nullptr;
+	st->out.b_size = b_size; st->out.c_level = c_level > 0 ? c_level : 1;
+	st->out.rid = st->rid.data(); st->out.pos = st->pos.data();
+	st->emitter.reset(new RecordEmitter(st->out, n_threads > 0 ? n_threads : 1));
+	return st.release();
+} catch (...) { return nullptr; }
+
+int twk_two_stream_append(void* h, const void* records, uint64_t n) try {
+	auto* st = static_cast<TwoStream*>(h);
+	if (!st || (!records && n)) return -1;
+	const twk_hip_record* r = static_cast<const twk_hip_record*>(records);
+	for (uint64_t i = 0; i < n; ++i) if (r[i].idxA >= st->rid.size() || r[i].idxB >= st->rid.size()) return -1;
+	return st->emitter->emit(r, n, false) ? 0 : -3;
+} catch (...) { return -9; }
+
+int twk_two_stream_close(void* h, uint64_t* n_records) try {
+	std::unique_ptr<TwoStream> st(static_cast<TwoStream*>(h));
+	if (!st) return -1;
+	bool ok = st->emitter->emit(nullptr, 0, true);
+	ok = st->out.writer.close() && ok;
+	if (n_records) *n_records = st->out.n_records;
+	return ok ? 0 : -3;
 } catch (...) { return -9; }
 
 }  // extern "C"

@@ -38,6 +38,11 @@ bool zstd_decompress(const uint8_t* src, size_t n, std::vector<uint8_t>& dst, si
 	if (ZSTD_isError(r) || r != n_unc) { std::cerr << "[zstd] decompress failed" << std::endl; return false; }
 	return true;
 }
+bool zstd_decompress_into(const uint8_t* src, size_t n, uint8_t* dst, size_t n_unc) {
+	if (ZSTD_getFrameContentSize(src, n) != (unsigned long long)n_unc) return false;
+	const size_t r = ZSTD_decompress(dst, n_unc, src, n);
+	return !ZSTD_isError(r) && r == n_unc;
+}
 const char* zstd_version() { return ZSTD_versionString(); }
 
 // ---- Header ----------------------------------------------------------------

@@ -39,6 +39,8 @@ public:
 
 bool zstd_compress(const uint8_t* src, size_t n, std::vector<uint8_t>& dst, int level);
 bool zstd_decompress(const uint8_t* src, size_t n, std::vector<uint8_t>& dst, size_t n_uncompressed);
+// The same into caller-owned memory of exactly n_uncompressed bytes (quiet: returns false on any mismatch).
+bool zstd_decompress_into(const uint8_t* src, size_t n, uint8_t* dst, size_t n_uncompressed);
 const char* zstd_version();
 
 // ---- header (include/header.h:115-128,312-416; lib/header.cpp:330-363) ----

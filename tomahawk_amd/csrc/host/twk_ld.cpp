@@ -25,9 +25,13 @@
 #include <sys/time.h>
 #include <cstdio>
 
+#include <fcntl.h>
+#include <unistd.h>
+
 #include "twk_format.h"
 #include "twk_hip.h"
 #include "twk_parallel.h"
+#include "twk_record_sink.h"
 #include "twk_util.h"
 
 #ifndef TWK_AMD_VERSION
@@ -94,88 +98,11 @@ public:
 	// per-variant (rid,pos) of the uploaded selection
 	std::vector<uint32_t> rid, pos;
 
-	// Output state.  The reference keeps one forward and one reverse block per thread
-	// (ld_engine.h:321) and flushes both when the forward block is full or the contig pair of
-	// the next record differs from the block's first (ld_engine.cpp:1270-1281).  Here the
-	// survivors of one tile arrive together: they are put in (row, col) order with a parallel
-	// key sort, cut into blocks by that same rule, and the blocks are expanded to forward +
-	// reverse records and compressed on worker threads while this thread writes them in order.
-	// The last, still open block carries over to the next tile.
-	TwoWriter writer;
-	uint32_t b_size = 10000;
-	int c_level = 1, n_workers = 1;
-	bool write_failed = false;
-	std::vector<twk_hip_record> carry;            // records of the open block (< b_size), in order
+	// Output: one shared writer, one emitter (pair of open forward / reverse blocks) per GPU driver
+	// thread - the reference's per-thread blocks behind one spinlocked writer (twk_record_sink.h).
+	TwoOutput out;
 
-	void expand(const twk_hip_record& r, TwoRecord& f, TwoRecord& v) const {
-		f.controller = (uint16_t)r.flags;
-		f.ridA = rid[r.idxA]; f.ridB = rid[r.idxB];
-		f.packA = pos[r.idxA] << 2; f.packB = pos[r.idxB] << 2;
-		std::memcpy(f.cnt, r.cnt, sizeof(f.cnt));
-		f.D = r.D; f.Dprime = r.Dprime; f.R = r.R; f.R2 = r.R2; f.P = r.P;
-		f.ChiSqFisher = r.ChiSqFisher; f.ChiSqModel = r.ChiSqModel;
-		v = f;                           // reverse copy swaps (rid,pos) only; cnt is NOT transposed (:1292-1298)
-		std::swap(v.ridA, v.ridB); std::swap(v.packA, v.packB);
-	}
-
-	// Write the survivors `recs[0..n)` (any order) behind the carried block; final: close the open block too.
-	bool emit(const twk_hip_record* recs, uint64_t n, bool final) {
-		// (row, col) order: the file is deterministic (the reference's order is thread-timing dependent)
-		par::Raw<par::SortKey> keys;
-		keys.alloc(n);
-		{
-			const int T = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)n_workers, n / 65536 + 1));
-			std::vector<std::thread> th;
-			for (int t = 0; t < T; ++t) th.emplace_back([&, t] {
-				for (uint64_t i = n * (uint64_t)t / T, e = n * (uint64_t)(t + 1) / T; i < e; ++i)
-					keys[i] = par::SortKey{0, (uint64_t)recs[i].idxA << 32 | recs[i].idxB, (uint32_t)i};
-			});
-			for (auto& x : th) x.join();
-		}
-		par::parallel_sort(keys, n_workers);
-		// the sequence is carry[0..nc) followed by recs[keys[.].idx]
-		const uint64_t nc = carry.size(), total = nc + n;
-		auto at = [&](uint64_t i) -> const twk_hip_record& { return i < nc ? carry[i] : recs[keys[i - nc].idx]; };
-		// cuts by the flush rule: a block ends when it holds b_size records or the next record's
-		// (ridA, ridB) differs from its first record's
-		std::vector<uint64_t> cut{0};
-		if (total) {
-			uint32_t fa = rid[at(0).idxA], fb = rid[at(0).idxB];
-			for (uint64_t i = 1; i < total; ++i) {
-				const twk_hip_record& r = at(i);
-				const uint32_t ra = rid[r.idxA], rb = rid[r.idxB];
-				if (i - cut.back() == b_size || ra != fa || rb != fb) { cut.push_back(i); fa = ra; fb = rb; }
-			}
-		}
-		// the block after the last cut stays open unless this is the end
-		const size_t n_closed = total ? (final ? cut.size() : cut.size() - 1) : 0;
-		if (final && total) cut.push_back(total);
-		struct Slot { std::vector<TwoRecord> f, v; TwoWriter::Packed pf, pv; };
-		const int level = c_level;
-		std::function<bool(size_t, Slot&)> produce = [&](size_t b, Slot& s) -> bool {
-			const uint64_t lo = cut[b], hi = cut[b + 1];
-			s.f.resize(hi - lo); s.v.resize(hi - lo);
-			for (uint64_t i = lo; i < hi; ++i) expand(at(i), s.f[i - lo], s.v[i - lo]);
-			return TwoWriter::pack(s.f.data(), (uint32_t)s.f.size(), level, s.pf) && TwoWriter::pack(s.v.data(), (uint32_t)s.v.size(), level, s.pv);
-		};
-		std::function<bool(size_t, Slot&)> consume = [&](size_t, Slot& s) -> bool {   // CompressBlock (:1804-1810): forward, then reverse
-			return writer.write_packed(s.pf) && writer.write_packed(s.pv);
-		};
-		if (n_closed && !par::ordered_parallel<Slot>(n_closed, n_workers, produce, consume)) return false;
-		std::vector<twk_hip_record> next;
-		if (!final && total) { next.reserve(total - cut.back()); for (uint64_t i = cut.back(); i < total; ++i) next.push_back(at(i)); }
-		carry.swap(next);
-		return true;
-	}
-
-	bool run(twk_ld_settings& settings, const Header& hdr, twk_hip_ctx* ctx, uint32_t n_samples, const void* spec);
-
-	static int sink(void* user, const twk_hip_record* recs, uint64_t n) {
-		auto* self = static_cast<twk_ld_impl*>(user);
-		if (!self->emit(recs, n, false)) { self->write_failed = true; return 1; }
-		self->n_records += 2 * n;
-		return 0;
-	}
+	bool run(twk_ld_settings& settings, const Header& hdr, const std::vector<twk_hip_ctx*>& ctxs, uint32_t n_samples, const void* spec);
 };
 
 twk_ld::twk_ld() : mImpl(new twk_ld_impl) {}
@@ -190,9 +117,9 @@ bool twk_ld::ComputePerformance() {
 	return false;
 }
 namespace {
-struct DeviceCtx {
-	twk_hip_ctx* ctx = nullptr;
-	~DeviceCtx() { if (ctx) twk_hip_ctx_destroy(ctx); }
+struct DeviceCtxs {          // one engine context per GPU of the run
+	std::vector<twk_hip_ctx*> ctx;
+	~DeviceCtxs() { for (auto* c : ctx) if (c) twk_hip_ctx_destroy(c); }
 };
 bool hip_ok(twk_hip_ctx* ctx, int rc, const char* what) {
 	if (rc == TWK_HIP_OK) return true;
@@ -277,99 +204,203 @@ static bool open_output(twk_ld_settings& settings, const Header& in_hdr, TwoWrit
 	return true;
 }
 
-// Unpack `sel` blocks (ld.cpp:370-465, ld_unpacker.h) in batches on T threads and upload them in file order.
-static bool load_blocks(const std::string& path, const TwkReader& reader, const std::vector<uint32_t>& sel,
-                        uint32_t n_samples, uint32_t T, twk_hip_ctx* ctx, std::vector<uint32_t>& rid, std::vector<uint32_t>& pos) {
-	const size_t w64 = ((size_t)2 * n_samples + 63) / 64;
-	std::vector<uint32_t> first(sel.size() + 1, 0);
-	for (size_t k = 0; k < sel.size(); ++k) first[k + 1] = first[k] + reader.index.ent[sel[k]].n;
-	rid.assign(first.back(), 0); pos.assign(first.back(), 0);
-	const size_t batch_bytes = (size_t)512 << 20;
-	size_t k0 = 0;
-	while (k0 < sel.size()) {
-		size_t k1 = k0; uint32_t nv = 0;
-		while (k1 < sel.size() && (nv == 0 || (size_t)(nv + reader.index.ent[sel[k1]].n) * w64 * 8 <= batch_bytes)) nv += reader.index.ent[sel[k1++]].n;
-		std::vector<uint64_t> data((size_t)nv * w64), mask;
-		std::vector<twk_hip_variant_meta> meta(nv);
-		std::vector<uint8_t> has_mask(k1 - k0, 0);
-		std::vector<Block> blocks(k1 - k0);
-		std::atomic<size_t> next(k0);
-		std::atomic<bool> failed(false);
-		auto reader_job = [&]() {
-			TwkReader rd;
-			if (!rd.open(path)) { failed = true; return; }
-			for (size_t k = next++; k < k1; k = next++) {
-				Block& blk = blocks[k - k0];
-				if (!rd.read_block(sel[k], blk) || blk.rcds.size() != reader.index.ent[sel[k]].n) { failed = true; return; }
-				for (const auto& v : blk.rcds) if (v.gt_missing) has_mask[k - k0] = 1;
-			}
-		};
-		const uint32_t nt = std::min<uint32_t>(T, (uint32_t)(k1 - k0));
-		{ std::vector<std::thread> th; for (uint32_t t = 0; t < nt; ++t) th.emplace_back(reader_job); for (auto& t : th) t.join(); }
-		if (failed) { std::cerr << stamp("ERROR") << "Failed to load blocks " << k0 << "-" << k1 << "!" << std::endl; return false; }
-		const bool any_mask = std::any_of(has_mask.begin(), has_mask.end(), [](uint8_t x) { return x != 0; });
-		if (any_mask) mask.assign((size_t)nv * w64, 0);
-		next = k0;
-		auto build_job = [&]() {
-			for (size_t k = next++; k < k1; k = next++) {
-				const Block& blk = blocks[k - k0];
-				const uint32_t base = first[k] - first[k0];
-				for (size_t i = 0; i < blk.rcds.size(); ++i) {
-					const Variant& v = blk.rcds[i];
-					uint64_t* d = &data[(size_t)(base + i) * w64];
-					uint64_t* m = (any_mask && v.gt_missing) ? &mask[(size_t)(base + i) * w64] : nullptr;
-					if (!v.build_bitvector(n_samples, d, m)) { failed = true; return; }
-					twk_hip_variant_meta& mm = meta[base + i];
-					mm.ac = v.ac; mm.an = v.an; mm.pos = v.pos; mm.rid = v.rid; mm.missing = v.gt_missing ? 1 : 0; mm._pad = 0; mm.hwe = v.hwe;
-				}
-			}
-		};
-		{ std::vector<std::thread> th; for (uint32_t t = 0; t < nt; ++t) th.emplace_back(build_job); for (auto& t : th) t.join(); }
-		if (failed) { std::cerr << stamp("ERROR") << "Corrupt genotype runs in blocks " << k0 << "-" << k1 << "!" << std::endl; return false; }
-		for (uint32_t i = 0; i < nv; ++i) { rid[first[k0] + i] = meta[i].rid; pos[first[k0] + i] = meta[i].pos; }
-		if (!hip_ok(ctx, twk_hip_upload_bitvectors(ctx, first[k0], nv, data.data(), any_mask ? mask.data() : nullptr, w64, meta.data()),
-		            "twk_hip_upload_bitvectors")) return false;
-		k0 = k1;
+// ---- input: .twk blocks -> HBM (ld.cpp:370-465, ld_unpacker.h:44-123) ------------------------------------
+// The reference's unpack threads decompress every block and expand every variant's run-length genotypes
+// into a bitvector in host memory.  Here the host only decompresses: blocks are cut into batches of
+// <= 256 MB (uncompressed), T threads read (pread) and zstd-decompress the blocks of a batch straight
+// into a page-locked staging buffer and walk the record headers for the per-variant metadata and the
+// place of the run words; the runs are expanded by a HIP kernel (twk_hip_upload_rle), so PCIe carries
+// the compressed genotypes.  Two staging buffers: batch b + 1 is decoded while batch b is uploaded, one
+// uploader thread per GPU.
+namespace {
+bool pread_all(int fd, void* buf, size_t n, uint64_t off) {
+	uint8_t* p = static_cast<uint8_t*>(buf);
+	while (n) {
+		const ssize_t r = pread(fd, p, n, (off_t)off);
+		if (r <= 0) return false;
+		p += r; n -= (size_t)r; off += (uint64_t)r;
 	}
 	return true;
 }
+struct Staging {            // page-locked when the HIP runtime can give it, plain memory otherwise
+	uint8_t* p = nullptr; size_t cap = 0; bool pinned = false;
+	bool reserve(size_t n) {
+		if (cap >= n) return true;
+		release();
+		void* q = nullptr;
+		if (twk_hip_host_alloc(n, &q) == TWK_HIP_OK && q) { p = static_cast<uint8_t*>(q); pinned = true; }
+		else { p = static_cast<uint8_t*>(std::malloc(n)); pinned = false; }
+		cap = p ? n : 0;
+		return p != nullptr;
+	}
+	void release() { if (p) { if (pinned) twk_hip_host_free(p); else std::free(p); } p = nullptr; cap = 0; }
+	~Staging() { release(); }
+};
+struct LoadBatch {
+	size_t k0 = 0, k1 = 0;                      // blocks [k0, k1) of the selection
+	uint32_t first = 0, nv = 0;                 // variants [first, first + nv)
+	size_t bytes = 0;
+	std::vector<size_t> boff;                   // where each block's bytes start in the staging buffer
+	std::vector<twk_hip_rle_desc> desc;
+	std::vector<twk_hip_variant_meta> meta;
+};
+// One decompressed block (core.cpp:245-261: u32 n, u32 m, u32 rid, then n records) -> descriptors + metadata
+// of its variants; record = 38-byte header (core.cpp:59-73) + n_runs run words.
+bool index_block(const uint8_t* base, size_t block_off, size_t block_len, uint32_t n_expected,
+                 twk_hip_rle_desc* desc, twk_hip_variant_meta* meta) {
+	const uint8_t* p = base + block_off; const uint8_t* end = p + block_len;
+	if (block_len < 12) return false;
+	uint32_t n; std::memcpy(&n, p, 4);
+	if (n != n_expected) return false;
+	p += 12;
+	for (uint32_t i = 0; i < n; ++i) {
+		if ((size_t)(end - p) < 38) return false;
+		const uint8_t pack = p[0];
+		const uint32_t width = pack >> 3;
+		if (width != 1 && width != 2 && width != 4) return false;       // "illegal gt primitive type" core.cpp:95
+		twk_hip_variant_meta& m = meta[i];
+		std::memcpy(&m.pos, p + 2, 4); std::memcpy(&m.ac, p + 6, 4); std::memcpy(&m.an, p + 10, 4); std::memcpy(&m.rid, p + 14, 4);
+		std::memcpy(&m.hwe, p + 26, 8);
+		uint32_t n_write; std::memcpy(&n_write, p + 34, 4);
+		const uint32_t n_runs = n_write >> 1, missing = n_write & 1;   // the container's own miss bit (= gt_missing in valid files)
+		m.missing = missing; m._pad = 0;
+		p += 38;
+		if ((uint64_t)n_runs * width > (uint64_t)(end - p)) return false;
+		desc[i].offset = (uint64_t)(p - base); desc[i].n_runs = n_runs; desc[i].width = (uint8_t)width; desc[i].missing = (uint8_t)missing; desc[i]._pad = 0;
+		p += (size_t)n_runs * width;
+	}
+	return true;
+}
+}  // namespace
 
-static bool create_device(DeviceCtx& dc) {
-	const char* dev_env = std::getenv("TWK_HIP_FORCE_DEVICE");        // testing: several workers on one GPU
-	if (!dev_env) dev_env = std::getenv("TWK_HIP_DEVICE");
-	const int device = dev_env ? std::atoi(dev_env) : 0;
-	if (twk_hip_device_count() <= 0) { std::cerr << stamp("ERROR", "HIP") << "No HIP device available (this build has no CPU path)." << std::endl; return false; }
-	return hip_ok(nullptr, twk_hip_ctx_create(device, &dc.ctx), "twk_hip_ctx_create");
+static bool load_blocks(const std::string& path, const TwkReader& reader, const std::vector<uint32_t>& sel,
+                        uint32_t T, const std::vector<twk_hip_ctx*>& ctxs, std::vector<uint32_t>& rid, std::vector<uint32_t>& pos) {
+	std::vector<uint32_t> first(sel.size() + 1, 0);
+	for (size_t k = 0; k < sel.size(); ++k) first[k + 1] = first[k] + reader.index.ent[sel[k]].n;
+	rid.assign(first.back(), 0); pos.assign(first.back(), 0);
+	const int fd = ::open(path.c_str(), O_RDONLY);
+	if (fd < 0) { std::cerr << stamp("ERROR") << "Failed to open " << path << std::endl; return false; }
+	struct Closer { int fd; ~Closer() { ::close(fd); } } closer{fd};
+	// batches
+	const size_t batch_cap = (size_t)256 << 20;
+	std::vector<LoadBatch> batches;
+	for (size_t k = 0; k < sel.size();) {
+		LoadBatch b; b.k0 = k; b.first = first[k];
+		while (k < sel.size() && (b.bytes == 0 || b.bytes + reader.index.ent[sel[k]].b_unc <= batch_cap)) {
+			b.boff.push_back(b.bytes);
+			b.bytes += ((size_t)reader.index.ent[sel[k]].b_unc + 15) / 16 * 16;
+			++k;
+		}
+		b.k1 = k; b.nv = first[k] - b.first;
+		batches.push_back(std::move(b));
+	}
+	size_t max_bytes = 0;
+	for (const auto& b : batches) max_bytes = std::max(max_bytes, b.bytes);
+	Staging stage[2];
+	if (!stage[0].reserve(max_bytes) || (batches.size() > 1 && !stage[1].reserve(max_bytes))) { std::cerr << stamp("ERROR") << "Out of host memory for the upload staging buffers" << std::endl; return false; }
+
+	std::atomic<bool> failed(false);
+	auto fill = [&](LoadBatch& b, uint8_t* buf) {
+		b.desc.resize(b.nv); b.meta.resize(b.nv);
+		std::atomic<size_t> next(b.k0);
+		auto job = [&]() {
+			std::vector<uint8_t> z;
+			for (size_t k = next++; k < b.k1 && !failed; k = next++) {
+				const IndexEntry& e = reader.index.ent[sel[k]];
+				uint8_t head[9];
+				if (!pread_all(fd, head, 9, e.foff)) { failed = true; return; }
+				uint32_t unc, cmp; std::memcpy(&unc, head + 1, 4); std::memcpy(&cmp, head + 5, 4);
+				if (head[0] != 1 || unc != e.b_unc || cmp > ((size_t)1 << 31)) { failed = true; return; }
+				z.resize(cmp);
+				if (!pread_all(fd, z.data(), cmp, e.foff + 9)) { failed = true; return; }
+				uint8_t* dst = buf + b.boff[k - b.k0];
+				if (!zstd_decompress_into(z.data(), cmp, dst, unc)) { failed = true; return; }
+				const uint32_t v0 = first[k] - b.first;
+				if (!index_block(buf, b.boff[k - b.k0], unc, e.n, &b.desc[v0], &b.meta[v0])) { failed = true; return; }
+			}
+		};
+		const uint32_t nt = (uint32_t)std::max<size_t>(1, std::min<size_t>(T, b.k1 - b.k0));
+		std::vector<std::thread> th;
+		for (uint32_t t = 0; t < nt; ++t) th.emplace_back(job);
+		for (auto& t : th) t.join();
+		for (uint32_t i = 0; i < b.nv && !failed; ++i) { rid[b.first + i] = b.meta[i].rid; pos[b.first + i] = b.meta[i].pos; }
+	};
+	std::vector<int> up_rc(ctxs.size(), TWK_HIP_OK);
+	std::vector<std::thread> uploaders;
+	auto join_uploads = [&]() -> bool {
+		for (auto& t : uploaders) t.join();
+		uploaders.clear();
+		for (size_t g = 0; g < ctxs.size(); ++g) if (!hip_ok(ctxs[g], up_rc[g], "twk_hip_upload_rle")) return false;
+		return true;
+	};
+	for (size_t bi = 0; bi < batches.size(); ++bi) {
+		LoadBatch& b = batches[bi];
+		uint8_t* buf = stage[bi & 1].p;
+		fill(b, buf);                                          // overlaps the upload of batch bi - 1
+		if (!join_uploads()) return false;
+		if (failed) { std::cerr << stamp("ERROR") << "Failed to load blocks " << b.k0 << "-" << b.k1 << "!" << std::endl; return false; }
+		for (size_t g = 0; g < ctxs.size(); ++g)
+			uploaders.emplace_back([&, g, buf]() { up_rc[g] = twk_hip_upload_rle(ctxs[g], b.first, b.nv, buf, b.bytes, b.desc.data(), b.meta.data()); });
+	}
+	return join_uploads();
+}
+
+static bool create_devices(DeviceCtxs& dc, int n_gpus) {
+	const char* force = std::getenv("TWK_HIP_FORCE_DEVICE");       // testing: several engine contexts on one GPU
+	const char* dev_env = std::getenv("TWK_HIP_DEVICE");
+	const int n_dev = twk_hip_device_count();
+	if (n_dev <= 0) { std::cerr << stamp("ERROR", "HIP") << "No HIP device available (this build has no CPU path)." << std::endl; return false; }
+	if (!force && n_gpus > n_dev) { std::cerr << stamp("ERROR", "HIP") << "TWK_HIP_GPUS=" << n_gpus << " but only " << n_dev << " device(s) are visible." << std::endl; return false; }
+	for (int g = 0; g < n_gpus; ++g) {
+		const int device = force ? std::atoi(force) : (n_gpus == 1 && dev_env ? std::atoi(dev_env) : g);
+		twk_hip_ctx* c = nullptr;
+		if (!hip_ok(nullptr, twk_hip_ctx_create(device, &c), "twk_hip_ctx_create")) return false;
+		dc.ctx.push_back(c);
+	}
+	return true;
+}
+static int gpus_from_env() {
+	if (const char* g = std::getenv("TWK_HIP_GPUS")) { const int n = std::atoi(g); if (n >= 1) return std::min(n, 64); }
+	return 1;
 }
 
 // compute + write + final log lines (ld.cpp:620-668, ld_progress.h:89-96)
-bool twk_ld::twk_ld_impl::run(twk_ld_settings& settings, const Header& hdr, twk_hip_ctx* ctx, uint32_t n_samples, const void* spec_) {
+bool twk_ld::twk_ld_impl::run(twk_ld_settings& settings, const Header& hdr, const std::vector<twk_hip_ctx*>& ctxs, uint32_t n_samples, const void* spec_) {
 	using clock = std::chrono::steady_clock;
 	const RunSpec& spec = *static_cast<const RunSpec*>(spec_);
-	if (!open_output(settings, hdr, writer)) return false;
-	b_size = (uint32_t)std::max(2, settings.b_size);
-	carry.clear(); write_failed = false; n_records = 0; n_pairs = 0;
-	c_level = settings.c_level; n_workers = std::min(std::max(1, settings.n_threads), 64);
+	if (!open_output(settings, hdr, out.writer)) return false;
+	out.b_size = (uint32_t)std::max(2, settings.b_size);
+	out.c_level = settings.c_level; out.rid = rid.data(); out.pos = pos.data(); out.n_records = 0;
+	n_records = 0; n_pairs = 0;
+	const int n_gpus = (int)ctxs.size();
+	const int n_workers = std::max(1, std::min(std::max(1, settings.n_threads), 64) / n_gpus);
 	const int mode = settings.single ? TWK_HIP_MODE_AUTO
 	               : settings.force_phased ? TWK_HIP_MODE_PHASED : (settings.forced_unphased ? TWK_HIP_MODE_UNPHASED : TWK_HIP_MODE_AUTO);
 	twk_hip_filters f{settings.minR2, settings.maxR2, settings.minDprime, settings.maxDprime, settings.minP};
-	// One process per GPU: shard k of n of every region (TWK_HIP_PART=k/n, set by the multi-GPU launcher).
-	uint32_t part = 0, n_parts = 1;
+	// Shards: GPU g of this process takes part k * n_gpus + g of n * n_gpus of every region, where k/n is
+	// this process's share of a multi-node (farm) run: TWK_HIP_PART=k/n (the reference's -c/-C idea,
+	// ld_balancing.h:23-80, with equal-area row bands; `concat` merges the processes' outputs).
+	uint32_t part0 = 0, n_procs = 1;
 	if (const char* e = std::getenv("TWK_HIP_PART")) {
 		unsigned k = 0, n = 1;
-		if (sscanf(e, "%u/%u", &k, &n) == 2 && n >= 1 && k < n) { part = k; n_parts = n; }
+		if (sscanf(e, "%u/%u", &k, &n) == 2 && n >= 1 && k < n) { part0 = k; n_procs = n; }
 		else { std::cerr << stamp("ERROR") << "Bad TWK_HIP_PART (want k/n): " << e << std::endl; return false; }
 	}
+	const uint32_t n_parts = n_procs * (uint32_t)n_gpus;
 	const auto t0 = clock::now();
-	uint64_t np = 0, nr = 0;
-	int rc = TWK_HIP_OK;
 	// Progress lines like the reference's ticker (ld_progress.h:40-86), every 30 s, driven by the
-	// engine's per-tile callback instead of a polling thread.
+	// engines' per-tile callbacks instead of a polling thread.
 	struct Progress {
-		twk_ld_impl* self; clock::time_point t0, last; uint64_t base = 0, total = 0; uint32_t n_s = 0; bool header = false;
+		twk_ld_impl* self; clock::time_point t0, last; uint64_t total = 0; uint32_t n_s = 0; bool header = false;
 		double every = 30.0;
+		std::mutex mu;
+		std::vector<uint64_t> done, base;         // per GPU: pairs finished in the current / earlier region calls
+		struct PerGpu { Progress* p; int g; };
 		static void cb(void* u, uint64_t pairs_done, uint32_t, uint32_t) {
-			Progress& p = *static_cast<Progress*>(u);
+			PerGpu& pg = *static_cast<PerGpu*>(u);
+			Progress& p = *pg.p;
+			std::lock_guard<std::mutex> lk(p.mu);
+			p.done[pg.g] = pairs_done;
 			const auto now = clock::now();
 			if (std::chrono::duration<double>(now - p.last).count() < p.every) return;
 			p.last = now;
@@ -379,41 +410,79 @@ bool twk_ld::twk_ld_impl::run(twk_ld_settings& settings, const Header& hdr, twk_
 				p.header = true;
 			}
 			const double sec = std::chrono::duration<double>(now - p.t0).count();
-			const uint64_t done = p.base + pairs_done;
+			uint64_t done = 0;
+			for (size_t g = 0; g < p.done.size(); ++g) done += p.done[g] + p.base[g];
 			const double frac = p.total ? (double)done / (double)p.total : 0.0;
+			uint64_t n_out;
+			{ std::lock_guard<std::mutex> lo(p.self->out.mu); n_out = p.self->out.n_records; }
 			std::cerr << stamp("PROGRESS") << std::setw(12) << elapsed_string(sec) << std::setw(15) << pretty(done)
-			          << std::setw(20) << pretty(done * p.n_s) << std::setw(15) << pretty(p.self->n_records)
+			          << std::setw(20) << pretty(done * p.n_s) << std::setw(15) << pretty(n_out)
 			          << std::setw(10) << frac * 100 << "%\t" << (frac > 0 ? elapsed_string(sec * (1 - frac) / frac) : std::string("-")) << std::endl;
 		}
 	} progress;
 	progress.self = this; progress.t0 = progress.last = t0; progress.n_s = n_samples;
+	progress.done.assign(n_gpus, 0); progress.base.assign(n_gpus, 0);
 	if (const char* e = std::getenv("TWK_HIP_PROGRESS_SECONDS")) progress.every = std::atof(e);      // test hook
 	progress.total = (spec.triangleA && spec.nA > 1 ? (uint64_t)spec.nA * (spec.nA - 1) / 2 : 0) + (spec.rectAB ? (uint64_t)spec.nA * spec.nB : 0);
-	if (n_parts > 1) progress.total /= n_parts;
-	twk_hip_set_progress(ctx, &Progress::cb, &progress);
-	struct ProgressOff { twk_hip_ctx* c; ~ProgressOff() { twk_hip_set_progress(c, nullptr, nullptr); } } progress_off{ctx};
-	if (spec.triangleA && spec.nA > 1) {
-		rc = twk_hip_ld_region(ctx, mode, &f, 0, spec.nA, 0, spec.nA, 1, part, n_parts, 0, spec.options, spec.l_window, sink, this, &np, &nr);
-		n_pairs += np;
-		progress.base = n_pairs;
+	if (n_procs > 1) progress.total /= n_procs;
+	std::vector<Progress::PerGpu> per_gpu(n_gpus);
+
+	// one driver thread per GPU: region calls for its shard, survivors into its own emitter
+	struct Driver {
+		twk_ld_impl* self; RecordEmitter emitter; bool write_failed = false; uint64_t pairs = 0; int rc = TWK_HIP_OK;
+		Driver(twk_ld_impl* s, int workers) : self(s), emitter(s->out, workers) {}
+		static int sink(void* user, const twk_hip_record* recs, uint64_t n) {
+			auto* d = static_cast<Driver*>(user);
+			if (!d->emitter.emit(recs, n, false)) { d->write_failed = true; return 1; }
+			return 0;
+		}
+	};
+	std::vector<std::unique_ptr<Driver>> drivers;
+	for (int g = 0; g < n_gpus; ++g) drivers.emplace_back(new Driver(this, n_workers));
+	auto drive = [&](int g) {
+		Driver& d = *drivers[g];
+		twk_hip_ctx* ctx = ctxs[g];
+		const uint32_t part = part0 * (uint32_t)n_gpus + (uint32_t)g;
+		per_gpu[g] = Progress::PerGpu{&progress, g};
+		twk_hip_set_progress(ctx, &Progress::cb, &per_gpu[g]);
+		uint64_t np = 0, nr = 0;
+		if (spec.triangleA && spec.nA > 1) {
+			d.rc = twk_hip_ld_region(ctx, mode, &f, 0, spec.nA, 0, spec.nA, 1, part, n_parts, 0, spec.options, spec.l_window, &Driver::sink, &d, &np, &nr);
+			d.pairs += np;
+			std::lock_guard<std::mutex> lk(progress.mu);
+			progress.base[g] += np; progress.done[g] = 0;
+		}
+		if (d.rc == TWK_HIP_OK && spec.rectAB && spec.nA && spec.nB) {
+			d.rc = twk_hip_ld_region(ctx, mode, &f, 0, spec.nA, spec.nA, spec.nB, 0, part, n_parts, 0, spec.options, spec.l_window, &Driver::sink, &d, &np, &nr);
+			d.pairs += np;
+		}
+		twk_hip_set_progress(ctx, nullptr, nullptr);
+		if (d.rc == TWK_HIP_OK && !d.write_failed && !d.emitter.emit(nullptr, 0, true)) d.write_failed = true;     // close the open blocks
+	};
+	if (n_gpus == 1) drive(0);
+	else {
+		std::vector<std::thread> th;
+		for (int g = 0; g < n_gpus; ++g) th.emplace_back(drive, g);
+		for (auto& t : th) t.join();
 	}
-	if (rc == TWK_HIP_OK && spec.rectAB && spec.nA && spec.nB) {
-		rc = twk_hip_ld_region(ctx, mode, &f, 0, spec.nA, spec.nA, spec.nB, 0, part, n_parts, 0, spec.options, spec.l_window, sink, this, &np, &nr);
-		n_pairs += np;
+	for (int g = 0; g < n_gpus; ++g) {
+		if (drivers[g]->write_failed) { std::cerr << stamp("ERROR", "WRITER") << "Failed to write output block!" << std::endl; return false; }
+		if (!hip_ok(ctxs[g], drivers[g]->rc, "twk_hip_ld_region")) return false;
+		n_pairs += drivers[g]->pairs;
 	}
-	if (write_failed) { std::cerr << stamp("ERROR", "WRITER") << "Failed to write output block!" << std::endl; return false; }
-	if (!hip_ok(ctx, rc, "twk_hip_ld_region")) return false;
-	if (!emit(nullptr, 0, true)) { std::cerr << stamp("ERROR", "WRITER") << "Failed to write output block!" << std::endl; return false; }
+	n_records = out.n_records;
 	const double sec = std::chrono::duration<double>(clock::now() - t0).count();
 	std::cerr << stamp("PROGRESS") << "Finished in " << elapsed_string(sec) << ". Variants: " << pretty(n_pairs) << ", genotypes: "
 	          << pretty(n_pairs * n_samples) << ", output: " << pretty(n_records) << std::endl;
 	std::cerr << stamp("PROGRESS") << pretty((uint64_t)(n_pairs / std::max(sec, 1e-9))) << " variants/s and "
 	          << pretty((uint64_t)((double)n_pairs * n_samples / std::max(sec, 1e-9))) << " genotypes/s" << std::endl;
-	twk_hip_timing tm;
-	if (twk_hip_timing_get(ctx, &tm) == TWK_HIP_OK)
-		std::cerr << stamp("LOG", "HIP") << "count kernel " << tm.count_ms << " ms in " << tm.count_launches << " launches, math kernel "
-		          << tm.stats_ms << " ms" << std::endl;
-	if (!writer.close()) { std::cerr << stamp("ERROR", "WRITER") << "Failed to write final block!" << std::endl; return false; }
+	for (int g = 0; g < n_gpus; ++g) {
+		twk_hip_timing tm;
+		if (twk_hip_timing_get(ctxs[g], &tm) == TWK_HIP_OK)
+			std::cerr << stamp("LOG", "HIP") << (n_gpus > 1 ? "GPU " + std::to_string(g) + ": " : std::string()) << "count kernel " << tm.count_ms << " ms in "
+			          << tm.count_launches << " launches, math kernel " << tm.stats_ms << " ms" << std::endl;
+	}
+	if (!out.writer.close()) { std::cerr << stamp("ERROR", "WRITER") << "Failed to write final block!" << std::endl; return false; }
 	return true;
 }
 
@@ -466,13 +535,15 @@ bool twk_ld::Compute() {
 	std::cerr << stamp("LOG", "PARAMS") << settings.GetString() << std::endl;
 	std::cerr << stamp("LOG") << "Performing: " << pretty(n_cmp) << " variant comparisons..." << std::endl;
 
-	DeviceCtx dc;
-	if (!create_device(dc)) return false;
-	if (!hip_ok(dc.ctx, twk_hip_set_problem(dc.ctx, n_samples, M), "twk_hip_set_problem")) return false;
+	const int n_gpus = gpus_from_env();
+	DeviceCtxs dc;
+	if (!create_devices(dc, n_gpus)) return false;
+	if (n_gpus > 1) std::cerr << stamp("LOG", "HIP") << "Using " << n_gpus << " GPUs: one driver thread each, equal-area row bands of the pair space..." << std::endl;
+	for (auto* c : dc.ctx) if (!hip_ok(c, twk_hip_set_problem(c, n_samples, M), "twk_hip_set_problem")) return false;
 	const auto t_load = clock::now();
 	const uint32_t T = (uint32_t)std::max(1, settings.n_threads);
 	std::cerr << stamp("LOG", "THREAD") << "Unpacking using " << T << " threads..." << std::endl;
-	if (!load_blocks(settings.in, reader, sel, n_samples, T, dc.ctx, mImpl->rid, mImpl->pos)) return false;
+	if (!load_blocks(settings.in, reader, sel, T, dc.ctx, mImpl->rid, mImpl->pos)) return false;
 	std::cerr << stamp("LOG") << "Unpacked and uploaded " << pretty(M) << " variants. "
 	          << elapsed_string(std::chrono::duration<double>(clock::now() - t_load).count()) << std::endl;
 
@@ -526,9 +597,10 @@ bool twk_ld::ComputeSingle(bool verbose, bool) {
 	const uint32_t nT = (uint32_t)targets.size(), nO = (uint32_t)others.size(), M = nT + nO;
 	if (verbose) std::cerr << stamp("LOG") << pretty(nT) << " target and " << pretty(nO) << " surrounding variants..." << std::endl;
 
-	DeviceCtx dc;
-	if (!create_device(dc)) return false;
-	if (!hip_ok(dc.ctx, twk_hip_set_problem(dc.ctx, n_samples, M), "twk_hip_set_problem")) return false;
+	DeviceCtxs dc;
+	if (!create_devices(dc, 1)) return false;
+	twk_hip_ctx* ctx = dc.ctx[0];
+	if (!hip_ok(ctx, twk_hip_set_problem(ctx, n_samples, M), "twk_hip_set_problem")) return false;
 	const size_t w64 = ((size_t)2 * n_samples + 63) / 64;
 	std::vector<uint64_t> data((size_t)M * w64), mask;
 	std::vector<twk_hip_variant_meta> meta(M);
@@ -545,7 +617,7 @@ bool twk_ld::ComputeSingle(bool verbose, bool) {
 		mm.ac = v.ac; mm.an = v.an; mm.pos = v.pos; mm.rid = v.rid; mm.missing = v.gt_missing ? 1 : 0; mm._pad = 0; mm.hwe = v.hwe;
 		mImpl->rid[i] = v.rid; mImpl->pos[i] = v.pos;
 	}
-	if (!hip_ok(dc.ctx, twk_hip_upload_bitvectors(dc.ctx, 0, M, data.data(), any_mask ? mask.data() : nullptr, w64, meta.data()),
+	if (!hip_ok(ctx, twk_hip_upload_bitvectors(ctx, 0, M, data.data(), any_mask ? mask.data() : nullptr, w64, meta.data()),
 	            "twk_hip_upload_bitvectors")) return false;
 	RunSpec spec;
 	spec.nA = nT; spec.nB = nO; spec.triangleA = true; spec.rectAB = true;

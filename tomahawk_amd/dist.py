@@ -4,7 +4,10 @@
 The data path needs no collective (every rank owns a band of rows of the pair triangle and holds
 all planes); the only exchange is the final gather of the surviving records to the writer rank,
 the multi-GPU counterpart of the reference's per-thread flush into one shared writer
-(lib/ld/ld_engine.cpp:1742-1802).
+(lib/ld/ld_engine.cpp:1742-1802).  Message shapes: an all_gather of one int64 count per
+rank, then count_r x 104 bytes from every rank r with survivors straight into rank dst's buffer -
+grouped point-to-point transfers (one ncclGroup of send/recv over the direct xGMI links), exact
+sizes, no padding to the largest rank.
 """
 from __future__ import annotations
 
@@ -18,8 +21,7 @@ from .hip import RECORD_DTYPE
 def gather_records(recs: np.ndarray, dst: int = 0, device: torch.device | None = None):
     """Gather variable-length RECORD_DTYPE arrays to rank `dst`.
 
-    all_gather of the counts (8 B per rank), then one gather of byte payloads padded to the
-    largest count.  Returns the concatenation (rank order) on `dst`, None elsewhere.
+    Returns the concatenation in rank order on `dst`, None elsewhere.
     """
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
@@ -27,20 +29,33 @@ def gather_records(recs: np.ndarray, dst: int = 0, device: torch.device | None =
     if world == 1:
         return recs
     device = device or torch.device("cpu")
-    cnt = torch.tensor([len(recs)], dtype=torch.int64, device=device)
-    counts = [torch.zeros_like(cnt) for _ in range(world)]
-    dist.all_gather(counts, cnt)
-    counts = [int(c.item()) for c in counts]
-    maxc = max(counts)
-    if maxc == 0:
-        return np.zeros(0, dtype=RECORD_DTYPE) if rank == dst else None
     item = RECORD_DTYPE.itemsize
-    payload = torch.zeros(maxc * item, dtype=torch.uint8, device=device)
-    if len(recs):
-        payload[: len(recs) * item] = torch.from_numpy(recs.view(np.uint8).reshape(-1).copy()).to(device)
-    gl = [torch.empty_like(payload) for _ in range(world)] if rank == dst else None
-    dist.gather(payload, gl, dst=dst)
+    cnt = torch.tensor([len(recs)], dtype=torch.int64, device=device)
+    gathered = [torch.zeros_like(cnt) for _ in range(world)]
+    dist.all_gather(gathered, cnt)
+    counts = [int(c.item()) for c in gathered]
+    total = sum(counts)
+    if total == 0:
+        return np.zeros(0, dtype=RECORD_DTYPE) if rank == dst else None
+
+    ops, out = [], None
+    if rank == dst:
+        # one receive buffer for everything, every rank's slice at its final place
+        out = torch.empty(total * item, dtype=torch.uint8, device=device)
+        off = 0
+        for r, c in enumerate(counts):
+            n = c * item
+            if c and r != dst:
+                ops.append(dist.P2POp(dist.irecv, out[off:off + n], r))
+            elif c:
+                out[off:off + n] = torch.from_numpy(recs.view(np.uint8).reshape(-1)).to(device)
+            off += n
+    elif len(recs):
+        payload = torch.from_numpy(recs.view(np.uint8).reshape(-1)).to(device)
+        ops.append(dist.P2POp(dist.isend, payload, dst))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
     if rank != dst:
         return None
-    parts = [g[: c * item].cpu().numpy().view(RECORD_DTYPE) for g, c in zip(gl, counts) if c]
-    return np.concatenate(parts) if parts else np.zeros(0, dtype=RECORD_DTYPE)
+    return out.cpu().numpy().view(RECORD_DTYPE)

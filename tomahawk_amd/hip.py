@@ -25,6 +25,10 @@ RECORD_DTYPE = np.dtype([("idxA", "<u4"), ("idxB", "<u4"), ("flags", "<u4"), ("_
                          ("R2", "<f8"), ("P", "<f8"), ("ChiSqFisher", "<f8"), ("ChiSqModel", "<f8")])
 assert RECORD_DTYPE.itemsize == 104
 
+# twk_hip_rle_desc: 16 bytes
+RLE_DESC_DTYPE = np.dtype([("offset", "<u8"), ("n_runs", "<u4"), ("width", "u1"), ("missing", "u1"), ("_pad", "<u2")])
+assert RLE_DESC_DTYPE.itemsize == 16
+
 # twk_hip_variant_meta: 32 bytes
 META_DTYPE = np.dtype([("ac", "<u4"), ("an", "<u4"), ("pos", "<u4"), ("rid", "<u4"),
                        ("missing", "<u4"), ("_pad", "<u4"), ("hwe", "<f8")])
@@ -89,6 +93,10 @@ def load_library() -> C.CDLL:
     lib.twk_hip_ctx_destroy.argtypes = [p]
     lib.twk_hip_set_problem.argtypes = [p, C.c_uint32, C.c_uint32]
     lib.twk_hip_upload_bitvectors.argtypes = [p, C.c_uint32, C.c_uint32, p, p, C.c_size_t, p]
+    lib.twk_hip_upload_rle.argtypes = [p, C.c_uint32, C.c_uint32, p, C.c_size_t, p, p]
+    lib.twk_hip_download_bitvectors.argtypes = [p, C.c_uint32, C.c_uint32, p, p, C.c_size_t]
+    lib.twk_hip_host_alloc.argtypes = [C.c_size_t, C.POINTER(p)]
+    lib.twk_hip_host_free.argtypes = [p]
     lib.twk_hip_generate_synthetic.argtypes = [p, C.c_uint64]
     lib.twk_hip_generate_synthetic_range.argtypes = [p, C.c_uint64, C.c_uint32]
     lib.twk_synth_bitvector.restype = C.c_uint32
@@ -186,6 +194,26 @@ class HipLd:
             mptr = mask.ctypes.data
         self._check(self._lib.twk_hip_upload_bitvectors(self._ctx, first, data.shape[0], data.ctypes.data, mptr,
                                                         data.shape[1], meta.ctypes.data), "twk_hip_upload_bitvectors")
+
+    def upload_rle(self, run_bytes: np.ndarray, desc: np.ndarray, meta: np.ndarray, first: int = 0):
+        """Run-length genotype words as stored in a .twk block (uint8 buffer) + RLE_DESC_DTYPE[count]:
+        expanded to bitvector + mask by a HIP kernel (twk_hip_upload_rle)."""
+        run_bytes = np.ascontiguousarray(run_bytes, dtype=np.uint8)
+        desc = np.ascontiguousarray(desc, dtype=RLE_DESC_DTYPE)
+        meta = np.ascontiguousarray(meta, dtype=META_DTYPE)
+        assert desc.shape == meta.shape
+        self._check(self._lib.twk_hip_upload_rle(self._ctx, first, len(desc), run_bytes.ctypes.data, run_bytes.size,
+                                                 desc.ctypes.data, meta.ctypes.data), "twk_hip_upload_rle")
+
+    def download(self, first: int = 0, count: int | None = None):
+        """-> (data, mask) uint64 [count, words64] in the reference layout, as held on the device."""
+        count = self.n_variants - first if count is None else count
+        w = words64(self.n_samples)
+        data = np.zeros((count, w), dtype=np.uint64)
+        mask = np.zeros((count, w), dtype=np.uint64)
+        self._check(self._lib.twk_hip_download_bitvectors(self._ctx, first, count, data.ctypes.data, mask.ctypes.data, w),
+                    "twk_hip_download_bitvectors")
+        return data, mask
 
     def generate_synthetic(self, seed: int = 42, first_variant: int = 0):
         """Synthetic benchmark input for global variants [first_variant, first_variant + n_variants)."""

@@ -40,6 +40,10 @@ def lib():
         L.twk_hwe_exact.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
         L.twk_hwe_exact.restype = C.c_double
         L.twk_file_header_literals.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_size_t]
+        L.twk_two_stream_open.restype = C.c_void_p
+        L.twk_two_stream_open.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, p, p, C.c_uint32, C.c_int, C.c_uint32, C.c_int]
+        L.twk_two_stream_append.argtypes = [p, p, C.c_uint64]
+        L.twk_two_stream_close.argtypes = [p, C.POINTER(C.c_uint64)]
         L.twk_ld_compute.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, p, p]
         _lib = L
@@ -163,3 +167,34 @@ def two_as_matrix(recs):
     for i, f in enumerate(("D", "Dprime", "R", "R2", "P", "ChiSqFisher", "ChiSqModel")):
         out[:, 9 + i] = recs[f]
     return out
+
+
+class TwoStream:
+    """The writer side of a calc run: engine records (tomahawk_amd.RECORD_DTYPE, variant indices) -> forward +
+    reverse blocks with the reference's flush rule -> a .two file.  What rank 0 of a multi-process run does
+    with the records gathered from the other ranks."""
+
+    def __init__(self, path, n_samples, rid, pos, n_contigs=1, c_level=1, b_size=10000, n_threads=4):
+        rid = np.ascontiguousarray(rid, dtype=np.uint32)
+        pos = np.ascontiguousarray(pos, dtype=np.uint32)
+        assert rid.shape == pos.shape
+        self._h = lib().twk_two_stream_open(path.encode(), n_samples, n_contigs, rid.ctypes.data, pos.ctypes.data, len(rid),
+                                            c_level, b_size, n_threads)
+        if not self._h:
+            raise RuntimeError(f"twk_two_stream_open failed for {path}")
+
+    def append(self, recs):
+        from .hip import RECORD_DTYPE
+        recs = np.ascontiguousarray(recs, dtype=RECORD_DTYPE)
+        rc = lib().twk_two_stream_append(self._h, recs.ctypes.data, len(recs))
+        if rc != 0:
+            raise RuntimeError(f"twk_two_stream_append failed: {rc}")
+
+    def close(self):
+        """-> number of records written (forward + reverse)."""
+        n = C.c_uint64()
+        h, self._h = self._h, None
+        rc = lib().twk_two_stream_close(h, C.byref(n))
+        if rc != 0:
+            raise RuntimeError(f"twk_two_stream_close failed: {rc}")
+        return n.value
