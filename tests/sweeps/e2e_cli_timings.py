@@ -1,0 +1,45 @@
+"""End-to-end `tomahawk calc` from a .twk on the GPU box: load (pread + zstd + device RLE inflate) vs compute.
+  python tests/sweeps/e2e_cli_timings.py [n_variants_at_1M=8192]
+Writes cohort-shaped inputs (hostlib.write_cohort_twk) under /tmp, runs the CLI, prints wall / load / engine times."""
+import os, re, subprocess, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from tomahawk_amd import hostlib as H
+
+CLI = H.CLI_PATH
+threads = min(os.cpu_count() or 8, 64)
+
+
+def run(tag, twk, args, env=None):
+    out = f"/tmp/e2e_{tag}.two"
+    t = time.time()
+    r = subprocess.run([CLI, "calc", "-i", twk, "-o", out] + args, capture_output=True, text=True, env=dict(os.environ, **(env or {})))
+    wall = time.time() - t
+    if r.returncode != 0:
+        print(tag, "FAILED", r.stderr[-400:]); return
+    log = r.stderr
+    load = re.search(r"Unpacked and uploaded .* variants\. (\S+)", log)
+    fin = re.search(r"Finished in (\S+)\. Variants: ([0-9,]+), genotypes: [0-9,]+, output: ([0-9,]+)", log)
+    rate = re.search(r"\] ([0-9,]+) variants/s", log)
+    eng = re.findall(r"count kernel ([0-9.e+]+) ms in (\d+) launches, math kernel ([0-9.e+]+) ms", log)
+    print(f"{tag}: wall {wall:.2f} s | load {load.group(1) if load else '?'} | compute+write {fin.group(1) if fin else '?'} | pairs {fin.group(2) if fin else '?'} | "
+          f"records {fin.group(3) if fin else '?'} | {rate.group(1) if rate else '?'} pairs/s in the compute phase | engine {eng}", flush=True)
+    try: os.remove(out)
+    except OSError: pass
+
+
+M1 = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+twk = f"/tmp/cohort_1m_{M1}.twk"
+if not os.path.exists(twk):
+    t = time.time(); H.write_cohort_twk(twk, 1_000_000, M1, seed=11, n_threads=threads, block_size=128)
+    print(f"wrote {twk}: {os.path.getsize(twk)/1e6:.0f} MB in {time.time()-t:.1f} s", flush=True)
+for args in (["-t", str(threads)], ["-u", "-t", str(threads)], ["-p", "-t", str(threads)]):
+    run(f"1M x {M1} cohort calc {' '.join(args[:1]) if args[0] != '-t' else '(default)'}", twk, args)
+run(f"1M x {M1} cohort calc -u, 2 driver threads on one GPU", twk, ["-u", "-t", str(threads)], {"TWK_HIP_GPUS": "2", "TWK_HIP_FORCE_DEVICE": "0"})
+
+twk2 = "/tmp/kg_2504_200k.twk"
+if not os.path.exists(twk2):
+    t = time.time(); H.write_cohort_twk(twk2, 2504, 200_000, seed=12, n_threads=threads, block_size=500, spacing=100)
+    print(f"wrote {twk2}: {os.path.getsize(twk2)/1e6:.0f} MB in {time.time()-t:.1f} s", flush=True)
+run("2504 x 200k cohort calc -p -w 1000000", twk2, ["-p", "-w", "1000000", "-t", str(threads)])
+run("2504 x 200k cohort calc -w 1000000 (default)", twk2, ["-w", "1000000", "-t", str(threads)])

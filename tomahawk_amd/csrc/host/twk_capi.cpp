@@ -1,5 +1,6 @@
 // Small C API over the host library for tests, tools and the benchmark harness
 // (ctypes-friendly; plain pointers and sizes).
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <memory>
@@ -79,6 +80,103 @@ int twk_file_write_synthetic_twk(const char* path, uint32_t n_samples, uint32_t 
 		for (uint32_t t = 0; t < T; ++t) th.emplace_back(job, t);
 		for (auto& t : th) t.join();
 		if (!w.write_block(blk)) return -3;
+	}
+	return w.close() ? 0 : -3;
+} catch (...) { return -9; }
+
+// A .twk with the shape of real cohort data, for the end-to-end and allele-frequency-spectrum measurements
+// (no counterpart in the reference; SURVEY 8(d)'s generator is iid): haplotypes are mosaics of `n_founders`
+// founder haplotypes whose assignment is redrawn, per haplotype with probability `p_switch`, at every file
+// block (so a block is a haplotype block); a fraction `rare_frac` of the variants is rare - ALT allele count
+// drawn from a 1/x spectrum between 1 and max_rare_af * 2N, carried by haplotypes of one founder - the rest
+// take their alleles from the founders (frequency U(0.05, 0.5)) plus `p_mut` noise; a fraction `miss_variants`
+// of the variants has `miss_rate` missing samples.  Counter-based randomness: the file depends on the arguments
+// only, not on the thread count.  Contigs "1".."n_contigs" of equal size, positions 1000 + spacing * i per contig.
+namespace {
+inline uint64_t cmix(uint64_t z) { z += 0x9E3779B97F4A7C15ull; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
+inline double cunit(uint64_t x) { return (double)(x >> 11) * (1.0 / 9007199254740992.0); }
+}
+int twk_file_write_cohort_twk(const char* path, uint32_t n_samples, uint32_t n_variants, uint64_t seed, uint32_t n_founders,
+                              double p_switch, double p_mut, double rare_frac, double max_rare_af, double miss_variants,
+                              double miss_rate, int phased, uint32_t n_contigs, uint32_t spacing, uint32_t block_size,
+                              int c_level, int n_threads) try {
+	if (!path || n_samples == 0 || n_variants == 0 || block_size == 0 || n_founders < 2 || n_founders > 255 || n_contigs == 0) return -1;
+	Header hdr;
+	hdr.literals = "##fileformat=VCFv4.2\n##source=tomahawk_amd cohort-shaped synthetic input seed=" + std::to_string(seed);
+	for (uint32_t s = 0; s < n_samples; ++s) hdr.samples.push_back("S" + std::to_string(s));
+	for (uint32_t c = 0; c < n_contigs; ++c) { Contig k; k.idx = c; k.name = std::to_string(c + 1); k.n_bases = 250000000; hdr.contigs.push_back(k); }
+	TwkWriter w;
+	if (!w.open(path, hdr, c_level)) return -2;
+	const size_t H = (size_t)2 * n_samples;
+	const uint32_t T = (uint32_t)std::max(1, n_threads);
+	const uint32_t per_contig = (n_variants + n_contigs - 1) / n_contigs;
+	std::vector<uint8_t> state(H);
+	for (size_t h = 0; h < H; ++h) state[h] = (uint8_t)(cmix(seed ^ (0xA5A5ull << 32) ^ h) % n_founders);
+	const uint64_t sw_thr = (uint64_t)(std::min(1.0, std::max(0.0, p_switch)) * 18446744073709551615.0);
+	const uint64_t mut_thr = (uint64_t)(std::min(1.0, std::max(0.0, p_mut)) * 18446744073709551615.0);
+	const uint64_t miss_thr = (uint64_t)(std::min(1.0, std::max(0.0, miss_rate)) * 18446744073709551615.0);
+	uint32_t blk_no = 0;
+	for (uint32_t v0 = 0; v0 < n_variants; ++blk_no) {
+		const uint32_t contig = v0 / per_contig;
+		const uint32_t nb = std::min(std::min(block_size, n_variants - v0), (contig + 1) * per_contig - v0);     // one contig per block
+		// redraw founder assignments for this block
+		{
+			std::vector<std::thread> th;
+			for (uint32_t t = 0; t < T; ++t) th.emplace_back([&, t] {
+				for (size_t h = H * t / T, e = H * (t + 1) / T; h < e; ++h) {
+					const uint64_t r = cmix(seed ^ ((uint64_t)(blk_no + 1) * 0xD6E8FEB86659FD93ull) ^ (h * 0x9E3779B97F4A7C15ull));
+					if (r < sw_thr) state[h] = (uint8_t)(cmix(r) % n_founders);
+				}
+			});
+			for (auto& t : th) t.join();
+		}
+		std::vector<size_t> founder_n(n_founders, 0);
+		for (size_t h = 0; h < H; ++h) ++founder_n[state[h]];
+		Block blk; blk.rid = contig; blk.rcds.resize(nb);
+		auto job = [&](uint32_t t) {
+			std::vector<int8_t> al(H);
+			for (uint32_t i = t; i < nb; i += T) {
+				const uint32_t v = v0 + i;
+				const uint64_t vk = cmix(seed + 0x632BE59BD9B4E019ull * (uint64_t)(v + 1));
+				const bool rare = cunit(cmix(vk ^ 1)) < rare_frac;
+				uint8_t fa[256];
+				uint64_t carrier_thr = 0; uint32_t rare_founder = 0;
+				if (rare) {
+					// 1/x spectrum: ac = exp(U(0, ln(max_ac)))
+					const double max_ac = std::max(1.0, max_rare_af * (double)H);
+					const double ac = std::exp(cunit(cmix(vk ^ 2)) * std::log(max_ac));
+					rare_founder = (uint32_t)(cmix(vk ^ 3) % n_founders);
+					const double q = std::min(1.0, ac / (double)std::max<size_t>(1, founder_n[rare_founder]));
+					carrier_thr = (uint64_t)(q * 18446744073709551615.0);
+				} else {
+					const double p = 0.05 + 0.45 * cunit(cmix(vk ^ 4));
+					uint32_t n1 = 0;
+					for (uint32_t f = 0; f < n_founders; ++f) { fa[f] = cunit(cmix(vk ^ (0x100 + f))) < p ? 1 : 0; n1 += fa[f]; }
+					if (n1 == 0) fa[cmix(vk ^ 5) % n_founders] = 1;
+					if (n1 == n_founders) fa[cmix(vk ^ 6) % n_founders] = 0;
+				}
+				const bool miss = cunit(cmix(vk ^ 7)) < miss_variants;
+				size_t n_alt = 0;
+				for (size_t h = 0; h < H; ++h) {
+					const uint64_t r = cmix(vk ^ (h * 0xD1342543DE82EF95ull));
+					int8_t a;
+					if (rare) a = (state[h] == rare_founder && r < carrier_thr) ? 1 : 0;
+					else a = (int8_t)(fa[state[h]] ^ (r < mut_thr ? 1 : 0));
+					al[h] = a; n_alt += (size_t)a;
+				}
+				if (n_alt == 0) { al[cmix(vk ^ 8) % H] = 1; }                        // keep every site polymorphic
+				if (n_alt == H) { al[cmix(vk ^ 9) % H] = 0; }
+				if (miss) for (uint32_t s2 = 0; s2 < n_samples; ++s2) if (cmix(vk ^ 0xABCDull ^ ((uint64_t)s2 << 20)) < miss_thr) { al[2 * (size_t)s2] = 2; al[2 * (size_t)s2 + 1] = 2; }
+				Variant& x = blk.rcds[i];
+				x.encode(al.data(), n_samples, phased != 0);
+				x.pos = 1000u + spacing * (v - contig * per_contig); x.rid = contig; x.hwe = 1.0; x.alleles = 0x12;
+			}
+		};
+		std::vector<std::thread> th;
+		for (uint32_t t = 0; t < T; ++t) th.emplace_back(job, t);
+		for (auto& t : th) t.join();
+		if (!w.write_block(blk)) return -3;
+		v0 += nb;
 	}
 	return w.close() ? 0 : -3;
 } catch (...) { return -9; }

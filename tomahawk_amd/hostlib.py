@@ -31,6 +31,9 @@ def lib():
         L.twk_file_write_twk.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, p, p, p, p, p, C.c_uint32, C.c_uint32, C.c_int]
         L.twk_file_write_synthetic_twk.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int, C.c_uint32,
                                                    C.c_int, C.c_int]
+        L.twk_file_write_cohort_twk.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_double, C.c_double,
+                                                C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_uint32, C.c_uint32,
+                                                C.c_uint32, C.c_int, C.c_int]
         L.twk_file_read_twk.argtypes = [C.c_char_p, p, p, p, p, p, p]
         L.twk_file_read_two.argtypes = [C.c_char_p, p, C.c_uint64, p, p]
         L.twk_file_write_two.argtypes = [C.c_char_p, p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
@@ -68,6 +71,17 @@ def write_synthetic_twk(path, n_samples, n_variants, seed=42, phased=False, bloc
                                             n_threads)
     if rc != 0:
         raise RuntimeError(f"twk_file_write_synthetic_twk failed: {rc}")
+
+
+def write_cohort_twk(path, n_samples, n_variants, seed=1, n_founders=12, p_switch=0.02, p_mut=0.0005, rare_frac=0.7,
+                     max_rare_af=0.01, miss_variants=0.0, miss_rate=0.0, phased=True, n_contigs=1, spacing=100, block_size=200,
+                     c_level=1, n_threads=8):
+    """A .twk shaped like real cohort data (founder mosaics, 1/x spectrum of rare variants, optional missing samples)."""
+    rc = lib().twk_file_write_cohort_twk(path.encode(), n_samples, n_variants, seed, n_founders, p_switch, p_mut, rare_frac,
+                                         max_rare_af, miss_variants, miss_rate, int(phased), n_contigs, spacing, block_size,
+                                         c_level, n_threads)
+    if rc != 0:
+        raise RuntimeError(f"twk_file_write_cohort_twk failed: {rc}")
 
 
 def read_twk(path):
