@@ -83,7 +83,12 @@ typedef struct {
 enum {
 	TWK_HIP_OPT_WINDOW      = 1, /* keep only same-contig pairs with |posA-posB| <= l_window (calc -w) */
 	TWK_HIP_OPT_KEEP_LOW_AC = 2  /* do not skip pairs with ac_A + ac_B <= 2: the single-site loop has the
-	                                skip commented out (ld_engine.cpp:2267-2269, 2293-2295)            */
+	                                skip commented out (ld_engine.cpp:2267-2269, 2293-2295)            */,
+	TWK_HIP_OPT_REF_COMPAT  = 4  /* reproduce what the reference's PhasedVectorized really returns for pairs with
+	                                missing genotypes when 2N is not a multiple of 128: its scalar tail adds the
+	                                (A ref, B alt) count to REFREF and swaps the two off-diagonal cells, and REFREF is
+	                                reduced by half the padding (ld_engine.cpp:596-609).  Off by
+	                                default: the engine returns the correct table. */
 };
 
 /* One surviving pair, device-compacted.  Field-for-field the payload of

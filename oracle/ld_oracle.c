@@ -80,6 +80,46 @@ void orc_count_phased(const uint64_t* a, const uint64_t* ma, const uint64_t* b, 
 	}
 }
 
+/* ---- K3 as compiled: PhasedVectorized, ld_engine.cpp:513-634 -----------------
+ * The SIMD body (128-bit lanes [0, vector_cycles), :555-581) counts the four masked cells correctly;
+ * the lanes it skips at the front / tail are all-zero in data and mask of both variants
+ * (core.cpp:394-435) and are credited to REFREF (:609), which is what they hold.  The scalar tail
+ * over the 64-bit words [byte_aligned_end, byte_width) (:596-603) adds popcnt(b_refalt) to REFREF
+ * instead of popcnt(b_refref), and its b_altref / b_refalt are (A alt, B ref) / (A ref, B alt) -
+ * the other way round from the body's PHASED_ALTREF / PHASED_REFALT (ld_engine.h:135-138) - while
+ * both feed the same counters.  Finally REFREF is reduced by phased_unbalanced_adjustment
+ * = (byte_width*64 - 2N)/2 (:61, :609).  All arithmetic is uint64 like the reference's (it wraps if
+ * the adjustment exceeds the count).  Only reached when either variant has missing genotypes
+ * (:515-517) and ac_A + ac_B is at or above the run-length threshold (:1925-1928). */
+void orc_count_phased_k3_as_is(const uint64_t* a, const uint64_t* ma, const uint64_t* b, const uint64_t* mb,
+                               uint32_t n_samples, uint64_t out[4]) {
+	const uint32_t byte_width = orc_words64(n_samples);                     /* :58 */
+	const uint32_t vector_cycles = 2 * n_samples / 128;                      /* :59 */
+	const uint32_t byte_aligned_end = vector_cycles * 2;                     /* :60 */
+	const uint64_t adjustment = ((uint64_t)byte_width * 64 - 2ull * n_samples) / 2;   /* :61 */
+	uint64_t refref = 0, simd_altref = 0, simd_refalt = 0, altalt = 0;
+	for (uint32_t k = 0; k < byte_width; ++k) {
+		const uint64_t m = ~((ma ? ma[k] : 0) | (mb ? mb[k] : 0));
+		const uint64_t x = a[k], y = b[k];
+		if (k < byte_aligned_end) {                                         /* body, ld_engine.h:131-142 */
+			refref      += (uint64_t)__builtin_popcountll(~x & ~y & m);
+			simd_altref += (uint64_t)__builtin_popcountll((x ^ y) & y & m);
+			simd_refalt += (uint64_t)__builtin_popcountll((x ^ y) & x & m);
+			altalt      += (uint64_t)__builtin_popcountll(x & y & m);
+		} else {                                                            /* scalar tail, :596-603 */
+			const uint64_t b_altref = (x ^ y) & x & m, b_refalt = (x ^ y) & y & m;
+			refref      += (uint64_t)__builtin_popcountll(b_refalt);
+			simd_refalt += (uint64_t)__builtin_popcountll(b_refalt);
+			simd_altref += (uint64_t)__builtin_popcountll(b_altref);
+			altalt      += (uint64_t)__builtin_popcountll(x & y & m);
+		}
+	}
+	out[0] = refref - adjustment;      /* alleleCounts[TWK_LD_REFREF], :609 */
+	out[1] = simd_refalt;              /* alleleCounts[TWK_LD_ALTREF] = counters[TWK_LD_SIMD_REFALT], :607 */
+	out[2] = simd_altref;              /* alleleCounts[TWK_LD_REFALT] = counters[TWK_LD_SIMD_ALTREF], :606 */
+	out[3] = altalt;
+}
+
 /* ---- K4: PhasedRunlength, ld_engine.cpp:1011-1091 ----------------------
  * index = (alleleA << 2) | alleleB per haplotype, alleles 0/1/2; only indices
  * 0,1,4,5 are read by PhasedMath.  A bitvector cannot tell 1|. from 1|1 with a
@@ -403,6 +443,8 @@ int orc_pair(const uint64_t* a, const uint64_t* ma, const orc_variant* A,
 		const uint32_t thresh_miss = (uint32_t)(0.0047 * n_samples + 5.2913); /* :1910 */
 		if (!vector_only && (A->gt_missing || B->gt_missing) && (A->ac + B->ac < thresh_miss))
 			orc_count_phased_rle(a, mA, b, mB, n_samples, c);              /* :1925-1926 */
+		else if (st->ref_compat && (A->gt_missing || B->gt_missing))
+			orc_count_phased_k3_as_is(a, mA, b, mB, n_samples, c);         /* :1928, as compiled */
 		else
 			orc_count_phased(a, mA, b, mB, n_samples, c);                  /* :1922-1923, :1928 */
 		return orc_phased_math(c, A, B, st, rec);

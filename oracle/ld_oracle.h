@@ -35,6 +35,9 @@ typedef struct {
 	double minR2, maxR2, minDprime, maxDprime, minP;
 	int force_phased, forced_unphased;
 	int keep_low_ac;   /* single-site loop: the ac skip is commented out (ld_engine.cpp:2267-2269) */
+	int ref_compat;    /* restate PhasedVectorized with its scalar-tail and pad-correction slips too
+	                      (ld_engine.cpp:596-609): what the reference really returns for
+	                      -p pairs with missing data when 2N is not a multiple of 128 */
 } orc_settings;
 
 /* twk1_two_t (include/core.h:826-833). */
@@ -70,6 +73,9 @@ void orc_count_phased(const uint64_t* a, const uint64_t* ma, const uint64_t* b, 
 /* Same table with the run-length kernel's semantics (PhasedRunlength,
  * ld_engine.cpp:1011-1091): per-allele exclusion of missing alleles and
  * c[1] = (A ref, B alt). */
+/* K3 PhasedVectorized exactly as compiled, slips included (ld_engine.cpp:513-634). */
+void orc_count_phased_k3_as_is(const uint64_t* a, const uint64_t* ma, const uint64_t* b, const uint64_t* mb,
+                               uint32_t n_samples, uint64_t out[4]);
 void orc_count_phased_rle(const uint64_t* a, const uint64_t* ma, const uint64_t* b, const uint64_t* mb,
                           uint32_t n_samples, uint64_t out[4]);
 /* 3x3 genotype table (UnphasedVectorized / UnphasedRunlength,

@@ -26,7 +26,7 @@ assert VARIANT_DTYPE.itemsize == 32 and RECORD_DTYPE.itemsize == 112
 class Settings(C.Structure):
     _fields_ = [("minR2", C.c_double), ("maxR2", C.c_double), ("minDprime", C.c_double),
                 ("maxDprime", C.c_double), ("minP", C.c_double), ("force_phased", C.c_int),
-                ("forced_unphased", C.c_int), ("keep_low_ac", C.c_int)]
+                ("forced_unphased", C.c_int), ("keep_low_ac", C.c_int), ("ref_compat", C.c_int)]
 
 
 _lib = None
@@ -49,6 +49,7 @@ def lib() -> C.CDLL:
         L.orc_build_bitvector.argtypes = [p, p, p, C.c_uint32, C.c_uint32, p, p]
         L.orc_count_phased.argtypes = [p, p, p, p, C.c_uint32, p]
         L.orc_count_phased_rle.argtypes = [p, p, p, p, C.c_uint32, p]
+        L.orc_count_phased_k3_as_is.argtypes = [p, p, p, p, C.c_uint32, p]
         L.orc_count_unphased.argtypes = [p, p, p, p, C.c_uint32, p]
         L.orc_fisher_exact.restype = C.c_double
         L.orc_fisher_exact.argtypes = [C.c_int] * 4 + [C.POINTER(C.c_double)] * 3
@@ -62,8 +63,8 @@ def lib() -> C.CDLL:
 
 
 def settings(minR2=0.1, maxR2=100.0, minDprime=0.0, maxDprime=100.0, minP=1.0, phased=False, unphased=False,
-             keep_low_ac=False) -> Settings:
-    return Settings(minR2, maxR2, minDprime, maxDprime, minP, int(phased), int(unphased), int(keep_low_ac))
+             keep_low_ac=False, ref_compat=False) -> Settings:
+    return Settings(minR2, maxR2, minDprime, maxDprime, minP, int(phased), int(unphased), int(keep_low_ac), int(ref_compat))
 
 
 def words64(n_samples: int) -> int:

@@ -42,6 +42,11 @@ CASES = {
     "n64_ld":       (64, 90, 107, dict(mosaic=True), 1, 30),
     "n500_ld":      (500, 100, 108, dict(mosaic=True, switch=0.01), 1, 40),
     "n128_ld_miss": (128, 80, 109, dict(mosaic=True, miss_rate=0.05, miss_variants=0.3), 1, 30),
+    # missing genotypes with 2N NOT a multiple of 128: -p goes through PhasedVectorized's scalar tail and padding
+    # correction, whose slips the reference's records carry; -u / default are unaffected
+    "n100_miss":    (100, 80, 110, dict(miss_rate=0.08, miss_variants=0.35, low_ac=4), 1, 30),       # 2N = 200: two tail words
+    "n70_ld_miss":  (70, 70, 111, dict(mosaic=True, miss_rate=0.06, miss_variants=0.3), 1, 30),      # 2N = 140: one tail word
+    "n161_miss":    (161, 60, 112, dict(miss_rate=0.05, miss_variants=0.4), 1, 30),                  # 2N = 322 = 2*128 + 66
 }
 
 

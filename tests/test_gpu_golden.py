@@ -14,7 +14,7 @@ from tomahawk_amd import hostlib
 pytestmark = pytest.mark.gpu
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
+CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "n*.npz")))      # cli_* belong to test_gpu_cli_golden.py
 MODES = {"p": T.MODE_PHASED, "u": T.MODE_UNPHASED, "d": T.MODE_AUTO}
 
 
@@ -36,10 +36,19 @@ def test_hip_equals_reference_records(hip, name, tag):
     al = z["alleles"]
     variants = O.variants_from_alleles(al, pos=z["pos"], rid=z["rid"], phase=1)
     util.upload(hip, al, variants)
-    got, npairs, _ = hip.ld_all(MODES[tag], T.Filters(minR2=0.0))
+    # -p, missing genotypes, 2N not a multiple of 128: the reference's records carry PhasedVectorized's tail / padding
+    # slips; the engine reproduces them on request (TWK_HIP_OPT_REF_COMPAT) and only then
+    N = al.shape[1]
+    compat = tag == "p" and bool((al == 2).any()) and (2 * N) % 128 != 0
+    got, npairs, _ = hip.ld_all(MODES[tag], T.Filters(minR2=0.0), window=T.OPT_REF_COMPAT if compat else 0)
     M = al.shape[0]
     assert npairs == M * (M - 1) // 2
     want = golden_as_oracle_records(z["rec_" + tag])
+    if compat:       # by default the engine returns the correct tables: equal to the oracle's, different from the reference's
+        fixed, _, _ = hip.ld_all(MODES[tag], T.Filters(minR2=0.0))
+        data, mask = O.bitvectors_from_alleles(al)
+        util.assert_records_match(fixed, O.all_pairs(data, mask, variants, N, O.settings(minR2=0.0, phased=True), vector_only=False), variants)
+        assert len(fixed) != len(got) or not np.array_equal(np.sort(fixed, order=["idxA", "idxB"])["cnt"], np.sort(got, order=["idxA", "idxB"])["cnt"])
     # includes which off-diagonal count sits in cnt[1] for pairs the reference ran through its run-length
     # kernel (missing data + low allele counts): the device mirrors that choice
     util.assert_records_match(got, want, variants)

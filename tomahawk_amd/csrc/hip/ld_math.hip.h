@@ -154,7 +154,7 @@ __device__ inline bool d_phased_math(uint64_t c0, uint64_t c1, uint64_t c4, uint
 	// cannot pass the reference's (rounded) test further down, and nothing else below has an effect.  Pairs
 	// inside the band minR2 * (1 +- 1e-6) always go through the reference's formula
 	// (tests: test_r2_screen_agrees_at_the_cutoff).
-	if (f.minR2 > 1e-6) {
+	if (f.minR2 > 1e-6 && c0 < (1ull << 62)) {       // (a wrapped REFREF of TWK_HIP_OPT_REF_COMPAT goes through the reference's own arithmetic)
 		const double dn = (double)c0 * (double)c5 - (double)c1 * (double)c4;
 		const double den = ((double)c0 + (double)c4) * ((double)c1 + (double)c5) * (((double)c0 + (double)c1) * ((double)c4 + (double)c5));
 		if (dn * dn < f.minR2 * (1.0 - 1e-6) * den) return false;
@@ -418,10 +418,41 @@ __device__ inline void d_cells_unphased(const TileView& t, uint32_t i, uint32_t 
 	c[0] = nvalid - (c[1] + c[2] + c[3] + c[4] + c[5] + c[6] + c[7] + c[8]);
 }
 
+// TWK_HIP_OPT_REF_COMPAT: turn the correct masked 2x2 table c = {REFREF, A alt/B ref, A ref/B alt, ALTALT} of
+// file-order variants A, B into what the reference's PhasedVectorized returns (ld_engine.cpp:513-634 as
+// compiled; oracle: orc_count_phased_k3_as_is).  Its SIMD body over the 128-bit lanes [0, 2N/128) is right;
+// its scalar tail over the remaining one or two 64-bit words adds popcnt(A ref, B alt) to REFREF instead of
+// the REFREF count, and feeds (A alt, B ref) / (A ref, B alt) to the opposite counters; REFREF is then
+// reduced by (ceil(2N/64)*64 - 2N)/2.  The tail is at most 128 bits per row: recomputed here from the raw rows.
+__device__ inline void d_k3_as_compiled(const uint32_t* __restrict__ raw, const uint32_t* __restrict__ rawmask, uint32_t Wp,
+                                        uint32_t n_samples, uint32_t A, uint32_t B, uint64_t c[4]) {
+	const uint64_t two_n = 2ull * n_samples;
+	const uint32_t byte_width = (uint32_t)((two_n + 63) / 64);              // 64-bit words per row
+	const uint32_t byte_aligned_end = (uint32_t)(two_n / 128) * 2;
+	const uint64_t adjustment = ((uint64_t)byte_width * 64 - two_n) / 2;
+	uint64_t t_ar = 0, t_ra = 0, t_rr = 0;                                   // tail: A alt/B ref, A ref/B alt, REFREF (real alleles)
+	for (uint32_t k = byte_aligned_end; k < byte_width; ++k) {
+		const size_t wa = (size_t)A * Wp + 2 * k, wb = (size_t)B * Wp + 2 * k;
+		const uint64_t x = (uint64_t)raw[wa] | (uint64_t)raw[wa + 1] << 32, y = (uint64_t)raw[wb] | (uint64_t)raw[wb + 1] << 32;
+		const uint64_t ma = (uint64_t)rawmask[wa] | (uint64_t)rawmask[wa + 1] << 32, mb = (uint64_t)rawmask[wb] | (uint64_t)rawmask[wb + 1] << 32;
+		const uint64_t m = ~(ma | mb);
+		const uint64_t bit0 = (uint64_t)k * 64;
+		const uint64_t live = two_n - bit0 >= 64 ? ~0ull : ((1ull << (two_n - bit0)) - 1);      // bits that are alleles
+		t_ar += (uint64_t)__popcll((x ^ y) & x & m);
+		t_ra += (uint64_t)__popcll((x ^ y) & y & m);
+		t_rr += (uint64_t)__popcll(~x & ~y & m & live);
+	}
+	const uint64_t c0 = c[0], c1 = c[1], c2 = c[2];
+	c[0] = (c0 - t_rr) + t_ra - adjustment;          // uint64 like the reference: wraps when the adjustment exceeds it
+	c[1] = (c1 - t_ar) + t_ra;
+	c[2] = (c2 - t_ra) + t_ar;
+}
+
 // ---- the math / filter / compaction kernel ---------------------------------------------------
 struct StatsParams {
 	TileView tv;
 	VariantMeta vm;
+	const uint32_t* raw; const uint32_t* rawmask; uint32_t Wp;   // raw rows (file order), for TWK_HIP_OPT_REF_COMPAT
 	uint32_t nA, nB;          // variants in the tile
 	uint32_t n_variants;      // total (pairs beyond it do not exist)
 	int diag;                 // keep only col > row (global indices)
@@ -474,6 +505,8 @@ void k_ld_stats(const StatsParams p) {
 				    p.vm.ac[A] + p.vm.ac[B] < (uint32_t)(0.0047 * p.tv.n_samples + 5.2913)) {
 					const uint64_t x = c[1]; c[1] = c[2]; c[2] = x;
 				}
+				else if ((p.window & TWK_HIP_OPT_REF_COMPAT) && (p.vm.missing[A] || p.vm.missing[B]) && p.rawmask)
+					d_k3_as_compiled(p.raw, p.rawmask, p.Wp, p.tv.n_samples, A, B, c);
 				keep = d_phased_math(c[0], c[1], c[2], c[3], p.vm, A, B, p.filt, &rec);
 			} else {
 				uint64_t c[9];

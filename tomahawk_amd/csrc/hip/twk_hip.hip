@@ -320,6 +320,7 @@ StatsParams make_stats(twk_hip_ctx* c, int set, const twk_hip_tile_desc& t, cons
 	p.tv.C = s.C; p.tv.ldc = tile_geometry(P, t).ldc; p.tv.rowpop = ps.rowpop; p.tv.kind = kind;
 	p.tv.n_samples = c->N; p.tv.a0 = t.rowA0; p.tv.b0 = t.rowB0; p.tv.ids = ps.ids;
 	p.vm = VariantMeta{c->d_ac, c->d_an, c->d_pos, c->d_rid, c->d_missing, c->d_hwe};
+	p.raw = c->raw; p.rawmask = c->rawmask; p.Wp = c->Wp;
 	p.nA = t.nA; p.nB = t.nB; p.n_variants = c->M;
 	p.diag = (t.diag && t.rowA0 == t.rowB0) ? 1 : 0;
 	p.phased_math = phased_math ? 1 : 0; p.auto_select = auto_select;

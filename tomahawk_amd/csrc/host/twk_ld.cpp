@@ -345,6 +345,12 @@ static bool load_blocks(const std::string& path, const TwkReader& reader, const 
 	return join_uploads();
 }
 
+// TWK_REF_COMPAT=1: reproduce two slips of the reference that change output bytes instead of the correct result -
+// PhasedVectorized's tail / padding arithmetic (TWK_HIP_OPT_REF_COMPAT, include/twk_hip.h) and scalc's dropping
+// of the last partial group of 100 neighbours.  (The window-mode and off-diagonal-chunk slips, SURVEY A.6 q8 / q9,
+// depend on the reference's block-pair visiting order and are not reproduced.)
+static bool ref_compat() { const char* e = std::getenv("TWK_REF_COMPAT"); return e && e[0] && e[0] != '0'; }
+
 static bool create_devices(DeviceCtxs& dc, int n_gpus) {
 	const char* force = std::getenv("TWK_HIP_FORCE_DEVICE");       // testing: several engine contexts on one GPU
 	const char* dev_env = std::getenv("TWK_HIP_DEVICE");
@@ -550,7 +556,7 @@ bool twk_ld::Compute() {
 	RunSpec spec;
 	spec.nA = bal.diag ? M : nL; spec.nB = bal.diag ? 0 : nR;
 	spec.triangleA = bal.diag; spec.rectAB = !bal.diag;
-	spec.options = settings.window ? TWK_HIP_OPT_WINDOW : 0; spec.l_window = (uint32_t)settings.l_window;
+	spec.options = (settings.window ? TWK_HIP_OPT_WINDOW : 0) | (ref_compat() ? TWK_HIP_OPT_REF_COMPAT : 0); spec.l_window = (uint32_t)settings.l_window;
 	if (!mImpl->run(settings, reader.hdr, dc.ctx, n_samples, &spec)) return false;
 	std::cerr << stamp("LOG", "PROGRESS") << "All done..." << elapsed_string(std::chrono::duration<double>(clock::now() - t_load).count()) << "!" << std::endl;
 	return true;
@@ -593,6 +599,7 @@ bool twk_ld::ComputeSingle(bool verbose, bool) {
 		}
 	}
 	if (targets.empty()) { std::cerr << "no data found for reference" << std::endl; return false; }
+	if (ref_compat()) others.resize(others.size() / 100 * 100);      // the reference keeps the neighbours in full groups of 100 only (ld.cpp:203-205, 239-244)
 	if (others.empty()) { std::cerr << "no surrounding variants" << std::endl; return false; }
 	const uint32_t nT = (uint32_t)targets.size(), nO = (uint32_t)others.size(), M = nT + nO;
 	if (verbose) std::cerr << stamp("LOG") << pretty(nT) << " target and " << pretty(nO) << " surrounding variants..." << std::endl;
@@ -621,7 +628,7 @@ bool twk_ld::ComputeSingle(bool verbose, bool) {
 	            "twk_hip_upload_bitvectors")) return false;
 	RunSpec spec;
 	spec.nA = nT; spec.nB = nO; spec.triangleA = true; spec.rectAB = true;
-	spec.options = TWK_HIP_OPT_KEEP_LOW_AC;      // the skip is commented out in CalculateSingle (:2267-2269)
+	spec.options = TWK_HIP_OPT_KEEP_LOW_AC | (ref_compat() ? TWK_HIP_OPT_REF_COMPAT : 0);      // the skip is commented out in CalculateSingle (:2267-2269)
 	return mImpl->run(settings, reader.hdr, dc.ctx, n_samples, &spec);
 }
 
