@@ -136,6 +136,8 @@ __device__ inline uint32_t d_common_flags(const VariantMeta& vm, uint32_t A, uin
 	return c;
 }
 
+#define TWK_N11_IN_PAD 0x80000000u     // internal: rec->_pad holds Fisher's n11 (see d_phased_math)
+
 // ---- PhasedMath: ld_engine.cpp:1162-1310 ------------------------------------------------
 // c0,c1,c4,c5 = alleleCounts[0],[1],[4],[5].  Returns true if the pair survives.
 __device__ inline bool d_phased_math(uint64_t c0, uint64_t c1, uint64_t c4, uint64_t c5,
@@ -180,6 +182,10 @@ __device__ inline bool d_phased_math(uint64_t c0, uint64_t c1, uint64_t c4, uint
 	rec->D = D; rec->Dprime = Dprime; rec->R = sqrt(R2); rec->R2 = R2; rec->P = 0;
 	rec->ChiSqFisher = T * R2; rec->ChiSqModel = 0;
 	rec->flags = d_common_flags(vm, A, B, rec->cnt, R2) | 1u;
+	// A REFREF count that wrapped (TWK_HIP_OPT_REF_COMPAT) no longer fits the double: the reference hands
+	// Fisher's test the uint64 narrowed to int (ld_engine.cpp:1222, fisher_math.cpp:231), i.e. its low 32
+	// bits; they ride in _pad to k_ld_fisher, which clears the marker bit again.
+	if (c0 >= (1ull << 53)) { rec->_pad = (uint32_t)c0; rec->flags |= TWK_N11_IN_PAD; }
 	return true;
 }
 
@@ -551,7 +557,9 @@ void k_ld_fisher(twk_hip_record* __restrict__ recs, const unsigned long long* __
 	for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
 	     i += (unsigned long long)gridDim.x * blockDim.x) {
 		twk_hip_record* r = recs + i;
-		const double both = d_fisher_two((int)round(r->cnt[0]), (int)round(r->cnt[2]), (int)round(r->cnt[1]), (int)round(r->cnt[3]));
+		int n11 = (int)round(r->cnt[0]);
+		if (r->flags & TWK_N11_IN_PAD) { n11 = (int)r->_pad; r->flags &= ~TWK_N11_IN_PAD; r->_pad = 0; }
+		const double both = d_fisher_two(n11, (int)round(r->cnt[2]), (int)round(r->cnt[1]), (int)round(r->cnt[3]));
 		r->P = both;
 		if (both > minP) r->idxA = TWK_DROPPED_RECORD;
 	}
