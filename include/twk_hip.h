@@ -88,7 +88,17 @@ enum {
 	                                missing genotypes when 2N is not a multiple of 128: its scalar tail adds the
 	                                (A ref, B alt) count to REFREF and swaps the two off-diagonal cells, and REFREF is
 	                                reduced by half the padding (ld_engine.cpp:596-609).  Off by
-	                                default: the engine returns the correct table. */
+	                                default: the engine returns the correct table. */,
+	TWK_HIP_OPT_R2_SCREEN   = 8  /* whole-triangle runs with filters.minR2 >= 0.001: decide from the two allele counts alone
+	                                which pairs can reach the r2 cut-off at all (|D| <= a(1-b) for minor allele frequencies
+	                                a <= b, so r2 <= a(1-b)/((1-a)b)), walk the variants in order of minor allele count and
+	                                never contract the tiles outside that band.  Same records as without it (pairs in the
+	                                band still go through the reference's formula); on cohort data, where most variants
+	                                are rare, most pairs fall outside the band.  This is the engine's answer to the
+	                                reference's O(carriers) list kernels for rare variants (twk_igt_list,
+	                                include/core.h:517-672, PhasedListVector ld_engine.cpp:185-267): not a faster way to
+	                                count a rare pair, a proof that it need not be counted.  Off by default at the ABI
+	                                (bench.py measures the full contraction); `tomahawk calc` switches it on. */
 };
 
 /* One surviving pair, device-compacted.  Field-for-field the payload of

@@ -306,3 +306,71 @@ def test_split_units_on_short_rows(hip, monkeypatch):
     plain, _, _ = hip.ld_all(T.MODE_AUTO, T.Filters(minR2=0.0))
     order = ["idxA", "idxB"]
     assert np.sort(whole, order=order).tobytes() == np.sort(plain, order=order).tobytes()
+
+
+# ---- the r2 screen (TWK_HIP_OPT_R2_SCREEN): same records, most of the contraction never done on cohort-shaped data ----
+def _cohort_alleles(M, N, seed, miss=False):
+    """Founder mosaics for a third of the variants, the rest rare with a 1/x allele-count spectrum carried by
+    haplotypes of one founder (LD among rare variants and with their founder's common ones)."""
+    rng = np.random.default_rng(seed)
+    al = util.mosaic_alleles(M, N, seed, n_founders=6, switch=0.01, mut=0.002)
+    H = 2 * N
+    rare = rng.random(M) < 0.65
+    flat = al.reshape(M, H)
+    for v in np.nonzero(rare)[0]:
+        ac = max(1, int(np.exp(rng.random() * np.log(0.02 * H))))
+        donors = np.nonzero(flat[max(0, v - 1)] == 1)[0] if v and rng.random() < 0.7 else np.arange(H)
+        if len(donors) < ac:
+            donors = np.arange(H)
+        flat[v] = 0
+        flat[v, rng.choice(donors, size=ac, replace=False)] = 1
+    al = flat.reshape(M, N, 2)
+    if miss:
+        for v in np.nonzero(rng.random(M) < 0.15)[0]:
+            al[v, rng.random(N) < 0.03, :] = 2
+            if not (al[v] == 2).any():
+                al[v, 0, :] = 2
+    return al
+
+
+@pytest.mark.parametrize("mode,miss", [(T.MODE_PHASED, False), (T.MODE_UNPHASED, False), (T.MODE_AUTO, False), (T.MODE_AUTO, True)])
+def test_r2_screen_gives_the_same_records(hip, mode, miss):
+    N, M = 1500, 2600
+    al = _cohort_alleles(M, N, 31 + int(miss), miss)
+    data, mask, variants = util.upload(hip, al)
+    order = ["idxA", "idxB"]
+    for minR2 in (0.1, 0.5, 0.004):
+        f = T.Filters(minR2=minR2)
+        hip.timing_reset()
+        plain, np0, _ = hip.ld_all(mode, f)
+        work0 = hip.timing()["row_pairs"]
+        hip.timing_reset()
+        scr, np1, nr1 = hip.ld_all(mode, f, window=T.OPT_R2_SCREEN)
+        work1 = hip.timing()["row_pairs"]
+        assert np1 == np0 == M * (M - 1) // 2 and nr1 == len(scr) == len(plain) > 50
+        a, b = np.sort(plain, order=order), np.sort(scr, order=order)
+        assert a.tobytes() == b.tobytes()
+        if minR2 >= 0.1 and not miss:
+            assert work1 < 0.75 * work0                   # tiles outside the band were not contracted
+    # the cut-off placed exactly on the r2 of existing pairs: the band is wide enough for the rounded test
+    r2 = np.unique(plain["R2"]); r2 = r2[(r2 > 0.004) & (r2 < 1)]
+    for x in r2[:: max(1, len(r2) // 6)][:6]:
+        for cut in (np.nextafter(x, 0.0), x, np.nextafter(x, 1.0)):
+            f = T.Filters(minR2=float(cut))
+            p2, _, _ = hip.ld_all(mode, f)
+            s2, _, _ = hip.ld_all(mode, f, window=T.OPT_R2_SCREEN)
+            assert np.sort(p2, order=order).tobytes() == np.sort(s2, order=order).tobytes()
+    # shards of the screened run partition it
+    f = T.Filters(minR2=0.1)
+    whole, _, _ = hip.ld_all(mode, f, window=T.OPT_R2_SCREEN)
+    parts = [hip.ld_all(mode, f, part=k, n_parts=3, window=T.OPT_R2_SCREEN) for k in range(3)]
+    assert sum(p[1] for p in parts) == M * (M - 1) // 2
+    assert np.sort(np.concatenate([p[0] for p in parts]), order=order).tobytes() == np.sort(whole, order=order).tobytes()
+    # and the oracle agrees with both (sampled: the oracle is scalar)
+    sub = np.sort(np.random.default_rng(5).choice(M, size=260, replace=False))
+    hip.set_problem(N, len(sub))
+    hip.upload(data[sub], util.to_hip_meta(variants[sub]), None if mask is None else mask[sub])
+    st = O.settings(minR2=0.1, phased=(mode == T.MODE_PHASED), unphased=(mode == T.MODE_UNPHASED))
+    want = O.all_pairs(data[sub], None if mask is None else mask[sub], variants[sub], N, st, vector_only=False)
+    got, _, _ = hip.ld_all(mode, T.Filters(minR2=0.1), window=T.OPT_R2_SCREEN)
+    util.assert_records_match(got, want, variants[sub], double_root=util.double_root_vetter(data[sub], None if mask is None else mask[sub], variants[sub], N))

@@ -459,6 +459,8 @@ struct StatsParams {
 	TileView tv;
 	VariantMeta vm;
 	const uint32_t* raw; const uint32_t* rawmask; uint32_t Wp;   // raw rows (file order), for TWK_HIP_OPT_REF_COMPAT
+	const uint32_t* col_hi; uint32_t hi_a0, hi_b0;               // r2 screen: the row at set position a reaches the columns
+	                                                             // below hi_b0 + col_hi[a - hi_a0] only (others were not contracted)
 	uint32_t nA, nB;          // variants in the tile
 	uint32_t n_variants;      // total (pairs beyond it do not exist)
 	int diag;                 // keep only col > row (global indices)
@@ -481,6 +483,7 @@ void k_ld_stats(const StatsParams p) {
 	if (i < p.nA && j < p.nB) {
 		const uint32_t sA = p.tv.a0 + i, sB = p.tv.b0 + j;       // positions in the plane set
 		bool todo = sA < p.n_variants && sB < p.n_variants && (!p.diag || sB > sA);
+		if (todo && p.col_hi && sB >= p.hi_b0 + p.col_hi[sA - p.hi_a0]) todo = false;
 		// A regrouped plane set (ids != null) can meet a pair in either order; the record always
 		// has the variant that comes first in the file as A, like the reference's i < j loops.
 		uint32_t A = sA, B = sB;

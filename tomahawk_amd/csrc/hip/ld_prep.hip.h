@@ -134,6 +134,14 @@ __global__ void k_build_phased_masked(const uint32_t* __restrict__ raw, const ui
 	}
 }
 
+// out[slot] = raw[ids[slot]]: a permuted copy of the raw rows (the allele-count-sorted phased plane set).
+__global__ void k_permute_rows(const uint32_t* __restrict__ raw, uint32_t Wp, uint32_t n_variants,
+                               uint32_t* __restrict__ out, const uint32_t* __restrict__ ids) {
+	const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+	if (w >= Wp) return;
+	for (uint32_t slot = blockIdx.y; slot < n_variants; slot += gridDim.y) out[(size_t)slot * Wp + w] = raw[(size_t)ids[slot] * Wp + w];
+}
+
 // Zero the bits of the raw layout that lie beyond allele 2N (defensive: the
 // reference guarantees it, core.cpp:361).
 __global__ void k_clear_tail(uint32_t* __restrict__ raw, uint32_t Wp, uint32_t n_samples, uint32_t n_variants) {

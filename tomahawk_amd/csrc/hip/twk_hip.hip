@@ -45,11 +45,18 @@ struct PlaneSet {
 // Default-mode runs (reference: phased math unless either variant has missing data)
 // then need the expensive 3-plane products only for the pairs that involve the leading group:
 // a triangle over it plus its rectangle against the rest.
-enum { PS_GROUPED = 4, N_PLANE_SETS = 5 };
-inline int set_kind(int set) { return set == PS_GROUPED ? (int)PK_UNPHASED_MASKED : set; }
+// ... and (TWK_HIP_OPT_R2_SCREEN) the plain phased / unphased planes in order of minor allele count, variants with
+// missing genotypes last: in that order the pairs whose r2 can reach the cut-off at all - a bound from the two
+// allele counts alone - are a band along the diagonal, and whole tiles outside it are never contracted.
+enum { PS_GROUPED = 4, PS_SORTED_P = 5, PS_SORTED_U = 6, N_PLANE_SETS = 7 };
+inline int set_kind(int set) {
+	return set == PS_GROUPED ? (int)PK_UNPHASED_MASKED : set == PS_SORTED_P ? (int)PK_PHASED : set == PS_SORTED_U ? (int)PK_UNPHASED : set;
+}
 // internal modes of the two stages of such a run
 enum { MODE_INT_AUTO_CLEAN = 0x10,     // phased math on the plain planes; pairs without missing data only
-       MODE_INT_GROUPED    = 0x11 };   // unphased math on the regrouped planes; every pair of the tile
+       MODE_INT_GROUPED    = 0x11,     // unphased math on the regrouped planes; every pair of the tile
+       MODE_INT_SORTED_P   = 0x12,     // phased math on the allele-count-sorted planes (variants without missing data)
+       MODE_INT_SORTED_U   = 0x13 };   // unphased math on the allele-count-sorted planes
 
 struct Slot {                      // one in-flight tile (double buffered)
 	uint32_t* C = nullptr; size_t C_words = 0;
@@ -65,7 +72,8 @@ struct Slot {                      // one in-flight tile (double buffered)
 };
 
 // Window mode: row variant a0 + r of a region reaches the columns [b0 + lo[r], b0 + hi[r]).
-struct ColRange { const uint32_t* lo = nullptr; const uint32_t* hi = nullptr; uint32_t a0 = 0, b0 = 0; };
+struct ColRange { const uint32_t* lo = nullptr; const uint32_t* hi = nullptr; uint32_t a0 = 0, b0 = 0;
+                  const uint32_t* d_hi = nullptr; };   // d_hi: device copy of hi (r2 screen: the math kernel skips what was not contracted)
 
 }  // namespace
 
@@ -94,6 +102,7 @@ struct twk_hip_ctx {
 	uint8_t* d_rle_desc = nullptr; size_t d_rle_desc_cap = 0;
 	uint32_t* d_rle_scratch = nullptr; size_t d_rle_scratch_cap = 0;
 	int* d_status = nullptr;
+	uint32_t* d_col_hi = nullptr; size_t d_col_hi_cap = 0;   // r2 screen: per-row column limit of the current region
 	char err[512] = {0};
 };
 
@@ -155,13 +164,33 @@ int ensure_planes(twk_hip_ctx* c, int set) {
 	ps.W_live = wide ? (uint32_t)((2ull * c->N + 31) / 32) : (c->N + 31) / 32;
 	ps.rows_alloc = round_up(c->M * P, TILE) + TILE;
 	if ((kind == PK_PHASED_MASKED || kind == PK_UNPHASED_MASKED) && !c->rawmask) return TWK_HIP_E_STATE;
-	if (kind == PK_PHASED) {
+	const bool sorted = set == PS_SORTED_P || set == PS_SORTED_U;
+	if (sorted) {
+		// order: minor allele count ascending (ties in file order), variants with missing genotypes last (file order)
+		const uint64_t T2 = 2ull * c->N;
+		ps.h_ids.resize(c->M);
+		for (uint32_t v = 0; v < c->M; ++v) ps.h_ids[v] = v;
+		auto key = [&](uint32_t v) -> uint64_t {
+			const twk_hip_variant_meta& m = c->h_meta[v];
+			if (m.missing || m.an) return ~0ull;
+			const uint64_t ac = std::min<uint64_t>(m.ac, T2);
+			return std::min(ac, T2 - ac);
+		};
+		std::stable_sort(ps.h_ids.begin(), ps.h_ids.end(), [&](uint32_t a, uint32_t b) { return key(a) < key(b); });
+		ps.n_front = 0;                                 // number of variants without missing genotypes (they lead the set)
+		for (uint32_t v = 0; v < c->M; ++v) if (key(ps.h_ids[v]) != ~0ull) ++ps.n_front;
+	}
+	if (kind == PK_PHASED && !sorted) {
 		ps.rows = c->raw; ps.owns_rows = false;       // the raw layout *is* the phased plane
 	} else {
 		const size_t bytes = (size_t)ps.rows_alloc * ps.W * 4;
 		HIPCHK(c, hipMalloc((void**)&ps.rows, bytes));
 		ps.owns_rows = true;
 		HIPCHK(c, hipMemsetAsync(ps.rows, 0, bytes, c->s_compute));
+		if (sorted) {
+			HIPCHK(c, hipMalloc((void**)&ps.ids, (size_t)c->M * 4));
+			HIPCHK(c, hipMemcpyAsync(ps.ids, ps.h_ids.data(), (size_t)c->M * 4, hipMemcpyHostToDevice, c->s_compute));
+		}
 		if (set == PS_GROUPED) {
 			ps.h_ids.clear(); ps.h_ids.reserve(c->M);
 			for (uint32_t v = 0; v < c->M; ++v) if (c->h_meta[v].an) ps.h_ids.push_back(v);
@@ -171,7 +200,9 @@ int ensure_planes(twk_hip_ctx* c, int set) {
 			HIPCHK(c, hipMemcpyAsync(ps.ids, ps.h_ids.data(), (size_t)c->M * 4, hipMemcpyHostToDevice, c->s_compute));
 		}
 		const dim3 blk(256), grd((ps.W + 255) / 256, std::min<uint32_t>(c->M, 65535u));
-		if (kind == PK_PHASED_MASKED)
+		if (set == PS_SORTED_P)
+			hipLaunchKernelGGL(k_permute_rows, grd, blk, 0, c->s_compute, c->raw, c->Wp, c->M, ps.rows, (const uint32_t*)ps.ids);
+		else if (kind == PK_PHASED_MASKED)
 			hipLaunchKernelGGL(k_build_phased_masked, grd, blk, 0, c->s_compute, c->raw, c->rawmask, c->Wp, c->M, ps.rows);
 		else
 			hipLaunchKernelGGL(k_build_unphased, grd, blk, 0, c->s_compute, c->raw,
@@ -312,7 +343,7 @@ int launch_count(twk_hip_ctx* c, int set, const twk_hip_tile_desc& t, Slot& s, i
 }
 
 StatsParams make_stats(twk_hip_ctx* c, int set, const twk_hip_tile_desc& t, const Slot& s, bool phased_math,
-                       int auto_select, const twk_hip_filters& f) {
+                       int auto_select, const twk_hip_filters& f, const ColRange* cr = nullptr) {
 	const PlaneSet& ps = c->planes[set];
 	const int kind = set_kind(set);
 	const int P = planes_per_variant(kind);
@@ -321,6 +352,7 @@ StatsParams make_stats(twk_hip_ctx* c, int set, const twk_hip_tile_desc& t, cons
 	p.tv.n_samples = c->N; p.tv.a0 = t.rowA0; p.tv.b0 = t.rowB0; p.tv.ids = ps.ids;
 	p.vm = VariantMeta{c->d_ac, c->d_an, c->d_pos, c->d_rid, c->d_missing, c->d_hwe};
 	p.raw = c->raw; p.rawmask = c->rawmask; p.Wp = c->Wp;
+	p.col_hi = cr ? cr->d_hi : nullptr; p.hi_a0 = cr ? cr->a0 : 0; p.hi_b0 = cr ? cr->b0 : 0;
 	p.nA = t.nA; p.nB = t.nB; p.n_variants = c->M;
 	p.diag = (t.diag && t.rowA0 == t.rowB0) ? 1 : 0;
 	p.phased_math = phased_math ? 1 : 0; p.auto_select = auto_select;
@@ -346,6 +378,8 @@ TilePlan plan_for(const twk_hip_ctx* c, int mode) {
 	case TWK_HIP_MODE_UNPHASED: p.set1 = plane_kind_for(c, false); p.phased1 = false; break;
 	case MODE_INT_AUTO_CLEAN:   p.select1 = 1; break;
 	case MODE_INT_GROUPED:      p.set1 = PS_GROUPED; p.phased1 = false; break;
+	case MODE_INT_SORTED_P:     p.set1 = PS_SORTED_P; break;
+	case MODE_INT_SORTED_U:     p.set1 = PS_SORTED_U; p.phased1 = false; break;
 	default:                    // AUTO on one tile: plain phased (pairs without missing) then masked unphased
 		if (c->any_missing) { p.select1 = 1; p.set2 = PK_UNPHASED_MASKED; }
 		break;
@@ -370,7 +404,7 @@ int enqueue_tile(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, const twk
 	HIPCHK(c, hipMemsetAsync(s.n_out, 0, sizeof(unsigned long long), c->s_compute));
 	rc = launch_count(c, kind1, t, s, 0, s.ev_c0, s.ev_c1, &s.row_pairs, cr); if (rc) return rc;
 	{
-		const StatsParams p = make_stats(c, kind1, t, s, phased, pl.select1, f);
+		const StatsParams p = make_stats(c, kind1, t, s, phased, pl.select1, f, cr);
 		hipLaunchKernelGGL(k_ld_stats, dim3((t.nB + 255) / 256, t.nA), dim3(256), 0, c->s_compute, p);
 		HIPCHK(c, hipGetLastError());
 	}
@@ -581,6 +615,7 @@ int twk_hip_ctx_destroy(twk_hip_ctx* c) {
 	if (c->d_rle_desc) (void)hipFree(c->d_rle_desc);
 	if (c->d_rle_scratch) (void)hipFree(c->d_rle_scratch);
 	if (c->d_status) (void)hipFree(c->d_status);
+	if (c->d_col_hi) (void)hipFree(c->d_col_hi);
 	if (c->s_compute) (void)hipStreamDestroy(c->s_compute);
 	if (c->s_copy) (void)hipStreamDestroy(c->s_copy);
 	delete c;
@@ -860,23 +895,57 @@ static int region_impl(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint3
                        uint32_t tile_variants, int32_t window, uint32_t l_window, twk_hip_record_sink sink,
                        void* user, uint64_t* n_pairs, uint64_t* n_records) {
 	const uint32_t* ids = nullptr;
-	if (mode == MODE_INT_GROUPED) {
-		int rc = ensure_planes(c, PS_GROUPED); if (rc) return rc;
-		ids = c->planes[PS_GROUPED].h_ids.data();
+	if (mode == MODE_INT_GROUPED || mode == MODE_INT_SORTED_P || mode == MODE_INT_SORTED_U) {
+		const int set = mode == MODE_INT_GROUPED ? PS_GROUPED : mode == MODE_INT_SORTED_P ? PS_SORTED_P : PS_SORTED_U;
+		int rc = ensure_planes(c, set); if (rc) return rc;
+		ids = c->planes[set].h_ids.data();
 	}
+	// r2 screen (TWK_HIP_OPT_R2_SCREEN): this region is a triangle over the leading, missing-free part of an
+	// allele-count-sorted set.  1: PhasedMath's r2, 2: UnphasedMath's.
+	const int screen = (mode == MODE_INT_SORTED_P) ? 1 : (mode == MODE_INT_SORTED_U) ? 2 : 0;
 	auto meta_at = [&](uint32_t i) -> const twk_hip_variant_meta& { return c->h_meta[ids ? ids[i] : i]; };
 	// ---- shard: a contiguous band of rows holding 1/n_parts of the region's pairs ----------
 	// Row i of a triangle has nA-1-i pairs, of a rectangle nB.  Equal-area bands, boundaries
 	// on multiples of 64 variants, derived identically (and without communication) by every rank.
 	// Replaces the reference's square-chunk farm partition (ld_balancing.h:59-78) for GPUs.
-	const bool windowed = (window & TWK_HIP_OPT_WINDOW) != 0;
+	const bool windowed = (window & TWK_HIP_OPT_WINDOW) != 0 || screen != 0;      // rows reach a column range only
 	// Window mode: the columns a row can reach, [lo[r], hi[r]) relative to b0 (same contig,
 	// |dpos| <= l_window; variants are sorted by (rid,pos) like every .twk, so both ends only
 	// move forward).  They drive the shard boundaries (equal in-window pairs), the tile edge and
 	// the column range of every row block; the exact test itself stays in the math kernel.
 	std::vector<uint32_t> lo, hi;
 	std::vector<uint64_t> cum;           // cum[r] = in-window pairs of rows [0, r)
-	if (windowed) {
+	if (screen) {
+		// With a and b the minor allele frequencies of two variants, a <= b, no 2x2 table with those margins has
+		// r2 above a(1-b) / ((1-a)b): |D| <= a(1-b), r2 = D^2 / (a(1-a)b(1-b)).  In order of minor allele count the
+		// pairs that can reach the cut-off are therefore a band above the diagonal: row r needs the columns
+		// (r, hi[r]) only, hi non-decreasing.  UnphasedMath estimates the haplotype frequency from genotypes and
+		// admits roots up to 1e-5 outside [minhap, maxhap] (ld_engine.h:37, ld_engine.cpp:1429-1558), so its |D|
+		// is bounded by a(1-b) + 1e-5.  The cut-off is lowered by a part in 1e6 against rounding in the
+		// reference's formula; pairs inside the band still go through that formula, so the survivors are the same.
+		lo.resize(nA); hi.resize(nA); cum.assign((size_t)nA + 1, 0);
+		const long double T2 = 2.0L * c->N, cut = (long double)f->minR2 * (1.0L - 1e-6L);
+		auto mac = [&](uint32_t i) -> long double {
+			const twk_hip_variant_meta& m = meta_at(i);
+			const long double ac = std::min<long double>(m.ac, T2);
+			return std::min(ac, T2 - ac);
+		};
+		auto reach = [&](long double ma, long double mb) -> bool {        // can a pair with these minor counts (ma <= mb) pass?
+			if (ma <= 0 || mb <= 0) return screen == 2;                     // a monomorphic site: PhasedMath drops it (D == 0)
+			if (screen == 1) return ma * (T2 - mb) >= cut * (T2 - ma) * mb;
+			const long double a = ma / T2, b = mb / T2, d = a * (1 - b) + 1e-5L;
+			return d * d >= cut * a * (1 - a) * b * (1 - b);
+		};
+		uint32_t h = 0;
+		for (uint32_t r = 0; r < nA; ++r) {
+			const long double mr = mac(a0 + r);
+			if (h < r + 1) h = std::min(r + 1, nB);
+			while (h < nB && reach(mr, mac(b0 + h))) ++h;
+			lo[r] = std::min(r + 1, nB);
+			hi[r] = std::max(h, lo[r]);
+			cum[r + 1] = cum[r] + (hi[r] - lo[r]);
+		}
+	} else if (windowed) {
 		lo.resize(nA); hi.resize(nA); cum.assign((size_t)nA + 1, 0);
 		uint32_t l = 0, h = 0;
 		for (uint32_t r = 0; r < nA; ++r) {
@@ -975,7 +1044,7 @@ static int region_impl(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint3
 		const uint64_t max_rows_b = std::min<uint64_t>(((2ull << 30) / 4) / (ra * TILE), 32768ull * Pmax / TILE);   // blocks
 		// window mode: the column range of a row block is already cut to what it can reach: one launch
 		// (or as few as the 2 GiB bound on C allows)
-		if (window & TWK_HIP_OPT_WINDOW)
+		if (windowed)
 			return std::max<uint32_t>(h, (uint32_t)std::min<uint64_t>(32768ull, max_rows_b * TILE / Pmax / 64 * 64));
 		uint32_t best = std::max(S, h); uint64_t best_cost = ~0ull;
 		for (uint32_t sc = round_up(h, 64); sc <= 32768; sc += 64) {
@@ -1025,6 +1094,16 @@ static int region_impl(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint3
 	const size_t n = mine.size();
 	ColRange col_range;
 	if (windowed) { col_range.lo = lo.data(); col_range.hi = hi.data(); col_range.a0 = a0; col_range.b0 = b0; }
+	if (screen && nA) {
+		if (c->d_col_hi_cap < nA) {
+			if (c->d_col_hi) (void)hipFree(c->d_col_hi);
+			c->d_col_hi = nullptr; c->d_col_hi_cap = 0;
+			HIPCHK(c, hipMalloc((void**)&c->d_col_hi, (size_t)nA * 4));
+			c->d_col_hi_cap = nA;
+		}
+		HIPCHK(c, hipMemcpy(c->d_col_hi, hi.data(), (size_t)nA * 4, hipMemcpyHostToDevice));
+		col_range.d_hi = c->d_col_hi;
+	}
 	// two-deep software pipeline over the tiles of this shard
 	while (done < n) {
 		while (issued < n && issued < done + 2) {
@@ -1050,7 +1129,8 @@ static int region_impl(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint3
 		++done;
 		if (c->progress_cb && !c->progress_muted) c->progress_cb(c->progress_user, tot_pairs, (uint32_t)done, (uint32_t)n);
 	}
-	if (windowed) tot_pairs = cum[r1] - cum[r0];       // pairs inside the window: the ones the math evaluates
+	if (screen) tot_pairs = band_pairs_before(r1, nA, nB, true) - band_pairs_before(r0, nA, nB, true);   // every pair of the band is decided
+	else if (windowed) tot_pairs = cum[r1] - cum[r0];       // pairs inside the window: the ones the math evaluates
 	if (n_pairs) *n_pairs = tot_pairs;
 	if (n_records) *n_records = tot_recs;
 	return TWK_HIP_OK;
@@ -1066,6 +1146,12 @@ int twk_hip_ld_region(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint32
 	if (triangle && (a0 != b0 || nB < nA)) return TWK_HIP_E_INVALID;
 	HIPCHK(c, hipSetDevice(c->device));
 	const bool whole = triangle && a0 == 0 && nA == c->M && nB == c->M;
+	// TWK_HIP_OPT_R2_SCREEN: whole-triangle runs with an r2 cut-off worth the name, outside window mode (which
+	// already prunes by position, in an order the allele-count sort would destroy)
+	const bool screen = (window & TWK_HIP_OPT_R2_SCREEN) && whole && !(window & TWK_HIP_OPT_WINDOW) && f->minR2 >= 1e-3 && c->M >= 2;
+	if (screen && !c->any_missing && (mode == TWK_HIP_MODE_PHASED || mode == TWK_HIP_MODE_AUTO || mode == TWK_HIP_MODE_UNPHASED))
+		return region_impl(c, mode == TWK_HIP_MODE_UNPHASED ? MODE_INT_SORTED_U : MODE_INT_SORTED_P, f, 0, c->M, 0, c->M, 1, part, n_parts,
+		                   tile_variants, window, l_window, sink, user, n_pairs, n_records);
 	if (!(mode == TWK_HIP_MODE_AUTO && c->any_missing && whole))
 		return region_impl(c, mode, f, a0, nA, b0, nB, triangle, part, n_parts, tile_variants, window, l_window,
 		                   sink, user, n_pairs, n_records);
@@ -1076,6 +1162,14 @@ int twk_hip_ld_region(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint32
 	int rc = ensure_planes(c, PS_GROUPED); if (rc) return rc;
 	const uint32_t nG = c->planes[PS_GROUPED].n_front;
 	uint64_t pairs = 0, recs = 0, p2 = 0, r2 = 0;
+	if (screen) {
+		// the pairs without missing data: a screened triangle over the missing-free head of the sorted set;
+		// the stages below then cover every pair that involves a variant with missing data
+		rc = ensure_planes(c, PS_SORTED_P); if (rc) return rc;
+		const uint32_t nC = c->planes[PS_SORTED_P].n_front;
+		if (nC >= 2) rc = region_impl(c, MODE_INT_SORTED_P, f, 0, nC, 0, nC, 1, part, n_parts, tile_variants, window, l_window,
+		                              sink, user, &pairs, &recs);
+	} else
 	rc = region_impl(c, MODE_INT_AUTO_CLEAN, f, 0, c->M, 0, c->M, 1, part, n_parts, tile_variants, window, l_window,
 	                 sink, user, &pairs, &recs);
 	struct Mute { twk_hip_ctx* c; ~Mute() { c->progress_muted = false; } } mute{c};
@@ -1084,11 +1178,13 @@ int twk_hip_ld_region(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint32
 		rc = region_impl(c, MODE_INT_GROUPED, f, 0, nG, 0, nG, 1, part, n_parts, tile_variants, window, l_window,
 		                 sink, user, &p2, &r2);
 		recs += r2;
+		if (screen) pairs += p2;               // the screened stage only counted the pairs without missing data
 	}
 	if (rc == TWK_HIP_OK && nG >= 1 && nG < c->M) {
 		rc = region_impl(c, MODE_INT_GROUPED, f, 0, nG, nG, c->M - nG, 0, part, n_parts, tile_variants, window, l_window,
 		                 sink, user, &p2, &r2);
 		recs += r2;
+		if (screen) pairs += p2;
 	}
 	if (n_pairs) *n_pairs = pairs;          // every pair of the shard is evaluated exactly once
 	if (n_records) *n_records = recs;

@@ -351,6 +351,9 @@ static bool load_blocks(const std::string& path, const TwkReader& reader, const 
 // depend on the reference's block-pair visiting order and are not reproduced.)
 static bool ref_compat() { const char* e = std::getenv("TWK_REF_COMPAT"); return e && e[0] && e[0] != '0'; }
 
+// The r2 screen (TWK_HIP_OPT_R2_SCREEN) is on unless TWK_HIP_NO_SCREEN=1 (A/B comparisons; the records are the same).
+static bool r2_screen() { const char* e = std::getenv("TWK_HIP_NO_SCREEN"); return !(e && e[0] && e[0] != '0'); }
+
 static bool create_devices(DeviceCtxs& dc, int n_gpus) {
 	const char* force = std::getenv("TWK_HIP_FORCE_DEVICE");       // testing: several engine contexts on one GPU
 	const char* dev_env = std::getenv("TWK_HIP_DEVICE");
@@ -556,7 +559,8 @@ bool twk_ld::Compute() {
 	RunSpec spec;
 	spec.nA = bal.diag ? M : nL; spec.nB = bal.diag ? 0 : nR;
 	spec.triangleA = bal.diag; spec.rectAB = !bal.diag;
-	spec.options = (settings.window ? TWK_HIP_OPT_WINDOW : 0) | (ref_compat() ? TWK_HIP_OPT_REF_COMPAT : 0); spec.l_window = (uint32_t)settings.l_window;
+	spec.options = (settings.window ? TWK_HIP_OPT_WINDOW : 0) | (ref_compat() ? TWK_HIP_OPT_REF_COMPAT : 0) | (r2_screen() ? TWK_HIP_OPT_R2_SCREEN : 0);
+	spec.l_window = (uint32_t)settings.l_window;
 	if (!mImpl->run(settings, reader.hdr, dc.ctx, n_samples, &spec)) return false;
 	std::cerr << stamp("LOG", "PROGRESS") << "All done..." << elapsed_string(std::chrono::duration<double>(clock::now() - t_load).count()) << "!" << std::endl;
 	return true;

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libtwk_hip.so")
 
 MODE_PHASED, MODE_UNPHASED, MODE_AUTO = 1, 2, 3
 # option bits of twk_hip_tile_desc.window / the `window` argument of ld_all / ld_region (TWK_HIP_OPT_*)
-OPT_WINDOW, OPT_KEEP_LOW_AC, OPT_REF_COMPAT = 1, 2, 4
+OPT_WINDOW, OPT_KEEP_LOW_AC, OPT_REF_COMPAT, OPT_R2_SCREEN = 1, 2, 4, 8
 E_OVERFLOW = -4
 
 # twk_hip_record (include/twk_hip.h): 104 bytes
