@@ -22,7 +22,7 @@ HOST_LIB_SRC := $(filter-out %/calc_main.cpp,$(HOST_SRC))
 HOST_DEPS := $(wildcard $(PKG)/csrc/host/*.h) include/twk_hip.h
 CXXFLAGS := -O2 -std=c++17 -fPIC -Wall -pthread -Iinclude -I$(PKG)/csrc/host
 
-.PHONY: all hip host cli oracle tools clean
+.PHONY: all hip host cli oracle tools clean asan asan-test
 all: hip host cli oracle
 
 hip: $(LIBDIR)/libtwk_hip.so
@@ -48,6 +48,19 @@ build/%: $(PKG)/csrc/tools/%.hip $(HIP_DEPS)
 	@mkdir -p build
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off $< -o $@
 
+# AddressSanitizer + UBSan build of the host side (the GPU side cannot be sanitised on this pool): same sources,
+# separate output directory; `make asan-test` runs the CPU test suite against it (python is not instrumented, so
+# libasan is preloaded; leak checking is off because the interpreter and the HIP runtime never free their arenas).
+ASAN_DIR := $(PKG)/lib_asan
+SANFLAGS := -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -fno-sanitize-recover=undefined
+asan: $(LIBDIR)/libtwk_hip.so
+	@mkdir -p $(ASAN_DIR)
+	$(CXX) $(CXXFLAGS) $(SANFLAGS) -shared $(HOST_LIB_SRC) -o $(ASAN_DIR)/libtomahawk_amd.so -L$(LIBDIR) -ltwk_hip $(ZSTD_LIB) $(ZLIB) -Wl,-rpath,'$$ORIGIN/../lib'
+	$(CXX) $(CXXFLAGS) $(SANFLAGS) $(PKG)/csrc/host/calc_main.cpp -o $(ASAN_DIR)/tomahawk -L$(ASAN_DIR) -ltomahawk_amd -L$(LIBDIR) -ltwk_hip $(ZSTD_LIB) -Wl,-rpath,'$$ORIGIN:$$ORIGIN/../lib'
+asan-test: asan
+	LD_PRELOAD=$$($(CXX) -print-file-name=libasan.so):$$($(CXX) -print-file-name=libubsan.so) ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1 \
+	TWK_HOST_LIB=$(abspath $(ASAN_DIR))/libtomahawk_amd.so TWK_CLI=$(abspath $(ASAN_DIR))/tomahawk python -m pytest tests -x -q -m "not gpu"
+
 clean:
-	rm -rf $(LIBDIR) $(BINDIR) build
+	rm -rf $(LIBDIR) $(BINDIR) $(ASAN_DIR) build
 	$(MAKE) -C oracle clean

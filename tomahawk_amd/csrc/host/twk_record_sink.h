@@ -104,7 +104,7 @@ private:
 		f.D = r.D; f.Dprime = r.Dprime; f.R = r.R; f.R2 = r.R2; f.P = r.P;
 		f.ChiSqFisher = r.ChiSqFisher; f.ChiSqModel = r.ChiSqModel;
 		v = f;                           // reverse copy swaps (rid,pos) only; cnt is NOT transposed (:1292-1298)
-		std::swap(v.ridA, v.ridB); std::swap(v.packA, v.packB);
+		v.ridA = f.ridB; v.ridB = f.ridA; v.packA = f.packB; v.packB = f.packA;      // (no references into the packed struct)
 	}
 };
 

@@ -8,8 +8,9 @@ import numpy as np
 from .hip import META_DTYPE
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libtomahawk_amd.so")
-CLI_PATH = os.path.join(_HERE, "bin", "tomahawk")
+# TWK_HOST_LIB / TWK_CLI: run the same tests against another build of the host side (`make asan-test`)
+LIB_PATH = os.environ.get("TWK_HOST_LIB") or os.path.join(_HERE, "lib", "libtomahawk_amd.so")
+CLI_PATH = os.environ.get("TWK_CLI") or os.path.join(_HERE, "bin", "tomahawk")
 
 # twk1_two_t as serialised (reference lib/core.cpp:470-490): 106 bytes, packed
 TWO_DTYPE = np.dtype({"names": ["controller", "ridA", "ridB", "packA", "packB", "cnt", "D", "Dprime", "R", "R2", "P",
