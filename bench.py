@@ -65,7 +65,10 @@ def cpu_baseline(n_samples, mode, seed, log):
     """Time the reference's SSE4.2 calc path (oracle/_ref) on a bounded sample of the same workload."""
     from oracle import oracle as O
     from tomahawk_amd import hostlib
-    cores = os.cpu_count() or 1
+    # 32 threads maximise the reference on the 256-thread GPU-box host (tests/sweeps/cpu_baseline_threads.py,
+    # profiles/r02_cpu_baseline_threads.txt: 223 k pairs/s at 32 threads, 203 k at 64, 187 k at 128, 137 k at 256 -
+    # its block-pair ticket is a spinlock and its output path a second one)
+    cores = min(os.cpu_count() or 1, 32)
     if not O.have_ref():
         return None
     # ~15 s of CPU work: SURVEY 6: 5.4 G (unphased) / 52 G (phased) genotype-pairs/s/core

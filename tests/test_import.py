@@ -228,3 +228,128 @@ def test_import_input_variants(tmp_path):
     assert cnt["sites"] == 0 and cnt["written"] == 0
     n, data, _, _, _ = read_back(out)
     assert n == N and len(data) == 0
+
+
+# ---- BCF2 input ------------------------------------------------------------------------------------------------------
+def _typed_int(v):
+    import struct
+    if -120 <= v <= 127:
+        return bytes([0x11]) + struct.pack("<b", v)
+    if -32000 <= v <= 32767:
+        return bytes([0x12]) + struct.pack("<h", v)
+    return bytes([0x13]) + struct.pack("<i", v)
+
+
+def _typed_str(s):
+    b = s.encode()
+    return (bytes([len(b) << 4 | 7]) if len(b) < 15 else bytes([0xF7]) + _typed_int(len(b))) + b
+
+
+def write_bcf(path, header_lines, sample_names, records, gz=True):
+    """A BCF2.2 file (BCF2 spec, section 6) from scratch.  records: dicts with chrom (index into the ##contig lines), pos
+    (1-based), ref, alts (list), fmt (list of (FORMAT id, per-sample lists of ints)) where GT values are given as
+    (allele or None, phased) tuples per ploidy position, None for a shorter ploidy."""
+    import struct
+    text = "\n".join(header_lines) + "\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(sample_names) + "\n"
+    ids = ["PASS"]
+    for l in header_lines:
+        if l.startswith(("##FILTER=<", "##INFO=<", "##FORMAT=<")):
+            i = l[l.index("ID=") + 3:].split(",")[0].rstrip(">")
+            if i not in ids:
+                ids.append(i)
+    out = b"BCF\x02\x02" + struct.pack("<I", len(text) + 1) + text.encode() + b"\0"
+    n_s = len(sample_names)
+    for r in records:
+        shared = struct.pack("<iiifII", r["chrom"], r["pos"] - 1, len(r["ref"]), float("nan"),
+                             (1 + len(r["alts"])) << 16 | 0, len(r.get("fmt", [])) << 24 | n_s)
+        shared += _typed_str("rs1") + _typed_str(r["ref"]) + b"".join(_typed_str(a) for a in r["alts"]) + bytes([0x00])   # no FILTER
+        indiv = b""
+        for name, vals in r.get("fmt", []):
+            indiv += _typed_int(ids.index(name))
+            if name == "GT":
+                ploidy = max(len(v) for v in vals)
+                wide = r.get("gt_int16", False)
+                indiv += bytes([ploidy << 4 | (2 if wide else 1)])
+                for v in vals:
+                    for k in range(ploidy):
+                        if k >= len(v):
+                            x = -32767 if wide else -127                 # vector end: this sample has fewer alleles
+                        else:
+                            a, ph = v[k]
+                            x = ((a + 1) if a is not None else 0) << 1 | int(bool(ph))
+                        indiv += struct.pack("<h" if wide else "<b", x)
+            else:
+                indiv += bytes([0x11]) + bytes(int(x) & 0xFF for x in vals)
+        out += struct.pack("<II", len(shared), len(indiv)) + shared + indiv
+    with (gzip.open(path, "wb") if gz else open(path, "wb")) as f:
+        f.write(out)
+
+
+@pytest.mark.parametrize("gz", [True, False])
+def test_import_bcf_equals_import_vcf(tmp_path, gz):
+    """`tomahawk import` reads BCF2 (the reference reads it through htslib): the same sites given as VCF text and as
+    BCF produce the same .twk - genotypes, phase, counts, filters, site order."""
+    N, M = 37, 60
+    rng = np.random.default_rng(8)
+    al = util.random_alleles(M, N, 8, miss_rate=0.1, miss_variants=0.3)
+    pos = np.sort(rng.choice(np.arange(100, 5000), size=M, replace=False))
+    chrom = (np.arange(M) >= 40).astype(int)
+    pos[40:] = np.sort(pos[40:])
+    phased = rng.random(M) < 0.7
+    contigs = ("20", "21")
+    vcf, bcf = str(tmp_path / "in.vcf"), str(tmp_path / ("in.bcf" if gz else "in.raw.bcf"))
+    ref_alt = [(BASES[v % 4], BASES[(v + 1) % 4]) for v in range(M)]
+    ref_alt[5] = ("A", "ACGTACGTACGTACGTACGT")           # not a SNP (and a string longer than 14: the long-length form)
+    raw = [(10, "20\t%d\trsX\tA\tC,G\t.\tPASS\tAC=1\tGT\t" % (pos[10] - 1 if pos[10] - 1 not in pos else pos[10]) + "\t".join(["0|2"] * N)),    # multi-allelic
+           (20, "20\t%d\trsY\tA\tC\t.\tPASS\tAC=1" % (pos[20] - 1 if pos[20] - 1 not in pos else pos[20]))]                                    # no FORMAT
+    write_vcf(vcf, al, pos, chrom, phased=phased, contigs=contigs, ref_alt=ref_alt, extra_format=True, raw_lines=raw)
+    header = [l for l in open(vcf).read().splitlines() if l.startswith("##")]
+    # the same records, in file order, as BCF
+    lines = [l for l in open(vcf).read().splitlines() if not l.startswith("#")]
+    recs = []
+    for l in lines:
+        f = l.split("\t")
+        r = dict(chrom=contigs.index(f[0]), pos=int(f[1]), ref=f[3], alts=f[4].split(","))
+        if len(f) > 8:
+            gts, dps = [], []
+            for smp in f[9:]:
+                g = smp.split(":")[0]
+                sep = "|" if "|" in g else "/"
+                parts = g.split(sep)
+                gts.append([(None if a == "." else int(a), k > 0 and sep == "|") for k, a in enumerate(parts)])
+                dps.append(17)
+            r["fmt"] = [("GT", gts)] + ([("DP", dps)] if f[8] == "GT:DP" else [])
+            r["gt_int16"] = (len(recs) % 3 == 0)
+        recs.append(r)
+    write_bcf(bcf, header, [f"S{i}" for i in range(N)], recs, gz=gz)
+    out_v, out_b = str(tmp_path / "v.twk"), str(tmp_path / "b.twk")
+    cv = H.import_vcf(vcf, out_v, threshold_miss=0.5, remove_univariate=False, block_size=16)
+    cb = H.import_vcf(bcf, out_b, threshold_miss=0.5, remove_univariate=False, block_size=16)
+    assert cv == cb and cv["written"] >= M - 3 and cv["not_biallelic"] == 1 and cv["not_snp"] == 1 and cv["no_format"] == 1
+    a, b = read_back(out_v), read_back(out_b)
+    assert a[0] == b[0] == N
+    for x, y in zip(a[1:], b[1:]):
+        assert np.array_equal(x, y)
+
+
+def test_import_bcf_ploidy_and_gt_placement(tmp_path):
+    """Haploid samples are padded with vector-end markers in BCF (mixed ploidy: dropped like in VCF); a FORMAT whose
+    first key is not GT has no genotypes for the importer."""
+    N = 8
+    header = ["##fileformat=VCFv4.2", "##contig=<ID=1,length=1000>", '##FORMAT=<ID=DP,Number=1,Type=Integer,Description="d">',
+              '##FORMAT=<ID=GT,Number=1,Type=String,Description="Genotype">']
+    dip = [[(i % 2, False), ((i // 2) % 2, True)] for i in range(N)]
+    hap = [list(g) for g in dip]; hap[3] = hap[3][:1]
+    recs = [dict(chrom=0, pos=10, ref="A", alts=["C"], fmt=[("GT", dip)]),
+            dict(chrom=0, pos=20, ref="A", alts=["C"], fmt=[("GT", hap)]),                       # one haploid sample
+            dict(chrom=0, pos=30, ref="A", alts=["C"], fmt=[("DP", [5] * N), ("GT", dip)]),     # GT not first
+            dict(chrom=0, pos=40, ref="G", alts=["T"], fmt=[("GT", dip)])]
+    bcf, out = str(tmp_path / "p.bcf"), str(tmp_path / "p.twk")
+    write_bcf(bcf, header, [f"S{i}" for i in range(N)], recs)
+    c = H.import_vcf(bcf, out, threshold_miss=0.0, remove_univariate=False)
+    assert c["sites"] == 4 and c["written"] == 2 and c["mixed_ploidy"] == 1 and c["no_genotypes"] == 1
+    n, data, mask, meta, extra = read_back(out)
+    assert n == N and meta["pos"].tolist() == [9, 39]
+    want = np.array([[g[0][0], g[1][0]] for g in dip], dtype=np.int8)[None]
+    d, _ = O.bitvectors_from_alleles(np.repeat(want, 2, axis=0))
+    assert np.array_equal(data, d) and extra[:, 2].tolist() == [1, 1]                           # phased: second allele's bit

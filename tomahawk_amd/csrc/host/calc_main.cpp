@@ -268,7 +268,7 @@ static int import_cmd(int argc, char** argv) {
 	if (argc < 3) {
 		program_message();
 		std::cerr << "About:  Convert VCF->TWK\n\nUsage:  tomahawk import [options] -i <in.vcf[.gz]> -o <out.twk>\n\nOptions:\n"
-		             "  -i FILE  input VCF, plain or gzip/bgzip text, '-' for stdin (required; for BCF: bcftools view in.bcf | tomahawk import -i - ...)\n  -o FILE  output file prefix (required)\n"
+		             "  -i FILE  input VCF (plain or gzip/bgzip text) or BCF2, '-' for stdin (required)\n  -o FILE  output file prefix (required)\n"
 		             "  -n FLOAT missingness fraction in range [0,1] (default: 0.9)\n  -H FLOAT Hardy-Weinberg P-value cutoff (default: 0)\n"
 		             "  -r       do not filter out univariate sites\n  -f       flip reference and alternative alleles when the major allele is the alternative (no effect, as in the reference)\n"
 		             "  -b INT   number of variants per block (default: 500)\n  -L INT   compression level 1-20 (default: 1)\n"

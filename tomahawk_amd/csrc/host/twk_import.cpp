@@ -60,23 +60,30 @@ double hardy_weinberg_exact(uint64_t obs_hom1, uint64_t obs_hets, uint64_t obs_h
 namespace {
 
 // ---- input ------------------------------------------------------------------------------------------
-class LineReader {           // plain or gzip/bgzip text, "-" = stdin
+class LineReader {           // VCF text (plain or gzip/bgzip) or BCF2 (bgzip or raw), "-" = stdin
 public:
 	bool open(const std::string& path) {
 		gz_ = (path == "-") ? gzdopen(0, "rb") : gzopen(path.c_str(), "rb");
-		if (gz_) gzbuffer(gz_, 1 << 20);
+		if (!gz_) return false;
+		gzbuffer(gz_, 1 << 20);
 		buf_.resize(1 << 22);
-		return gz_ != nullptr;
+		fill();
+		// BCF2 (htslib's binary VCF; lib/importer.cpp:25-337 reads either through bcf_read): magic "BCF\2\2"
+		if (len_ >= 5 && std::memcmp(buf_.data(), "BCF\2\2", 5) == 0) { bcf_ = true; pos_ = 5; return bcf_header(); }
+		return true;
 	}
 	~LineReader() { if (gz_) gzclose(gz_); }
+	// Next text line.  For BCF input: the header text line by line, then every record as the VCF data line
+	// that carries what the importer reads (CHROM POS . REF ALT . . . FORMAT GT...), so that one site parser and
+	// one set of filters serves both containers.
 	bool next(std::string& line) {
 		line.clear();
+		if (bcf_) {
+			if (hdr_line_ < hdr_lines_.size()) { line = hdr_lines_[hdr_line_++]; return true; }
+			return bcf_record(line);
+		}
 		for (;;) {
-			if (pos_ == len_) {
-				const int n = gzread(gz_, buf_.data(), (unsigned)buf_.size());
-				if (n <= 0) { if (n < 0) bad_ = true; return !line.empty(); }
-				pos_ = 0; len_ = (size_t)n;
-			}
+			if (pos_ == len_) { if (!fill()) return !line.empty(); }
 			const char* s = buf_.data() + pos_;
 			const char* nl = (const char*)std::memchr(s, '\n', len_ - pos_);
 			if (nl) {
@@ -94,7 +101,160 @@ private:
 	gzFile gz_ = nullptr;
 	std::vector<char> buf_;
 	size_t pos_ = 0, len_ = 0;
-	bool bad_ = false;
+	bool bad_ = false, bcf_ = false;
+	// BCF state: header lines to hand out, the two dictionaries (header_internal / htslib bcf_hdr: strings of
+	// FILTER/INFO/FORMAT IDs with PASS at 0, contigs in header order, both overridable with IDX=)
+	std::vector<std::string> hdr_lines_; size_t hdr_line_ = 0;
+	std::vector<std::string> dict_str_, dict_ctg_;
+	std::vector<uint8_t> rec_;
+
+	bool fill() {
+		const int n = gzread(gz_, buf_.data(), (unsigned)buf_.size());
+		if (n <= 0) { if (n < 0) bad_ = true; pos_ = len_ = 0; return false; }
+		pos_ = 0; len_ = (size_t)n;
+		return true;
+	}
+	bool read_bytes(void* dst, size_t n) {
+		uint8_t* d = static_cast<uint8_t*>(dst);
+		while (n) {
+			if (pos_ == len_ && !fill()) return false;
+			const size_t k = std::min(n, len_ - pos_);
+			std::memcpy(d, buf_.data() + pos_, k);
+			d += k; pos_ += k; n -= k;
+		}
+		return true;
+	}
+	static std::string field_of(const std::string& line, const char* key) {      // value of key= inside <...>
+		const std::string k = std::string(key) + "=";
+		size_t i = line.find('<');
+		while (i != std::string::npos) {
+			const size_t j = line.find(k, i + 1);
+			if (j == std::string::npos) return "";
+			if (line[j - 1] == '<' || line[j - 1] == ',') {
+				size_t e = j + k.size(), b = e;
+				bool q = false;
+				while (e < line.size() && (q || (line[e] != ',' && line[e] != '>'))) { if (line[e] == '"') q = !q; ++e; }
+				return line.substr(b, e - b);
+			}
+			i = j;
+		}
+		return "";
+	}
+	bool bcf_header() {
+		uint32_t l_text = 0;
+		if (!read_bytes(&l_text, 4) || l_text > (1u << 30)) { bad_ = true; return false; }
+		std::string text(l_text, '\0');
+		if (l_text && !read_bytes(&text[0], l_text)) { bad_ = true; return false; }
+		while (!text.empty() && text.back() == '\0') text.pop_back();
+		size_t b = 0;
+		while (b < text.size()) {
+			size_t e = text.find('\n', b);
+			if (e == std::string::npos) e = text.size();
+			if (e > b) hdr_lines_.push_back(text.substr(b, e - b));
+			b = e + 1;
+		}
+		dict_str_.push_back("PASS");
+		auto place = [](std::vector<std::string>& d, const std::string& id, const std::string& idx) {
+			if (!idx.empty()) { const size_t k = (size_t)std::atoll(idx.c_str()); if (d.size() <= k) d.resize(k + 1); d[k] = id; return; }
+			if (std::find(d.begin(), d.end(), id) == d.end()) d.push_back(id);
+		};
+		for (const auto& l : hdr_lines_) {
+			if (l.compare(0, 10, "##contig=<") == 0) place(dict_ctg_, field_of(l, "ID"), field_of(l, "IDX"));
+			else if (l.compare(0, 10, "##FILTER=<") == 0 || l.compare(0, 8, "##INFO=<") == 0 || l.compare(0, 10, "##FORMAT=<") == 0) {
+				const std::string id = field_of(l, "ID");
+				if (id == "PASS" && field_of(l, "IDX").empty()) continue;
+				place(dict_str_, id, field_of(l, "IDX"));
+			}
+		}
+		return true;
+	}
+	// typed values (BCF2 spec 6.3): descriptor byte = length << 4 | type, length 15 = a typed integer follows
+	struct Typed { int type = 0; uint32_t n = 0; const uint8_t* p = nullptr; };
+	static int type_size(int t) { return t == 1 ? 1 : t == 2 ? 2 : t == 3 ? 4 : t == 5 ? 4 : t == 7 ? 1 : 0; }
+	static bool typed_int(const uint8_t*& p, const uint8_t* end, int64_t& v) {
+		if (p >= end) return false;
+		const int t = *p & 15, n = *p >> 4; ++p;
+		if (n != 1 || (t != 1 && t != 2 && t != 3) || p + type_size(t) > end) return false;
+		if (t == 1) v = (int8_t)p[0]; else if (t == 2) { int16_t x; std::memcpy(&x, p, 2); v = x; } else { int32_t x; std::memcpy(&x, p, 4); v = x; }
+		p += type_size(t);
+		return true;
+	}
+	static bool typed(const uint8_t*& p, const uint8_t* end, Typed& out) {
+		if (p >= end) return false;
+		out.type = *p & 15; uint32_t n = *p >> 4; ++p;
+		if (n == 15) { int64_t v; if (!typed_int(p, end, v) || v < 0) return false; n = (uint32_t)v; }
+		out.n = n; out.p = p;
+		const size_t bytes = (size_t)n * type_size(out.type);
+		if ((size_t)(end - p) < bytes) return false;
+		p += bytes;
+		return true;
+	}
+	bool bcf_record(std::string& line) {
+		uint32_t l_shared = 0, l_indiv = 0;
+		if (!read_bytes(&l_shared, 4)) return false;                                // clean end of file
+		if (!read_bytes(&l_indiv, 4) || l_shared < 24 || (uint64_t)l_shared + l_indiv > (1ull << 31)) { bad_ = true; return false; }
+		rec_.resize((size_t)l_shared + l_indiv);
+		if (!read_bytes(rec_.data(), rec_.size())) { bad_ = true; return false; }
+		const uint8_t* p = rec_.data(); const uint8_t* const se = p + l_shared; const uint8_t* const ie = se + l_indiv;
+		int32_t chrom, pos; uint32_t n_allele_info, n_fmt_sample;
+		std::memcpy(&chrom, p, 4); std::memcpy(&pos, p + 4, 4); std::memcpy(&n_allele_info, p + 16, 4); std::memcpy(&n_fmt_sample, p + 20, 4);
+		p += 24;
+		const uint32_t n_allele = n_allele_info >> 16, n_fmt = n_fmt_sample >> 24, n_sample = n_fmt_sample & 0xFFFFFFu;
+		Typed id;
+		if (!typed(p, se, id)) { bad_ = true; return false; }
+		line = (chrom >= 0 && (size_t)chrom < dict_ctg_.size()) ? dict_ctg_[chrom] : std::string("?");
+		line += '\t'; line += std::to_string((int64_t)pos + 1); line += "\t.";
+		std::string alt;
+		for (uint32_t a = 0; a < n_allele; ++a) {
+			Typed al;
+			if (!typed(p, se, al) || al.type != 7) { bad_ = true; return false; }
+			const std::string s((const char*)al.p, al.n);
+			if (a == 0) { line += '\t'; line += s.empty() ? "." : s; }
+			else { if (!alt.empty()) alt += ','; alt += s; }
+		}
+		if (n_allele == 0) line += "\t.";
+		line += '\t'; line += alt.empty() ? "." : alt;
+		line += "\t.\t.\t.";                                                      // QUAL FILTER INFO: not read by the importer
+		if (n_fmt == 0) return true;                                                 // no FORMAT column: "no fmt" (importer.cpp:278-282)
+		// FORMAT keys; the genotypes are written out only when GT leads (VCF requires it to; the importer looks there)
+		p = se;
+		std::string fmt; Typed gt; bool have_gt = false;
+		for (uint32_t k = 0; k < n_fmt; ++k) {
+			int64_t key;
+			if (!typed_int(p, ie, key)) { bad_ = true; return false; }
+			if (p >= ie) { bad_ = true; return false; }
+			Typed v; v.type = *p & 15; uint32_t n = *p >> 4; ++p;
+			if (n == 15) { int64_t x; if (!typed_int(p, ie, x) || x < 0) { bad_ = true; return false; } n = (uint32_t)x; }
+			v.n = n; v.p = p;
+			const size_t bytes = (size_t)n * type_size(v.type) * n_sample;
+			if ((size_t)(ie - p) < bytes) { bad_ = true; return false; }
+			p += bytes;
+			const std::string name = (key >= 0 && (size_t)key < dict_str_.size()) ? dict_str_[key] : std::string("?");
+			if (k) fmt += ':';
+			fmt += name;
+			if (k == 0 && name == "GT") { gt = v; have_gt = true; }
+		}
+		line += '\t'; line += fmt;
+		const int es = type_size(gt.type);
+		for (uint32_t s = 0; s < n_sample; ++s) {
+			line += '\t';
+			if (!have_gt || (gt.type != 1 && gt.type != 2 && gt.type != 3)) { line += '.'; continue; }
+			bool any = false;
+			for (uint32_t k = 0; k < gt.n; ++k) {
+				const uint8_t* q = gt.p + ((size_t)s * gt.n + k) * es;
+				int32_t v; bool vec_end;
+				if (es == 1) { v = (int8_t)q[0]; vec_end = v == -127; } else if (es == 2) { int16_t x; std::memcpy(&x, q, 2); v = x; vec_end = x == -32767; }
+				else { std::memcpy(&v, q, 4); vec_end = v == -2147483647; }
+				if (vec_end) break;                                                  // lower ploidy than the widest sample
+				if (k) line += (v & 1) ? '|' : '/';
+				const int allele = (v >> 1) - 1;                                     // 0 = missing
+				if (allele < 0) line += '.'; else line += std::to_string(allele);
+				any = true;
+			}
+			if (!any) line += '.';
+		}
+		return true;
+	}
 };
 
 // `##key=<a=b,c="d,e">` -> pairs (values keep their quotes, like htslib's hrec)

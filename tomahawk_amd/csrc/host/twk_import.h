@@ -1,9 +1,11 @@
-// `.twk` producer without htslib: VCF text (plain or gzip/bgzip) -> `.twk`.
+// `.twk` producer without htslib: VCF text (plain or gzip/bgzip) or BCF2 -> `.twk`.
 //
 // Same settings, site filters, counters and output bytes layout as the reference importer
 // (include/importer.h:33-58, lib/importer.cpp:25-338, lib/genotype_encoder.h:44-343,
 // twk1_t::calculateHardyWeinberg lib/core.cpp:103-201).  The reference reads VCF/BCF through
-// htslib; here the VCF text is parsed directly (BCF is not read).
+// htslib; here VCF text is parsed directly, and BCF2 records (BCF2 spec section 6: typed values, the string
+// and contig dictionaries of the header, genotypes as (allele + 1) << 1 | phased with vector-end padding)
+// are turned into the data line the same site parser reads, so both containers share filters and counters.
 #pragma once
 #include <cstdint>
 #include <string>
