@@ -34,13 +34,15 @@ pmc() {     # pmc <name> <counter list> <bench args...>: one counter pass, per-k
 for stage in "$@"; do
 	case $stage in
 	microbench)   # the instruction-rate evidence behind the VALU ceiling
-		for t in valu_rate issue_test2 hbm_read_bw; do
+		for t in valu_rate issue_test2 bank_test2 hbm_read_bw; do
 			echo "== $t"; timeout 300 $R/build/$t > $OUT/microbench_$t.txt 2>&1; cat $OUT/microbench_$t.txt
 		done
 		echo "== count_microbench (kernel alone, full K of N = 1M unphased planes: 4096 rows x 31264 words)"
 		timeout 300 $R/build/count_microbench 4096 31264 3 > $OUT/microbench_count_microbench.txt 2>&1; cat $OUT/microbench_count_microbench.txt
 		echo "== count_microbench (configs[1] rows: 10112 rows x 6272 words)"
 		timeout 300 $R/build/count_microbench 10112 6272 3 >> $OUT/microbench_count_microbench.txt 2>&1; tail -3 $OUT/microbench_count_microbench.txt
+		echo "== per-block finish times of the ticketed kernel (2 rounds of whole-K tiles, N = 1M rows)"
+		FINISH=1 timeout 300 $R/build/count_microbench 4096 31264 3 512 > $OUT/microbench_finish_times.txt 2>&1; head -3 $OUT/microbench_finish_times.txt
 		;;
 	cfg3)  timeout 600 python3 $R/bench.py --steps 2 --warmup 1 > $OUT/bench_cfg3.json 2> $OUT/bench_cfg3.log; cat $OUT/bench_cfg3.json ;;
 	cfg3_stats) stats cfg3 --steps 2 --warmup 1 ;;
