@@ -48,6 +48,9 @@ CASES = {       # name: reference CLI flags
     "c6C6":     ["-c", "6", "-C", "6"],
     "w20000":   ["-w", "20000"],
     "w5000":    ["-w", "5000"],
+    "u_w5000":  ["-u", "-w", "5000"],        # forced mode: the slave's per-pair window test and its goto end_cycle (q8)
+    "u_w1000":  ["-u", "-w", "1000"],
+    "w1000":    ["-w", "1000"],              # default mode: the window only prunes whole block pairs
 }
 CHAIN_CALC = ["-p", "-r", "0.75", "-I", "2"]        # phased, no missing-data pairs involved in the comparison below
 

@@ -102,6 +102,35 @@ public:
 	// thread - the reference's per-thread blocks behind one spinlocked writer (twk_record_sink.h).
 	TwoOutput out;
 
+	// TWK_REF_COMPAT=1 with -w: what the reference's window mode really keeps, as a filter on the
+	// exact window's records.  blk_first[k] = first variant of the k-th loaded block.
+	struct CompatWindow {
+		bool on = false, forced = false;             // forced: -p / -u (the slave loops test every pair)
+		uint32_t w = 0;
+		std::vector<uint32_t> blk_first;             // [n_blocks + 1]
+		std::vector<uint32_t> blk_of;                // [n_variants]
+	} cw;
+	// Reference, block pair (bi, bj) of a window run:
+	//  * the ticker issues (i, j), j = i, i+1, ..., and gives up the rest of row i at the first j != i with
+	//    pos(first of j) - pos(last of i) > w - in uint32 arithmetic and without looking at the contigs
+	//    (ld_balancing.h:176-203);
+	//  * -p / -u: the slave walks the pairs (p, q) of the block pair in order and leaves the WHOLE block pair at
+	//    the first same-contig pair with pos(q) - pos(p) > w (goto end_cycle, ld_engine.cpp:2553-2560, 2582-2588).
+	//    Positions ascend, so that happens in the first row or never: of a block pair that is not wholly inside
+	//    the window only the first variant's in-window pairs come out;
+	//  * default mode has no window loop at all (ld_engine.cpp:1841-1843: Calculate): every pair of every block
+	//    pair the ticker issued is computed.
+	bool compat_keep(uint32_t A, uint32_t B) const {
+		const uint32_t bi = cw.blk_of[A], bj = cw.blk_of[B];
+		const uint32_t last_i = cw.blk_first[bi + 1] - 1;
+		for (uint32_t j = bi + 1; j <= bj; ++j)
+			if ((uint32_t)(pos[cw.blk_first[j]] - pos[last_i]) > cw.w) return false;
+		if (!cw.forced) return true;
+		const uint32_t first_i = cw.blk_first[bi], last_j = cw.blk_first[bj + 1] - 1;
+		if (rid[first_i] != rid[last_j] || (uint32_t)(pos[last_j] - pos[first_i]) <= cw.w) return true;      // wholly inside
+		return A == first_i && rid[A] == rid[B] && (uint32_t)(pos[B] - pos[A]) <= cw.w;
+	}
+
 	bool run(twk_ld_settings& settings, const Header& hdr, const std::vector<twk_hip_ctx*>& ctxs, uint32_t n_samples, const void* spec);
 };
 
@@ -345,10 +374,10 @@ static bool load_blocks(const std::string& path, const TwkReader& reader, const 
 	return join_uploads();
 }
 
-// TWK_REF_COMPAT=1: reproduce two slips of the reference that change output bytes instead of the correct result -
-// PhasedVectorized's tail / padding arithmetic (TWK_HIP_OPT_REF_COMPAT, include/twk_hip.h) and scalc's dropping
-// of the last partial group of 100 neighbours.  (The window-mode and off-diagonal-chunk slips, SURVEY A.6 q8 / q9,
-// depend on the reference's block-pair visiting order and are not reproduced.)
+// TWK_REF_COMPAT=1: reproduce slips of the reference that change output bytes instead of the correct result -
+// PhasedVectorized's tail / padding arithmetic (q6/q7; TWK_HIP_OPT_REF_COMPAT, include/twk_hip.h), scalc's dropping
+// of the last partial group of 100 neighbours (q15) and, with -w, the reference's window mode as it really
+// behaves (q8; twk_ld_impl::compat_keep).  The off-diagonal-chunk slip (q9) is not reproduced.
 static bool ref_compat() { const char* e = std::getenv("TWK_REF_COMPAT"); return e && e[0] && e[0] != '0'; }
 
 // The r2 screen (TWK_HIP_OPT_R2_SCREEN) is on unless TWK_HIP_NO_SCREEN=1 (A/B comparisons; the records are the same).
@@ -439,9 +468,15 @@ bool twk_ld::twk_ld_impl::run(twk_ld_settings& settings, const Header& hdr, cons
 	// one driver thread per GPU: region calls for its shard, survivors into its own emitter
 	struct Driver {
 		twk_ld_impl* self; RecordEmitter emitter; bool write_failed = false; uint64_t pairs = 0; int rc = TWK_HIP_OK;
+		std::vector<twk_hip_record> kept;
 		Driver(twk_ld_impl* s, int workers) : self(s), emitter(s->out, workers) {}
 		static int sink(void* user, const twk_hip_record* recs, uint64_t n) {
 			auto* d = static_cast<Driver*>(user);
+			if (d->self->cw.on) {
+				d->kept.clear();
+				for (uint64_t i = 0; i < n; ++i) if (d->self->compat_keep(recs[i].idxA, recs[i].idxB)) d->kept.push_back(recs[i]);
+				recs = d->kept.data(); n = d->kept.size();
+			}
 			if (!d->emitter.emit(recs, n, false)) { d->write_failed = true; return 1; }
 			return 0;
 		}
@@ -561,6 +596,18 @@ bool twk_ld::Compute() {
 	spec.triangleA = bal.diag; spec.rectAB = !bal.diag;
 	spec.options = (settings.window ? TWK_HIP_OPT_WINDOW : 0) | (ref_compat() ? TWK_HIP_OPT_REF_COMPAT : 0) | (r2_screen() ? TWK_HIP_OPT_R2_SCREEN : 0);
 	spec.l_window = (uint32_t)settings.l_window;
+	mImpl->cw = twk_ld_impl::CompatWindow();
+	if (ref_compat() && settings.window) {
+		auto& cw = mImpl->cw;
+		cw.on = true; cw.w = (uint32_t)settings.l_window;
+		cw.forced = settings.force_phased || settings.forced_unphased;
+		cw.blk_first.assign(1, 0);
+		for (uint32_t b : sel) cw.blk_first.push_back(cw.blk_first.back() + reader.index.ent[b].n);
+		cw.blk_of.resize(M);
+		for (size_t k = 0; k + 1 < cw.blk_first.size(); ++k) for (uint32_t v = cw.blk_first[k]; v < cw.blk_first[k + 1]; ++v) cw.blk_of[v] = (uint32_t)k;
+		// default mode: the reference tests no pair against the window, so pairs outside it come out too: compute them all
+		if (!cw.forced) spec.options &= ~TWK_HIP_OPT_WINDOW;
+	}
 	if (!mImpl->run(settings, reader.hdr, dc.ctx, n_samples, &spec)) return false;
 	std::cerr << stamp("LOG", "PROGRESS") << "All done..." << elapsed_string(std::chrono::duration<double>(clock::now() - t_load).count()) << "!" << std::endl;
 	return true;
