@@ -34,6 +34,7 @@ host: $(LIBDIR)/libtomahawk_amd.so
 $(LIBDIR)/libtomahawk_amd.so: $(HOST_LIB_SRC) $(HOST_DEPS) $(LIBDIR)/libtwk_hip.so
 	@mkdir -p $(LIBDIR)
 	$(CXX) $(CXXFLAGS) -shared $(HOST_LIB_SRC) -o $@ -L$(LIBDIR) -ltwk_hip $(ZSTD_LIB) $(ZLIB) -Wl,-rpath,'$$ORIGIN'
+	ln -sf libtomahawk_amd.so $(LIBDIR)/libtomahawk.so      # the reference library's name (makefile:162-182), for -ltomahawk
 
 cli: $(BINDIR)/tomahawk
 $(BINDIR)/tomahawk: $(PKG)/csrc/host/calc_main.cpp $(LIBDIR)/libtomahawk_amd.so

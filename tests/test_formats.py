@@ -146,3 +146,30 @@ def test_concat_copies_blocks_and_rebases_index(tmp_path):
     assert r.returncode == 0 and len(hostlib.read_two(str(tmp_path / "c3.two"))[0]) == 3 * len(one)
     r = subprocess.run([hostlib.CLI_PATH, "concat", "-i", src, "-o", out], capture_output=True, text=True)
     assert r.returncode == 1 and "Only one input file" in r.stderr
+
+
+def test_reference_client_source_builds_against_the_shim(tmp_path):
+    """A libtomahawk client written against the reference (`#include "ld.h"`, tomahawk::twk_ld, -ltomahawk; lib/calc.h:96,
+    237-238) compiles and links unchanged: include/ld.h is a shim of the reference header's name, lib/libtomahawk.so the
+    engine's library under the reference library's name.  (Running it needs a GPU: without one Compute() fails loudly.)"""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "tomahawk_amd", "lib")
+    if not os.path.exists(os.path.join(lib, "libtomahawk.so")):
+        os.symlink("libtomahawk_amd.so", os.path.join(lib, "libtomahawk.so"))       # (make host creates it)
+    src = tmp_path / "client.cpp"
+    src.write_text('#include "ld.h"\n'
+                   'namespace tomahawk { std::string LITERAL_COMMAND_LINE = "client"; }\n'
+                   'int main(int argc, char** argv) {\n'
+                   '    tomahawk::twk_ld_settings settings;\n'
+                   '    settings.in = argc > 1 ? argv[1] : ""; settings.out = "out.two"; settings.force_phased = true;\n'
+                   '    tomahawk::twk_ld ld;\n'
+                   '    if (ld.Compute(settings) == false) return 1;\n'
+                   '    return 0;\n}\n')
+    exe = str(tmp_path / "client")
+    r = subprocess.run([shutil.which("g++") or "g++", "-std=c++11", "-I" + os.path.join(root, "include"), str(src), "-o", exe,
+                        "-L" + lib, "-ltomahawk", "-ltwk_hip", "-Wl,-rpath," + lib], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 1 and "No file-name provided" in r.stderr
