@@ -118,6 +118,9 @@ def main():
     ap.add_argument("--tile", type=int, default=0, help="super-tile edge in variants (0 = engine default)")
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (debug: gloo lets "
+                    "several ranks share one GPU, to exercise the N > 1 orchestration on a single-GPU box)")
+    ap.add_argument("--min-r2", type=float, default=None, help="override the r2 cut-off (debug: produce survivors)")
     ap.add_argument("--emulate-shard", default="", help="K/N: run shard K of N on this one GPU (validation of the "
                     "sharded configs on a single-GPU box; the value then covers that shard only)")
     args = ap.parse_args()
@@ -148,12 +151,16 @@ def main():
     dev_index = local_rank if local_rank < n_vis else local_rank % max(n_vis, 1)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    xdev = dev if args.backend == "nccl" else torch.device("cpu")      # where the collectives' tensors live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend="gloo")
         # RCCL sets up its rings and the point-to-point channels of gather() lazily on first use:
         # do that once here, outside any step (one empty-ish gather + a barrier).
-        gather_records(np.zeros(1, dtype=T.RECORD_DTYPE), dst=0, device=dev)
+        gather_records(np.zeros(1, dtype=T.RECORD_DTYPE), dst=0, device=xdev)
         dist.barrier()
 
     n_samples, n_variants, mode = CONFIGS[args.config]
@@ -163,6 +170,8 @@ def main():
         n_samples = args.samples
     hip_mode = T.MODE_UNPHASED if mode == "unphased" else T.MODE_PHASED
     filters = T.Filters(minP=MIN_P.get(args.config, 1.0))   # reference defaults: r2 >= 0.1, P <= 1
+    if args.min_r2 is not None:
+        filters.minR2 = args.min_r2
     window_bp = WINDOW_BP.get(args.config, 0)
     shard_rank, shard_world = rank, world
     if args.emulate_shard:
@@ -234,7 +243,7 @@ def main():
         else:
             recs, npairs, nrec = eng.ld_all(hip_mode, filters, part=shard_rank, n_parts=shard_world, tile_variants=args.tile)
         if world > 1:
-            recs = gather_records(recs, dst=0, device=dev)      # RCCL: all_gather(counts) + grouped send/recv of exact sizes
+            recs = gather_records(recs, dst=0, device=xdev)     # RCCL: all_gather(counts) + grouped send/recv of exact sizes
         if rank == 0:
             stream.append(recs)
             written["records"] += stream.close()
@@ -259,8 +268,8 @@ def main():
         shutil.rmtree(out_dir, ignore_errors=True)
     tm = eng.timing()
 
-    stats = torch.tensor([elapsed, tm["count_ms"], tm["stats_ms"]], dtype=torch.float64, device=dev)
-    sums = torch.tensor([my_pairs, my_recs, tm["count_launches"], tm["row_pairs"]], dtype=torch.float64, device=dev)
+    stats = torch.tensor([elapsed, tm["count_ms"], tm["stats_ms"]], dtype=torch.float64, device=xdev)
+    sums = torch.tensor([my_pairs, my_recs, tm["count_launches"], tm["row_pairs"]], dtype=torch.float64, device=xdev)
     if world > 1:
         dist.all_reduce(stats, op=dist.ReduceOp.MAX)
         dist.all_reduce(sums, op=dist.ReduceOp.SUM)
@@ -291,7 +300,7 @@ def main():
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": (f"BASELINE {NAMES[args.config]}: {n_samples} samples x {n_variants} variants, "
                                     + (f"windowed +-{window_bp} bp" if window_bp else "all-vs-all")
-                                    + f" {mode} genotype LD (calc {'-u' if mode == 'unphased' else '-p'}, r2>=0.1"
+                                    + f" {mode} genotype LD (calc {'-u' if mode == 'unphased' else '-p'}, r2>={filters.minR2:g}"
                                     + (f", P<={filters.minP:g}" if filters.minP < 1 else "") + f"), {total_pairs} pairs/step"
                                     + (f"; EMULATED shard {args.emulate_shard} only" if args.emulate_shard else "")),
                        "n_samples": n_samples, "n_variants": n_variants, "mode": mode, "tile_variants": args.tile,
