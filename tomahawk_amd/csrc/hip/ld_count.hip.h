@@ -12,24 +12,21 @@
 // 668, 941-943): same AND, same popcount, but as a tiled contraction instead
 // of one pair at a time.
 //
-// CDNA4 mapping (gfx950, wave64, 4 x SIMD32 per CU):
-//   * block = 256 threads = 4 waves, computes a 128 x 128 tile of row pairs;
-//     wave (wr,wc) owns a 64 x 64 quadrant; lane (li,lj) of the 8 x 8 lane grid
-//     owns the 8 x 8 pairs { wr*64 + li + 8t } x { wc*64 + lj + 8u }: 64 u32
-//     accumulators in VGPRs.  Per 16 bytes of K a lane issues 16 ds_read_b128
-//     (8 A rows, 8 B rows) against 256 v_and_b32 + 256 v_bcnt_u32_b32: the
-//     loop is VALU-issue bound by construction (LDS pipe at ~25 %).
-//   * K is walked in chunks of KC = 32 words (128 B = one cache line per row).
-//     A chunk of the A tile and of the B tile (2 x 16 KiB) is DMA'd HBM -> LDS
-//     with global_load_lds_dwordx4 (no VGPR staging), double buffered: the
-//     loads of chunk c+1 are in flight while chunk c is contracted; one
-//     barrier per chunk.
-//   * LDS image is lane-linear per wave-instruction (8 rows x 128 B), so the
-//     bank swizzle lives on the *source* address: 16-byte slot q of row r is
-//     stored at slot q ^ ((r >> 1) & 7).  A ds_read_b128 lane group then sees
-//     8 consecutive rows at 8 distinct (row parity, slot) bank positions:
-//     conflict free (MI355X_MICROARCH.md, LDS table).
+// CDNA4 mapping (gfx950, wave64, 4 x SIMD32 per CU) - the production kernel is k_count_list_t below:
+//   * block = 512 threads = 8 waves as a 2 x 4 wave grid over a 128 x 128 tile of row pairs; lane (li,lj)
+//     of the 8 x 8 lane grid owns the 8 x 4 pairs { wr*64 + li + 8t } x { wc*32 + lj + 8u }: 32 u32
+//     accumulators; <= 128 VGPRs, 2 blocks/CU = 4 waves/SIMD.
+//   * K is walked in chunks of KC = 32 words (128 B = one cache line per row).  A chunk of the A tile and
+//     of the B tile (2 x 16 KiB) is DMA'd HBM -> LDS with global_load_lds_dwordx4 (no VGPR staging), double
+//     buffered: the loads of chunk c+1 are in flight while chunk c is contracted; one barrier per chunk.
+//   * LDS image is lane-linear per wave-instruction (8 rows x 128 B), so the bank swizzle lives on the
+//     *source* address: 16-byte slot q of row r is stored at slot q ^ ((r >> 1) & 7).  The LDS reads of a
+//     lane group then see 8 consecutive rows at 8 distinct (row parity, slot) bank positions: conflict free.
+//   * the loop is VALU-issue bound by construction: one v_and_b32 + one v_bcnt_u32_b32 per 32-bit word pair
+//     (2 + 4 cycles per wave64 on a SIMD), LDS pipe at ~25 %.
 //   * no MFMA: this is integer popcount.
+// k_count_tile_t (one block per tile on a 2-D grid) is the round-1 kernel, kept as the baseline of the
+// dev tool csrc/tools/count_microbench.hip; the engine launches k_count_list_t only.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -174,6 +171,7 @@ __device__ __forceinline__ void contract_slot(uint32_t (&acc)[8][TB], int u, con
 	          a[0].w, a[1].w, a[2].w, a[3].w, a[4].w, a[5].w, a[6].w, a[7].w, b.w);
 }
 
+// ---- round-1 kernel (baseline of the micro-benchmark only) -----------------------------------
 // grid: x = column tiles, y = row tiles of the super-tile.  C is the count
 // matrix of the super-tile: C[(by*128 + r) * ldc + bx*128 + c].
 // diag != 0: the super-tile sits on the diagonal (rowA0 == rowB0); tiles with
