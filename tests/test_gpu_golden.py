@@ -225,6 +225,47 @@ def test_cli_multi_gpu_driver_threads_equal_single(tmp_path):
     assert r.returncode != 0 and "device(s) are visible" in r.stderr
 
 
+def test_cli_window_mode_slabs_per_gpu(tmp_path):
+    """`calc -w` on several GPUs: every GPU loads only the blocks of its band of rows plus the halo its window reaches
+    (what makes configs[4] - 500 GB of bitvectors - fit), and the union of the bands is the single-GPU output.  Several
+    contigs with positions that start over, missing genotypes, every mode; also as two processes (TWK_HIP_PART)."""
+    N = 90
+    sizes = [700, 500, 40, 360]
+    M = sum(sizes)
+    al = util.mosaic_alleles(M, N, 91, n_founders=5, switch=0.02, mut=0.01, miss_rate=0.05, miss_variants=0.25)
+    rid = np.repeat(np.arange(len(sizes)), sizes).astype(np.uint32)
+    pos = np.concatenate([1000 + 50 * np.arange(n) for n in sizes]).astype(np.uint32)
+    twk = str(tmp_path / "in.twk")
+    hostlib.write_twk(twk, al, pos, rid, np.ones(M, np.uint8), n_contigs=len(sizes), block_size=37)
+    key = lambda m: m[np.lexsort((m[:, 4], m[:, 3], m[:, 2], m[:, 1]))]
+    def run(env_extra, out, extra):
+        r = subprocess.run([hostlib.CLI_PATH, "calc", "-i", twk, "-o", out, "-r", "0.05", "-w", "2500"] + list(extra), capture_output=True,
+                           text=True, env=dict(os.environ, **env_extra))
+        assert r.returncode == 0, r.stderr
+        return key(hostlib.two_as_matrix(hostlib.read_two(out)[0])), r.stderr
+    for mode in ((), ("-u",), ("-p",)):
+        one, _ = run({}, str(tmp_path / "one.two"), mode)
+        multi, log = run({"TWK_HIP_GPUS": "4", "TWK_HIP_FORCE_DEVICE": "0"}, str(tmp_path / "m.two"), mode)
+        assert len(one) > 2000 and np.array_equal(one, multi)
+        halos = [int(l.split("+ ")[1].split(" halo")[0]) for l in log.splitlines() if "halo variants" in l]
+        assert len(halos) == 4 and max(halos) <= 3 * 37 + 50 and "GPU 3: rows = variants" in log        # a window of 50 variants: <= 2-3 blocks of halo
+    parts = []
+    for k in range(2):
+        out = str(tmp_path / f"farm{k}.two")
+        run({"TWK_HIP_GPUS": "2", "TWK_HIP_FORCE_DEVICE": "0", "TWK_HIP_PART": f"{k}/2"}, out, ())
+        parts.append(out)
+    cat = str(tmp_path / "cat.two")
+    r = subprocess.run([hostlib.CLI_PATH, "concat", "-i", parts[0], "-i", parts[1], "-o", cat], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    whole, _ = run({}, str(tmp_path / "w.two"), ())
+    assert np.array_equal(whole, key(hostlib.two_as_matrix(hostlib.read_two(cat)[0])))
+    # TWK_REF_COMPAT window filter composes with the slabs (forced mode) and switches them off where it must (default mode)
+    for mode in (("-u",), ()):
+        one, _ = run({"TWK_REF_COMPAT": "1"}, str(tmp_path / "c1.two"), mode)
+        multi, _ = run({"TWK_REF_COMPAT": "1", "TWK_HIP_GPUS": "3", "TWK_HIP_FORCE_DEVICE": "0"}, str(tmp_path / "c3.two"), mode)
+        assert len(one) > 0 and np.array_equal(one, multi)
+
+
 def test_cli_full_chain_import_calc_sort_view(tmp_path):
     """VCF -> import -> calc (default mode, missing genotypes) -> sort -> view: the chain a user of the reference runs."""
     from tests.test_import import write_vcf

@@ -209,6 +209,10 @@ struct RunSpec {
 	bool rectAB = false;         // row set x column set
 	int options = 0;             // TWK_HIP_OPT_*
 	uint32_t l_window = 0;
+	// Window mode on several GPUs: GPU g holds only its band of rows plus the halo its window reaches, as
+	// local variants [0, n_local) = global [first, first + n_local); rows [0, n_band) are its own.
+	struct Slab { uint32_t first = 0, n_band = 0, n_local = 0; };
+	std::vector<Slab> slabs;     // empty: every GPU holds everything and takes shard g of n of every region
 };
 }  // namespace
 
@@ -383,6 +387,17 @@ static bool ref_compat() { const char* e = std::getenv("TWK_REF_COMPAT"); return
 // The r2 screen (TWK_HIP_OPT_R2_SCREEN) is on unless TWK_HIP_NO_SCREEN=1 (A/B comparisons; the records are the same).
 static bool r2_screen() { const char* e = std::getenv("TWK_HIP_NO_SCREEN"); return !(e && e[0] && e[0] != '0'); }
 
+// TWK_HIP_PART=k/n: this process's share of a multi-process run.
+static bool part_from_env(uint32_t& part0, uint32_t& n_procs) {
+	part0 = 0; n_procs = 1;
+	if (const char* e = std::getenv("TWK_HIP_PART")) {
+		unsigned k = 0, n = 1;
+		if (sscanf(e, "%u/%u", &k, &n) == 2 && n >= 1 && k < n) { part0 = k; n_procs = n; }
+		else { std::cerr << stamp("ERROR") << "Bad TWK_HIP_PART (want k/n): " << e << std::endl; return false; }
+	}
+	return true;
+}
+
 static bool create_devices(DeviceCtxs& dc, int n_gpus) {
 	const char* force = std::getenv("TWK_HIP_FORCE_DEVICE");       // testing: several engine contexts on one GPU
 	const char* dev_env = std::getenv("TWK_HIP_DEVICE");
@@ -419,11 +434,7 @@ bool twk_ld::twk_ld_impl::run(twk_ld_settings& settings, const Header& hdr, cons
 	// this process's share of a multi-node (farm) run: TWK_HIP_PART=k/n (the reference's -c/-C idea,
 	// ld_balancing.h:23-80, with equal-area row bands; `concat` merges the processes' outputs).
 	uint32_t part0 = 0, n_procs = 1;
-	if (const char* e = std::getenv("TWK_HIP_PART")) {
-		unsigned k = 0, n = 1;
-		if (sscanf(e, "%u/%u", &k, &n) == 2 && n >= 1 && k < n) { part0 = k; n_procs = n; }
-		else { std::cerr << stamp("ERROR") << "Bad TWK_HIP_PART (want k/n): " << e << std::endl; return false; }
-	}
+	if (!part_from_env(part0, n_procs)) return false;
 	const uint32_t n_parts = n_procs * (uint32_t)n_gpus;
 	const auto t0 = clock::now();
 	// Progress lines like the reference's ticker (ld_progress.h:40-86), every 30 s, driven by the
@@ -469,12 +480,18 @@ bool twk_ld::twk_ld_impl::run(twk_ld_settings& settings, const Header& hdr, cons
 	struct Driver {
 		twk_ld_impl* self; RecordEmitter emitter; bool write_failed = false; uint64_t pairs = 0; int rc = TWK_HIP_OK;
 		std::vector<twk_hip_record> kept;
+		uint32_t shift = 0;
 		Driver(twk_ld_impl* s, int workers) : self(s), emitter(s->out, workers) {}
 		static int sink(void* user, const twk_hip_record* recs, uint64_t n) {
 			auto* d = static_cast<Driver*>(user);
-			if (d->self->cw.on) {
+			if (d->shift || d->self->cw.on) {
+				// slab-local variant indices -> positions in the run's rid / pos arrays; TWK_REF_COMPAT window filter
 				d->kept.clear();
-				for (uint64_t i = 0; i < n; ++i) if (d->self->compat_keep(recs[i].idxA, recs[i].idxB)) d->kept.push_back(recs[i]);
+				for (uint64_t i = 0; i < n; ++i) {
+					twk_hip_record r = recs[i];
+					r.idxA += d->shift; r.idxB += d->shift;
+					if (!d->self->cw.on || d->self->compat_keep(r.idxA, r.idxB)) d->kept.push_back(r);
+				}
 				recs = d->kept.data(); n = d->kept.size();
 			}
 			if (!d->emitter.emit(recs, n, false)) { d->write_failed = true; return 1; }
@@ -490,13 +507,20 @@ bool twk_ld::twk_ld_impl::run(twk_ld_settings& settings, const Header& hdr, cons
 		per_gpu[g] = Progress::PerGpu{&progress, g};
 		twk_hip_set_progress(ctx, &Progress::cb, &per_gpu[g]);
 		uint64_t np = 0, nr = 0;
+		if (!spec.slabs.empty()) {          // this GPU's own slab: its band of rows against band + halo, nothing to shard
+			const RunSpec::Slab& sl = spec.slabs[g];
+			d.shift = sl.first;
+			if (sl.n_band && sl.n_local > 1)
+				d.rc = twk_hip_ld_region(ctx, mode, &f, 0, sl.n_band, 0, sl.n_local, 1, 0, 1, 0, spec.options, spec.l_window, &Driver::sink, &d, &np, &nr);
+			d.pairs += np;
+		} else
 		if (spec.triangleA && spec.nA > 1) {
 			d.rc = twk_hip_ld_region(ctx, mode, &f, 0, spec.nA, 0, spec.nA, 1, part, n_parts, 0, spec.options, spec.l_window, &Driver::sink, &d, &np, &nr);
 			d.pairs += np;
 			std::lock_guard<std::mutex> lk(progress.mu);
 			progress.base[g] += np; progress.done[g] = 0;
 		}
-		if (d.rc == TWK_HIP_OK && spec.rectAB && spec.nA && spec.nB) {
+		if (spec.slabs.empty() && d.rc == TWK_HIP_OK && spec.rectAB && spec.nA && spec.nB) {
 			d.rc = twk_hip_ld_region(ctx, mode, &f, 0, spec.nA, spec.nA, spec.nB, 0, part, n_parts, 0, spec.options, spec.l_window, &Driver::sink, &d, &np, &nr);
 			d.pairs += np;
 		}
@@ -583,15 +607,71 @@ bool twk_ld::Compute() {
 	DeviceCtxs dc;
 	if (!create_devices(dc, n_gpus)) return false;
 	if (n_gpus > 1) std::cerr << stamp("LOG", "HIP") << "Using " << n_gpus << " GPUs: one driver thread each, equal-area row bands of the pair space..." << std::endl;
-	for (auto* c : dc.ctx) if (!hip_ok(c, twk_hip_set_problem(c, n_samples, M), "twk_hip_set_problem")) return false;
+	uint32_t part0 = 0, n_procs = 1;
+	if (!part_from_env(part0, n_procs)) return false;
+	const uint32_t n_parts = n_procs * (uint32_t)n_gpus;
+	RunSpec spec;
 	const auto t_load = clock::now();
 	const uint32_t T = (uint32_t)std::max(1, settings.n_threads);
 	std::cerr << stamp("LOG", "THREAD") << "Unpacking using " << T << " threads..." << std::endl;
-	if (!load_blocks(settings.in, reader, sel, T, dc.ctx, mImpl->rid, mImpl->pos)) return false;
+	// Window mode on several GPUs (or processes): a GPU needs only the blocks of its band of rows plus the blocks its
+	// window reaches beyond it (the reference's ticker prunes block pairs the same way, ld_balancing.h:176-203) -
+	// for BASELINE configs[4] that is 75 GB per GPU instead of 500 GB.  Bands are cut at block boundaries with equal
+	// estimated in-window pairs, from the index alone (block span and size), identically in every process.
+	if (settings.window && bal.diag && n_parts > 1 && !(ref_compat() && !(settings.force_phased || settings.forced_unphased))) {
+		const uint64_t w = (uint64_t)std::max(0, settings.l_window);
+		const size_t nb = sel.size();
+		auto ent = [&](size_t k) -> const IndexEntry& { return reader.index.ent[sel[k]]; };
+		std::vector<size_t> reach(nb);                       // first block beyond what block k's window can touch
+		std::vector<uint64_t> nvar(nb + 1, 0), cost(nb + 1, 0);
+		for (size_t k = 0; k < nb; ++k) nvar[k + 1] = nvar[k] + ent(k).n;
+		for (size_t k = 0, e = 0; k < nb; ++k) {
+			if (e < k + 1) e = k + 1;
+			while (e < nb && ent(e).rid == ent(k).rid && (uint64_t)ent(e).minpos <= (uint64_t)ent(k).maxpos + w) ++e;
+			reach[k] = e;
+			const uint64_t n = ent(k).n;
+			cost[k + 1] = cost[k] + n * (n - 1) / 2 + n * (nvar[e] - nvar[k + 1]);
+		}
+		auto boundary = [&](uint32_t p) -> size_t {
+			if (p == 0) return 0;
+			if (p >= n_parts) return nb;
+			const long double target = (long double)cost[nb] * p / n_parts;
+			return (size_t)(std::lower_bound(cost.begin(), cost.end(), (uint64_t)target) - cost.begin());
+		};
+		std::vector<std::vector<uint32_t>> sel_g(n_gpus);
+		for (int g = 0; g < n_gpus; ++g) {
+			const uint32_t p = part0 * (uint32_t)n_gpus + (uint32_t)g;
+			const size_t B0 = boundary(p), B1 = std::max(B0, boundary(p + 1));
+			const size_t H1 = B1 > B0 ? std::max(B1, reach[B1 - 1]) : B1;
+			RunSpec::Slab sl;
+			sl.first = (uint32_t)nvar[B0]; sl.n_band = (uint32_t)(nvar[B1] - nvar[B0]); sl.n_local = (uint32_t)(nvar[H1] - nvar[B0]);
+			spec.slabs.push_back(sl);
+			for (size_t k = B0; k < H1; ++k) sel_g[g].push_back(sel[k]);
+			std::cerr << stamp("LOG", "BALANCING") << "GPU " << g << ": rows = variants [" << sl.first << ", " << sl.first + sl.n_band << "), + "
+			          << sl.n_local - sl.n_band << " halo variants" << std::endl;
+		}
+		mImpl->rid.assign(M, 0); mImpl->pos.assign(M, 0);
+		std::vector<std::vector<uint32_t>> rid_g(n_gpus), pos_g(n_gpus);
+		std::vector<char> ok(n_gpus, 1);
+		std::vector<std::thread> th;
+		for (int g = 0; g < n_gpus; ++g) th.emplace_back([&, g] {
+			if (sel_g[g].empty()) return;
+			if (!hip_ok(dc.ctx[g], twk_hip_set_problem(dc.ctx[g], n_samples, spec.slabs[g].n_local), "twk_hip_set_problem")) { ok[g] = 0; return; }
+			if (!load_blocks(settings.in, reader, sel_g[g], std::max<uint32_t>(1, T / (uint32_t)n_gpus), {dc.ctx[g]}, rid_g[g], pos_g[g])) ok[g] = 0;
+		});
+		for (auto& t : th) t.join();
+		for (int g = 0; g < n_gpus; ++g) {
+			if (!ok[g]) return false;
+			std::copy(rid_g[g].begin(), rid_g[g].end(), mImpl->rid.begin() + spec.slabs[g].first);
+			std::copy(pos_g[g].begin(), pos_g[g].end(), mImpl->pos.begin() + spec.slabs[g].first);
+		}
+	} else {
+		for (auto* c : dc.ctx) if (!hip_ok(c, twk_hip_set_problem(c, n_samples, M), "twk_hip_set_problem")) return false;
+		if (!load_blocks(settings.in, reader, sel, T, dc.ctx, mImpl->rid, mImpl->pos)) return false;
+	}
 	std::cerr << stamp("LOG") << "Unpacked and uploaded " << pretty(M) << " variants. "
 	          << elapsed_string(std::chrono::duration<double>(clock::now() - t_load).count()) << std::endl;
 
-	RunSpec spec;
 	spec.nA = bal.diag ? M : nL; spec.nB = bal.diag ? 0 : nR;
 	spec.triangleA = bal.diag; spec.rectAB = !bal.diag;
 	spec.options = (settings.window ? TWK_HIP_OPT_WINDOW : 0) | (ref_compat() ? TWK_HIP_OPT_REF_COMPAT : 0) | (r2_screen() ? TWK_HIP_OPT_R2_SCREEN : 0);
