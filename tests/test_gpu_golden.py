@@ -266,6 +266,48 @@ def test_cli_window_mode_slabs_per_gpu(tmp_path):
         assert len(one) > 0 and np.array_equal(one, multi)
 
 
+def test_cli_corrupt_input_fails_cleanly(tmp_path):
+    """Damaged .twk blocks - bad zstd frames, record headers that lie, run lengths that do not add up to the sample count
+    (found by the device inflate kernel) - end the run with an error message and exit code 1; nothing crashes or hangs."""
+    N, M = 120, 400
+    al = util.random_alleles(M, N, 3, miss_rate=0.05, miss_variants=0.2)
+    twk = str(tmp_path / "ok.twk")
+    hostlib.write_twk(twk, al, (1000 + 10 * np.arange(M)).astype(np.uint32), np.zeros(M, np.uint32), np.ones(M, np.uint8), block_size=64)
+    good = open(twk, "rb").read()
+    r = subprocess.run([hostlib.CLI_PATH, "calc", "-i", twk, "-o", str(tmp_path / "ok.two")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0
+    rng = np.random.default_rng(1)
+    outcomes = set()
+    for trial in range(12):
+        bad = bytearray(good)
+        lo = len(good) // 8 + int(rng.integers(0, len(good) // 2))
+        if trial % 3 == 0:
+            for k in range(lo, lo + 40): bad[k] = int(rng.integers(0, 256))          # scribble inside a compressed block
+        elif trial % 3 == 1:
+            bad[lo] ^= 1 << int(rng.integers(0, 8))                                     # one flipped bit
+        else:
+            del bad[lo:lo + int(rng.integers(1, 200))]                                  # bytes missing: every offset after it is off
+        p = str(tmp_path / f"bad{trial}.twk")
+        open(p, "wb").write(bytes(bad))
+        r = subprocess.run([hostlib.CLI_PATH, "calc", "-i", p, "-o", str(tmp_path / "bad.two")], capture_output=True, text=True, timeout=120)
+        assert r.returncode in (0, 1), (trial, r.returncode, r.stderr[-300:])
+        outcomes.add(r.returncode)
+        if r.returncode == 1:
+            assert "ERROR" in r.stderr or "failed" in r.stderr.lower()
+    assert 1 in outcomes
+    # run lengths that do not add up, in an otherwise well-formed file: only the device can see it
+    from tomahawk_amd.hip import RLE_DESC_DTYPE
+    import tomahawk_amd as T
+    with T.HipLd(0) as eng:
+        eng.set_problem(N, 1)
+        runs = np.array([((N - 1) << 2) | 1], dtype=np.uint8)                         # one run of N - 1 samples
+        desc = np.zeros(1, dtype=RLE_DESC_DTYPE); desc[0] = (0, 1, 1, 0, 0)
+        meta = np.zeros(1, dtype=T.META_DTYPE)
+        with pytest.raises(T.HipError) as e:
+            eng.upload_rle(runs, desc, meta)
+        assert e.value.code == -1 and "do not add up" in str(e.value)
+
+
 def test_cli_full_chain_import_calc_sort_view(tmp_path):
     """VCF -> import -> calc (default mode, missing genotypes) -> sort -> view: the chain a user of the reference runs."""
     from tests.test_import import write_vcf

@@ -366,16 +366,27 @@ static bool load_blocks(const std::string& path, const TwkReader& reader, const 
 		for (size_t g = 0; g < ctxs.size(); ++g) if (!hip_ok(ctxs[g], up_rc[g], "twk_hip_upload_rle")) return false;
 		return true;
 	};
+	using lclock = std::chrono::steady_clock;
+	double t_fill = 0, t_wait = 0; size_t total_bytes = 0;
 	for (size_t bi = 0; bi < batches.size(); ++bi) {
 		LoadBatch& b = batches[bi];
 		uint8_t* buf = stage[bi & 1].p;
+		const auto t0 = lclock::now();
 		fill(b, buf);                                          // overlaps the upload of batch bi - 1
+		const auto t1 = lclock::now();
 		if (!join_uploads()) return false;
+		t_fill += std::chrono::duration<double>(t1 - t0).count(); t_wait += std::chrono::duration<double>(lclock::now() - t1).count();
+		total_bytes += b.bytes;
 		if (failed) { std::cerr << stamp("ERROR") << "Failed to load blocks " << b.k0 << "-" << b.k1 << "!" << std::endl; return false; }
 		for (size_t g = 0; g < ctxs.size(); ++g)
 			uploaders.emplace_back([&, g, buf]() { up_rc[g] = twk_hip_upload_rle(ctxs[g], b.first, b.nv, buf, b.bytes, b.desc.data(), b.meta.data()); });
 	}
-	return join_uploads();
+	const auto t2 = lclock::now();
+	const bool ok = join_uploads();
+	t_wait += std::chrono::duration<double>(lclock::now() - t2).count();
+	std::cerr << stamp("LOG", "UNPACK") << batches.size() << " batches, " << total_bytes / 1000000 << " MB of run-length genotypes: read + decompress "
+	          << t_fill << " s, waiting for uploads + device inflate " << t_wait << " s" << (stage[0].pinned ? "" : " (staging not page-locked)") << std::endl;
+	return ok;
 }
 
 // TWK_REF_COMPAT=1: reproduce slips of the reference that change output bytes instead of the correct result -
