@@ -24,6 +24,8 @@ def run(tag, twk, args, env=None):
     eng = re.findall(r"count kernel ([0-9.e+]+) ms in (\d+) launches, math kernel ([0-9.e+]+) ms", log)
     print(f"{tag}: wall {wall:.2f} s | load {load.group(1) if load else '?'} | compute+write {fin.group(1) if fin else '?'} | pairs {fin.group(2) if fin else '?'} | "
           f"records {fin.group(3) if fin else '?'} | {rate.group(1) if rate else '?'} pairs/s in the compute phase | engine {eng}", flush=True)
+    for l in log.splitlines():
+        if "[UNPACK]" in l and "batches" in l: print("    " + l.split("[UNPACK]")[1].strip(), flush=True)
     try: os.remove(out)
     except OSError: pass
 

@@ -27,12 +27,13 @@ def golden_as_oracle_records(mat):
     return r
 
 
-@pytest.mark.parametrize("tag", ["p", "u", "d"])
-@pytest.mark.parametrize("name", CASES)
+def _cases_with_records():
+    return [(name, tag) for tag in ("p", "u", "d") for name in CASES if "rec_" + tag in np.load(os.path.join(GOLDEN, name + ".npz")).files]
+
+
+@pytest.mark.parametrize("name,tag", _cases_with_records())
 def test_hip_equals_reference_records(hip, name, tag):
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
-    if "rec_" + tag not in z.files:
-        pytest.skip("case has no all-pairs records")
     al = z["alleles"]
     variants = O.variants_from_alleles(al, pos=z["pos"], rid=z["rid"], phase=1)
     util.upload(hip, al, variants)

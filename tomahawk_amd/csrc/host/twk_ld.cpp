@@ -308,14 +308,21 @@ bool index_block(const uint8_t* base, size_t block_off, size_t block_len, uint32
 
 static bool load_blocks(const std::string& path, const TwkReader& reader, const std::vector<uint32_t>& sel,
                         uint32_t T, const std::vector<twk_hip_ctx*>& ctxs, std::vector<uint32_t>& rid, std::vector<uint32_t>& pos) {
+	using lclock = std::chrono::steady_clock;
+	const auto t_begin = lclock::now();
 	std::vector<uint32_t> first(sel.size() + 1, 0);
 	for (size_t k = 0; k < sel.size(); ++k) first[k + 1] = first[k] + reader.index.ent[sel[k]].n;
 	rid.assign(first.back(), 0); pos.assign(first.back(), 0);
+	if (sel.empty()) return true;
 	const int fd = ::open(path.c_str(), O_RDONLY);
 	if (fd < 0) { std::cerr << stamp("ERROR") << "Failed to open " << path << std::endl; return false; }
 	struct Closer { int fd; ~Closer() { ::close(fd); } } closer{fd};
-	// batches
-	const size_t batch_cap = (size_t)256 << 20;
+	// Batches of whole blocks, one decode thread each.  A batch holds at least one block and at most 128 MB;
+	// small inputs are cut finer so that every decode thread gets several.
+	const uint32_t W = std::max<uint32_t>(1, std::min<uint32_t>(T, 16));           // decode threads
+	size_t total_unc = 0, max_block = 0;
+	for (uint32_t k : sel) { const size_t u = ((size_t)reader.index.ent[k].b_unc + 15) / 16 * 16; total_unc += u; max_block = std::max(max_block, u); }
+	const size_t batch_cap = std::max(max_block, std::min<size_t>((size_t)128 << 20, std::max<size_t>((size_t)2 << 20, total_unc / (4 * (size_t)W))));
 	std::vector<LoadBatch> batches;
 	for (size_t k = 0; k < sel.size();) {
 		LoadBatch b; b.k0 = k; b.first = first[k];
@@ -329,64 +336,110 @@ static bool load_blocks(const std::string& path, const TwkReader& reader, const 
 	}
 	size_t max_bytes = 0;
 	for (const auto& b : batches) max_bytes = std::max(max_bytes, b.bytes);
-	Staging stage[2];
-	if (!stage[0].reserve(max_bytes) || (batches.size() > 1 && !stage[1].reserve(max_bytes))) { std::cerr << stamp("ERROR") << "Out of host memory for the upload staging buffers" << std::endl; return false; }
-
+	const size_t n_batches = batches.size(), n_gpus = ctxs.size();
+	const uint32_t n_workers = (uint32_t)std::min<size_t>(W, n_batches);
+	// Staging slots (page-locked, allocated by the first thread that needs one): a decode thread takes a free
+	// slot, then the next batch in file order, and fills it; one uploader thread per GPU takes the batches in
+	// file order (copy + device inflate); the slot is free again when every GPU has it.  Taking the slot before
+	// the batch means the oldest batch not yet uploaded always has one, so the in-order uploaders never starve.
+	const size_t n_slots = std::min<size_t>(n_batches, (size_t)n_workers + 2);
+	std::vector<Staging> slots(n_slots);
+	std::mutex mu;
+	std::condition_variable cv_free, cv_ready;
+	std::vector<size_t> free_slots;
+	for (size_t i = 0; i < n_slots; ++i) free_slots.push_back(n_slots - 1 - i);
+	std::vector<int> slot_of(n_batches, -1);         // under mu
+	std::vector<char> ready(n_batches, 0);           // under mu
+	std::vector<uint32_t> pending(n_batches, (uint32_t)n_gpus);
+	size_t next_batch = 0;                           // under mu
 	std::atomic<bool> failed(false);
-	auto fill = [&](LoadBatch& b, uint8_t* buf) {
-		b.desc.resize(b.nv); b.meta.resize(b.nv);
-		std::atomic<size_t> next(b.k0);
-		auto job = [&]() {
-			std::vector<uint8_t> z;
-			for (size_t k = next++; k < b.k1 && !failed; k = next++) {
-				const IndexEntry& e = reader.index.ent[sel[k]];
-				uint8_t head[9];
-				if (!pread_all(fd, head, 9, e.foff)) { failed = true; return; }
-				uint32_t unc, cmp; std::memcpy(&unc, head + 1, 4); std::memcpy(&cmp, head + 5, 4);
-				if (head[0] != 1 || unc != e.b_unc || cmp > ((size_t)1 << 31)) { failed = true; return; }
-				z.resize(cmp);
-				if (!pread_all(fd, z.data(), cmp, e.foff + 9)) { failed = true; return; }
-				uint8_t* dst = buf + b.boff[k - b.k0];
-				if (!zstd_decompress_into(z.data(), cmp, dst, unc)) { failed = true; return; }
-				const uint32_t v0 = first[k] - b.first;
-				if (!index_block(buf, b.boff[k - b.k0], unc, e.n, &b.desc[v0], &b.meta[v0])) { failed = true; return; }
-			}
-		};
-		const uint32_t nt = (uint32_t)std::max<size_t>(1, std::min<size_t>(T, b.k1 - b.k0));
-		std::vector<std::thread> th;
-		for (uint32_t t = 0; t < nt; ++t) th.emplace_back(job);
-		for (auto& t : th) t.join();
-		for (uint32_t i = 0; i < b.nv && !failed; ++i) { rid[b.first + i] = b.meta[i].rid; pos[b.first + i] = b.meta[i].pos; }
+	std::string fail_msg;                            // under mu, first failure only
+	auto fail = [&](const std::string& msg) {
+		std::lock_guard<std::mutex> lk(mu);
+		if (!failed.exchange(true)) fail_msg = msg;
+		cv_free.notify_all(); cv_ready.notify_all();
 	};
-	std::vector<int> up_rc(ctxs.size(), TWK_HIP_OK);
-	std::vector<std::thread> uploaders;
-	auto join_uploads = [&]() -> bool {
-		for (auto& t : uploaders) t.join();
-		uploaders.clear();
-		for (size_t g = 0; g < ctxs.size(); ++g) if (!hip_ok(ctxs[g], up_rc[g], "twk_hip_upload_rle")) return false;
+	std::vector<double> busy_decode(n_workers, 0.0), busy_upload(n_gpus, 0.0);
+	bool pinned_all = true;                          // under mu
+
+	auto decode_batch = [&](LoadBatch& b, uint8_t* buf) -> bool {
+		b.desc.resize(b.nv); b.meta.resize(b.nv);
+		std::vector<uint8_t> z;
+		for (size_t k = b.k0; k < b.k1; ++k) {
+			const IndexEntry& e = reader.index.ent[sel[k]];
+			uint8_t head[9];
+			if (!pread_all(fd, head, 9, e.foff)) return false;
+			uint32_t unc, cmp; std::memcpy(&unc, head + 1, 4); std::memcpy(&cmp, head + 5, 4);
+			if (head[0] != 1 || unc != e.b_unc || cmp > ((size_t)1 << 31)) return false;
+			z.resize(cmp);
+			if (!pread_all(fd, z.data(), cmp, e.foff + 9)) return false;
+			if (!zstd_decompress_into(z.data(), cmp, buf + b.boff[k - b.k0], unc)) return false;
+			const uint32_t v0 = first[k] - b.first;
+			if (!index_block(buf, b.boff[k - b.k0], unc, e.n, &b.desc[v0], &b.meta[v0])) return false;
+		}
+		for (uint32_t i = 0; i < b.nv; ++i) { rid[b.first + i] = b.meta[i].rid; pos[b.first + i] = b.meta[i].pos; }
 		return true;
 	};
-	using lclock = std::chrono::steady_clock;
-	double t_fill = 0, t_wait = 0; size_t total_bytes = 0;
-	for (size_t bi = 0; bi < batches.size(); ++bi) {
-		LoadBatch& b = batches[bi];
-		uint8_t* buf = stage[bi & 1].p;
-		const auto t0 = lclock::now();
-		fill(b, buf);                                          // overlaps the upload of batch bi - 1
-		const auto t1 = lclock::now();
-		if (!join_uploads()) return false;
-		t_fill += std::chrono::duration<double>(t1 - t0).count(); t_wait += std::chrono::duration<double>(lclock::now() - t1).count();
-		total_bytes += b.bytes;
-		if (failed) { std::cerr << stamp("ERROR") << "Failed to load blocks " << b.k0 << "-" << b.k1 << "!" << std::endl; return false; }
-		for (size_t g = 0; g < ctxs.size(); ++g)
-			uploaders.emplace_back([&, g, buf]() { up_rc[g] = twk_hip_upload_rle(ctxs[g], b.first, b.nv, buf, b.bytes, b.desc.data(), b.meta.data()); });
-	}
-	const auto t2 = lclock::now();
-	const bool ok = join_uploads();
-	t_wait += std::chrono::duration<double>(lclock::now() - t2).count();
-	std::cerr << stamp("LOG", "UNPACK") << batches.size() << " batches, " << total_bytes / 1000000 << " MB of run-length genotypes: read + decompress "
-	          << t_fill << " s, waiting for uploads + device inflate " << t_wait << " s" << (stage[0].pinned ? "" : " (staging not page-locked)") << std::endl;
-	return ok;
+	auto decoder = [&](uint32_t w) {
+		for (;;) {
+			size_t slot, bi;
+			{
+				std::unique_lock<std::mutex> lk(mu);
+				if (next_batch >= n_batches) return;           // nothing left: do not hold a slot for it
+				cv_free.wait(lk, [&] { return failed || !free_slots.empty(); });
+				if (failed || next_batch >= n_batches) return;
+				slot = free_slots.back(); free_slots.pop_back();
+				bi = next_batch++;
+				slot_of[bi] = (int)slot;
+				if (next_batch >= n_batches) cv_free.notify_all();     // the threads still waiting for a slot can go home
+			}
+			const auto t0 = lclock::now();
+			if (!slots[slot].reserve(max_bytes)) { fail("Out of host memory for the upload staging buffers"); return; }
+			if (!slots[slot].pinned) { std::lock_guard<std::mutex> lk(mu); pinned_all = false; }
+			if (!decode_batch(batches[bi], slots[slot].p)) {
+				fail("Failed to load blocks " + std::to_string(batches[bi].k0) + "-" + std::to_string(batches[bi].k1) + "!");
+				return;
+			}
+			busy_decode[w] += std::chrono::duration<double>(lclock::now() - t0).count();
+			{ std::lock_guard<std::mutex> lk(mu); ready[bi] = 1; }
+			cv_ready.notify_all();
+		}
+	};
+	auto uploader = [&](size_t g) {
+		for (size_t bi = 0; bi < n_batches; ++bi) {
+			int slot;
+			{
+				std::unique_lock<std::mutex> lk(mu);
+				cv_ready.wait(lk, [&] { return failed || ready[bi]; });
+				if (failed) return;
+				slot = slot_of[bi];
+			}
+			const LoadBatch& b = batches[bi];
+			const auto t0 = lclock::now();
+			const int rc = twk_hip_upload_rle(ctxs[g], b.first, b.nv, slots[slot].p, b.bytes, b.desc.data(), b.meta.data());
+			busy_upload[g] += std::chrono::duration<double>(lclock::now() - t0).count();
+			if (rc != TWK_HIP_OK) {
+				const char* m = twk_hip_last_error(ctxs[g]);
+				fail(std::string("twk_hip_upload_rle: ") + twk_hip_strerror(rc) + (m && m[0] ? std::string(" (") + m + ")" : std::string()));
+				return;
+			}
+			std::lock_guard<std::mutex> lk(mu);
+			if (--pending[bi] == 0) { free_slots.push_back((size_t)slot); cv_free.notify_all(); }
+		}
+	};
+	std::vector<std::thread> th;
+	for (size_t g = 0; g < n_gpus; ++g) th.emplace_back(uploader, g);
+	for (uint32_t w = 0; w < n_workers; ++w) th.emplace_back(decoder, w);
+	for (auto& t : th) t.join();
+	if (failed) { std::cerr << stamp("ERROR") << fail_msg << std::endl; return false; }
+	double dec = 0, up = 0;
+	for (double x : busy_decode) dec += x;
+	for (double x : busy_upload) up = std::max(up, x);
+	std::cerr << stamp("LOG", "UNPACK") << n_batches << " batches, " << total_unc / 1000000 << " MB of run-length genotypes in "
+	          << std::chrono::duration<double>(lclock::now() - t_begin).count() << " s: " << n_workers << " decode threads busy " << dec
+	          << " s in all (read + decompress), copy + device inflate " << up << " s per GPU, " << n_slots << " staging slots of "
+	          << max_bytes / 1000000 << " MB" << (pinned_all ? "" : " (not page-locked)") << std::endl;
+	return true;
 }
 
 // TWK_REF_COMPAT=1: reproduce slips of the reference that change output bytes instead of the correct result -
