@@ -162,111 +162,228 @@ __global__ void k_clear_tail(uint32_t* __restrict__ raw, uint32_t Wp, uint32_t n
 // with m = 1 and two bits per allele (0 ref, 1 alt, 2 missing) when the variant has missing genotypes,
 // m = 0 and one bit per allele otherwise.
 //
-// One 256-thread block per variant, two phases:
-//   1. every thread sums the lengths of groups of 32 runs, a block scan turns the sums into the first
-//      sample of every group (scratch: one u32 per group);
-//   2. every thread produces spans of 8 output words (128 samples): binary search for the group that
-//      holds the span's first sample, walk the runs, OR the allele patterns in, store.
-// Output-centric, so no atomics, every row word is written exactly once (zero where nothing is ALT) and
-// the padding beyond 2N bits is zero.  status[0] is set to 1 if any variant's runs do not add up to
-// n_samples (corrupt input).
+// Run-centric, a variant's runs cut into chunks of RLE_CHUNK_STEPS steps of 4096 bytes (16 bytes per
+// thread: 16 / 8 / 4 runs of 1 / 2 / 4 bytes), one 256-thread block per chunk, so a common variant with
+// half a million short runs is expanded by a hundred blocks and a rare one by one:
+//   k_rle_chunk_sums   the samples every chunk covers (sum of its run lengths);
+//   k_inflate_rle      a block adds up the chunks before its own (its first sample), then walks its
+//                      steps: dword loads from the aligned address below the thread's first run +
+//                      v_alignbit, the step after the current one already in flight; a block scan of
+//                      the run lengths gives every run its first sample.
+// The rows are zero when the kernel starts (the host clears them on the same stream), so only the runs
+// that carry an ALT or a missing allele are painted: ORed into an LDS window of RLE_WIN row words that
+// starts at the step's first word (ds_or), and the window is then stored to the row - plain coalesced
+// stores, except the step's first and last word, which it shares with its neighbours (atomic OR; the
+// neighbour may be another block).  Words of a step beyond the window (runs longer than 32 samples on
+// average: few of them carry anything) are ORed straight into the row.  A run that covers 64 words or
+// more is painted by its whole wave.  status[0] is set to 1 if a variant's runs do not add up to
+// n_samples (corrupt input); nothing is ever written outside the variant's row.
 struct RleDesc {
 	unsigned long long off;     // byte offset of the variant's first run word in `bytes`
 	uint32_t n_runs;
 	uint32_t width_missing;     // bits 0-7: bytes per run word (1, 2, 4); bit 8: variant has missing genotypes
 };
-constexpr int RLE_GROUP = 32;          // runs per scan group
-constexpr int RLE_SPAN_WORDS = 8;      // 32-bit output words per paint step of a thread
+constexpr int RLE_STEP_BYTES = 16;         // run bytes per thread and step
+constexpr uint32_t RLE_CHUNK_STEPS = 4;    // steps per block
+constexpr uint32_t RLE_CHUNK_BYTES = RLE_CHUNK_STEPS * 256 * RLE_STEP_BYTES;
+constexpr uint32_t RLE_WIN = 4096;         // row words per LDS window (65,536 samples)
 
-__device__ __forceinline__ uint32_t rle_word(const uint8_t* __restrict__ p, uint32_t i, uint32_t width) {
-	p += (size_t)i * width;
-	if (width == 1) return p[0];
-	if (width == 2) return (uint32_t)p[0] | (uint32_t)p[1] << 8;
-	return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24;
+// The part of samples [s, e) that lies in row word w gets `pat` (and all-ones in the mask row when miss):
+// in the LDS window when the word is inside it, in the row itself otherwise.
+__device__ __forceinline__ void rle_paint_word(uint32_t* __restrict__ row, uint32_t* __restrict__ mrow,
+                                               uint32_t* win, uint32_t* winm, uint32_t w_base, uint32_t w,
+                                               uint32_t s, uint32_t e, uint32_t pat, bool miss) {
+	const uint32_t w_s = w << 4;
+	const uint32_t lo = s > w_s ? s - w_s : 0u, hi = min(e - w_s, 16u);
+	const uint32_t bits = (hi - lo) * 2;
+	const uint32_t rng = (bits == 32 ? 0xFFFFFFFFu : ((1u << bits) - 1u)) << (lo * 2);
+	const uint32_t i = w - w_base;
+	if (i < RLE_WIN) {
+		if (pat) atomicOr(win + i, pat & rng);
+		if (miss) atomicOr(winm + i, rng);
+	} else {
+		if (pat) atomicOr(row + w, pat & rng);
+		if (miss) atomicOr(mrow + w, rng);
+	}
+}
+
+struct RleRegs { uint32_t q[5]; };
+__device__ __forceinline__ void rle_load(RleRegs& r, const uint8_t* __restrict__ runs, uint32_t first_run, uint32_t n_runs, uint32_t width) {
+	if (first_run < n_runs) {
+		const uintptr_t a = reinterpret_cast<uintptr_t>(runs) + (size_t)first_run * width;
+		const uint32_t* q = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
+#pragma unroll
+		for (int i = 0; i < 5; ++i) r.q[i] = q[i];                 // up to 19 bytes past the last run: the buffer is padded
+	} else {
+#pragma unroll
+		for (int i = 0; i < 5; ++i) r.q[i] = 0;
+	}
+}
+// The thread's R runs of a step (0 beyond the variant's last run) and the samples they cover.
+template <int WIDTH>
+__device__ __forceinline__ unsigned long long rle_unpack(const RleRegs& regs, uint32_t sh, uint32_t r_first, uint32_t n_runs,
+                                                         uint32_t shift, uint32_t (&run)[RLE_STEP_BYTES / WIDTH]) {
+	constexpr int R = RLE_STEP_BYTES / WIDTH;
+	uint32_t w[4];
+#pragma unroll
+	for (int i = 0; i < 4; ++i) w[i] = __builtin_amdgcn_alignbit(regs.q[i + 1], regs.q[i], sh);
+	const uint32_t nv = r_first < n_runs ? min((uint32_t)R, n_runs - r_first) : 0u;
+	unsigned long long sum = 0;
+#pragma unroll
+	for (int j = 0; j < R; ++j) {
+		uint32_t x;
+		if (WIDTH == 4) x = w[j];
+		else if (WIDTH == 2) x = (w[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
+		else x = (w[j >> 2] >> ((j & 3) * 8)) & 0xFFu;
+		run[j] = (uint32_t)j < nv ? x : 0u;
+		sum += run[j] >> shift;
+	}
+	return sum;
+}
+__device__ __forceinline__ unsigned long long rle_block_sum(unsigned long long x, unsigned long long* wave_tot) {
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+	for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o);
+	if (lane == 0) wave_tot[wv] = x;
+	__syncthreads();
+	const unsigned long long t = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+	__syncthreads();
+	return t;
+}
+// block -> (variant, chunk of the variant): chunk_base[v] = first block of variant v, ascending, chunk_base[count] = grid
+__device__ __forceinline__ uint32_t rle_variant_of_block(const uint32_t* __restrict__ chunk_base, uint32_t count, uint32_t blk) {
+	uint32_t lo = 0, hi = count;                                   // invariant: chunk_base[lo] <= blk < chunk_base[hi]
+	while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (chunk_base[mid] <= blk) lo = mid; else hi = mid; }
+	return lo;
+}
+
+template <int WIDTH>
+__device__ __forceinline__ unsigned long long rle_chunk_sum(const uint8_t* __restrict__ runs, uint32_t n_runs, uint32_t m, uint32_t chunk) {
+	constexpr int R = RLE_STEP_BYTES / WIDTH;
+	const uint32_t shift = 2 + 2 * m, tid = threadIdx.x;
+	const uint32_t sh = (uint32_t)((reinterpret_cast<uintptr_t>(runs) + (size_t)tid * RLE_STEP_BYTES) & 3) * 8;
+	unsigned long long sum = 0;
+	RleRegs regs[RLE_CHUNK_STEPS];
+#pragma unroll
+	for (uint32_t k = 0; k < RLE_CHUNK_STEPS; ++k) rle_load(regs[k], runs, (chunk * RLE_CHUNK_STEPS + k) * 256 * R + tid * R, n_runs, WIDTH);
+#pragma unroll
+	for (uint32_t k = 0; k < RLE_CHUNK_STEPS; ++k) {
+		uint32_t run[R];
+		sum += rle_unpack<WIDTH>(regs[k], sh, (chunk * RLE_CHUNK_STEPS + k) * 256 * R + tid * R, n_runs, shift, run);
+	}
+	return sum;
 }
 
 __global__ __launch_bounds__(256)
-void k_inflate_rle(const uint8_t* __restrict__ bytes, const RleDesc* __restrict__ desc,
-                   const unsigned long long* __restrict__ group_base,   // first scratch slot of every variant
-                   uint32_t* __restrict__ scratch, uint32_t* __restrict__ raw, uint32_t* __restrict__ rawmask,
-                   uint32_t Wp, uint32_t n_samples, uint32_t first_row, int* __restrict__ status) {
-	const uint32_t v = blockIdx.x;
+void k_rle_chunk_sums(const uint8_t* __restrict__ bytes, const RleDesc* __restrict__ desc, const uint32_t* __restrict__ chunk_base,
+                      uint32_t count, unsigned long long* __restrict__ chunk_sum) {
+	__shared__ unsigned long long wave_tot[4];
+	const uint32_t v = rle_variant_of_block(chunk_base, count, blockIdx.x), chunk = blockIdx.x - chunk_base[v];
 	const RleDesc d = desc[v];
 	const uint32_t width = d.width_missing & 0xFFu, m = (d.width_missing >> 8) & 1u;
-	const uint32_t shift = 2 + 2 * m, amask = (1u << (1 + m)) - 1;
 	const uint8_t* runs = bytes + d.off;
-	const uint32_t n_groups = (d.n_runs + RLE_GROUP - 1) / RLE_GROUP;
-	uint32_t* gstart = scratch + group_base[v];                  // first sample of every group
-	__shared__ uint32_t warp_sum[4];
-	__shared__ uint32_t carry_s;
+	unsigned long long s;
+	if (width == 2) s = rle_chunk_sum<2>(runs, d.n_runs, m, chunk);
+	else if (width == 1) s = rle_chunk_sum<1>(runs, d.n_runs, m, chunk);
+	else s = rle_chunk_sum<4>(runs, d.n_runs, m, chunk);
+	s = rle_block_sum(s, wave_tot);
+	if (threadIdx.x == 0) chunk_sum[blockIdx.x] = s;
+}
+
+template <int WIDTH>
+__device__ __forceinline__ void rle_inflate_chunk(const uint8_t* __restrict__ runs, const uint32_t n_runs, const uint32_t m,
+                                                  const uint32_t chunk, unsigned long long pos, const bool last_chunk,
+                                                  uint32_t* __restrict__ row, uint32_t* __restrict__ mrow,
+                                                  const uint32_t n_samples, int* __restrict__ status, unsigned long long* wave_tot,
+                                                  uint32_t* win, uint32_t* winm) {
+	constexpr int R = RLE_STEP_BYTES / WIDTH;                      // runs per thread and step
+	const uint32_t shift = 2 + 2 * m, amask = (1u << (1 + m)) - 1;
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-	if (tid == 0) carry_s = 0;
-	__syncthreads();
-	// ---- phase 1: exclusive scan of the group sums -------------------------------------------
-	for (uint32_t g0 = 0; g0 < n_groups; g0 += 256) {
-		const uint32_t g = g0 + tid;
-		uint32_t sum = 0;
-		if (g < n_groups) {
-			const uint32_t r1 = min(d.n_runs, (g + 1) * RLE_GROUP);
-			for (uint32_t r = g * RLE_GROUP; r < r1; ++r) sum += rle_word(runs, r, width) >> shift;
+	const uint32_t sh = (uint32_t)((reinterpret_cast<uintptr_t>(runs) + (size_t)tid * RLE_STEP_BYTES) & 3) * 8;   // same for every step: a step is 4096 bytes
+	const uint32_t r_begin = chunk * RLE_CHUNK_STEPS * 256 * R;
+	const uint32_t r_end = min(n_runs, r_begin + RLE_CHUNK_STEPS * 256 * R);
+	RleRegs cur_regs, next_regs;                                   // pos: first sample of the step (uniform)
+	rle_load(cur_regs, runs, r_begin + (uint32_t)tid * R, n_runs, WIDTH);
+	for (uint32_t r0 = r_begin; r0 < r_end; r0 += 256 * R) {
+		const uint32_t r_first = r0 + (uint32_t)tid * R;
+		if (r0 + 256 * R < r_end) rle_load(next_regs, runs, r_first + 256 * R, n_runs, WIDTH);
+		uint32_t run[R];
+		const unsigned long long sum = rle_unpack<WIDTH>(cur_regs, sh, r_first, n_runs, shift, run);
+		unsigned long long inc = sum;                              // inclusive scan within the wave
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) { const unsigned long long t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+		if (lane == 63) wave_tot[wv] = inc;
+		__syncthreads();
+		unsigned long long cur = pos + inc - sum, step_total = 0;
+#pragma unroll
+		for (int k = 0; k < 4; ++k) { const unsigned long long t = wave_tot[k]; if (k < wv) cur += t; step_total += t; }
+		__syncthreads();                                           // wave_tot is rewritten by the next step
+		// the step's words: [w_base, w_base + n_words)
+		const unsigned long long step_end = pos + step_total < n_samples ? pos + step_total : n_samples;
+		const uint32_t w_base = (uint32_t)(pos < n_samples ? pos : n_samples) >> 4;
+		const uint32_t n_words = step_end > pos ? (uint32_t)((step_end - 1) >> 4) - w_base + 1 : 0u;
+#pragma unroll
+		for (int j = 0; j < R; ++j) {
+			const uint32_t len = run[j] >> shift, a = (run[j] >> (1 + m)) & amask, b = run[j] & amask;
+			const unsigned long long e64 = cur + len;
+			const bool live = len != 0 && (a | b) != 0 && cur < n_samples;
+			const uint32_t s = (uint32_t)cur, e = (uint32_t)(e64 < n_samples ? e64 : n_samples);
+			const uint32_t pat = (a == 1 ? 0x55555555u : 0u) | (b == 1 ? 0xAAAAAAAAu : 0u);
+			const bool miss = mrow != nullptr && (a == 2 || b == 2);
+			const uint32_t wa = s >> 4, wb = live ? (e - 1) >> 4 : 0u;
+			const bool wide = live && wb - wa >= 64;
+			if (live && !wide) for (uint32_t x = wa; x <= wb; ++x) rle_paint_word(row, mrow, win, winm, w_base, x, s, e, pat, miss);
+			unsigned long long todo = __ballot(wide);              // long runs: the whole wave paints
+			while (todo) {
+				const int src = __ffsll((long long)todo) - 1;
+				todo &= todo - 1;
+				const uint32_t s2 = __shfl(s, src), e2 = __shfl(e, src), pat2 = __shfl(pat, src);
+				const bool miss2 = __shfl((int)miss, src) != 0;
+				for (uint32_t x = (s2 >> 4) + lane; x <= (e2 - 1) >> 4; x += 64) rle_paint_word(row, mrow, win, winm, w_base, x, s2, e2, pat2, miss2);
+			}
+			cur = e64;
 		}
-		uint32_t inc = sum;                                     // inclusive scan within the wave
-		for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o); if (lane >= o) inc += t; }
-		if (lane == 63) warp_sum[wv] = inc;
 		__syncthreads();
-		uint32_t before = carry_s;
-		for (int k = 0; k < wv; ++k) before += warp_sum[k];
-		if (g < n_groups) gstart[g] = before + inc - sum;
-		__syncthreads();
-		if (tid == 255) carry_s = before + inc;
-		__syncthreads();
-	}
-	const uint32_t total = carry_s;
-	if (total != n_samples) { if (tid == 0) status[0] = 1; }
-	// ---- phase 2: paint -----------------------------------------------------------------------------
-	uint32_t* row = raw + (size_t)(first_row + v) * Wp;
-	uint32_t* mrow = rawmask ? rawmask + (size_t)(first_row + v) * Wp : nullptr;
-	const uint32_t n_spans = (Wp + RLE_SPAN_WORDS - 1) / RLE_SPAN_WORDS;
-	const uint32_t live = min(total, n_samples);                // samples the runs actually describe
-	for (uint32_t sp = tid; sp < n_spans; sp += 256) {
-		uint32_t out[RLE_SPAN_WORDS], outm[RLE_SPAN_WORDS];
-#pragma unroll
-		for (int k = 0; k < RLE_SPAN_WORDS; ++k) { out[k] = 0; outm[k] = 0; }
-		const uint32_t s0 = sp * (RLE_SPAN_WORDS * 16);          // first sample of the span
-		const uint32_t s1 = min(live, s0 + RLE_SPAN_WORDS * 16);
-		if (s0 < s1 && n_groups) {
-			// largest group g with gstart[g] <= s0
-			uint32_t lo = 0, hi = n_groups;                     // invariant: gstart[lo] <= s0 (gstart[0] = 0)
-			while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (gstart[mid] <= s0) lo = mid; else hi = mid; }
-			uint32_t r = lo * RLE_GROUP, cur = gstart[lo];      // run r starts at sample cur
-			while (r < d.n_runs && cur < s1) {
-				const uint32_t wd = rle_word(runs, r, width);
-				const uint32_t len = wd >> shift, a = (wd >> (1 + m)) & amask, b = wd & amask;
-				const uint32_t e = cur + len;
-				if (e > s0 && (a | b)) {
-					const uint32_t p0 = max(cur, s0) - s0, p1 = min(e, s1) - s0;       // samples [p0, p1) of the span
-					const uint32_t pat = (a == 1 ? 0x55555555u : 0u) | (b == 1 ? 0xAAAAAAAAu : 0u);
-					const uint32_t miss = (a == 2 || b == 2) ? 0xFFFFFFFFu : 0u;
-#pragma unroll
-					for (int k = 0; k < RLE_SPAN_WORDS; ++k) {
-						const uint32_t w0 = k * 16, w1 = w0 + 16;
-						if (p1 > w0 && p0 < w1) {
-							const uint32_t lo_s = max(p0, w0) - w0, hi_s = min(p1, w1) - w0;       // samples [lo_s, hi_s) of word k
-							const uint32_t bits = (hi_s - lo_s) * 2;
-							const uint32_t rng = (bits == 32 ? 0xFFFFFFFFu : ((1u << bits) - 1u)) << (lo_s * 2);
-							out[k] |= pat & rng; outm[k] |= miss & rng;
-						}
-					}
-				}
-				cur = e; ++r;
+		// window -> row, and the window is zero again
+		for (uint32_t i = tid; i < min(n_words, RLE_WIN); i += 256) {
+			const bool shared_word = i == 0 || i == n_words - 1;       // also holds bits of the previous / next step
+			const uint32_t x = win[i];
+			if (x) { if (shared_word) atomicOr(row + w_base + i, x); else row[w_base + i] = x; win[i] = 0; }
+			if (mrow) {
+				const uint32_t y = winm[i];
+				if (y) { if (shared_word) atomicOr(mrow + w_base + i, y); else mrow[w_base + i] = y; winm[i] = 0; }
 			}
 		}
-#pragma unroll
-		for (int k = 0; k < RLE_SPAN_WORDS; ++k) {
-			const uint32_t w = sp * RLE_SPAN_WORDS + k;
-			if (w < Wp) { row[w] = out[k]; if (mrow) mrow[w] = outm[k]; }
-		}
+		__syncthreads();
+		pos += step_total;
+		cur_regs = next_regs;
 	}
+	if (last_chunk && pos != n_samples && tid == 0) status[0] = 1;
+}
+
+__global__ __launch_bounds__(256)
+void k_inflate_rle(const uint8_t* __restrict__ bytes, const RleDesc* __restrict__ desc, const uint32_t* __restrict__ chunk_base,
+                   uint32_t count, const unsigned long long* __restrict__ chunk_sum,
+                   uint32_t* __restrict__ raw, uint32_t* __restrict__ rawmask,
+                   uint32_t Wp, uint32_t n_samples, uint32_t first_row, int* __restrict__ status) {
+	__shared__ unsigned long long wave_tot[4];
+	__shared__ uint32_t win[RLE_WIN], winm[RLE_WIN];
+	const uint32_t v = rle_variant_of_block(chunk_base, count, blockIdx.x);
+	const uint32_t cb = chunk_base[v], chunk = blockIdx.x - cb, n_chunks = chunk_base[v + 1] - cb;
+	const RleDesc d = desc[v];
+	const uint32_t width = d.width_missing & 0xFFu, m = (d.width_missing >> 8) & 1u;
+	const uint8_t* runs = bytes + d.off;
+	uint32_t* row = raw + (size_t)(first_row + v) * Wp;
+	uint32_t* mrow = rawmask ? rawmask + (size_t)(first_row + v) * Wp : nullptr;
+	for (uint32_t i = threadIdx.x; i < RLE_WIN; i += 256) { win[i] = 0; winm[i] = 0; }
+	unsigned long long before = 0;                                 // samples of the chunks before this one
+	for (uint32_t k = threadIdx.x; k < chunk; k += 256) before += chunk_sum[cb + k];
+	const unsigned long long pos = rle_block_sum(before, wave_tot);                 // (also the barrier after the window's zeroing)
+	const bool last = chunk + 1 == n_chunks;
+	if (d.n_runs == 0) { if (n_samples != 0 && threadIdx.x == 0) status[0] = 1; return; }
+	if (width == 2) rle_inflate_chunk<2>(runs, d.n_runs, m, chunk, pos, last, row, mrow, n_samples, status, wave_tot, win, winm);
+	else if (width == 1) rle_inflate_chunk<1>(runs, d.n_runs, m, chunk, pos, last, row, mrow, n_samples, status, wave_tot, win, winm);
+	else rle_inflate_chunk<4>(runs, d.n_runs, m, chunk, pos, last, row, mrow, n_samples, status, wave_tot, win, winm);
 }
 
 }  // namespace twk

@@ -97,10 +97,9 @@ struct twk_hip_ctx {
 	bool progress_muted = false;       // second stage of a default-mode run: its pairs were already counted
 	uint32_t resident_blocks = 512;   // count-kernel blocks the chip holds at once (2 per CU)
 	uint32_t* tickets = nullptr;      // [6] work tickets of the count launches: one per (slot, launch)
-	// staging of twk_hip_upload_rle (grow-only): run bytes, descriptors + scratch offsets, scan scratch, status word
+	// staging of twk_hip_upload_rle (grow-only): run bytes, descriptors, status word
 	uint8_t* d_rle = nullptr; size_t d_rle_cap = 0;
 	uint8_t* d_rle_desc = nullptr; size_t d_rle_desc_cap = 0;
-	uint32_t* d_rle_scratch = nullptr; size_t d_rle_scratch_cap = 0;
 	int* d_status = nullptr;
 	uint32_t* d_col_hi = nullptr; size_t d_col_hi_cap = 0;   // r2 screen: per-row column limit of the current region
 	char err[512] = {0};
@@ -613,7 +612,6 @@ int twk_hip_ctx_destroy(twk_hip_ctx* c) {
 	if (c->tickets) (void)hipFree(c->tickets);
 	if (c->d_rle) (void)hipFree(c->d_rle);
 	if (c->d_rle_desc) (void)hipFree(c->d_rle_desc);
-	if (c->d_rle_scratch) (void)hipFree(c->d_rle_scratch);
 	if (c->d_status) (void)hipFree(c->d_status);
 	if (c->d_col_hi) (void)hipFree(c->d_col_hi);
 	if (c->s_compute) (void)hipStreamDestroy(c->s_compute);
@@ -699,8 +697,8 @@ int twk_hip_upload_rle(twk_hip_ctx* c, uint32_t first, uint32_t count, const voi
 	// validate before anything changes (same rules as twk_hip_upload_bitvectors)
 	bool any_mask = false;
 	std::vector<RleDesc> dd(count);
-	std::vector<unsigned long long> gbase(count);
-	unsigned long long groups = 0;
+	std::vector<uint32_t> chunk_base(count + 1);      // one block per chunk of RLE_CHUNK_BYTES run bytes, at least one per variant
+	uint64_t n_chunks = 0;
 	for (uint32_t i = 0; i < count; ++i) {
 		const twk_hip_rle_desc& d = desc[i];
 		if (d.width != 1 && d.width != 2 && d.width != 4) return TWK_HIP_E_INVALID;
@@ -709,9 +707,11 @@ int twk_hip_upload_rle(twk_hip_ctx* c, uint32_t first, uint32_t count, const voi
 		if ((meta[i].an != 0) != (meta[i].missing != 0)) return TWK_HIP_E_INVALID;
 		if (d.missing) any_mask = true;
 		dd[i].off = d.offset; dd[i].n_runs = d.n_runs; dd[i].width_missing = (uint32_t)d.width | (d.missing ? 256u : 0u);
-		gbase[i] = groups;
-		groups += ((unsigned long long)d.n_runs + RLE_GROUP - 1) / RLE_GROUP;
+		chunk_base[i] = (uint32_t)n_chunks;
+		n_chunks += std::max<uint64_t>(1, ((uint64_t)d.n_runs * d.width + RLE_CHUNK_BYTES - 1) / RLE_CHUNK_BYTES);
 	}
+	if (n_chunks > 0x7FFFFFFFull) return TWK_HIP_E_INVALID;
+	chunk_base[count] = (uint32_t)n_chunks;
 	HIPCHK(c, hipSetDevice(c->device));
 	free_planes(c);                                             // derived planes are stale now
 	auto grow = [&](void** p, size_t* cap, size_t need) -> hipError_t {
@@ -723,10 +723,10 @@ int twk_hip_upload_rle(twk_hip_ctx* c, uint32_t first, uint32_t count, const voi
 		if (e == hipSuccess) *cap = want;
 		return e;
 	};
-	const size_t desc_bytes = (size_t)count * (sizeof(RleDesc) + sizeof(unsigned long long));
-	HIPCHK(c, grow((void**)&c->d_rle, &c->d_rle_cap, n_bytes + 16));
+	// descriptors | chunk sums (u64 per block) | first block of every variant
+	const size_t desc_bytes = (size_t)count * sizeof(RleDesc) + (size_t)n_chunks * 8 + ((size_t)count + 1) * 4;
+	HIPCHK(c, grow((void**)&c->d_rle, &c->d_rle_cap, n_bytes + 32));        // the kernel's dword loads run up to 19 bytes past the last run
 	HIPCHK(c, grow((void**)&c->d_rle_desc, &c->d_rle_desc_cap, desc_bytes));
-	HIPCHK(c, grow((void**)&c->d_rle_scratch, &c->d_rle_scratch_cap, (size_t)std::max<unsigned long long>(groups, 1) * 4));
 	if (!c->d_status) HIPCHK(c, hipMalloc((void**)&c->d_status, sizeof(int)));
 	if (any_mask && !c->rawmask) {
 		const size_t raw_bytes = (size_t)c->M_alloc * c->Wp * 4;
@@ -734,12 +734,18 @@ int twk_hip_upload_rle(twk_hip_ctx* c, uint32_t first, uint32_t count, const voi
 		HIPCHK(c, hipMemsetAsync(c->rawmask, 0, raw_bytes, c->s_compute));
 	}
 	RleDesc* d_desc = reinterpret_cast<RleDesc*>(c->d_rle_desc);
-	unsigned long long* d_gbase = reinterpret_cast<unsigned long long*>(c->d_rle_desc + (size_t)count * sizeof(RleDesc));
+	unsigned long long* d_chunk_sum = reinterpret_cast<unsigned long long*>(c->d_rle_desc + (size_t)count * sizeof(RleDesc));
+	uint32_t* d_chunk_base = reinterpret_cast<uint32_t*>(c->d_rle_desc + (size_t)count * sizeof(RleDesc) + (size_t)n_chunks * 8);
 	HIPCHK(c, hipMemsetAsync(c->d_status, 0, sizeof(int), c->s_compute));
 	HIPCHK(c, hipMemcpyAsync(c->d_rle, bytes, n_bytes, hipMemcpyHostToDevice, c->s_compute));
 	HIPCHK(c, hipMemcpyAsync(d_desc, dd.data(), (size_t)count * sizeof(RleDesc), hipMemcpyHostToDevice, c->s_compute));
-	HIPCHK(c, hipMemcpyAsync(d_gbase, gbase.data(), (size_t)count * sizeof(unsigned long long), hipMemcpyHostToDevice, c->s_compute));
-	hipLaunchKernelGGL(k_inflate_rle, dim3(count), dim3(256), 0, c->s_compute, c->d_rle, d_desc, d_gbase, c->d_rle_scratch,
+	// the kernel ORs the ALT / missing runs into rows of zeros
+	HIPCHK(c, hipMemsetAsync(c->raw + (size_t)first * c->Wp, 0, (size_t)count * c->Wp * 4, c->s_compute));
+	if (c->rawmask) HIPCHK(c, hipMemsetAsync(c->rawmask + (size_t)first * c->Wp, 0, (size_t)count * c->Wp * 4, c->s_compute));
+	HIPCHK(c, hipMemcpyAsync(d_chunk_base, chunk_base.data(), ((size_t)count + 1) * 4, hipMemcpyHostToDevice, c->s_compute));
+	hipLaunchKernelGGL(k_rle_chunk_sums, dim3((uint32_t)n_chunks), dim3(256), 0, c->s_compute, c->d_rle, d_desc, d_chunk_base, count, d_chunk_sum);
+	HIPCHK(c, hipGetLastError());
+	hipLaunchKernelGGL(k_inflate_rle, dim3((uint32_t)n_chunks), dim3(256), 0, c->s_compute, c->d_rle, d_desc, d_chunk_base, count, d_chunk_sum,
 	                   c->raw, c->rawmask, c->Wp, c->N, first, c->d_status);
 	HIPCHK(c, hipGetLastError());
 	int status = 0;

@@ -307,22 +307,26 @@ bool index_block(const uint8_t* base, size_t block_off, size_t block_len, uint32
 }  // namespace
 
 static bool load_blocks(const std::string& path, const TwkReader& reader, const std::vector<uint32_t>& sel,
-                        uint32_t T, const std::vector<twk_hip_ctx*>& ctxs, std::vector<uint32_t>& rid, std::vector<uint32_t>& pos) {
+                        uint32_t T, const std::vector<twk_hip_ctx*>& ctxs, uint32_t n_samples, std::vector<uint32_t>& rid, std::vector<uint32_t>& pos) {
 	using lclock = std::chrono::steady_clock;
 	const auto t_begin = lclock::now();
 	std::vector<uint32_t> first(sel.size() + 1, 0);
 	for (size_t k = 0; k < sel.size(); ++k) first[k + 1] = first[k] + reader.index.ent[sel[k]].n;
 	rid.assign(first.back(), 0); pos.assign(first.back(), 0);
-	if (sel.empty()) return true;
+	if (sel.empty()) {
+		for (auto* c : ctxs) if (!hip_ok(c, twk_hip_set_problem(c, n_samples, 0), "twk_hip_set_problem")) return false;
+		return true;
+	}
 	const int fd = ::open(path.c_str(), O_RDONLY);
 	if (fd < 0) { std::cerr << stamp("ERROR") << "Failed to open " << path << std::endl; return false; }
 	struct Closer { int fd; ~Closer() { ::close(fd); } } closer{fd};
-	// Batches of whole blocks, one decode thread each.  A batch holds at least one block and at most 128 MB;
-	// small inputs are cut finer so that every decode thread gets several.
-	const uint32_t W = std::max<uint32_t>(1, std::min<uint32_t>(T, 16));           // decode threads
+	// Batches of whole blocks, one decode thread each.  A batch holds at least one block and at most 32 MB
+	// (the first batch reaches the GPU after ~30 ms); small inputs are cut finer so that every decode thread
+	// gets several.
+	const uint32_t W = std::max<uint32_t>(1, std::min<uint32_t>(T, 32));           // decode threads
 	size_t total_unc = 0, max_block = 0;
 	for (uint32_t k : sel) { const size_t u = ((size_t)reader.index.ent[k].b_unc + 15) / 16 * 16; total_unc += u; max_block = std::max(max_block, u); }
-	const size_t batch_cap = std::max(max_block, std::min<size_t>((size_t)128 << 20, std::max<size_t>((size_t)2 << 20, total_unc / (4 * (size_t)W))));
+	const size_t batch_cap = std::max(max_block, std::min<size_t>((size_t)32 << 20, std::max<size_t>((size_t)2 << 20, total_unc / (4 * (size_t)W))));
 	std::vector<LoadBatch> batches;
 	for (size_t k = 0; k < sel.size();) {
 		LoadBatch b; b.k0 = k; b.first = first[k];
@@ -338,33 +342,44 @@ static bool load_blocks(const std::string& path, const TwkReader& reader, const 
 	for (const auto& b : batches) max_bytes = std::max(max_bytes, b.bytes);
 	const size_t n_batches = batches.size(), n_gpus = ctxs.size();
 	const uint32_t n_workers = (uint32_t)std::min<size_t>(W, n_batches);
-	// Staging slots (page-locked, allocated by the first thread that needs one): a decode thread takes a free
-	// slot, then the next batch in file order, and fills it; one uploader thread per GPU takes the batches in
-	// file order (copy + device inflate); the slot is free again when every GPU has it.  Taking the slot before
-	// the batch means the oldest batch not yet uploaded always has one, so the in-order uploaders never starve.
-	const size_t n_slots = std::min<size_t>(n_batches, (size_t)n_workers + 2);
-	std::vector<Staging> slots(n_slots);
+	// A decode thread takes the next batch in file order, reads and decompresses its blocks into its own buffer
+	// and walks the record headers; when its batch's turn comes it copies the bytes into a slot of a small ring of
+	// page-locked memory (page-locking costs ~0.2 s per GB here, unlocking ~0.13 s: the ring is 8 slots, not one
+	// per thread).  One uploader thread per GPU takes the batches in file order (copy + device inflate); batch b
+	// uses slot b mod 8, free again when every GPU has batch b - 8.  The device allocations of the problem are
+	// made before the threads start: 10-20 ms for 12.5 GB then, but up to a second next to 32 threads faulting
+	// their buffers in.
+	const size_t n_slots = std::min<size_t>(n_batches, 8);
+	const auto t_alloc0 = lclock::now();
+	{
+		std::vector<int> rc(n_gpus, TWK_HIP_OK);
+		std::vector<std::thread> th;
+		for (size_t g = 0; g < n_gpus; ++g) th.emplace_back([&, g] { rc[g] = twk_hip_set_problem(ctxs[g], n_samples, first.back()); });
+		for (auto& t : th) t.join();
+		for (size_t g = 0; g < n_gpus; ++g) if (!hip_ok(ctxs[g], rc[g], "twk_hip_set_problem")) return false;
+	}
+	Staging ring;
+	if (!ring.reserve(n_slots * max_bytes)) { std::cerr << stamp("ERROR") << "Out of host memory for the upload staging buffers" << std::endl; return false; }
+	const double t_alloc = std::chrono::duration<double>(lclock::now() - t_alloc0).count();
+	size_t max_cmp = 0;
+	for (uint32_t k : sel) max_cmp = std::max<size_t>(max_cmp, reader.index.ent[k].b_cmp);
 	std::mutex mu;
-	std::condition_variable cv_free, cv_ready;
-	std::vector<size_t> free_slots;
-	for (size_t i = 0; i < n_slots; ++i) free_slots.push_back(n_slots - 1 - i);
-	std::vector<int> slot_of(n_batches, -1);         // under mu
-	std::vector<char> ready(n_batches, 0);           // under mu
+	std::condition_variable cv_slot, cv_ready;
+	std::vector<char> ready(n_batches, 0);           // under mu: batch is in its slot
 	std::vector<uint32_t> pending(n_batches, (uint32_t)n_gpus);
-	size_t next_batch = 0;                           // under mu
+	size_t released = 0;                             // under mu: batches [0, released) have left their slots
+	std::atomic<size_t> next_batch(0);
 	std::atomic<bool> failed(false);
 	std::string fail_msg;                            // under mu, first failure only
 	auto fail = [&](const std::string& msg) {
 		std::lock_guard<std::mutex> lk(mu);
 		if (!failed.exchange(true)) fail_msg = msg;
-		cv_free.notify_all(); cv_ready.notify_all();
+		cv_slot.notify_all(); cv_ready.notify_all();
 	};
 	std::vector<double> busy_decode(n_workers, 0.0), busy_upload(n_gpus, 0.0);
-	bool pinned_all = true;                          // under mu
 
-	auto decode_batch = [&](LoadBatch& b, uint8_t* buf) -> bool {
+	auto decode_batch = [&](LoadBatch& b, uint8_t* buf, std::vector<uint8_t>& z) -> bool {
 		b.desc.resize(b.nv); b.meta.resize(b.nv);
-		std::vector<uint8_t> z;
 		for (size_t k = b.k0; k < b.k1; ++k) {
 			const IndexEntry& e = reader.index.ent[sel[k]];
 			uint8_t head[9];
@@ -381,42 +396,41 @@ static bool load_blocks(const std::string& path, const TwkReader& reader, const 
 		return true;
 	};
 	auto decoder = [&](uint32_t w) {
+		std::vector<uint8_t> z;                          // compressed block, sized once
+		z.reserve(max_cmp + 16);
+		std::unique_ptr<uint8_t[]> own(new (std::nothrow) uint8_t[max_bytes]);
+		if (!own) { fail("Out of host memory for the decode buffers"); return; }
 		for (;;) {
-			size_t slot, bi;
-			{
-				std::unique_lock<std::mutex> lk(mu);
-				if (next_batch >= n_batches) return;           // nothing left: do not hold a slot for it
-				cv_free.wait(lk, [&] { return failed || !free_slots.empty(); });
-				if (failed || next_batch >= n_batches) return;
-				slot = free_slots.back(); free_slots.pop_back();
-				bi = next_batch++;
-				slot_of[bi] = (int)slot;
-				if (next_batch >= n_batches) cv_free.notify_all();     // the threads still waiting for a slot can go home
-			}
+			const size_t bi = next_batch++;
+			if (bi >= n_batches || failed) return;
 			const auto t0 = lclock::now();
-			if (!slots[slot].reserve(max_bytes)) { fail("Out of host memory for the upload staging buffers"); return; }
-			if (!slots[slot].pinned) { std::lock_guard<std::mutex> lk(mu); pinned_all = false; }
-			if (!decode_batch(batches[bi], slots[slot].p)) {
+			if (!decode_batch(batches[bi], own.get(), z)) {
 				fail("Failed to load blocks " + std::to_string(batches[bi].k0) + "-" + std::to_string(batches[bi].k1) + "!");
 				return;
 			}
 			busy_decode[w] += std::chrono::duration<double>(lclock::now() - t0).count();
+			{
+				std::unique_lock<std::mutex> lk(mu);
+				cv_slot.wait(lk, [&] { return failed || bi < released + n_slots; });
+				if (failed) return;
+			}
+			const auto t1 = lclock::now();
+			std::memcpy(ring.p + (bi % n_slots) * max_bytes, own.get(), batches[bi].bytes);
+			busy_decode[w] += std::chrono::duration<double>(lclock::now() - t1).count();
 			{ std::lock_guard<std::mutex> lk(mu); ready[bi] = 1; }
 			cv_ready.notify_all();
 		}
 	};
 	auto uploader = [&](size_t g) {
 		for (size_t bi = 0; bi < n_batches; ++bi) {
-			int slot;
 			{
 				std::unique_lock<std::mutex> lk(mu);
 				cv_ready.wait(lk, [&] { return failed || ready[bi]; });
 				if (failed) return;
-				slot = slot_of[bi];
 			}
 			const LoadBatch& b = batches[bi];
 			const auto t0 = lclock::now();
-			const int rc = twk_hip_upload_rle(ctxs[g], b.first, b.nv, slots[slot].p, b.bytes, b.desc.data(), b.meta.data());
+			const int rc = twk_hip_upload_rle(ctxs[g], b.first, b.nv, ring.p + (bi % n_slots) * max_bytes, b.bytes, b.desc.data(), b.meta.data());
 			busy_upload[g] += std::chrono::duration<double>(lclock::now() - t0).count();
 			if (rc != TWK_HIP_OK) {
 				const char* m = twk_hip_last_error(ctxs[g]);
@@ -424,7 +438,10 @@ static bool load_blocks(const std::string& path, const TwkReader& reader, const 
 				return;
 			}
 			std::lock_guard<std::mutex> lk(mu);
-			if (--pending[bi] == 0) { free_slots.push_back((size_t)slot); cv_free.notify_all(); }
+			if (--pending[bi] == 0) {                         // every GPU is in file order, so batches leave in file order too
+				while (released < n_batches && pending[released] == 0) ++released;
+				cv_slot.notify_all();
+			}
 		}
 	};
 	std::vector<std::thread> th;
@@ -437,8 +454,9 @@ static bool load_blocks(const std::string& path, const TwkReader& reader, const 
 	for (double x : busy_upload) up = std::max(up, x);
 	std::cerr << stamp("LOG", "UNPACK") << n_batches << " batches, " << total_unc / 1000000 << " MB of run-length genotypes in "
 	          << std::chrono::duration<double>(lclock::now() - t_begin).count() << " s: " << n_workers << " decode threads busy " << dec
-	          << " s in all (read + decompress), copy + device inflate " << up << " s per GPU, " << n_slots << " staging slots of "
-	          << max_bytes / 1000000 << " MB" << (pinned_all ? "" : " (not page-locked)") << std::endl;
+	          << " s in all (read + decompress + copy to staging), copy + device inflate " << up
+	          << " s per GPU, device + staging allocations " << t_alloc << " s, " << n_slots << " staging slots of "
+	          << max_bytes / 1000000 << " MB" << (ring.pinned ? "" : " (not page-locked)") << std::endl;
 	return true;
 }
 
@@ -720,8 +738,7 @@ bool twk_ld::Compute() {
 		std::vector<std::thread> th;
 		for (int g = 0; g < n_gpus; ++g) th.emplace_back([&, g] {
 			if (sel_g[g].empty()) return;
-			if (!hip_ok(dc.ctx[g], twk_hip_set_problem(dc.ctx[g], n_samples, spec.slabs[g].n_local), "twk_hip_set_problem")) { ok[g] = 0; return; }
-			if (!load_blocks(settings.in, reader, sel_g[g], std::max<uint32_t>(1, T / (uint32_t)n_gpus), {dc.ctx[g]}, rid_g[g], pos_g[g])) ok[g] = 0;
+			if (!load_blocks(settings.in, reader, sel_g[g], std::max<uint32_t>(1, T / (uint32_t)n_gpus), {dc.ctx[g]}, n_samples, rid_g[g], pos_g[g])) ok[g] = 0;
 		});
 		for (auto& t : th) t.join();
 		for (int g = 0; g < n_gpus; ++g) {
@@ -730,8 +747,7 @@ bool twk_ld::Compute() {
 			std::copy(pos_g[g].begin(), pos_g[g].end(), mImpl->pos.begin() + spec.slabs[g].first);
 		}
 	} else {
-		for (auto* c : dc.ctx) if (!hip_ok(c, twk_hip_set_problem(c, n_samples, M), "twk_hip_set_problem")) return false;
-		if (!load_blocks(settings.in, reader, sel, T, dc.ctx, mImpl->rid, mImpl->pos)) return false;
+		if (!load_blocks(settings.in, reader, sel, T, dc.ctx, n_samples, mImpl->rid, mImpl->pos)) return false;
 	}
 	std::cerr << stamp("LOG") << "Unpacked and uploaded " << pretty(M) << " variants. "
 	          << elapsed_string(std::chrono::duration<double>(clock::now() - t_load).count()) << std::endl;
