@@ -63,6 +63,21 @@ for stage in "$@"; do
 		stats cfg5_shard3of8 --config cfg5 --emulate-shard 3/8 --steps 1 --warmup 0
 		pmc cfg5_sq "SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" --config cfg5 --emulate-shard 3/8 --steps 1 --warmup 0
 		;;
+	load_prof)  # the CLI's input path: kernel + copy trace of `tomahawk calc` on a 1 M x 20 k cohort-shaped .twk
+		python3 - <<PY
+import sys, os, time
+sys.path.insert(0, "$R")
+from tomahawk_amd import hostlib as H
+if not os.path.exists("/tmp/c20k.twk"):
+    H.write_cohort_twk("/tmp/c20k.twk", 1_000_000, 20000, seed=11, n_threads=64, block_size=128)
+PY
+		rm -rf /tmp/prof_load
+		timeout 300 rocprofv3 --kernel-trace --memory-copy-trace --stats --output-format csv -d /tmp/prof_load -o load -- \
+			$R/tomahawk_amd/bin/tomahawk calc -i /tmp/c20k.twk -o /tmp/o.two -t 64 > /dev/null 2> $OUT/load_under_rocprof.log
+		f=$(find /tmp/prof_load -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/load_kernel_stats.csv && head -8 "$f" | cut -c1-160
+		f=$(find /tmp/prof_load -name "*memory_copy_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/load_memory_copy_stats.csv && cat "$f" | cut -c1-160
+		grep "UNPACK\|Unpacked" $OUT/load_under_rocprof.log | cut -c1-400
+		;;
 	shards)  timeout 1200 python3 $R/tests/sweeps/shard_timings.py > $OUT/shard_timings.txt 2>&1; tail -20 $OUT/shard_timings.txt ;;
 	*) echo "unknown stage $stage" ;;
 	esac
