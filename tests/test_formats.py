@@ -173,3 +173,57 @@ def test_reference_client_source_builds_against_the_shim(tmp_path):
     assert r.returncode == 0, r.stderr
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 1 and "No file-name provided" in r.stderr
+
+
+@pytest.mark.parametrize("n_threads,b_size", [(1, 50), (3, 128), (8, 1000)])
+def test_record_stream_blocks_follow_the_flush_rule(tmp_path, n_threads, b_size):
+    """hostlib.TwoStream (RecordEmitter: worker threads expand + compress, a writer thread appends in order, at most
+    6 x threads blocks in flight): many appends of ragged sizes, sorted and unsorted, on three contigs.  Every record
+    comes out twice (forward, then reverse with rid / pos swapped), in (idxA, idxB) order within an append; a block
+    holds one (ridA, ridB) pair and at most b_size records, and only a block followed by a contig change (or the
+    last one) is short (ld_engine.cpp:1270-1281)."""
+    M = 400
+    rng = np.random.default_rng(5)
+    rid = np.repeat([0, 1, 2], [150, 150, 100]).astype(np.uint32)
+    pos = (1000 + 10 * np.arange(M)).astype(np.uint32)
+    path = str(tmp_path / "s.two")
+    st = hostlib.TwoStream(path, 10, rid, pos, n_contigs=3, b_size=b_size, n_threads=n_threads)
+    want = []
+    for k, n in enumerate([0, 1, 7, 5000, 3, 12000, 2 * b_size, 40]):
+        a = rng.integers(0, M - 1, n).astype(np.uint32)
+        b = (a + 1 + rng.integers(0, M, n) % (M - 1 - a)).astype(np.uint32)
+        key = np.unique(a.astype(np.uint64) << 32 | b)                       # distinct pairs, sorted
+        rec = np.zeros(len(key), dtype=T.RECORD_DTYPE)
+        rec["idxA"] = key >> 32; rec["idxB"] = key & 0xFFFFFFFF
+        rec["flags"] = 3; rec["R2"] = rng.random(len(key)); rec["cnt"] = rng.integers(0, 20, (len(key), 4))
+        want.append(rec.copy())
+        if k % 2:
+            rec = rec[rng.permutation(len(rec))]                               # unsorted input is put in order
+        st.append(rec)
+    n_written = st.close()
+    want = np.concatenate(want)
+    got, info = hostlib.read_two(path)
+    assert n_written == 2 * len(want) == len(got)
+    state, ent, _ = hostlib.two_index(path)
+    assert state == 0 and ent[:, 2].sum() == len(got) and len(ent) % 2 == 0
+    # blocks come in forward / reverse pairs; walk them
+    o = 0
+    fwd = []
+    for k in range(0, len(ent), 2):
+        n = int(ent[k, 2])
+        assert n == ent[k + 1, 2] and 0 < n <= b_size
+        f, v = got[o:o + n], got[o + n:o + 2 * n]
+        o += 2 * n
+        assert (f["ridA"] == f["ridA"][0]).all() and (f["ridB"] == f["ridB"][0]).all()
+        assert np.array_equal(v["ridA"], f["ridB"]) and np.array_equal(v["ridB"], f["ridA"])
+        assert np.array_equal(v["packA"], f["packB"]) and np.array_equal(v["packB"], f["packA"])
+        assert np.array_equal(v["R2"], f["R2"]) and np.array_equal(v["cnt"], f["cnt"])
+        fwd.append(f)
+    # only a contig change (or the end) closes a block early
+    for k in range(len(fwd) - 1):
+        if len(fwd[k]) < b_size:
+            assert (fwd[k]["ridA"][0], fwd[k]["ridB"][0]) != (fwd[k + 1]["ridA"][0], fwd[k + 1]["ridB"][0])
+    fwd = np.concatenate(fwd)
+    assert np.array_equal(fwd["ridA"], rid[want["idxA"]]) and np.array_equal(fwd["ridB"], rid[want["idxB"]])
+    assert np.array_equal(fwd["packA"] >> 2, pos[want["idxA"]]) and np.array_equal(fwd["packB"] >> 2, pos[want["idxB"]])
+    assert np.array_equal(fwd["R2"], want["R2"]) and np.array_equal(fwd["cnt"], want["cnt"])

@@ -374,3 +374,27 @@ def test_r2_screen_gives_the_same_records(hip, mode, miss):
     want = O.all_pairs(data[sub], None if mask is None else mask[sub], variants[sub], N, st, vector_only=False)
     got, _, _ = hip.ld_all(mode, T.Filters(minR2=0.1), window=T.OPT_R2_SCREEN)
     util.assert_records_match(got, want, variants[sub], double_root=util.double_root_vetter(data[sub], None if mask is None else mask[sub], variants[sub], N))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M", [40, 700, 2300])
+def test_survivors_leave_the_device_in_pair_order(hip, M):
+    """The survivors of a tile are compacted with an atomic counter, then put in (idxA, idxB) order on the device
+    (key sort + gather) - the order the writer keeps, which makes a one-GPU run's file deterministic.  Records the
+    Fisher cut-off drops are only marked by the math kernel: they sort behind the rest and are cut off.  Same
+    records as the oracle either way."""
+    N = 96
+    al = util.random_alleles(M, N, 900 + M, miss_rate=0.04, miss_variants=0.25)
+    data, mask, variants = util.upload(hip, al)
+    for mode, filt in ((T.MODE_PHASED, T.Filters(minR2=0.0)), (T.MODE_UNPHASED, T.Filters(minR2=0.0, minP=0.05)),
+                       (T.MODE_AUTO, T.Filters(minR2=0.02))):
+        recs, npairs = hip.ld_tile(mode, 0, M, 0, M, True, filt)
+        assert npairs == M * (M - 1) // 2
+        key = recs["idxA"].astype(np.int64) << 32 | recs["idxB"].astype(np.int64)
+        assert (np.diff(key) > 0).all()
+        assert (recs["idxA"] < recs["idxB"]).all() and recs["idxB"].max() < M
+        if M <= 700:
+            st = O.settings(minR2=filt.minR2, minP=filt.minP, phased=mode == T.MODE_PHASED, unphased=mode == T.MODE_UNPHASED)
+            want = O.all_pairs(data, mask, variants, N, st, vector_only=False)
+            assert len(want) > 100
+            util.assert_records_match(recs, want, variants, double_root=util.double_root_vetter(data, mask, variants, N))

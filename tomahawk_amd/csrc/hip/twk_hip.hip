@@ -13,6 +13,8 @@
 #include <cstring>
 #include <new>
 #include <vector>
+#include <string.h>
+#include <rocprim/device/device_radix_sort.hpp>
 
 #include "../../../include/twk_hip.h"
 #include "ld_count.hip.h"
@@ -92,6 +94,11 @@ struct twk_hip_ctx {
 	PlaneSet planes[N_PLANE_SETS];
 	Slot slot[3];                  // [0],[1]: ld_all pipeline; [2]: synchronous single-tile calls
 	twk_hip_record* h_recs = nullptr; unsigned long long h_recs_cap = 0;   // pinned staging
+	// the survivors of a tile leave in (idxA, idxB) order: sort keys / permutation (double-buffered), the
+	// reordered records, rocprim's scratch (grow-only)
+	unsigned long long* d_sort_keys = nullptr; uint32_t* d_sort_vals = nullptr; twk_hip_record* d_sorted = nullptr;
+	unsigned long long sort_cap = 0;
+	void* d_sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
 	twk_hip_timing timing{};
 	twk_hip_progress_cb progress_cb = nullptr; void* progress_user = nullptr;
 	bool progress_muted = false;       // second stage of a default-mode run: its pairs were already counted
@@ -421,6 +428,65 @@ int enqueue_tile(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, const twk
 	return TWK_HIP_OK;
 }
 
+// Survivors are appended with an atomic counter, in no order.  They leave the device in (idxA, idxB) order
+// - the order the writer puts them in the file, which makes a one-GPU run's output deterministic - by a key
+// sort of (idxA << bits | idxB, position) and a gather; records the Fisher cut-off dropped sort behind the rest.
+__global__ void k_record_keys(const twk_hip_record* __restrict__ recs, unsigned long long n, uint32_t bits_b,
+                              unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals) {
+	const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const uint32_t a = recs[i].idxA, b = recs[i].idxB;
+	keys[i] = a == TWK_DROPPED_RECORD ? ~0ull : ((unsigned long long)a << bits_b | b);
+	vals[i] = (uint32_t)i;
+}
+__global__ void k_gather_records(const twk_hip_record* __restrict__ recs, const uint32_t* __restrict__ order, unsigned long long n,
+                                 twk_hip_record* __restrict__ out) {
+	constexpr uint32_t W = sizeof(twk_hip_record) / 8;              // 13 eight-byte words per record
+	const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n * W) return;
+	const unsigned long long r = i / W; const uint32_t w = (uint32_t)(i % W);
+	reinterpret_cast<unsigned long long*>(out)[i] = reinterpret_cast<const unsigned long long*>(recs + order[r])[w];
+}
+static_assert(sizeof(twk_hip_record) % 8 == 0, "record gather copies 8-byte words");
+
+// recs[0..n) on the device -> c->d_sorted in (idxA, idxB) order, on stream st.
+int sort_records(twk_hip_ctx* c, const twk_hip_record* recs, unsigned long long n, hipStream_t st) {
+	if (n > 0xFFFFFFFFull) return TWK_HIP_E_INVALID;
+	if (c->sort_cap < n) {
+		if (c->d_sort_keys) (void)hipFree(c->d_sort_keys);
+		if (c->d_sort_vals) (void)hipFree(c->d_sort_vals);
+		if (c->d_sorted) (void)hipFree(c->d_sorted);
+		c->d_sort_keys = nullptr; c->d_sort_vals = nullptr; c->d_sorted = nullptr; c->sort_cap = 0;
+		const unsigned long long cap = std::max<unsigned long long>(n + n / 4, 1ull << 16);
+		HIPCHK(c, hipMalloc((void**)&c->d_sort_keys, (size_t)cap * 2 * sizeof(unsigned long long)));
+		HIPCHK(c, hipMalloc((void**)&c->d_sort_vals, (size_t)cap * 2 * sizeof(uint32_t)));
+		HIPCHK(c, hipMalloc((void**)&c->d_sorted, (size_t)cap * sizeof(twk_hip_record)));
+		c->sort_cap = cap;
+	}
+	unsigned long long* keys_in = c->d_sort_keys; unsigned long long* keys_out = c->d_sort_keys + c->sort_cap;
+	uint32_t* vals_in = c->d_sort_vals; uint32_t* vals_out = c->d_sort_vals + c->sort_cap;
+	uint32_t bits_b = 1; while (bits_b < 32 && (1ull << bits_b) < c->M) ++bits_b;
+	// dropped records carry the all-ones key: sort every bit when there can be any, else only the bits in use
+	const unsigned end_bit = 64;
+	size_t tmp = 0;
+	HIPCHK(c, rocprim::radix_sort_pairs(nullptr, tmp, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u, end_bit, st));
+	if (!c->d_sort_tmp || tmp > c->sort_tmp_bytes) {          // (a null scratch pointer would turn the sort into another size query)
+		if (c->d_sort_tmp) (void)hipFree(c->d_sort_tmp);
+		c->d_sort_tmp = nullptr; c->sort_tmp_bytes = 0;
+		const size_t want = std::max<size_t>(tmp + tmp / 4, 4096);
+		HIPCHK(c, hipMalloc(&c->d_sort_tmp, want));
+		c->sort_tmp_bytes = want;
+	}
+	hipLaunchKernelGGL(k_record_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, recs, n, bits_b, keys_in, vals_in);
+	HIPCHK(c, hipGetLastError());
+	tmp = c->sort_tmp_bytes;
+	HIPCHK(c, rocprim::radix_sort_pairs(c->d_sort_tmp, tmp, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u, end_bit, st));
+	const unsigned long long words = n * (sizeof(twk_hip_record) / 8);
+	hipLaunchKernelGGL(k_gather_records, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, recs, vals_out, n, c->d_sorted);
+	HIPCHK(c, hipGetLastError());
+	return TWK_HIP_OK;
+}
+
 // Wait for slot s, account timing, fetch its records into the pinned staging buffer.
 int finish_tile(twk_hip_ctx* c, Slot& s, const twk_hip_tile_desc& t, unsigned long long* n_out) {
 	HIPCHK(c, hipEventSynchronize(s.ev_s1));
@@ -446,13 +512,13 @@ int finish_tile(twk_hip_ctx* c, Slot& s, const twk_hip_tile_desc& t, unsigned lo
 	if (n > s.capacity) return TWK_HIP_E_OVERFLOW;
 	if (n) {
 		int rc = ensure_host_records(c, n); if (rc) return rc;
-		HIPCHK(c, hipMemcpyAsync(c->h_recs, s.out, (size_t)n * sizeof(twk_hip_record), hipMemcpyDeviceToHost, c->s_copy));
+		rc = sort_records(c, s.out, n, c->s_copy); if (rc) return rc;
+		HIPCHK(c, hipMemcpyAsync(c->h_recs, c->d_sorted, (size_t)n * sizeof(twk_hip_record), hipMemcpyDeviceToHost, c->s_copy));
 		HIPCHK(c, hipStreamSynchronize(c->s_copy));
-		if (s.minP < 1.0) {        // records that failed the Fisher cutoff were only marked on the device
-			unsigned long long k = 0;
-			for (unsigned long long i = 0; i < n; ++i)
-				if (c->h_recs[i].idxA != TWK_DROPPED_RECORD) { if (k != i) c->h_recs[k] = c->h_recs[i]; ++k; }
-			*n_out = k;
+		if (s.minP < 1.0) {        // records that failed the Fisher cutoff were only marked on the device: they are the tail now
+			unsigned long long lo = 0, hi = n;
+			while (lo < hi) { const unsigned long long mid = (lo + hi) / 2; if (c->h_recs[mid].idxA == TWK_DROPPED_RECORD) hi = mid; else lo = mid + 1; }
+			*n_out = lo;
 		}
 	}
 	return TWK_HIP_OK;
@@ -609,6 +675,10 @@ int twk_hip_ctx_destroy(twk_hip_ctx* c) {
 		if (s.h_n_out) (void)hipHostFree(s.h_n_out);
 	}
 	if (c->h_recs) (void)hipHostFree(c->h_recs);
+	if (c->d_sort_keys) (void)hipFree(c->d_sort_keys);
+	if (c->d_sort_vals) (void)hipFree(c->d_sort_vals);
+	if (c->d_sorted) (void)hipFree(c->d_sorted);
+	if (c->d_sort_tmp) (void)hipFree(c->d_sort_tmp);
 	if (c->tickets) (void)hipFree(c->tickets);
 	if (c->d_rle) (void)hipFree(c->d_rle);
 	if (c->d_rle_desc) (void)hipFree(c->d_rle_desc);

@@ -360,7 +360,7 @@ void* twk_two_stream_open(const char* path, uint32_t n_samples, uint32_t n_conti
 	for (uint32_t v = 0; v < n_variants; ++v) if (st->rid[v] >= n_contigs) return nullptr;
 	if (!st->out.writer.open(path, hdr, c_level > 0 ? c_level : 1)) return nullptr;
 	st->out.b_size = b_size; st->out.c_level = c_level > 0 ? c_level : 1;
-	st->out.rid = st->rid.data(); st->out.pos = st->pos.data();
+	st->out.rid = st->rid.data(); st->out.pos = st->pos.data(); st->out.n_variants = st->rid.size();
 	st->emitter.reset(new RecordEmitter(st->out, n_threads > 0 ? n_threads : 1));
 	return st.release();
 } catch (...) { return nullptr; }
@@ -378,6 +378,8 @@ int twk_two_stream_close(void* h, uint64_t* n_records) try {
 	if (!st) return -1;
 	bool ok = st->emitter->emit(nullptr, 0, true);
 	ok = st->out.writer.close() && ok;
+	if (std::getenv("TWK_EMIT_STATS")) fprintf(stderr, "[emit] ordering %.3f s, blocks %.3f s, %llu blocks, %llu MB compressed\n", st->emitter->t_sort, st->emitter->t_blocks,
+	                                           (unsigned long long)st->out.n_blocks, (unsigned long long)(st->out.bytes_packed / 1000000));
 	if (n_records) *n_records = st->out.n_records;
 	return ok ? 0 : -3;
 } catch (...) { return -9; }

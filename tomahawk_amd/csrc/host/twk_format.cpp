@@ -10,6 +10,10 @@ extern "C" {
 size_t ZSTD_compress(void* dst, size_t dstCapacity, const void* src, size_t srcSize, int compressionLevel);
 size_t ZSTD_decompress(void* dst, size_t dstCapacity, const void* src, size_t compressedSize);
 size_t ZSTD_compressBound(size_t srcSize);
+typedef struct ZSTD_CCtx_s ZSTD_CCtx;
+ZSTD_CCtx* ZSTD_createCCtx(void);
+size_t ZSTD_freeCCtx(ZSTD_CCtx* cctx);
+size_t ZSTD_compressCCtx(ZSTD_CCtx* cctx, void* dst, size_t dstCapacity, const void* src, size_t srcSize, int compressionLevel);
 unsigned ZSTD_isError(size_t code);
 const char* ZSTD_getErrorName(size_t code);
 const char* ZSTD_versionString(void);
@@ -22,9 +26,15 @@ const char TWK_MAGIC[9]    = {'T','O','M','A','H','A','W','K','\1'};
 const char TWO_MAGIC[4]    = {'T','W','O','\1'};
 const char TWK_EOF_HEX[33] = "a4f54f39f5e251a6993796f48164ccf5";
 
+// One compression context per thread, kept: ZSTD_compress() builds and frees one (its tables, ~1 MB at
+// level 1) on every call, which costs as much as compressing a small block.
+namespace {
+struct CCtxHolder { ZSTD_CCtx* c = ZSTD_createCCtx(); ~CCtxHolder() { if (c) ZSTD_freeCCtx(c); } };
+}
 bool zstd_compress(const uint8_t* src, size_t n, std::vector<uint8_t>& dst, int level) {
+	static thread_local CCtxHolder ctx;
 	dst.resize(ZSTD_compressBound(n));
-	const size_t r = ZSTD_compress(dst.data(), dst.size(), src, n, level);
+	const size_t r = ctx.c ? ZSTD_compressCCtx(ctx.c, dst.data(), dst.size(), src, n, level) : ZSTD_compress(dst.data(), dst.size(), src, n, level);
 	if (ZSTD_isError(r)) { std::cerr << "[zstd] " << ZSTD_getErrorName(r) << std::endl; return false; }
 	dst.resize(r);
 	return true;
@@ -381,14 +391,19 @@ bool TwoWriter::pack(const TwoRecord* recs, uint32_t n, int c_level, Packed& out
 	ByteBuf b;
 	b.put<uint32_t>(n); b.put<uint32_t>(n);               // core.cpp:626-631 (n, m)
 	b.put_bytes(recs, (size_t)n * sizeof(TwoRecord));
-	if (!zstd_compress(b.v.data(), b.v.size(), out.z, c_level)) return false;
+	return pack_block(b.v.data(), n, c_level, out);
+}
+bool TwoWriter::pack_block(const uint8_t* block, uint32_t n, int c_level, Packed& out) {
+	const TwoRecord* recs = reinterpret_cast<const TwoRecord*>(block + 8);      // (packed struct: no alignment)
+	const size_t bytes = 8 + (size_t)n * sizeof(TwoRecord);
+	if (!zstd_compress(block, bytes, out.z, c_level)) return false;
 	IndexEntryOutput& e = out.entry;                      // ld_engine.cpp:1270-1288,1757-1763
 	e = IndexEntryOutput();
 	e.rid = (int32_t)recs[0].ridA; e.ridB = (int32_t)recs[0].ridB;
 	e.minpos = recs[0].Apos(); e.maxpos = recs[n - 1].Apos();
 	for (uint32_t i = 1; i < n; ++i) if ((int32_t)recs[i].ridB != e.ridB) { e.ridB = -1; break; }
 	e.n = n; e.b_unc = 106u * n + 8u; e.b_cmp = (uint32_t)out.z.size();
-	out.b_unc = (uint32_t)b.size();
+	out.b_unc = (uint32_t)bytes;
 	return true;
 }
 

@@ -171,6 +171,8 @@ public:
 	// pack() is thread-safe and touches no writer state; write_packed() appends in call order.
 	struct Packed { std::vector<uint8_t> z; IndexEntryOutput entry; uint32_t b_unc = 0; };
 	static bool pack(const TwoRecord* recs, uint32_t n, int c_level, Packed& out);
+	// the same from a block already laid out as it goes into the frame: u32 n, u32 n, n records
+	static bool pack_block(const uint8_t* block, uint32_t n, int c_level, Packed& out);
 	// The generic .two block of view -O b and sort (twk_two_writer_t::WriteBlockCompressedTWO,
 	// writer.h:346-396): the index entry carries contigs and positions only in a sorted file.
 	static bool pack_generic(const TwoRecord* recs, uint32_t n, int c_level, bool sorted, Packed& out);

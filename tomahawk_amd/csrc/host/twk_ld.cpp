@@ -505,7 +505,7 @@ bool twk_ld::twk_ld_impl::run(twk_ld_settings& settings, const Header& hdr, cons
 	const RunSpec& spec = *static_cast<const RunSpec*>(spec_);
 	if (!open_output(settings, hdr, out.writer)) return false;
 	out.b_size = (uint32_t)std::max(2, settings.b_size);
-	out.c_level = settings.c_level; out.rid = rid.data(); out.pos = pos.data(); out.n_records = 0;
+	out.c_level = settings.c_level; out.rid = rid.data(); out.pos = pos.data(); out.n_variants = rid.size(); out.n_records = 0;
 	n_records = 0; n_pairs = 0;
 	const int n_gpus = (int)ctxs.size();
 	const int n_workers = std::max(1, std::min(std::max(1, settings.n_threads), 64) / n_gpus);
@@ -576,7 +576,7 @@ bool twk_ld::twk_ld_impl::run(twk_ld_settings& settings, const Header& hdr, cons
 				}
 				recs = d->kept.data(); n = d->kept.size();
 			}
-			if (!d->emitter.emit(recs, n, false)) { d->write_failed = true; return 1; }
+			if (!d->emitter.emit(recs, n, false, true)) { d->write_failed = true; return 1; }     // (the engine's survivors come sorted)
 			return 0;
 		}
 	};
@@ -631,6 +631,12 @@ bool twk_ld::twk_ld_impl::run(twk_ld_settings& settings, const Header& hdr, cons
 		if (twk_hip_timing_get(ctxs[g], &tm) == TWK_HIP_OK)
 			std::cerr << stamp("LOG", "HIP") << (n_gpus > 1 ? "GPU " + std::to_string(g) + ": " : std::string()) << "count kernel " << tm.count_ms << " ms in "
 			          << tm.count_launches << " launches, math kernel " << tm.stats_ms << " ms" << std::endl;
+	}
+	{
+		double t_sort = 0, t_blocks = 0;
+		for (int g = 0; g < n_gpus; ++g) { t_sort = std::max(t_sort, drivers[g]->emitter.t_sort); t_blocks = std::max(t_blocks, drivers[g]->emitter.t_blocks); }
+		std::cerr << stamp("LOG", "WRITER") << pretty(out.n_blocks) << " blocks, " << out.bytes_packed / 1000000 << " MB compressed; the producer spent "
+		          << t_sort + t_blocks << " s handing its survivors over" << (n_gpus > 1 ? " (slowest GPU's emitter)" : "") << std::endl;
 	}
 	if (!out.writer.close()) { std::cerr << stamp("ERROR", "WRITER") << "Failed to write final block!" << std::endl; return false; }
 	return true;
