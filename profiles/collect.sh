@@ -78,6 +78,20 @@ PY
 		f=$(find /tmp/prof_load -name "*memory_copy_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/load_memory_copy_stats.csv && cat "$f" | cut -c1-160
 		grep "UNPACK\|Unpacked" $OUT/load_under_rocprof.log | cut -c1-400
 		;;
+	math_prof)  # a survivor-heavy run: 2,504 samples x 200,000 cohort-shaped variants, -p -w 1000000 (33 M surviving pairs)
+		python3 - <<PY
+import sys, os
+sys.path.insert(0, "$R")
+from tomahawk_amd import hostlib as H
+if not os.path.exists("/tmp/kg_2504_200k.twk"):
+    H.write_cohort_twk("/tmp/kg_2504_200k.twk", 2504, 200_000, seed=12, n_threads=64, block_size=500, spacing=100)
+PY
+		rm -rf /tmp/prof_math
+		timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_math -o m -- \
+			$R/tomahawk_amd/bin/tomahawk calc -i /tmp/kg_2504_200k.twk -o /tmp/o.two -t 64 -p -w 1000000 > /dev/null 2> $OUT/kg_under_rocprof.log
+		f=$(find /tmp/prof_math -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/kg_kernel_stats.csv && head -8 "$f" | cut -c1-160
+		grep "Finished\|HIP\]\|WRITER\]" $OUT/kg_under_rocprof.log | cut -c1-300
+		;;
 	shards)  timeout 1200 python3 $R/tests/sweeps/shard_timings.py > $OUT/shard_timings.txt 2>&1; tail -20 $OUT/shard_timings.txt ;;
 	*) echo "unknown stage $stage" ;;
 	esac

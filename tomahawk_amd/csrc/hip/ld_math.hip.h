@@ -34,15 +34,26 @@ struct VariantMeta {       // SoA view of twk_hip_variant_meta on the device
 };
 
 // ---- Fisher's exact test: fisher_math.cpp:183-267 ------------------------------
-__device__ inline double d_lbinom(int n, int k) {
+// lbinom (fisher_math.cpp:183-187) is three lgamma calls, and the test evaluates it nine times per
+// re-synchronisation of its recurrence (every 11th term) and for every verified starting point.  The
+// arguments are integers <= 2N + 1, so the values come from a table lf[i] = lgamma(i + 1) filled once per
+// problem with the same lgamma (k_build_lfact): the same bits, three loads instead of three evaluations.
+struct LFact { const double* lf; int n; };       // lf[0..n)
+// lgamma(i + 1); arguments outside the table (the wrapped counts of TWK_HIP_OPT_REF_COMPAT narrow to negative ints) take lgamma itself
+__device__ inline double d_lgamma1(const LFact& t, int i) { return (unsigned)i < (unsigned)t.n ? t.lf[i] : lgamma((double)(i + 1)); }
+__device__ inline double d_lbinom(const LFact& t, int n, int k) {
 	if (k == 0 || n == k) return 0;
-	return lgamma((double)(n + 1)) - lgamma((double)(k + 1)) - lgamma((double)(n - k + 1));
+	return d_lgamma1(t, n) - d_lgamma1(t, k) - d_lgamma1(t, n - k);
 }
-__device__ inline double d_hypergeo(int n11, int n1_, int n_1, int n) {
-	return exp(d_lbinom(n1_, n11) + d_lbinom(n - n1_, n_1 - n11) - d_lbinom(n, n_1));
+__device__ inline double d_hypergeo(const LFact& t, int n11, int n1_, int n_1, int n) {
+	return exp(d_lbinom(t, n1_, n11) + d_lbinom(t, n - n1_, n_1 - n11) - d_lbinom(t, n, n_1));
+}
+__global__ void k_build_lfact(double* __restrict__ lf, int n) {
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) lf[i] = lgamma((double)i + 1.0);
 }
 struct hgacc { int n11, n1_, n_1, n; double p; };
-__device__ inline double d_hypergeo_acc(int n11, int n1_, int n_1, int n, hgacc* aux) {
+__device__ inline double d_hypergeo_acc(const LFact& t, int n11, int n1_, int n_1, int n, hgacc* aux) {
 	if (n1_ || n_1 || n) {
 		aux->n11 = n11; aux->n1_ = n1_; aux->n_1 = n_1; aux->n = n;
 	} else {
@@ -62,11 +73,11 @@ __device__ inline double d_hypergeo_acc(int n11, int n1_, int n_1, int n, hgacc*
 		}
 		aux->n11 = n11;
 	}
-	aux->p = d_hypergeo(aux->n11, aux->n1_, aux->n_1, aux->n);
+	aux->p = d_hypergeo(t, aux->n11, aux->n1_, aux->n_1, aux->n);
 	return aux->p;
 }
 // Two-sided P only (left / right tails are not stored in the record).
-__device__ inline double d_fisher_two(int n11, int n12, int n21, int n22) {
+__device__ inline double d_fisher_two(const LFact& t, int n11, int n12, int n21, int n22) {
 	int i, j, max, min;
 	double p, q, left, right;
 	hgacc aux;
@@ -75,42 +86,48 @@ __device__ inline double d_fisher_two(int n11, int n12, int n21, int n22) {
 	min = n1_ + n_1 - n;
 	if (min < 0) min = 0;
 	if (min == max) return 1.;
-	q = d_hypergeo_acc(n11, n1_, n_1, n, &aux);
+	q = d_hypergeo_acc(t, n11, n1_, n_1, n, &aux);
 	// The reference walks both tails from the ends of the support (min, max) inwards until the
 	// terms reach q: up to min(n1_, n_1) steps per record, almost all of them over terms that are
 	// zero or tens of orders of magnitude below q.  Start each walk closer in instead, at a point
-	// that is *verified* (one log-pmf evaluation) to lie below q by a factor e^-50: the pmf is
-	// monotone out there, so everything skipped sums to < (max - min) * 2e-22 * q, i.e. < 1e-15
-	// of the result (P >= q) -- far inside the 1e-6 bar; the walk itself, its re-synchronisation
-	// every 11th step and its stopping rule are unchanged.
+	// that is *verified* (one log-pmf evaluation) to lie below q by a factor e^-40: the pmf is
+	// monotone out there, so everything skipped sums to < (max - min) * 4e-18 * q, i.e. < 1e-10
+	// of the result (P >= q) even at 2e7 haplotypes -- far inside the 1e-6 bar; the walk itself, its
+	// re-synchronisation every 11th step and its stopping rule are unchanged.  The candidate point
+	// comes from the normal approximation of the log-pmf, -(s - mean)^2 / (2 sd^2) relative to the
+	// mode: a term e^-K below q lies sqrt(dev^2 + 2 K sd^2) from the mean (dev = |n11 - mean|), a
+	// few sd beyond n11's own distance for a significant table instead of a fixed 12 sd; the
+	// approximation only proposes, the exact log-pmf decides, and a point that fails moves outwards.
 	int i0 = min, j0 = max;
 	if (q > 0 && max - min > 64) {
 		const double lq = log(q), nn = (double)n;
 		const double mean = (double)n1_ * (double)n_1 / nn;
 		const double sd = sqrt(mean * ((nn - n1_) / nn) * ((nn - n_1) / (nn - 1.0)));
-		const double lden = d_lbinom(n, n_1);
-		double D = fabs((double)n11 - mean) + 12.0 * sd + 16.0;
-		for (int t = 0; t < 3; ++t, D *= 2.0) {
+		const double lden = d_lbinom(t, n, n_1);
+		const double dev = fabs((double)n11 - mean);
+		const double D0 = sqrt(dev * dev + 96.0 * sd * sd) + 4.0;                 // K = 48 proposed, 40 required
+		double D = D0;
+		for (int k = 0; k < 4; ++k, D = D * 1.5 + 8.0) {
 			const double sf = floor(mean - D);
 			if (sf <= (double)min) break;
 			const int s = (int)sf;
-			if (d_lbinom(n1_, s) + d_lbinom(n - n1_, n_1 - s) - lden <= lq - 50.0) { i0 = s; break; }
+			if (d_lbinom(t, n1_, s) + d_lbinom(t, n - n1_, n_1 - s) - lden <= lq - 40.0) { i0 = s; break; }
 		}
-		D = fabs((double)n11 - mean) + 12.0 * sd + 16.0;
-		for (int t = 0; t < 3; ++t, D *= 2.0) {
+		D = D0;
+		for (int k = 0; k < 4; ++k, D = D * 1.5 + 8.0) {
 			const double sf = ceil(mean + D);
 			if (sf >= (double)max) break;
 			const int s = (int)sf;
-			if (d_lbinom(n1_, s) + d_lbinom(n - n1_, n_1 - s) - lden <= lq - 50.0) { j0 = s; break; }
+			if (d_lbinom(t, n1_, s) + d_lbinom(t, n - n1_, n_1 - s) - lden <= lq - 40.0) { j0 = s; break; }
 		}
 	}
-	p = d_hypergeo_acc(i0, 0, 0, 0, &aux);
+	p = d_hypergeo_acc(t, i0, 0, 0, 0, &aux);
 	for (left = 0., i = i0 + 1; p < 0.99999999 * q && i <= max; ++i)
-		left += p, p = d_hypergeo_acc(i, 0, 0, 0, &aux);
+		left += p, p = d_hypergeo_acc(t, i, 0, 0, 0, &aux);
 	if (p < 1.00000001 * q) left += p;
-	p = d_hypergeo_acc(j0, 0, 0, 0, &aux);
+	p = d_hypergeo_acc(t, j0, 0, 0, 0, &aux);
 	for (right = 0., j = j0 - 1; p < 0.99999999 * q && j >= 0; --j)
-		right += p, p = d_hypergeo_acc(j, 0, 0, 0, &aux);
+		right += p, p = d_hypergeo_acc(t, j, 0, 0, 0, &aux);
 	if (p < 1.00000001 * q) right += p;
 	double two = left + right;
 	if (two > 1.) two = 1.;
@@ -554,7 +571,7 @@ void k_ld_stats(const StatsParams p) {
 #define TWK_DROPPED_RECORD 0xFFFFFFFFu
 __global__ __launch_bounds__(256)
 void k_ld_fisher(twk_hip_record* __restrict__ recs, const unsigned long long* __restrict__ n_out,
-                 unsigned long long capacity, double minP) {
+                 unsigned long long capacity, double minP, const LFact lfact) {
 	unsigned long long n = *n_out;
 	if (n > capacity) n = capacity;
 	for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
@@ -562,7 +579,7 @@ void k_ld_fisher(twk_hip_record* __restrict__ recs, const unsigned long long* __
 		twk_hip_record* r = recs + i;
 		int n11 = (int)round(r->cnt[0]);
 		if (r->flags & TWK_N11_IN_PAD) { n11 = (int)r->_pad; r->flags &= ~TWK_N11_IN_PAD; r->_pad = 0; }
-		const double both = d_fisher_two(n11, (int)round(r->cnt[2]), (int)round(r->cnt[1]), (int)round(r->cnt[3]));
+		const double both = d_fisher_two(lfact, n11, (int)round(r->cnt[2]), (int)round(r->cnt[1]), (int)round(r->cnt[3]));
 		r->P = both;
 		if (both > minP) r->idxA = TWK_DROPPED_RECORD;
 	}

@@ -90,6 +90,7 @@ struct twk_hip_ctx {
 	// metadata (device SoA) + host mirror
 	uint32_t *d_ac = nullptr, *d_an = nullptr, *d_pos = nullptr, *d_rid = nullptr, *d_missing = nullptr;
 	double* d_hwe = nullptr;
+	double* d_lfact = nullptr; int lfact_n = 0;    // lgamma(i + 1), i <= 2N: Fisher's log-binomials (ld_math.hip.h)
 	std::vector<twk_hip_variant_meta> h_meta;
 	PlaneSet planes[N_PLANE_SETS];
 	Slot slot[3];                  // [0],[1]: ld_all pipeline; [2]: synchronous single-tile calls
@@ -147,9 +148,9 @@ void free_slots(twk_hip_ctx* c) {
 void free_problem(twk_hip_ctx* c) {
 	free_planes(c);
 	free_slots(c);
-	void* ptrs[] = {c->raw, c->rawmask, c->d_ac, c->d_an, c->d_pos, c->d_rid, c->d_missing, c->d_hwe};
+	void* ptrs[] = {c->raw, c->rawmask, c->d_ac, c->d_an, c->d_pos, c->d_rid, c->d_missing, c->d_hwe, c->d_lfact};
 	for (void* p : ptrs) if (p) (void)hipFree(p);
-	c->raw = c->rawmask = nullptr;
+	c->raw = c->rawmask = nullptr; c->d_lfact = nullptr; c->lfact_n = 0;
 	c->d_ac = c->d_an = c->d_pos = c->d_rid = c->d_missing = nullptr; c->d_hwe = nullptr;
 	c->h_meta.clear();
 	c->N = c->M = c->M_alloc = 0; c->any_missing = false;
@@ -420,7 +421,7 @@ int enqueue_tile(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, const twk
 		hipLaunchKernelGGL(k_ld_stats, dim3((t.nB + 255) / 256, t.nA), dim3(256), 0, c->s_compute, p);
 		HIPCHK(c, hipGetLastError());
 	}
-	hipLaunchKernelGGL(k_ld_fisher, dim3(c->resident_blocks * 2), dim3(256), 0, c->s_compute, s.out, s.n_out, s.capacity, f.minP);
+	hipLaunchKernelGGL(k_ld_fisher, dim3(c->resident_blocks * 2), dim3(256), 0, c->s_compute, s.out, s.n_out, s.capacity, f.minP, LFact{c->d_lfact, c->lfact_n});
 	HIPCHK(c, hipGetLastError());
 	s.minP = f.minP;
 	HIPCHK(c, hipMemcpyAsync(s.h_n_out, s.n_out, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->s_compute));
@@ -720,6 +721,14 @@ int twk_hip_set_problem(twk_hip_ctx* c, uint32_t n_samples, uint32_t n_variants)
 	HIPCHK(c, hipMemset(c->d_rid, 0, m4)); HIPCHK(c, hipMemset(c->d_missing, 0, m4)); HIPCHK(c, hipMemset(c->d_hwe, 0, (size_t)c->M_alloc * 8));
 	c->h_meta.assign(n_variants, twk_hip_variant_meta{});
 	c->timing.words_per_row = 0;
+	{	// every count Fisher's test sees is <= 2N (+ rounding of the unphased expected counts); beyond 2^26 entries lgamma itself is used
+		const unsigned long long want = std::min<unsigned long long>(2ull * n_samples + 16, 1ull << 26);
+		HIPCHK(c, hipMalloc((void**)&c->d_lfact, (size_t)want * sizeof(double)));
+		c->lfact_n = (int)want;
+		hipLaunchKernelGGL(k_build_lfact, dim3((unsigned)((want + 255) / 256)), dim3(256), 0, c->s_compute, c->d_lfact, c->lfact_n);
+		HIPCHK(c, hipGetLastError());
+		HIPCHK(c, hipStreamSynchronize(c->s_compute));
+	}
 	return TWK_HIP_OK;
 }
 

@@ -6,8 +6,8 @@
 #include "../hip/ld_math.hip.h"
 #define CK(x) do{hipError_t e=(x); if(e!=hipSuccess){fprintf(stderr,"HIP %s: %s\n",#x,hipGetErrorString(e)); exit(1);} }while(0)
 __global__ void k_lg(const double* x, double* y, int n){ int i=blockIdx.x*blockDim.x+threadIdx.x; if(i<n) y[i]=lgamma(x[i]); }
-__global__ void k_fi(const int* t, double* p, double* q, int n){ int i=blockIdx.x*blockDim.x+threadIdx.x; if(i<n){ p[i]=twk::d_fisher_two(t[4*i],t[4*i+1],t[4*i+2],t[4*i+3]);
-  const int n1_=t[4*i]+t[4*i+1], n_1=t[4*i]+t[4*i+2], nn=t[4*i]+t[4*i+1]+t[4*i+2]+t[4*i+3]; q[i]=twk::d_hypergeo(t[4*i],n1_,n_1,nn);} }
+__global__ void k_fi(const int* t, double* p, double* q, int n){ int i=blockIdx.x*blockDim.x+threadIdx.x; if(i<n){ p[i]=twk::d_fisher_two(twk::LFact{nullptr, 0}, t[4*i],t[4*i+1],t[4*i+2],t[4*i+3]);
+  const int n1_=t[4*i]+t[4*i+1], n_1=t[4*i]+t[4*i+2], nn=t[4*i]+t[4*i+1]+t[4*i+2]+t[4*i+3]; q[i]=twk::d_hypergeo(twk::LFact{nullptr, 0}, t[4*i],n1_,n_1,nn);} }
 static double h_lbinom(int n,int k){ if(k==0||n==k) return 0; return lgamma(n+1.0)-lgamma(k+1.0)-lgamma(n-k+1.0); }
 int main(){
   const int n=12; double hx[n]={10.5,1e3+1,1e5+1,2e6+1,8388609.0,1.2e7+1,16777217.0,2e7+1,19583418.0,4e7+1,126360.0,4044197.0};
