@@ -64,6 +64,7 @@ public:
 
 	// seconds the producer spent in emit(): ordering unsorted input / cutting + waiting for the expansion (and, at the end, for the drain)
 	double t_sort = 0, t_blocks = 0;
+	std::atomic<uint64_t> ns_expand{0}, ns_pack{0}, ns_write{0};   // worker / writer thread time, summed
 
 	// Write the survivors recs[0..n) behind this producer's open block; final: close it too and wait
 	// until everything is in the file.  presorted: the records are in (idxA, idxB) order already.
@@ -213,13 +214,17 @@ private:
 			std::memcpy(s.v.data(), &m, 4); std::memcpy(s.v.data() + 4, &m, 4);
 			TwoRecord* f = reinterpret_cast<TwoRecord*>(s.f.data() + 8);
 			TwoRecord* v = reinterpret_cast<TwoRecord*>(s.v.data() + 8);
+			const auto w0 = std::chrono::steady_clock::now();
 			for (uint64_t i = 0; i < s.n_a; ++i) expand(s.src_a[i], f[i], v[i]);
 			for (uint64_t i = 0; i < s.n_b; ++i) expand(s.src_b[i], f[s.n_a + i], v[s.n_a + i]);
 			{
 				std::lock_guard<std::mutex> lk(mu_);
 				if (--expanding_ == 0) cv_expanded_.notify_all();
 			}
+			const auto w1 = std::chrono::steady_clock::now();
 			const bool ok = TwoWriter::pack_block(s.f.data(), m, out_.c_level, s.pf) && TwoWriter::pack_block(s.v.data(), m, out_.c_level, s.pv);
+			ns_expand += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(w1 - w0).count();
+			ns_pack += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - w1).count();
 			{
 				std::lock_guard<std::mutex> lk(mu_);
 				if (!ok) fail_locked();
@@ -238,12 +243,14 @@ private:
 				s = &slots_[written_ % window_];
 			}
 			bool ok = true;
+			const auto w0 = std::chrono::steady_clock::now();
 			if (!failed_.load()) {
 				std::lock_guard<std::mutex> lk(out_.mu);
 				out_.n_records += 2 * (uint64_t)s->n;
 				out_.n_blocks += 2; out_.bytes_packed += s->pf.z.size() + s->pv.z.size();
 				ok = out_.writer.write_packed(s->pf) && out_.writer.write_packed(s->pv);
 			}
+			ns_write += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - w0).count();
 			std::lock_guard<std::mutex> lk(mu_);
 			if (!ok) fail_locked();
 			s->state = Slot::FREE;
