@@ -216,7 +216,9 @@ int twk_hip_ld_tile(twk_hip_ctx* ctx, int mode, const twk_hip_tile_desc* tile,
  * replaces twk_ld_balancer::Build (ld_balancing.h:23-80) for multi-GPU sharding.
  * tile_variants = edge of a super-tile in variants (0 = choose).  Survivors
  * are handed to `sink` (may be NULL to discard) tile by tile on the calling
- * thread.  *n_pairs / *n_records (may be NULL) receive totals for this shard. */
+ * thread; the records of one call are in (idxA, idxB) order (sorted on the device)
+ * and stay valid until the sink returns.  *n_pairs / *n_records (may be NULL)
+ * receive totals for this shard. */
 typedef int (*twk_hip_record_sink)(void* user, const twk_hip_record* recs, uint64_t n);
 int twk_hip_ld_all(twk_hip_ctx* ctx, int mode, const twk_hip_filters* filters,
                    uint32_t part, uint32_t n_parts, uint32_t tile_variants,
