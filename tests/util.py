@@ -134,11 +134,13 @@ def double_root_vetter(data, mask, variants, n_samples):
 
 # Absolute floors for records that come out of the unphased cubic (ld_engine.cpp:1363-1558), on top of the 1e-6
 # relative bar.  The cubic is ill-conditioned where D ~ 0 and next to a double root, so device (ocml) and reference
-# (glibc) differ in the last digits there; the floors are ~10x the largest deviation seen over 236 k such records
-# of every parity test (TWK_PARITY_STATS sweep, round 2: D 1.9e-12, D' 7.5e-10, R 1.6e-11, R2 5.6e-12, expected
-# counts 1.9e-12 of the table total) - four to six orders of magnitude inside the 1e-6 bar of the quantities'
-# natural range.
-CUBIC_FLOOR = {"D": 2e-11, "Dprime": 1e-8, "R": 2e-10, "R2": 1e-10, "cnt/total": 2e-11, "ChiSqFisher/total": 1e-10}
+# (glibc) differ in the last digits of the root there, and D = f11 - pA pB cancels: the floors are ~10x the largest
+# deviation *beyond the relative bar* seen over 867 k such records - every -m gpu test plus the four oracle sweeps of
+# tests/sweeps (TWK_PARITY_STATS, build/parity_stats.sh, round 2): D 3.4e-12, D' 8.8e-8, R 7.8e-10, R2 9e-14, expected
+# counts 4.3e-12 and ChiSqFisher 1.8e-11 of the table total.  The D' and R figures are one pair of
+# haplotype_block_sweep_large_n.py (N = 20,000 with missing genotypes, r2 = 3e-9, D' = 0.0063: D itself is 1e-9 and
+# agrees to 1.5e-14); without it the worst are D' 7.5e-10 and R 1.6e-11.
+CUBIC_FLOOR = {"D": 5e-11, "Dprime": 1e-6, "R": 1e-8, "R2": 1e-10, "cnt/total": 5e-11, "ChiSqFisher/total": 2e-10}
 
 
 def _one_term_apart(p_a, p_b, table):
@@ -188,6 +190,8 @@ def assert_records_match(gpu_recs, orc_recs, variants, n_samples=None, rtol=1e-6
             tot = float(np.sum(w["cnt"]))
             for f in ("D", "Dprime", "R", "R2"):
                 dev[f] = max(dev.get(f, 0.0), abs(float(g[f]) - float(w[f])))
+                # what an absolute floor has to cover: the part of the deviation the relative bar does not
+                dev[f + "_beyond_rtol"] = max(dev.get(f + "_beyond_rtol", 0.0), abs(float(g[f]) - float(w[f])) - rtol * abs(float(w[f])))
             dev["cnt/total"] = max(dev.get("cnt/total", 0.0), float(np.max(np.abs(g["cnt"] - w["cnt"]))) / tot)
             dev["ChiSqFisher/total"] = max(dev.get("ChiSqFisher/total", 0.0), abs(float(g["ChiSqFisher"]) - float(w["ChiSqFisher"])) / tot)
             dev["n"] = dev.get("n", 0) + 1
