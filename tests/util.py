@@ -136,10 +136,10 @@ def double_root_vetter(data, mask, variants, n_samples):
 # relative bar.  The cubic is ill-conditioned where D ~ 0 and next to a double root, so device (ocml) and reference
 # (glibc) differ in the last digits of the root there, and D = f11 - pA pB cancels: the floors are ~10x the largest
 # deviation *beyond the relative bar* seen over 867 k such records - every -m gpu test plus the four oracle sweeps of
-# tests/sweeps (TWK_PARITY_STATS, build/parity_stats.sh, round 2): D 3.4e-12, D' 8.8e-8, R 7.8e-10, R2 9e-14, expected
+# tests/sweeps (TWK_PARITY_STATS, tests/sweeps/parity_stats.sh, round 2): D 3.4e-12, D' 8.8e-8, R 7.8e-10, R2 9e-14, expected
 # counts 4.3e-12 and ChiSqFisher 1.8e-11 of the table total.  The D' and R figures are one pair of
-# haplotype_block_sweep_large_n.py (N = 20,000 with missing genotypes, r2 = 3e-9, D' = 0.0063: D itself is 1e-9 and
-# agrees to 1.5e-14); without it the worst are D' 7.5e-10 and R 1.6e-11.
+# haplotype_block_sweep_large_n.py (N = 20,000 with missing genotypes, r2 = 3e-9, D' = 0.0063: D itself is -2.4e-7 and
+# agrees to 3.6e-12, 1.5e-5 relative); without it the worst are D' 7.5e-10 and R 1.6e-11.
 CUBIC_FLOOR = {"D": 5e-11, "Dprime": 1e-6, "R": 1e-8, "R2": 1e-10, "cnt/total": 5e-11, "ChiSqFisher/total": 2e-10}
 
 
