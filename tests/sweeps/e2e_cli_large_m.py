@@ -17,7 +17,7 @@ def run(tag, twk, args, env=None):
         print(tag, "FAILED", r.stderr[-600:]); return
     fin = re.search(r"Finished in (\S+)\. Variants: ([0-9,]+), genotypes: [0-9,]+, output: ([0-9,]+)", r.stderr)
     load = re.search(r"Unpacked and uploaded .* variants\. (\S+)", r.stderr)
-    eng = re.findall(r"count kernel ([0-9.e+]+) ms in (\d+) launches, math kernel ([0-9.e+]+) ms", r.stderr)
+    eng = re.findall(r"count kernel ([0-9.e+]+) ms in (\d+) launches \(([0-9.e+-]+) % [^)]*\), math kernels ([0-9.e+]+) ms", r.stderr)
     print(f"{tag}: wall {wall:.2f} s | load {load.group(1) if load else '?'} | compute+write {fin.group(1)} | pairs {fin.group(2)} | records {fin.group(3)} | engine {eng}", flush=True)
     os.remove(out)
 
