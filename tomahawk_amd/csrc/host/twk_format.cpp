@@ -3,10 +3,6 @@
 
 #include <algorithm>
 #include <iostream>
-#include <sstream>
-#include <fcntl.h>
-#include <sys/uio.h>
-#include <unistd.h>
 
 // libzstd's stable one-shot API (zstd.h).  The image ships libzstd.so.1 but no
 // system header, so the six prototypes we use are declared here.
@@ -372,41 +368,23 @@ bool TwkReader::read_block(size_t i, Block& blk) { // twk_reader.cpp:8-44
 }
 
 // ---- .two writer / reader ------------------------------------------------------------
-namespace {
-bool pwrite_all(int fd, const void* buf, size_t n, uint64_t off) {
-	const uint8_t* p = static_cast<const uint8_t*>(buf);
-	while (n) {
-		const ssize_t w = ::pwrite(fd, p, n, (off_t)off);
-		if (w <= 0) return false;
-		p += w; n -= (size_t)w; off += (uint64_t)w;
-	}
-	return true;
-}
-}  // namespace
-TwoWriter::~TwoWriter() { if (fd_ >= 0) ::close(fd_); }
-// A file is written through a descriptor at tracked offsets (so that blocks whose place is known can be written by
-// several threads at once, write_frame_at); stdout through the stream.
-bool TwoWriter::put(const void* p, size_t n) {
-	if (fd_ >= 0) { if (!pwrite_all(fd_, p, n, off_)) { failed_ = true; return false; } off_ += n; return true; }
-	os_->write((const char*)p, n); off_ += n; return os_->good();
-}
+bool TwoWriter::put(const void* p, size_t n) { os_->write((const char*)p, n); off_ += n; return os_->good(); }
 
 bool TwoWriter::open(const std::string& path, const Header& hdr, int c_level) {
 	c_level_ = c_level; off_ = 0; n_records = n_blocks = 0;
-	failed_ = false; os_ = nullptr;
-	if (fd_ >= 0) { ::close(fd_); fd_ = -1; }
 	if (path.empty() || path == "-") os_ = &std::cout;
 	else {
-		fd_ = ::open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
-		if (fd_ < 0) return false;
+		file_.open(path, std::ios::binary | std::ios::trunc);
+		if (!file_.good()) return false;
+		os_ = &file_;
 	}
 	index_ = TwoIndex();
 	index_.meta.resize(hdr.contigs.size()); // IndexOutput(n_contigs): all-zero meta (ld.cpp:621)
 	if (!put(TWO_MAGIC, 4)) return false;
-	std::ostringstream hs;
-	if (!write_header_frame(hs, hdr, c_level_, nullptr)) return false; // writer.h:225-242
-	const std::string h = hs.str();
-	return put(h.data(), h.size());
+	uint64_t w = 0;
+	if (!write_header_frame(*os_, hdr, c_level_, &w)) return false; // writer.h:225-242
+	off_ += w;
+	return true;
 }
 
 bool TwoWriter::pack(const TwoRecord* recs, uint32_t n, int c_level, Packed& out) {
@@ -436,41 +414,11 @@ bool TwoWriter::pack_generic(const TwoRecord* recs, uint32_t n, int c_level, boo
 }
 
 bool TwoWriter::write_packed(const Packed& p) {
-	if (fd_ >= 0) { const uint64_t at = reserve_packed(p); return write_frame_at(at, p); }
 	IndexEntryOutput e = p.entry;
 	e.foff = off_;
 	const uint8_t marker = 1; const uint32_t unc = p.b_unc, cmp = (uint32_t)p.z.size();
 	if (!put(&marker, 1) || !put(&unc, 4) || !put(&cmp, 4) || !put(p.z.data(), p.z.size())) return false;
 	e.fend = off_;
-	note_block(e);
-	return true;
-}
-// The place of the next block in the file and its index entry, without its bytes: write_frame_at() puts them there
-// (from any thread; the writer must stay open until every reserved block has been written).
-uint64_t TwoWriter::reserve_packed(const Packed& p) {
-	IndexEntryOutput e = p.entry;
-	e.foff = off_;
-	off_ += 9 + p.z.size();
-	e.fend = off_;
-	note_block(e);
-	return e.foff;
-}
-bool TwoWriter::write_frame_at(uint64_t at, const Packed& p) {
-	if (fd_ < 0) return false;
-	uint8_t head[9]; head[0] = 1;
-	const uint32_t unc = p.b_unc, cmp = (uint32_t)p.z.size();
-	std::memcpy(head + 1, &unc, 4); std::memcpy(head + 5, &cmp, 4);
-	struct iovec iov[2] = {{head, 9}, {const_cast<uint8_t*>(p.z.data()), p.z.size()}};
-	const ssize_t w = ::pwritev(fd_, iov, 2, (off_t)at);
-	if (w == (ssize_t)(9 + p.z.size())) return true;
-	if (w < 0) { failed_ = true; return false; }
-	// a short write: finish it piecewise
-	std::vector<uint8_t> all(9 + p.z.size());
-	std::memcpy(all.data(), head, 9); std::memcpy(all.data() + 9, p.z.data(), p.z.size());
-	if (!pwrite_all(fd_, all.data() + w, all.size() - (size_t)w, at + (uint64_t)w)) { failed_ = true; return false; }
-	return true;
-}
-void TwoWriter::note_block(const IndexEntryOutput& e) {
 	index_.ent.push_back(e);
 	if (index_.state == 2 && e.rid >= 0 && (size_t)e.rid < index_.meta.size()) {      // index.cpp:70-88
 		IndexEntryEntry& m = index_.meta[e.rid];
@@ -478,6 +426,7 @@ void TwoWriter::note_block(const IndexEntryOutput& e) {
 		m.n += e.n; m.maxpos = e.maxpos; m.fend = e.fend; ++m.nn;
 	}
 	n_records += e.n; ++n_blocks;
+	return true;
 }
 
 bool TwoWriter::write_raw(uint32_t b_unc, const std::vector<uint8_t>& z, IndexEntryOutput e) {
@@ -497,16 +446,16 @@ bool TwoWriter::write_block(const TwoRecord* recs, uint32_t n) {
 }
 
 bool TwoWriter::close() { // writer.h:293-313
-	if (!os_ && fd_ < 0) return false;
+	if (!os_) return false;
 	ByteBuf b; index_.serialize(b);
 	std::vector<uint8_t> z;
 	if (!zstd_compress(b.v.data(), b.v.size(), z, c_level_)) return false;
 	const uint64_t off = off_, unc = b.size(), cmp = z.size();
 	const uint8_t marker = 0;
 	put(&marker, 1); put(&unc, 8); put(&cmp, 8); put(z.data(), z.size()); put(&off, 8); put(TWK_EOF_HEX, 32);
-	bool ok;
-	if (fd_ >= 0) { ok = !failed_; if (::close(fd_) != 0) ok = false; fd_ = -1; }
-	else { os_->flush(); ok = os_->good(); }
+	os_->flush();
+	const bool ok = os_->good();
+	if (file_.is_open()) file_.close();
 	os_ = nullptr;
 	return ok;
 }

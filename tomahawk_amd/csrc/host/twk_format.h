@@ -6,7 +6,6 @@
 // primitive append).  Compression: one-shot zstd frames (lib/zstd_codec.cpp:
 // 136-168).
 #pragma once
-#include <atomic>
 #include <cstdint>
 #include <cstring>
 #include <fstream>
@@ -163,10 +162,6 @@ static_assert(sizeof(TwoRecord) == 106, "twk1_two_t::packed_size");
 
 class TwoWriter {         // include/writer.h:163-406 as used by calc
 public:
-	TwoWriter() = default;
-	~TwoWriter();
-	TwoWriter(const TwoWriter&) = delete;
-	TwoWriter& operator=(const TwoWriter&) = delete;
 	// path "-" or "" -> stdout (ld.cpp:585-587)
 	bool open(const std::string& path, const Header& hdr, int c_level = 1);
 	// One block: u32 n, u32 m, n records -> zstd -> [1][b_unc][b_cmp][bytes]
@@ -185,21 +180,14 @@ public:
 	// extends the per-contig entry of its ridA (writer.h:384-386, index.cpp:70-88).
 	void set_state(uint8_t s) { index_.state = s; }
 	bool write_packed(const Packed& p);
-	// File output only (positional()): the same in two steps - reserve_packed() assigns the block its place in the
-	// file and its index entry, in call order; write_frame_at() puts the bytes there, from any thread.
-	bool positional() const { return fd_ >= 0; }
-	uint64_t reserve_packed(const Packed& p);
-	bool write_frame_at(uint64_t at, const Packed& p);
 	// Append an already compressed block under the given index entry (concat, lib/concat.h:160-175).
 	bool write_raw(uint32_t b_unc, const std::vector<uint8_t>& z, IndexEntryOutput entry);
 	int  compression_level() const { return c_level_; }
 	bool close();             // writer.h:293-313
 	uint64_t n_records = 0, n_blocks = 0;
 private:
-	std::ostream* os_ = nullptr;   // stdout
-	int fd_ = -1;                  // a file
-	std::atomic<bool> failed_{false};
-	void note_block(const IndexEntryOutput& e);
+	std::ostream* os_ = nullptr;
+	std::ofstream file_;
 	uint64_t off_ = 0;        // bytes written so far (tellp is unusable on stdout)
 	TwoIndex index_;
 	int c_level_ = 1;

@@ -12,10 +12,8 @@
 // engine (sorted on the device), so the emitter only cuts them into blocks by the flush rule; its
 // worker threads expand the blocks into their forward and reverse forms straight out of the
 // producer's buffer, and emit() returns as soon as that is done - the buffer is the engine's again.
-// Compressing the blocks and appending them in order goes on behind the producer's back: the
-// same workers compress; a sequencer thread gives every compressed block, in order, its place in
-// the file and its index entry (the only step under the shared writer's lock), and the workers
-// put the bytes there (pwrite; to stdout the sequencer writes them itself).  At most `window`
+// Compressing the blocks and appending them in order goes on behind the producer's back (the same
+// workers, one writer thread); only the append holds the shared writer's lock.  At most `window`
 // blocks are in flight.  (With 33 M survivors of a 2,504-sample run the producer thread spent 2.1 s
 // of a 2.3 s run in here when every call compressed and wrote its own blocks before returning.)
 #pragma once
@@ -54,7 +52,7 @@ public:
 		window_ = (size_t)n_workers_ * 6;
 		slots_.resize(window_);
 		for (int t = 0; t < n_workers_; ++t) th_.emplace_back([this] { worker(); });
-		th_.emplace_back([this] { sequencer(); });
+		th_.emplace_back([this] { writer(); });
 	}
 	~RecordEmitter() {
 		{ std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
@@ -109,15 +107,15 @@ public:
 			expanding_ = 0;
 			for (size_t b = 0; b < n_closed; ++b) {
 				const uint64_t seq = next_seq_;
-				Slot& s = slots_[seq % window_];
-				cv_room_.wait(lk, [&] { return failed_.load() || s.state == Slot::FREE; });
+				cv_room_.wait(lk, [&] { return failed_.load() || seq < written_ + window_; });
 				if (failed_.load()) return false;
+				Slot& s = slots_[seq % window_];
 				const uint64_t lo = cut[b], hi = cut[b + 1];
 				// the block's records: [lo, hi) of carry ++ recs
 				s.src_a = lo < nc ? carry_.data() + lo : nullptr; s.n_a = lo < nc ? std::min(hi, nc) - lo : 0;
 				s.src_b = hi > nc ? recs + (std::max(lo, nc) - nc) : nullptr; s.n_b = hi > nc ? hi - std::max(lo, nc) : 0;
 				s.n = (uint32_t)(hi - lo); s.state = Slot::QUEUED;
-				jobs_.push_back(Job{seq, false});
+				jobs_.push_back(seq);
 				++next_seq_; ++expanding_;
 				cv_job_.notify_one();
 			}
@@ -129,7 +127,7 @@ public:
 		carry_.swap(next);
 		if (final) {
 			std::unique_lock<std::mutex> lk(mu_);
-			cv_room_.wait(lk, [&] { return failed_.load() || done_ == next_seq_; });
+			cv_room_.wait(lk, [&] { return failed_.load() || written_ == next_seq_; });
 		}
 		t_blocks += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_sorted).count();
 		return !failed_.load();
@@ -137,8 +135,7 @@ public:
 
 private:
 	struct Slot {
-		enum State { FREE, QUEUED, PACKED, PLACED } state = FREE;
-		uint64_t at_f = 0, at_v = 0;      // PLACED: where the two frames go in the file
+		enum State { FREE, QUEUED, PACKED } state = FREE;
 		const twk_hip_record* src_a = nullptr; const twk_hip_record* src_b = nullptr;   // the block = src_a[0..n_a) ++ src_b[0..n_b)
 		uint64_t n_a = 0, n_b = 0;
 		uint32_t n = 0;
@@ -152,9 +149,8 @@ private:
 	std::vector<std::thread> th_;
 	std::mutex mu_;
 	std::condition_variable cv_job_, cv_expanded_, cv_packed_, cv_room_;
-	struct Job { uint64_t seq; bool write; };
-	std::deque<Job> jobs_;                // under mu_: blocks to expand + compress, placed blocks to write
-	uint64_t next_seq_ = 0, placed_ = 0, done_ = 0;   // under mu_: blocks handed out / given their place in the file / in the file
+	std::deque<uint64_t> jobs_;           // under mu_
+	uint64_t next_seq_ = 0, written_ = 0; // under mu_: blocks handed out / appended
 	uint64_t expanding_ = 0;              // under mu_: blocks of the current emit() still reading the producer's buffer
 	bool stop_ = false;
 	std::atomic<bool> failed_{false};
@@ -204,25 +200,14 @@ private:
 
 	void worker() {
 		for (;;) {
-			Job job;
+			uint64_t seq;
 			{
 				std::unique_lock<std::mutex> lk(mu_);
 				cv_job_.wait(lk, [&] { return stop_ || !jobs_.empty(); });
 				if (jobs_.empty()) return;             // stop_
-				job = jobs_.front(); jobs_.pop_front();
+				seq = jobs_.front(); jobs_.pop_front();
 			}
-			const uint64_t seq = job.seq;
 			Slot& s = slots_[seq % window_];
-			if (job.write) {                          // a placed block: put its two frames where they belong
-				const auto w0 = std::chrono::steady_clock::now();
-				const bool ok = failed_.load() || (out_.writer.write_frame_at(s.at_f, s.pf) && out_.writer.write_frame_at(s.at_v, s.pv));
-				ns_write += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - w0).count();
-				std::lock_guard<std::mutex> lk(mu_);
-				if (!ok) fail_locked();
-				s.state = Slot::FREE; ++done_;
-				cv_room_.notify_all();
-				continue;
-			}
 			const uint32_t m = s.n;
 			s.f.resize(8 + (size_t)m * sizeof(TwoRecord)); s.v.resize(8 + (size_t)m * sizeof(TwoRecord));       // u32 n, u32 n, records (core.cpp:626-631)
 			std::memcpy(s.f.data(), &m, 4); std::memcpy(s.f.data() + 4, &m, 4);
@@ -244,36 +229,34 @@ private:
 				std::lock_guard<std::mutex> lk(mu_);
 				if (!ok) fail_locked();
 				s.state = Slot::PACKED;
-				if (seq == placed_) cv_packed_.notify_one();
+				if (seq == written_) cv_packed_.notify_one();
 			}
 		}
 	}
-	void sequencer() {                        // CompressBlock (:1804-1810): forward, then reverse, blocks in order
+	void writer() {                           // CompressBlock (:1804-1810): forward, then reverse, blocks in order
 		for (;;) {
 			Slot* s;
 			{
 				std::unique_lock<std::mutex> lk(mu_);
-				cv_packed_.wait(lk, [&] { return stop_ || (placed_ < next_seq_ && slots_[placed_ % window_].state == Slot::PACKED); });
-				if (!(placed_ < next_seq_ && slots_[placed_ % window_].state == Slot::PACKED)) return;       // stop_
-				s = &slots_[placed_ % window_];
+				cv_packed_.wait(lk, [&] { return stop_ || (written_ < next_seq_ && slots_[written_ % window_].state == Slot::PACKED); });
+				if (!(written_ < next_seq_ && slots_[written_ % window_].state == Slot::PACKED)) return;       // stop_
+				s = &slots_[written_ % window_];
 			}
-			bool ok = true, written = false;
+			bool ok = true;
+			const auto w0 = std::chrono::steady_clock::now();
 			if (!failed_.load()) {
 				std::lock_guard<std::mutex> lk(out_.mu);
 				out_.n_records += 2 * (uint64_t)s->n;
 				out_.n_blocks += 2; out_.bytes_packed += s->pf.z.size() + s->pv.z.size();
-				if (out_.writer.positional()) { s->at_f = out_.writer.reserve_packed(s->pf); s->at_v = out_.writer.reserve_packed(s->pv); }
-				else {
-					const auto w0 = std::chrono::steady_clock::now();
-					ok = out_.writer.write_packed(s->pf) && out_.writer.write_packed(s->pv); written = true;
-					ns_write += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - w0).count();
-				}
-			} else written = true;
+				ok = out_.writer.write_packed(s->pf) && out_.writer.write_packed(s->pv);
+			}
+			ns_write += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - w0).count();
 			std::lock_guard<std::mutex> lk(mu_);
 			if (!ok) fail_locked();
-			const uint64_t seq = placed_++;
-			if (written) { s->state = Slot::FREE; ++done_; cv_room_.notify_all(); }
-			else { s->state = Slot::PLACED; jobs_.push_front(Job{seq, true}); cv_job_.notify_one(); }      // ahead of the blocks still to compress: it frees a slot
+			s->state = Slot::FREE;
+			++written_;
+			cv_room_.notify_all();
+			if (written_ < next_seq_ && slots_[written_ % window_].state == Slot::PACKED) cv_packed_.notify_one();
 		}
 	}
 	void fail_locked() {
