@@ -267,6 +267,27 @@ def test_cli_window_mode_slabs_per_gpu(tmp_path):
         assert len(one) > 0 and np.array_equal(one, multi)
 
 
+def test_cli_stdout_output_is_the_same_file(tmp_path):
+    """`-o -` (ld.cpp:585-587): the .two container goes to stdout, logging stays on stderr; piped into a file it is the
+    file `-o path` writes (one GPU, survivors in pair order: deterministic), and `view` reads it."""
+    z = np.load(os.path.join(GOLDEN, "n1000.npz"))
+    al = z["alleles"]
+    M = al.shape[0]
+    twk = str(tmp_path / "in.twk")
+    hostlib.write_twk(twk, al, z["pos"], z["rid"], phased=np.ones(M, np.uint8), n_contigs=int(z["rid"].max()) + 1, block_size=23)
+    a, b = str(tmp_path / "a.two"), str(tmp_path / "b.two")
+    r = subprocess.run([hostlib.CLI_PATH, "calc", "-i", twk, "-o", a, "-r", "0", "-p"], capture_output=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([hostlib.CLI_PATH, "calc", "-i", twk, "-o", "-", "-r", "0", "-p"], capture_output=True)
+    assert r.returncode == 0 and b"variants/s" in r.stderr
+    open(b, "wb").write(r.stdout)
+    ra, ia = hostlib.read_two(a)
+    rb, ib = hostlib.read_two(b)
+    assert ia == ib and ra.tobytes() == rb.tobytes() and len(ra) == 2 * len(z["rec_p"])
+    state, ent, _ = hostlib.two_index(b)
+    assert state == 0 and ent[:, 2].sum() == len(rb)
+
+
 def test_cli_corrupt_input_fails_cleanly(tmp_path):
     """Damaged .twk blocks - bad zstd frames, record headers that lie, run lengths that do not add up to the sample count
     (found by the device inflate kernel) - end the run with an error message and exit code 1; nothing crashes or hangs."""
