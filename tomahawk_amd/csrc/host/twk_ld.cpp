@@ -239,12 +239,11 @@ static bool open_output(twk_ld_settings& settings, const Header& in_hdr, TwoWrit
 
 // ---- input: .twk blocks -> HBM (ld.cpp:370-465, ld_unpacker.h:44-123) ------------------------------------
 // The reference's unpack threads decompress every block and expand every variant's run-length genotypes
-// into a bitvector in host memory.  Here the host only decompresses: blocks are cut into batches of
-// <= 256 MB (uncompressed), T threads read (pread) and zstd-decompress the blocks of a batch straight
-// into a page-locked staging buffer and walk the record headers for the per-variant metadata and the
-// place of the run words; the runs are expanded by a HIP kernel (twk_hip_upload_rle), so PCIe carries
-// the compressed genotypes.  Two staging buffers: batch b + 1 is decoded while batch b is uploaded, one
-// uploader thread per GPU.
+// into a bitvector in host memory.  Here the host only decompresses: blocks are grouped into batches of
+// <= 32 MB (uncompressed), decode threads read (pread) and zstd-decompress a batch each and walk the
+// record headers for the per-variant metadata and the place of the run words; the runs are expanded by
+// HIP kernels (twk_hip_upload_rle), so PCIe carries the compressed genotypes.  The batches pass through a
+// small ring of page-locked slots to one uploader thread per GPU (load_blocks below).
 namespace {
 bool pread_all(int fd, void* buf, size_t n, uint64_t off) {
 	uint8_t* p = static_cast<uint8_t*>(buf);
