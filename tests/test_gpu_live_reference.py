@@ -138,3 +138,46 @@ def test_off_diagonal_chunk_is_its_rectangle_of_the_full_run(tmp_path):
         util.assert_records_match(got, _as_oracle_records(whole[keep], variants), variants, double_root=vet)
         parts.append(got)
     assert abs(sum(len(p) for p in parts) - len(whole)) <= 2            # (double-root pairs may be on one side only)
+
+
+@pytest.mark.parametrize("w,compat", [(3000, True), (1700, True), (3000, False)])
+def test_scalc_equals_the_reference_run_live(tmp_path, w, compat):
+    """`scalc -I chr:pos -w W` (single site against its neighbourhood, scalc.h:50-194, ld.cpp:170-260).  The reference
+    works through the neighbours in groups of 100 and drops the last partial group (q15): with TWK_REF_COMPAT=1 the two
+    files hold the same records; without it the engine's file holds the reference's records plus the dropped remainder."""
+    N, M = 333, 450
+    al, pos, rid = _dataset("iid", N, M, 21, 2)
+    twk = str(tmp_path / "in.twk")
+    hostlib.write_twk(twk, al, pos, rid, phased=np.ones(M, np.uint8), n_contigs=2, block_size=100)
+    target = f"1:{int(pos[120])}"
+    ref_two, my_two = str(tmp_path / "ref.two"), str(tmp_path / "mine.two")
+    ref = subprocess.run([O.REF_BIN, "scalc", "-i", twk, "-o", ref_two, "-I", target, "-w", str(w), "-t", "2"], capture_output=True, text=True,
+                         stdin=subprocess.DEVNULL)
+    r = subprocess.run([hostlib.CLI_PATH, "scalc", "-i", twk, "-o", my_two, "-I", target, "-w", str(w)], capture_output=True, text=True,
+                       env=dict(os.environ, **(COMPAT if compat else {})))
+    if ref.returncode != 0:             # fewer than 100 neighbours: the reference has no full group and gives up; so does the engine when asked to mirror it
+        assert "no surrounding variants" in ref.stderr and compat
+        assert r.returncode == 1 and "no surrounding variants" in r.stderr
+        r = subprocess.run([hostlib.CLI_PATH, "scalc", "-i", twk, "-o", my_two, "-I", target, "-w", str(w)], capture_output=True, text=True)
+        assert r.returncode == 0 and 40 < len(hostlib.read_two(my_two)[0]) < 200
+        return
+    assert r.returncode == 0, r.stderr
+    a = hostlib.two_as_matrix(hostlib.read_two(ref_two)[0])
+    b = hostlib.two_as_matrix(hostlib.read_two(my_two)[0])
+    key = lambda m: [tuple(int(x) for x in row[1:5]) for row in m]
+    ka, kb = key(a), key(b)
+    assert len(set(ka)) == len(ka) and len(set(kb)) == len(kb) and len(ka) > 40
+    if compat:
+        assert set(ka) == set(kb)
+    else:
+        assert set(ka) <= set(kb) and len(kb) - len(ka) < 200            # the remainder of the last group of 100, both copies
+    ib = {k: i for i, k in enumerate(kb)}
+    bsel = b[[ib[k] for k in ka]]
+    assert np.array_equal(a[:, 0], bsel[:, 0])                              # flags
+    phased_math = (a[:, 0].astype(np.int64) & 1) == 1
+    assert np.array_equal(a[phased_math, 5:9], bsel[phased_math, 5:9])      # integer counts, slot for slot
+    total = a[:, 5:9].sum(axis=1, keepdims=True)
+    np.testing.assert_allclose(bsel[:, 5:9] / total, a[:, 5:9] / total, rtol=0, atol=util.CUBIC_FLOOR["cnt/total"])
+    for col, name in ((9, "D"), (10, "Dprime"), (11, "R"), (12, "R2")):
+        np.testing.assert_allclose(bsel[:, col], a[:, col], rtol=1e-6, atol=util.CUBIC_FLOOR[name])
+    np.testing.assert_allclose(bsel[:, 13], a[:, 13], rtol=1e-6, atol=1e-290)      # P
