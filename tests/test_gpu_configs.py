@@ -416,3 +416,32 @@ def test_cubic_record_with_cancelling_d(hip):
         util.assert_records_match(got, want, variants)
         g = util.records_by_pair(got, "idxA", "idxB")[(33, 89)]
         assert g["R2"] < 1e-8 and abs(g["D"]) < 1e-6 and 1e-3 < abs(g["Dprime"]) < 1e-2
+
+
+@pytest.mark.gpu
+def test_bench_orchestration_with_two_ranks_on_one_gpu(tmp_path):
+    """bench.py as the driver launches it for N > 1 (python -m torch.distributed.run, one process per rank), with the
+    gloo backend so that both ranks can share this box's one GPU: equal-area row bands, survivors gathered to rank 0
+    (counts all-gather + exact-size point-to-point transfers, tomahawk_amd/dist.py), rank 0 packs them into a real .two
+    inside the timed region, one JSON line.  (RCCL itself needs one GPU per rank: the 8-GPU run is the driver's.)"""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--variants", "4096",
+           "--samples", "50000", "--min-r2", "0.00005", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    M = 4096
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["scaling"] == "strong"
+    assert d["config"]["survivors_per_step"] > 1000
+    assert d["config"]["two_records_written_per_step"] == 2 * d["config"]["survivors_per_step"]
+    assert f"{M * (M - 1) // 2} pairs/step" in d["config"]["workload"]
+    assert d["roofline"]["bound"] == "valu" and 0 < d["roofline"]["frac"] < 1
