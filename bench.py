@@ -152,16 +152,37 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     xdev = dev if args.backend == "nccl" else torch.device("cpu")      # where the collectives' tensors live
+    collective = "none (one rank)"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        collective = args.backend
         if args.backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=dev)
+            # RCCL sets up its rings and the point-to-point channels of gather() lazily on first use:
+            # do that once here, outside any step (one empty-ish gather + a barrier).  Should RCCL fail to come up
+            # on this node (every rank sees the same error: IPC mode, no peer access ...), the survivors - a handful
+            # of KB at the default cut-off - travel over gloo instead, and the JSON line says so.
+            try:
+                if os.environ.get("TWK_BENCH_FORCE_RCCL_FAILURE"):          # test hook
+                    raise RuntimeError("forced by TWK_BENCH_FORCE_RCCL_FAILURE")
+                dist.init_process_group(backend="nccl", device_id=dev)
+                gather_records(np.zeros(1, dtype=T.RECORD_DTYPE), dst=0, device=xdev)
+                dist.barrier()
+            except Exception as e:
+                print(f"[bench] rank {rank}: RCCL did not come up ({e!r}); falling back to gloo for the gather", file=sys.stderr, flush=True)
+                try:
+                    if dist.is_initialized():
+                        dist.destroy_process_group()
+                except Exception:
+                    pass
+                dist.init_process_group(backend="gloo")
+                xdev = torch.device("cpu")
+                collective = f"gloo (RCCL failed to initialise: {str(e)[:120]})"
+                gather_records(np.zeros(1, dtype=T.RECORD_DTYPE), dst=0, device=xdev)
+                dist.barrier()
         else:
             dist.init_process_group(backend="gloo")
-        # RCCL sets up its rings and the point-to-point channels of gather() lazily on first use:
-        # do that once here, outside any step (one empty-ish gather + a barrier).
-        gather_records(np.zeros(1, dtype=T.RECORD_DTYPE), dst=0, device=xdev)
-        dist.barrier()
+            gather_records(np.zeros(1, dtype=T.RECORD_DTYPE), dst=0, device=xdev)
+            dist.barrier()
 
     n_samples, n_variants, mode = CONFIGS[args.config]
     if args.variants:
@@ -306,6 +327,7 @@ def main():
                        "n_samples": n_samples, "n_variants": n_variants, "mode": mode, "tile_variants": args.tile,
                        "partition": f"equal-area row bands of the pair triangle over {world} GPU(s), RCCL gather of survivors, "
                                     "rank 0 writes the .two file",
+                       "collective_backend": collective,
                        "survivors_per_step": recs_all / args.steps,
                        "two_records_written_per_step": written["records"] / args.steps},
             "roofline": {"bound": "valu", "achieved": lane_ops_per_s / 1e12, "peak": VALU_LANE_PEAK / 1e12,

@@ -445,3 +445,11 @@ def test_bench_orchestration_with_two_ranks_on_one_gpu(tmp_path):
     assert d["config"]["two_records_written_per_step"] == 2 * d["config"]["survivors_per_step"]
     assert f"{M * (M - 1) // 2} pairs/step" in d["config"]["workload"]
     assert d["roofline"]["bound"] == "valu" and 0 < d["roofline"]["frac"] < 1
+    assert d["config"]["collective_backend"] == "gloo"
+    # the default backend with RCCL made to fail on every rank: the run falls back to gloo and says so
+    cmd2 = [c for c in cmd if c not in ("--backend", "gloo")]
+    cmd2[cmd2.index("--master-port") + 1] = str(port + 1 if port < 65000 else port - 1)
+    r = subprocess.run(cmd2, capture_output=True, text=True, timeout=600, cwd=root, env=dict(os.environ, TWK_BENCH_FORCE_RCCL_FAILURE="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    d2 = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d2["config"]["collective_backend"].startswith("gloo (RCCL failed") and d2["config"]["survivors_per_step"] == d["config"]["survivors_per_step"]
