@@ -78,6 +78,10 @@ RUNS = [
     ("mosaic", 64, 600, 13, 3, [], None),
     ("mosaic", 2504, 900, 14, 2, ["-r", "0.3"], None),
     ("mosaic", 2504, 900, 14, 2, ["-u", "-w", "4000"], COMPAT),   # the reference's window mode as it behaves (q8)
+    # the headline's sample count, through the reference itself rather than the oracle
+    ("clean", 1_000_000, 120, 15, 1, ["-u", "-r", "0.01"], None),
+    ("mosaic", 1_000_000, 100, 16, 1, ["-r", "0.01"], None),
+    ("clean", 1_000_000, 120, 15, 1, ["-p", "-r", "0.01"], None),
 ]
 
 
