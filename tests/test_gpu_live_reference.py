@@ -82,6 +82,8 @@ RUNS = [
     ("clean", 1_000_000, 120, 15, 1, ["-u", "-r", "0.01"], None),
     ("mosaic", 1_000_000, 100, 16, 1, ["-r", "0.01"], None),
     ("clean", 1_000_000, 120, 15, 1, ["-p", "-r", "0.01"], None),
+    # configs[4]'s sample count (counts near 2e7: the int narrowing of Fisher's arguments, its stop-band instability)
+    ("clean", 10_000_000, 24, 17, 1, ["-u", "-r", "0.001"], None),
 ]
 
 
