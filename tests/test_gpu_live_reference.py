@@ -78,6 +78,9 @@ RUNS = [
     ("mosaic", 64, 600, 13, 3, [], None),
     ("mosaic", 2504, 900, 14, 2, ["-r", "0.3"], None),
     ("mosaic", 2504, 900, 14, 2, ["-u", "-w", "4000"], COMPAT),   # the reference's window mode as it behaves (q8)
+    # BASELINE configs[0] as it stands (1k diploid samples x 1k variants, unphased) and configs[1]'s shape (100k samples, phased)
+    ("clean", 1000, 1000, 18, 1, ["-u"], None),
+    ("clean", 100_000, 1500, 19, 1, ["-p"], None),
     # the headline's sample count, through the reference itself rather than the oracle
     ("clean", 1_000_000, 120, 15, 1, ["-u", "-r", "0.01"], None),
     ("mosaic", 1_000_000, 100, 16, 1, ["-r", "0.01"], None),
