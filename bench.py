@@ -30,6 +30,13 @@ The JSON line also carries
                is not measured inside this run: null here, the per-round figure is in profiles/.
   cpu_baseline the compiled reference (oracle/_ref, SSE4.2) on this box's host cores, on the first
                M_s variants of the same synthetic input (rank 0, N=1 only).
+  e2e          (N=1 only, after the timed region like cpu_baseline) `tomahawk calc`, default mode, from a cohort-shaped
+               .twk of the headline size written to /tmp: load (pread + zstd + device run-length inflate), r2 screen,
+               count / math kernels, device sort, .two writer - the parts of the path the survivor-free headline step
+               does not exercise, under the driver's clock.
+For N > 1 the line also carries per_rank_ms (each rank's compute time per step), gather_ms / write_ms (rank 0: the
+gather of the survivors incl. waiting for the slowest rank; packing the .two) and ranks_seen (an all-gather of the rank
+ids over the group that carried the gather).
 """
 import argparse
 import ctypes
@@ -107,6 +114,49 @@ def cpu_baseline(n_samples, mode, seed, log):
                       f"-t {cores}, {block} variants/block, SSE4.2 build of the reference, {wall:.1f}s wall)"}
 
 
+def e2e_from_disk(n_samples, n_variants, log):
+    """`tomahawk calc` (default mode: r2 screen on) from a cohort-shaped .twk on disk -> dict for the JSON line."""
+    from tomahawk_amd import hostlib
+    threads = min(os.cpu_count() or 8, 64)
+    twk = os.path.join(tempfile.gettempdir(), f"twk_bench_cohort_{n_samples}_{n_variants}.twk")
+    if not os.path.exists(twk):
+        t0 = time.time()
+        hostlib.write_cohort_twk(twk + ".tmp", n_samples, n_variants, seed=11, n_threads=threads, block_size=128)
+        os.replace(twk + ".tmp", twk)
+        log(f"e2e: wrote {twk} ({os.path.getsize(twk) / 1e6:.0f} MB) in {time.time() - t0:.1f}s")
+    out = os.path.join(tempfile.gettempdir(), f"twk_bench_e2e_{os.getpid()}.two")
+    res = None
+    for attempt in ("warm-up (the input was just written)", "timed"):
+        t0 = time.time()
+        r = subprocess.run([hostlib.CLI_PATH, "calc", "-i", twk, "-o", out, "-t", str(threads)], capture_output=True, text=True)
+        wall = time.time() - t0
+        if r.returncode != 0:
+            log("e2e: tomahawk calc failed: " + r.stderr[-300:])
+            return None
+        lg = r.stderr
+        load = re.search(r"Unpacked and uploaded .* variants\. (\S+)", lg)
+        fin = re.search(r"Finished in (\S+)\. Variants: ([0-9,]+), genotypes: [0-9,]+, output: ([0-9,]+)", lg)
+        eng = re.search(r"count kernel ([0-9.e+]+) ms in (\d+) launches \(([0-9.e+-]+) % [^)]*\), math kernels ([0-9.e+]+) ms", lg)
+        def secs(txt):          # the CLI prints [Hh][Mm]S.sss"s" (twk_util.h elapsed_string)
+            mo = re.fullmatch(r"(?:(\d+)h)?(?:(\d+)m)?([0-9.]+)s\.?", txt)
+            return (int(mo.group(1) or 0) * 3600 + int(mo.group(2) or 0) * 60 + float(mo.group(3))) if mo else None
+        res = {"wall_s": wall, "load_s": secs(load.group(1)) if load else None,
+               "compute_write_s": secs(fin.group(1)) if fin else None,
+               "pairs": int(fin.group(2).replace(",", "")) if fin else None,
+               "records": int(fin.group(3).replace(",", "")) if fin else None,
+               "two_bytes": os.path.getsize(out) if os.path.exists(out) else None,
+               "screen": "on", "count_kernel_ms": float(eng.group(1)) if eng else None,
+               "math_kernels_ms": float(eng.group(4)) if eng else None,
+               "input": f"{n_samples} samples x {n_variants} cohort-shaped variants (founder mosaics, 70 % rare), "
+                        f"{os.path.getsize(twk) / 1e6:.0f} MB .twk, calc default mode -t {threads}"}
+        log(f"e2e {attempt}: wall {wall:.2f}s {res}")
+    try:
+        os.remove(out)
+    except OSError:
+        pass
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -121,6 +171,10 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (debug: gloo lets "
                     "several ranks share one GPU, to exercise the N > 1 orchestration on a single-GPU box)")
     ap.add_argument("--min-r2", type=float, default=None, help="override the r2 cut-off (debug: produce survivors)")
+    ap.add_argument("--min-p", type=float, default=None, help="override the Fisher P cut-off (debug)")
+    ap.add_argument("--keep-two", default="", help="rank 0 keeps the .two file of the last timed step at this path")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the from-disk `tomahawk calc` measurement (N=1, cfg3)")
+    ap.add_argument("--e2e-variants", type=int, default=0, help="variants of the e2e input (0: the config's own count)")
     ap.add_argument("--emulate-shard", default="", help="K/N: run shard K of N on this one GPU (validation of the "
                     "sharded configs on a single-GPU box; the value then covers that shard only)")
     args = ap.parse_args()
@@ -129,7 +183,7 @@ def main():
     import torch.distributed as dist
     import numpy as np
     import tomahawk_amd as T
-    from tomahawk_amd.dist import gather_records
+    from tomahawk_amd.dist import gather_records, init_groups, window_slab, window_total_pairs
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -151,38 +205,13 @@ def main():
     dev_index = local_rank if local_rank < n_vis else local_rank % max(n_vis, 1)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    xdev = dev if args.backend == "nccl" else torch.device("cpu")      # where the collectives' tensors live
+    # Control traffic (barriers, the statistics all-reduce) runs over a gloo group, the gather of the survivors over
+    # RCCL - after every rank has agreed that RCCL came up (tomahawk_amd/dist.py init_groups).
+    xdev = torch.device("cpu")          # where the gather's transfer buffers live
+    gather_group = None
     collective = "none (one rank)"
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        collective = args.backend
-        if args.backend == "nccl":
-            # RCCL sets up its rings and the point-to-point channels of gather() lazily on first use:
-            # do that once here, outside any step (one empty-ish gather + a barrier).  Should RCCL fail to come up
-            # on this node (every rank sees the same error: IPC mode, no peer access ...), the survivors - a handful
-            # of KB at the default cut-off - travel over gloo instead, and the JSON line says so.
-            try:
-                if os.environ.get("TWK_BENCH_FORCE_RCCL_FAILURE"):          # test hook
-                    raise RuntimeError("forced by TWK_BENCH_FORCE_RCCL_FAILURE")
-                dist.init_process_group(backend="nccl", device_id=dev)
-                gather_records(np.zeros(1, dtype=T.RECORD_DTYPE), dst=0, device=xdev)
-                dist.barrier()
-            except Exception as e:
-                print(f"[bench] rank {rank}: RCCL did not come up ({e!r}); falling back to gloo for the gather", file=sys.stderr, flush=True)
-                try:
-                    if dist.is_initialized():
-                        dist.destroy_process_group()
-                except Exception:
-                    pass
-                dist.init_process_group(backend="gloo")
-                xdev = torch.device("cpu")
-                collective = f"gloo (RCCL failed to initialise: {str(e)[:120]})"
-                gather_records(np.zeros(1, dtype=T.RECORD_DTYPE), dst=0, device=xdev)
-                dist.barrier()
-        else:
-            dist.init_process_group(backend="gloo")
-            gather_records(np.zeros(1, dtype=T.RECORD_DTYPE), dst=0, device=xdev)
-            dist.barrier()
+        gather_group, xdev, collective = init_groups(args.backend, dev, force_rccl_failure=bool(os.environ.get("TWK_BENCH_FORCE_RCCL_FAILURE")))
 
     n_samples, n_variants, mode = CONFIGS[args.config]
     if args.variants:
@@ -193,6 +222,8 @@ def main():
     filters = T.Filters(minP=MIN_P.get(args.config, 1.0))   # reference defaults: r2 >= 0.1, P <= 1
     if args.min_r2 is not None:
         filters.minR2 = args.min_r2
+    if args.min_p is not None:
+        filters.minP = args.min_p
     window_bp = WINDOW_BP.get(args.config, 0)
     shard_rank, shard_world = rank, world
     if args.emulate_shard:
@@ -206,22 +237,11 @@ def main():
         # Band of rows with 1/world of the in-window pairs + the halo its last row reaches (positions are
         # 1000 + 100 v: SURVEY 8(d)); every rank derives the same partition from the positions alone.
         wv = window_bp // 100
-        cost = np.minimum(wv, n_variants - 1 - np.arange(n_variants, dtype=np.int64))
-        cum = np.concatenate(([0], np.cumsum(cost)))
-        def boundary(k):
-            if k <= 0:
-                return 0
-            if k >= shard_world:
-                return n_variants
-            r = int(np.searchsorted(cum, cum[-1] * k // shard_world, side="left"))
-            return min(n_variants, (r + 32) // 64 * 64)
-        r0, r1 = boundary(shard_rank), boundary(shard_rank + 1)
-        col_end = min(n_variants, r1 + wv)
+        r0, r1, col_end, my_expected = window_slab(n_variants, wv, shard_rank, shard_world)
         slab = (r0, r1, col_end)
         eng.set_problem(n_samples, col_end - r0)
         eng.generate_synthetic(args.seed, first_variant=r0)
-        total_pairs = int(cum[-1])
-        my_expected = int(cum[r1] - cum[r0])
+        total_pairs = window_total_pairs(n_variants, wv)
     else:
         eng.set_problem(n_samples, n_variants)
         eng.generate_synthetic(args.seed)          # every rank generates the same bits in its own HBM
@@ -251,29 +271,47 @@ def main():
                                  n_threads=min(os.cpu_count() or 1, 32))
 
     written = {"records": 0}
+    phase = {"compute": 0.0, "gather": 0.0, "write": 0.0}       # seconds, this rank, summed over the timed steps
 
     def step(stream):
         """One pass of the hot path over this rank's shard + the gather of survivors to rank 0 + the .two blocks."""
+        t_a = time.perf_counter()
+        if world > 1:
+            eng.set_device_sink(True)       # survivors stay in HBM: they leave this GPU over the gather, not over PCIe
         if slab:
             r0, r1, col_end = slab
             recs, npairs, nrec = eng.ld_region(hip_mode, filters, 0, r1 - r0, 0, col_end - r0, True,
                                                tile_variants=args.tile, window=1, l_window=window_bp)
             assert npairs == my_expected, (npairs, my_expected)
-            if len(recs):                                # slab-local variant indices -> global
-                recs["idxA"] += r0; recs["idxB"] += r0
         else:
             recs, npairs, nrec = eng.ld_all(hip_mode, filters, part=shard_rank, n_parts=shard_world, tile_variants=args.tile)
         if world > 1:
-            recs = gather_records(recs, dst=0, device=xdev)     # RCCL: all_gather(counts) + grouped send/recv of exact sizes
+            recs = eng.device_records_tensor()
+            assert recs.numel() == nrec * T.RECORD_DTYPE.itemsize, (recs.numel(), nrec)
+            if slab and nrec and slab[0]:        # slab-local variant indices -> global (idxA, idxB: the first two u32 of a record)
+                idx = recs.view(torch.int32).view(-1, T.RECORD_DTYPE.itemsize // 4)
+                idx[:, 0:2] += slab[0]
+            torch.cuda.synchronize()
+        elif slab and len(recs) and slab[0]:
+            recs["idxA"] += slab[0]; recs["idxB"] += slab[0]
+        t_b = time.perf_counter()
+        if world > 1:
+            # RCCL: all_gather(counts) + grouped send/recv of exact sizes, HBM to HBM; rank 0 copies to host once
+            recs = gather_records(recs, dst=0, device=xdev, group=gather_group)
+        t_c = time.perf_counter()
         if rank == 0:
             stream.append(recs)
             written["records"] += stream.close()
+        t_d = time.perf_counter()
+        phase["compute"] += t_b - t_a; phase["gather"] += t_c - t_b; phase["write"] += t_d - t_c
         return npairs, nrec
 
     for i in range(args.warmup):
         step(open_stream(f"w{i}"))
     streams = [open_stream(i) for i in range(args.steps)]
     written["records"] = 0
+    for k in phase:
+        phase[k] = 0.0
     barrier()
     eng.timing_reset()
     t0 = time.perf_counter()
@@ -286,14 +324,26 @@ def main():
     elapsed = time.perf_counter() - t0
     if rank == 0:
         import shutil
+        if args.keep_two and args.steps:
+            shutil.copyfile(os.path.join(out_dir, f"step{args.steps - 1}.two"), args.keep_two)
         shutil.rmtree(out_dir, ignore_errors=True)
     tm = eng.timing()
 
-    stats = torch.tensor([elapsed, tm["count_ms"], tm["stats_ms"]], dtype=torch.float64, device=xdev)
-    sums = torch.tensor([my_pairs, my_recs, tm["count_launches"], tm["row_pairs"]], dtype=torch.float64, device=xdev)
+    stats = torch.tensor([elapsed, tm["count_ms"], tm["stats_ms"]], dtype=torch.float64)
+    sums = torch.tensor([my_pairs, my_recs, tm["count_launches"], tm["row_pairs"]], dtype=torch.float64)
+    per_rank_ms, ranks_seen = [phase["compute"] / max(args.steps, 1) * 1e3], [rank]
     if world > 1:
         dist.all_reduce(stats, op=dist.ReduceOp.MAX)
         dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+        mine = torch.tensor([phase["compute"] / max(args.steps, 1) * 1e3], dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank_ms = [float(x.item()) for x in every]
+        # which ranks the group that carried the gather really connects: an all-gather of the rank ids over it
+        me = torch.tensor([rank], dtype=torch.int64, device=xdev)
+        seen = [torch.zeros_like(me) for _ in range(world)]
+        dist.all_gather(seen, me, group=gather_group)
+        ranks_seen = sorted(int(x.item()) for x in seen)
     elapsed_max, count_ms_max, stats_ms_max = (float(x) for x in stats.tolist())
     pairs_all, recs_all, launches_all, row_pairs_all = (float(x) for x in sums.tolist())
     if not args.emulate_shard:
@@ -350,6 +400,10 @@ def main():
                                  "and+bcnt ceiling = 64 lanes / (2 + 4 cycles) per SIMD = 2.62e13 word pairs/s "
                                  "(v_bcnt_u32_b32 is half rate: profiles/*microbench_valu_rate.txt)"},
             "kernel_ms": {"count": count_ms_max, "math": stats_ms_max, "wall": elapsed_max * 1e3},
+            "per_rank_ms": per_rank_ms,                                   # compute per step, every rank (balance of the bands)
+            "gather_ms": phase["gather"] / max(args.steps, 1) * 1e3,      # rank 0, per step: waits for the slowest rank, then the transfers
+            "write_ms": phase["write"] / max(args.steps, 1) * 1e3,        # rank 0, per step: survivors -> .two blocks -> file
+            "ranks_seen": ranks_seen,
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
@@ -359,6 +413,15 @@ def main():
                 cb = None
             if cb:
                 out["cpu_baseline"] = cb
+        if world == 1 and not args.no_e2e and args.config == "cfg3" and not args.emulate_shard:
+            eng.close()                  # the CLI gets the whole GPU
+            try:
+                e2e = e2e_from_disk(n_samples, args.e2e_variants or n_variants, log)
+            except Exception as e:       # never take the GPU number down with it
+                log(f"e2e failed: {e!r}")
+                e2e = None
+            if e2e:
+                out["e2e"] = e2e
         print(json.dumps(out), flush=True)
     eng.close()
     if world > 1:

@@ -234,6 +234,17 @@ int twk_hip_ld_region(twk_hip_ctx* ctx, int mode, const twk_hip_filters* filters
                       int32_t window, uint32_t l_window,
                       twk_hip_record_sink sink, void* user, uint64_t* n_pairs, uint64_t* n_records);
 
+/* Multi-GPU runs: keep the survivors of twk_hip_ld_all / twk_hip_ld_region on the device.  With on != 0 the
+ * record sink of those calls is not invoked; the survivors of every tile are appended (each tile in (idxA, idxB)
+ * order, tiles in the order they finish) to one device buffer that twk_hip_device_records() returns, so that a
+ * gather over RCCL can send them GPU to GPU and only the writer rank copies them to host memory, once.  This is
+ * the per-worker output block of the reference (twk_ld_engine::blk_f / blk_r, lib/ld/ld_engine.h:321, flushed
+ * into the shared writer at ld_engine.cpp:1270-1281) held in HBM until the gather.  Every call of
+ * twk_hip_set_device_sink (on or off) empties the buffer.  *records is device memory owned by the ctx, valid
+ * until the next compute call or twk_hip_set_device_sink; NULL when *n == 0. */
+int twk_hip_set_device_sink(twk_hip_ctx* ctx, int on);
+int twk_hip_device_records(twk_hip_ctx* ctx, const twk_hip_record** records, uint64_t* n);
+
 /* The row band [row_begin,row_end) that shard `part` of `n_parts` owns in a region of
  * n_rows x n_cols variants (triangle != 0: col > row only, n_rows == n_cols) and the
  * number of pairs in it.  Pure host arithmetic (no device needed): lets a launcher

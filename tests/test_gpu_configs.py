@@ -376,6 +376,26 @@ def test_r2_screen_gives_the_same_records(hip, mode, miss):
     util.assert_records_match(got, want, variants[sub], double_root=util.double_root_vetter(data[sub], None if mask is None else mask[sub], variants[sub], N))
 
 
+@pytest.mark.parametrize("mode", [T.MODE_PHASED, T.MODE_UNPHASED])
+def test_r2_screen_ignores_a_wrong_ac_field(hip, mode):
+    """The screen's bound is about the margins of the counted table, so it must come from the bits on the device: a
+    .twk whose `ac` header field disagrees with its genotypes (here: every variant claims 7 ALT alleles, which would
+    put the common variants' partners outside any band) gives the same records with and without the screen."""
+    N, M = 1200, 1500
+    al = _cohort_alleles(M, N, 77)
+    data, mask, variants = util.upload(hip, al)
+    liar = variants.copy()
+    liar["ac"] = 7
+    hip.set_problem(N, M)
+    hip.upload(data, util.to_hip_meta(liar), mask)
+    order = ["idxA", "idxB"]
+    f = T.Filters(minR2=0.3)
+    plain, _, _ = hip.ld_all(mode, f)
+    scr, _, nrec = hip.ld_all(mode, f, window=T.OPT_R2_SCREEN)
+    assert nrec == len(plain) > 200
+    assert np.sort(plain, order=order).tobytes() == np.sort(scr, order=order).tobytes()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("M", [40, 700, 2300])
 def test_survivors_leave_the_device_in_pair_order(hip, M):
@@ -453,3 +473,52 @@ def test_bench_orchestration_with_two_ranks_on_one_gpu(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     d2 = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert d2["config"]["collective_backend"].startswith("gloo (RCCL failed") and d2["config"]["survivors_per_step"] == d["config"]["survivors_per_step"]
+
+
+def _run_bench(tmp_path, world, extra, tag):
+    """bench.py as the driver launches it (python -m torch.distributed.run for N > 1; gloo so that the ranks can share
+    this box's one GPU) -> (JSON line, records of the .two rank 0 wrote in the last timed step)."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    from tomahawk_amd import hostlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    two = str(tmp_path / f"{tag}_{world}.two")
+    common = ["--gpus", str(world), "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-e2e", "--keep-two", two] + extra
+    if world == 1:
+        cmd = [sys.executable, os.path.join(root, "bench.py")] + common
+    else:
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(root, "bench.py"), "--backend", "gloo"] + common
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    recs, info = hostlib.read_two(two)
+    return json.loads(lines[0]), recs
+
+
+@pytest.mark.parametrize("config,extra", [
+    ("cfg3", ["--samples", "20000", "--variants", "4096", "--min-r2", "0.0002"]),
+    # configs[4]'s slab path: +-500 kb at 100 bp spacing = 5,000 partners per variant, i.e. more than two of the eight
+    # bands of 16,384 variants wide - every rank's halo reaches beyond its neighbour's band
+    ("cfg5", ["--samples", "20000", "--variants", "16384", "--min-r2", "0.0002", "--min-p", "1e-3"]),
+])
+def test_bench_with_eight_ranks_on_one_gpu_equals_one_rank(tmp_path, config, extra):
+    """The N > 1 code of bench.py - equal-area row bands (cfg3) and window-mode slabs with halos (cfg5), survivors kept
+    in HBM (twk_hip_set_device_sink), gathered to rank 0 and packed into one .two - with the world size of the driver's
+    8-GPU run, on this box's one GPU over gloo: the file rank 0 writes holds exactly the records of the 1-rank file.
+    (What this cannot show is RCCL itself: that needs one GPU per rank.)"""
+    args = ["--config", config] + extra
+    d1, one = _run_bench(tmp_path, 1, args, config)
+    d8, eight = _run_bench(tmp_path, 8, args, config)
+    assert d8["n_gpus"] == 8 and d8["ranks_seen"] == list(range(8)) and len(d8["per_rank_ms"]) == 8
+    assert d8["gather_ms"] >= 0 and d8["write_ms"] > 0 and all(x > 0 for x in d8["per_rank_ms"])
+    assert d8["config"]["collective_backend"] == "gloo"
+    assert d1["config"]["survivors_per_step"] == d8["config"]["survivors_per_step"] > 1000
+    assert len(one) == len(eight) == 2 * d1["config"]["survivors_per_step"]
+    order = ["ridA", "packA", "ridB", "packB"]
+    assert np.sort(one, order=order).tobytes() == np.sort(eight, order=order).tobytes()

@@ -114,3 +114,76 @@ def test_gather_records_world3_gloo_and_writer_rank(tmp_path):
     assert seen == fwd | {(b, a) for a, b in fwd}
     state, ent, _ = hostlib.two_index(two_path)
     assert state == 0 and int(ent[:, 2].sum()) == len(recs) and ent[:, 2].max() <= 500
+
+
+@pytest.mark.parametrize("M,wv", [(200_000, 5000), (16_384, 5000), (4096, 300), (700, 5000), (64, 3)])
+@pytest.mark.parametrize("n_parts", [1, 2, 3, 8])
+def test_window_slabs_partition_the_band(M, wv, n_parts):
+    """bench.py's configs[4] partition (tomahawk_amd.dist.window_slab): bands of rows with equal in-window pairs, each
+    rank's slab = its band + the halo its window reaches; together they hold every in-window pair exactly once."""
+    from tomahawk_amd.dist import window_slab, window_total_pairs
+    total = window_total_pairs(M, wv)
+    assert total == sum(min(wv, M - 1 - i) for i in range(M))
+    prev, pairs = 0, []
+    for k in range(n_parts):
+        r0, r1, col_end, n = window_slab(M, wv, k, n_parts)
+        assert r0 == prev and r0 <= r1 <= M and col_end == min(M, r1 + wv)
+        assert n == sum(min(wv, M - 1 - i) for i in range(r0, r1))
+        assert r0 % 64 == 0 or r0 == M
+        prev = r1
+        pairs.append(n)
+    assert prev == M and sum(pairs) == total
+    if M >= 200_000:
+        assert max(pairs) <= 1.02 * total / n_parts
+
+
+def _worker_groups(rank, world, port, q, backend, force_fail):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from tomahawk_amd.dist import gather_records, init_groups
+    group, xdev, desc = init_groups(backend, None, force_rccl_failure=force_fail, timeout_s=60)
+    # the payload as bench.py hands it over: a uint8 tensor of n x 104 bytes (the engine's buffer on the GPU box)
+    n = [3, 0, 7, 1][rank % 4]
+    recs = np.zeros(n, dtype=T.RECORD_DTYPE)
+    recs["idxA"] = rank; recs["idxB"] = 100 + np.arange(n)
+    payload = torch.from_numpy(recs.view(np.uint8).reshape(-1).copy())
+    got = gather_records(payload, dst=0, device=xdev, group=group)
+    raw = gather_records(payload, dst=0, device=xdev, group=group, to_host=False)
+    me = torch.tensor([rank], dtype=torch.int64)
+    seen = [torch.zeros_like(me) for _ in range(world)]
+    dist.all_gather(seen, me, group=group)
+    if rank == 0:
+        assert raw.dtype == torch.uint8 and raw.numel() == len(got) * 104
+        q.put((desc, got["idxA"].tolist(), got["idxB"].tolist(), sorted(int(x) for x in seen)))
+    else:
+        assert got is None and raw is None
+        q.put((rank, desc))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("backend,force_fail", [("gloo", False), ("nccl", True)])
+def test_backend_agreement_and_tensor_payload(backend, force_fail):
+    """init_groups: a gloo control group, and the gather's backend agreed by all ranks.  With RCCL made to fail on
+    every rank (there is no GPU here) every rank ends up on gloo together and says why; the gather takes the uint8
+    tensor payload of the device-resident path."""
+    world = 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_groups, args=(r, world, port, q, backend, force_fail)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    root = next(o for o in outs if len(o) == 4)
+    desc, idxA, idxB, seen = root
+    assert seen == [0, 1, 2, 3]
+    assert idxA == [0] * 3 + [2] * 7 + [3] * 1 and idxB == [100, 101, 102] + list(range(100, 107)) + [100]
+    if force_fail:
+        assert desc.startswith("gloo (RCCL failed to initialise") and "forced" in desc
+    else:
+        assert desc == "gloo"
+    assert all(o[1] == desc for o in outs if len(o) == 2)

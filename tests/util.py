@@ -5,8 +5,39 @@ from oracle import oracle as O
 import tomahawk_amd as T
 from tomahawk_amd.hip import META_DTYPE
 
+import collections as _collections
 import os as _os
 _STATS_PATH = _os.environ.get("TWK_PARITY_STATS", "")     # tests/sweeps: record the observed deviations
+
+# ---- bookkeeping of every exemption assert_records_match grants (reported at session end, tests/conftest.py) -------
+# kinds: "floor:<field>"   a cubic-path record passed <field> only through its absolute floor (CUBIC_FLOOR), not the 1e-6 bar
+#        "p-floor"         Fisher's P compared through the absolute underflow floor (both ~0)
+#        "tie:roots"       root-multiplicity flag (bit 5) differs
+#        "tie:round"       round()ed expected counts differ by one: the device's P is Fisher's P of its own table
+#        "tie:fisher-stop" P differs by exactly the observed table's own probability (n >= 1e6)
+#        "double-root"     pair reported by one side only, proved to sit on a double root of the cubic
+EXEMPTIONS = _collections.Counter()
+COMPARED = _collections.Counter()          # "records", "cubic" (records out of the unphased cubic), "calls"
+# Caps on the session totals, as a fraction of the cubic-path records compared (floors, roots, round, double-root) or of
+# all records compared (p-floor, fisher-stop): about twice the rates of the first full accounting run
+# (profiles/r03_parity_exemptions.json).  A drift beyond them fails the session.
+EXEMPTION_CAPS = {"floor:D": 2e-4, "floor:Dprime": 2e-4, "floor:R": 2e-4, "floor:R2": 2e-4, "floor:ChiSqFisher": 2e-4,
+                  "floor:cnt": 2e-4, "tie:roots": 4e-3, "tie:round": 2e-3, "tie:fisher-stop": 1e-3, "double-root": 1e-4,
+                  "p-floor": 1.0}
+
+
+def exemption_summary():
+    """Session totals + whether every kind stays under its cap -> (dict, list of violations)."""
+    out = {"compared": dict(COMPARED), "exemptions": dict(EXEMPTIONS), "rates": {}, "caps": dict(EXEMPTION_CAPS)}
+    bad = []
+    for kind, cap in EXEMPTION_CAPS.items():
+        denom = COMPARED["records"] if kind in ("p-floor", "tie:fisher-stop") else COMPARED["cubic"]
+        rate = EXEMPTIONS[kind] / denom if denom else 0.0
+        out["rates"][kind] = rate
+        # (sessions that compare a handful of records cannot be held to a rate: allow two of a kind)
+        if EXEMPTIONS[kind] > max(2, cap * denom):
+            bad.append(f"{kind}: {EXEMPTIONS[kind]} of {denom} ({rate:.3g} > cap {cap:g})")
+    return out, bad
 
 
 def random_alleles(M, N, seed, maf_lo=0.05, maf_hi=0.5, miss_rate=0.0, miss_variants=0.0, low_ac=0):
@@ -173,11 +204,14 @@ def assert_records_match(gpu_recs, orc_recs, variants, n_samples=None, rtol=1e-6
     assert len(got) == len(gpu_recs), "duplicate pairs in GPU output"
     missing = set(want) - set(got)
     extra = set(got) - set(want)
+    n_double_root = 0
+    used = _collections.Counter()               # exemptions this call grants
     if double_root is not None and (missing or extra):
         # pairs on a double root of the cubic may be reported by one side only (see double_root_vetter)
         vetted = {k for k in missing | extra if double_root(*k)}
         assert len(vetted) <= max(1, len(want) // 2000), f"too many double-root differences: {sorted(vetted)[:8]}"
         missing -= vetted; extra -= vetted
+        n_double_root = len(vetted)
         for k in vetted:
             want.pop(k, None); got.pop(k, None)
     assert not missing and not extra, f"pair sets differ: missing {sorted(missing)[:5]} extra {sorted(extra)[:5]}"
@@ -208,12 +242,16 @@ def assert_records_match(gpu_recs, orc_recs, variants, n_samples=None, rtol=1e-6
                           ChiSqFisher=CUBIC_FLOOR["ChiSqFisher/total"] * total, ChiSqModel=0.0)
             if not np.allclose(g["cnt"], w["cnt"], rtol=0.0, atol=CUBIC_FLOOR["cnt/total"] * total):
                 bad.append((k, "cnt", g["cnt"].tolist(), w["cnt"].tolist()))
+            elif not np.allclose(g["cnt"], w["cnt"], rtol=rtol, atol=0.0):
+                used["floor:cnt"] += 1
             if (int(g["flags"]) ^ int(w["controller"])) & (1 << 5):
                 # root multiplicity may flip when a second root sits on the admissibility boundary
                 ties.append((k, "roots"))
         for f, atol in floors.items():
             if not np.isclose(g[f], w[f], rtol=rtol, atol=atol):
                 bad.append((k, f, float(g[f]), float(w[f])))
+            elif atol and not np.isclose(g[f], w[f], rtol=rtol, atol=0.0):
+                used["floor:" + f] += 1
         # Fisher P underflows to exactly 0 for strong associations: absolute floor.
         # UnphasedMath runs Fisher on round(expected counts) (ld_engine.cpp:1656).  The expected counts
         # are only as good as the cubic root (above), so when one of them lies within that error of a
@@ -221,6 +259,8 @@ def assert_records_match(gpu_recs, orc_recs, variants, n_samples=None, rtol=1e-6
         # haplotype frequency is 0.2 counts.  Such a record is not skipped: the device's P must then be
         # Fisher's P of the device's *own* rounded table (computed by the oracle), and that table must
         # be the oracle's up to one count per cell.
+        if np.isclose(g["P"], w["P"], rtol=rtol, atol=p_floor) and not np.isclose(g["P"], w["P"], rtol=rtol, atol=0.0):
+            used["p-floor"] += 1
         if not np.isclose(g["P"], w["P"], rtol=rtol, atol=p_floor):
             gt = [int(np.floor(float(x) + 0.5)) for x in g["cnt"]]       # C round(): halves away from zero
             wt = [int(np.floor(float(x) + 0.5)) for x in w["cnt"]]
@@ -251,5 +291,14 @@ def assert_records_match(gpu_recs, orc_recs, variants, n_samples=None, rtol=1e-6
         with open(_STATS_PATH, "a") as fh:
             fh.write(json.dumps(dev) + "\n")
     assert not bad, f"{len(bad)} field mismatches of {len(want)} records, first: {bad[:8]}"
-    roots = [t for t in ties if t[1] == "roots"]
-    assert len(roots) <= max(2, len(want) // 50), f"too many root-multiplicity ties: {len(roots)} of {len(want)}: {roots[:5]}"
+    # every tie kind is argued record by record above AND capped per call, so that a systematic device error (always
+    # rounding halves the other way, never counting the observed table in Fisher's sum) cannot hide behind them
+    for kind, frac in (("roots", 0.02), ("round", 0.02), ("fisher-stop", 0.25)):
+        mine = [t for t in ties if t[1] == kind]
+        used["tie:" + kind] += len(mine)
+        assert len(mine) <= max(2, int(len(want) * frac)), f"too many {kind} ties: {len(mine)} of {len(want)}: {mine[:5]}"
+    used["double-root"] += n_double_root
+    n_cubic = sum(1 for w in want.values() if not (int(w["controller"]) & 1))
+    EXEMPTIONS.update(used)
+    COMPARED.update({"records": len(want), "cubic": n_cubic, "calls": 1})
+    return {"records": len(want), "cubic": n_cubic, **{k: v for k, v in used.items() if v}}

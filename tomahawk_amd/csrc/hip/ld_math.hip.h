@@ -52,41 +52,48 @@ __global__ void k_build_lfact(double* __restrict__ lf, int n) {
 	const int i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i < n) lf[i] = lgamma((double)i + 1.0);
 }
-struct hgacc { int n11, n1_, n_1, n; double p; };
-__device__ inline double d_hypergeo_acc(const LFact& t, int n11, int n1_, int n_1, int n, hgacc* aux) {
-	if (n1_ || n_1 || n) {
-		aux->n11 = n11; aux->n1_ = n1_; aux->n_1 = n_1; aux->n = n;
-	} else {
-		if (n11 % 11 && n11 + aux->n - aux->n1_ - aux->n_1) {
-			if (n11 == aux->n11 + 1) {
-				aux->p *= (double)(aux->n1_ - aux->n11) / n11
-				        * (aux->n_1 - aux->n11) / (n11 + aux->n - aux->n1_ - aux->n_1);
-				aux->n11 = n11;
-				return aux->p;
+// The pmf along one margin-fixed family of 2x2 tables, as kt_fisher_exact walks it (fisher_math.cpp:206-229):
+// the table is fixed by its margins (row1, col1, total) and the walk moves its upper-left cell k one step at a
+// time.  Neighbouring cells are reached by the ratio pmf(k+1)/pmf(k) = (row1-k)(col1-k) / ((k+1)(k+1+total-row1-col1)),
+// but every 11th cell - and the cell where that last factor would vanish - is evaluated from the log-binomials again, so
+// rounding never accumulates over more than ten ratios.  The order of the multiplications and divisions below is the
+// reference's: P then agrees with it to the last bits, including which terms its stopping rule lets in.
+struct TableWalk {
+	int k, row1, col1, total;          // current upper-left cell and the margins
+	double pmf;                        // probability of the current table
+	__device__ inline double reset(const LFact& t, int k0, int r1, int c1, int n) {      // fix the margins, evaluate cell k0 in full
+		k = k0; row1 = r1; col1 = c1; total = n;
+		return pmf = d_hypergeo(t, k, row1, col1, total);
+	}
+	__device__ inline double move_to(const LFact& t, int to) {                            // pmf of cell `to` (same margins)
+		const int slack = total - row1 - col1;                                            // lower-right cell = to + slack
+		if (to % 11 != 0 && to + slack != 0) {
+			if (to == k + 1) {
+				pmf *= (double)(row1 - k) / to * (col1 - k) / (to + slack);
+				k = to;
+				return pmf;
 			}
-			if (n11 == aux->n11 - 1) {
-				aux->p *= (double)aux->n11 / (aux->n1_ - n11)
-				        * (aux->n11 + aux->n - aux->n1_ - aux->n_1) / (aux->n_1 - n11);
-				aux->n11 = n11;
-				return aux->p;
+			if (to == k - 1) {
+				pmf *= (double)k / (row1 - to) * (k + slack) / (col1 - to);
+				k = to;
+				return pmf;
 			}
 		}
-		aux->n11 = n11;
+		k = to;
+		return pmf = d_hypergeo(t, k, row1, col1, total);
 	}
-	aux->p = d_hypergeo(t, aux->n11, aux->n1_, aux->n_1, aux->n);
-	return aux->p;
-}
+};
 // Two-sided P only (left / right tails are not stored in the record).
 __device__ inline double d_fisher_two(const LFact& t, int n11, int n12, int n21, int n22) {
 	int i, j, max, min;
 	double p, q, left, right;
-	hgacc aux;
+	TableWalk w;
 	const int n1_ = n11 + n12, n_1 = n11 + n21, n = n11 + n12 + n21 + n22;
 	max = (n_1 < n1_) ? n_1 : n1_;
 	min = n1_ + n_1 - n;
 	if (min < 0) min = 0;
 	if (min == max) return 1.;
-	q = d_hypergeo_acc(t, n11, n1_, n_1, n, &aux);
+	q = w.reset(t, n11, n1_, n_1, n);
 	// The reference walks both tails from the ends of the support (min, max) inwards until the
 	// terms reach q: up to min(n1_, n_1) steps per record, almost all of them over terms that are
 	// zero or tens of orders of magnitude below q.  Start each walk closer in instead, at a point
@@ -121,13 +128,13 @@ __device__ inline double d_fisher_two(const LFact& t, int n11, int n12, int n21,
 			if (d_lbinom(t, n1_, s) + d_lbinom(t, n - n1_, n_1 - s) - lden <= lq - 40.0) { j0 = s; break; }
 		}
 	}
-	p = d_hypergeo_acc(t, i0, 0, 0, 0, &aux);
+	p = w.move_to(t, i0);
 	for (left = 0., i = i0 + 1; p < 0.99999999 * q && i <= max; ++i)
-		left += p, p = d_hypergeo_acc(t, i, 0, 0, 0, &aux);
+		left += p, p = w.move_to(t, i);
 	if (p < 1.00000001 * q) left += p;
-	p = d_hypergeo_acc(t, j0, 0, 0, 0, &aux);
+	p = w.move_to(t, j0);
 	for (right = 0., j = j0 - 1; p < 0.99999999 * q && j >= 0; --j)
-		right += p, p = d_hypergeo_acc(t, j, 0, 0, 0, &aux);
+		right += p, p = w.move_to(t, j);
 	if (p < 1.00000001 * q) right += p;
 	double two = left + right;
 	if (two > 1.) two = 1.;
@@ -570,10 +577,11 @@ void k_ld_stats(const StatsParams p) {
 // Records with P > minP are dropped (:1228, :1661): marked idxA = 0xFFFFFFFF for the host.
 #define TWK_DROPPED_RECORD 0xFFFFFFFFu
 __global__ __launch_bounds__(256)
-void k_ld_fisher(twk_hip_record* __restrict__ recs, const unsigned long long* __restrict__ n_out,
+void k_ld_fisher(twk_hip_record* __restrict__ recs, unsigned long long* __restrict__ n_out,
                  unsigned long long capacity, double minP, const LFact lfact) {
-	unsigned long long n = *n_out;
+	unsigned long long n = n_out[0];
 	if (n > capacity) n = capacity;
+	uint32_t dropped = 0;
 	for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
 	     i += (unsigned long long)gridDim.x * blockDim.x) {
 		twk_hip_record* r = recs + i;
@@ -581,8 +589,11 @@ void k_ld_fisher(twk_hip_record* __restrict__ recs, const unsigned long long* __
 		if (r->flags & TWK_N11_IN_PAD) { n11 = (int)r->_pad; r->flags &= ~TWK_N11_IN_PAD; r->_pad = 0; }
 		const double both = d_fisher_two(lfact, n11, (int)round(r->cnt[2]), (int)round(r->cnt[1]), (int)round(r->cnt[3]));
 		r->P = both;
-		if (both > minP) r->idxA = TWK_DROPPED_RECORD;
+		if (both > minP) { r->idxA = TWK_DROPPED_RECORD; ++dropped; }
 	}
+	// how many were dropped (n_out[1]): the host cuts them off behind the sort without looking at the records
+	for (int o = 32; o > 0; o >>= 1) dropped += __shfl_xor(dropped, o);
+	if ((threadIdx.x & 63) == 0 && dropped) atomicAdd(n_out + 1, (unsigned long long)dropped);
 }
 
 // Raw cells for parity tests: out[(i*nB + j)*ncell + k] (uint64).

@@ -63,8 +63,8 @@ enum { MODE_INT_AUTO_CLEAN = 0x10,     // phased math on the plain planes; pairs
 struct Slot {                      // one in-flight tile (double buffered)
 	uint32_t* C = nullptr; size_t C_words = 0;
 	twk_hip_record* out = nullptr; unsigned long long capacity = 0;
-	unsigned long long* n_out = nullptr;          // device counter
-	unsigned long long* h_n_out = nullptr;        // pinned host copy
+	unsigned long long* n_out = nullptr;          // device counters: [0] survivors appended, [1] of those dropped by the Fisher cut-off
+	unsigned long long* h_n_out = nullptr;        // pinned host copy of both
 	hipEvent_t ev_c0 = nullptr, ev_c1 = nullptr, ev_s1 = nullptr, ev_c0b = nullptr, ev_c1b = nullptr;
 	bool two_pass = false;
 	double minP = 1.0;
@@ -92,9 +92,13 @@ struct twk_hip_ctx {
 	double* d_hwe = nullptr;
 	double* d_lfact = nullptr; int lfact_n = 0;    // lgamma(i + 1), i <= 2N: Fisher's log-binomials (ld_math.hip.h)
 	std::vector<twk_hip_variant_meta> h_meta;
+	std::vector<uint32_t> h_popc;  // ALT alleles per variant as counted on the device (r2 screen; empty until needed, dropped on upload)
 	PlaneSet planes[N_PLANE_SETS];
 	Slot slot[3];                  // [0],[1]: ld_all pipeline; [2]: synchronous single-tile calls
 	twk_hip_record* h_recs = nullptr; unsigned long long h_recs_cap = 0;   // pinned staging
+	// twk_hip_set_device_sink: the survivors of region calls stay on the device, appended here tile by tile
+	bool device_sink = false;
+	twk_hip_record* d_keep = nullptr; unsigned long long d_keep_n = 0, d_keep_cap = 0;
 	// the survivors of a tile leave in (idxA, idxB) order: sort keys / permutation (double-buffered), the
 	// reordered records, rocprim's scratch (grow-only)
 	unsigned long long* d_sort_keys = nullptr; uint32_t* d_sort_vals = nullptr; twk_hip_record* d_sorted = nullptr;
@@ -126,6 +130,7 @@ namespace {
 	} while (0)
 
 void free_planes(twk_hip_ctx* c) {
+	c->h_popc.clear();
 	for (auto& p : c->planes) {
 		if (p.owns_rows && p.rows) (void)hipFree(p.rows);
 		if (p.rowpop) (void)hipFree(p.rowpop);
@@ -161,6 +166,24 @@ int plane_kind_for(const twk_hip_ctx* c, bool phased) {
 	return c->any_missing ? PK_UNPHASED_MASKED : PK_UNPHASED;
 }
 
+// The r2 screen's bound is a statement about the margins of the table the kernels count, so it takes the
+// allele counts from the bits on the device, not from the `ac` field of the file (a .twk whose header
+// disagrees with its genotypes must not lose records to the screen).
+int ensure_popcounts(twk_hip_ctx* c) {
+	if (c->h_popc.size() == c->M) return TWK_HIP_OK;
+	uint32_t* d = nullptr;
+	HIPCHK(c, hipMalloc((void**)&d, (size_t)c->M * 4));
+	hipLaunchKernelGGL(k_row_popcount, dim3((c->M + 3) / 4), dim3(256), 0, c->s_compute, c->raw, c->Wp, c->M, d);
+	hipError_t e = hipGetLastError();
+	c->h_popc.assign(c->M, 0);
+	if (e == hipSuccess) e = hipMemcpyAsync(c->h_popc.data(), d, (size_t)c->M * 4, hipMemcpyDeviceToHost, c->s_compute);
+	if (e == hipSuccess) e = hipStreamSynchronize(c->s_compute);
+	(void)hipFree(d);
+	if (e != hipSuccess) c->h_popc.clear();
+	HIPCHK(c, e);
+	return TWK_HIP_OK;
+}
+
 int ensure_planes(twk_hip_ctx* c, int set) {
 	PlaneSet& ps = c->planes[set];
 	if (ps.built) return TWK_HIP_OK;
@@ -175,12 +198,13 @@ int ensure_planes(twk_hip_ctx* c, int set) {
 	if (sorted) {
 		// order: minor allele count ascending (ties in file order), variants with missing genotypes last (file order)
 		const uint64_t T2 = 2ull * c->N;
+		{ const int rc = ensure_popcounts(c); if (rc) return rc; }
 		ps.h_ids.resize(c->M);
 		for (uint32_t v = 0; v < c->M; ++v) ps.h_ids[v] = v;
 		auto key = [&](uint32_t v) -> uint64_t {
 			const twk_hip_variant_meta& m = c->h_meta[v];
 			if (m.missing || m.an) return ~0ull;
-			const uint64_t ac = std::min<uint64_t>(m.ac, T2);
+			const uint64_t ac = std::min<uint64_t>(c->h_popc[v], T2);
 			return std::min(ac, T2 - ac);
 		};
 		std::stable_sort(ps.h_ids.begin(), ps.h_ids.end(), [&](uint32_t a, uint32_t b) { return key(a) < key(b); });
@@ -408,7 +432,7 @@ int enqueue_tile(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, const twk
 	rc = ensure_slot(c, s, (size_t)g.rowsA * g.rowsB, capacity); if (rc) return rc;
 	s.two_pass = two_pass;
 
-	HIPCHK(c, hipMemsetAsync(s.n_out, 0, sizeof(unsigned long long), c->s_compute));
+	HIPCHK(c, hipMemsetAsync(s.n_out, 0, 2 * sizeof(unsigned long long), c->s_compute));
 	rc = launch_count(c, kind1, t, s, 0, s.ev_c0, s.ev_c1, &s.row_pairs, cr); if (rc) return rc;
 	{
 		const StatsParams p = make_stats(c, kind1, t, s, phased, pl.select1, f, cr);
@@ -424,7 +448,7 @@ int enqueue_tile(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, const twk
 	hipLaunchKernelGGL(k_ld_fisher, dim3(c->resident_blocks * 2), dim3(256), 0, c->s_compute, s.out, s.n_out, s.capacity, f.minP, LFact{c->d_lfact, c->lfact_n});
 	HIPCHK(c, hipGetLastError());
 	s.minP = f.minP;
-	HIPCHK(c, hipMemcpyAsync(s.h_n_out, s.n_out, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->s_compute));
+	HIPCHK(c, hipMemcpyAsync(s.h_n_out, s.n_out, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->s_compute));
 	HIPCHK(c, hipEventRecord(s.ev_s1, c->s_compute));
 	return TWK_HIP_OK;
 }
@@ -451,7 +475,7 @@ __global__ void k_gather_records(const twk_hip_record* __restrict__ recs, const 
 static_assert(sizeof(twk_hip_record) % 8 == 0, "record gather copies 8-byte words");
 
 // recs[0..n) on the device -> c->d_sorted in (idxA, idxB) order, on stream st.
-int sort_records(twk_hip_ctx* c, const twk_hip_record* recs, unsigned long long n, hipStream_t st) {
+int sort_records(twk_hip_ctx* c, const twk_hip_record* recs, unsigned long long n, bool any_dropped, hipStream_t st) {
 	if (n > 0xFFFFFFFFull) return TWK_HIP_E_INVALID;
 	if (c->sort_cap < n) {
 		if (c->d_sort_keys) (void)hipFree(c->d_sort_keys);
@@ -467,8 +491,9 @@ int sort_records(twk_hip_ctx* c, const twk_hip_record* recs, unsigned long long 
 	unsigned long long* keys_in = c->d_sort_keys; unsigned long long* keys_out = c->d_sort_keys + c->sort_cap;
 	uint32_t* vals_in = c->d_sort_vals; uint32_t* vals_out = c->d_sort_vals + c->sort_cap;
 	uint32_t bits_b = 1; while (bits_b < 32 && (1ull << bits_b) < c->M) ++bits_b;
-	// dropped records carry the all-ones key: sort every bit when there can be any, else only the bits in use
-	const unsigned end_bit = 64;
+	// dropped records (Fisher cut-off) carry the all-ones key: sort every bit when there can be any, else only the
+	// 2 * bits_b bits a (idxA, idxB) key uses
+	const unsigned end_bit = any_dropped ? 64u : 2u * bits_b;
 	size_t tmp = 0;
 	HIPCHK(c, rocprim::radix_sort_pairs(nullptr, tmp, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u, end_bit, st));
 	if (!c->d_sort_tmp || tmp > c->sort_tmp_bytes) {          // (a null scratch pointer would turn the sort into another size query)
@@ -488,8 +513,26 @@ int sort_records(twk_hip_ctx* c, const twk_hip_record* recs, unsigned long long 
 	return TWK_HIP_OK;
 }
 
-// Wait for slot s, account timing, fetch its records into the pinned staging buffer.
-int finish_tile(twk_hip_ctx* c, Slot& s, const twk_hip_tile_desc& t, unsigned long long* n_out) {
+// Room for n more records behind the ones the device sink holds (grow-only, contents kept).
+int ensure_device_keep(twk_hip_ctx* c, unsigned long long n_more) {
+	const unsigned long long need = c->d_keep_n + n_more;
+	if (need <= c->d_keep_cap) return TWK_HIP_OK;
+	const unsigned long long cap = std::max<unsigned long long>(need + need / 2, 1ull << 16);
+	twk_hip_record* p = nullptr;
+	HIPCHK(c, hipMalloc((void**)&p, (size_t)cap * sizeof(twk_hip_record)));
+	if (c->d_keep_n) {
+		const hipError_t e = hipMemcpyAsync(p, c->d_keep, (size_t)c->d_keep_n * sizeof(twk_hip_record), hipMemcpyDeviceToDevice, c->s_copy);
+		if (e != hipSuccess) { (void)hipFree(p); HIPCHK(c, e); }
+		HIPCHK(c, hipStreamSynchronize(c->s_copy));
+	}
+	if (c->d_keep) (void)hipFree(c->d_keep);
+	c->d_keep = p; c->d_keep_cap = cap;
+	return TWK_HIP_OK;
+}
+
+// Wait for slot s, account timing, put its records in (idxA, idxB) order and fetch them into the pinned staging
+// buffer (to_host) or append them to the device sink.
+int finish_tile(twk_hip_ctx* c, Slot& s, const twk_hip_tile_desc& t, unsigned long long* n_out, bool to_host = true) {
 	HIPCHK(c, hipEventSynchronize(s.ev_s1));
 	float ms = 0;
 	HIPCHK(c, hipEventElapsedTime(&ms, s.ev_c0, s.ev_c1));
@@ -512,25 +555,29 @@ int finish_tile(twk_hip_ctx* c, Slot& s, const twk_hip_tile_desc& t, unsigned lo
 	*n_out = n;
 	if (n > s.capacity) return TWK_HIP_E_OVERFLOW;
 	if (n) {
-		int rc = ensure_host_records(c, n); if (rc) return rc;
-		rc = sort_records(c, s.out, n, c->s_copy); if (rc) return rc;
-		HIPCHK(c, hipMemcpyAsync(c->h_recs, c->d_sorted, (size_t)n * sizeof(twk_hip_record), hipMemcpyDeviceToHost, c->s_copy));
-		HIPCHK(c, hipStreamSynchronize(c->s_copy));
-		if (s.minP < 1.0) {        // records that failed the Fisher cutoff were only marked on the device: they are the tail now
-			unsigned long long lo = 0, hi = n;
-			while (lo < hi) { const unsigned long long mid = (lo + hi) / 2; if (c->h_recs[mid].idxA == TWK_DROPPED_RECORD) hi = mid; else lo = mid + 1; }
-			*n_out = lo;
+		// records that failed the Fisher cut-off were only marked on the device (and counted): they sort behind the rest
+		const unsigned long long dropped = std::min(s.h_n_out[1], n), kept = n - dropped;
+		int rc = sort_records(c, s.out, n, dropped != 0, c->s_copy); if (rc) return rc;
+		if (to_host) {
+			rc = ensure_host_records(c, kept); if (rc) return rc;
+			if (kept) HIPCHK(c, hipMemcpyAsync(c->h_recs, c->d_sorted, (size_t)kept * sizeof(twk_hip_record), hipMemcpyDeviceToHost, c->s_copy));
+		} else {
+			rc = ensure_device_keep(c, kept); if (rc) return rc;
+			if (kept) HIPCHK(c, hipMemcpyAsync(c->d_keep + c->d_keep_n, c->d_sorted, (size_t)kept * sizeof(twk_hip_record), hipMemcpyDeviceToDevice, c->s_copy));
+			c->d_keep_n += kept;
 		}
+		HIPCHK(c, hipStreamSynchronize(c->s_copy));
+		*n_out = kept;
 	}
 	return TWK_HIP_OK;
 }
 
 // One tile, synchronously, on the spare slot; survivors end up in c->h_recs.
 int run_tile_sync(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, const twk_hip_filters& f,
-                  unsigned long long capacity, unsigned long long* n_out) {
+                  unsigned long long capacity, unsigned long long* n_out, bool to_host = true) {
 	Slot& s = c->slot[2];
 	int rc = enqueue_tile(c, mode, t, f, s, capacity); if (rc) return rc;
-	return finish_tile(c, s, t, n_out);
+	return finish_tile(c, s, t, n_out, to_host);
 }
 
 // A tile whose survivors overflowed the device buffer: redo it in row strips
@@ -555,9 +602,9 @@ int redo_tile_in_strips(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, co
 		}
 		for (int k = 0; k < np; ++k) {
 			unsigned long long n = 0;
-			int rc = run_tile_sync(c, mode, parts[k], f, (unsigned long long)parts[k].nA * parts[k].nB, &n);
+			int rc = run_tile_sync(c, mode, parts[k], f, (unsigned long long)parts[k].nA * parts[k].nB, &n, !c->device_sink);
 			if (rc) return rc;
-			if (sink && n && sink(user, c->h_recs, n)) return TWK_HIP_E_INVALID;
+			if (!c->device_sink && sink && n && sink(user, c->h_recs, n)) return TWK_HIP_E_INVALID;
 			*n_recs += n;
 		}
 	}
@@ -657,8 +704,8 @@ int twk_hip_ctx_create(int device, twk_hip_ctx** out) {
 	for (auto& s : c->slot) {
 		hipEvent_t* evs[] = {&s.ev_c0, &s.ev_c1, &s.ev_s1, &s.ev_c0b, &s.ev_c1b};
 		for (auto* e : evs) if (hipEventCreate(e) != hipSuccess) return fail(TWK_HIP_E_DEVICE);
-		if (hipMalloc((void**)&s.n_out, sizeof(unsigned long long)) != hipSuccess) return fail(TWK_HIP_E_NOMEM);
-		if (hipHostMalloc((void**)&s.h_n_out, sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) return fail(TWK_HIP_E_NOMEM);
+		if (hipMalloc((void**)&s.n_out, 2 * sizeof(unsigned long long)) != hipSuccess) return fail(TWK_HIP_E_NOMEM);
+		if (hipHostMalloc((void**)&s.h_n_out, 2 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) return fail(TWK_HIP_E_NOMEM);
 	}
 	*out = c;
 	return TWK_HIP_OK;
@@ -676,6 +723,7 @@ int twk_hip_ctx_destroy(twk_hip_ctx* c) {
 		if (s.h_n_out) (void)hipHostFree(s.h_n_out);
 	}
 	if (c->h_recs) (void)hipHostFree(c->h_recs);
+	if (c->d_keep) (void)hipFree(c->d_keep);
 	if (c->d_sort_keys) (void)hipFree(c->d_sort_keys);
 	if (c->d_sort_vals) (void)hipFree(c->d_sort_vals);
 	if (c->d_sorted) (void)hipFree(c->d_sorted);
@@ -1010,9 +1058,9 @@ static int region_impl(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint3
 		// reference's formula; pairs inside the band still go through that formula, so the survivors are the same.
 		lo.resize(nA); hi.resize(nA); cum.assign((size_t)nA + 1, 0);
 		const long double T2 = 2.0L * c->N, cut = (long double)f->minR2 * (1.0L - 1e-6L);
-		auto mac = [&](uint32_t i) -> long double {
-			const twk_hip_variant_meta& m = meta_at(i);
-			const long double ac = std::min<long double>(m.ac, T2);
+		{ const int rc = ensure_popcounts(c); if (rc) return rc; }
+		auto mac = [&](uint32_t i) -> long double {      // minor allele count as the device counts it (see ensure_popcounts)
+			const long double ac = std::min<long double>(c->h_popc[ids ? ids[i] : i], T2);
 			return std::min(ac, T2 - ac);
 		};
 		auto reach = [&](long double ma, long double mb) -> bool {        // can a pair with these minor counts (ma <= mb) pass?
@@ -1198,7 +1246,7 @@ static int region_impl(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint3
 		}
 		Slot& s = c->slot[done & 1];
 		unsigned long long nrec = 0;
-		rc = finish_tile(c, s, mine[done], &nrec);
+		rc = finish_tile(c, s, mine[done], &nrec, !c->device_sink);
 		if (rc == TWK_HIP_E_OVERFLOW) {
 			uint64_t nr = 0;
 			rc = redo_tile_in_strips(c, mode, mine[done], *f, s.capacity, sink, user, &nr);
@@ -1207,7 +1255,7 @@ static int region_impl(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint3
 		} else if (rc) {
 			return rc;
 		} else {
-			if (sink && nrec) { if (sink(user, c->h_recs, nrec)) return TWK_HIP_E_INVALID; }
+			if (!c->device_sink && sink && nrec) { if (sink(user, c->h_recs, nrec)) return TWK_HIP_E_INVALID; }
 			tot_recs += nrec;
 		}
 		tot_pairs += pairs_in_tile(c, mine[done]);
@@ -1284,6 +1332,23 @@ int twk_hip_shard_rows(uint32_t n_rows, uint32_t n_cols, int32_t triangle, uint3
 	if (row_begin) *row_begin = r0;
 	if (row_end) *row_end = r1;
 	if (n_pairs) *n_pairs = band_pairs_before(r1, n_rows, n_cols, triangle != 0) - band_pairs_before(r0, n_rows, n_cols, triangle != 0);
+	return TWK_HIP_OK;
+}
+
+int twk_hip_set_device_sink(twk_hip_ctx* c, int on) {
+	if (!c) return TWK_HIP_E_INVALID;
+	c->device_sink = on != 0;
+	c->d_keep_n = 0;
+	return TWK_HIP_OK;
+}
+
+int twk_hip_device_records(twk_hip_ctx* c, const twk_hip_record** records, uint64_t* n) {
+	if (!c || !records || !n) return TWK_HIP_E_INVALID;
+	if (!c->device_sink) return TWK_HIP_E_STATE;
+	HIPCHK(c, hipSetDevice(c->device));
+	HIPCHK(c, hipStreamSynchronize(c->s_copy));
+	*records = c->d_keep_n ? c->d_keep : nullptr;
+	*n = c->d_keep_n;
 	return TWK_HIP_OK;
 }
 

@@ -154,8 +154,16 @@ private:
 			b = e + 1;
 		}
 		dict_str_.push_back("PASS");
-		auto place = [](std::vector<std::string>& d, const std::string& id, const std::string& idx) {
-			if (!idx.empty()) { const size_t k = (size_t)std::atoll(idx.c_str()); if (d.size() <= k) d.resize(k + 1); d[k] = id; return; }
+		// an IDX= sizes the dictionary: bounded (1 << 24 entries is far beyond any real header), or a hostile
+		// header asks for gigabytes
+		bool idx_ok = true;
+		auto place = [&idx_ok](std::vector<std::string>& d, const std::string& id, const std::string& idx) {
+			if (!idx.empty()) {
+				const long long k = std::atoll(idx.c_str());
+				if (k < 0 || k > (1ll << 24)) { idx_ok = false; return; }
+				if (d.size() <= (size_t)k) d.resize((size_t)k + 1);
+				d[(size_t)k] = id; return;
+			}
 			if (std::find(d.begin(), d.end(), id) == d.end()) d.push_back(id);
 		};
 		for (const auto& l : hdr_lines_) {
@@ -166,6 +174,7 @@ private:
 				place(dict_str_, id, field_of(l, "IDX"));
 			}
 		}
+		if (!idx_ok) { std::cerr << "BCF header: IDX= outside [0, " << (1 << 24) << "]" << std::endl; bad_ = true; return false; }
 		return true;
 	}
 	// typed values (BCF2 spec 6.3): descriptor byte = length << 4 | type, length 15 = a typed integer follows

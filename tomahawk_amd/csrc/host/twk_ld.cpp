@@ -384,7 +384,7 @@ static bool load_blocks(const std::string& path, const TwkReader& reader, const 
 			uint8_t head[9];
 			if (!pread_all(fd, head, 9, e.foff)) return false;
 			uint32_t unc, cmp; std::memcpy(&unc, head + 1, 4); std::memcpy(&cmp, head + 5, 4);
-			if (head[0] != 1 || unc != e.b_unc || cmp > ((size_t)1 << 31)) return false;
+			if (head[0] != 1 || unc != e.b_unc || cmp != e.b_cmp) return false;      // the header must agree with the index (sizes the buffers)
 			z.resize(cmp);
 			if (!pread_all(fd, z.data(), cmp, e.foff + 9)) return false;
 			if (!zstd_decompress_into(z.data(), cmp, buf + b.boff[k - b.k0], unc)) return false;
@@ -562,8 +562,9 @@ bool twk_ld::twk_ld_impl::run(twk_ld_settings& settings, const Header& hdr, cons
 
 	// one driver thread per GPU: region calls for its shard, survivors into its own emitter
 	struct Driver {
-		twk_ld_impl* self; RecordEmitter emitter; bool write_failed = false; uint64_t pairs = 0; int rc = TWK_HIP_OK;
-		std::vector<twk_hip_record> kept;
+		twk_ld_impl* self;
+		std::vector<twk_hip_record> kept;      // declared before the emitter: its workers read it until they are joined
+		RecordEmitter emitter; bool write_failed = false; uint64_t pairs = 0; int rc = TWK_HIP_OK;
 		uint32_t shift = 0;
 		Driver(twk_ld_impl* s, int workers) : self(s), emitter(s->out, workers) {}
 		static int sink(void* user, const twk_hip_record* recs, uint64_t n) {

@@ -108,7 +108,7 @@ public:
 			for (size_t b = 0; b < n_closed; ++b) {
 				const uint64_t seq = next_seq_;
 				cv_room_.wait(lk, [&] { return failed_.load() || seq < written_ + window_; });
-				if (failed_.load()) return false;
+				if (failed_.load()) break;
 				Slot& s = slots_[seq % window_];
 				const uint64_t lo = cut[b], hi = cut[b + 1];
 				// the block's records: [lo, hi) of carry ++ recs
@@ -119,7 +119,9 @@ public:
 				++next_seq_; ++expanding_;
 				cv_job_.notify_one();
 			}
-			cv_expanded_.wait(lk, [&] { return failed_.load() || expanding_ == 0; });
+			// also on failure (disk full, a block that would not pack): the workers still hold pointers into the
+			// producer's buffer until every queued block of this call is expanded - they count down whatever happened
+			cv_expanded_.wait(lk, [&] { return expanding_ == 0; });
 			if (failed_.load()) return false;
 		}
 		std::vector<twk_hip_record> next;

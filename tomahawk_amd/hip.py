@@ -112,6 +112,8 @@ def load_library() -> C.CDLL:
                                       C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.twk_hip_shard_rows.argtypes = [C.c_uint32, C.c_uint32, C.c_int32, C.c_uint32, C.c_uint32,
                                        C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
+    lib.twk_hip_set_device_sink.argtypes = [p, C.c_int]
+    lib.twk_hip_device_records.argtypes = [p, C.POINTER(p), C.POINTER(C.c_uint64)]
     lib.twk_hip_timing_reset.argtypes = [p]
     lib.twk_hip_timing_get.argtypes = [p, C.POINTER(_Timing)]
     _lib = lib
@@ -294,6 +296,30 @@ class HipLd:
                                                 C.byref(npairs), C.byref(nrec)), "twk_hip_ld_region")
         recs = np.concatenate(chunks) if chunks else np.zeros(0, dtype=RECORD_DTYPE)
         return recs, npairs.value, nrec.value
+
+    # ---- multi-GPU: survivors stay in HBM until the gather ----
+    def set_device_sink(self, on: bool = True):
+        """Region / all-vs-all calls keep their survivors on the device (twk_hip_set_device_sink); empties the buffer."""
+        self._check(self._lib.twk_hip_set_device_sink(self._ctx, int(bool(on))), "twk_hip_set_device_sink")
+
+    def device_records(self):
+        """-> (device pointer, n records) of what the device sink holds (twk_hip_device_records)."""
+        ptr, n = C.c_void_p(), C.c_uint64(0)
+        self._check(self._lib.twk_hip_device_records(self._ctx, C.byref(ptr), C.byref(n)), "twk_hip_device_records")
+        return (ptr.value or 0), n.value
+
+    def device_records_tensor(self):
+        """The device sink's records as a torch uint8 tensor [n * 104] that aliases the engine's HBM buffer (no copy):
+        what tomahawk_amd.dist.gather_records sends over RCCL.  Valid until the next compute call."""
+        import torch
+        ptr, n = self.device_records()
+        dev = torch.device("cuda", torch.cuda.current_device())
+        if n == 0:
+            return torch.empty(0, dtype=torch.uint8, device=dev)
+
+        class _Span:          # the CUDA array interface is how torch wraps foreign device memory without owning it
+            __cuda_array_interface__ = {"shape": (n * RECORD_DTYPE.itemsize,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+        return torch.as_tensor(_Span(), device=dev)
 
     # ---- measurement ----
     def timing_reset(self):
