@@ -264,6 +264,9 @@ typedef struct {
 	uint64_t row_pairs;     /* plane-row pairs contracted by the count kernel    */
 	uint64_t variant_pairs; /* variant pairs evaluated by the math kernel        */
 	uint64_t words_per_row; /* 32-bit words contracted per row pair (unpadded)   */
+	uint64_t fused_launches;/* count launches that ran the fused count -> r2 screen form (short rows,
+	                           phased math: no count matrix, candidates only)    */
+	uint64_t candidates;    /* pairs those launches handed to the math kernel    */
 } twk_hip_timing;
 /* Progress of twk_hip_ld_all / twk_hip_ld_region: `cb` runs on the calling thread after every tile
  * with the variant pairs finished so far in the current call and the tile counts.  Replaces the

@@ -92,6 +92,39 @@ PY
 		f=$(find /tmp/prof_math -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/kg_kernel_stats.csv && head -8 "$f" | cut -c1-160
 		grep "Finished\|HIP\]\|WRITER\]" $OUT/kg_under_rocprof.log | cut -c1-300
 		;;
+	kg_prof)  # the small-N regime (the reference's published shape, 2,504 samples x 200,000 cohort-shaped variants): kernel traces of
+		# `calc -p -w 1000000` (33 M surviving pairs) and of all-vs-all `-r 0.8` without the allele-count band, each with the
+		# fused count -> r2 screen kernel (default) and without it (TWK_HIP_FUSED=0)
+		python3 - <<PY
+import sys, os
+sys.path.insert(0, "$R")
+from tomahawk_amd import hostlib as H
+if not os.path.exists("/tmp/kg_2504_200k.twk"):
+    H.write_cohort_twk("/tmp/kg_2504_200k.twk", 2504, 200_000, seed=12, n_threads=64, block_size=500, spacing=100)
+PY
+		$R/tomahawk_amd/bin/tomahawk calc -i /tmp/kg_2504_200k.twk -o /tmp/o.two -t 64 -r 0.8 > /dev/null 2>&1     # warm the page cache
+		for fused in 1 0; do
+			for run in w1m all; do
+				if [ $run = w1m ]; then args="-p -w 1000000"; export TWK_HIP_NO_SCREEN=0; else args="-r 0.8"; export TWK_HIP_NO_SCREEN=1; fi
+				[ $TWK_HIP_NO_SCREEN = 0 ] && unset TWK_HIP_NO_SCREEN
+				name=kg_${run}_fused$fused
+				rm -rf /tmp/prof_$name
+				TWK_HIP_FUSED=$fused timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -o m -- \
+					$R/tomahawk_amd/bin/tomahawk calc -i /tmp/kg_2504_200k.twk -o /tmp/o.two -t 64 $args > /dev/null 2> $OUT/${name}_under_rocprof.log
+				f=$(find /tmp/prof_$name -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/${name}_kernel_stats.csv
+				echo "== $name"; grep "Finished\|HIP\]" $OUT/${name}_under_rocprof.log | cut -c1-330
+				python3 - <<PY
+import csv
+rows = list(csv.DictReader(open("$OUT/${name}_kernel_stats.csv")))
+tot = sum(float(r["TotalDurationNs"]) for r in rows)
+for r in rows[:7]:
+    print("   %-60s calls %5s  total %9.3f ms  avg %9.3f us" % (r["Name"][:60], r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3))
+print("   all kernels: %.3f ms" % (tot / 1e6))
+PY
+			done
+		done
+		unset TWK_HIP_NO_SCREEN
+		;;
 	shards)  timeout 1200 python3 $R/tests/sweeps/shard_timings.py > $OUT/shard_timings.txt 2>&1; tail -20 $OUT/shard_timings.txt ;;
 	*) echo "unknown stage $stage" ;;
 	esac

@@ -1,0 +1,135 @@
+"""The fused count -> r2 screen -> candidate list form of the count kernel (k_count_screen_t + k_ld_stats_list,
+ld_count.hip.h / ld_math.hip.h): for short rows (<= 16 K-chunks: N <= 8192 phased) the block that counted a tile screens
+it in registers and only candidate pairs reach the math kernel - no count matrix in HBM, no one-thread-per-pair math
+front end.  Reference shape: the per-pair loop count -> math of lib/ld/ld_engine.cpp:1898-2015 with PhasedMath
+(:1162-1310).  The records must be those of the plain path, bit for bit, and those of the oracle."""
+import numpy as np
+import pytest
+
+import tomahawk_amd as T
+from oracle import oracle as O
+from tests import util
+from tests.test_gpu_configs import _cohort_alleles
+
+pytestmark = pytest.mark.gpu
+ORDER = ["idxA", "idxB"]
+
+
+def _both(hip, monkeypatch, call):
+    """Run `call` with the fused form off and on -> (plain records, fused records, fused launches, candidates)."""
+    monkeypatch.setenv("TWK_HIP_FUSED", "0")
+    hip.timing_reset()
+    plain = call()
+    assert hip.timing()["fused_launches"] == 0
+    monkeypatch.setenv("TWK_HIP_FUSED", "1")
+    hip.timing_reset()
+    fused = call()
+    tm = hip.timing()
+    monkeypatch.delenv("TWK_HIP_FUSED")
+    return plain, fused, tm["fused_launches"], tm["candidates"]
+
+
+@pytest.mark.parametrize("N", [64, 1000, 2504, 8192])
+def test_fused_equals_plain_and_oracle(hip, monkeypatch, N):
+    """Every phased-math route that qualifies: -p, default mode without missing data, with and without the allele-count
+    band (r2 screen), a window, shards, several cut-offs incl. one placed on existing r2 values."""
+    M = 1700 if N <= 2504 else 700
+    al = _cohort_alleles(M, N, 500 + N)
+    data, mask, variants = util.upload(hip, al)
+    n_fused = 0
+    for mode in (T.MODE_PHASED, T.MODE_AUTO):
+        for minR2 in (0.1, 0.6, 0.004):
+            for opt in (0, T.OPT_R2_SCREEN):
+                f = T.Filters(minR2=minR2)
+                (p, np0, _), (q, np1, nr1), nf, ncand = _both(hip, monkeypatch, lambda: hip.ld_all(mode, f, window=opt))
+                assert nf > 0 and np0 == np1 == M * (M - 1) // 2 and nr1 == len(q) == len(p) > 20
+                assert ncand >= len(q)                          # every survivor was a candidate
+                assert ncand < 0.5 * np1 or minR2 < 0.01         # and the screen did screen
+                assert np.sort(p, order=ORDER).tobytes() == np.sort(q, order=ORDER).tobytes()
+                n_fused += nf
+    # cut-offs on, just below and just above r2 values that exist
+    f0 = T.Filters(minR2=0.05)
+    base, _, _ = hip.ld_all(T.MODE_PHASED, f0)
+    r2 = np.unique(base["R2"]); r2 = r2[r2 < 1]
+    for x in r2[:: max(1, len(r2) // 5)][:5]:
+        for cut in (np.nextafter(x, 0.0), x, np.nextafter(x, 1.0)):
+            f = T.Filters(minR2=float(cut))
+            (p, _, _), (q, _, _), nf, _ = _both(hip, monkeypatch, lambda: hip.ld_all(T.MODE_PHASED, f))
+            assert nf > 0 and np.sort(p, order=ORDER).tobytes() == np.sort(q, order=ORDER).tobytes()
+    # window mode (positions 100 bp apart) and shards of it
+    f = T.Filters(minR2=0.1)
+    (p, np0, _), (q, np1, _), nf, _ = _both(hip, monkeypatch, lambda: hip.ld_all(T.MODE_PHASED, f, window=T.OPT_WINDOW, l_window=30_000))
+    assert nf > 0 and np0 == np1 and len(p) > 20 and np.sort(p, order=ORDER).tobytes() == np.sort(q, order=ORDER).tobytes()
+    parts = [hip.ld_all(T.MODE_PHASED, f, part=k, n_parts=3) for k in range(3)]
+    whole, _, _ = hip.ld_all(T.MODE_PHASED, f)
+    assert np.sort(np.concatenate([x[0] for x in parts]), order=ORDER).tobytes() == np.sort(whole, order=ORDER).tobytes()
+    # small super-tiles: diagonal + rectangle launches, two-deep pipeline
+    (p, _, _), (q, _, _), nf, _ = _both(hip, monkeypatch, lambda: hip.ld_all(T.MODE_PHASED, f, tile_variants=256))
+    assert nf > 3 and np.sort(p, order=ORDER).tobytes() == np.sort(q, order=ORDER).tobytes()
+    # and the oracle agrees (sampled: it is scalar)
+    sub = np.sort(np.random.default_rng(N).choice(M, size=240, replace=False))
+    hip.set_problem(N, len(sub))
+    hip.upload(data[sub], util.to_hip_meta(variants[sub]), None)
+    want = O.all_pairs(data[sub], None, variants[sub], N, O.settings(minR2=0.1, phased=True), vector_only=False)
+    hip.timing_reset()
+    got, _, _ = hip.ld_all(T.MODE_PHASED, T.Filters(minR2=0.1))
+    assert hip.timing()["fused_launches"] > 0 and len(want) > 20
+    util.assert_records_match(got, want, variants[sub])
+
+
+def test_fused_first_pass_of_default_mode_with_missing_data(hip, monkeypatch):
+    """Default mode with missing genotypes: the plain phased planes decide the pairs without missing data (fused), the
+    masked unphased planes the rest (through C as before); single tiles run both passes into one survivor buffer."""
+    N, M = 1500, 1300
+    al = _cohort_alleles(M, N, 41, miss=True)
+    data, mask, variants = util.upload(hip, al)
+    f = T.Filters(minR2=0.2)
+    for call in (lambda: hip.ld_all(T.MODE_AUTO, f), lambda: hip.ld_all(T.MODE_AUTO, f, window=T.OPT_R2_SCREEN),
+                 lambda: hip.ld_tile(T.MODE_AUTO, 0, M, 0, M, True, f) + (0,),
+                 lambda: hip.ld_tile(T.MODE_AUTO, 130, 300, 600, 513, False, f) + (0,)):
+        p, q, nf, _ = _both(hip, monkeypatch, call)
+        assert nf > 0 and len(p[0]) > 20
+        assert np.sort(p[0], order=ORDER).tobytes() == np.sort(q[0], order=ORDER).tobytes()
+    sub = np.sort(np.random.default_rng(3).choice(M, size=230, replace=False))
+    hip.set_problem(N, len(sub))
+    hip.upload(data[sub], util.to_hip_meta(variants[sub]), mask[sub])
+    want = O.all_pairs(data[sub], mask[sub], variants[sub], N, O.settings(minR2=0.2), vector_only=False)
+    got, _, _ = hip.ld_all(T.MODE_AUTO, f)
+    util.assert_records_match(got, want, variants[sub], double_root=util.double_root_vetter(data[sub], mask[sub], variants[sub], N))
+
+
+def test_fused_candidate_overflow_falls_back_to_the_plain_path(hip, monkeypatch):
+    """The candidate list lives in the slot's count-matrix buffer (a third of the pairs fit).  Haplotype-block data
+    with a cut-off just above the screen's floor puts most pairs on it: the tile is redone through C, the rest of the
+    call runs plain, the records are the same."""
+    N, M = 300, 900
+    al = util.mosaic_alleles(M, N, 5, n_founders=3, switch=0.002, mut=0.0005)
+    util.upload(hip, al)
+    f = T.Filters(minR2=2e-6)
+    for tile in (0, 256):
+        (p, _, _), (q, _, nr), nf, ncand = _both(hip, monkeypatch, lambda: hip.ld_all(T.MODE_PHASED, f, tile_variants=tile))
+        assert nf >= 1 and ncand > M * (M - 1) // 2 // 3 or tile      # the first fused tile overflowed ...
+        assert len(p) == nr > 0.6 * M * (M - 1) // 2                   # ... (most pairs survive this cut-off)
+        assert np.sort(p, order=ORDER).tobytes() == np.sort(q, order=ORDER).tobytes()
+    # the next call starts fused again
+    hip.timing_reset()
+    hip.ld_all(T.MODE_PHASED, T.Filters(minR2=0.5))
+    assert hip.timing()["fused_launches"] > 0
+
+
+def test_fused_forced_on_long_rows(hip, monkeypatch):
+    """TWK_HIP_FUSED=2 (test hook): the fused form whatever the row length - N = 60,000 phased is 118 K-chunks per
+    tile, which the default policy would split into units near the end of a launch."""
+    N, M = 60_000, 400
+    al = util.mosaic_alleles(M, N, 8, n_founders=6, switch=0.01, mut=0.001)
+    util.upload(hip, al)
+    f = T.Filters(minR2=0.3)
+    monkeypatch.setenv("TWK_HIP_FUSED", "1")
+    hip.timing_reset()
+    plain, _, _ = hip.ld_all(T.MODE_PHASED, f)
+    assert hip.timing()["fused_launches"] == 0           # too long for the default policy
+    monkeypatch.setenv("TWK_HIP_FUSED", "2")
+    hip.timing_reset()
+    forced, _, _ = hip.ld_all(T.MODE_PHASED, f)
+    assert hip.timing()["fused_launches"] > 0 and len(plain) > 50
+    assert np.sort(plain, order=ORDER).tobytes() == np.sort(forced, order=ORDER).tobytes()

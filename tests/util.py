@@ -21,9 +21,12 @@ COMPARED = _collections.Counter()          # "records", "cubic" (records out of 
 # Caps on the session totals, as a fraction of the cubic-path records compared (floors, roots, round, double-root) or of
 # all records compared (p-floor, fisher-stop): about twice the rates of the first full accounting run
 # (profiles/r03_parity_exemptions.json).  A drift beyond them fails the session.
-EXEMPTION_CAPS = {"floor:D": 2e-4, "floor:Dprime": 2e-4, "floor:R": 2e-4, "floor:R2": 2e-4, "floor:ChiSqFisher": 2e-4,
-                  "floor:cnt": 2e-4, "tie:roots": 4e-3, "tie:round": 2e-3, "tie:fisher-stop": 1e-3, "double-root": 1e-4,
-                  "p-floor": 1.0}
+# First accounting run (round 3, 171 -m gpu tests): 1,245,531 records, 420,616 of them from the cubic: floor:D / Dprime /
+# R / R2 / ChiSqFisher 54 each (1.3e-4), floor:cnt 1,027 (2.4e-3: expected counts next to zero, where a relative bar means
+# nothing), tie:round 4 (1e-5), tie:roots 0, double-root 2 (5e-6), tie:fisher-stop 26 (2.1e-5 of all records), p-floor 0.
+EXEMPTION_CAPS = {"floor:D": 3e-4, "floor:Dprime": 3e-4, "floor:R": 3e-4, "floor:R2": 3e-4, "floor:ChiSqFisher": 3e-4,
+                  "floor:cnt": 5e-3, "tie:roots": 1e-5, "tie:round": 3e-5, "tie:fisher-stop": 5e-5, "double-root": 1.5e-5,
+                  "p-floor": 1e-5}
 
 
 def exemption_summary():

@@ -390,9 +390,29 @@ inline uint32_t build_count_units(uint32_t n_tiles, uint32_t nchunks, uint32_t n
 	return first_split;
 }
 
-template <int NW, int EXPERIMENT = 0>      // EXPERIMENT == 5: the dev tool's finish-time probe (overwrites C)
-__global__ __launch_bounds__(NW * 64, NW / 2)
-void k_count_list_t(const CountWork w) {
+// What a block does with the 8 x TB counts each of its lanes holds when a unit ends.  StoreCounts is the plain form:
+// the counts go to the super-tile's C matrix (stored for a whole tile, added for a part of its K range).
+template <int TB>
+struct StoreCounts {
+	uint32_t* C; uint32_t ldc;
+	__device__ __forceinline__ void operator()(uint32_t (&acc)[8][TB], uint32_t yx, int wr, int wc, int li, int lj, int lane, bool whole) const {
+		uint32_t* Cblk = C + (size_t)((yx >> 16) * TILE + wr * 64 + li) * ldc + (yx & 0xFFFFu) * TILE + wc * 8 * TB + lj;
+		if (whole) {
+#pragma unroll
+			for (int t = 0; t < 8; ++t)
+#pragma unroll
+				for (int u = 0; u < TB; ++u) { Cblk[(size_t)(8 * t) * ldc + 8 * u] = acc[t][u]; acc[t][u] = 0; }
+		} else {
+#pragma unroll
+			for (int t = 0; t < 8; ++t)
+#pragma unroll
+				for (int u = 0; u < TB; ++u) { atomicAdd(&Cblk[(size_t)(8 * t) * ldc + 8 * u], acc[t][u]); acc[t][u] = 0; }
+		}
+	}
+};
+
+template <int NW, int EXPERIMENT, class Epilogue>      // EXPERIMENT == 5: the dev tool's finish-time probe (overwrites C)
+__device__ __forceinline__ void count_list_body(const CountWork& w, const Epilogue& epilogue) {
 	constexpr int WC = NW / 2;
 	constexpr int TB = 16 / WC;
 	constexpr int NSEG = 32 / NW;
@@ -513,20 +533,9 @@ void k_count_list_t(const CountWork w) {
 			for (int u = 0; u < TB; ++u) contract_half<TB>(acc, u, ra[h & 1], rb[h & 1][u]);
 		}
 
-		if (c + 1 == c_end) {          // unit done: write (whole tile) or add (part of a tile's K range)
+		if (c + 1 == c_end) {          // unit done: write (whole tile) or add (part of a tile's K range) - or screen (fused form)
 			const uint32_t yx = __builtin_amdgcn_readfirstlane(w.tiles[tile]);
-			uint32_t* Cblk = w.C + (size_t)((yx >> 16) * TILE + wr * 64 + li) * w.ldc + (yx & 0xFFFFu) * TILE + wc * 8 * TB + lj;
-			if (seg_c0 == 0 && c_end == nchunks) {
-#pragma unroll
-				for (int t = 0; t < 8; ++t)
-#pragma unroll
-					for (int u = 0; u < TB; ++u) { Cblk[(size_t)(8 * t) * w.ldc + 8 * u] = acc[t][u]; acc[t][u] = 0; }
-			} else {
-#pragma unroll
-				for (int t = 0; t < 8; ++t)
-#pragma unroll
-					for (int u = 0; u < TB; ++u) { atomicAdd(&Cblk[(size_t)(8 * t) * w.ldc + 8 * u], acc[t][u]); acc[t][u] = 0; }
-			}
+			epilogue(acc, yx, wr, wc, li, lj, lane, seg_c0 == 0 && c_end == nchunks);
 			if (!more) {
 				if (EXPERIMENT == 5 && tid == 0) {      // probe: when did this block finish, and on which XCD / CU?
 					uint32_t xcc, hwid;
@@ -542,6 +551,118 @@ void k_count_list_t(const CountWork w) {
 		tile = n_tile; c = n_c; c_end = n_end;
 		buf ^= 1;
 	}
+}
+
+template <int NW, int EXPERIMENT = 0>
+__global__ __launch_bounds__(NW * 64, NW / 2)
+void k_count_list_t(const CountWork w) {
+	count_list_body<NW, EXPERIMENT>(w, StoreCounts<16 / (NW / 2)>{w.C, w.ldc});
+}
+
+// ---- fused form for short rows: count -> r2 screen -> candidate list --------------------------------------
+// With a few thousand samples a pair's whole contraction is a few hundred word pairs, and writing its count
+// to C (4 B), reading it back in the math kernel and running that kernel's FP64 front end on it - one thread
+// per pair, almost all of them rejected by the r2 cut-off - costs as much as counting it.  The reference has
+// no such round trip: its per-pair loop goes count -> math in registers (ld_engine.cpp:1898-2015).  Here the
+// block that counted a tile also screens it: phased planes only (one count per pair, in the lane's own
+// accumulator), and only the part of PhasedMath that needs no division (ld_engine.cpp:1162-1310):
+//     r2 = D^2 / (pA qA pB qB) = (2N AA - acA acB)^2 / (acA (2N - acA) acB (2N - acB))
+// (AA = the pair's count, acA / acB = the rows' popcounts, 2N haplotypes, no missing data in these planes), so
+//     a pair can pass r2 >= minR2 only if  (2N AA - acA acB)^2 >= minR2 (1 - 1e-6) acA (2N - acA) acB (2N - acB).
+// All integers involved are exact in FP64 for 2N < 2^26; the factor 1 - 1e-6 is six orders of magnitude more
+// than the rounding of either side, so no pair the reference's rounded formula would keep is lost (the same
+// screen stands at the head of d_phased_math).  Pairs that pass - with the structural tests: inside the
+// super-tile, above the diagonal, inside the r2 band / the window - are *candidates*: (set position A, set
+// position B, AA) appended to a list with one atomic per wave, and k_ld_stats_list (ld_math.hip.h) runs the
+// whole of the reference's math on exactly those, one candidate per lane.  Nothing is written for the rest.
+struct ScreenWork {
+	const uint32_t* rowpop;            // ALT alleles per position of the plane set (row popcounts, P = 1)
+	uint32_t a0, b0, nA, nB;           // set positions of the super-tile's first row / column, variants on each axis
+	uint32_t n_variants; int diag;
+	const uint32_t* col_hi; uint32_t hi_a0, hi_b0;       // r2 band (twk_hip.hip region_impl): row at set position a reaches columns < hi_b0 + col_hi[a - hi_a0]
+	double two_n, cut;                 // 2N; minR2 * (1 - 1e-6)
+	uint32_t* cand; unsigned long long cap;            // [cap][3]: set position A, set position B, AA
+	unsigned long long* n_cand;        // device counter (may run past cap: the host then redoes the tile the plain way)
+};
+// (Window mode's position test is left to the list kernel: the tiles of a window-mode launch are the ones the band
+// crosses, so the pairs outside the window are a corner of each, and few of those reach the r2 cut-off.  Testing it here
+// would hold four more values per row and column in registers through the epilogue for nothing.)
+
+template <int TB>
+struct ScreenCounts {
+	const ScreenWork* sp;              // in device memory: read where it is needed, not held in registers through the K loop
+	__device__ __forceinline__ void operator()(uint32_t (&acc)[8][TB], uint32_t yx, int wr, int wc, int li, int lj, int lane, bool) const {
+		const ScreenWork& s = *sp;
+		const uint32_t r0 = (yx >> 16) * TILE + wr * 64 + li;             // this lane's rows: r0 + 8t
+		const uint32_t c0 = (yx & 0xFFFFu) * TILE + wc * 8 * TB + lj;     // and columns: c0 + 8u
+		const double two_n = s.two_n, cut = s.cut;
+		const uint32_t a0 = s.a0, b0 = s.b0;
+		// allele counts of the lane's rows and columns (0 for padding rows: such a pair has dn = 0 and is dropped);
+		// hiA: first column the row does not reach (0 for a padding row: reaches nothing)
+		uint32_t acB[TB], acA[8], hiA[8];
+#pragma unroll
+		for (int u = 0; u < TB; ++u) {
+			const uint32_t cu = c0 + 8 * u, sB = b0 + cu;
+			acB[u] = (cu < s.nB && sB < s.n_variants) ? s.rowpop[sB] : 0u;
+		}
+#pragma unroll
+		for (int t = 0; t < 8; ++t) {
+			const uint32_t rt = r0 + 8 * t, sA = a0 + rt;
+			const bool ok = rt < s.nA && sA < s.n_variants;
+			acA[t] = ok ? s.rowpop[sA] : 0u;
+			hiA[t] = !ok ? 0u : (s.col_hi ? s.hi_b0 + s.col_hi[sA - s.hi_a0] : 0xFFFFFFFFu);
+		}
+		const bool diag = s.diag != 0;
+		uint32_t m = 0;                  // bit 4t + u: pair (t, u) is a candidate
+#pragma unroll
+		for (int t = 0; t < 8; ++t) {
+			const uint32_t sA = a0 + r0 + 8 * t;
+			const double a = (double)acA[t];
+			const double fA = cut * (a * (two_n - a));
+#pragma unroll
+			for (int u = 0; u < TB; ++u) {
+				const uint32_t sB = b0 + c0 + 8 * u;
+				const double b = (double)acB[u];
+				const double dn = two_n * (double)acc[t][u] - a * b;
+				const bool ok = (!diag || sB > sA) && sB < hiA[t] && dn != 0.0 && dn * dn >= fA * (b * (two_n - b));
+				m |= (ok ? 1u : 0u) << (4 * t + u);
+			}
+		}
+		if (__ballot(m != 0)) {          // (most tiles of unlinked variants end here)
+			const uint32_t cnt = __popc(m);
+			uint32_t incl = cnt;           // inclusive prefix sum over the wave
+#pragma unroll
+			for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+			const uint32_t total = __shfl(incl, 63);
+			unsigned long long base = 0;
+			if (lane == 0) base = atomicAdd(s.n_cand, (unsigned long long)total);
+			base = __shfl(base, 0);
+			unsigned long long slot = base + (incl - cnt);
+			uint32_t* const cand = s.cand; const unsigned long long cap = s.cap;
+#pragma unroll
+			for (int t = 0; t < 8; ++t)
+#pragma unroll
+				for (int u = 0; u < TB; ++u)
+					if ((m >> (4 * t + u)) & 1u) {
+						if (slot < cap) {
+							uint32_t* e = cand + slot * 3;
+							e[0] = a0 + r0 + 8 * t; e[1] = b0 + c0 + 8 * u; e[2] = acc[t][u];
+						}
+						++slot;
+					}
+		}
+#pragma unroll
+		for (int t = 0; t < 8; ++t)
+#pragma unroll
+			for (int u = 0; u < TB; ++u) acc[t][u] = 0;
+	}
+};
+static_assert(16 / (8 / 2) == 4, "ScreenCounts packs (t, u) as 4t + u: TB = 4");
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64, NW / 2)
+void k_count_screen_t(const CountWork w, const ScreenWork* sw) {
+	count_list_body<NW, 0>(w, ScreenCounts<16 / (NW / 2)>{sw});
 }
 
 // Zero the tiles [first, n_tiles) of the list (the ones whose K range is split into several units).

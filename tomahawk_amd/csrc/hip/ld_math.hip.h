@@ -416,6 +416,14 @@ __device__ inline void d_cells_phased(const TileView& t, uint32_t i, uint32_t j,
 	}
 }
 
+// The same 2x2 table for the plain phased planes from a count that arrives by value (the candidate list of the fused
+// count kernel, ld_count.hip.h): sA / sB are positions in the plane set.
+__device__ inline void d_cells_phased_aa(const TileView& t, uint32_t sA, uint32_t sB, uint64_t AA, uint64_t c[4]) {
+	const uint64_t twoN = 2ull * t.n_samples;
+	const uint64_t acA = t.rowpop[sA], acB = t.rowpop[sB];
+	c[3] = AA; c[1] = acA - AA; c[2] = acB - AA; c[0] = twoN - ((acA + acB) - AA);
+}
+
 // 3x3 table as the nine sums UnphasedMath reads.
 __device__ inline void d_cells_unphased(const TileView& t, uint32_t i, uint32_t j, uint64_t c[9]) {
 	uint64_t HH, HQ, QH, QQ, nhA, nqA, nhB, nqB, nvalid;
@@ -498,63 +506,61 @@ struct StatsParams {
 	unsigned long long* n_out; // device counter
 };
 
-__global__ __launch_bounds__(256)
-void k_ld_stats(const StatsParams p) {
-	const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-	const uint32_t i = blockIdx.y;
-	bool keep = false;
-	twk_hip_record rec;
-	if (i < p.nA && j < p.nB) {
-		const uint32_t sA = p.tv.a0 + i, sB = p.tv.b0 + j;       // positions in the plane set
-		bool todo = sA < p.n_variants && sB < p.n_variants && (!p.diag || sB > sA);
-		if (todo && p.col_hi && sB >= p.hi_b0 + p.col_hi[sA - p.hi_a0]) todo = false;
-		// A regrouped plane set (ids != null) can meet a pair in either order; the record always
-		// has the variant that comes first in the file as A, like the reference's i < j loops.
-		uint32_t A = sA, B = sB;
-		if (todo && p.tv.ids) { A = p.tv.ids[sA]; B = p.tv.ids[sB]; }
-		const bool flip = A > B;
-		if (flip) { const uint32_t x = A; A = B; B = x; }
-		// ld_engine.cpp:1918 / 2033: nothing to learn from two singletons
-		if (todo && !(p.window & TWK_HIP_OPT_KEEP_LOW_AC) && p.vm.ac[A] + p.vm.ac[B] <= 2) todo = false;
-		if (todo && p.auto_select) {
-			const bool anymiss = p.vm.an[A] || p.vm.an[B];
-			if ((p.auto_select == 1) == anymiss) todo = false;
-		}
-		if (todo && (p.window & TWK_HIP_OPT_WINDOW)) {   // exact window: same contig, |dpos| <= w
-			const int64_t d = (int64_t)p.vm.pos[A] - (int64_t)p.vm.pos[B];
-			if (p.vm.rid[A] != p.vm.rid[B] || (d < 0 ? -d : d) > (int64_t)p.l_window) todo = false;
-		}
-		if (todo) {
-			if (p.phased_math) {
-				uint64_t c[4];
-				d_cells_phased(p.tv, i, j, c);
-				if (flip) { const uint64_t x = c[1]; c[1] = c[2]; c[2] = x; }
-				// Which of the two off-diagonal counts is stored in cnt[1] depends on the CPU kernel the
-				// reference picks for the pair: its run-length kernel - taken when either
-				// variant has missing genotypes and ac_A + ac_B is below a sample-count dependent
-				// threshold (ld_engine.cpp:1910, :1925-1926) - has (A ref, B alt) there, the vector
-				// kernels (A alt, B ref).  The statistics are symmetric in the two; mirror the slot.
-				if ((p.vm.missing[A] || p.vm.missing[B]) &&
-				    p.vm.ac[A] + p.vm.ac[B] < (uint32_t)(0.0047 * p.tv.n_samples + 5.2913)) {
-					const uint64_t x = c[1]; c[1] = c[2]; c[2] = x;
-				}
-				else if ((p.window & TWK_HIP_OPT_REF_COMPAT) && (p.vm.missing[A] || p.vm.missing[B]) && p.rawmask)
-					d_k3_as_compiled(p.raw, p.rawmask, p.Wp, p.tv.n_samples, A, B, c);
-				keep = d_phased_math(c[0], c[1], c[2], c[3], p.vm, A, B, p.filt, &rec);
-			} else {
-				uint64_t c[9];
-				d_cells_unphased(p.tv, i, j, c);
-				if (flip) {          // transpose the 3x3 table
-					uint64_t x;
-					x = c[1]; c[1] = c[3]; c[3] = x;
-					x = c[2]; c[2] = c[6]; c[6] = x;
-					x = c[5]; c[5] = c[7]; c[7] = x;
-				}
-				keep = d_unphased_math(c, p.vm, A, B, p.filt, &rec);
-			}
-		}
+// One pair of the super-tile: skips, window, cells -> math -> filters.  sA / sB: positions in the plane set; i / j the
+// same relative to the tile (C is indexed by them); aa: the pair's count when it arrives by value (plain phased planes,
+// from the fused count kernel's candidate list) instead of through C.  Returns true if the pair survives (rec filled).
+template <bool BY_VALUE>
+__device__ __forceinline__ bool d_pair(const StatsParams& p, uint32_t sA, uint32_t sB, uint32_t i, uint32_t j, uint64_t aa, twk_hip_record* rec) {
+	bool todo = sA < p.n_variants && sB < p.n_variants && (!p.diag || sB > sA);
+	if (todo && p.col_hi && sB >= p.hi_b0 + p.col_hi[sA - p.hi_a0]) todo = false;
+	// A regrouped plane set (ids != null) can meet a pair in either order; the record always
+	// has the variant that comes first in the file as A, like the reference's i < j loops.
+	uint32_t A = sA, B = sB;
+	if (todo && p.tv.ids) { A = p.tv.ids[sA]; B = p.tv.ids[sB]; }
+	const bool flip = A > B;
+	if (flip) { const uint32_t x = A; A = B; B = x; }
+	// ld_engine.cpp:1918 / 2033: nothing to learn from two singletons
+	if (todo && !(p.window & TWK_HIP_OPT_KEEP_LOW_AC) && p.vm.ac[A] + p.vm.ac[B] <= 2) todo = false;
+	if (todo && p.auto_select) {
+		const bool anymiss = p.vm.an[A] || p.vm.an[B];
+		if ((p.auto_select == 1) == anymiss) todo = false;
 	}
-	// wave-level compaction: one atomic per wave
+	if (todo && (p.window & TWK_HIP_OPT_WINDOW)) {   // exact window: same contig, |dpos| <= w
+		const int64_t d = (int64_t)p.vm.pos[A] - (int64_t)p.vm.pos[B];
+		if (p.vm.rid[A] != p.vm.rid[B] || (d < 0 ? -d : d) > (int64_t)p.l_window) todo = false;
+	}
+	if (!todo) return false;
+	if (BY_VALUE || p.phased_math) {          // (a count that arrives by value is a plain phased pair: the list kernel carries no cubic)
+		uint64_t c[4];
+		if (BY_VALUE) d_cells_phased_aa(p.tv, sA, sB, aa, c);
+		else d_cells_phased(p.tv, i, j, c);
+		if (flip) { const uint64_t x = c[1]; c[1] = c[2]; c[2] = x; }
+		// Which of the two off-diagonal counts is stored in cnt[1] depends on the CPU kernel the
+		// reference picks for the pair: its run-length kernel - taken when either
+		// variant has missing genotypes and ac_A + ac_B is below a sample-count dependent
+		// threshold (ld_engine.cpp:1910, :1925-1926) - has (A ref, B alt) there, the vector
+		// kernels (A alt, B ref).  The statistics are symmetric in the two; mirror the slot.
+		if ((p.vm.missing[A] || p.vm.missing[B]) &&
+		    p.vm.ac[A] + p.vm.ac[B] < (uint32_t)(0.0047 * p.tv.n_samples + 5.2913)) {
+			const uint64_t x = c[1]; c[1] = c[2]; c[2] = x;
+		}
+		else if ((p.window & TWK_HIP_OPT_REF_COMPAT) && (p.vm.missing[A] || p.vm.missing[B]) && p.rawmask)
+			d_k3_as_compiled(p.raw, p.rawmask, p.Wp, p.tv.n_samples, A, B, c);
+		return d_phased_math(c[0], c[1], c[2], c[3], p.vm, A, B, p.filt, rec);
+	}
+	uint64_t c[9];
+	d_cells_unphased(p.tv, i, j, c);
+	if (flip) {          // transpose the 3x3 table
+		uint64_t x;
+		x = c[1]; c[1] = c[3]; c[3] = x;
+		x = c[2]; c[2] = c[6]; c[6] = x;
+		x = c[5]; c[5] = c[7]; c[7] = x;
+	}
+	return d_unphased_math(c, p.vm, A, B, p.filt, rec);
+}
+
+// wave-level compaction of the survivors: one atomic per wave
+__device__ __forceinline__ void d_append_survivor(const StatsParams& p, bool keep, const twk_hip_record& rec) {
 	const unsigned long long ballot = __ballot(keep);
 	if (ballot) {
 		const int lane = threadIdx.x & 63;
@@ -566,6 +572,43 @@ void k_ld_stats(const StatsParams p) {
 			const unsigned long long slot = base + __popcll(ballot & ((1ull << lane) - 1));
 			if (slot < p.capacity) p.out[slot] = rec;
 		}
+	}
+}
+
+__global__ __launch_bounds__(256)
+void k_ld_stats(const StatsParams p) {
+	const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t i = blockIdx.y;
+	bool keep = false;
+	twk_hip_record rec;
+	if (i < p.nA && j < p.nB) keep = d_pair<false>(p, p.tv.a0 + i, p.tv.b0 + j, i, j, 0, &rec);
+	d_append_survivor(p, keep, rec);
+}
+
+// The math on the candidate list of the fused count kernel (k_count_screen_t): one candidate (set position A, set
+// position B, AA) per lane, grid-stride; n_cand is the device counter the count kernel left (it may have run past
+// `cap`: the host then redoes the tile through C).  Everything the plain kernel tests is tested again here - the count
+// kernel's screen only decides what is worth looking at.
+__global__ __launch_bounds__(256)
+void k_ld_stats_list(const StatsParams* pp, const uint32_t* __restrict__ cand, const unsigned long long* __restrict__ n_cand,
+                     unsigned long long cap) {
+	unsigned long long n = *n_cand;
+	if (n > cap) n = cap;
+	const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+	const unsigned long long n_up = (n + 63) / 64 * 64;          // whole waves stay together for the ballot
+#pragma unroll 1
+	for (unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; k < n_up; k += stride) {
+		// the parameter block is read from memory inside the loop (the fence keeps the loads from being hoisted: held
+		// across the loop they cost ~170 scalar registers, spilled into vector registers, and half the occupancy)
+		asm volatile("" ::: "memory");
+		const StatsParams& p = *pp;
+		bool keep = false;
+		twk_hip_record rec;
+		if (k < n) {
+			const uint32_t sA = cand[3 * k], sB = cand[3 * k + 1];
+			keep = d_pair<true>(p, sA, sB, 0, 0, cand[3 * k + 2], &rec);
+		}
+		d_append_survivor(p, keep, rec);
 	}
 }
 

@@ -63,10 +63,14 @@ enum { MODE_INT_AUTO_CLEAN = 0x10,     // phased math on the plain planes; pairs
 struct Slot {                      // one in-flight tile (double buffered)
 	uint32_t* C = nullptr; size_t C_words = 0;
 	twk_hip_record* out = nullptr; unsigned long long capacity = 0;
-	unsigned long long* n_out = nullptr;          // device counters: [0] survivors appended, [1] of those dropped by the Fisher cut-off
-	unsigned long long* h_n_out = nullptr;        // pinned host copy of both
+	unsigned long long* n_out = nullptr;          // device counters: [0] survivors appended, [1] of those dropped by the Fisher cut-off,
+	                                              // [2] candidates of the fused count kernel, [3] spare
+	unsigned long long* h_n_out = nullptr;        // pinned host copy of all four
 	hipEvent_t ev_c0 = nullptr, ev_c1 = nullptr, ev_s1 = nullptr, ev_c0b = nullptr, ev_c1b = nullptr;
 	bool two_pass = false;
+	bool fused = false;                           // first launch ran the fused count -> screen kernel: C holds the candidate list
+	unsigned long long cand_cap = 0;              // ... of this many entries; n_out[2] counts them
+	bool cand_overflow = false;                   // set by finish_tile: the list did not hold them all
 	double minP = 1.0;
 	uint64_t row_pairs = 0, row_pairs_b = 0;
 	// work lists of the (up to two) count launches of the tile: pinned host copy + device copy
@@ -97,6 +101,7 @@ struct twk_hip_ctx {
 	Slot slot[3];                  // [0],[1]: ld_all pipeline; [2]: synchronous single-tile calls
 	twk_hip_record* h_recs = nullptr; unsigned long long h_recs_cap = 0;   // pinned staging
 	// twk_hip_set_device_sink: the survivors of region calls stay on the device, appended here tile by tile
+	bool fused_ok = true;           // cleared for the rest of a call when a fused tile's candidate list overflowed
 	bool device_sink = false;
 	twk_hip_record* d_keep = nullptr; unsigned long long d_keep_n = 0, d_keep_cap = 0;
 	// the survivors of a tile leave in (idxA, idxB) order: sort keys / permutation (double-buffered), the
@@ -277,6 +282,11 @@ int ensure_host_records(twk_hip_ctx* c, unsigned long long n) {
 	return TWK_HIP_OK;
 }
 
+// Rows of at most this many K chunks (32 words each: 2N <= 16384 bits, N <= 8192 phased) take the fused
+// count -> screen kernel: at that length a tile is never worth splitting, and the C round trip plus the
+// one-thread-per-pair math front end cost as much as the counting itself.
+constexpr uint32_t FUSED_MAX_CHUNKS = 16;
+
 struct Geometry { uint32_t rowsA, rowsB, gx, gy, ldc; };
 Geometry tile_geometry(int P, const twk_hip_tile_desc& t) {
 	Geometry g;
@@ -316,8 +326,16 @@ void build_tile_list(const twk_hip_tile_desc& t, int P, const Geometry& g, bool 
 }
 
 // Launch the count kernel for one tile on the compute stream (which: first or second launch of the slot).
+// screen != null: the fused form (k_count_screen_t) if the launch qualifies - rows short enough that no tile's K range
+// is split (or TWK_HIP_FUSED=2: never split) - in which case *fused is set and the slot's C buffer holds the candidate
+// list instead of counts.
+// The two parameter blocks of a fused launch travel to the device behind the tile list and the unit table (one copy
+// per launch as before): the kernels read them from memory where they need them instead of holding ~60 more scalar
+// registers through the contraction loop / the candidate loop.
+struct FusedArgs { ScreenWork screen; StatsParams stats; };
 int launch_count(twk_hip_ctx* c, int set, const twk_hip_tile_desc& t, Slot& s, int which, hipEvent_t e0, hipEvent_t e1,
-                 uint64_t* row_pairs, const ColRange* cr = nullptr) {
+                 uint64_t* row_pairs, const ColRange* cr = nullptr, const FusedArgs* fa = nullptr, bool* fused = nullptr,
+                 const StatsParams** d_stats = nullptr) {
 	const PlaneSet& ps = c->planes[set];
 	const int P = planes_per_variant(set_kind(set));
 	const Geometry g = tile_geometry(P, t);
@@ -335,9 +353,19 @@ int launch_count(twk_hip_ctx* c, int set, const twk_hip_tile_desc& t, Slot& s, i
 		const unsigned long v = std::strtoul(e, nullptr, 10);
 		if (v) min_chunks = (uint32_t)v;
 	}
+	bool fuse = false;
+	if (fa) {
+		const char* fe = std::getenv("TWK_HIP_FUSED");      // 0: never; 1 (default): rows of <= FUSED_MAX_CHUNKS chunks; 2: always (test hook)
+		const int fused_env = fe ? std::atoi(fe) : 1;
+		fuse = fused_env == 2 || (fused_env == 1 && nchunks <= FUSED_MAX_CHUNKS);
+		if (fuse) min_chunks = nchunks + 1;          // whole tiles only: a block must hold a pair's whole count to screen it
+	}
+	if (fused) *fused = fuse;
 	std::vector<CountUnit> units;
 	const uint32_t first_split = T ? build_count_units((uint32_t)T, nchunks, n_blocks, min_chunks, units) : 0;
-	const size_t T4 = (T + 3) / 4 * 4, words = T4 + units.size() * 4;       // [tiles | pad | units], units 16-byte aligned
+	const size_t T4 = (T + 3) / 4 * 4, words_units = T4 + units.size() * 4;       // [tiles | pad | units], units 16-byte aligned
+	const size_t fa_words = (sizeof(FusedArgs) + 15) / 16 * 4;
+	const size_t words = words_units + (fuse ? fa_words : 0);                    // [... | FusedArgs] for a fused launch
 	if (s.tiles_cap[which] < words) {
 		if (s.h_tiles[which]) (void)hipHostFree(s.h_tiles[which]);
 		if (s.d_tiles[which]) (void)hipFree(s.d_tiles[which]);
@@ -350,6 +378,7 @@ int launch_count(twk_hip_ctx* c, int set, const twk_hip_tile_desc& t, Slot& s, i
 	if (T) {
 		std::memcpy(s.h_tiles[which], list.data(), T * 4);
 		std::memcpy(s.h_tiles[which] + T4, units.data(), units.size() * sizeof(CountUnit));
+		if (fuse) std::memcpy(s.h_tiles[which] + words_units, fa, sizeof(FusedArgs));
 		HIPCHK(c, hipMemcpyAsync(s.d_tiles[which], s.h_tiles[which], words * 4, hipMemcpyHostToDevice, c->s_compute));
 	}
 	HIPCHK(c, hipEventRecord(e0, c->s_compute));
@@ -365,7 +394,10 @@ int launch_count(twk_hip_ctx* c, int set, const twk_hip_tile_desc& t, Slot& s, i
 			hipLaunchKernelGGL(k_zero_tiles, dim3((uint32_t)T - first_split), dim3(256), 0, c->s_compute, w.tiles, first_split, w.C, w.ldc);
 			HIPCHK(c, hipGetLastError());
 		}
-		hipLaunchKernelGGL((k_count_list_t<COUNT_NW>), dim3(std::min(n_blocks, w.n_units)), dim3(COUNT_THREADS), 0, c->s_compute, w);
+		const FusedArgs* d_fa = reinterpret_cast<const FusedArgs*>(s.d_tiles[which] + words_units);
+		if (fuse && d_stats) *d_stats = &d_fa->stats;
+		if (fuse) hipLaunchKernelGGL((k_count_screen_t<COUNT_NW>), dim3(std::min(n_blocks, w.n_units)), dim3(COUNT_THREADS), 0, c->s_compute, w, &d_fa->screen);
+		else hipLaunchKernelGGL((k_count_list_t<COUNT_NW>), dim3(std::min(n_blocks, w.n_units)), dim3(COUNT_THREADS), 0, c->s_compute, w);
 		HIPCHK(c, hipGetLastError());
 	}
 	HIPCHK(c, hipEventRecord(e1, c->s_compute));
@@ -432,13 +464,32 @@ int enqueue_tile(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, const twk
 	rc = ensure_slot(c, s, (size_t)g.rowsA * g.rowsB, capacity); if (rc) return rc;
 	s.two_pass = two_pass;
 
-	HIPCHK(c, hipMemsetAsync(s.n_out, 0, 2 * sizeof(unsigned long long), c->s_compute));
-	rc = launch_count(c, kind1, t, s, 0, s.ev_c0, s.ev_c1, &s.row_pairs, cr); if (rc) return rc;
-	{
+	HIPCHK(c, hipMemsetAsync(s.n_out, 0, 4 * sizeof(unsigned long long), c->s_compute));
+	// The fused form: plain phased planes (one count per pair), PhasedMath, an r2 cut-off the screen can use.
+	const bool want_fused = c->fused_ok && phased && set_kind(kind1) == PK_PHASED && f.minR2 > 1e-6 && f.minR2 <= 1.0;
+	FusedArgs fa{};
+	ScreenWork& sw = fa.screen;
+	s.fused = false; s.cand_overflow = false; s.cand_cap = s.C_words / 3;
+	if (want_fused) {
+		const PlaneSet& ps = c->planes[kind1];
+		fa.stats = make_stats(c, kind1, t, s, phased, pl.select1, f, cr);
+		sw.rowpop = ps.rowpop; sw.a0 = t.rowA0; sw.b0 = t.rowB0; sw.nA = t.nA; sw.nB = t.nB;
+		sw.n_variants = c->M; sw.diag = (t.diag && t.rowA0 == t.rowB0) ? 1 : 0;
+		sw.col_hi = cr ? cr->d_hi : nullptr; sw.hi_a0 = cr ? cr->a0 : 0; sw.hi_b0 = cr ? cr->b0 : 0;
+		sw.two_n = 2.0 * (double)c->N; sw.cut = f.minR2 * (1.0 - 1e-6);
+		sw.cand = s.C; sw.cap = s.cand_cap; sw.n_cand = s.n_out + 2;
+	}
+	const StatsParams* d_stats = nullptr;
+	rc = launch_count(c, kind1, t, s, 0, s.ev_c0, s.ev_c1, &s.row_pairs, cr, want_fused ? &fa : nullptr, &s.fused, &d_stats); if (rc) return rc;
+	if (s.fused) {
+		if (d_stats)     // (no tiles, no launch, no candidates)
+			hipLaunchKernelGGL(k_ld_stats_list, dim3(c->resident_blocks * 4), dim3(256), 0, c->s_compute, d_stats, (const uint32_t*)s.C,
+			                   (const unsigned long long*)(s.n_out + 2), s.cand_cap);
+	} else {
 		const StatsParams p = make_stats(c, kind1, t, s, phased, pl.select1, f, cr);
 		hipLaunchKernelGGL(k_ld_stats, dim3((t.nB + 255) / 256, t.nA), dim3(256), 0, c->s_compute, p);
-		HIPCHK(c, hipGetLastError());
 	}
+	HIPCHK(c, hipGetLastError());
 	if (two_pass) {
 		rc = launch_count(c, kind2, t, s, 1, s.ev_c0b, s.ev_c1b, &s.row_pairs_b, cr); if (rc) return rc;
 		const StatsParams p = make_stats(c, kind2, t, s, false, 2, f);
@@ -448,7 +499,7 @@ int enqueue_tile(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, const twk
 	hipLaunchKernelGGL(k_ld_fisher, dim3(c->resident_blocks * 2), dim3(256), 0, c->s_compute, s.out, s.n_out, s.capacity, f.minP, LFact{c->d_lfact, c->lfact_n});
 	HIPCHK(c, hipGetLastError());
 	s.minP = f.minP;
-	HIPCHK(c, hipMemcpyAsync(s.h_n_out, s.n_out, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->s_compute));
+	HIPCHK(c, hipMemcpyAsync(s.h_n_out, s.n_out, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->s_compute));
 	HIPCHK(c, hipEventRecord(s.ev_s1, c->s_compute));
 	return TWK_HIP_OK;
 }
@@ -483,7 +534,7 @@ int sort_records(twk_hip_ctx* c, const twk_hip_record* recs, unsigned long long 
 		if (c->d_sorted) (void)hipFree(c->d_sorted);
 		c->d_sort_keys = nullptr; c->d_sort_vals = nullptr; c->d_sorted = nullptr; c->sort_cap = 0;
 		const unsigned long long cap = std::max<unsigned long long>(n + n / 4, 1ull << 16);
-		HIPCHK(c, hipMalloc((void**)&c->d_sort_keys, (size_t)cap * 2 * sizeof(unsigned long long)));
+		HIPCHK(c, hipMalloc((void**)&c->d_sort_keys, (size_t)cap * 4 * sizeof(unsigned long long)));
 		HIPCHK(c, hipMalloc((void**)&c->d_sort_vals, (size_t)cap * 2 * sizeof(uint32_t)));
 		HIPCHK(c, hipMalloc((void**)&c->d_sorted, (size_t)cap * sizeof(twk_hip_record)));
 		c->sort_cap = cap;
@@ -537,6 +588,7 @@ int finish_tile(twk_hip_ctx* c, Slot& s, const twk_hip_tile_desc& t, unsigned lo
 	float ms = 0;
 	HIPCHK(c, hipEventElapsedTime(&ms, s.ev_c0, s.ev_c1));
 	c->timing.count_ms += ms; c->timing.count_launches += 1; c->timing.row_pairs += s.row_pairs;
+	if (s.fused) { c->timing.fused_launches += 1; c->timing.candidates += s.h_n_out[2]; }
 	float ms_all = 0;
 	if (s.two_pass) {
 		HIPCHK(c, hipEventElapsedTime(&ms, s.ev_c0b, s.ev_c1b));
@@ -553,6 +605,7 @@ int finish_tile(twk_hip_ctx* c, Slot& s, const twk_hip_tile_desc& t, unsigned lo
 	c->timing.variant_pairs += pairs_in_tile(c, t);
 	const unsigned long long n = *s.h_n_out;
 	*n_out = n;
+	if (s.fused && s.h_n_out[2] > s.cand_cap) { s.cand_overflow = true; return TWK_HIP_E_OVERFLOW; }   // more candidates than the list holds
 	if (n > s.capacity) return TWK_HIP_E_OVERFLOW;
 	if (n) {
 		// records that failed the Fisher cut-off were only marked on the device (and counted): they sort behind the rest
@@ -577,7 +630,13 @@ int run_tile_sync(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, const tw
                   unsigned long long capacity, unsigned long long* n_out, bool to_host = true) {
 	Slot& s = c->slot[2];
 	int rc = enqueue_tile(c, mode, t, f, s, capacity); if (rc) return rc;
-	return finish_tile(c, s, t, n_out, to_host);
+	rc = finish_tile(c, s, t, n_out, to_host);
+	if (rc == TWK_HIP_E_OVERFLOW && s.cand_overflow) {       // too many candidates for the fused form: through C, for the rest of this call
+		c->fused_ok = false;
+		rc = enqueue_tile(c, mode, t, f, s, capacity); if (rc) return rc;
+		rc = finish_tile(c, s, t, n_out, to_host);
+	}
+	return rc;
 }
 
 // A tile whose survivors overflowed the device buffer: redo it in row strips
@@ -704,8 +763,8 @@ int twk_hip_ctx_create(int device, twk_hip_ctx** out) {
 	for (auto& s : c->slot) {
 		hipEvent_t* evs[] = {&s.ev_c0, &s.ev_c1, &s.ev_s1, &s.ev_c0b, &s.ev_c1b};
 		for (auto* e : evs) if (hipEventCreate(e) != hipSuccess) return fail(TWK_HIP_E_DEVICE);
-		if (hipMalloc((void**)&s.n_out, 2 * sizeof(unsigned long long)) != hipSuccess) return fail(TWK_HIP_E_NOMEM);
-		if (hipHostMalloc((void**)&s.h_n_out, 2 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) return fail(TWK_HIP_E_NOMEM);
+		if (hipMalloc((void**)&s.n_out, 4 * sizeof(unsigned long long)) != hipSuccess) return fail(TWK_HIP_E_NOMEM);
+		if (hipHostMalloc((void**)&s.h_n_out, 4 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) return fail(TWK_HIP_E_NOMEM);
 	}
 	*out = c;
 	return TWK_HIP_OK;
@@ -1003,6 +1062,7 @@ int twk_hip_ld_tile(twk_hip_ctx* c, int mode, const twk_hip_tile_desc* t, const 
 	if (!c->raw) return TWK_HIP_E_STATE;
 	if (!valid_tile(c, t)) return TWK_HIP_E_INVALID;
 	HIPCHK(c, hipSetDevice(c->device));
+	c->fused_ok = true;
 	unsigned long long n = 0;
 	int rc = run_tile_sync(c, mode, *t, *f, std::max<unsigned long long>(capacity, 1), &n);
 	*n_out = n;
@@ -1247,6 +1307,10 @@ static int region_impl(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint3
 		Slot& s = c->slot[done & 1];
 		unsigned long long nrec = 0;
 		rc = finish_tile(c, s, mine[done], &nrec, !c->device_sink);
+		if (rc == TWK_HIP_E_OVERFLOW && s.cand_overflow) {     // the fused form's candidate list overflowed: this tile again through C
+			c->fused_ok = false;                                 // (and the tiles not yet enqueued as well)
+			rc = run_tile_sync(c, mode, mine[done], *f, cap_default, &nrec, !c->device_sink);
+		}
 		if (rc == TWK_HIP_E_OVERFLOW) {
 			uint64_t nr = 0;
 			rc = redo_tile_in_strips(c, mode, mine[done], *f, s.capacity, sink, user, &nr);
@@ -1278,6 +1342,7 @@ int twk_hip_ld_region(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint32
 	if (nA == 0 || nB == 0 || (uint64_t)a0 + nA > c->M || (uint64_t)b0 + nB > c->M) return TWK_HIP_E_INVALID;
 	if (triangle && (a0 != b0 || nB < nA)) return TWK_HIP_E_INVALID;
 	HIPCHK(c, hipSetDevice(c->device));
+	c->fused_ok = true;
 	const bool whole = triangle && a0 == 0 && nA == c->M && nB == c->M;
 	// TWK_HIP_OPT_R2_SCREEN: whole-triangle runs with an r2 cut-off worth the name, outside window mode (which
 	// already prunes by position, in an order the allele-count sort would destroy)

@@ -635,7 +635,9 @@ bool twk_ld::twk_ld_impl::run(twk_ld_settings& settings, const Header& hdr, cons
 			std::cerr << stamp("LOG", "HIP") << (n_gpus > 1 ? "GPU " + std::to_string(g) + ": " : std::string()) << "count kernel " << tm.count_ms << " ms in "
 			          << tm.count_launches << " launches ("
 			          << (tm.count_ms > 0 ? (double)tm.row_pairs * (double)tm.words_per_row / (tm.count_ms * 1e-3) / 2.62e13 * 100.0 : 0.0)
-			          << " % of the and+bcnt issue ceiling over the tiles it contracted), math kernels " << tm.stats_ms << " ms" << std::endl;
+			          << " % of the and+bcnt issue ceiling over the tiles it contracted), math kernels " << tm.stats_ms << " ms"
+			          << (tm.fused_launches ? "; " + std::to_string(tm.fused_launches) + " launches fused count -> r2 screen, " + pretty(tm.candidates) + " candidate pairs" : std::string())
+			          << std::endl;
 	}
 	{
 		double t_sort = 0, t_blocks = 0;
