@@ -639,6 +639,108 @@ void k_ld_fisher(twk_hip_record* __restrict__ recs, unsigned long long* __restri
 	if ((threadIdx.x & 63) == 0 && dropped) atomicAdd(n_out + 1, (unsigned long long)dropped);
 }
 
+// ---- Fisher's test, sixteen lanes per record ------------------------------------------------------------
+// k_ld_fisher above is the reference's walk as it stands: one record per lane, one term after the other through the
+// ratio recurrence (two FP64 divisions per term, the log-binomials again every 11th term).  A wave then runs as long
+// as its longest record, every term waits for the one before it, and the divisions alone are ~300 cycles per term:
+// 69 ms for the 33 M survivors of the 2,504-sample run.  The terms of a tail do not depend on each other, though:
+//     pmf(s) = exp( lbinom(row1, s) + lbinom(total - row1, col1 - s) - lbinom(total, col1) )
+// is what the reference itself evaluates at every 11th step, and with the log-factorial table it is four loads and one
+// exp.  So a group of 16 lanes takes one record and evaluates 16 consecutive terms of a tail at once - coalesced
+// loads, no divisions, no dependency chain - and the reference's stopping rule becomes a ballot: the walk ends at
+// the first term (from the outside) that is not below 0.99999999 q; the terms before it are summed, that term is
+// added if it is below 1.00000001 q (fisher_math.cpp:249-258).  Each term is the value the reference's recurrence
+// would be re-synchronised to at that point, so the two differ by the rounding the recurrence accumulates over at
+// most ten ratios (~1e-15 relative): the same stop decisions, P equal to ~1e-14.  The verified starting points of
+// d_fisher_two are kept, their (up to four) proposals per side evaluated by eight lanes at once.
+constexpr int FISHER_GROUP = 16;
+__device__ __forceinline__ uint32_t d_group_ballot(bool pred, int g0) { return (uint32_t)(__ballot(pred) >> g0) & 0xFFFFu; }
+__device__ __forceinline__ double d_group_sum(double v) {
+#pragma unroll
+	for (int o = FISHER_GROUP / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, FISHER_GROUP);
+	return v;
+}
+
+__global__ __launch_bounds__(256)
+void k_ld_fisher_group(twk_hip_record* __restrict__ recs, unsigned long long* __restrict__ n_out,
+                       unsigned long long capacity, double minP, const LFact lfact) {
+	unsigned long long n_recs = n_out[0];
+	if (n_recs > capacity) n_recs = capacity;
+	const int lane = threadIdx.x & 63, l = lane & (FISHER_GROUP - 1), g0 = lane & ~(FISHER_GROUP - 1);
+	const unsigned long long n_groups = (unsigned long long)gridDim.x * blockDim.x / FISHER_GROUP;
+	uint32_t dropped = 0;
+	for (unsigned long long rec_i = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) / FISHER_GROUP; rec_i < n_recs; rec_i += n_groups) {
+		twk_hip_record* r = recs + rec_i;
+		// arguments as in k_ld_fisher (every lane of the group reads the same words)
+		int n11 = (int)round(r->cnt[0]);
+		const uint32_t flags = r->flags;
+		if (flags & TWK_N11_IN_PAD) n11 = (int)r->_pad;
+		const int n12 = (int)round(r->cnt[2]), n21 = (int)round(r->cnt[1]), n22 = (int)round(r->cnt[3]);
+		const int n1_ = n11 + n12, n_1 = n11 + n21, n = n11 + n12 + n21 + n22;
+		int max = (n_1 < n1_) ? n_1 : n1_;
+		int min = n1_ + n_1 - n;
+		if (min < 0) min = 0;
+		double two = 1.;
+		if (min != max) {
+			const double q = d_hypergeo(lfact, n11, n1_, n_1, n);
+			const double thr = 0.99999999 * q, tie = 1.00000001 * q;
+			int i0 = min, j0 = max;
+			if (q > 0 && max - min > 64) {
+				// verified starting points (see d_fisher_two): lanes 0-3 try the left proposals k = 0..3, lanes 4-7 the right ones
+				const double lq = log(q), nn = (double)n;
+				const double mean = (double)n1_ * (double)n_1 / nn;
+				const double sd = sqrt(mean * ((nn - n1_) / nn) * ((nn - n_1) / (nn - 1.0)));
+				const double lden = d_lbinom(lfact, n, n_1);
+				const double dev = fabs((double)n11 - mean);
+				double D = sqrt(dev * dev + 96.0 * sd * sd) + 4.0;
+				for (int k = 0; k < (l & 3); ++k) D = D * 1.5 + 8.0;
+				const bool right = (l & 4) != 0;
+				const double sf = right ? ceil(mean + D) : floor(mean - D);
+				const bool out = right ? sf >= (double)max : sf <= (double)min;       // the proposal left the support: stay at its end
+				const int s = out ? (right ? max : min) : (int)sf;
+				bool hit = out;
+				if (!out && l < 8) hit = d_lbinom(lfact, n1_, s) + d_lbinom(lfact, n - n1_, n_1 - s) - lden <= lq - 40.0;
+				const uint32_t hits = d_group_ballot(hit && l < 8, g0);
+				const uint32_t hl = hits & 0xFu, hr = (hits >> 4) & 0xFu;
+				if (hl) i0 = __shfl(s, g0 + (__ffs(hl) - 1));
+				if (hr) j0 = __shfl(s, g0 + 4 + (__ffs(hr) - 1));
+			}
+			// left tail: terms i0, i0 + 1, ... up to the first that is not below thr (or the end of the support)
+			double left = 0.;
+			for (int base = i0;; base += FISHER_GROUP) {
+				const int s = base + l;
+				const bool valid = s <= max;
+				const double p = valid ? d_hypergeo(lfact, s, n1_, n_1, n) : 0.;
+				const uint32_t stop = d_group_ballot(valid && !(p < thr), g0);
+				const int first = stop ? __ffs(stop) - 1 : FISHER_GROUP;
+				left += d_group_sum((valid && l < first) ? p : 0.);
+				if (stop) { const double ps = __shfl(p, g0 + first); if (ps < tie) left += ps; break; }
+				if (base + FISHER_GROUP > max) break;
+			}
+			double right = 0.;
+			for (int base = j0;; base -= FISHER_GROUP) {
+				const int s = base - l;
+				const bool valid = s >= 0;
+				const double p = valid ? d_hypergeo(lfact, s, n1_, n_1, n) : 0.;
+				const uint32_t stop = d_group_ballot(valid && !(p < thr), g0);
+				const int first = stop ? __ffs(stop) - 1 : FISHER_GROUP;
+				right += d_group_sum((valid && l < first) ? p : 0.);
+				if (stop) { const double ps = __shfl(p, g0 + first); if (ps < tie) right += ps; break; }
+				if (base - FISHER_GROUP < 0) break;
+			}
+			two = left + right;
+			if (two > 1.) two = 1.;
+		}
+		if (l == 0) {
+			r->P = two;
+			if (flags & TWK_N11_IN_PAD) { r->flags = flags & ~TWK_N11_IN_PAD; r->_pad = 0; }
+			if (two > minP) { r->idxA = TWK_DROPPED_RECORD; ++dropped; }
+		}
+	}
+	for (int o = 32; o > 0; o >>= 1) dropped += __shfl_xor(dropped, o);
+	if ((threadIdx.x & 63) == 0 && dropped) atomicAdd(n_out + 1, (unsigned long long)dropped);
+}
+
 // Raw cells for parity tests: out[(i*nB + j)*ncell + k] (uint64).
 __global__ void k_ld_cells(const TileView tv, uint32_t nA, uint32_t nB, uint32_t n_variants, int diag,
                            int phased, unsigned long long* __restrict__ out) {

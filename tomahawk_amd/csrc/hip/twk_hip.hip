@@ -496,7 +496,13 @@ int enqueue_tile(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, const twk
 		hipLaunchKernelGGL(k_ld_stats, dim3((t.nB + 255) / 256, t.nA), dim3(256), 0, c->s_compute, p);
 		HIPCHK(c, hipGetLastError());
 	}
-	hipLaunchKernelGGL(k_ld_fisher, dim3(c->resident_blocks * 2), dim3(256), 0, c->s_compute, s.out, s.n_out, s.capacity, f.minP, LFact{c->d_lfact, c->lfact_n});
+	{	// Fisher's exact test on the compacted survivors: 16 lanes per record (TWK_HIP_FISHER=lane: the one-lane-per-record walk, kept for A/B tests)
+		const char* fe = std::getenv("TWK_HIP_FISHER");
+		if (fe && std::strcmp(fe, "lane") == 0)
+			hipLaunchKernelGGL(k_ld_fisher, dim3(c->resident_blocks * 2), dim3(256), 0, c->s_compute, s.out, s.n_out, s.capacity, f.minP, LFact{c->d_lfact, c->lfact_n});
+		else
+			hipLaunchKernelGGL(k_ld_fisher_group, dim3(c->resident_blocks * 8), dim3(256), 0, c->s_compute, s.out, s.n_out, s.capacity, f.minP, LFact{c->d_lfact, c->lfact_n});
+	}
 	HIPCHK(c, hipGetLastError());
 	s.minP = f.minP;
 	HIPCHK(c, hipMemcpyAsync(s.h_n_out, s.n_out, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->s_compute));
@@ -1173,23 +1179,44 @@ static int region_impl(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint3
 	const int Pmax = plan_for(c, mode).Pmax;
 	uint32_t S = tile_variants ? tile_variants : (16384u / (uint32_t)Pmax);
 	if (windowed && !tile_variants && r1 > r0) {
-		// Search the row-block height: total rounds = sum over row blocks of ceil(blocks / resident),
-		// blocks = the diagonal part + the rectangle out to the farthest reachable column.
+		// Search the row-block height.  A launch over rows [x, x + h) holds, per row of tiles, the tiles from the diagonal
+		// (or the first column its rows reach) to the last column they reach - what build_tile_list lists - and costs
+		// ceil(tiles / resident blocks) rounds plus about half a round of launch, ramp-up and tail; the sum over the
+		// band's row blocks is minimised.  (The first version priced a launch as the whole rectangle out to the farthest
+		// column of its last row, which overstates tall blocks by up to half and made it choose ~1.7 rounds per launch
+		// for a 10,000-variant window at N = 2,504: 143 launches at 50 % of the kernel's rate.)
 		const uint64_t wv = std::max<uint64_t>(1, (cum[r1] - cum[r0]) / (r1 - r0));   // mean partners per row
-		const uint32_t s_hi = std::min<uint32_t>(S, std::max<uint32_t>(512u, round_up((uint32_t)std::min<uint64_t>(wv, 1u << 20), 64)));
+		// The plain path's math kernel visits every pair of the launch's rectangle, so there the block height stays near the
+		// window width; the fused path (count -> screen in the same kernel) visits the listed tiles only.
+		const TilePlan pl = plan_for(c, mode);
+		const char* fe = std::getenv("TWK_HIP_FUSED");
+		const bool fused_likely = pl.phased1 && set_kind(pl.set1) == PK_PHASED && f->minR2 > 1e-6 && f->minR2 <= 1.0 && (!fe || std::atoi(fe) != 0)
+		                          && ensure_planes(c, pl.set1) == TWK_HIP_OK && c->planes[pl.set1].W / KC <= FUSED_MAX_CHUNKS;
+		const uint32_t s_hi = fused_likely ? S : std::min<uint32_t>(S, std::max<uint32_t>(512u, round_up((uint32_t)std::min<uint64_t>(wv, 1u << 20), 64)));
 		const uint32_t s_lo = std::max<uint32_t>(128u, std::min<uint32_t>(s_hi, round_up((uint32_t)std::min<uint64_t>(wv / 8, 1u << 20), 64)));
 		const uint64_t R = c->resident_blocks;
 		auto rb = [&](uint64_t nv) -> uint64_t { return (nv * Pmax + TILE - 1) / TILE; };
+		auto launch_tiles = [&](uint32_t x, uint32_t h) -> uint64_t {
+			const uint32_t col0 = triangle ? x : lo[x];
+			const uint64_t gy = rb(h);
+			uint64_t tiles = 0;
+			for (uint64_t by = 0; by < gy; ++by) {
+				const uint32_t v0 = x + (uint32_t)((by * TILE) / Pmax);
+				const uint32_t v1 = (uint32_t)std::min<uint64_t>((uint64_t)x + h, (uint64_t)x + ((by + 1) * TILE + Pmax - 1) / Pmax);
+				if (v0 >= v1 || hi[v1 - 1] <= col0) continue;
+				uint64_t c_lo = lo[v0] > col0 ? ((uint64_t)(lo[v0] - col0) * Pmax) / TILE : 0;
+				if (triangle) c_lo = std::max<uint64_t>(c_lo, by);
+				const uint64_t c_hi = ((uint64_t)(hi[v1 - 1] - col0) * Pmax + TILE - 1) / TILE;
+				if (c_hi > c_lo) tiles += c_hi - c_lo;
+			}
+			return tiles;
+		};
 		uint32_t best = s_lo; uint64_t best_cost = ~0ull;
 		for (uint32_t cand = s_lo; cand <= s_hi; cand += 64) {
-			uint64_t cost = 0;
+			uint64_t cost = 0;                    // in half rounds
 			for (uint32_t x = r0; x < r1; x += cand) {
-				const uint32_t h = std::min(cand, r1 - x);
-				const uint32_t cs = triangle ? x : lo[x], ce = hi[x + h - 1];
-				if (ce <= cs) continue;
-				const uint64_t ra = rb(h), rbw = rb(std::max<uint32_t>(ce - cs, triangle ? h : 0));
-				const uint64_t blocks = triangle ? ra * (ra + 1) / 2 + ra * (rbw > ra ? rbw - ra : 0) : ra * rbw;
-				cost += (blocks + R - 1) / R;
+				const uint64_t tiles = launch_tiles(x, std::min(cand, r1 - x));
+				if (tiles) cost += 2 * ((tiles + R - 1) / R) + 1;
 			}
 			if (cost < best_cost || (cost == best_cost && cand > best)) { best_cost = cost; best = cand; }
 		}
