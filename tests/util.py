@@ -11,7 +11,8 @@ _STATS_PATH = _os.environ.get("TWK_PARITY_STATS", "")     # tests/sweeps: record
 
 # ---- bookkeeping of every exemption assert_records_match grants (reported at session end, tests/conftest.py) -------
 # kinds: "floor:<field>"   a cubic-path record passed <field> only through its absolute floor (CUBIC_FLOOR), not the 1e-6 bar
-#        "p-floor"         Fisher's P compared through the absolute underflow floor (both ~0)
+#        "p-denormal"      Fisher's P below DBL_MIN on both sides, equal to a few hundred steps of the denormal grid
+#        "p-floor"         Fisher's P compared through the absolute underflow floor 1e-290 otherwise (both ~0)
 #        "tie:roots"       root-multiplicity flag (bit 5) differs
 #        "tie:round"       round()ed expected counts differ by one: the device's P is Fisher's P of its own table
 #        "tie:fisher-stop" P differs by exactly the observed table's own probability (n >= 1e6)
@@ -26,7 +27,7 @@ COMPARED = _collections.Counter()          # "records", "cubic" (records out of 
 # nothing), tie:round 4 (1e-5), tie:roots 0, double-root 2 (5e-6), tie:fisher-stop 26 (2.1e-5 of all records), p-floor 0.
 EXEMPTION_CAPS = {"floor:D": 3e-4, "floor:Dprime": 3e-4, "floor:R": 3e-4, "floor:R2": 3e-4, "floor:ChiSqFisher": 3e-4,
                   "floor:cnt": 5e-3, "tie:roots": 1e-5, "tie:round": 3e-5, "tie:fisher-stop": 5e-5, "double-root": 1.5e-5,
-                  "p-floor": 1e-5}
+                  "p-floor": 1e-5, "p-denormal": 2e-3}
 
 
 def exemption_summary():
@@ -34,7 +35,7 @@ def exemption_summary():
     out = {"compared": dict(COMPARED), "exemptions": dict(EXEMPTIONS), "rates": {}, "caps": dict(EXEMPTION_CAPS)}
     bad = []
     for kind, cap in EXEMPTION_CAPS.items():
-        denom = COMPARED["records"] if kind in ("p-floor", "tie:fisher-stop") else COMPARED["cubic"]
+        denom = COMPARED["records"] if kind in ("p-floor", "p-denormal", "tie:fisher-stop") else COMPARED["cubic"]
         rate = EXEMPTIONS[kind] / denom if denom else 0.0
         out["rates"][kind] = rate
         # (sessions that compare a handful of records cannot be held to a rate: allow two of a kind)
@@ -263,7 +264,10 @@ def assert_records_match(gpu_recs, orc_recs, variants, n_samples=None, rtol=1e-6
         # Fisher's P of the device's *own* rounded table (computed by the oracle), and that table must
         # be the oracle's up to one count per cell.
         if np.isclose(g["P"], w["P"], rtol=rtol, atol=p_floor) and not np.isclose(g["P"], w["P"], rtol=rtol, atol=0.0):
-            used["p-floor"] += 1
+            # below DBL_MIN a double has no relative precision left (spacing 4.9e-324): the reference's ratio recurrence and the
+            # device's term-by-term exp() round differently on that grid - a few hundred grid steps is all that can be asked
+            denormal = max(abs(float(g["P"])), abs(float(w["P"]))) < 2.2250738585072014e-308 and abs(float(g["P"]) - float(w["P"])) <= 2e-321
+            used["p-denormal" if denormal else "p-floor"] += 1
         if not np.isclose(g["P"], w["P"], rtol=rtol, atol=p_floor):
             gt = [int(np.floor(float(x) + 0.5)) for x in g["cnt"]]       # C round(): halves away from zero
             wt = [int(np.floor(float(x) + 0.5)) for x in w["cnt"]]

@@ -634,18 +634,22 @@ struct ScreenCounts {
 #pragma unroll
 			for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o); if (lane >= o) incl += v; }
 			const uint32_t total = __shfl(incl, 63);
+			// (the pointers come out of the parameter block as generic addresses: say that they are global memory, or
+			// every candidate store becomes a flat store that also waits on the LDS queue)
+			typedef __attribute__((address_space(1))) uint32_t g_u32;
+			typedef __attribute__((address_space(1))) unsigned long long g_u64;
 			unsigned long long base = 0;
-			if (lane == 0) base = atomicAdd(s.n_cand, (unsigned long long)total);
+			if (lane == 0) base = __hip_atomic_fetch_add((g_u64*)s.n_cand, (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			base = __shfl(base, 0);
 			unsigned long long slot = base + (incl - cnt);
-			uint32_t* const cand = s.cand; const unsigned long long cap = s.cap;
+			g_u32* const cand = (g_u32*)s.cand; const unsigned long long cap = s.cap;
 #pragma unroll
 			for (int t = 0; t < 8; ++t)
 #pragma unroll
 				for (int u = 0; u < TB; ++u)
 					if ((m >> (4 * t + u)) & 1u) {
 						if (slot < cap) {
-							uint32_t* e = cand + slot * 3;
+							g_u32* e = cand + slot * 3;
 							e[0] = a0 + r0 + 8 * t; e[1] = b0 + c0 + 8 * u; e[2] = acc[t][u];
 						}
 						++slot;

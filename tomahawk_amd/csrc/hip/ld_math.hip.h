@@ -654,6 +654,23 @@ void k_ld_fisher(twk_hip_record* __restrict__ recs, unsigned long long* __restri
 // most ten ratios (~1e-15 relative): the same stop decisions, P equal to ~1e-14.  The verified starting points of
 // d_fisher_two are kept, their (up to four) proposals per side evaluated by eight lanes at once.
 constexpr int FISHER_GROUP = 16;
+// pmf(s) for fixed margins, bit for bit d_hypergeo(t, s, row1, col1, total) - the same subtractions and additions in
+// the same order - but with the four table entries that depend on s loaded side by side: d_hypergeo reaches every
+// entry through its own range check (a branch per load), which strings nine memory round trips together.  The
+// record's constants come in by value: lf_row1 = lf[row1], lf_rest = lf[total - row1], lb_all = lbinom(total, col1).
+// Indices outside the table (the wrapped counts of TWK_HIP_OPT_REF_COMPAT) take d_hypergeo itself.
+__device__ __forceinline__ double d_pmf_logterm(const LFact& t, int s, int row1, int col1, int total, double lf_row1, double lf_rest, double lb_all) {
+	const int i1 = s, i2 = row1 - s, i3 = col1 - s, i4 = total - row1 - col1 + s, rest = total - row1;
+	if ((unsigned)(i1 | i2 | i3 | i4 | row1 | rest) >= (unsigned)t.n)
+		return d_lbinom(t, row1, s) + d_lbinom(t, rest, i3) - lb_all;
+	const double a1 = t.lf[i1], a2 = t.lf[i2], a3 = t.lf[i3], a4 = t.lf[i4];
+	const double lb1 = (i1 == 0 || i2 == 0) ? 0. : lf_row1 - a1 - a2;          // d_lbinom(row1, s)
+	const double lb2 = (i3 == 0 || i4 == 0) ? 0. : lf_rest - a3 - a4;          // d_lbinom(total - row1, col1 - s)
+	return lb1 + lb2 - lb_all;
+}
+__device__ __forceinline__ double d_pmf_term(const LFact& t, int s, int row1, int col1, int total, double lf_row1, double lf_rest, double lb_all) {
+	return exp(d_pmf_logterm(t, s, row1, col1, total, lf_row1, lf_rest, lb_all));
+}
 __device__ __forceinline__ uint32_t d_group_ballot(bool pred, int g0) { return (uint32_t)(__ballot(pred) >> g0) & 0xFFFFu; }
 __device__ __forceinline__ double d_group_sum(double v) {
 #pragma unroll
@@ -682,7 +699,8 @@ void k_ld_fisher_group(twk_hip_record* __restrict__ recs, unsigned long long* __
 		if (min < 0) min = 0;
 		double two = 1.;
 		if (min != max) {
-			const double q = d_hypergeo(lfact, n11, n1_, n_1, n);
+			const double lf_row1 = d_lgamma1(lfact, n1_), lf_rest = d_lgamma1(lfact, n - n1_), lb_all = d_lbinom(lfact, n, n_1);
+			const double q = d_pmf_term(lfact, n11, n1_, n_1, n, lf_row1, lf_rest, lb_all);
 			const double thr = 0.99999999 * q, tie = 1.00000001 * q;
 			int i0 = min, j0 = max;
 			if (q > 0 && max - min > 64) {
@@ -690,7 +708,7 @@ void k_ld_fisher_group(twk_hip_record* __restrict__ recs, unsigned long long* __
 				const double lq = log(q), nn = (double)n;
 				const double mean = (double)n1_ * (double)n_1 / nn;
 				const double sd = sqrt(mean * ((nn - n1_) / nn) * ((nn - n_1) / (nn - 1.0)));
-				const double lden = d_lbinom(lfact, n, n_1);
+				const double lden = lb_all;
 				const double dev = fabs((double)n11 - mean);
 				double D = sqrt(dev * dev + 96.0 * sd * sd) + 4.0;
 				for (int k = 0; k < (l & 3); ++k) D = D * 1.5 + 8.0;
@@ -699,7 +717,7 @@ void k_ld_fisher_group(twk_hip_record* __restrict__ recs, unsigned long long* __
 				const bool out = right ? sf >= (double)max : sf <= (double)min;       // the proposal left the support: stay at its end
 				const int s = out ? (right ? max : min) : (int)sf;
 				bool hit = out;
-				if (!out && l < 8) hit = d_lbinom(lfact, n1_, s) + d_lbinom(lfact, n - n1_, n_1 - s) - lden <= lq - 40.0;
+				if (!out && l < 8) hit = d_pmf_logterm(lfact, s, n1_, n_1, n, lf_row1, lf_rest, lden) <= lq - 40.0;
 				const uint32_t hits = d_group_ballot(hit && l < 8, g0);
 				const uint32_t hl = hits & 0xFu, hr = (hits >> 4) & 0xFu;
 				if (hl) i0 = __shfl(s, g0 + (__ffs(hl) - 1));
@@ -710,7 +728,7 @@ void k_ld_fisher_group(twk_hip_record* __restrict__ recs, unsigned long long* __
 			for (int base = i0;; base += FISHER_GROUP) {
 				const int s = base + l;
 				const bool valid = s <= max;
-				const double p = valid ? d_hypergeo(lfact, s, n1_, n_1, n) : 0.;
+				const double p = valid ? d_pmf_term(lfact, s, n1_, n_1, n, lf_row1, lf_rest, lb_all) : 0.;
 				const uint32_t stop = d_group_ballot(valid && !(p < thr), g0);
 				const int first = stop ? __ffs(stop) - 1 : FISHER_GROUP;
 				left += d_group_sum((valid && l < first) ? p : 0.);
@@ -721,7 +739,7 @@ void k_ld_fisher_group(twk_hip_record* __restrict__ recs, unsigned long long* __
 			for (int base = j0;; base -= FISHER_GROUP) {
 				const int s = base - l;
 				const bool valid = s >= 0;
-				const double p = valid ? d_hypergeo(lfact, s, n1_, n_1, n) : 0.;
+				const double p = valid ? d_pmf_term(lfact, s, n1_, n_1, n, lf_row1, lf_rest, lb_all) : 0.;
 				const uint32_t stop = d_group_ballot(valid && !(p < thr), g0);
 				const int first = stop ? __ffs(stop) - 1 : FISHER_GROUP;
 				right += d_group_sum((valid && l < first) ? p : 0.);
