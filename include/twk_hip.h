@@ -252,6 +252,16 @@ int twk_hip_device_records(twk_hip_ctx* ctx, const twk_hip_record** records, uin
 int twk_hip_shard_rows(uint32_t n_rows, uint32_t n_cols, int32_t triangle, uint32_t part, uint32_t n_parts,
                        uint32_t* row_begin, uint32_t* row_end, uint64_t* n_pairs);
 
+/* Fisher's exact test on n caller-supplied 2x2 tables (tables[4*i + {0,1,2,3}] = n11, n12, n21, n22), two-sided P
+ * into p_two_sided[i]: kt_fisher_exact (lib/fisher_math.cpp:231-267) as the pair math calls it
+ * (ld_engine.cpp:1222-1226, :1656-1658), through the engine's own Fisher kernel - one_lane_per_table == 0: the
+ * production kernel (16 lanes per table); != 0: the one-lane-per-table walk kept for comparison.  Needs
+ * twk_hip_set_problem first (the log-factorial table covers counts up to 2 * n_samples + 15; larger counts take
+ * lgamma itself).  *kernel_ms (may be NULL): the kernel's duration (HIP events).  A parity and measurement entry
+ * point: the pair math reaches the same kernels internally. */
+int twk_hip_fisher_exact(twk_hip_ctx* ctx, const int32_t* tables, uint64_t n, double* p_two_sided,
+                         int32_t one_lane_per_table, float* kernel_ms);
+
 /* ---- measurement ------------------------------------------------------ */
 /* Cumulative device time (HIP events on the engine's own stream) and launch
  * count of the dominant kernel (count-tile) and of the math kernel since the

@@ -1427,6 +1427,65 @@ int twk_hip_shard_rows(uint32_t n_rows, uint32_t n_cols, int32_t triangle, uint3
 	return TWK_HIP_OK;
 }
 
+// Fisher's exact test on caller-supplied tables, through the same kernels the pair math uses.
+__global__ void k_tables_to_records(const int32_t* __restrict__ t, unsigned long long n, twk_hip_record* __restrict__ r) {
+	const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	twk_hip_record x{};
+	x.idxA = 0; x.idxB = 1;
+	x.cnt[0] = t[4 * i]; x.cnt[2] = t[4 * i + 1]; x.cnt[1] = t[4 * i + 2]; x.cnt[3] = t[4 * i + 3];      // n12 rides in the REFALT slot (ld_engine.cpp:1222-1226)
+	r[i] = x;
+}
+__global__ void k_records_to_p(const twk_hip_record* __restrict__ r, unsigned long long n, double* __restrict__ p) {
+	const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) p[i] = r[i].P;
+}
+
+int twk_hip_fisher_exact(twk_hip_ctx* c, const int32_t* tables, uint64_t n, double* p_two_sided, int32_t one_lane_per_table, float* kernel_ms) {
+	if (!c || !tables || !p_two_sided || n == 0 || n > (1ull << 28)) return TWK_HIP_E_INVALID;
+	if (!c->d_lfact) return TWK_HIP_E_STATE;
+	HIPCHK(c, hipSetDevice(c->device));
+	int32_t* d_t = nullptr; twk_hip_record* d_r = nullptr; double* d_p = nullptr; unsigned long long* d_n = nullptr;
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	auto cleanup = [&] {
+		if (d_t) (void)hipFree(d_t);
+		if (d_r) (void)hipFree(d_r);
+		if (d_p) (void)hipFree(d_p);
+		if (d_n) (void)hipFree(d_n);
+		if (e0) (void)hipEventDestroy(e0);
+		if (e1) (void)hipEventDestroy(e1);
+	};
+	hipError_t e = hipMalloc((void**)&d_t, (size_t)n * 16);
+	if (e == hipSuccess) e = hipMalloc((void**)&d_r, (size_t)n * sizeof(twk_hip_record));
+	if (e == hipSuccess) e = hipMalloc((void**)&d_p, (size_t)n * 8);
+	if (e == hipSuccess) e = hipMalloc((void**)&d_n, 4 * sizeof(unsigned long long));
+	if (e == hipSuccess) e = hipEventCreate(&e0);
+	if (e == hipSuccess) e = hipEventCreate(&e1);
+	const unsigned long long counters[4] = {n, 0, 0, 0};
+	if (e == hipSuccess) e = hipMemcpyAsync(d_t, tables, (size_t)n * 16, hipMemcpyHostToDevice, c->s_compute);
+	if (e == hipSuccess) e = hipMemcpyAsync(d_n, counters, sizeof(counters), hipMemcpyHostToDevice, c->s_compute);
+	if (e == hipSuccess) {
+		hipLaunchKernelGGL(k_tables_to_records, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->s_compute, d_t, (unsigned long long)n, d_r);
+		e = hipEventRecord(e0, c->s_compute);
+	}
+	if (e == hipSuccess) {
+		const LFact lf{c->d_lfact, c->lfact_n};
+		if (one_lane_per_table) hipLaunchKernelGGL(k_ld_fisher, dim3(c->resident_blocks * 2), dim3(256), 0, c->s_compute, d_r, d_n, (unsigned long long)n, 2.0, lf);
+		else hipLaunchKernelGGL(k_ld_fisher_group, dim3(c->resident_blocks * 8), dim3(256), 0, c->s_compute, d_r, d_n, (unsigned long long)n, 2.0, lf);
+		e = hipEventRecord(e1, c->s_compute);
+	}
+	if (e == hipSuccess) {
+		hipLaunchKernelGGL(k_records_to_p, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->s_compute, d_r, (unsigned long long)n, d_p);
+		e = hipMemcpyAsync(p_two_sided, d_p, (size_t)n * 8, hipMemcpyDeviceToHost, c->s_compute);
+	}
+	if (e == hipSuccess) e = hipStreamSynchronize(c->s_compute);
+	if (e == hipSuccess) e = hipGetLastError();
+	if (e == hipSuccess && kernel_ms) e = hipEventElapsedTime(kernel_ms, e0, e1);
+	cleanup();
+	HIPCHK(c, e);
+	return TWK_HIP_OK;
+}
+
 int twk_hip_set_device_sink(twk_hip_ctx* c, int on) {
 	if (!c) return TWK_HIP_E_INVALID;
 	c->device_sink = on != 0;

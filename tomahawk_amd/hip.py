@@ -112,6 +112,7 @@ def load_library() -> C.CDLL:
                                       C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.twk_hip_shard_rows.argtypes = [C.c_uint32, C.c_uint32, C.c_int32, C.c_uint32, C.c_uint32,
                                        C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
+    lib.twk_hip_fisher_exact.argtypes = [p, p, C.c_uint64, p, C.c_int32, C.POINTER(C.c_float)]
     lib.twk_hip_set_device_sink.argtypes = [p, C.c_int]
     lib.twk_hip_device_records.argtypes = [p, C.POINTER(p), C.POINTER(C.c_uint64)]
     lib.twk_hip_timing_reset.argtypes = [p]
@@ -296,6 +297,16 @@ class HipLd:
                                                 C.byref(npairs), C.byref(nrec)), "twk_hip_ld_region")
         recs = np.concatenate(chunks) if chunks else np.zeros(0, dtype=RECORD_DTYPE)
         return recs, npairs.value, nrec.value
+
+    def fisher_exact(self, tables: np.ndarray, one_lane_per_table: bool = False):
+        """Two-sided Fisher P of int32 tables [n, 4] = (n11, n12, n21, n22) through the engine's Fisher kernel
+        (twk_hip_fisher_exact).  -> (P float64[n], kernel milliseconds)."""
+        t = np.ascontiguousarray(tables, dtype=np.int32).reshape(-1, 4)
+        out = np.zeros(len(t), dtype=np.float64)
+        ms = C.c_float(0)
+        self._check(self._lib.twk_hip_fisher_exact(self._ctx, t.ctypes.data, len(t), out.ctypes.data, int(bool(one_lane_per_table)),
+                                                   C.byref(ms)), "twk_hip_fisher_exact")
+        return out, float(ms.value)
 
     # ---- multi-GPU: survivors stay in HBM until the gather ----
     def set_device_sink(self, on: bool = True):
