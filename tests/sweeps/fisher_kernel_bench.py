@@ -46,7 +46,7 @@ print(f"  group vs oracle (kt_fisher_exact restated, {len(idx)} sampled tables):
 # tables whose P runs through the underflow region: 2 x 1e6 haplotypes, balanced margins, n11 stepping away from independence
 print("P across the underflow region (n = 2,000,000 haplotypes, margins 1e6 / 1e6):")
 eng.set_problem(1_000_000, 64)
-ks = np.arange(18_000, 28_500, 150)
+ks = np.arange(12_600, 14_300, 25)
 tabs = np.array([[500_000 + k, 500_000 - k, 500_000 - k, 500_000 + k] for k in ks], dtype=np.int32)
 pg, _ = eng.fisher_exact(tabs)
 pl, _ = eng.fisher_exact(tabs, one_lane_per_table=True)

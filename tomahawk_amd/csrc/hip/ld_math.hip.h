@@ -619,15 +619,18 @@ void k_ld_stats_list(const StatsParams* pp, const uint32_t* __restrict__ cand, c
 // haplotype counts): n11 = cnt[0], n12 = cnt[2] (REFALT slot), n21 = cnt[1], n22 = cnt[3].
 // Records with P > minP are dropped (:1228, :1661): marked idxA = 0xFFFFFFFF for the host.
 #define TWK_DROPPED_RECORD 0xFFFFFFFFu
+#define TWK_FISHER_DEFERRED (-2.0)      // in rec->P between the two Fisher kernels: this record is k_ld_fisher's (no P is negative)
 __global__ __launch_bounds__(256)
 void k_ld_fisher(twk_hip_record* __restrict__ recs, unsigned long long* __restrict__ n_out,
-                 unsigned long long capacity, double minP, const LFact lfact) {
+                 unsigned long long capacity, double minP, const LFact lfact, int only_deferred) {
 	unsigned long long n = n_out[0];
 	if (n > capacity) n = capacity;
+	if (only_deferred && n_out[3] == 0) return;       // behind k_ld_fisher_group: nothing was left over (the usual case)
 	uint32_t dropped = 0;
 	for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
 	     i += (unsigned long long)gridDim.x * blockDim.x) {
 		twk_hip_record* r = recs + i;
+		if (only_deferred && !(r->P == TWK_FISHER_DEFERRED)) continue;
 		int n11 = (int)round(r->cnt[0]);
 		if (r->flags & TWK_N11_IN_PAD) { n11 = (int)r->_pad; r->flags &= ~TWK_N11_IN_PAD; r->_pad = 0; }
 		const double both = d_fisher_two(lfact, n11, (int)round(r->cnt[2]), (int)round(r->cnt[1]), (int)round(r->cnt[3]));
@@ -654,22 +657,41 @@ void k_ld_fisher(twk_hip_record* __restrict__ recs, unsigned long long* __restri
 // most ten ratios (~1e-15 relative): the same stop decisions, P equal to ~1e-14.  The verified starting points of
 // d_fisher_two are kept, their (up to four) proposals per side evaluated by eight lanes at once.
 constexpr int FISHER_GROUP = 16;
-// pmf(s) for fixed margins, bit for bit d_hypergeo(t, s, row1, col1, total) - the same subtractions and additions in
-// the same order - but with the four table entries that depend on s loaded side by side: d_hypergeo reaches every
-// entry through its own range check (a branch per load), which strings nine memory round trips together.  The
-// record's constants come in by value: lf_row1 = lf[row1], lf_rest = lf[total - row1], lb_all = lbinom(total, col1).
-// Indices outside the table (the wrapped counts of TWK_HIP_OPT_REF_COMPAT) take d_hypergeo itself.
-__device__ __forceinline__ double d_pmf_logterm(const LFact& t, int s, int row1, int col1, int total, double lf_row1, double lf_rest, double lb_all) {
-	const int i1 = s, i2 = row1 - s, i3 = col1 - s, i4 = total - row1 - col1 + s, rest = total - row1;
-	if ((unsigned)(i1 | i2 | i3 | i4 | row1 | rest) >= (unsigned)t.n)
-		return d_lbinom(t, row1, s) + d_lbinom(t, rest, i3) - lb_all;
+// What a walk needs to know about its record: the margins and the three table values that do not depend on the term.
+struct FisherMargins {
+	int row1, col1, total;             // n1_, n_1, n
+	double lf_row1, lf_rest, lb_all;   // lf[row1], lf[total - row1], lbinom(total, col1)
+};
+// log pmf(s) for fixed margins, bit for bit the exponent of d_hypergeo(t, s, row1, col1, total) - the same subtractions and
+// additions in the same order - but with the table entries loaded side by side: d_hypergeo reaches every entry through
+// its own range check (a branch per load), which strings nine memory round trips together.  Every index lies inside the
+// table: the group kernel only takes records whose margins do (the others go to k_ld_fisher), and min <= s <= max.
+__device__ __forceinline__ double d_pmf_logterm(const LFact& t, const FisherMargins& m, int s) {
+	const int i1 = s, i2 = m.row1 - s, i3 = m.col1 - s, i4 = m.total - m.row1 - m.col1 + s;
 	const double a1 = t.lf[i1], a2 = t.lf[i2], a3 = t.lf[i3], a4 = t.lf[i4];
-	const double lb1 = (i1 == 0 || i2 == 0) ? 0. : lf_row1 - a1 - a2;          // d_lbinom(row1, s)
-	const double lb2 = (i3 == 0 || i4 == 0) ? 0. : lf_rest - a3 - a4;          // d_lbinom(total - row1, col1 - s)
-	return lb1 + lb2 - lb_all;
+	const double lb1 = (i1 == 0 || i2 == 0) ? 0. : m.lf_row1 - a1 - a2;          // d_lbinom(row1, s)
+	const double lb2 = (i3 == 0 || i4 == 0) ? 0. : m.lf_rest - a3 - a4;          // d_lbinom(total - row1, col1 - s)
+	return lb1 + lb2 - m.lb_all;
 }
-__device__ __forceinline__ double d_pmf_term(const LFact& t, int s, int row1, int col1, int total, double lf_row1, double lf_rest, double lb_all) {
-	return exp(d_pmf_logterm(t, s, row1, col1, total, lf_row1, lf_rest, lb_all));
+// Two terms at once (one of each tail): eight loads in flight, then two exps.  A term that is not wanted comes back as 0
+// and touches nothing.
+__device__ __forceinline__ void d_pmf_term2(const LFact& t, const FisherMargins& m, int sL, bool wantL, int sR, bool wantR, double& pL, double& pR) {
+	const int l1 = sL, l2 = m.row1 - sL, l3 = m.col1 - sL, l4 = m.total - m.row1 - m.col1 + sL;
+	const int r1 = sR, r2 = m.row1 - sR, r3 = m.col1 - sR, r4 = m.total - m.row1 - m.col1 + sR;
+	double a1 = 0, a2 = 0, a3 = 0, a4 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0;
+	if (wantL) { a1 = t.lf[l1]; a2 = t.lf[l2]; a3 = t.lf[l3]; a4 = t.lf[l4]; }
+	if (wantR) { b1 = t.lf[r1]; b2 = t.lf[r2]; b3 = t.lf[r3]; b4 = t.lf[r4]; }
+	pL = 0.; pR = 0.;
+	if (wantL) {
+		const double lb1 = (l1 == 0 || l2 == 0) ? 0. : m.lf_row1 - a1 - a2;
+		const double lb2 = (l3 == 0 || l4 == 0) ? 0. : m.lf_rest - a3 - a4;
+		pL = exp(lb1 + lb2 - m.lb_all);
+	}
+	if (wantR) {
+		const double lb1 = (r1 == 0 || r2 == 0) ? 0. : m.lf_row1 - b1 - b2;
+		const double lb2 = (r3 == 0 || r4 == 0) ? 0. : m.lf_rest - b3 - b4;
+		pR = exp(lb1 + lb2 - m.lb_all);
+	}
 }
 __device__ __forceinline__ uint32_t d_group_ballot(bool pred, int g0) { return (uint32_t)(__ballot(pred) >> g0) & 0xFFFFu; }
 __device__ __forceinline__ double d_group_sum(double v) {
@@ -693,14 +715,32 @@ void k_ld_fisher_group(twk_hip_record* __restrict__ recs, unsigned long long* __
 		const uint32_t flags = r->flags;
 		if (flags & TWK_N11_IN_PAD) n11 = (int)r->_pad;
 		const int n12 = (int)round(r->cnt[2]), n21 = (int)round(r->cnt[1]), n22 = (int)round(r->cnt[3]);
-		const int n1_ = n11 + n12, n_1 = n11 + n21, n = n11 + n12 + n21 + n22;
+		FisherMargins m;
+		m.row1 = n11 + n12; m.col1 = n11 + n21; m.total = n11 + n12 + n21 + n22;
+		const int n1_ = m.row1, n_1 = m.col1, n = m.total;
 		int max = (n_1 < n1_) ? n_1 : n1_;
 		int min = n1_ + n_1 - n;
 		if (min < 0) min = 0;
 		double two = 1.;
 		if (min != max) {
-			const double lf_row1 = d_lgamma1(lfact, n1_), lf_rest = d_lgamma1(lfact, n - n1_), lb_all = d_lbinom(lfact, n, n_1);
-			const double q = d_pmf_term(lfact, n11, n1_, n_1, n, lf_row1, lf_rest, lb_all);
+			// the record's constants and q, the observed table's own probability: nine table entries side by side
+			double q;
+			{
+				const int rest = n - n1_, i2 = n1_ - n11, i3 = n_1 - n11, i4 = n - n1_ - n_1 + n11, k5 = n - n_1;
+				if ((unsigned)(n | n1_ | rest | n_1 | k5 | n11 | i2 | i3 | i4) >= (unsigned)lfact.n) {
+					// a count beyond the log-factorial table (the wrapped counts of TWK_HIP_OPT_REF_COMPAT, sample counts past the
+					// table's limit): left to k_ld_fisher, which runs behind this kernel over the records marked here
+					if (l == 0) { r->P = TWK_FISHER_DEFERRED; atomicAdd(n_out + 3, 1ull); }
+					continue;
+				}
+				const double c1 = lfact.lf[n1_], c2 = lfact.lf[rest], c3 = lfact.lf[n], c4 = lfact.lf[n_1], c5 = lfact.lf[k5];
+				const double a1 = lfact.lf[n11], a2 = lfact.lf[i2], a3 = lfact.lf[i3], a4 = lfact.lf[i4];
+				m.lf_row1 = c1; m.lf_rest = c2;
+				m.lb_all = (n_1 == 0 || k5 == 0) ? 0. : c3 - c4 - c5;                   // d_lbinom(n, n_1)
+				const double lb1 = (n11 == 0 || i2 == 0) ? 0. : c1 - a1 - a2;
+				const double lb2 = (i3 == 0 || i4 == 0) ? 0. : c2 - a3 - a4;
+				q = exp(lb1 + lb2 - m.lb_all);
+			}
 			const double thr = 0.99999999 * q, tie = 1.00000001 * q;
 			int i0 = min, j0 = max;
 			if (q > 0 && max - min > 64) {
@@ -708,7 +748,6 @@ void k_ld_fisher_group(twk_hip_record* __restrict__ recs, unsigned long long* __
 				const double lq = log(q), nn = (double)n;
 				const double mean = (double)n1_ * (double)n_1 / nn;
 				const double sd = sqrt(mean * ((nn - n1_) / nn) * ((nn - n_1) / (nn - 1.0)));
-				const double lden = lb_all;
 				const double dev = fabs((double)n11 - mean);
 				double D = sqrt(dev * dev + 96.0 * sd * sd) + 4.0;
 				for (int k = 0; k < (l & 3); ++k) D = D * 1.5 + 8.0;
@@ -717,34 +756,36 @@ void k_ld_fisher_group(twk_hip_record* __restrict__ recs, unsigned long long* __
 				const bool out = right ? sf >= (double)max : sf <= (double)min;       // the proposal left the support: stay at its end
 				const int s = out ? (right ? max : min) : (int)sf;
 				bool hit = out;
-				if (!out && l < 8) hit = d_pmf_logterm(lfact, s, n1_, n_1, n, lf_row1, lf_rest, lden) <= lq - 40.0;
+				if (!out && l < 8) hit = d_pmf_logterm(lfact, m, s) <= lq - 40.0;
 				const uint32_t hits = d_group_ballot(hit && l < 8, g0);
 				const uint32_t hl = hits & 0xFu, hr = (hits >> 4) & 0xFu;
 				if (hl) i0 = __shfl(s, g0 + (__ffs(hl) - 1));
 				if (hr) j0 = __shfl(s, g0 + 4 + (__ffs(hr) - 1));
 			}
-			// left tail: terms i0, i0 + 1, ... up to the first that is not below thr (or the end of the support)
-			double left = 0.;
-			for (int base = i0;; base += FISHER_GROUP) {
-				const int s = base + l;
-				const bool valid = s <= max;
-				const double p = valid ? d_pmf_term(lfact, s, n1_, n_1, n, lf_row1, lf_rest, lb_all) : 0.;
-				const uint32_t stop = d_group_ballot(valid && !(p < thr), g0);
-				const int first = stop ? __ffs(stop) - 1 : FISHER_GROUP;
-				left += d_group_sum((valid && l < first) ? p : 0.);
-				if (stop) { const double ps = __shfl(p, g0 + first); if (ps < tie) left += ps; break; }
-				if (base + FISHER_GROUP > max) break;
-			}
-			double right = 0.;
-			for (int base = j0;; base -= FISHER_GROUP) {
-				const int s = base - l;
-				const bool valid = s >= 0;
-				const double p = valid ? d_pmf_term(lfact, s, n1_, n_1, n, lf_row1, lf_rest, lb_all) : 0.;
-				const uint32_t stop = d_group_ballot(valid && !(p < thr), g0);
-				const int first = stop ? __ffs(stop) - 1 : FISHER_GROUP;
-				right += d_group_sum((valid && l < first) ? p : 0.);
-				if (stop) { const double ps = __shfl(p, g0 + first); if (ps < tie) right += ps; break; }
-				if (base - FISHER_GROUP < 0) break;
+			// Both tails at once, 16 terms of each per round: the left walk takes i0, i0 + 1, ... and the right walk j0, j0 - 1, ...,
+			// each up to its first term that is not below thr (or the end: max for the left walk, 0 for the right, like the
+			// reference's loop bounds); a walk that is done no longer loads anything.
+			double left = 0., right = 0.;
+			bool moreL = true, moreR = true;
+			for (int baseL = i0, baseR = j0; moreL || moreR; baseL += FISHER_GROUP, baseR -= FISHER_GROUP) {
+				const int sL = baseL + l, sR = baseR - l;
+				const bool validL = moreL && sL <= max, validR = moreR && sR >= 0;
+				double pL, pR;
+				d_pmf_term2(lfact, m, sL, validL, sR, validR, pL, pR);
+				if (moreL) {
+					const uint32_t stop = d_group_ballot(validL && !(pL < thr), g0);
+					const int first = stop ? __ffs(stop) - 1 : FISHER_GROUP;
+					left += d_group_sum((validL && l < first) ? pL : 0.);
+					if (stop) { const double ps = __shfl(pL, g0 + first); if (ps < tie) left += ps; moreL = false; }
+					else if (baseL + FISHER_GROUP > max) moreL = false;
+				}
+				if (moreR) {
+					const uint32_t stop = d_group_ballot(validR && !(pR < thr), g0);
+					const int first = stop ? __ffs(stop) - 1 : FISHER_GROUP;
+					right += d_group_sum((validR && l < first) ? pR : 0.);
+					if (stop) { const double ps = __shfl(pR, g0 + first); if (ps < tie) right += ps; moreR = false; }
+					else if (baseR - FISHER_GROUP < 0) moreR = false;
+				}
 			}
 			two = left + right;
 			if (two > 1.) two = 1.;

@@ -498,10 +498,15 @@ int enqueue_tile(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, const twk
 	}
 	{	// Fisher's exact test on the compacted survivors: 16 lanes per record (TWK_HIP_FISHER=lane: the one-lane-per-record walk, kept for A/B tests)
 		const char* fe = std::getenv("TWK_HIP_FISHER");
-		if (fe && std::strcmp(fe, "lane") == 0)
-			hipLaunchKernelGGL(k_ld_fisher, dim3(c->resident_blocks * 2), dim3(256), 0, c->s_compute, s.out, s.n_out, s.capacity, f.minP, LFact{c->d_lfact, c->lfact_n});
-		else
-			hipLaunchKernelGGL(k_ld_fisher_group, dim3(c->resident_blocks * 8), dim3(256), 0, c->s_compute, s.out, s.n_out, s.capacity, f.minP, LFact{c->d_lfact, c->lfact_n});
+		const LFact lf{c->d_lfact, c->lfact_n};
+		if (fe && std::strcmp(fe, "lane") == 0) {
+			hipLaunchKernelGGL(k_ld_fisher, dim3(c->resident_blocks * 2), dim3(256), 0, c->s_compute, s.out, s.n_out, s.capacity, f.minP, lf, 0);
+		} else {
+			hipLaunchKernelGGL(k_ld_fisher_group, dim3(c->resident_blocks * 8), dim3(256), 0, c->s_compute, s.out, s.n_out, s.capacity, f.minP, lf);
+			// records with a count beyond the log-factorial table are left to the one-lane walk (which calls lgamma itself):
+			// it ends at once when there are none
+			hipLaunchKernelGGL(k_ld_fisher, dim3(c->resident_blocks * 2), dim3(256), 0, c->s_compute, s.out, s.n_out, s.capacity, f.minP, lf, 1);
+		}
 	}
 	HIPCHK(c, hipGetLastError());
 	s.minP = f.minP;
@@ -1470,8 +1475,11 @@ int twk_hip_fisher_exact(twk_hip_ctx* c, const int32_t* tables, uint64_t n, doub
 	}
 	if (e == hipSuccess) {
 		const LFact lf{c->d_lfact, c->lfact_n};
-		if (one_lane_per_table) hipLaunchKernelGGL(k_ld_fisher, dim3(c->resident_blocks * 2), dim3(256), 0, c->s_compute, d_r, d_n, (unsigned long long)n, 2.0, lf);
-		else hipLaunchKernelGGL(k_ld_fisher_group, dim3(c->resident_blocks * 8), dim3(256), 0, c->s_compute, d_r, d_n, (unsigned long long)n, 2.0, lf);
+		if (one_lane_per_table) hipLaunchKernelGGL(k_ld_fisher, dim3(c->resident_blocks * 2), dim3(256), 0, c->s_compute, d_r, d_n, (unsigned long long)n, 2.0, lf, 0);
+		else {
+			hipLaunchKernelGGL(k_ld_fisher_group, dim3(c->resident_blocks * 8), dim3(256), 0, c->s_compute, d_r, d_n, (unsigned long long)n, 2.0, lf);
+			hipLaunchKernelGGL(k_ld_fisher, dim3(c->resident_blocks * 2), dim3(256), 0, c->s_compute, d_r, d_n, (unsigned long long)n, 2.0, lf, 1);
+		}
 		e = hipEventRecord(e1, c->s_compute);
 	}
 	if (e == hipSuccess) {
