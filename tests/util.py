@@ -25,11 +25,11 @@ COMPARED = _collections.Counter()          # "records", "cubic" (records out of 
 # First accounting run (round 3, 171 -m gpu tests): 1,245,531 records, 420,616 of them from the cubic: floor:D / Dprime /
 # R / R2 / ChiSqFisher 54 each (1.3e-4), floor:cnt 1,027 (2.4e-3: expected counts next to zero, where a relative bar means
 # nothing), tie:round 4 (1e-5), tie:roots 0, double-root 2 (5e-6), tie:fisher-stop 26 (2.1e-5 of all records), p-floor 0.
-# With Fisher's test evaluated term by term (k_ld_fisher_group) the observed table's own probability is no longer lost where
-# the reference's recurrence starts on denormal terms (P below ~1e-280): ~3e-4 of all records are fisher-stop ties of that
-# kind, and a few hundred more differ on the denormal grid itself (p-denormal).
+# (Fisher's test evaluated term by term - k_ld_fisher_group - would add ~3e-4 of all records as ties where the reference's
+# recurrence starts on denormal terms, P below ~1e-280, and a few hundred on the denormal grid itself; those records are
+# therefore left to the one-lane walk, which runs the reference's recurrence and agrees with it bit for bit.)
 EXEMPTION_CAPS = {"floor:D": 3e-4, "floor:Dprime": 3e-4, "floor:R": 3e-4, "floor:R2": 3e-4, "floor:ChiSqFisher": 3e-4,
-                  "floor:cnt": 5e-3, "tie:roots": 1e-5, "tie:round": 3e-5, "tie:fisher-stop": 1e-3, "double-root": 1.5e-5,
+                  "floor:cnt": 5e-3, "tie:roots": 1e-5, "tie:round": 3e-5, "tie:fisher-stop": 6e-5, "double-root": 1.5e-5,
                   "p-floor": 1e-5, "p-denormal": 2e-3}
 
 
@@ -282,20 +282,17 @@ def assert_records_match(gpu_recs, orc_recs, variants, n_samples=None, rtol=1e-6
                 used["p-denormal"] += 1
             elif neighbour and np.isclose(g["P"], own, rtol=rtol, atol=p_floor):
                 ties.append((k, "round"))
-            elif gt == wt and (sum(gt) >= 1_000_000 or max(gP, wP) < 1e-280) and _one_term_apart(gP, wP, gt):
+            elif gt == wt and sum(gt) >= 1_000_000 and _one_term_apart(gP, wP, gt):
                 # kt_fisher_exact stops its tail walks where a term reaches 0.99999999 q (q = the observed
                 # table's probability) and adds that term only if it is below 1.00000001 q
                 # (fisher_math.cpp:249-258).  On the observed table's own side that term IS q, recomputed
-                # through the ratio recurrence from the walk's starting value - and whether it lands inside
-                # the 1e-8 band is decided by rounding noise in two regimes: at n ~ 1e7 the lgamma noise
-                # (~1e-7 relative in q) exceeds the band, and for q below ~1e-280 the walk starts on a
-                # *denormal* term (q e^-40 and less: a few dozen significant bits at best), which the
-                # recurrence carries to the observed table with 1e-8 .. 1e-3 relative error.  The reference
-                # then drops the observed table's own probability from P (for a table far out in the tail
-                # that is nearly all of P: e.g. (3741, 794, 8, 465) has q = 1.103e-296 and P = 1.107e-296,
-                # the reference returns 4.0e-299); the device, which evaluates every term from the
-                # log-factorial table, keeps it.  The two P then differ by exactly q: checked here, nothing
-                # else is allowed.
+                # through lgamma - whose rounding noise at n ~ 1e7 (~1e-7 relative in q) exceeds the 1e-8
+                # band, so whether the observed table's own probability is counted in P is decided by the
+                # last bits of libm's lgamma, in the reference itself as on the device (a high-precision
+                # evaluation agrees with the reference to 2e-8 when it does count it).  The two P then
+                # differ by exactly q: checked here, nothing else is allowed.  (The same happens for q below
+                # ~1e-290 at any n, where the reference's recurrence starts on denormal terms; there the
+                # device runs the reference's own recurrence - k_ld_fisher - and agrees bit for bit.)
                 ties.append((k, "fisher-stop"))
             elif np.isclose(gP, wP, rtol=rtol, atol=p_floor):
                 # Fisher P underflows to exactly 0 for strong associations: absolute floor for what is left

@@ -619,18 +619,17 @@ void k_ld_stats_list(const StatsParams* pp, const uint32_t* __restrict__ cand, c
 // haplotype counts): n11 = cnt[0], n12 = cnt[2] (REFALT slot), n21 = cnt[1], n22 = cnt[3].
 // Records with P > minP are dropped (:1228, :1661): marked idxA = 0xFFFFFFFF for the host.
 #define TWK_DROPPED_RECORD 0xFFFFFFFFu
-#define TWK_FISHER_DEFERRED (-2.0)      // in rec->P between the two Fisher kernels: this record is k_ld_fisher's (no P is negative)
+#define TWK_FISHER_RECURRENCE_BELOW 1e-270   // observed-table probabilities below this take the reference's own recurrence (k_ld_fisher)
 __global__ __launch_bounds__(256)
 void k_ld_fisher(twk_hip_record* __restrict__ recs, unsigned long long* __restrict__ n_out,
-                 unsigned long long capacity, double minP, const LFact lfact, int only_deferred) {
-	unsigned long long n = n_out[0];
-	if (n > capacity) n = capacity;
-	if (only_deferred && n_out[3] == 0) return;       // behind k_ld_fisher_group: nothing was left over (the usual case)
+                 unsigned long long capacity, double minP, const LFact lfact, const uint32_t* __restrict__ deferred) {
+	// deferred == null: every record; else (behind k_ld_fisher_group) the n_out[3] records that kernel listed
+	unsigned long long n = deferred ? n_out[3] : n_out[0];
+	if (!deferred && n > capacity) n = capacity;
 	uint32_t dropped = 0;
-	for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-	     i += (unsigned long long)gridDim.x * blockDim.x) {
-		twk_hip_record* r = recs + i;
-		if (only_deferred && !(r->P == TWK_FISHER_DEFERRED)) continue;
+	for (unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; k < n;
+	     k += (unsigned long long)gridDim.x * blockDim.x) {
+		twk_hip_record* r = recs + (deferred ? (unsigned long long)deferred[k] : k);
 		int n11 = (int)round(r->cnt[0]);
 		if (r->flags & TWK_N11_IN_PAD) { n11 = (int)r->_pad; r->flags &= ~TWK_N11_IN_PAD; r->_pad = 0; }
 		const double both = d_fisher_two(lfact, n11, (int)round(r->cnt[2]), (int)round(r->cnt[1]), (int)round(r->cnt[3]));
@@ -702,7 +701,7 @@ __device__ __forceinline__ double d_group_sum(double v) {
 
 __global__ __launch_bounds__(256)
 void k_ld_fisher_group(twk_hip_record* __restrict__ recs, unsigned long long* __restrict__ n_out,
-                       unsigned long long capacity, double minP, const LFact lfact) {
+                       unsigned long long capacity, double minP, const LFact lfact, uint32_t* __restrict__ deferred) {
 	unsigned long long n_recs = n_out[0];
 	if (n_recs > capacity) n_recs = capacity;
 	const int lane = threadIdx.x & 63, l = lane & (FISHER_GROUP - 1), g0 = lane & ~(FISHER_GROUP - 1);
@@ -727,10 +726,11 @@ void k_ld_fisher_group(twk_hip_record* __restrict__ recs, unsigned long long* __
 			double q;
 			{
 				const int rest = n - n1_, i2 = n1_ - n11, i3 = n_1 - n11, i4 = n - n1_ - n_1 + n11, k5 = n - n_1;
-				if ((unsigned)(n | n1_ | rest | n_1 | k5 | n11 | i2 | i3 | i4) >= (unsigned)lfact.n) {
+				// every index is one of the table's cells or margins: none negative and the total inside the table means all are
+				if ((n | n1_ | rest | n_1 | k5 | n11 | i2 | i3 | i4) < 0 || n >= lfact.n) {
 					// a count beyond the log-factorial table (the wrapped counts of TWK_HIP_OPT_REF_COMPAT, sample counts past the
-					// table's limit): left to k_ld_fisher, which runs behind this kernel over the records marked here
-					if (l == 0) { r->P = TWK_FISHER_DEFERRED; atomicAdd(n_out + 3, 1ull); }
+					// table's limit): left to k_ld_fisher, which runs behind this kernel over the records listed here
+					if (l == 0) deferred[atomicAdd(n_out + 3, 1ull)] = (uint32_t)rec_i;
 					continue;
 				}
 				const double c1 = lfact.lf[n1_], c2 = lfact.lf[rest], c3 = lfact.lf[n], c4 = lfact.lf[n_1], c5 = lfact.lf[k5];
@@ -740,6 +740,16 @@ void k_ld_fisher_group(twk_hip_record* __restrict__ recs, unsigned long long* __
 				const double lb1 = (n11 == 0 || i2 == 0) ? 0. : c1 - a1 - a2;
 				const double lb2 = (i3 == 0 || i4 == 0) ? 0. : c2 - a3 - a4;
 				q = exp(lb1 + lb2 - m.lb_all);
+			}
+			// Where the walk would start on denormal terms (q e^-40 below ~1e-308) the reference's recurrence carries a value
+			// with a few dozen significant bits to the observed table, and whether that lands inside its 1e-8 stopping band -
+			// i.e. whether the observed table's own probability is counted in P at all - is decided by that rounding
+			// (fisher_math.cpp:249-258; e.g. the table (3741, 794, 8, 465): q = 1.103e-296, the sum of all terms <= q is
+			// 1.107e-296, the reference returns 4.0e-299).  Evaluating every term exactly does not reproduce that; the
+			// one-lane walk, which runs the same recurrence on the same values, does: such records are left to it.
+			if (q > 0 && q < TWK_FISHER_RECURRENCE_BELOW) {
+				if (l == 0) deferred[atomicAdd(n_out + 3, 1ull)] = (uint32_t)rec_i;
+				continue;
 			}
 			const double thr = 0.99999999 * q, tie = 1.00000001 * q;
 			int i0 = min, j0 = max;
@@ -763,13 +773,15 @@ void k_ld_fisher_group(twk_hip_record* __restrict__ recs, unsigned long long* __
 				if (hr) j0 = __shfl(s, g0 + 4 + (__ffs(hr) - 1));
 			}
 			// Both tails at once, 16 terms of each per round: the left walk takes i0, i0 + 1, ... and the right walk j0, j0 - 1, ...,
-			// each up to its first term that is not below thr (or the end: max for the left walk, 0 for the right, like the
-			// reference's loop bounds); a walk that is done no longer loads anything.
+			// each up to its first term that is not below thr (or the end of the support); a walk that is done no longer loads
+			// anything.
 			double left = 0., right = 0.;
 			bool moreL = true, moreR = true;
 			for (int baseL = i0, baseR = j0; moreL || moreR; baseL += FISHER_GROUP, baseR -= FISHER_GROUP) {
 				const int sL = baseL + l, sR = baseR - l;
-				const bool validL = moreL && sL <= max, validR = moreR && sR >= 0;
+				// (the reference's right walk is bounded by 0, but it ends at the observed table at the latest, and n11 >= min: lanes
+				// beyond min would index the table with a negative cell)
+				const bool validL = moreL && sL <= max, validR = moreR && sR >= min;
 				double pL, pR;
 				d_pmf_term2(lfact, m, sL, validL, sR, validR, pL, pR);
 				if (moreL) {
@@ -784,7 +796,7 @@ void k_ld_fisher_group(twk_hip_record* __restrict__ recs, unsigned long long* __
 					const int first = stop ? __ffs(stop) - 1 : FISHER_GROUP;
 					right += d_group_sum((validR && l < first) ? pR : 0.);
 					if (stop) { const double ps = __shfl(pR, g0 + first); if (ps < tie) right += ps; moreR = false; }
-					else if (baseR - FISHER_GROUP < 0) moreR = false;
+					else if (baseR - FISHER_GROUP < min) moreR = false;
 				}
 			}
 			two = left + right;

@@ -500,12 +500,14 @@ int enqueue_tile(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, const twk
 		const char* fe = std::getenv("TWK_HIP_FISHER");
 		const LFact lf{c->d_lfact, c->lfact_n};
 		if (fe && std::strcmp(fe, "lane") == 0) {
-			hipLaunchKernelGGL(k_ld_fisher, dim3(c->resident_blocks * 2), dim3(256), 0, c->s_compute, s.out, s.n_out, s.capacity, f.minP, lf, 0);
+			hipLaunchKernelGGL(k_ld_fisher, dim3(c->resident_blocks * 2), dim3(256), 0, c->s_compute, s.out, s.n_out, s.capacity, f.minP, lf, (const uint32_t*)nullptr);
 		} else {
-			hipLaunchKernelGGL(k_ld_fisher_group, dim3(c->resident_blocks * 8), dim3(256), 0, c->s_compute, s.out, s.n_out, s.capacity, f.minP, lf);
-			// records with a count beyond the log-factorial table are left to the one-lane walk (which calls lgamma itself):
-			// it ends at once when there are none
-			hipLaunchKernelGGL(k_ld_fisher, dim3(c->resident_blocks * 2), dim3(256), 0, c->s_compute, s.out, s.n_out, s.capacity, f.minP, lf, 1);
+			// Records the group kernel does not take - a count beyond the log-factorial table, or an observed-table probability
+			// so small that the reference's recurrence runs on denormals (ld_math.hip.h) - are listed (in the slot's count
+			// buffer: the math kernels are done with it, and it has a word for every pair of the tile) and go through the
+			// one-lane walk, which ends at once when the list is empty.
+			hipLaunchKernelGGL(k_ld_fisher_group, dim3(c->resident_blocks * 8), dim3(256), 0, c->s_compute, s.out, s.n_out, s.capacity, f.minP, lf, s.C);
+			hipLaunchKernelGGL(k_ld_fisher, dim3(c->resident_blocks * 2), dim3(256), 0, c->s_compute, s.out, s.n_out, s.capacity, f.minP, lf, (const uint32_t*)s.C);
 		}
 	}
 	HIPCHK(c, hipGetLastError());
@@ -1475,10 +1477,10 @@ int twk_hip_fisher_exact(twk_hip_ctx* c, const int32_t* tables, uint64_t n, doub
 	}
 	if (e == hipSuccess) {
 		const LFact lf{c->d_lfact, c->lfact_n};
-		if (one_lane_per_table) hipLaunchKernelGGL(k_ld_fisher, dim3(c->resident_blocks * 2), dim3(256), 0, c->s_compute, d_r, d_n, (unsigned long long)n, 2.0, lf, 0);
+		if (one_lane_per_table) hipLaunchKernelGGL(k_ld_fisher, dim3(c->resident_blocks * 2), dim3(256), 0, c->s_compute, d_r, d_n, (unsigned long long)n, 2.0, lf, (const uint32_t*)nullptr);
 		else {
-			hipLaunchKernelGGL(k_ld_fisher_group, dim3(c->resident_blocks * 8), dim3(256), 0, c->s_compute, d_r, d_n, (unsigned long long)n, 2.0, lf);
-			hipLaunchKernelGGL(k_ld_fisher, dim3(c->resident_blocks * 2), dim3(256), 0, c->s_compute, d_r, d_n, (unsigned long long)n, 2.0, lf, 1);
+			hipLaunchKernelGGL(k_ld_fisher_group, dim3(c->resident_blocks * 8), dim3(256), 0, c->s_compute, d_r, d_n, (unsigned long long)n, 2.0, lf, (uint32_t*)d_t);   // (the tables are in the records by now)
+			hipLaunchKernelGGL(k_ld_fisher, dim3(c->resident_blocks * 2), dim3(256), 0, c->s_compute, d_r, d_n, (unsigned long long)n, 2.0, lf, (const uint32_t*)d_t);
 		}
 		e = hipEventRecord(e1, c->s_compute);
 	}
