@@ -254,8 +254,10 @@ int twk_hip_shard_rows(uint32_t n_rows, uint32_t n_cols, int32_t triangle, uint3
 
 /* Fisher's exact test on n caller-supplied 2x2 tables (tables[4*i + {0,1,2,3}] = n11, n12, n21, n22), two-sided P
  * into p_two_sided[i]: kt_fisher_exact (lib/fisher_math.cpp:231-267) as the pair math calls it
- * (ld_engine.cpp:1222-1226, :1656-1658), through the engine's own Fisher kernel - one_lane_per_table == 0: the
- * production kernel (16 lanes per table); != 0: the one-lane-per-table walk kept for comparison.  Needs
+ * (ld_engine.cpp:1222-1226, :1656-1658), through the engine's own Fisher kernels - one_lane_per_table != 0: the
+ * reference's walk, one table per lane (the kernel the pair math uses); == 0: the experimental 16-lanes-per-table
+ * kernel, which evaluates every term from the log-factorial table and hands the tables it cannot reproduce the
+ * reference on (underflow band, counts beyond the table) to the former.  Needs
  * twk_hip_set_problem first (the log-factorial table covers counts up to 2 * n_samples + 15; larger counts take
  * lgamma itself).  *kernel_ms (may be NULL): the kernel's duration (HIP events).  A parity and measurement entry
  * point: the pair math reaches the same kernels internally. */

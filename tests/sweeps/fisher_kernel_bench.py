@@ -26,6 +26,16 @@ print(f"{len(tables):,} tables from calc -p -w {W} on 2,504 samples x 200,000 co
       f"(support width: median {int(np.median(np.minimum(tables[:,0]+tables[:,1], tables[:,0]+tables[:,2]) - np.maximum(0, tables[:,0]-tables[:,3])))}, "
       f"> 64 in {np.mean((np.minimum(tables[:,0]+tables[:,1], tables[:,0]+tables[:,2]) - np.maximum(0, tables[:,0]-tables[:,3])) > 64) * 100:.1f} %)", flush=True)
 
+from scipy.special import gammaln
+def log_q(t):
+    n11, n12, n21, n22 = (t[:, k].astype(np.float64) for k in range(4))
+    lb = lambda n, k: gammaln(n + 1) - gammaln(k + 1) - gammaln(n - k + 1)
+    return lb(n11 + n12, n11) + lb(n21 + n22, n21) - lb(n11 + n12 + n21 + n22, n11 + n21)
+lq = log_q(tables) / np.log(10)
+print(f"  log10 q (the observed table's own probability): {np.mean(lq < -323.3) * 100:.1f} % underflow to 0, "
+      f"{np.mean((lq >= -323.3) & (lq < -270)) * 100:.1f} % in (0, 1e-270) - the band left to the one-lane recurrence, "
+      f"{np.mean((lq >= -270) & (lq < -100)) * 100:.1f} % in [1e-270, 1e-100), {np.mean(lq >= -100) * 100:.1f} % above", flush=True)
+
 eng = T.HipLd(0)
 eng.set_problem(2504, 64)
 for rep in range(3):

@@ -133,3 +133,32 @@ def test_fused_forced_on_long_rows(hip, monkeypatch):
     forced, _, _ = hip.ld_all(T.MODE_PHASED, f)
     assert hip.timing()["fused_launches"] > 0 and len(plain) > 50
     assert np.sort(plain, order=ORDER).tobytes() == np.sort(forced, order=ORDER).tobytes()
+
+
+def test_fisher_kernels_agree_with_each_other_and_the_oracle(hip):
+    """twk_hip_fisher_exact: the two Fisher kernels on the same tables - the reference's walk with one table per lane
+    (production) and the 16-lanes-per-table kernel (every term from the log-factorial table; tables in the underflow
+    band go through the recurrence) - against kt_fisher_exact as the oracle restates it (fisher_math.cpp:231-267):
+    rare and common margins at n = 5,008, P from 1 down through the underflow region, and tables beyond the
+    log-factorial table."""
+    rng = np.random.default_rng(12)
+    hip.set_problem(2504, 8)
+    n = 5008
+    tabs = []
+    for _ in range(3000):
+        r1 = int(rng.integers(1, n)); c1 = int(rng.choice([rng.integers(1, 60), rng.integers(1, n)]))
+        lo, hi = max(0, r1 + c1 - n), min(r1, c1)
+        mean = r1 * c1 / n
+        n11 = int(np.clip(round(mean + rng.normal() * rng.choice([0.5, 3, 12, 40]) * max(1.0, np.sqrt(mean * (1 - r1 / n) * (1 - c1 / n)))), lo, hi))
+        tabs.append([n11, r1 - n11, c1 - n11, n - r1 - c1 + n11])
+    tabs += [[3741, 794, 8, 465], [3763, 10, 775, 460], [1792, 1208, 1994, 14], [2504, 0, 0, 2504], [0, 2504, 2504, 0], [5008, 0, 0, 0],
+             [1, 0, 0, 5007], [2500, 4, 4, 2500], [20_000, 5, 7, 30_000], [7_000, 6_000, 6_500, 7_200]]        # the last two: beyond the table
+    tabs = np.array(tabs, dtype=np.int32)
+    assert (tabs >= 0).all()
+    lane, _ = hip.fisher_exact(tabs, one_lane_per_table=True)
+    group, _ = hip.fisher_exact(tabs)
+    want = np.array([O.fisher(*[int(x) for x in t])[2] for t in tabs])
+    assert (want < 1e-250).sum() > 100 and (want > 0.05).sum() > 100
+    big = want > 1e-300
+    assert np.allclose(lane[big], want[big], rtol=1e-7, atol=0) and np.allclose(group[big], want[big], rtol=1e-7, atol=0)
+    assert np.allclose(lane[~big], want[~big], rtol=1e-6, atol=1e-320) and np.allclose(group[~big], want[~big], rtol=1e-6, atol=1e-320)

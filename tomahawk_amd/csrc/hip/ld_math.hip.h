@@ -83,6 +83,9 @@ struct TableWalk {
 		return pmf = d_hypergeo(t, k, row1, col1, total);
 	}
 };
+// How far below q (in e-folds) a tail walk may start: everything further out is at most (max - min) terms, each below
+// q e^-K, so with K = 17.5 + ln(max - min) the part of P that is not summed is below e^-17.5 q = 2.5e-8 q <= 2.5e-8 P.
+__device__ inline double d_fisher_skip_exponent(int support) { return 17.5 + log((double)support); }
 // Two-sided P only (left / right tails are not stored in the record).
 __device__ inline double d_fisher_two(const LFact& t, int n11, int n12, int n21, int n22) {
 	int i, j, max, min;
@@ -97,10 +100,12 @@ __device__ inline double d_fisher_two(const LFact& t, int n11, int n12, int n21,
 	// The reference walks both tails from the ends of the support (min, max) inwards until the
 	// terms reach q: up to min(n1_, n_1) steps per record, almost all of them over terms that are
 	// zero or tens of orders of magnitude below q.  Start each walk closer in instead, at a point
-	// that is *verified* (one log-pmf evaluation) to lie below q by a factor e^-40: the pmf is
-	// monotone out there, so everything skipped sums to < (max - min) * 4e-18 * q, i.e. < 1e-10
-	// of the result (P >= q) even at 2e7 haplotypes -- far inside the 1e-6 bar; the walk itself, its
-	// re-synchronisation every 11th step and its stopping rule are unchanged.  The candidate point
+	// that is *verified* (one log-pmf evaluation) to lie below q by a factor e^-K, K = 17.5 + ln(max - min):
+	// the pmf is monotone out there, so everything skipped sums to < (max - min) e^-K q = 2.5e-8 q, i.e.
+	// < 2.5e-8 of the result (P >= q) at any sample count -- forty times inside the 1e-6 bar (a fixed K = 40,
+	// the first version, skipped < 1e-10 of P at 2e7 haplotypes and 1e-14 at 5,008, and walked a third more
+	// terms for it); the walk itself, its re-synchronisation every 11th step and its stopping rule are
+	// unchanged.  The candidate point
 	// comes from the normal approximation of the log-pmf, -(s - mean)^2 / (2 sd^2) relative to the
 	// mode: a term e^-K below q lies sqrt(dev^2 + 2 K sd^2) from the mean (dev = |n11 - mean|), a
 	// few sd beyond n11's own distance for a significant table instead of a fixed 12 sd; the
@@ -112,20 +117,21 @@ __device__ inline double d_fisher_two(const LFact& t, int n11, int n12, int n21,
 		const double sd = sqrt(mean * ((nn - n1_) / nn) * ((nn - n_1) / (nn - 1.0)));
 		const double lden = d_lbinom(t, n, n_1);
 		const double dev = fabs((double)n11 - mean);
-		const double D0 = sqrt(dev * dev + 96.0 * sd * sd) + 4.0;                 // K = 48 proposed, 40 required
+		const double K = d_fisher_skip_exponent(max - min);
+		const double D0 = sqrt(dev * dev + 2.0 * (K + 8.0) * sd * sd) + 4.0;      // K + 8 proposed, K required
 		double D = D0;
 		for (int k = 0; k < 4; ++k, D = D * 1.5 + 8.0) {
 			const double sf = floor(mean - D);
 			if (sf <= (double)min) break;
 			const int s = (int)sf;
-			if (d_lbinom(t, n1_, s) + d_lbinom(t, n - n1_, n_1 - s) - lden <= lq - 40.0) { i0 = s; break; }
+			if (d_lbinom(t, n1_, s) + d_lbinom(t, n - n1_, n_1 - s) - lden <= lq - K) { i0 = s; break; }
 		}
 		D = D0;
 		for (int k = 0; k < 4; ++k, D = D * 1.5 + 8.0) {
 			const double sf = ceil(mean + D);
 			if (sf >= (double)max) break;
 			const int s = (int)sf;
-			if (d_lbinom(t, n1_, s) + d_lbinom(t, n - n1_, n_1 - s) - lden <= lq - 40.0) { j0 = s; break; }
+			if (d_lbinom(t, n1_, s) + d_lbinom(t, n - n1_, n_1 - s) - lden <= lq - K) { j0 = s; break; }
 		}
 	}
 	p = w.move_to(t, i0);
@@ -741,7 +747,7 @@ void k_ld_fisher_group(twk_hip_record* __restrict__ recs, unsigned long long* __
 				const double lb2 = (i3 == 0 || i4 == 0) ? 0. : c2 - a3 - a4;
 				q = exp(lb1 + lb2 - m.lb_all);
 			}
-			// Where the walk would start on denormal terms (q e^-40 below ~1e-308) the reference's recurrence carries a value
+			// Where the walk would start on denormal terms (q e^-K below ~1e-308) the reference's recurrence carries a value
 			// with a few dozen significant bits to the observed table, and whether that lands inside its 1e-8 stopping band -
 			// i.e. whether the observed table's own probability is counted in P at all - is decided by that rounding
 			// (fisher_math.cpp:249-258; e.g. the table (3741, 794, 8, 465): q = 1.103e-296, the sum of all terms <= q is
@@ -759,14 +765,15 @@ void k_ld_fisher_group(twk_hip_record* __restrict__ recs, unsigned long long* __
 				const double mean = (double)n1_ * (double)n_1 / nn;
 				const double sd = sqrt(mean * ((nn - n1_) / nn) * ((nn - n_1) / (nn - 1.0)));
 				const double dev = fabs((double)n11 - mean);
-				double D = sqrt(dev * dev + 96.0 * sd * sd) + 4.0;
+				const double K = d_fisher_skip_exponent(max - min);
+				double D = sqrt(dev * dev + 2.0 * (K + 8.0) * sd * sd) + 4.0;
 				for (int k = 0; k < (l & 3); ++k) D = D * 1.5 + 8.0;
 				const bool right = (l & 4) != 0;
 				const double sf = right ? ceil(mean + D) : floor(mean - D);
 				const bool out = right ? sf >= (double)max : sf <= (double)min;       // the proposal left the support: stay at its end
 				const int s = out ? (right ? max : min) : (int)sf;
 				bool hit = out;
-				if (!out && l < 8) hit = d_pmf_logterm(lfact, m, s) <= lq - 40.0;
+				if (!out && l < 8) hit = d_pmf_logterm(lfact, m, s) <= lq - K;
 				const uint32_t hits = d_group_ballot(hit && l < 8, g0);
 				const uint32_t hl = hits & 0xFu, hr = (hits >> 4) & 0xFu;
 				if (hl) i0 = __shfl(s, g0 + (__ffs(hl) - 1));

@@ -496,10 +496,14 @@ int enqueue_tile(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, const twk
 		hipLaunchKernelGGL(k_ld_stats, dim3((t.nB + 255) / 256, t.nA), dim3(256), 0, c->s_compute, p);
 		HIPCHK(c, hipGetLastError());
 	}
-	{	// Fisher's exact test on the compacted survivors: 16 lanes per record (TWK_HIP_FISHER=lane: the one-lane-per-record walk, kept for A/B tests)
+	{	// Fisher's exact test on the compacted survivors.  Default: the reference's walk, one record per lane (k_ld_fisher).
+		// TWK_HIP_FISHER=group: 16 lanes per record, every term from the log-factorial table (k_ld_fisher_group) - 1.3x the
+		// rate on records it can take, but the records whose observed-table probability lies in the underflow band
+		// (10 % of an LD-rich 2,504-sample run) must still go through the recurrence to agree with the reference, and
+		// the two passes together are slower than the one (tests/sweeps/fisher_kernel_bench.py, profiles/): not the default.
 		const char* fe = std::getenv("TWK_HIP_FISHER");
 		const LFact lf{c->d_lfact, c->lfact_n};
-		if (fe && std::strcmp(fe, "lane") == 0) {
+		if (!fe || std::strcmp(fe, "group") != 0) {
 			hipLaunchKernelGGL(k_ld_fisher, dim3(c->resident_blocks * 2), dim3(256), 0, c->s_compute, s.out, s.n_out, s.capacity, f.minP, lf, (const uint32_t*)nullptr);
 		} else {
 			// Records the group kernel does not take - a count beyond the log-factorial table, or an observed-table probability
