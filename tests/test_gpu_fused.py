@@ -158,7 +158,7 @@ def test_fisher_kernels_agree_with_each_other_and_the_oracle(hip):
     lane, _ = hip.fisher_exact(tabs, one_lane_per_table=True)
     group, _ = hip.fisher_exact(tabs)
     want = np.array([O.fisher(*[int(x) for x in t])[2] for t in tabs])
-    assert (want < 1e-250).sum() > 100 and (want > 0.05).sum() > 100
+    assert (want < 1e-250).sum() > 50 and (want > 0.05).sum() > 100
     big = want > 1e-300
     assert np.allclose(lane[big], want[big], rtol=1e-7, atol=0) and np.allclose(group[big], want[big], rtol=1e-7, atol=0)
     assert np.allclose(lane[~big], want[~big], rtol=1e-6, atol=1e-320) and np.allclose(group[~big], want[~big], rtol=1e-6, atol=1e-320)
