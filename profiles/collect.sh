@@ -16,7 +16,7 @@ stats() {   # stats <name> <bench args...>: kernel trace + stats of one bench ru
 	local name=$1; shift
 	rm -rf /tmp/prof_$name
 	timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -o $name -- \
-		python3 $R/bench.py --no-cpu-baseline "$@" > $OUT/${name}_under_rocprof.json 2> $OUT/${name}_under_rocprof.log < /dev/null
+		python3 $R/bench.py --no-cpu-baseline --no-e2e "$@" > $OUT/${name}_under_rocprof.json 2> $OUT/${name}_under_rocprof.log < /dev/null
 	echo "$name stats rc=$?"
 	local f; f=$(find /tmp/prof_$name -name "*kernel_stats.csv" | head -1)
 	[ -n "$f" ] && cp "$f" $OUT/${name}_kernel_stats.csv && head -5 "$f" | cut -c1-220
@@ -25,7 +25,7 @@ pmc() {     # pmc <name> <counter list> <bench args...>: one counter pass, per-k
 	local name=$1 ctr=$2; shift 2
 	rm -rf /tmp/pmc_$name
 	timeout 900 rocprofv3 --pmc $ctr --output-format csv -d /tmp/pmc_$name -o $name -- \
-		python3 $R/bench.py --no-cpu-baseline "$@" > $OUT/${name}_pmc.json 2> $OUT/${name}_pmc.log < /dev/null
+		python3 $R/bench.py --no-cpu-baseline --no-e2e "$@" > $OUT/${name}_pmc.json 2> $OUT/${name}_pmc.log < /dev/null
 	echo "$name pmc rc=$?"
 	local f; f=$(find /tmp/pmc_$name -name "*counter_collection.csv" | head -1)
 	[ -n "$f" ] && python3 $R/profiles/sum_counters.py "$f" > $OUT/${name}_pmc_sums.json && cat $OUT/${name}_pmc_sums.json | head -60
@@ -50,6 +50,18 @@ for stage in "$@"; do
 		pmc cfg3_fetch FETCH_SIZE --steps 1 --warmup 0 --variants 16384
 		pmc cfg3_write WRITE_SIZE --steps 1 --warmup 0 --variants 16384
 		pmc cfg3_sq "SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" --steps 1 --warmup 0 --variants 16384
+		;;
+	patch_pmc)   # HBM read traffic of the count kernel against the shape of the tile patches (TWK_HIP_PATCH), 16,384 variants at N = 1 M
+		for shape in 8x8 16x32 32x16 23x23 32x32 8x64; do
+			TWK_HIP_PATCH=$shape pmc patch_$shape FETCH_SIZE --steps 1 --warmup 0 --variants 16384 > /dev/null
+			python3 - <<PY
+import json
+f = json.load(open("$OUT/patch_${shape}_pmc_sums.json")); r = json.load(open("$OUT/patch_${shape}_pmc.json"))
+k = next(x for x in f if "k_count_list" in x)
+gb = f[k]["FETCH_SIZE"] * 1024 * 2 / 1e9
+print("patch %-6s FETCH_SIZE x2 = %8.1f GB over %d launches (%.1f GB/launch), count kernel %.1f ms, %.1f M pairs/s" % ("$shape", gb, f[k]["launches"], gb / f[k]["launches"], r["kernel_ms"]["count"], r["value"] / 1e6))
+PY
+		done
 		;;
 	cfg2)
 		timeout 600 python3 $R/bench.py --config cfg2 --steps 20 --warmup 3 > $OUT/bench_cfg2.json 2> $OUT/bench_cfg2.log; cat $OUT/bench_cfg2.json

@@ -297,8 +297,8 @@ Geometry tile_geometry(int P, const twk_hip_tile_desc& t) {
 
 // The 128 x 128 tiles of a super-tile that hold wanted pairs, as (tile row << 16 | tile column):
 // on or above the diagonal (diag), and in window mode only those some row of the tile can reach.
-// Order: 8 x 8 patches of tiles, patch by patch - the blocks pull consecutive tickets, so the ~P tiles in
-// flight at any time are a few neighbouring patches (shared row / column tiles meet in L2 and the MALL).
+// Order: patches of 16 x 32 tiles, patch by patch - the blocks pull consecutive tickets, so the ~P tiles in
+// flight at any time are one patch or the end of one and the start of the next (shared row / column tiles meet in the MALL).
 void build_tile_list(const twk_hip_tile_desc& t, int P, const Geometry& g, bool diag, const ColRange* cr,
                      std::vector<uint32_t>& out) {
 	std::vector<uint32_t> x0(g.gy, 0), x1(g.gy, g.gx);
@@ -318,10 +318,20 @@ void build_tile_list(const twk_hip_tile_desc& t, int P, const Geometry& g, bool 
 	}
 	std::vector<uint32_t> seq;
 	seq.reserve((size_t)g.gx * g.gy);
-	for (uint32_t py = 0; py < g.gy; py += 8)
-		for (uint32_t px = 0; px < g.gx; px += 8)
-			for (uint32_t y = py; y < std::min(py + 8, g.gy); ++y)
-				for (uint32_t x = std::max(px, x0[y]); x < std::min(px + 8, x1[y]); ++x) seq.push_back(y << 16 | x);
+	// Patch shape: the ~512 tiles in flight should touch as few distinct row and column tiles as possible, because a row
+	// tile's chunks are re-read by every block that contracts a tile of that row - at different times, the blocks of a
+	// patch drift apart by hundreds of chunks over a long row - and what keeps those re-reads out of HBM is the MALL
+	// holding (distinct row + column tiles in flight) x (drift) chunks.  8 x 8 patches: 8 patches in flight, 128 distinct
+	// tiles; one 16 x 32 patch: 48.  (TWK_HIP_PATCH=RxC overrides, for the measurement in profiles/.)
+	uint32_t PR = 16, PC = 32;
+	if (const char* e = std::getenv("TWK_HIP_PATCH")) {
+		unsigned r = 0, cc = 0;
+		if (std::sscanf(e, "%ux%u", &r, &cc) == 2 && r >= 1 && cc >= 1 && r <= 4096 && cc <= 4096) { PR = r; PC = cc; }
+	}
+	for (uint32_t py = 0; py < g.gy; py += PR)
+		for (uint32_t px = 0; px < g.gx; px += PC)
+			for (uint32_t y = py; y < std::min(py + PR, g.gy); ++y)
+				for (uint32_t x = std::max(px, x0[y]); x < std::min(px + PC, x1[y]); ++x) seq.push_back(y << 16 | x);
 	out.swap(seq);
 }
 
