@@ -51,15 +51,17 @@ for stage in "$@"; do
 		pmc cfg3_write WRITE_SIZE --steps 1 --warmup 0 --variants 16384
 		pmc cfg3_sq "SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" --steps 1 --warmup 0 --variants 16384
 		;;
-	patch_pmc)   # HBM read traffic of the count kernel against the shape of the tile patches (TWK_HIP_PATCH), 16,384 variants at N = 1 M
-		for shape in 8x8 16x32 32x16 23x23 32x32 8x64; do
-			TWK_HIP_PATCH=$shape pmc patch_$shape FETCH_SIZE --steps 1 --warmup 0 --variants 16384 > /dev/null
+	patch_pmc)   # HBM read traffic of the count kernel against the shape of the tile patches (TWK_HIP_PATCH) and the length of the K
+		# segments the tiles of a patch advance by (TWK_HIP_SEG, 0 = whole tiles), 16,384 variants at N = 1 M
+		for combo in 8x8:0 16x32:0 8x8:64 16x32:64 16x32:32 16x32:128 32x32:64 16x64:64; do
+			shape=${combo%%:*}; seg=${combo##*:}
+			TWK_HIP_PATCH=$shape TWK_HIP_SEG=$seg pmc patch_${shape}_seg$seg FETCH_SIZE --steps 1 --warmup 0 --variants 16384 > /dev/null
 			python3 - <<PY
 import json
-f = json.load(open("$OUT/patch_${shape}_pmc_sums.json")); r = json.load(open("$OUT/patch_${shape}_pmc.json"))
+f = json.load(open("$OUT/patch_${shape}_seg${seg}_pmc_sums.json")); r = json.load(open("$OUT/patch_${shape}_seg${seg}_pmc.json"))
 k = next(x for x in f if "k_count_list" in x)
 gb = f[k]["FETCH_SIZE"] * 1024 * 2 / 1e9
-print("patch %-6s FETCH_SIZE x2 = %8.1f GB over %d launches (%.1f GB/launch), count kernel %.1f ms, %.1f M pairs/s" % ("$shape", gb, f[k]["launches"], gb / f[k]["launches"], r["kernel_ms"]["count"], r["value"] / 1e6))
+print("patch %-6s seg %3s FETCH_SIZE x2 = %8.1f GB over %d launches (%.1f GB/launch), count kernel %.1f ms, %.1f M pairs/s" % ("$shape", "$seg", gb, f[k]["launches"], gb / f[k]["launches"], r["kernel_ms"]["count"], r["value"] / 1e6))
 PY
 		done
 		;;

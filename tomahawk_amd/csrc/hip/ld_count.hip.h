@@ -369,25 +369,48 @@ struct CountWork {
 // of the shortest units of perfect balance however unequal the blocks' speeds are (measured: finish
 // times of the 512 blocks within 0.14 ms of each other on a 21 ms launch).  Returns the index of the
 // first tile that is split (tiles from there on must be zeroed before the launch); n_tiles if none.
+// Long rows, segmented walk (seg_chunks != 0, rows of at least two segments, patch_end = the list index where each
+// patch of tiles ends): the tiles of a patch - which share their row and column tiles - are not contracted one whole
+// tile per block, each block at its own pace, but K segment by K segment: all tiles of the patch over chunks
+// [0, seg), then all over [seg, 2 seg), ...  The blocks working on a patch are then always within a segment of each
+// other, so a chunk of a row tile fetched for one block is still in the MALL (and often in L2) when the other blocks
+// that need it come by: HBM sees every (row tile, segment) about once per patch instead of once per tile.  The price:
+// every unit is a part of its tile's K range (counts added with atomics into zeroed tiles - 32 adds per lane per
+// segment, nothing next to the segment's 2048 x seg VALU ops).
 template <class Vec>
 inline uint32_t build_count_units(uint32_t n_tiles, uint32_t nchunks, uint32_t n_blocks, uint32_t min_chunks, Vec& units,
-                                  uint32_t share_div = 8, uint32_t tail_rounds = 8) {
+                                  uint32_t share_div = 8, uint32_t tail_rounds = 8,
+                                  const uint32_t* patch_end = nullptr, uint32_t n_patches = 0, uint32_t seg_chunks = 0) {
 	units.clear();
 	const uint32_t tail = (uint32_t)(n_tiles < (unsigned long long)tail_rounds * n_blocks ? n_tiles : (unsigned long long)tail_rounds * n_blocks);
 	uint32_t first_split = n_tiles - tail;
 	if (nchunks < 2 * min_chunks) first_split = n_tiles;             // rows too short to be worth splitting
-	for (uint32_t t = 0; t < first_split; ++t) units.push_back(CountUnit{t, 0, nchunks, 0});
+	const bool segmented = seg_chunks && patch_end && n_patches && nchunks >= 2 * seg_chunks && nchunks >= 2 * min_chunks;
+	if (segmented) {
+		const uint32_t nseg = (nchunks + seg_chunks - 1) / seg_chunks;
+		uint32_t p0 = 0;
+		for (uint32_t p = 0; p < n_patches && p0 < first_split; ++p) {
+			const uint32_t p1 = patch_end[p] < first_split ? patch_end[p] : first_split;
+			for (uint32_t sgm = 0; sgm < nseg; ++sgm)
+				for (uint32_t t = p0; t < p1; ++t)
+					units.push_back(CountUnit{t, (uint32_t)((unsigned long long)nchunks * sgm / nseg), (uint32_t)((unsigned long long)nchunks * (sgm + 1) / nseg), 0});
+			p0 = p1;
+		}
+	} else {
+		for (uint32_t t = 0; t < first_split; ++t) units.push_back(CountUnit{t, 0, nchunks, 0});
+	}
 	for (uint32_t t = first_split; t < n_tiles; ++t) {
 		const unsigned long long rem = (unsigned long long)(n_tiles - t) * nchunks;      // chunks left, this tile included
 		unsigned long long target = rem / ((unsigned long long)share_div * n_blocks);
 		if (target < min_chunks) target = min_chunks;
+		if (segmented && target > seg_chunks) target = seg_chunks;
 		uint32_t S = (uint32_t)((nchunks + target - 1) / target);
 		if (S < 1) S = 1;
 		if (S > nchunks) S = nchunks;
 		for (uint32_t k = 0; k < S; ++k)
 			units.push_back(CountUnit{t, (uint32_t)((unsigned long long)nchunks * k / S), (uint32_t)((unsigned long long)nchunks * (k + 1) / S), 0});
 	}
-	return first_split;
+	return segmented ? 0 : first_split;
 }
 
 // What a block does with the 8 x TB counts each of its lanes holds when a unit ends.  StoreCounts is the plain form:

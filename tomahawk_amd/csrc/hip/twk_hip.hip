@@ -286,6 +286,8 @@ int ensure_host_records(twk_hip_ctx* c, unsigned long long n) {
 // count -> screen kernel: at that length a tile is never worth splitting, and the C round trip plus the
 // one-thread-per-pair math front end cost as much as the counting itself.
 constexpr uint32_t FUSED_MAX_CHUNKS = 16;
+// Long rows: the tiles of a patch advance through K in segments of this many chunks (ld_count.hip.h build_count_units).
+constexpr uint32_t COUNT_SEG_CHUNKS = 64;
 
 struct Geometry { uint32_t rowsA, rowsB, gx, gy, ldc; };
 Geometry tile_geometry(int P, const twk_hip_tile_desc& t) {
@@ -300,7 +302,7 @@ Geometry tile_geometry(int P, const twk_hip_tile_desc& t) {
 // Order: patches of 16 x 32 tiles, patch by patch - the blocks pull consecutive tickets, so the ~P tiles in
 // flight at any time are one patch or the end of one and the start of the next (shared row / column tiles meet in the MALL).
 void build_tile_list(const twk_hip_tile_desc& t, int P, const Geometry& g, bool diag, const ColRange* cr,
-                     std::vector<uint32_t>& out) {
+                     std::vector<uint32_t>& out, std::vector<uint32_t>* patch_end = nullptr) {
 	std::vector<uint32_t> x0(g.gy, 0), x1(g.gy, g.gx);
 	for (uint32_t by = 0; by < g.gy; ++by) {
 		if (diag) x0[by] = by;
@@ -328,10 +330,13 @@ void build_tile_list(const twk_hip_tile_desc& t, int P, const Geometry& g, bool 
 		unsigned r = 0, cc = 0;
 		if (std::sscanf(e, "%ux%u", &r, &cc) == 2 && r >= 1 && cc >= 1 && r <= 4096 && cc <= 4096) { PR = r; PC = cc; }
 	}
+	if (patch_end) patch_end->clear();
 	for (uint32_t py = 0; py < g.gy; py += PR)
-		for (uint32_t px = 0; px < g.gx; px += PC)
+		for (uint32_t px = 0; px < g.gx; px += PC) {
 			for (uint32_t y = py; y < std::min(py + PR, g.gy); ++y)
 				for (uint32_t x = std::max(px, x0[y]); x < std::min(px + PC, x1[y]); ++x) seq.push_back(y << 16 | x);
+			if (patch_end && (patch_end->empty() ? !seq.empty() : seq.size() > patch_end->back())) patch_end->push_back((uint32_t)seq.size());
+		}
 	out.swap(seq);
 }
 
@@ -353,8 +358,8 @@ int launch_count(twk_hip_ctx* c, int set, const twk_hip_tile_desc& t, Slot& s, i
 	if (g.gx > 0xFFFFu || g.gy > 0xFFFFu) return TWK_HIP_E_INVALID;
 	const bool diag = t.diag && t.rowA0 == t.rowB0;
 	const uint32_t n_blocks = c->resident_blocks;
-	std::vector<uint32_t> list;
-	build_tile_list(t, P, g, diag, cr, list);
+	std::vector<uint32_t> list, patch_end;
+	build_tile_list(t, P, g, diag, cr, list, &patch_end);
 	const size_t T = list.size();
 	// units of work: see build_count_units (ld_count.hip.h)
 	const uint32_t nchunks = ps.W / KC;
@@ -372,7 +377,10 @@ int launch_count(twk_hip_ctx* c, int set, const twk_hip_tile_desc& t, Slot& s, i
 	}
 	if (fused) *fused = fuse;
 	std::vector<CountUnit> units;
-	const uint32_t first_split = T ? build_count_units((uint32_t)T, nchunks, n_blocks, min_chunks, units) : 0;
+	uint32_t seg_chunks = COUNT_SEG_CHUNKS;
+	if (const char* e = std::getenv("TWK_HIP_SEG")) seg_chunks = (uint32_t)std::strtoul(e, nullptr, 10);     // 0: whole tiles (measurement hook)
+	if (fuse) seg_chunks = 0;
+	const uint32_t first_split = T ? build_count_units((uint32_t)T, nchunks, n_blocks, min_chunks, units, 8, 8, patch_end.data(), (uint32_t)patch_end.size(), seg_chunks) : 0;
 	const size_t T4 = (T + 3) / 4 * 4, words_units = T4 + units.size() * 4;       // [tiles | pad | units], units 16-byte aligned
 	const size_t fa_words = (sizeof(FusedArgs) + 15) / 16 * 4;
 	const size_t words = words_units + (fuse ? fa_words : 0);                    // [... | FusedArgs] for a fused launch
