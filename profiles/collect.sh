@@ -53,15 +53,16 @@ for stage in "$@"; do
 		;;
 	patch_pmc)   # HBM read traffic of the count kernel against the shape of the tile patches (TWK_HIP_PATCH) and the length of the K
 		# segments the tiles of a patch advance by (TWK_HIP_SEG, 0 = whole tiles), 16,384 variants at N = 1 M
-		for combo in 8x8:0 16x32:0 8x8:64 16x32:64 16x32:32 16x32:128 32x32:64 16x64:64; do
-			shape=${combo%%:*}; seg=${combo##*:}
-			TWK_HIP_PATCH=$shape TWK_HIP_SEG=$seg pmc patch_${shape}_seg$seg FETCH_SIZE --steps 1 --warmup 0 --variants 16384 > /dev/null
+		# and, with segments, one unit queue per XCD (TWK_HIP_XCD_QUEUES=8: patches dealt round robin to the XCDs)
+		for combo in ${PATCH_COMBOS:-8x8:0:0 16x32:0:0 8x8:64:0 16x32:64:0 8x8:64:8 8x8:32:8 8x8:16:8 8x8:8:8 4x16:16:8 8x16:16:8}; do
+			shape=${combo%%:*}; rest=${combo#*:}; seg=${rest%%:*}; nq=${rest##*:}
+			TWK_HIP_PATCH=$shape TWK_HIP_SEG=$seg TWK_HIP_XCD_QUEUES=$nq pmc patch_${shape}_seg${seg}_q$nq FETCH_SIZE --steps 1 --warmup 0 --variants 16384 > /dev/null
 			python3 - <<PY
 import json
-f = json.load(open("$OUT/patch_${shape}_seg${seg}_pmc_sums.json")); r = json.load(open("$OUT/patch_${shape}_seg${seg}_pmc.json"))
+f = json.load(open("$OUT/patch_${shape}_seg${seg}_q${nq}_pmc_sums.json")); r = json.load(open("$OUT/patch_${shape}_seg${seg}_q${nq}_pmc.json"))
 k = next(x for x in f if "k_count_list" in x)
 gb = f[k]["FETCH_SIZE"] * 1024 * 2 / 1e9
-print("patch %-6s seg %3s FETCH_SIZE x2 = %8.1f GB over %d launches (%.1f GB/launch), count kernel %.1f ms, %.1f M pairs/s" % ("$shape", "$seg", gb, f[k]["launches"], gb / f[k]["launches"], r["kernel_ms"]["count"], r["value"] / 1e6))
+print("patch %-6s seg %3s queues %s FETCH_SIZE x2 = %8.1f GB over %d launches (%.1f GB/launch), count kernel %.1f ms, %.1f M pairs/s" % ("$shape", "$seg", "$nq", gb, f[k]["launches"], gb / f[k]["launches"], r["kernel_ms"]["count"], r["value"] / 1e6))
 PY
 		done
 		;;

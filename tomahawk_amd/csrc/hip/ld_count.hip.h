@@ -359,7 +359,11 @@ struct CountWork {
 	const CountUnit* units;                // [n_units], in the order they are handed out
 	uint32_t n_units;
 	uint32_t* C; uint32_t ldc;             // counts of the super-tile
-	uint32_t* ticket;                      // zeroed before the launch
+	uint32_t* ticket;                      // [n_queues], zeroed before the launch
+	// One queue: units[0, n_units) in order.  Several (long rows, one per XCD): queue q is units[queue_begin[q],
+	// queue_begin[q + 1]); a block starts on the queue of the XCD it runs on and moves on to the next when that is empty.
+	uint32_t n_queues;
+	uint32_t queue_begin[9];
 };
 
 // The unit table of a launch (host side; shared by the engine and the dev tools).  Guided self-scheduling:
@@ -456,9 +460,27 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 		tl = __builtin_amdgcn_readfirstlane(cu.tile); c0 = __builtin_amdgcn_readfirstlane(cu.c0); c1 = __builtin_amdgcn_readfirstlane(cu.c1);
 	};
 
+	// Drawing a unit (thread 0): the next ticket of the block's queue; with one queue per XCD the queue of the XCD this
+	// block runs on - whose L2 then holds the row and column tiles its 64 blocks share - and, once that is empty, the
+	// next one that still has work.
+	uint32_t my_q = 0;
+	if (w.n_queues > 1) {
+		uint32_t xcc;
+		asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+		my_q = (xcc & 0xFu) % w.n_queues;
+	}
+	auto draw = [&]() -> uint32_t {
+		if (w.n_queues <= 1) return atomicAdd(w.ticket, 1u);
+		for (uint32_t k = 0; k < w.n_queues; ++k) {
+			const uint32_t q = my_q + k < w.n_queues ? my_q + k : my_q + k - w.n_queues;
+			const uint32_t t = atomicAdd(w.ticket + q, 1u);
+			if (t < w.queue_begin[q + 1] - w.queue_begin[q]) { my_q = q; return w.queue_begin[q] + t; }
+		}
+		return 0xFFFFFFFFu;
+	};
 	// the first ticket of the block
 	uint32_t fetched = 0;                       // thread 0: the ticket in flight (the next unit)
-	if (tid == 0) mbox[0] = atomicAdd(w.ticket, 1u);
+	if (tid == 0) mbox[0] = draw();
 	__syncthreads();
 	uint32_t unit = __builtin_amdgcn_readfirstlane(mbox[0]);
 	if (unit >= n_units) return;
@@ -514,7 +536,7 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 			// unit has to wait for it here.  A block thus never holds more than its current and next unit,
 			// which keeps the slow block of a CU from sitting on big units drawn long ago.
 			++n_started;
-			if (tid == 0) fetched = atomicAdd(w.ticket, 1u);
+			if (tid == 0) fetched = draw();
 			if (c + 1 == c_end) {
 				if (tid == 0) mbox[n_started & 1u] = fetched;
 				__syncthreads();

@@ -113,7 +113,7 @@ struct twk_hip_ctx {
 	twk_hip_progress_cb progress_cb = nullptr; void* progress_user = nullptr;
 	bool progress_muted = false;       // second stage of a default-mode run: its pairs were already counted
 	uint32_t resident_blocks = 512;   // count-kernel blocks the chip holds at once (2 per CU)
-	uint32_t* tickets = nullptr;      // [6] work tickets of the count launches: one per (slot, launch)
+	uint32_t* tickets = nullptr;      // [6][8] work tickets of the count launches: one set of queues per (slot, launch)
 	// staging of twk_hip_upload_rle (grow-only): run bytes, descriptors, status word
 	uint8_t* d_rle = nullptr; size_t d_rle_cap = 0;
 	uint8_t* d_rle_desc = nullptr; size_t d_rle_desc_cap = 0;
@@ -286,8 +286,6 @@ int ensure_host_records(twk_hip_ctx* c, unsigned long long n) {
 // count -> screen kernel: at that length a tile is never worth splitting, and the C round trip plus the
 // one-thread-per-pair math front end cost as much as the counting itself.
 constexpr uint32_t FUSED_MAX_CHUNKS = 16;
-// Long rows: the tiles of a patch advance through K in segments of this many chunks (ld_count.hip.h build_count_units).
-constexpr uint32_t COUNT_SEG_CHUNKS = 64;
 
 struct Geometry { uint32_t rowsA, rowsB, gx, gy, ldc; };
 Geometry tile_geometry(int P, const twk_hip_tile_desc& t) {
@@ -299,8 +297,8 @@ Geometry tile_geometry(int P, const twk_hip_tile_desc& t) {
 
 // The 128 x 128 tiles of a super-tile that hold wanted pairs, as (tile row << 16 | tile column):
 // on or above the diagonal (diag), and in window mode only those some row of the tile can reach.
-// Order: patches of 16 x 32 tiles, patch by patch - the blocks pull consecutive tickets, so the ~P tiles in
-// flight at any time are one patch or the end of one and the start of the next (shared row / column tiles meet in the MALL).
+// Order: 8 x 8 patches of tiles, patch by patch - the blocks pull consecutive tickets, so the ~P tiles in
+// flight at any time are a few neighbouring patches (shared row / column tiles meet in L2 and the MALL).
 void build_tile_list(const twk_hip_tile_desc& t, int P, const Geometry& g, bool diag, const ColRange* cr,
                      std::vector<uint32_t>& out, std::vector<uint32_t>* patch_end = nullptr) {
 	std::vector<uint32_t> x0(g.gy, 0), x1(g.gy, g.gx);
@@ -320,12 +318,14 @@ void build_tile_list(const twk_hip_tile_desc& t, int P, const Geometry& g, bool 
 	}
 	std::vector<uint32_t> seq;
 	seq.reserve((size_t)g.gx * g.gy);
-	// Patch shape: the ~512 tiles in flight should touch as few distinct row and column tiles as possible, because a row
-	// tile's chunks are re-read by every block that contracts a tile of that row - at different times, the blocks of a
-	// patch drift apart by hundreds of chunks over a long row - and what keeps those re-reads out of HBM is the MALL
-	// holding (distinct row + column tiles in flight) x (drift) chunks.  8 x 8 patches: 8 patches in flight, 128 distinct
-	// tiles; one 16 x 32 patch: 48.  (TWK_HIP_PATCH=RxC overrides, for the measurement in profiles/.)
-	uint32_t PR = 16, PC = 32;
+	// Patch shape 8 x 8.  Measured (profiles/r03_patch_pmc.txt, FETCH_SIZE = what the L2s ask the fabric for, 16,384 variants
+	// at N = 1 M, 1.05 TB of tile-level demand per launch): 8 x 8 patches 258 GB per launch; wider patches are *worse*
+	// (16 x 32: 309 GB), and so is walking a patch K segment by K segment (TWK_HIP_SEG=64: 306 GB) - the tiles in flight
+	// are spread over eight L2s by the dispatcher, so fewer distinct row tiles in flight buys nothing per L2.  What does
+	// help is giving each XCD its own patches (TWK_HIP_XCD_QUEUES=8 with 64-chunk segments: 149 GB, -42 %), at +0.5 % kernel
+	// time for the adds into C; since the kernel is VALU-bound and the fabric sees < 10 % of its rate either way, that
+	// trade is not taken by default.  (TWK_HIP_PATCH=RxC / TWK_HIP_SEG / TWK_HIP_XCD_QUEUES are the hooks of that measurement.)
+	uint32_t PR = 8, PC = 8;
 	if (const char* e = std::getenv("TWK_HIP_PATCH")) {
 		unsigned r = 0, cc = 0;
 		if (std::sscanf(e, "%ux%u", &r, &cc) == 2 && r >= 1 && cc >= 1 && r <= 4096 && cc <= 4096) { PR = r; PC = cc; }
@@ -377,10 +377,32 @@ int launch_count(twk_hip_ctx* c, int set, const twk_hip_tile_desc& t, Slot& s, i
 	}
 	if (fused) *fused = fuse;
 	std::vector<CountUnit> units;
-	uint32_t seg_chunks = COUNT_SEG_CHUNKS;
-	if (const char* e = std::getenv("TWK_HIP_SEG")) seg_chunks = (uint32_t)std::strtoul(e, nullptr, 10);     // 0: whole tiles (measurement hook)
+	uint32_t seg_chunks = 0;                    // whole tiles (see build_tile_list for the measurement behind that)
+	if (const char* e = std::getenv("TWK_HIP_SEG")) seg_chunks = (uint32_t)std::strtoul(e, nullptr, 10);     // measurement hook: K segments of this many chunks
 	if (fuse) seg_chunks = 0;
-	const uint32_t first_split = T ? build_count_units((uint32_t)T, nchunks, n_blocks, min_chunks, units, 8, 8, patch_end.data(), (uint32_t)patch_end.size(), seg_chunks) : 0;
+	uint32_t first_split = 0, n_queues = 1, queue_begin[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+	uint32_t xcd_queues = 0;
+	if (const char* e = std::getenv("TWK_HIP_XCD_QUEUES")) xcd_queues = (uint32_t)std::strtoul(e, nullptr, 10);    // measurement hook (profiles/): one unit queue per XCD
+	if (T && !fuse && xcd_queues > 1 && xcd_queues <= 8 && nchunks >= 128 && !patch_end.empty()) {
+		// patches dealt round robin to the queues; within a queue patch after patch, each K segment by K segment
+		const uint32_t nseg = seg_chunks ? (nchunks + seg_chunks - 1) / seg_chunks : 1;
+		std::vector<std::vector<CountUnit>> qs(xcd_queues);
+		uint32_t p0 = 0;
+		for (size_t pi = 0; pi < patch_end.size(); ++pi) {
+			auto& qv = qs[pi % xcd_queues];
+			for (uint32_t sgm = 0; sgm < nseg; ++sgm)
+				for (uint32_t tl = p0; tl < patch_end[pi]; ++tl)
+					qv.push_back(CountUnit{tl, (uint32_t)((unsigned long long)nchunks * sgm / nseg), (uint32_t)((unsigned long long)nchunks * (sgm + 1) / nseg), 0});
+			p0 = patch_end[pi];
+		}
+		n_queues = xcd_queues;
+		for (uint32_t q = 0; q < n_queues; ++q) { queue_begin[q] = (uint32_t)units.size(); units.insert(units.end(), qs[q].begin(), qs[q].end()); }
+		for (uint32_t q = n_queues; q <= 8; ++q) queue_begin[q] = (uint32_t)units.size();
+		first_split = nseg > 1 ? 0 : (uint32_t)T;
+	} else {
+		first_split = T ? build_count_units((uint32_t)T, nchunks, n_blocks, min_chunks, units, 8, 8, patch_end.data(), (uint32_t)patch_end.size(), seg_chunks) : 0;
+		queue_begin[1] = (uint32_t)units.size();
+	}
 	const size_t T4 = (T + 3) / 4 * 4, words_units = T4 + units.size() * 4;       // [tiles | pad | units], units 16-byte aligned
 	const size_t fa_words = (sizeof(FusedArgs) + 15) / 16 * 4;
 	const size_t words = words_units + (fuse ? fa_words : 0);                    // [... | FusedArgs] for a fused launch
@@ -406,8 +428,10 @@ int launch_count(twk_hip_ctx* c, int set, const twk_hip_tile_desc& t, Slot& s, i
 		w.tiles = s.d_tiles[which];
 		w.units = reinterpret_cast<const CountUnit*>(s.d_tiles[which] + T4); w.n_units = (uint32_t)units.size();
 		w.C = s.C; w.ldc = g.ldc;
-		w.ticket = c->tickets + ((&s - c->slot) * 2 + which);
-		HIPCHK(c, hipMemsetAsync(w.ticket, 0, 4, c->s_compute));
+		w.ticket = c->tickets + ((&s - c->slot) * 2 + which) * 8;
+		w.n_queues = n_queues;
+		for (int q = 0; q < 9; ++q) w.queue_begin[q] = queue_begin[q];
+		HIPCHK(c, hipMemsetAsync(w.ticket, 0, 8 * 4, c->s_compute));
 		if (first_split < T) {
 			hipLaunchKernelGGL(k_zero_tiles, dim3((uint32_t)T - first_split), dim3(256), 0, c->s_compute, w.tiles, first_split, w.C, w.ldc);
 			HIPCHK(c, hipGetLastError());
@@ -794,7 +818,7 @@ int twk_hip_ctx_create(int device, twk_hip_ctx** out) {
 	}
 	if (hipStreamCreateWithFlags(&c->s_compute, hipStreamNonBlocking) != hipSuccess) return fail(TWK_HIP_E_DEVICE);
 	if (hipStreamCreateWithFlags(&c->s_copy, hipStreamNonBlocking) != hipSuccess) return fail(TWK_HIP_E_DEVICE);
-	if (hipMalloc((void**)&c->tickets, 6 * sizeof(uint32_t)) != hipSuccess) return fail(TWK_HIP_E_NOMEM);
+	if (hipMalloc((void**)&c->tickets, 6 * 8 * sizeof(uint32_t)) != hipSuccess) return fail(TWK_HIP_E_NOMEM);
 	for (auto& s : c->slot) {
 		hipEvent_t* evs[] = {&s.ev_c0, &s.ev_c1, &s.ev_s1, &s.ev_c0b, &s.ev_c1b};
 		for (auto* e : evs) if (hipEventCreate(e) != hipSuccess) return fail(TWK_HIP_E_DEVICE);
