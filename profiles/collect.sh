@@ -107,6 +107,12 @@ PY
 		f=$(find /tmp/prof_math -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/kg_kernel_stats.csv && head -8 "$f" | cut -c1-160
 		grep "Finished\|HIP\]\|WRITER\]" $OUT/kg_under_rocprof.log | cut -c1-300
 		;;
+	t2_list)  # T2 evidence: a rare pair as a sorted carrier-list intersection against the dense contraction (csrc/tools/list_vs_dense.hip)
+		: > $OUT/t2_list_vs_dense.txt
+		for ac in 2 10 100 1000 10000; do timeout 600 $R/build/list_vs_dense 2000000 $ac 4096 3 >> $OUT/t2_list_vs_dense.txt 2>&1; done
+		for ac in 2 10 100 1000; do timeout 600 $R/build/list_vs_dense 5008 $ac 16384 3 >> $OUT/t2_list_vs_dense.txt 2>&1; done
+		cat $OUT/t2_list_vs_dense.txt
+		;;
 	kg_prof)  # the small-N regime (the reference's published shape, 2,504 samples x 200,000 cohort-shaped variants): kernel traces of
 		# `calc -p -w 1000000` (33 M surviving pairs) and of all-vs-all `-r 0.8` without the allele-count band, each with the
 		# fused count -> r2 screen kernel (default) and without it (TWK_HIP_FUSED=0)
