@@ -42,6 +42,17 @@ run(f"1M x {M1} cohort calc -u, 2 driver threads on one GPU", twk, ["-u", "-t", 
 for args in (["-t", str(threads)], ["-u", "-t", str(threads)]):
     run(f"1M x {M1} cohort calc {' '.join(args[:1]) if args[0] != '-t' else '(default)'} WITHOUT the r2 screen", twk, args, {"TWK_HIP_NO_SCREEN": "1"})
 
+# the regime the r2 screen cannot help: a cut-off below its threshold (r2 >= 0.001 is where it switches on) - every pair of the
+# rare-heavy input is contracted densely (the T2 row of SURVEY 8a: the reference's list kernels are O(carriers) there)
+if M1 > 8192:
+    twk_s = "/tmp/cohort_1m_8192.twk"
+    if not os.path.exists(twk_s):
+        H.write_cohort_twk(twk_s, 1_000_000, 8192, seed=11, n_threads=threads, block_size=128)
+else:
+    twk_s = twk
+for args in (["-r", "0.0009", "-t", str(threads)], ["-r", "0.1", "-t", str(threads)]):
+    run(f"1M x {min(M1, 8192)} cohort calc (default) {' '.join(args[:2])}" + (" [below the screen's threshold: every pair contracted]" if args[1] == "0.0009" else " [screen on]"), twk_s, args)
+
 twk2 = "/tmp/kg_2504_200k.twk"
 if not os.path.exists(twk2):
     t = time.time(); H.write_cohort_twk(twk2, 2504, 200_000, seed=12, n_threads=threads, block_size=500, spacing=100)
