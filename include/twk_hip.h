@@ -279,6 +279,10 @@ typedef struct {
 	uint64_t fused_launches;/* count launches that ran the fused count -> r2 screen form (short rows,
 	                           phased math: no count matrix, candidates only)    */
 	uint64_t candidates;    /* pairs those launches handed to the math kernel    */
+	double   list_ms;       /* sum of carrier-list intersection kernel durations (rare variants at very large sample
+	                           counts: the device's twk_igt_list / PhasedListVector, core.h:517-672, ld_engine.cpp:185-267) */
+	uint64_t list_launches;
+	uint64_t list_pairs;    /* variant pairs decided by list intersection instead of the dense contraction */
 } twk_hip_timing;
 /* Progress of twk_hip_ld_all / twk_hip_ld_region: `cb` runs on the calling thread after every tile
  * with the variant pairs finished so far in the current call and the tile counts.  Replaces the

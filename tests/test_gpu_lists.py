@@ -1,0 +1,92 @@
+"""Rare variants as carrier lists (ld_list.hip.h: k_build_lists + k_list_screen): the device's answer to the reference's
+twk_igt_list / PhasedListVector (include/core.h:517-672, lib/ld/ld_engine.cpp:185-267) for very large sample counts.  The
+pairs of the list zone are intersected instead of contracted; the records must be those of the dense path, bit for bit,
+and those of the oracle."""
+import numpy as np
+import pytest
+
+import tomahawk_amd as T
+from oracle import oracle as O
+from tests import util
+from tests.test_gpu_configs import _cohort_alleles
+
+pytestmark = pytest.mark.gpu
+ORDER = ["idxA", "idxB"]
+
+
+def _with_flips(al, seed):
+    """Turn a few rare variants into their complements (ALT frequency near 1: the minor allele is REF)."""
+    rng = np.random.default_rng(seed)
+    M = al.shape[0]
+    ac = (al == 1).sum(axis=(1, 2))
+    rare = np.nonzero((ac > 0) & (ac < 40))[0]
+    for v in rng.choice(rare, size=min(len(rare) // 6, 60), replace=False):
+        al[v] = 1 - al[v]
+    return al
+
+
+def _run(hip, monkeypatch, lists_env, data, mask, variants, calls):
+    monkeypatch.setenv("TWK_HIP_LISTS", lists_env)
+    N = variants_n = None
+    hip.set_problem(_run.N, len(variants))
+    hip.upload(data, util.to_hip_meta(variants), mask)
+    out = []
+    for call in calls:
+        hip.timing_reset()
+        recs = call()
+        out.append((recs, hip.timing()))
+    monkeypatch.delenv("TWK_HIP_LISTS")
+    return out
+
+
+@pytest.mark.parametrize("N,forced", [(66_000, False), (1500, True)])
+def test_list_zone_equals_dense_and_oracle(hip, monkeypatch, N, forced):
+    """N = 66,000: rows of 4,128 words, lists of up to 32 carriers are kept by default.  N = 1,500 with TWK_HIP_LISTS=2:
+    the list pass next to the fused count kernel (short rows), whose epilogue must leave the zone's pairs alone."""
+    M = 1500 if not forced else 2200
+    al = _with_flips(_cohort_alleles(M, N, 900 + N), 5)
+    data, mask = O.bitvectors_from_alleles(al)
+    variants = O.variants_from_alleles(al)
+    _run.N = N
+    calls = [lambda: hip.ld_all(T.MODE_PHASED, T.Filters(minR2=0.1), window=T.OPT_R2_SCREEN)[0],
+             lambda: hip.ld_all(T.MODE_AUTO, T.Filters(minR2=0.5), window=T.OPT_R2_SCREEN)[0],
+             lambda: hip.ld_all(T.MODE_PHASED, T.Filters(minR2=0.004), window=T.OPT_R2_SCREEN)[0],
+             lambda: np.concatenate([hip.ld_all(T.MODE_PHASED, T.Filters(minR2=0.1), part=k, n_parts=3, window=T.OPT_R2_SCREEN)[0] for k in range(3)]),
+             lambda: hip.ld_all(T.MODE_PHASED, T.Filters(minR2=0.1, minP=1e-8), window=T.OPT_R2_SCREEN)[0]]
+    dense = _run(hip, monkeypatch, "0", data, None, variants, calls)
+    lists = _run(hip, monkeypatch, "2" if forced else "1", data, None, variants, calls)
+    for k, ((a, ta), (b, tb)) in enumerate(zip(dense, lists)):
+        assert ta["list_launches"] == 0 and tb["list_launches"] > 0 and tb["list_pairs"] > 10_000, (k, tb)
+        assert len(a) == len(b) > 20, k
+        assert np.sort(a, order=ORDER).tobytes() == np.sort(b, order=ORDER).tobytes(), k
+        if k == 0:
+            assert tb["row_pairs"] < ta["row_pairs"]          # the zone's tiles were not contracted
+    # the oracle on the rarest variants (the zone) plus a sample of the rest
+    ac = np.minimum(variants["ac"], 2 * N - variants["ac"])
+    rare = np.argsort(ac, kind="stable")[:160]
+    sub = np.sort(np.concatenate([rare, np.random.default_rng(1).choice(np.setdiff1d(np.arange(M), rare), size=100, replace=False)]))
+    monkeypatch.setenv("TWK_HIP_LISTS", "2")
+    hip.set_problem(N, len(sub))
+    hip.upload(data[sub], util.to_hip_meta(variants[sub]), None)
+    hip.timing_reset()
+    got, _, _ = hip.ld_all(T.MODE_PHASED, T.Filters(minR2=0.05), window=T.OPT_R2_SCREEN)
+    assert hip.timing()["list_launches"] > 0
+    monkeypatch.delenv("TWK_HIP_LISTS")
+    want = O.all_pairs(data[sub], None, variants[sub], N, O.settings(minR2=0.05, phased=True), vector_only=False)
+    assert len(want) > 20
+    util.assert_records_match(got, want, variants[sub])
+
+
+def test_list_zone_with_missing_data_in_default_mode(hip, monkeypatch):
+    """Default mode with missing genotypes: the screened stage runs over the missing-free head of the sorted set - lists
+    there - and the variants with missing data go through the masked unphased planes as before."""
+    N, M = 66_000, 1100
+    al = _cohort_alleles(M, N, 77, miss=True)
+    data, mask = O.bitvectors_from_alleles(al)
+    variants = O.variants_from_alleles(al)
+    _run.N = N
+    calls = [lambda: hip.ld_all(T.MODE_AUTO, T.Filters(minR2=0.2), window=T.OPT_R2_SCREEN)[0]]
+    (a, ta), = _run(hip, monkeypatch, "0", data, mask, variants, calls)
+    (b, tb), = _run(hip, monkeypatch, "1", data, mask, variants, calls)
+    assert tb["list_launches"] > 0 and ta["list_launches"] == 0 and len(a) == len(b) > 20
+    assert np.sort(a, order=ORDER).tobytes() == np.sort(b, order=ORDER).tobytes()

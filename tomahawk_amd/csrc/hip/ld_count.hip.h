@@ -625,6 +625,7 @@ struct ScreenWork {
 	uint32_t a0, b0, nA, nB;           // set positions of the super-tile's first row / column, variants on each axis
 	uint32_t n_variants; int diag;
 	const uint32_t* col_hi; uint32_t hi_a0, hi_b0;       // r2 band (twk_hip.hip region_impl): row at set position a reaches columns < hi_b0 + col_hi[a - hi_a0]
+	uint32_t list_zone;                // pairs with both set positions below it belong to the carrier-list pass (ld_list.hip.h)
 	double two_n, cut;                 // 2N; minR2 * (1 - 1e-6)
 	uint32_t* cand; unsigned long long cap;            // [cap][3]: set position A, set position B, AA
 	unsigned long long* n_cand;        // device counter (may run past cap: the host then redoes the tile the plain way)
@@ -658,6 +659,7 @@ struct ScreenCounts {
 			hiA[t] = !ok ? 0u : (s.col_hi ? s.hi_b0 + s.col_hi[sA - s.hi_a0] : 0xFFFFFFFFu);
 		}
 		const bool diag = s.diag != 0;
+		const uint32_t zone = s.list_zone;
 		uint32_t m = 0;                  // bit 4t + u: pair (t, u) is a candidate
 #pragma unroll
 		for (int t = 0; t < 8; ++t) {
@@ -669,7 +671,7 @@ struct ScreenCounts {
 				const uint32_t sB = b0 + c0 + 8 * u;
 				const double b = (double)acB[u];
 				const double dn = two_n * (double)acc[t][u] - a * b;
-				const bool ok = (!diag || sB > sA) && sB < hiA[t] && dn != 0.0 && dn * dn >= fA * (b * (two_n - b));
+				const bool ok = (!diag || sB > sA) && sB < hiA[t] && !(sA < zone && sB < zone) && dn != 0.0 && dn * dn >= fA * (b * (two_n - b));
 				m |= (ok ? 1u : 0u) << (4 * t + u);
 			}
 		}

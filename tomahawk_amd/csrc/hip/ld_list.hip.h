@@ -1,0 +1,122 @@
+// Rare variants as sorted carrier lists: the device counterpart of the reference's twk_igt_list (include/core.h:368-692,
+// built at :517-672) and of PhasedListVector (lib/ld/ld_engine.cpp:185-267), for very large sample counts.
+//
+// The dense contraction decides a pair in time proportional to the row length W (62,528 words at N = 1 M: 2.55 ns), a
+// merge of two sorted carrier lists in time proportional to the carriers (about 2.5 ps per merge step,
+// profiles/r03_t2_list_vs_dense.txt): at N = 1 M the lists win below ~400 carriers per variant (5x at 100, 100x at 10),
+// at N = 2,504 they never do (a dense pair costs 7 ps).  So this path exists for long rows only: the variants of the
+// allele-count-sorted plane set (the r2 screen's order, twk_hip.hip) whose minor allele has at most L carriers - they
+// lead that set, as the "list zone" - get a list of the haplotypes that carry their *minor* allele, and the pairs inside
+// the zone (and inside the r2 band) are intersected instead of contracted:
+//     X = |minor_A & minor_B|   ->   ALTALT = X,  ac_B - X,  ac_A - X  or  2N - (mac_A + mac_B - X)
+// depending on which of the two has REF as its minor allele.  ALTALT is the one count the plain phased planes yield per
+// pair, so from here on the pair goes the way of the fused count kernel's candidates (ld_count.hip.h): the same division-
+// free r2 screen, the candidate list, k_ld_stats_list - records bit for bit those of the dense path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace twk {
+
+constexpr uint32_t LIST_END = 0xFFFFFFFFu;      // sentinel behind a variant's last carrier
+
+// rows: the allele-count-sorted phased planes (one row of W words per variant, bit h = haplotype h carries ALT);
+// variant v < n_list gets lists[v * stride + k], k < mac[v]: the haplotypes carrying its minor allele, ascending,
+// then LIST_END.  flip[v] != 0: the minor allele is REF (the row has more than N ones).  One wave per variant.
+__global__ __launch_bounds__(256)
+void k_build_lists(const uint32_t* __restrict__ rows, uint32_t W, uint32_t W_live, uint64_t two_n, const uint32_t* __restrict__ rowpop,
+                   uint32_t n_list, uint32_t stride, uint32_t* __restrict__ lists, uint32_t* __restrict__ mac, uint32_t* __restrict__ flip) {
+	const uint32_t v = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+	if (v >= n_list) return;
+	const int lane = threadIdx.x & 63;
+	const uint32_t ac = rowpop[v];
+	const bool inv = (uint64_t)ac * 2 > two_n;
+	const uint32_t m = inv ? (uint32_t)(two_n - ac) : ac;
+	const uint32_t* row = rows + (size_t)v * W;
+	uint32_t* out = lists + (size_t)v * stride;
+	uint32_t base = 0;                                     // carriers written so far (wave-uniform)
+	for (uint32_t k0 = 0; k0 < W_live; k0 += 64) {
+		const uint32_t k = k0 + lane;
+		uint32_t x = k < W_live ? row[k] : 0u;
+		if (inv && k < W_live) {
+			x = ~x;
+			const uint64_t bit0 = (uint64_t)k * 32;          // the padding bits of the last word are not haplotypes
+			if (two_n - bit0 < 32) x &= (1u << (two_n - bit0)) - 1u;
+		}
+		const unsigned long long any = __ballot(x != 0);
+		if (!any) continue;
+		const uint32_t cnt = __popc(x);
+		uint32_t incl = cnt;
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(incl, o); if (lane >= o) incl += y; }
+		uint32_t at = base + incl - cnt;
+		while (x) {                                         // this lane's carriers, ascending
+			const int b = __ffs(x) - 1;
+			x &= x - 1;
+			if (at < stride - 1) out[at] = k * 32 + b;
+			++at;
+		}
+		base += __shfl(incl, 63);
+	}
+	if (lane == 0) { out[m < stride - 1 ? m : stride - 1] = LIST_END; mac[v] = m; flip[v] = inv ? 1u : 0u; }
+}
+
+struct ListWork {
+	const uint32_t* lists; uint32_t stride;        // [n_list][stride], LIST_END-terminated
+	const uint32_t* mac; const uint32_t* flip;     // carriers of the minor allele; minor allele is REF
+	const uint32_t* rowpop;                        // ALT alleles per set position
+	uint32_t n_list;                               // the list zone: set positions [0, n_list)
+	uint32_t row0, n_rows;                         // rows of this launch
+	const uint32_t* col_hi; uint32_t hi_a0, hi_b0; // r2 band: row a reaches the columns below hi_b0 + col_hi[a - hi_a0]
+	double two_n, cut;                             // 2N; minR2 * (1 - 1e-6)
+	uint32_t* cand; unsigned long long cap; unsigned long long* n_cand;      // as in ScreenWork (ld_count.hip.h)
+};
+
+// One pair per lane: row i = row0 + blockIdx.y against the columns i + 1 + (64 consecutive per wave); neighbours in the
+// allele-count order have lists of similar length, so the lanes of a wave run about equally long.
+__global__ __launch_bounds__(256)
+void k_list_screen(const ListWork w) {
+	const uint32_t i = w.row0 + blockIdx.y;
+	const uint32_t j = i + 1 + blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t limit = w.col_hi ? w.hi_b0 + w.col_hi[i - w.hi_a0] : w.n_list;
+	if (limit > w.n_list) limit = w.n_list;
+	bool keep = false;
+	uint32_t aa = 0;
+	if (j < limit) {
+		const uint32_t* a = w.lists + (size_t)i * w.stride;
+		const uint32_t* b = w.lists + (size_t)j * w.stride;
+		const uint32_t na = w.mac[i], nb = w.mac[j];
+		uint32_t ia = 0, ib = 0, x = 0, va = a[0], vb = b[0];
+		while (ia < na && ib < nb) {           // merge step: count a match, advance the smaller head (both on a match)
+			x += va == vb;
+			const bool fa = va <= vb, fb = vb <= va;
+			ia += fa; ib += fb;
+			if (fa) va = a[ia];
+			if (fb) vb = b[ib];
+		}
+		const uint32_t acA = w.rowpop[i], acB = w.rowpop[j];
+		const bool fA = w.flip[i] != 0, fB = w.flip[j] != 0;
+		// ALT carriers of both: the lists hold the minor allele's carriers
+		if (!fA && !fB) aa = x;
+		else if (fA && !fB) aa = nb - x;               // ALT_A = everyone but minor_A
+		else if (!fA && fB) aa = na - x;
+		else aa = (uint32_t)((uint64_t)w.two_n - ((uint64_t)na + nb - x));
+		const double da = (double)acA, db = (double)acB;
+		const double dn = w.two_n * (double)aa - da * db;
+		keep = dn != 0.0 && dn * dn >= w.cut * (da * (w.two_n - da)) * (db * (w.two_n - db));
+	}
+	const unsigned long long ballot = __ballot(keep);
+	if (ballot) {
+		const int lane = threadIdx.x & 63;
+		const int leader = __ffsll((long long)ballot) - 1;
+		unsigned long long base = 0;
+		if (lane == leader) base = atomicAdd(w.n_cand, (unsigned long long)__popcll(ballot));
+		base = __shfl(base, leader);
+		if (keep) {
+			const unsigned long long slot = base + __popcll(ballot & ((1ull << lane) - 1));
+			if (slot < w.cap) { uint32_t* e = w.cand + slot * 3; e[0] = i; e[1] = j; e[2] = aa; }
+		}
+	}
+}
+
+}  // namespace twk

@@ -20,6 +20,7 @@
 #include "ld_count.hip.h"
 #include "ld_prep.hip.h"
 #include "ld_math.hip.h"
+#include "ld_list.hip.h"
 
 using namespace twk;
 
@@ -40,6 +41,10 @@ struct PlaneSet {
 	uint32_t* ids = nullptr;
 	std::vector<uint32_t> h_ids;
 	uint32_t  n_front = 0;
+	// allele-count-sorted phased set only (ld_list.hip.h): carrier lists of the variants that lead the set with at most
+	// list_max carriers of their minor allele - positions [0, n_list), n_list a multiple of the tile edge
+	uint32_t* lists = nullptr; uint32_t* list_mac = nullptr; uint32_t* list_flip = nullptr;
+	uint32_t  n_list = 0, list_max = 0;
 };
 
 // Plane sets a context can hold: one per PlaneKind in file order, plus the masked unphased planes
@@ -68,6 +73,7 @@ struct Slot {                      // one in-flight tile (double buffered)
 	unsigned long long* h_n_out = nullptr;        // pinned host copy of all four
 	hipEvent_t ev_c0 = nullptr, ev_c1 = nullptr, ev_s1 = nullptr, ev_c0b = nullptr, ev_c1b = nullptr;
 	bool two_pass = false;
+	bool is_list = false;                         // the launch was a carrier-list pass (ld_list.hip.h): C holds its candidate list
 	bool fused = false;                           // first launch ran the fused count -> screen kernel: C holds the candidate list
 	unsigned long long cand_cap = 0;              // ... of this many entries; n_out[2] counts them
 	bool cand_overflow = false;                   // set by finish_tile: the list did not hold them all
@@ -79,7 +85,8 @@ struct Slot {                      // one in-flight tile (double buffered)
 
 // Window mode: row variant a0 + r of a region reaches the columns [b0 + lo[r], b0 + hi[r]).
 struct ColRange { const uint32_t* lo = nullptr; const uint32_t* hi = nullptr; uint32_t a0 = 0, b0 = 0;
-                  const uint32_t* d_hi = nullptr; };   // d_hi: device copy of hi (r2 screen: the math kernel skips what was not contracted)
+                  const uint32_t* d_hi = nullptr;      // d_hi: device copy of hi (r2 screen: the math kernel skips what was not contracted)
+                  uint32_t list_zone = 0; };           // pairs with both set positions below it are intersected as carrier lists (ld_list.hip.h), not contracted
 
 }  // namespace
 
@@ -101,6 +108,7 @@ struct twk_hip_ctx {
 	Slot slot[3];                  // [0],[1]: ld_all pipeline; [2]: synchronous single-tile calls
 	twk_hip_record* h_recs = nullptr; unsigned long long h_recs_cap = 0;   // pinned staging
 	// twk_hip_set_device_sink: the survivors of region calls stay on the device, appended here tile by tile
+	StatsParams* d_list_stats = nullptr;          // parameter block of the list pass's math kernel (device copy)
 	bool fused_ok = true;           // cleared for the rest of a call when a fused tile's candidate list overflowed
 	bool device_sink = false;
 	twk_hip_record* d_keep = nullptr; unsigned long long d_keep_n = 0, d_keep_cap = 0;
@@ -140,6 +148,9 @@ void free_planes(twk_hip_ctx* c) {
 		if (p.owns_rows && p.rows) (void)hipFree(p.rows);
 		if (p.rowpop) (void)hipFree(p.rowpop);
 		if (p.ids) (void)hipFree(p.ids);
+		if (p.lists) (void)hipFree(p.lists);
+		if (p.list_mac) (void)hipFree(p.list_mac);
+		if (p.list_flip) (void)hipFree(p.list_flip);
 		p = PlaneSet();
 	}
 }
@@ -251,6 +262,35 @@ int ensure_planes(twk_hip_ctx* c, int set) {
 	const uint32_t live_rows = c->M * P;
 	hipLaunchKernelGGL(k_row_popcount, dim3((live_rows + 3) / 4), dim3(256), 0, c->s_compute, ps.rows, ps.W, live_rows, ps.rowpop);
 	HIPCHK(c, hipGetLastError());
+	if (set == PS_SORTED_P) {
+		// Carrier lists for the head of the set (ld_list.hip.h): worth it where a dense pair costs more than a merge of
+		// two lists, i.e. for long rows only.  list_max = W / 128 carriers (the measured break-even is ~W / 150 merge
+		// steps per side, profiles/r03_t2_list_vs_dense.txt), and not below 32 - rows shorter than 4096 words (N < 65,536)
+		// keep no lists.  TWK_HIP_LISTS=0: never; =2: always, with at least 8 carriers (test hook).
+		const char* le = std::getenv("TWK_HIP_LISTS");
+		const int lists_env = le ? std::atoi(le) : 1;
+		uint32_t lmax = ps.W / 128;
+		if (lists_env == 2) lmax = std::max<uint32_t>(lmax, 8);
+		if (lists_env != 0 && (lmax >= 32 || lists_env == 2)) {
+			const uint64_t T2 = 2ull * c->N;
+			uint32_t n = 0;                                  // variants of the missing-free head with a minor allele count <= lmax
+			while (n < ps.n_front) {
+				const uint64_t ac = std::min<uint64_t>(c->h_popc[ps.h_ids[n]], T2);
+				if (std::min(ac, T2 - ac) > lmax) break;
+				++n;
+			}
+			n = n / TILE * TILE;                             // whole tiles: a tile is either intersected or contracted
+			if (n >= 2 * TILE) {
+				ps.n_list = n; ps.list_max = lmax;
+				HIPCHK(c, hipMalloc((void**)&ps.lists, (size_t)n * (lmax + 1) * 4));
+				HIPCHK(c, hipMalloc((void**)&ps.list_mac, (size_t)n * 4));
+				HIPCHK(c, hipMalloc((void**)&ps.list_flip, (size_t)n * 4));
+				hipLaunchKernelGGL(k_build_lists, dim3((n + 3) / 4), dim3(256), 0, c->s_compute, (const uint32_t*)ps.rows, ps.W, ps.W_live, (uint64_t)T2,
+				                   (const uint32_t*)ps.rowpop, n, lmax + 1, ps.lists, ps.list_mac, ps.list_flip);
+				HIPCHK(c, hipGetLastError());
+			}
+		}
+	}
 	HIPCHK(c, hipStreamSynchronize(c->s_compute));
 	ps.built = true;
 	return TWK_HIP_OK;
@@ -314,6 +354,13 @@ void build_tile_list(const twk_hip_tile_desc& t, int P, const Geometry& g, bool 
 			x0[by] = std::max<uint32_t>(x0[by], (uint32_t)(((lo - t.rowB0) * P) / TILE));
 			x1[by] = std::min<uint32_t>(x1[by], (uint32_t)(((hi - t.rowB0) * P + TILE - 1) / TILE));
 			if (x1[by] < x0[by]) x1[by] = x0[by];
+		}
+		if (cr && cr->list_zone) {      // a row of tiles that lies wholly inside the list zone starts at the zone's last column tile
+			const uint64_t v1 = std::min<uint64_t>((uint64_t)t.rowA0 + t.nA, (uint64_t)t.rowA0 + ((uint64_t)(by + 1) * TILE + P - 1) / P);
+			if (v1 <= cr->list_zone && cr->list_zone > t.rowB0) {
+				x0[by] = std::max<uint32_t>(x0[by], (uint32_t)((((uint64_t)cr->list_zone - t.rowB0) * P) / TILE));
+				if (x1[by] < x0[by]) x1[by] = x0[by];
+			}
 		}
 	}
 	std::vector<uint32_t> seq;
@@ -458,6 +505,7 @@ StatsParams make_stats(twk_hip_ctx* c, int set, const twk_hip_tile_desc& t, cons
 	p.vm = VariantMeta{c->d_ac, c->d_an, c->d_pos, c->d_rid, c->d_missing, c->d_hwe};
 	p.raw = c->raw; p.rawmask = c->rawmask; p.Wp = c->Wp;
 	p.col_hi = cr ? cr->d_hi : nullptr; p.hi_a0 = cr ? cr->a0 : 0; p.hi_b0 = cr ? cr->b0 : 0;
+	p.list_zone = cr ? cr->list_zone : 0;
 	p.nA = t.nA; p.nB = t.nB; p.n_variants = c->M;
 	p.diag = (t.diag && t.rowA0 == t.rowB0) ? 1 : 0;
 	p.phased_math = phased_math ? 1 : 0; p.auto_select = auto_select;
@@ -511,13 +559,14 @@ int enqueue_tile(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, const twk
 	const bool want_fused = c->fused_ok && phased && set_kind(kind1) == PK_PHASED && f.minR2 > 1e-6 && f.minR2 <= 1.0;
 	FusedArgs fa{};
 	ScreenWork& sw = fa.screen;
-	s.fused = false; s.cand_overflow = false; s.cand_cap = s.C_words / 3;
+	s.fused = false; s.is_list = false; s.cand_overflow = false; s.cand_cap = s.C_words / 3;
 	if (want_fused) {
 		const PlaneSet& ps = c->planes[kind1];
 		fa.stats = make_stats(c, kind1, t, s, phased, pl.select1, f, cr);
 		sw.rowpop = ps.rowpop; sw.a0 = t.rowA0; sw.b0 = t.rowB0; sw.nA = t.nA; sw.nB = t.nB;
 		sw.n_variants = c->M; sw.diag = (t.diag && t.rowA0 == t.rowB0) ? 1 : 0;
 		sw.col_hi = cr ? cr->d_hi : nullptr; sw.hi_a0 = cr ? cr->a0 : 0; sw.hi_b0 = cr ? cr->b0 : 0;
+		sw.list_zone = cr ? cr->list_zone : 0;
 		sw.two_n = 2.0 * (double)c->N; sw.cut = f.minR2 * (1.0 - 1e-6);
 		sw.cand = s.C; sw.cap = s.cand_cap; sw.n_cand = s.n_out + 2;
 	}
@@ -646,7 +695,8 @@ int finish_tile(twk_hip_ctx* c, Slot& s, const twk_hip_tile_desc& t, unsigned lo
 	HIPCHK(c, hipEventSynchronize(s.ev_s1));
 	float ms = 0;
 	HIPCHK(c, hipEventElapsedTime(&ms, s.ev_c0, s.ev_c1));
-	c->timing.count_ms += ms; c->timing.count_launches += 1; c->timing.row_pairs += s.row_pairs;
+	if (s.is_list) { c->timing.list_ms += ms; c->timing.list_launches += 1; c->timing.list_pairs += s.row_pairs; c->timing.candidates += s.h_n_out[2]; }
+	else { c->timing.count_ms += ms; c->timing.count_launches += 1; c->timing.row_pairs += s.row_pairs; }
 	if (s.fused) { c->timing.fused_launches += 1; c->timing.candidates += s.h_n_out[2]; }
 	float ms_all = 0;
 	if (s.two_pass) {
@@ -664,7 +714,7 @@ int finish_tile(twk_hip_ctx* c, Slot& s, const twk_hip_tile_desc& t, unsigned lo
 	c->timing.variant_pairs += pairs_in_tile(c, t);
 	const unsigned long long n = *s.h_n_out;
 	*n_out = n;
-	if (s.fused && s.h_n_out[2] > s.cand_cap) { s.cand_overflow = true; return TWK_HIP_E_OVERFLOW; }   // more candidates than the list holds
+	if ((s.fused || s.is_list) && s.h_n_out[2] > s.cand_cap) { s.cand_overflow = true; return TWK_HIP_E_OVERFLOW; }   // more candidates than the list holds
 	if (n > s.capacity) return TWK_HIP_E_OVERFLOW;
 	if (n) {
 		// records that failed the Fisher cut-off were only marked on the device (and counted): they sort behind the rest
@@ -682,6 +732,60 @@ int finish_tile(twk_hip_ctx* c, Slot& s, const twk_hip_tile_desc& t, unsigned lo
 		*n_out = kept;
 	}
 	return TWK_HIP_OK;
+}
+
+// Rows [row0, row0 + n_rows) of the list zone of the allele-count-sorted phased set, synchronously on the spare slot: every
+// pair (i, j), i < j < zone, inside the r2 band, as an intersection of two carrier lists (ld_list.hip.h) -> candidates ->
+// the list math kernel -> Fisher -> sorted survivors (c->h_recs or the device sink, like a tile).
+int run_list_block(twk_hip_ctx* c, const twk_hip_filters& f, uint32_t row0, uint32_t n_rows, uint32_t zone, int32_t window, uint32_t l_window,
+                   const ColRange& cr, unsigned long long capacity, unsigned long long* n_out, bool to_host) {
+	const PlaneSet& ps = c->planes[PS_SORTED_P];
+	Slot& s = c->slot[2];
+	const uint64_t pairs_max = (uint64_t)n_rows * (zone - row0);
+	int rc = ensure_slot(c, s, (size_t)std::max<uint64_t>(3 * pairs_max, 1024), capacity); if (rc) return rc;
+	if (!c->d_list_stats) HIPCHK(c, hipMalloc((void**)&c->d_list_stats, sizeof(StatsParams)));
+	s.two_pass = false; s.fused = false; s.is_list = true; s.cand_overflow = false; s.cand_cap = s.C_words / 3; s.minP = f.minP;
+	twk_hip_tile_desc t{};
+	t.rowA0 = row0; t.nA = n_rows; t.rowB0 = row0; t.nB = zone - row0; t.diag = 1; t.window = window; t.l_window = l_window;
+	const StatsParams sp = make_stats(c, PS_SORTED_P, t, s, true, 0, f, &cr);
+	HIPCHK(c, hipMemsetAsync(s.n_out, 0, 4 * sizeof(unsigned long long), c->s_compute));
+	HIPCHK(c, hipMemcpyAsync(c->d_list_stats, &sp, sizeof(sp), hipMemcpyHostToDevice, c->s_compute));
+	ListWork w{};
+	w.lists = ps.lists; w.stride = ps.list_max + 1; w.mac = ps.list_mac; w.flip = ps.list_flip; w.rowpop = ps.rowpop;
+	w.n_list = zone; w.row0 = row0; w.n_rows = n_rows;
+	w.col_hi = cr.d_hi; w.hi_a0 = cr.a0; w.hi_b0 = cr.b0;
+	w.two_n = 2.0 * (double)c->N; w.cut = f.minR2 * (1.0 - 1e-6);
+	w.cand = s.C; w.cap = s.cand_cap; w.n_cand = s.n_out + 2;
+	// the widest row of the block decides the grid; lanes beyond a row's own reach leave at once
+	uint32_t width = 0;
+	for (uint32_t i = row0; i < row0 + n_rows; ++i) {
+		const uint32_t lim = std::min<uint32_t>(zone, cr.hi ? cr.b0 + cr.hi[i - cr.a0] : zone);
+		if (lim > i + 1) width = std::max(width, lim - i - 1);
+	}
+	s.row_pairs = 0;
+	for (uint32_t i = row0; i < row0 + n_rows; ++i) {
+		const uint32_t lim = std::min<uint32_t>(zone, cr.hi ? cr.b0 + cr.hi[i - cr.a0] : zone);
+		if (lim > i + 1) s.row_pairs += lim - i - 1;              // pairs intersected (accounting only)
+	}
+	HIPCHK(c, hipEventRecord(s.ev_c0, c->s_compute));
+	if (width) {
+		hipLaunchKernelGGL(k_list_screen, dim3((width + 255) / 256, n_rows), dim3(256), 0, c->s_compute, w);
+		HIPCHK(c, hipGetLastError());
+	}
+	HIPCHK(c, hipEventRecord(s.ev_c1, c->s_compute));
+	if (width) {
+		hipLaunchKernelGGL(k_ld_stats_list, dim3(c->resident_blocks * 4), dim3(256), 0, c->s_compute, (const StatsParams*)c->d_list_stats, (const uint32_t*)s.C,
+		                   (const unsigned long long*)(s.n_out + 2), s.cand_cap);
+		HIPCHK(c, hipGetLastError());
+	}
+	{
+		const LFact lf{c->d_lfact, c->lfact_n};
+		hipLaunchKernelGGL(k_ld_fisher, dim3(c->resident_blocks * 2), dim3(256), 0, c->s_compute, s.out, s.n_out, s.capacity, f.minP, lf, (const uint32_t*)nullptr);
+		HIPCHK(c, hipGetLastError());
+	}
+	HIPCHK(c, hipMemcpyAsync(s.h_n_out, s.n_out, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->s_compute));
+	HIPCHK(c, hipEventRecord(s.ev_s1, c->s_compute));
+	return finish_tile(c, s, t, n_out, to_host);
 }
 
 // One tile, synchronously, on the spare slot; survivors end up in c->h_recs.
@@ -842,6 +946,7 @@ int twk_hip_ctx_destroy(twk_hip_ctx* c) {
 	}
 	if (c->h_recs) (void)hipHostFree(c->h_recs);
 	if (c->d_keep) (void)hipFree(c->d_keep);
+	if (c->d_list_stats) (void)hipFree(c->d_list_stats);
 	if (c->d_sort_keys) (void)hipFree(c->d_sort_keys);
 	if (c->d_sort_vals) (void)hipFree(c->d_sort_vals);
 	if (c->d_sorted) (void)hipFree(c->d_sorted);
@@ -1376,6 +1481,27 @@ static int region_impl(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint3
 		}
 		HIPCHK(c, hipMemcpy(c->d_col_hi, hi.data(), (size_t)nA * 4, hipMemcpyHostToDevice));
 		col_range.d_hi = c->d_col_hi;
+	}
+	// The list zone of the allele-count-sorted phased set (long rows only): its pairs are intersected as carrier lists,
+	// block of rows after block of rows, before the tiles that are left are contracted.
+	if (screen == 1 && a0 == 0 && b0 == 0) {
+		const PlaneSet& ps = c->planes[PS_SORTED_P];
+		const uint32_t zone = std::min(ps.n_list, nA);
+		if (zone >= 2 && ps.lists) {
+			col_range.list_zone = zone;
+			const uint32_t lr0 = std::min(r0, zone), lr1 = std::min(r1, zone);
+			uint32_t rows_per = (uint32_t)std::max<uint64_t>(64, std::min<uint64_t>(32768, (1ull << 25) / zone));
+			for (uint32_t row = lr0; row < lr1;) {
+				const uint32_t nr = std::min(rows_per, lr1 - row);
+				unsigned long long nrec = 0;
+				rc = run_list_block(c, *f, row, nr, zone, window, l_window, col_range, cap_default, &nrec, !c->device_sink);
+				if (rc == TWK_HIP_E_OVERFLOW && nr > 1) { rows_per = std::max<uint32_t>(1, nr / 2); continue; }      // more survivors than the buffer holds: fewer rows
+				if (rc) return rc;
+				if (!c->device_sink && sink && nrec) { if (sink(user, c->h_recs, nrec)) return TWK_HIP_E_INVALID; }
+				tot_recs += nrec;
+				row += nr;
+			}
+		}
 	}
 	// two-deep software pipeline over the tiles of this shard
 	while (done < n) {
