@@ -63,8 +63,8 @@ def test_list_zone_equals_dense_and_oracle(hip, monkeypatch, N, forced):
             assert tb["row_pairs"] < ta["row_pairs"]          # the zone's tiles were not contracted
     # the oracle on the rarest variants (the zone) plus a sample of the rest
     ac = np.minimum(variants["ac"], 2 * N - variants["ac"])
-    rare = np.argsort(ac, kind="stable")[:160]
-    sub = np.sort(np.concatenate([rare, np.random.default_rng(1).choice(np.setdiff1d(np.arange(M), rare), size=100, replace=False)]))
+    rare = np.argsort(ac, kind="stable")[:300]          # (a zone needs two tiles of variants: 256)
+    sub = np.sort(np.concatenate([rare, np.random.default_rng(1).choice(np.setdiff1d(np.arange(M), rare), size=60, replace=False)]))
     monkeypatch.setenv("TWK_HIP_LISTS", "2")
     hip.set_problem(N, len(sub))
     hip.upload(data[sub], util.to_hip_meta(variants[sub]), None)
