@@ -80,7 +80,7 @@ def test_list_zone_equals_dense_and_oracle(hip, monkeypatch, N, forced):
 def test_list_zone_with_missing_data_in_default_mode(hip, monkeypatch):
     """Default mode with missing genotypes: the screened stage runs over the missing-free head of the sorted set - lists
     there - and the variants with missing data go through the masked unphased planes as before."""
-    N, M = 66_000, 1100
+    N, M = 66_000, 1900
     al = _cohort_alleles(M, N, 77, miss=True)
     data, mask = O.bitvectors_from_alleles(al)
     variants = O.variants_from_alleles(al)
