@@ -137,6 +137,7 @@ def e2e_from_disk(n_samples, n_variants, log):
         load = re.search(r"Unpacked and uploaded .* variants\. (\S+)", lg)
         fin = re.search(r"Finished in (\S+)\. Variants: ([0-9,]+), genotypes: [0-9,]+, output: ([0-9,]+)", lg)
         eng = re.search(r"count kernel ([0-9.e+]+) ms in (\d+) launches \(([0-9.e+-]+) % [^)]*\), math kernels ([0-9.e+]+) ms", lg)
+        lst = re.search(r"carrier-list kernel ([0-9.e+]+) ms in (\d+) launches over ([0-9,]+) rare pairs", lg)
         def secs(txt):          # the CLI prints [Hh][Mm]S.sss"s" (twk_util.h elapsed_string)
             mo = re.fullmatch(r"(?:(\d+)h)?(?:(\d+)m)?([0-9.]+)s\.?", txt)
             return (int(mo.group(1) or 0) * 3600 + int(mo.group(2) or 0) * 60 + float(mo.group(3))) if mo else None
@@ -147,6 +148,8 @@ def e2e_from_disk(n_samples, n_variants, log):
                "two_bytes": os.path.getsize(out) if os.path.exists(out) else None,
                "screen": "on", "count_kernel_ms": float(eng.group(1)) if eng else None,
                "math_kernels_ms": float(eng.group(4)) if eng else None,
+               "list_kernel_ms": float(lst.group(1)) if lst else None,
+               "pairs_decided_by_carrier_lists": int(lst.group(3).replace(",", "")) if lst else None,
                "input": f"{n_samples} samples x {n_variants} cohort-shaped variants (founder mosaics, 70 % rare), "
                         f"{os.path.getsize(twk) / 1e6:.0f} MB .twk, calc default mode -t {threads}"}
         log(f"e2e {attempt}: wall {wall:.2f}s {res}")

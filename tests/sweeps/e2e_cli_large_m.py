@@ -18,6 +18,8 @@ def run(tag, twk, args, env=None):
     fin = re.search(r"Finished in (\S+)\. Variants: ([0-9,]+), genotypes: [0-9,]+, output: ([0-9,]+)", r.stderr)
     load = re.search(r"Unpacked and uploaded .* variants\. (\S+)", r.stderr)
     eng = re.findall(r"count kernel ([0-9.e+]+) ms in (\d+) launches \(([0-9.e+-]+) % [^)]*\), math kernels ([0-9.e+]+) ms", r.stderr)
+    eng += re.findall(r"(carrier-list kernel [0-9.e+]+ ms in \d+ launches over [0-9,]+ rare pairs)", r.stderr)
+    eng += re.findall(r"(\d+ launches fused count -> r2 screen, [0-9,]+ candidate pairs)", r.stderr)
     print(f"{tag}: wall {wall:.2f} s | load {load.group(1) if load else '?'} | compute+write {fin.group(1)} | pairs {fin.group(2)} | records {fin.group(3)} | engine {eng}", flush=True)
     os.remove(out)
 

@@ -22,6 +22,8 @@ def run(tag, twk, args, env=None):
     fin = re.search(r"Finished in (\S+)\. Variants: ([0-9,]+), genotypes: [0-9,]+, output: ([0-9,]+)", log)
     rate = re.search(r"\] ([0-9,]+) variants/s", log)
     eng = re.findall(r"count kernel ([0-9.e+]+) ms in (\d+) launches \(([0-9.e+-]+) % [^)]*\), math kernels ([0-9.e+]+) ms", log)
+    eng += re.findall(r"(carrier-list kernel [0-9.e+]+ ms in \d+ launches over [0-9,]+ rare pairs)", log)
+    eng += re.findall(r"(\d+ launches fused count -> r2 screen, [0-9,]+ candidate pairs)", log)
     print(f"{tag}: wall {wall:.2f} s | load {load.group(1) if load else '?'} | compute+write {fin.group(1) if fin else '?'} | pairs {fin.group(2) if fin else '?'} | "
           f"records {fin.group(3) if fin else '?'} | {rate.group(1) if rate else '?'} pairs/s in the compute phase | engine {eng}", flush=True)
     for l in log.splitlines():
