@@ -26,8 +26,9 @@ The JSON line also carries
                issue at best (v_and_b32 2 cycles + v_bcnt_u32_b32 4 cycles per wave64: 2.62e13 word
                pairs/s; microbenchmarks under profiles/).  `hbm_algorithmic` keeps SURVEY 8(d)'s
                HBM-read accounting (N/4 bytes per pair against 8 TB/s; > 1 by construction because
-               of the LDS reuse).  `traffic` (HBM bytes per launch) needs rocprofv3 counter passes and
-               is not measured inside this run: null here, the per-round figure is in profiles/.
+               of the LDS reuse).  `traffic` (bytes per launch between the L2s and memory): at N=1 two rocprofv3
+               counter passes over one step of the same workload are run as child processes after the timed
+               region (FETCH_SIZE, WRITE_SIZE; --no-traffic skips them, then it is null).
   cpu_baseline the compiled reference (oracle/_ref, SSE4.2) on this box's host cores, on the first
                M_s variants of the same synthetic input (rank 0, N=1 only).
   e2e          (N=1 only, after the timed region like cpu_baseline) `tomahawk calc`, default mode, from a cohort-shaped
@@ -114,6 +115,47 @@ def cpu_baseline(n_samples, mode, seed, log):
                       f"-t {cores}, {block} variants/block, SSE4.2 build of the reference, {wall:.1f}s wall)"}
 
 
+def measure_traffic(config_args, log):
+    """Memory-side traffic of the dominant kernel, per launch, from rocprofv3 counter passes over this very workload (one
+    step, no warm-up; child processes started after the timed region): FETCH_SIZE and WRITE_SIZE in separate passes, as
+    MI355X_MICROARCH.md prescribes, FETCH_SIZE doubled (gfx950: 128-byte requests tallied at 64 bytes).  FETCH_SIZE counts
+    what the L2s request from the fabric - Infinity-Cache hits included - so this is an upper bound on HBM reads."""
+    import csv
+    import glob
+    import shutil
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None
+    got = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="twk_pmc_")
+        cmd = [rocprof, "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
+               "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-e2e", "--no-traffic"] + config_args
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=tempfile.gettempdir(), env=dict(os.environ, TMPDIR=tempfile.gettempdir()))
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                log(f"traffic: rocprofv3 --pmc {ctr} failed (rc {r.returncode}): {r.stderr[-200:]}")
+                return None
+            total, launches = 0.0, set()
+            with open(files[0], newline="") as fh:
+                for row in csv.DictReader(fh):
+                    name = row.get("Kernel_Name") or row.get("kernel_name") or ""
+                    if "k_count_list_t" in name and row.get("Counter_Name") == ctr:
+                        total += float(row["Counter_Value"])
+                        launches.add(row.get("Dispatch_Id") or row.get("dispatch_id"))
+            if not launches:
+                return None
+            got[ctr] = (total * 1024.0, len(launches))       # KiB -> bytes
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    fetch_b, n_f = got["FETCH_SIZE"]
+    write_b, n_w = got["WRITE_SIZE"]
+    per_launch = 2.0 * fetch_b / n_f + write_b / n_w
+    log(f"traffic: FETCH_SIZE x2 {2 * fetch_b / 1e9:.1f} GB over {n_f} launches, WRITE_SIZE {write_b / 1e9:.1f} GB over {n_w}")
+    return {"bytes_per_launch": per_launch, "read_bytes_per_launch": 2.0 * fetch_b / n_f, "write_bytes_per_launch": write_b / n_w, "launches": n_f}
+
+
 def e2e_from_disk(n_samples, n_variants, log):
     """`tomahawk calc` (default mode: r2 screen on) from a cohort-shaped .twk on disk -> dict for the JSON line."""
     from tomahawk_amd import hostlib
@@ -177,6 +219,7 @@ def main():
     ap.add_argument("--min-p", type=float, default=None, help="override the Fisher P cut-off (debug)")
     ap.add_argument("--keep-two", default="", help="rank 0 keeps the .two file of the last timed step at this path")
     ap.add_argument("--no-e2e", action="store_true", help="skip the from-disk `tomahawk calc` measurement (N=1, cfg3)")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 counter passes behind roofline.traffic (N=1)")
     ap.add_argument("--e2e-variants", type=int, default=0, help="variants of the e2e input (0: the config's own count)")
     ap.add_argument("--emulate-shard", default="", help="K/N: run shard K of N on this one GPU (validation of the "
                     "sharded configs on a single-GPU box; the value then covers that shard only)")
@@ -387,8 +430,7 @@ def main():
                          "unit": "Tlane-op/s", "frac": lane_ops_per_s / VALU_LANE_PEAK,
                          "and_bcnt_ceiling_frac": (lane_ops_per_s / 2) / VALU_PAIR_PEAK,
                          "traffic": None,
-                         "traffic_note": "HBM bytes need rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE, separate runs); "
-                                         "see profiles/ for the round's figure",
+                         "traffic_note": "not measured in this run (rocprofv3 counter passes skipped or unavailable); see profiles/ for the round's figure",
                          "kernel": "twk::k_count_list_t", "launches": int(tm["count_launches"]),
                          "avg_launch_ms": k_ms / max(tm["count_launches"], 1),
                          "algorithmic_lane_ops_per_pair": lane_ops_per_pair,
@@ -416,6 +458,29 @@ def main():
                 cb = None
             if cb:
                 out["cpu_baseline"] = cb
+        if world == 1 and not args.no_traffic and not args.emulate_shard:
+            eng.close()                  # the profiled child runs the same workload on the same GPU
+            cfg_args = ["--config", args.config, "--seed", str(args.seed)]
+            if args.variants:
+                cfg_args += ["--variants", str(args.variants)]
+            if args.samples:
+                cfg_args += ["--samples", str(args.samples)]
+            if args.min_r2 is not None:
+                cfg_args += ["--min-r2", str(args.min_r2)]
+            if args.tile:
+                cfg_args += ["--tile", str(args.tile)]
+            try:
+                tr = measure_traffic(cfg_args, log)
+            except Exception as e:       # never take the GPU number down with it
+                log(f"traffic measurement failed: {e!r}")
+                tr = None
+            if tr:
+                out["roofline"]["traffic"] = tr["bytes_per_launch"]
+                out["roofline"]["traffic_detail"] = tr
+                out["roofline"]["traffic_note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes over one step of this workload, run "
+                                                   "as child processes after the timed region), FETCH_SIZE x2 (gfx950), bytes per launch of "
+                                                   "twk::k_count_list_t; FETCH_SIZE counts the L2s' fabric requests (Infinity-Cache hits "
+                                                   "included): an upper bound on HBM reads")
         if world == 1 and not args.no_e2e and args.config == "cfg3" and not args.emulate_shard:
             eng.close()                  # the CLI gets the whole GPU
             try:

@@ -16,7 +16,7 @@ stats() {   # stats <name> <bench args...>: kernel trace + stats of one bench ru
 	local name=$1; shift
 	rm -rf /tmp/prof_$name
 	timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -o $name -- \
-		python3 $R/bench.py --no-cpu-baseline --no-e2e "$@" > $OUT/${name}_under_rocprof.json 2> $OUT/${name}_under_rocprof.log < /dev/null
+		python3 $R/bench.py --no-cpu-baseline --no-e2e --no-traffic "$@" > $OUT/${name}_under_rocprof.json 2> $OUT/${name}_under_rocprof.log < /dev/null
 	echo "$name stats rc=$?"
 	local f; f=$(find /tmp/prof_$name -name "*kernel_stats.csv" | head -1)
 	[ -n "$f" ] && cp "$f" $OUT/${name}_kernel_stats.csv && head -5 "$f" | cut -c1-220
@@ -25,7 +25,7 @@ pmc() {     # pmc <name> <counter list> <bench args...>: one counter pass, per-k
 	local name=$1 ctr=$2; shift 2
 	rm -rf /tmp/pmc_$name
 	timeout 900 rocprofv3 --pmc $ctr --output-format csv -d /tmp/pmc_$name -o $name -- \
-		python3 $R/bench.py --no-cpu-baseline --no-e2e "$@" > $OUT/${name}_pmc.json 2> $OUT/${name}_pmc.log < /dev/null
+		python3 $R/bench.py --no-cpu-baseline --no-e2e --no-traffic "$@" > $OUT/${name}_pmc.json 2> $OUT/${name}_pmc.log < /dev/null
 	echo "$name pmc rc=$?"
 	local f; f=$(find /tmp/pmc_$name -name "*counter_collection.csv" | head -1)
 	[ -n "$f" ] && python3 $R/profiles/sum_counters.py "$f" > $OUT/${name}_pmc_sums.json && cat $OUT/${name}_pmc_sums.json | head -60
@@ -67,12 +67,12 @@ PY
 		done
 		;;
 	cfg2)
-		timeout 600 python3 $R/bench.py --config cfg2 --steps 20 --warmup 3 > $OUT/bench_cfg2.json 2> $OUT/bench_cfg2.log; cat $OUT/bench_cfg2.json
+		timeout 600 python3 $R/bench.py --config cfg2 --no-traffic --steps 20 --warmup 3 > $OUT/bench_cfg2.json 2> $OUT/bench_cfg2.log; cat $OUT/bench_cfg2.json
 		stats cfg2 --config cfg2 --steps 20 --warmup 3
 		pmc cfg2_sq "SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" --config cfg2 --steps 5 --warmup 1
 		;;
 	cfg5)
-		timeout 900 python3 $R/bench.py --config cfg5 --emulate-shard 3/8 --steps 1 --warmup 0 > $OUT/bench_cfg5_shard3of8.json 2> $OUT/bench_cfg5_shard3of8.log; cat $OUT/bench_cfg5_shard3of8.json
+		timeout 900 python3 $R/bench.py --config cfg5 --no-traffic --emulate-shard 3/8 --steps 1 --warmup 0 > $OUT/bench_cfg5_shard3of8.json 2> $OUT/bench_cfg5_shard3of8.log; cat $OUT/bench_cfg5_shard3of8.json
 		;;
 	cfg5_prof)
 		stats cfg5_shard3of8 --config cfg5 --emulate-shard 3/8 --steps 1 --warmup 0

@@ -486,7 +486,7 @@ def _run_bench(tmp_path, world, extra, tag):
     from tomahawk_amd import hostlib
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     two = str(tmp_path / f"{tag}_{world}.two")
-    common = ["--gpus", str(world), "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-e2e", "--keep-two", two] + extra
+    common = ["--gpus", str(world), "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-e2e", "--no-traffic", "--keep-two", two] + extra
     if world == 1:
         cmd = [sys.executable, os.path.join(root, "bench.py")] + common
     else:
