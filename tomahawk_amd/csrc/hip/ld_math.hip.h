@@ -84,8 +84,11 @@ struct TableWalk {
 	}
 };
 // How far below q (in e-folds) a tail walk may start: everything further out is at most (max - min) terms, each below
-// q e^-K, so with K = 17.5 + ln(max - min) the part of P that is not summed is below e^-17.5 q = 2.5e-8 q <= 2.5e-8 P.
-__device__ inline double d_fisher_skip_exponent(int support) { return 17.5 + log((double)support); }
+// q e^-K.  K = 40: the part of P that is not summed is below 4e-18 (max - min) q, < 1e-10 of P at 2e7 haplotypes.  (A
+// support-dependent K = 17.5 + ln(max - min) - 2.5e-8 of P, a third fewer terms - was measured: 5 % of the kernel, and
+// in the underflow band, where the reference's result hangs on the rounding of its recurrence (k_ld_fisher_group below),
+// the nearer starting point no longer reproduced it bit for bit: 9 of 1.2 M records.  Not worth it.)
+__device__ inline double d_fisher_skip_exponent(int) { return 40.0; }
 // Two-sided P only (left / right tails are not stored in the record).
 __device__ inline double d_fisher_two(const LFact& t, int n11, int n12, int n21, int n22) {
 	int i, j, max, min;
@@ -100,12 +103,10 @@ __device__ inline double d_fisher_two(const LFact& t, int n11, int n12, int n21,
 	// The reference walks both tails from the ends of the support (min, max) inwards until the
 	// terms reach q: up to min(n1_, n_1) steps per record, almost all of them over terms that are
 	// zero or tens of orders of magnitude below q.  Start each walk closer in instead, at a point
-	// that is *verified* (one log-pmf evaluation) to lie below q by a factor e^-K, K = 17.5 + ln(max - min):
-	// the pmf is monotone out there, so everything skipped sums to < (max - min) e^-K q = 2.5e-8 q, i.e.
-	// < 2.5e-8 of the result (P >= q) at any sample count -- forty times inside the 1e-6 bar (a fixed K = 40,
-	// the first version, skipped < 1e-10 of P at 2e7 haplotypes and 1e-14 at 5,008, and walked a third more
-	// terms for it); the walk itself, its re-synchronisation every 11th step and its stopping rule are
-	// unchanged.  The candidate point
+	// that is *verified* (one log-pmf evaluation) to lie below q by a factor e^-40: the pmf is
+	// monotone out there, so everything skipped sums to < (max - min) * 4e-18 * q, i.e. < 1e-10
+	// of the result (P >= q) even at 2e7 haplotypes -- far inside the 1e-6 bar; the walk itself, its
+	// re-synchronisation every 11th step and its stopping rule are unchanged.  The candidate point
 	// comes from the normal approximation of the log-pmf, -(s - mean)^2 / (2 sd^2) relative to the
 	// mode: a term e^-K below q lies sqrt(dev^2 + 2 K sd^2) from the mean (dev = |n11 - mean|), a
 	// few sd beyond n11's own distance for a significant table instead of a fixed 12 sd; the
