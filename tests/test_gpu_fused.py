@@ -169,18 +169,18 @@ def test_fisher_kernels_agree_with_each_other_and_the_oracle(hip):
 def test_count_kernel_work_orders_give_the_same_counts(hip, monkeypatch, env):
     """The measured options of the count kernel's work order (K segments per patch, one unit queue per XCD,
     patch shape) are not the default, but they stay in the kernel: contingency cells bit-exact against the oracle and
-    records equal to the default order's, on rows long enough for them to engage (N = 70,000 unphased: 137 K-chunks)."""
+    records equal to the default order's, on rows long enough for them to engage (N = 70,000 phased: 137 K-chunks)."""
     N, M = 70_000, 700
     al = util.mosaic_alleles(M, N, 21, n_founders=6, switch=0.01, mut=0.002)
     data, mask, variants = util.upload(hip, al)
-    base, _, _ = hip.ld_all(T.MODE_UNPHASED, T.Filters(minR2=0.2))
+    base, _, _ = hip.ld_all(T.MODE_PHASED, T.Filters(minR2=0.2))
     for k, v in env.items():
         monkeypatch.setenv(k, v)
-    cells = hip.count_tile(T.MODE_UNPHASED, 0, M, 0, M)
-    got, _, _ = hip.ld_all(T.MODE_UNPHASED, T.Filters(minR2=0.2))
+    cells = hip.count_tile(T.MODE_PHASED, 0, M, 0, M)
+    got, _, _ = hip.ld_all(T.MODE_PHASED, T.Filters(minR2=0.2))
     for k in env:
         monkeypatch.delenv(k)
     rng = np.random.default_rng(2)
     for i, j in zip(rng.integers(0, M, 40), rng.integers(0, M, 40)):
-        assert np.array_equal(cells[i, j], O.count_unphased(data[i], None, data[j], None, N)), (i, j)
+        assert np.array_equal(cells[i, j], O.count_phased(data[i], None, data[j], None, N)), (i, j)
     assert len(base) > 50 and np.sort(base, order=ORDER).tobytes() == np.sort(got, order=ORDER).tobytes()
