@@ -309,6 +309,20 @@ __device__ inline bool d_unphased_math(const uint64_t c[9], const VariantMeta& v
 	const double n11 = (double)(2 * a0 + a14 + a1664);
 	const double minhap = n11 / (2.0 * total);
 	const double maxhap = (n11 + dh) / (2.0 * total);
+	// Screen before the cubic.  Whatever root the reference ends up with, it only keeps one inside
+	// [minhap - 1e-5, maxhap + 1e-5] (the admissibility tests below, applied to the computed values), and from it
+	// D = f11 f22 - f12 f21, which is f11 - P Q written out (f12 = P - f11, f21 = Q - f11, f22 = 1 - f11 - f12 - f21), and
+	// r2 = D^2 / (P (1 - P) Q (1 - Q)).  (x - P Q)^2 over that interval is largest at an end, so no admissible root can
+	// reach the cut-off when both ends fail it - with the same 1e-6 margin as the phased screen against the rounding of
+	// either evaluation.  For unlinked variants the interval is centred on P Q with half width P (1 - P) Q (1 - Q)
+	// (a quarter of the double-het frequency), so the screen rejects them whenever that product is below the cut-off:
+	// always at the default r2 >= 0.1 (the product never exceeds 1/16).
+	if (f.minR2 > 1e-6) {
+		const double pq = P * Q, v = (P * (1.0 - P)) * (Q * (1.0 - Q));
+		const double d_lo = (minhap - TWK_D_ROUNDING_ERR) - pq, d_hi = (maxhap + TWK_D_ROUNDING_ERR) - pq;
+		const double bound = f.minR2 * (1.0 - 1e-6) * v;
+		if (d_lo * d_lo < bound && d_hi * d_hi < bound) return false;
+	}
 	const double dee = -n11 * P * Q;
 	const double cc = -n11 * (1.0 - 2.0 * P - 2.0 * Q) - dh * (1.0 - P - Q) + (2.0 * total * P * Q);
 	const double b = 2.0 * total * (1.0 - 2.0 * P - 2.0 * Q) - 2.0 * n11 - dh;
