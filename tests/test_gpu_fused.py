@@ -184,3 +184,51 @@ def test_count_kernel_work_orders_give_the_same_counts(hip, monkeypatch, env):
     for i, j in zip(rng.integers(0, M, 40), rng.integers(0, M, 40)):
         assert np.array_equal(cells[i, j], O.count_phased(data[i], None, data[j], None, N)), (i, j)
     assert len(base) > 50 and np.sort(base, order=ORDER).tobytes() == np.sort(got, order=ORDER).tobytes()
+
+
+@pytest.mark.parametrize("N", [64, 1000, 2504, 16_000])
+def test_fused_unphased_equals_plain_and_oracle(hip, monkeypatch, N):
+    """The unphased form (k_count_screen_unphased_t + k_ld_stats_list_unphased): a variant pair's four products are
+    gathered from four lanes with DPP moves, the screen is the interval test on the admissible haplotype frequencies
+    (UnphasedMath, ld_engine.cpp:1312-1560), candidates carry HH, HQ, QH, QQ.  `-u` on data without missing genotypes, with
+    and without the allele-count band, windows, shards, small tiles, cut-offs on existing r2 values; N = 16,000 is the
+    longest row the default policy fuses (16 chunks of N bits)."""
+    M = 1500 if N <= 2504 else 600
+    al = _cohort_alleles(M, N, 700 + N)
+    data, mask, variants = util.upload(hip, al)
+    mode = T.MODE_UNPHASED
+    for minR2 in (0.1, 0.6, 0.004):
+        for opt in (0, T.OPT_R2_SCREEN):
+            f = T.Filters(minR2=minR2)
+            (p, np0, _), (q, np1, nr1), nf, ncand = _both(hip, monkeypatch, lambda: hip.ld_all(mode, f, window=opt))
+            assert nf > 0 and np0 == np1 == M * (M - 1) // 2 and nr1 == len(q) == len(p) > 20
+            assert ncand >= len(q) or minR2 < 0.01                 # (at 0.004 the list may overflow and the tile be redone plain)
+            assert ncand < 0.5 * np1 or minR2 < 0.05
+            assert np.sort(p, order=ORDER).tobytes() == np.sort(q, order=ORDER).tobytes()
+    base, _, _ = hip.ld_all(mode, T.Filters(minR2=0.05))
+    r2 = np.unique(base["R2"]); r2 = r2[r2 < 1]
+    for x in r2[:: max(1, len(r2) // 4)][:4]:
+        for cut in (np.nextafter(x, 0.0), x, np.nextafter(x, 1.0)):
+            f = T.Filters(minR2=float(cut))
+            (p, _, _), (q, _, _), nf, _ = _both(hip, monkeypatch, lambda: hip.ld_all(mode, f))
+            assert nf > 0 and np.sort(p, order=ORDER).tobytes() == np.sort(q, order=ORDER).tobytes()
+    f = T.Filters(minR2=0.1)
+    (p, np0, _), (q, np1, _), nf, _ = _both(hip, monkeypatch, lambda: hip.ld_all(mode, f, window=T.OPT_WINDOW, l_window=30_000))
+    assert nf > 0 and np0 == np1 and len(p) > 20 and np.sort(p, order=ORDER).tobytes() == np.sort(q, order=ORDER).tobytes()
+    parts = [hip.ld_all(mode, f, part=k, n_parts=3) for k in range(3)]
+    whole, _, _ = hip.ld_all(mode, f)
+    assert np.sort(np.concatenate([x[0] for x in parts]), order=ORDER).tobytes() == np.sort(whole, order=ORDER).tobytes()
+    (p, _, _), (q, _, _), nf, _ = _both(hip, monkeypatch, lambda: hip.ld_all(mode, f, tile_variants=256))
+    assert nf > 3 and np.sort(p, order=ORDER).tobytes() == np.sort(q, order=ORDER).tobytes()
+    # odd tile origins through the single-tile entry point (plane rows start even whatever the variant index)
+    for a0, nA, b0, nB, diag in ((0, M, 0, M, True), (3, 301, 377, 411, False), (129, 200, 129, 333, True)):
+        (p, _), (q, _), nf, _ = _both(hip, monkeypatch, lambda: hip.ld_tile(mode, a0, nA, b0, nB, diag, f))
+        assert nf > 0 and np.sort(p, order=ORDER).tobytes() == np.sort(q, order=ORDER).tobytes()
+    sub = np.sort(np.random.default_rng(N).choice(M, size=220, replace=False))
+    hip.set_problem(N, len(sub))
+    hip.upload(data[sub], util.to_hip_meta(variants[sub]), None)
+    want = O.all_pairs(data[sub], None, variants[sub], N, O.settings(minR2=0.1, unphased=True), vector_only=False)
+    hip.timing_reset()
+    got, _, _ = hip.ld_all(mode, T.Filters(minR2=0.1))
+    assert hip.timing()["fused_launches"] > 0 and len(want) > 20
+    util.assert_records_match(got, want, variants[sub], double_root=util.double_root_vetter(data[sub], None, variants[sub], N))

@@ -627,7 +627,7 @@ struct ScreenWork {
 	const uint32_t* col_hi; uint32_t hi_a0, hi_b0;       // r2 band (twk_hip.hip region_impl): row at set position a reaches columns < hi_b0 + col_hi[a - hi_a0]
 	uint32_t list_zone;                // pairs with both set positions below it belong to the carrier-list pass (ld_list.hip.h)
 	double two_n, cut;                 // 2N; minR2 * (1 - 1e-6)
-	uint32_t* cand; unsigned long long cap;            // [cap][3]: set position A, set position B, AA
+	uint32_t* cand; unsigned long long cap;            // [cap][3]: set position A, set position B, AA  (unphased form: [cap][6]: ..., HH, HQ, QH, QQ)
 	unsigned long long* n_cand;        // device counter (may run past cap: the host then redoes the tile the plain way)
 };
 // (Window mode's position test is left to the list kernel: the tiles of a window-mode launch are the ones the band
@@ -710,10 +710,105 @@ struct ScreenCounts {
 };
 static_assert(16 / (8 / 2) == 4, "ScreenCounts packs (t, u) as 4t + u: TB = 4");
 
+// ---- the same for the unphased planes (two rows per variant: H = het, Q = hom-alt; no missing data) -----------
+// A variant pair's four products HH, HQ, QH, QQ sit in four lanes: a lane's rows are li + 8t and its columns lj + 8u, the
+// tile starts on an even plane row, so the parity of li / lj is the plane - lane (li, lj) holds (plane li & 1 of A) x
+// (plane lj & 1 of B), and its neighbours lane ^ 1 (other B plane), lane ^ 8 (other A plane) and lane ^ 9 hold the other
+// three products of the same variant pair at the same (t, u).  Three DPP moves per slot bring them together
+// (quad_perm [1,0,3,2] and row_ror:8 - no LDS, no shuffle through memory); of the 32 slots of such a group of four lanes
+// each lane then screens the eight with u = 2 (li & 1) + (lj & 1).
+//
+// The screen (UnphasedMath, ld_engine.cpp:1312-1560; d_unphased_math has the same test in front of its cubic): every root the
+// reference may keep lies in [minhap - 1e-5, maxhap + 1e-5], minhap = n11 / 2N, maxhap = (n11 + HH) / 2N with
+// n11 = 2 (0/0,0/0) + (0/0,het) + (het,0/0) = (2N - h_A - 2 q_A) - (h_B + 2 q_B) + QH + HQ + 2 QQ, and D = f11 - P Q,
+// r2 = D^2 / (P (1 - P) Q (1 - Q)) with the REF frequencies P = 1 - (h_A + 2 q_A) / 2N, Q likewise: the pair can pass only if
+// one end of that interval reaches the cut-off.  For unlinked variants the interval is centred on P Q with half width
+// P (1 - P) Q (1 - Q), which is below any cut-off above 1/16: at the default r2 >= 0.1 only pairs in LD are candidates.
+__device__ __forceinline__ uint32_t dpp_xor1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true); }     // quad_perm [1,0,3,2]: lane ^ 1
+__device__ __forceinline__ uint32_t dpp_xor8(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, true); }    // row_ror:8: lane ^ 8
+
+template <int TB>
+struct ScreenCountsUnphased {
+	const ScreenWork* sp;
+	__device__ __forceinline__ void operator()(uint32_t (&acc)[8][TB], uint32_t yx, int wr, int wc, int li, int lj, int lane, bool) const {
+		static_assert(TB == 4, "four column slots per lane: one per lane of a 2 x 2 group");
+		const ScreenWork& s = *sp;
+		const int pa = li & 1, pb = lj & 1, k = 2 * pa + pb;          // my planes; the column slot I screen
+		// set positions (variants) of my slots: rows (li + 8t) >> 1, column (lj + 8k) >> 1 within the wave's sub-tile
+		const uint32_t vA0 = s.a0 + (yx >> 16) * (TILE / 2) + wr * 32 + (li >> 1);         // + 4t
+		const uint32_t vB = s.b0 + (yx & 0xFFFFu) * (TILE / 2) + wc * (4 * TB) + (lj >> 1) + 4 * k;
+		const double two_n = s.two_n, cut = s.cut;
+		const bool okB = vB < s.b0 + s.nB && vB < s.n_variants;
+		const uint32_t hB = okB ? s.rowpop[2 * vB] : 0u, qB = okB ? s.rowpop[2 * vB + 1] : 0u;
+		const double altB = (double)hB + 2.0 * (double)qB;                               // ALT alleles of B
+		const double Q = 1.0 - altB / two_n, vQ = Q * (1.0 - Q);
+		const bool diag = s.diag != 0;
+		uint32_t hh[8], hq[8], qh[8], qq[8], m = 0;
+#pragma unroll
+		for (int t = 0; t < 8; ++t) {
+			// the group's four products at slot (t, u), for every u; keep u == k
+			uint32_t own = 0, p1 = 0, p8 = 0, p9 = 0;
+#pragma unroll
+			for (int u = 0; u < TB; ++u) {
+				const uint32_t x = acc[t][u], x1 = dpp_xor1(x), x8 = dpp_xor8(x), x9 = dpp_xor8(x1);
+				if (u == k) { own = x; p1 = x1; p8 = x8; p9 = x9; }
+			}
+			// own = (pa, pb), p1 = (pa, pb ^ 1), p8 = (pa ^ 1, pb), p9 = (pa ^ 1, pb ^ 1)
+			const uint32_t r0 = pb ? p1 : own, r1 = pb ? own : p1;        // (pa, 0), (pa, 1)
+			const uint32_t o0 = pb ? p9 : p8, o1 = pb ? p8 : p9;          // (pa ^ 1, 0), (pa ^ 1, 1)
+			hh[t] = pa ? o0 : r0; hq[t] = pa ? o1 : r1; qh[t] = pa ? r0 : o0; qq[t] = pa ? r1 : o1;
+			const uint32_t vA = vA0 + 4 * t;
+			const bool okA = vA < s.a0 + s.nA && vA < s.n_variants;
+			const uint32_t hA = okA ? s.rowpop[2 * vA] : 0u, qA = okA ? s.rowpop[2 * vA + 1] : 0u;
+			const uint32_t hi = !okA ? 0u : (s.col_hi ? s.hi_b0 + s.col_hi[vA - s.hi_a0] : 0xFFFFFFFFu);
+			const double altA = (double)hA + 2.0 * (double)qA;
+			const double P = 1.0 - altA / two_n;
+			const double n11 = (two_n - altA) - altB + ((double)qh[t] + (double)hq[t] + 2.0 * (double)qq[t]);
+			const double pq = P * Q;
+			const double d_lo = (n11 / two_n - 1e-5) - pq, d_hi = ((n11 + (double)hh[t]) / two_n + 1e-5) - pq;
+			const double bound = cut * ((P * (1.0 - P)) * vQ);
+			const bool ok = okA && okB && (!diag || vB > vA) && vB < hi && !(d_lo * d_lo < bound && d_hi * d_hi < bound);
+			m |= (ok ? 1u : 0u) << t;
+		}
+		if (__ballot(m != 0)) {
+			typedef __attribute__((address_space(1))) uint32_t g_u32;
+			typedef __attribute__((address_space(1))) unsigned long long g_u64;
+			const uint32_t cnt = __popc(m);
+			uint32_t incl = cnt;
+#pragma unroll
+			for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+			const uint32_t total = __shfl(incl, 63);
+			unsigned long long base = 0;
+			if (lane == 0) base = __hip_atomic_fetch_add((g_u64*)s.n_cand, (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			base = __shfl(base, 0);
+			unsigned long long slot = base + (incl - cnt);
+			g_u32* const cand = (g_u32*)s.cand; const unsigned long long cap = s.cap;
+#pragma unroll
+			for (int t = 0; t < 8; ++t)
+				if ((m >> t) & 1u) {
+					if (slot < cap) {
+						g_u32* e = cand + slot * 6;
+						e[0] = vA0 + 4 * t; e[1] = vB; e[2] = hh[t]; e[3] = hq[t]; e[4] = qh[t]; e[5] = qq[t];
+					}
+					++slot;
+				}
+		}
+#pragma unroll
+		for (int t = 0; t < 8; ++t)
+#pragma unroll
+			for (int u = 0; u < TB; ++u) acc[t][u] = 0;
+	}
+};
+
 template <int NW>
 __global__ __launch_bounds__(NW * 64, NW / 2)
 void k_count_screen_t(const CountWork w, const ScreenWork* sw) {
 	count_list_body<NW, 0>(w, ScreenCounts<16 / (NW / 2)>{sw});
+}
+template <int NW>
+__global__ __launch_bounds__(NW * 64, NW / 2)
+void k_count_screen_unphased_t(const CountWork w, const ScreenWork* sw) {
+	count_list_body<NW, 0>(w, ScreenCountsUnphased<16 / (NW / 2)>{sw});
 }
 
 // Zero the tiles [first, n_tiles) of the list (the ones whose K range is split into several units).

@@ -445,6 +445,16 @@ __device__ inline void d_cells_phased_aa(const TileView& t, uint32_t sA, uint32_
 	c[3] = AA; c[1] = acA - AA; c[2] = acB - AA; c[0] = twoN - ((acA + acB) - AA);
 }
 
+// The 3x3 table of the plain unphased planes from products that arrive by value (the candidate list of the fused count
+// kernel's unphased form): the arithmetic of d_cells_unphased's PK_UNPHASED branch.
+__device__ inline void d_cells_unphased_v(const TileView& t, uint32_t sA, uint32_t sB, uint64_t HH, uint64_t HQ, uint64_t QH, uint64_t QQ, uint64_t c[9]) {
+	const uint64_t nhA = t.rowpop[2 * sA], nqA = t.rowpop[2 * sA + 1], nhB = t.rowpop[2 * sB], nqB = t.rowpop[2 * sB + 1];
+	const uint64_t nvalid = t.n_samples;
+	c[4] = HH; c[5] = HQ; c[7] = QH; c[8] = QQ;
+	c[3] = nhA - HH - HQ; c[6] = nqA - QH - QQ; c[1] = nhB - HH - QH; c[2] = nqB - HQ - QQ;
+	c[0] = nvalid - (c[1] + c[2] + c[3] + c[4] + c[5] + c[6] + c[7] + c[8]);
+}
+
 // 3x3 table as the nine sums UnphasedMath reads.
 __device__ inline void d_cells_unphased(const TileView& t, uint32_t i, uint32_t j, uint64_t c[9]) {
 	uint64_t HH, HQ, QH, QQ, nhA, nqA, nhB, nqB, nvalid;
@@ -531,8 +541,11 @@ struct StatsParams {
 // One pair of the super-tile: skips, window, cells -> math -> filters.  sA / sB: positions in the plane set; i / j the
 // same relative to the tile (C is indexed by them); aa: the pair's count when it arrives by value (plain phased planes,
 // from the fused count kernel's candidate list) instead of through C.  Returns true if the pair survives (rec filled).
-template <bool BY_VALUE>
-__device__ __forceinline__ bool d_pair(const StatsParams& p, uint32_t sA, uint32_t sB, uint32_t i, uint32_t j, uint64_t aa, twk_hip_record* rec) {
+enum { SRC_MATRIX = 0, SRC_PHASED_VALUE = 1, SRC_UNPHASED_VALUES = 2 };
+template <int SRC>
+__device__ __forceinline__ bool d_pair(const StatsParams& p, uint32_t sA, uint32_t sB, uint32_t i, uint32_t j, uint64_t aa, twk_hip_record* rec,
+                                       uint32_t hq = 0, uint32_t qh = 0, uint32_t qq = 0) {
+	constexpr bool BY_VALUE = SRC != SRC_MATRIX;
 	bool todo = sA < p.n_variants && sB < p.n_variants && (!p.diag || sB > sA);
 	if (todo && p.col_hi && sB >= p.hi_b0 + p.col_hi[sA - p.hi_a0]) todo = false;
 	if (!BY_VALUE && sA < p.list_zone && sB < p.list_zone) todo = false;       // (the list pass hands its own pairs over by value)
@@ -553,9 +566,9 @@ __device__ __forceinline__ bool d_pair(const StatsParams& p, uint32_t sA, uint32
 		if (p.vm.rid[A] != p.vm.rid[B] || (d < 0 ? -d : d) > (int64_t)p.l_window) todo = false;
 	}
 	if (!todo) return false;
-	if (BY_VALUE || p.phased_math) {          // (a count that arrives by value is a plain phased pair: the list kernel carries no cubic)
+	if (SRC == SRC_PHASED_VALUE || (SRC == SRC_MATRIX && p.phased_math)) {          // (the phased list kernel carries no cubic, the unphased one no PhasedMath front end)
 		uint64_t c[4];
-		if (BY_VALUE) d_cells_phased_aa(p.tv, sA, sB, aa, c);
+		if (SRC == SRC_PHASED_VALUE) d_cells_phased_aa(p.tv, sA, sB, aa, c);
 		else d_cells_phased(p.tv, i, j, c);
 		if (flip) { const uint64_t x = c[1]; c[1] = c[2]; c[2] = x; }
 		// Which of the two off-diagonal counts is stored in cnt[1] depends on the CPU kernel the
@@ -572,7 +585,8 @@ __device__ __forceinline__ bool d_pair(const StatsParams& p, uint32_t sA, uint32
 		return d_phased_math(c[0], c[1], c[2], c[3], p.vm, A, B, p.filt, rec);
 	}
 	uint64_t c[9];
-	d_cells_unphased(p.tv, i, j, c);
+	if (SRC == SRC_UNPHASED_VALUES) d_cells_unphased_v(p.tv, sA, sB, aa, hq, qh, qq, c);
+	else d_cells_unphased(p.tv, i, j, c);
 	if (flip) {          // transpose the 3x3 table
 		uint64_t x;
 		x = c[1]; c[1] = c[3]; c[3] = x;
@@ -604,7 +618,7 @@ void k_ld_stats(const StatsParams p) {
 	const uint32_t i = blockIdx.y;
 	bool keep = false;
 	twk_hip_record rec;
-	if (i < p.nA && j < p.nB) keep = d_pair<false>(p, p.tv.a0 + i, p.tv.b0 + j, i, j, 0, &rec);
+	if (i < p.nA && j < p.nB) keep = d_pair<SRC_MATRIX>(p, p.tv.a0 + i, p.tv.b0 + j, i, j, 0, &rec);
 	d_append_survivor(p, keep, rec);
 }
 
@@ -629,10 +643,32 @@ void k_ld_stats_list(const StatsParams* pp, const uint32_t* __restrict__ cand, c
 		twk_hip_record rec;
 		if (k < n) {
 			const uint32_t sA = cand[3 * k], sB = cand[3 * k + 1];
-			keep = d_pair<true>(p, sA, sB, 0, 0, cand[3 * k + 2], &rec);
+			keep = d_pair<SRC_PHASED_VALUE>(p, sA, sB, 0, 0, cand[3 * k + 2], &rec);
 		}
 		d_append_survivor(p, keep, rec);
 	}
+}
+
+// One candidate of the unphased form; out of line, so that the cubic's registers are the callee's and not held across the
+// candidate loop (inlined into it the kernel needs 212 VGPRs: two waves per SIMD).
+__device__ __noinline__ void d_list_item_unphased(const StatsParams* pp, const uint32_t* e, bool valid) {
+	const StatsParams& p = *pp;
+	bool keep = false;
+	twk_hip_record rec;
+	if (valid) keep = d_pair<SRC_UNPHASED_VALUES>(p, e[0], e[1], 0, 0, e[2], &rec, e[3], e[4], e[5]);
+	d_append_survivor(p, keep, rec);
+}
+// The same over the unphased form's candidates: (set position A, set position B, HH, HQ, QH, QQ), the cubic and all.
+__global__ __launch_bounds__(256)
+void k_ld_stats_list_unphased(const StatsParams* pp, const uint32_t* __restrict__ cand, const unsigned long long* __restrict__ n_cand,
+                              unsigned long long cap) {
+	unsigned long long n = *n_cand;
+	if (n > cap) n = cap;
+	const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+	const unsigned long long n_up = (n + 63) / 64 * 64;
+#pragma unroll 1
+	for (unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; k < n_up; k += stride)
+		d_list_item_unphased(pp, cand + 6 * k, k < n);
 }
 
 // Second stage of the math: Fisher's exact test on the compacted survivors (one thread per

@@ -394,7 +394,7 @@ void build_tile_list(const twk_hip_tile_desc& t, int P, const Geometry& g, bool 
 // The two parameter blocks of a fused launch travel to the device behind the tile list and the unit table (one copy
 // per launch as before): the kernels read them from memory where they need them instead of holding ~60 more scalar
 // registers through the contraction loop / the candidate loop.
-struct FusedArgs { ScreenWork screen; StatsParams stats; };
+struct FusedArgs { ScreenWork screen; StatsParams stats; int unphased; };
 int launch_count(twk_hip_ctx* c, int set, const twk_hip_tile_desc& t, Slot& s, int which, hipEvent_t e0, hipEvent_t e1,
                  uint64_t* row_pairs, const ColRange* cr = nullptr, const FusedArgs* fa = nullptr, bool* fused = nullptr,
                  const StatsParams** d_stats = nullptr) {
@@ -485,7 +485,8 @@ int launch_count(twk_hip_ctx* c, int set, const twk_hip_tile_desc& t, Slot& s, i
 		}
 		const FusedArgs* d_fa = reinterpret_cast<const FusedArgs*>(s.d_tiles[which] + words_units);
 		if (fuse && d_stats) *d_stats = &d_fa->stats;
-		if (fuse) hipLaunchKernelGGL((k_count_screen_t<COUNT_NW>), dim3(std::min(n_blocks, w.n_units)), dim3(COUNT_THREADS), 0, c->s_compute, w, &d_fa->screen);
+		if (fuse && fa->unphased) hipLaunchKernelGGL((k_count_screen_unphased_t<COUNT_NW>), dim3(std::min(n_blocks, w.n_units)), dim3(COUNT_THREADS), 0, c->s_compute, w, &d_fa->screen);
+		else if (fuse) hipLaunchKernelGGL((k_count_screen_t<COUNT_NW>), dim3(std::min(n_blocks, w.n_units)), dim3(COUNT_THREADS), 0, c->s_compute, w, &d_fa->screen);
 		else hipLaunchKernelGGL((k_count_list_t<COUNT_NW>), dim3(std::min(n_blocks, w.n_units)), dim3(COUNT_THREADS), 0, c->s_compute, w);
 		HIPCHK(c, hipGetLastError());
 	}
@@ -555,11 +556,14 @@ int enqueue_tile(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, const twk
 	s.two_pass = two_pass;
 
 	HIPCHK(c, hipMemsetAsync(s.n_out, 0, 4 * sizeof(unsigned long long), c->s_compute));
-	// The fused form: plain phased planes (one count per pair), PhasedMath, an r2 cut-off the screen can use.
-	const bool want_fused = c->fused_ok && phased && set_kind(kind1) == PK_PHASED && f.minR2 > 1e-6 && f.minR2 <= 1.0;
+	// The fused form: plain phased planes (one count per pair) with PhasedMath, or plain unphased planes (four products per
+	// pair, gathered in the epilogue) with UnphasedMath, and an r2 cut-off the screen can use.
+	const bool fused_u = !phased && set_kind(kind1) == PK_UNPHASED;
+	const bool want_fused = c->fused_ok && ((phased && set_kind(kind1) == PK_PHASED) || fused_u) && f.minR2 > 1e-6 && f.minR2 <= 1.0;
 	FusedArgs fa{};
+	fa.unphased = fused_u ? 1 : 0;
 	ScreenWork& sw = fa.screen;
-	s.fused = false; s.is_list = false; s.cand_overflow = false; s.cand_cap = s.C_words / 3;
+	s.fused = false; s.is_list = false; s.cand_overflow = false; s.cand_cap = s.C_words / (fused_u ? 6 : 3);
 	if (want_fused) {
 		const PlaneSet& ps = c->planes[kind1];
 		fa.stats = make_stats(c, kind1, t, s, phased, pl.select1, f, cr);
@@ -573,7 +577,10 @@ int enqueue_tile(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, const twk
 	const StatsParams* d_stats = nullptr;
 	rc = launch_count(c, kind1, t, s, 0, s.ev_c0, s.ev_c1, &s.row_pairs, cr, want_fused ? &fa : nullptr, &s.fused, &d_stats); if (rc) return rc;
 	if (s.fused) {
-		if (d_stats)     // (no tiles, no launch, no candidates)
+		if (d_stats && fused_u)
+			hipLaunchKernelGGL(k_ld_stats_list_unphased, dim3(c->resident_blocks * 4), dim3(256), 0, c->s_compute, d_stats, (const uint32_t*)s.C,
+			                   (const unsigned long long*)(s.n_out + 2), s.cand_cap);
+		else if (d_stats)     // (no tiles, no launch, no candidates)
 			hipLaunchKernelGGL(k_ld_stats_list, dim3(c->resident_blocks * 4), dim3(256), 0, c->s_compute, d_stats, (const uint32_t*)s.C,
 			                   (const unsigned long long*)(s.n_out + 2), s.cand_cap);
 	} else {
@@ -1348,7 +1355,8 @@ static int region_impl(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint3
 		// window width; the fused path (count -> screen in the same kernel) visits the listed tiles only.
 		const TilePlan pl = plan_for(c, mode);
 		const char* fe = std::getenv("TWK_HIP_FUSED");
-		const bool fused_likely = pl.phased1 && set_kind(pl.set1) == PK_PHASED && f->minR2 > 1e-6 && f->minR2 <= 1.0 && (!fe || std::atoi(fe) != 0)
+		const bool fused_likely = ((pl.phased1 && set_kind(pl.set1) == PK_PHASED) || (!pl.phased1 && set_kind(pl.set1) == PK_UNPHASED)) && pl.set2 < 0
+		                          && f->minR2 > 1e-6 && f->minR2 <= 1.0 && (!fe || std::atoi(fe) != 0)
 		                          && ensure_planes(c, pl.set1) == TWK_HIP_OK && c->planes[pl.set1].W / KC <= FUSED_MAX_CHUNKS;
 		const uint32_t s_hi = fused_likely ? S : std::min<uint32_t>(S, std::max<uint32_t>(512u, round_up((uint32_t)std::min<uint64_t>(wv, 1u << 20), 64)));
 		const uint32_t s_lo = std::max<uint32_t>(128u, std::min<uint32_t>(s_hi, round_up((uint32_t)std::min<uint64_t>(wv / 8, 1u << 20), 64)));
