@@ -737,11 +737,15 @@ struct ScreenCountsUnphased {
 		// set positions (variants) of my slots: rows (li + 8t) >> 1, column (lj + 8k) >> 1 within the wave's sub-tile
 		const uint32_t vA0 = s.a0 + (yx >> 16) * (TILE / 2) + wr * 32 + (li >> 1);         // + 4t
 		const uint32_t vB = s.b0 + (yx & 0xFFFFu) * (TILE / 2) + wc * (4 * TB) + (lj >> 1) + 4 * k;
-		const double two_n = s.two_n, cut = s.cut;
+		// The screen without a division: with T = 2N, a / b the ALT allele counts and ra = T - a, rb = T - b the REF counts,
+		//     (f11 - P Q) T^2 = n11 T - ra rb   at f11 = minhap,   (n11 + HH) T - ra rb   at f11 = maxhap
+		// (integers, exact in FP64), the admissibility slack 1e-5 becomes 1e-5 T^2, and r2 >= cut reads
+		//     ((f11 - P Q) T^2)^2 >= cut a ra b rb.
+		const double T2n = s.two_n, cut = s.cut, eps = 1e-5 * (T2n * T2n);
 		const bool okB = vB < s.b0 + s.nB && vB < s.n_variants;
 		const uint32_t hB = okB ? s.rowpop[2 * vB] : 0u, qB = okB ? s.rowpop[2 * vB + 1] : 0u;
-		const double altB = (double)hB + 2.0 * (double)qB;                               // ALT alleles of B
-		const double Q = 1.0 - altB / two_n, vQ = Q * (1.0 - Q);
+		const uint32_t altB = hB + 2u * qB;
+		const double db = (double)altB, rb = T2n - db, fB = db * rb;
 		const bool diag = s.diag != 0;
 		uint32_t hh[8], hq[8], qh[8], qq[8], m = 0;
 #pragma unroll
@@ -761,13 +765,13 @@ struct ScreenCountsUnphased {
 			const bool okA = vA < s.a0 + s.nA && vA < s.n_variants;
 			const uint32_t hA = okA ? s.rowpop[2 * vA] : 0u, qA = okA ? s.rowpop[2 * vA + 1] : 0u;
 			const uint32_t hi = !okA ? 0u : (s.col_hi ? s.hi_b0 + s.col_hi[vA - s.hi_a0] : 0xFFFFFFFFu);
-			const double altA = (double)hA + 2.0 * (double)qA;
-			const double P = 1.0 - altA / two_n;
-			const double n11 = (two_n - altA) - altB + ((double)qh[t] + (double)hq[t] + 2.0 * (double)qq[t]);
-			const double pq = P * Q;
-			const double d_lo = (n11 / two_n - 1e-5) - pq, d_hi = ((n11 + (double)hh[t]) / two_n + 1e-5) - pq;
-			const double bound = cut * ((P * (1.0 - P)) * vQ);
-			const bool ok = okA && okB && (!diag || vB > vA) && vB < hi && !(d_lo * d_lo < bound && d_hi * d_hi < bound);
+			const double da = (double)(hA + 2u * qA), ra = T2n - da;
+			// n11 = ra - b + (QH + HQ + 2 QQ): the (REF, REF) haplotypes that are certain
+			const double n11 = (ra - db) + (double)(qh[t] + hq[t] + 2u * qq[t]);
+			const double e_lo = (n11 * T2n - ra * rb) - eps;
+			const double e_hi = ((n11 + (double)hh[t]) * T2n - ra * rb) + eps;
+			const double bound = (cut * (da * ra)) * fB;
+			const bool ok = okA && okB && (!diag || vB > vA) && vB < hi && !(e_lo * e_lo < bound && e_hi * e_hi < bound);
 			m |= (ok ? 1u : 0u) << t;
 		}
 		if (__ballot(m != 0)) {
