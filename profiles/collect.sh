@@ -125,8 +125,13 @@ if not os.path.exists("/tmp/kg_2504_200k.twk"):
 PY
 		$R/tomahawk_amd/bin/tomahawk calc -i /tmp/kg_2504_200k.twk -o /tmp/o.two -t 64 -r 0.8 > /dev/null 2>&1     # warm the page cache
 		for fused in 1 0; do
-			for run in w1m all; do
-				if [ $run = w1m ]; then args="-p -w 1000000"; export TWK_HIP_NO_SCREEN=0; else args="-r 0.8"; export TWK_HIP_NO_SCREEN=1; fi
+			for run in w1m all w1m_u all_u; do
+				case $run in
+				w1m)   args="-p -w 1000000"; export TWK_HIP_NO_SCREEN=0 ;;
+				all)   args="-r 0.8"; export TWK_HIP_NO_SCREEN=1 ;;
+				w1m_u) args="-u -w 1000000"; export TWK_HIP_NO_SCREEN=0 ;;
+				all_u) args="-u -r 0.8"; export TWK_HIP_NO_SCREEN=1 ;;
+				esac
 				[ $TWK_HIP_NO_SCREEN = 0 ] && unset TWK_HIP_NO_SCREEN
 				name=kg_${run}_fused$fused
 				rm -rf /tmp/prof_$name
