@@ -25,7 +25,10 @@
 extern "C" {
 #endif
 
-#define TWK_HIP_ABI_VERSION 1
+/* 2: twk_hip_timing grew (fused / carrier-list counters); new entry points twk_hip_set_device_sink,
+ *    twk_hip_device_records, twk_hip_fisher_exact.  A caller built against another version must not pass
+ *    its structs in: compare twk_hip_abi_version() with the header it was compiled with. */
+#define TWK_HIP_ABI_VERSION 2
 
 enum {
 	TWK_HIP_OK         =  0,

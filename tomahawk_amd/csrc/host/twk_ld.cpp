@@ -482,6 +482,10 @@ static bool part_from_env(uint32_t& part0, uint32_t& n_procs) {
 static bool create_devices(DeviceCtxs& dc, int n_gpus) {
 	const char* force = std::getenv("TWK_HIP_FORCE_DEVICE");       // testing: several engine contexts on one GPU
 	const char* dev_env = std::getenv("TWK_HIP_DEVICE");
+	if (twk_hip_abi_version() != TWK_HIP_ABI_VERSION) {      // (struct layouts cross this boundary: twk_hip_timing, twk_hip_record)
+		std::cerr << stamp("ERROR", "HIP") << "libtwk_hip has ABI version " << twk_hip_abi_version() << ", this library was built against " << TWK_HIP_ABI_VERSION << "." << std::endl;
+		return false;
+	}
 	const int n_dev = twk_hip_device_count();
 	if (n_dev <= 0) { std::cerr << stamp("ERROR", "HIP") << "No HIP device available (this build has no CPU path)." << std::endl; return false; }
 	if (!force && n_gpus > n_dev) { std::cerr << stamp("ERROR", "HIP") << "TWK_HIP_GPUS=" << n_gpus << " but only " << n_dev << " device(s) are visible." << std::endl; return false; }

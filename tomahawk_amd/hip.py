@@ -14,6 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libtwk_hip.so")
 
+ABI_VERSION = 2                 # TWK_HIP_ABI_VERSION of include/twk_hip.h (struct layouts below)
 MODE_PHASED, MODE_UNPHASED, MODE_AUTO = 1, 2, 3
 # option bits of twk_hip_tile_desc.window / the `window` argument of ld_all / ld_region (TWK_HIP_OPT_*)
 OPT_WINDOW, OPT_KEEP_LOW_AC, OPT_REF_COMPAT, OPT_R2_SCREEN = 1, 2, 4, 8
@@ -85,6 +86,8 @@ def load_library() -> C.CDLL:
     lib = C.CDLL(LIB_PATH)
     p = C.c_void_p
     lib.twk_hip_abi_version.restype = C.c_int
+    if lib.twk_hip_abi_version() != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH} has ABI version {lib.twk_hip_abi_version()}, this binding was written for {ABI_VERSION}: rebuild (`make hip`)")
     lib.twk_hip_device_count.restype = C.c_int
     lib.twk_hip_strerror.restype = C.c_char_p
     lib.twk_hip_strerror.argtypes = [C.c_int]
