@@ -279,6 +279,13 @@ __device__ __forceinline__ void glds16s(const void* sbase, uint32_t voff, uint32
 	             "global_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
 	             : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte) : "memory");
 }
+// One dword per lane, HBM (per-lane address) -> LDS (lds_byte + 4 * lane).
+__device__ __forceinline__ void glds4(const void* gsrc, uint32_t lds_byte) {
+	uint32_t keep;
+	asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+	             "global_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+	             : "=&s"(keep) : "v"(gsrc), "s"(lds_byte) : "memory");
+}
 // One chunk of one 128-row operand tile, this wave's `n` segments from `seg0` on.  voff_even / voff_odd:
 // (lr * W + src_slot * 4) * 4 for even / odd segments, lr = lane >> 3, src_slot = (lane & 7) ^ (lr >> 1)
 // [^ 4 for odd segments]: the source-side swizzle of stage_rows, (r >> 1) & 7 with r = seg * 8 + lr.
@@ -421,8 +428,10 @@ inline uint32_t build_count_units(uint32_t n_tiles, uint32_t nchunks, uint32_t n
 // the counts go to the super-tile's C matrix (stored for a whole tile, added for a part of its K range).
 template <int TB>
 struct StoreCounts {
+	static constexpr int META_WORDS = 0;       // nothing to stage for the epilogue
 	uint32_t* C; uint32_t ldc;
-	__device__ __forceinline__ void operator()(uint32_t (&acc)[8][TB], uint32_t yx, int wr, int wc, int li, int lj, int lane, bool whole) const {
+	__device__ __forceinline__ const uint32_t* meta_src(uint32_t, uint32_t) const { return nullptr; }
+	__device__ __forceinline__ void operator()(uint32_t (&acc)[8][TB], uint32_t yx, int wr, int wc, int li, int lj, int lane, bool whole, const uint32_t*) const {
 		uint32_t* Cblk = C + (size_t)((yx >> 16) * TILE + wr * 64 + li) * ldc + (yx & 0xFFFFu) * TILE + wc * 8 * TB + lj;
 		if (whole) {
 #pragma unroll
@@ -445,6 +454,12 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 	constexpr int NSEG = 32 / NW;
 	__shared__ __attribute__((aligned(16))) uint32_t lds[2 * 2 * TILE * KC];
 	__shared__ uint32_t mbox[2];
+	// What a fused epilogue reads per row and column of its tile (allele counts, band limits): fetched by LDS-DMA when the
+	// unit starts - one dword per lane, no registers held - and published by the chunk barriers like the operand chunks, so
+	// that the epilogue finds it in LDS instead of waiting a memory round trip per tile.
+	constexpr int META = Epilogue::META_WORDS;
+	static_assert(META % 64 == 0 && META <= NW * 64, "whole waves, at most one dword per thread");
+	__shared__ uint32_t meta[META ? META : 1];
 
 	const int tid  = threadIdx.x;
 	const int lane = tid & 63;
@@ -537,6 +552,13 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 			// which keeps the slow block of a CU from sitting on big units drawn long ago.
 			++n_started;
 			if (tid == 0) fetched = draw();
+			if (META) {
+				if (wave_u < META / 64) {
+					const uint32_t yx_m = __builtin_amdgcn_readfirstlane(w.tiles[tile]);
+					glds4(epilogue.meta_src(yx_m, (uint32_t)(wave_u * 64 + lane)), (uint32_t)(uintptr_t)(lptr_t*)meta + (uint32_t)wave_u * 256u);
+				}
+				if (c + 1 == c_end) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // a one-chunk unit needs it in this very iteration: the barrier below publishes it
+			}
 			if (c + 1 == c_end) {
 				if (tid == 0) mbox[n_started & 1u] = fetched;
 				__syncthreads();
@@ -580,7 +602,7 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 
 		if (c + 1 == c_end) {          // unit done: write (whole tile) or add (part of a tile's K range) - or screen (fused form)
 			const uint32_t yx = __builtin_amdgcn_readfirstlane(w.tiles[tile]);
-			epilogue(acc, yx, wr, wc, li, lj, lane, seg_c0 == 0 && c_end == nchunks);
+			epilogue(acc, yx, wr, wc, li, lj, lane, seg_c0 == 0 && c_end == nchunks, meta);
 			if (!more) {
 				if (EXPERIMENT == 5 && tid == 0) {      // probe: when did this block finish, and on which XCD / CU?
 					uint32_t xcc, hwid;
@@ -625,6 +647,7 @@ struct ScreenWork {
 	uint32_t a0, b0, nA, nB;           // set positions of the super-tile's first row / column, variants on each axis
 	uint32_t n_variants; int diag;
 	const uint32_t* col_hi; uint32_t hi_a0, hi_b0;       // r2 band (twk_hip.hip region_impl): row at set position a reaches columns < hi_b0 + col_hi[a - hi_a0]
+	uint32_t hi_n;                     // entries of col_hi (the region's rows)
 	uint32_t list_zone;                // pairs with both set positions below it belong to the carrier-list pass (ld_list.hip.h)
 	double two_n, cut;                 // 2N; minR2 * (1 - 1e-6)
 	uint32_t* cand; unsigned long long cap;            // [cap][3]: set position A, set position B, AA  (unphased form: [cap][6]: ..., HH, HQ, QH, QQ)
@@ -636,8 +659,19 @@ struct ScreenWork {
 
 template <int TB>
 struct ScreenCounts {
+	static constexpr int META_WORDS = 3 * TILE;      // allele counts of the tile's 128 rows, of its 128 columns, band limits of the rows
 	const ScreenWork* sp;              // in device memory: read where it is needed, not held in registers through the K loop
-	__device__ __forceinline__ void operator()(uint32_t (&acc)[8][TB], uint32_t yx, int wr, int wc, int li, int lj, int lane, bool) const {
+	// where word i of the staged block comes from (always a readable address; what lies outside the region is masked in the epilogue)
+	__device__ __forceinline__ const uint32_t* meta_src(uint32_t yx, uint32_t i) const {
+		const ScreenWork& s = *sp;
+		const uint32_t r = i & (TILE - 1), sA = s.a0 + (yx >> 16) * TILE + r, sB = s.b0 + (yx & 0xFFFFu) * TILE + r;
+		if (i < TILE) return s.rowpop + sA;
+		if (i < 2 * TILE) return s.rowpop + sB;
+		if (!s.col_hi) return s.rowpop;
+		const uint32_t k = sA - s.hi_a0;
+		return s.col_hi + (k < s.hi_n ? k : s.hi_n - 1);
+	}
+	__device__ __forceinline__ void operator()(uint32_t (&acc)[8][TB], uint32_t yx, int wr, int wc, int li, int lj, int lane, bool, const uint32_t* meta) const {
 		const ScreenWork& s = *sp;
 		const uint32_t r0 = (yx >> 16) * TILE + wr * 64 + li;             // this lane's rows: r0 + 8t
 		const uint32_t c0 = (yx & 0xFFFFu) * TILE + wc * 8 * TB + lj;     // and columns: c0 + 8u
@@ -649,14 +683,14 @@ struct ScreenCounts {
 #pragma unroll
 		for (int u = 0; u < TB; ++u) {
 			const uint32_t cu = c0 + 8 * u, sB = b0 + cu;
-			acB[u] = (cu < s.nB && sB < s.n_variants) ? s.rowpop[sB] : 0u;
+			acB[u] = (cu < s.nB && sB < s.n_variants) ? meta[TILE + wc * 8 * TB + lj + 8 * u] : 0u;
 		}
 #pragma unroll
 		for (int t = 0; t < 8; ++t) {
 			const uint32_t rt = r0 + 8 * t, sA = a0 + rt;
 			const bool ok = rt < s.nA && sA < s.n_variants;
-			acA[t] = ok ? s.rowpop[sA] : 0u;
-			hiA[t] = !ok ? 0u : (s.col_hi ? s.hi_b0 + s.col_hi[sA - s.hi_a0] : 0xFFFFFFFFu);
+			acA[t] = ok ? meta[wr * 64 + li + 8 * t] : 0u;
+			hiA[t] = !ok ? 0u : (s.col_hi ? s.hi_b0 + meta[2 * TILE + wr * 64 + li + 8 * t] : 0xFFFFFFFFu);
 		}
 		const bool diag = s.diag != 0;
 		const uint32_t zone = s.list_zone;
@@ -729,8 +763,17 @@ __device__ __forceinline__ uint32_t dpp_xor8(uint32_t v) { return (uint32_t)__bu
 
 template <int TB>
 struct ScreenCountsUnphased {
+	static constexpr int META_WORDS = 2 * TILE + TILE / 2;     // H / Q counts of the tile's 128 plane rows, of its 128 plane columns, band limits of its 64 row variants
 	const ScreenWork* sp;
-	__device__ __forceinline__ void operator()(uint32_t (&acc)[8][TB], uint32_t yx, int wr, int wc, int li, int lj, int lane, bool) const {
+	__device__ __forceinline__ const uint32_t* meta_src(uint32_t yx, uint32_t i) const {
+		const ScreenWork& s = *sp;
+		if (i < TILE) return s.rowpop + 2 * s.a0 + (yx >> 16) * TILE + i;
+		if (i < 2 * TILE) return s.rowpop + 2 * s.b0 + (yx & 0xFFFFu) * TILE + (i - TILE);
+		if (!s.col_hi) return s.rowpop;
+		const uint32_t k = s.a0 + (yx >> 16) * (TILE / 2) + (i - 2 * TILE) - s.hi_a0;
+		return s.col_hi + (k < s.hi_n ? k : s.hi_n - 1);
+	}
+	__device__ __forceinline__ void operator()(uint32_t (&acc)[8][TB], uint32_t yx, int wr, int wc, int li, int lj, int lane, bool, const uint32_t* meta) const {
 		static_assert(TB == 4, "four column slots per lane: one per lane of a 2 x 2 group");
 		const ScreenWork& s = *sp;
 		const int pa = li & 1, pb = lj & 1, k = 2 * pa + pb;          // my planes; the column slot I screen
@@ -743,7 +786,8 @@ struct ScreenCountsUnphased {
 		//     ((f11 - P Q) T^2)^2 >= cut a ra b rb.
 		const double T2n = s.two_n, cut = s.cut, eps = 1e-5 * (T2n * T2n);
 		const bool okB = vB < s.b0 + s.nB && vB < s.n_variants;
-		const uint32_t hB = okB ? s.rowpop[2 * vB] : 0u, qB = okB ? s.rowpop[2 * vB + 1] : 0u;
+		const int colB = TILE + wc * 8 * TB + (lj & ~1) + 8 * k;            // plane column of my variant's H row within the tile
+		const uint32_t hB = okB ? meta[colB] : 0u, qB = okB ? meta[colB + 1] : 0u;
 		const uint32_t altB = hB + 2u * qB;
 		const double db = (double)altB, rb = T2n - db, fB = db * rb;
 		const bool diag = s.diag != 0;
@@ -763,8 +807,9 @@ struct ScreenCountsUnphased {
 			hh[t] = pa ? o0 : r0; hq[t] = pa ? o1 : r1; qh[t] = pa ? r0 : o0; qq[t] = pa ? r1 : o1;
 			const uint32_t vA = vA0 + 4 * t;
 			const bool okA = vA < s.a0 + s.nA && vA < s.n_variants;
-			const uint32_t hA = okA ? s.rowpop[2 * vA] : 0u, qA = okA ? s.rowpop[2 * vA + 1] : 0u;
-			const uint32_t hi = !okA ? 0u : (s.col_hi ? s.hi_b0 + s.col_hi[vA - s.hi_a0] : 0xFFFFFFFFu);
+			const int rowA = wr * 64 + (li & ~1) + 8 * t;
+			const uint32_t hA = okA ? meta[rowA] : 0u, qA = okA ? meta[rowA + 1] : 0u;
+			const uint32_t hi = !okA ? 0u : (s.col_hi ? s.hi_b0 + meta[2 * TILE + wr * 32 + (li >> 1) + 4 * t] : 0xFFFFFFFFu);
 			const double da = (double)(hA + 2u * qA), ra = T2n - da;
 			// n11 = ra - b + (QH + HQ + 2 QQ): the (REF, REF) haplotypes that are certain
 			const double n11 = (ra - db) + (double)(qh[t] + hq[t] + 2u * qq[t]);

@@ -85,7 +85,7 @@ struct Slot {                      // one in-flight tile (double buffered)
 
 // Window mode: row variant a0 + r of a region reaches the columns [b0 + lo[r], b0 + hi[r]).
 struct ColRange { const uint32_t* lo = nullptr; const uint32_t* hi = nullptr; uint32_t a0 = 0, b0 = 0;
-                  const uint32_t* d_hi = nullptr;      // d_hi: device copy of hi (r2 screen: the math kernel skips what was not contracted)
+                  const uint32_t* d_hi = nullptr; uint32_t n_hi = 0;      // d_hi: device copy of hi, n_hi entries (r2 screen: the math kernel skips what was not contracted)
                   uint32_t list_zone = 0; };           // pairs with both set positions below it are intersected as carrier lists (ld_list.hip.h), not contracted
 
 }  // namespace
@@ -569,7 +569,7 @@ int enqueue_tile(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, const twk
 		fa.stats = make_stats(c, kind1, t, s, phased, pl.select1, f, cr);
 		sw.rowpop = ps.rowpop; sw.a0 = t.rowA0; sw.b0 = t.rowB0; sw.nA = t.nA; sw.nB = t.nB;
 		sw.n_variants = c->M; sw.diag = (t.diag && t.rowA0 == t.rowB0) ? 1 : 0;
-		sw.col_hi = cr ? cr->d_hi : nullptr; sw.hi_a0 = cr ? cr->a0 : 0; sw.hi_b0 = cr ? cr->b0 : 0;
+		sw.col_hi = cr ? cr->d_hi : nullptr; sw.hi_a0 = cr ? cr->a0 : 0; sw.hi_b0 = cr ? cr->b0 : 0; sw.hi_n = cr ? cr->n_hi : 0;
 		sw.list_zone = cr ? cr->list_zone : 0;
 		sw.two_n = 2.0 * (double)c->N; sw.cut = f.minR2 * (1.0 - 1e-6);
 		sw.cand = s.C; sw.cap = s.cand_cap; sw.n_cand = s.n_out + 2;
@@ -1488,7 +1488,7 @@ static int region_impl(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint3
 			c->d_col_hi_cap = nA;
 		}
 		HIPCHK(c, hipMemcpy(c->d_col_hi, hi.data(), (size_t)nA * 4, hipMemcpyHostToDevice));
-		col_range.d_hi = c->d_col_hi;
+		col_range.d_hi = c->d_col_hi; col_range.n_hi = nA;
 	}
 	// The list zone of the allele-count-sorted phased set (long rows only): its pairs are intersected as carrier lists,
 	// block of rows after block of rows, before the tiles that are left are contracted.
