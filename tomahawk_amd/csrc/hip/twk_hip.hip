@@ -1660,6 +1660,15 @@ int twk_hip_fisher_exact(twk_hip_ctx* c, const int32_t* tables, uint64_t n, doub
 		if (one_lane_per_table) hipLaunchKernelGGL(k_ld_fisher, dim3(c->resident_blocks * 2), dim3(256), 0, c->s_compute, d_r, d_n, (unsigned long long)n, 2.0, lf, (const uint32_t*)nullptr);
 		else {
 			hipLaunchKernelGGL(k_ld_fisher_group, dim3(c->resident_blocks * 8), dim3(256), 0, c->s_compute, d_r, d_n, (unsigned long long)n, 2.0, lf, (uint32_t*)d_t);   // (the tables are in the records by now)
+			if (std::getenv("TWK_HIP_FISHER_SPLIT")) {      // measurement hook: time the two passes apart (stderr)
+				hipEvent_t em = nullptr; (void)hipEventCreate(&em); (void)hipEventRecord(em, c->s_compute);
+				hipLaunchKernelGGL(k_ld_fisher, dim3(c->resident_blocks * 2), dim3(256), 0, c->s_compute, d_r, d_n, (unsigned long long)n, 2.0, lf, (const uint32_t*)d_t);
+				(void)hipEventRecord(e1, c->s_compute); (void)hipEventSynchronize(e1);
+				float a = 0, b = 0; (void)hipEventElapsedTime(&a, e0, em); (void)hipEventElapsedTime(&b, em, e1);
+				unsigned long long cnt[4] = {0, 0, 0, 0}; (void)hipMemcpy(cnt, d_n, sizeof(cnt), hipMemcpyDeviceToHost);
+				fprintf(stderr, "[fisher split] group kernel %.3f ms, one-lane pass over %llu deferred tables %.3f ms\n", a, cnt[3], b);
+				(void)hipEventDestroy(em);
+			} else
 			hipLaunchKernelGGL(k_ld_fisher, dim3(c->resident_blocks * 2), dim3(256), 0, c->s_compute, d_r, d_n, (unsigned long long)n, 2.0, lf, (const uint32_t*)d_t);
 		}
 		e = hipEventRecord(e1, c->s_compute);
