@@ -522,3 +522,30 @@ def test_bench_with_eight_ranks_on_one_gpu_equals_one_rank(tmp_path, config, ext
     assert len(one) == len(eight) == 2 * d1["config"]["survivors_per_step"]
     order = ["ridA", "packA", "ridB", "packB"]
     assert np.sort(one, order=order).tobytes() == np.sort(eight, order=order).tobytes()
+
+
+def test_rccl_itself_on_this_box(tmp_path):
+    """What one GPU can show of RCCL.  (1) A world of one: the bench's own init_groups("nccl") creates the RCCL group on
+    cuda:0 and the collectives of the N > 1 path (all_gather of counts / rank ids, barrier) run on it.  (2) Two ranks on
+    the one GPU with the default backend: RCCL refuses the duplicate device on both ranks, the ranks agree on gloo over
+    the control group, say why in the JSON line, and the run completes with both ranks seen."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "sweeps", "rccl_probe.py")], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, MASTER_PORT=str(port)))
+    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+    assert "init_groups -> nccl cuda:0" in r.stdout and "collectives on the RCCL group ok: 0 5" in r.stdout, r.stdout[-1000:]
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--variants", "4096", "--samples", "50000", "--min-r2", "0.00005", "--steps", "1", "--warmup", "0",
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["config"]["collective_backend"].startswith("gloo (RCCL failed to initialise") and d["ranks_seen"] == [0, 1]
+    assert d["config"]["survivors_per_step"] > 1000 and d["config"]["two_records_written_per_step"] == 2 * d["config"]["survivors_per_step"]
