@@ -1499,11 +1499,13 @@ static int region_impl(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint3
 			col_range.list_zone = zone;
 			const uint32_t lr0 = std::min(r0, zone), lr1 = std::min(r1, zone);
 			uint32_t rows_per = (uint32_t)std::max<uint64_t>(64, std::min<uint64_t>(32768, (1ull << 25) / zone));
+			unsigned long long cap_list = std::max<unsigned long long>(cap_default, 1024);
 			for (uint32_t row = lr0; row < lr1;) {
 				const uint32_t nr = std::min(rows_per, lr1 - row);
 				unsigned long long nrec = 0;
-				rc = run_list_block(c, *f, row, nr, zone, window, l_window, col_range, cap_default, &nrec, !c->device_sink);
+				rc = run_list_block(c, *f, row, nr, zone, window, l_window, col_range, cap_list, &nrec, !c->device_sink);
 				if (rc == TWK_HIP_E_OVERFLOW && nr > 1) { rows_per = std::max<uint32_t>(1, nr / 2); continue; }      // more survivors than the buffer holds: fewer rows
+				if (rc == TWK_HIP_E_OVERFLOW && cap_list < zone) { cap_list = zone; continue; }                      // one row: it cannot have more than `zone` partners
 				if (rc) return rc;
 				if (!c->device_sink && sink && nrec) { if (sink(user, c->h_recs, nrec)) return TWK_HIP_E_INVALID; }
 				tot_recs += nrec;
