@@ -90,3 +90,20 @@ def test_list_zone_with_missing_data_in_default_mode(hip, monkeypatch):
     (b, tb), = _run(hip, monkeypatch, "1", data, mask, variants, calls)
     assert tb["list_launches"] > 0 and ta["list_launches"] == 0 and len(a) == len(b) > 20
     assert np.sort(a, order=ORDER).tobytes() == np.sort(b, order=ORDER).tobytes()
+
+
+def test_list_pass_with_a_tiny_survivor_buffer(hip, monkeypatch):
+    """TWK_HIP_RECORD_CAP (test hook) makes every buffer overflow: the list pass then takes fewer rows per launch, down to one
+    row with a buffer grown to the zone's width, and the dense tiles go through their strip redo - the same records."""
+    N, M = 1500, 1600
+    al = _cohort_alleles(M, N, 33)
+    data, mask = O.bitvectors_from_alleles(al)
+    variants = O.variants_from_alleles(al)
+    _run.N = N
+    calls = [lambda: hip.ld_all(T.MODE_PHASED, T.Filters(minR2=0.05), window=T.OPT_R2_SCREEN)[0]]
+    (a, ta), = _run(hip, monkeypatch, "2", data, None, variants, calls)
+    monkeypatch.setenv("TWK_HIP_RECORD_CAP", "40")
+    (b, tb), = _run(hip, monkeypatch, "2", data, None, variants, calls)
+    monkeypatch.delenv("TWK_HIP_RECORD_CAP")
+    assert ta["list_launches"] > 0 and tb["list_launches"] > ta["list_launches"] and len(a) == len(b) > 500
+    assert np.sort(a, order=ORDER).tobytes() == np.sort(b, order=ORDER).tobytes()
