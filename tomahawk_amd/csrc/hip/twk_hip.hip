@@ -1499,7 +1499,7 @@ static int region_impl(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint3
 			col_range.list_zone = zone;
 			const uint32_t lr0 = std::min(r0, zone), lr1 = std::min(r1, zone);
 			uint32_t rows_per = (uint32_t)std::max<uint64_t>(64, std::min<uint64_t>(32768, (1ull << 25) / zone));
-			unsigned long long cap_list = std::max<unsigned long long>(cap_default, 1024);
+			unsigned long long cap_list = cap_default;
 			for (uint32_t row = lr0; row < lr1;) {
 				const uint32_t nr = std::min(rows_per, lr1 - row);
 				unsigned long long nrec = 0;
