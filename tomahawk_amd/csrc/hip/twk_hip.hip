@@ -67,7 +67,8 @@ enum { MODE_INT_AUTO_CLEAN = 0x10,     // phased math on the plain planes; pairs
 
 struct Slot {                      // one in-flight tile (double buffered)
 	uint32_t* C = nullptr; size_t C_words = 0;
-	twk_hip_record* out = nullptr; unsigned long long capacity = 0;
+	twk_hip_record* out = nullptr; unsigned long long capacity = 0;      // survivor buffer and its size (grow-only)
+	unsigned long long cap_use = 0;               // ... of which the current launch may use this many (what the caller asked for)
 	unsigned long long* n_out = nullptr;          // device counters: [0] survivors appended, [1] of those dropped by the Fisher cut-off,
 	                                              // [2] candidates of the fused count kernel, [3] spare
 	unsigned long long* h_n_out = nullptr;        // pinned host copy of all four
@@ -309,6 +310,7 @@ int ensure_slot(twk_hip_ctx* c, Slot& s, size_t C_words, unsigned long long capa
 		HIPCHK(c, hipMalloc((void**)&s.out, (size_t)capacity * sizeof(twk_hip_record)));
 		s.capacity = capacity;
 	}
+	s.cap_use = capacity;
 	return TWK_HIP_OK;
 }
 
@@ -511,7 +513,7 @@ StatsParams make_stats(twk_hip_ctx* c, int set, const twk_hip_tile_desc& t, cons
 	p.diag = (t.diag && t.rowA0 == t.rowB0) ? 1 : 0;
 	p.phased_math = phased_math ? 1 : 0; p.auto_select = auto_select;
 	p.window = t.window; p.l_window = t.l_window;
-	p.filt = f; p.out = s.out; p.capacity = s.capacity; p.n_out = s.n_out;
+	p.filt = f; p.out = s.out; p.capacity = s.cap_use; p.n_out = s.n_out;
 	return p;
 }
 
@@ -602,14 +604,14 @@ int enqueue_tile(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, const twk
 		const char* fe = std::getenv("TWK_HIP_FISHER");
 		const LFact lf{c->d_lfact, c->lfact_n};
 		if (!fe || std::strcmp(fe, "group") != 0) {
-			hipLaunchKernelGGL(k_ld_fisher, dim3(c->resident_blocks * 2), dim3(256), 0, c->s_compute, s.out, s.n_out, s.capacity, f.minP, lf, (const uint32_t*)nullptr);
+			hipLaunchKernelGGL(k_ld_fisher, dim3(c->resident_blocks * 2), dim3(256), 0, c->s_compute, s.out, s.n_out, s.cap_use, f.minP, lf, (const uint32_t*)nullptr);
 		} else {
 			// Records the group kernel does not take - a count beyond the log-factorial table, or an observed-table probability
 			// so small that the reference's recurrence runs on denormals (ld_math.hip.h) - are listed (in the slot's count
 			// buffer: the math kernels are done with it, and it has a word for every pair of the tile) and go through the
 			// one-lane walk, which ends at once when the list is empty.
-			hipLaunchKernelGGL(k_ld_fisher_group, dim3(c->resident_blocks * 8), dim3(256), 0, c->s_compute, s.out, s.n_out, s.capacity, f.minP, lf, s.C);
-			hipLaunchKernelGGL(k_ld_fisher, dim3(c->resident_blocks * 2), dim3(256), 0, c->s_compute, s.out, s.n_out, s.capacity, f.minP, lf, (const uint32_t*)s.C);
+			hipLaunchKernelGGL(k_ld_fisher_group, dim3(c->resident_blocks * 8), dim3(256), 0, c->s_compute, s.out, s.n_out, s.cap_use, f.minP, lf, s.C);
+			hipLaunchKernelGGL(k_ld_fisher, dim3(c->resident_blocks * 2), dim3(256), 0, c->s_compute, s.out, s.n_out, s.cap_use, f.minP, lf, (const uint32_t*)s.C);
 		}
 	}
 	HIPCHK(c, hipGetLastError());
@@ -722,7 +724,7 @@ int finish_tile(twk_hip_ctx* c, Slot& s, const twk_hip_tile_desc& t, unsigned lo
 	const unsigned long long n = *s.h_n_out;
 	*n_out = n;
 	if ((s.fused || s.is_list) && s.h_n_out[2] > s.cand_cap) { s.cand_overflow = true; return TWK_HIP_E_OVERFLOW; }   // more candidates than the list holds
-	if (n > s.capacity) return TWK_HIP_E_OVERFLOW;
+	if (n > s.cap_use) return TWK_HIP_E_OVERFLOW;
 	if (n) {
 		// records that failed the Fisher cut-off were only marked on the device (and counted): they sort behind the rest
 		const unsigned long long dropped = std::min(s.h_n_out[1], n), kept = n - dropped;
@@ -787,7 +789,7 @@ int run_list_block(twk_hip_ctx* c, const twk_hip_filters& f, uint32_t row0, uint
 	}
 	{
 		const LFact lf{c->d_lfact, c->lfact_n};
-		hipLaunchKernelGGL(k_ld_fisher, dim3(c->resident_blocks * 2), dim3(256), 0, c->s_compute, s.out, s.n_out, s.capacity, f.minP, lf, (const uint32_t*)nullptr);
+		hipLaunchKernelGGL(k_ld_fisher, dim3(c->resident_blocks * 2), dim3(256), 0, c->s_compute, s.out, s.n_out, s.cap_use, f.minP, lf, (const uint32_t*)nullptr);
 		HIPCHK(c, hipGetLastError());
 	}
 	HIPCHK(c, hipMemcpyAsync(s.h_n_out, s.n_out, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->s_compute));
@@ -1529,7 +1531,7 @@ static int region_impl(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint3
 		}
 		if (rc == TWK_HIP_E_OVERFLOW) {
 			uint64_t nr = 0;
-			rc = redo_tile_in_strips(c, mode, mine[done], *f, s.capacity, sink, user, &nr);
+			rc = redo_tile_in_strips(c, mode, mine[done], *f, s.cap_use, sink, user, &nr);
 			if (rc) return rc;
 			tot_recs += nr;
 		} else if (rc) {
