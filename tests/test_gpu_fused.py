@@ -232,3 +232,25 @@ def test_fused_unphased_equals_plain_and_oracle(hip, monkeypatch, N):
     got, _, _ = hip.ld_all(mode, T.Filters(minR2=0.1))
     assert hip.timing()["fused_launches"] > 0 and len(want) > 20
     util.assert_records_match(got, want, variants[sub], double_root=util.double_root_vetter(data[sub], None, variants[sub], N))
+
+
+@pytest.mark.parametrize("mode", [T.MODE_PHASED, T.MODE_UNPHASED])
+def test_fused_tiles_that_end_inside_a_block_tile(hip, monkeypatch, mode):
+    """Tiles whose variant counts are not multiples of the 128-row block tile, in the middle of an LD-rich matrix: the
+    columns (and rows) of the last block tile that lie beyond the tile's own variants belong to other tiles and must not
+    become candidates (found by the overflow path, which cuts a tile into one-row strips)."""
+    N, M = 800, 900
+    al = util.mosaic_alleles(M, N, 15, n_founders=4, switch=0.004, mut=0.001)
+    util.upload(hip, al)
+    f = T.Filters(minR2=0.3)
+    for a0, nA, b0, nB, diag in ((265, 1, 265, 1, True), (265, 1, 266, 100, False), (100, 70, 100, 200, True), (300, 129, 429, 131, False), (5, 3, 400, 2, False)):
+        (p, np0), (q, np1), nf, _ = _both(hip, monkeypatch, lambda: hip.ld_tile(mode, a0, nA, b0, nB, diag, f))
+        assert np0 == np1 and np.sort(p, order=ORDER).tobytes() == np.sort(q, order=ORDER).tobytes(), (a0, nA, b0, nB)
+        assert len(q) == 0 or ((q["idxA"] >= a0) & (q["idxA"] < a0 + nA) & (q["idxB"] >= b0) & (q["idxB"] < b0 + nB)).all()
+    assert len(hip.ld_tile(mode, 100, 70, 100, 200, True, f)[0]) > 100
+    # and the whole run with a survivor buffer that overflows everywhere (strips of one row)
+    whole, _, _ = hip.ld_all(mode, f)
+    monkeypatch.setenv("TWK_HIP_RECORD_CAP", "300")
+    strips, _, nrec = hip.ld_all(mode, f)
+    monkeypatch.delenv("TWK_HIP_RECORD_CAP")
+    assert nrec == len(whole) > 5000 and np.sort(whole, order=ORDER).tobytes() == np.sort(strips, order=ORDER).tobytes()

@@ -677,8 +677,8 @@ struct ScreenCounts {
 		const uint32_t c0 = (yx & 0xFFFFu) * TILE + wc * 8 * TB + lj;     // and columns: c0 + 8u
 		const double two_n = s.two_n, cut = s.cut;
 		const uint32_t a0 = s.a0, b0 = s.b0;
-		// allele counts of the lane's rows and columns (0 for padding rows: such a pair has dn = 0 and is dropped);
-		// hiA: first column the row does not reach (0 for a padding row: reaches nothing)
+		// allele counts of the lane's rows and columns; hiA: first column the row does not reach (0 for a row outside the
+		// tile's variants: reaches nothing) - the columns outside the tile's variants lie beyond every row's reach
 		uint32_t acB[TB], acA[8], hiA[8];
 #pragma unroll
 		for (int u = 0; u < TB; ++u) {
@@ -690,7 +690,10 @@ struct ScreenCounts {
 			const uint32_t rt = r0 + 8 * t, sA = a0 + rt;
 			const bool ok = rt < s.nA && sA < s.n_variants;
 			acA[t] = ok ? meta[wr * 64 + li + 8 * t] : 0u;
-			hiA[t] = !ok ? 0u : (s.col_hi ? s.hi_b0 + meta[2 * TILE + wr * 64 + li + 8 * t] : 0xFFFFFFFFu);
+			// first column the row does not reach: the end of the tile's columns, of the matrix, of the row's r2 band
+			uint32_t h = s.b0 + s.nB < s.n_variants ? s.b0 + s.nB : s.n_variants;
+			if (s.col_hi) { const uint32_t hb = s.hi_b0 + meta[2 * TILE + wr * 64 + li + 8 * t]; h = hb < h ? hb : h; }
+			hiA[t] = ok ? h : 0u;
 		}
 		const bool diag = s.diag != 0;
 		const uint32_t zone = s.list_zone;

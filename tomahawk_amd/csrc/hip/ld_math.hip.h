@@ -547,6 +547,7 @@ __device__ __forceinline__ bool d_pair(const StatsParams& p, uint32_t sA, uint32
                                        uint32_t hq = 0, uint32_t qh = 0, uint32_t qq = 0) {
 	constexpr bool BY_VALUE = SRC != SRC_MATRIX;
 	bool todo = sA < p.n_variants && sB < p.n_variants && (!p.diag || sB > sA);
+	if (BY_VALUE && (sA - p.tv.a0 >= p.nA || sB - p.tv.b0 >= p.nB)) todo = false;       // (a candidate is a pair of the tile's own variants: checked again here)
 	if (todo && p.col_hi && sB >= p.hi_b0 + p.col_hi[sA - p.hi_a0]) todo = false;
 	if (!BY_VALUE && sA < p.list_zone && sB < p.list_zone) todo = false;       // (the list pass hands its own pairs over by value)
 	// A regrouped plane set (ids != null) can meet a pair in either order; the record always

@@ -723,8 +723,15 @@ int finish_tile(twk_hip_ctx* c, Slot& s, const twk_hip_tile_desc& t, unsigned lo
 	c->timing.variant_pairs += pairs_in_tile(c, t);
 	const unsigned long long n = *s.h_n_out;
 	*n_out = n;
-	if ((s.fused || s.is_list) && s.h_n_out[2] > s.cand_cap) { s.cand_overflow = true; return TWK_HIP_E_OVERFLOW; }   // more candidates than the list holds
-	if (n > s.cap_use) return TWK_HIP_E_OVERFLOW;
+	if ((s.fused || s.is_list) && s.h_n_out[2] > s.cand_cap) {       // more candidates than the list holds
+		s.cand_overflow = true;
+		snprintf(c->err, sizeof(c->err), "%llu candidates for a list of %llu (tile rows %u+%u, cols %u+%u)", s.h_n_out[2], s.cand_cap, t.rowA0, t.nA, t.rowB0, t.nB);
+		return TWK_HIP_E_OVERFLOW;
+	}
+	if (n > s.cap_use) {
+		snprintf(c->err, sizeof(c->err), "%llu survivors for a buffer of %llu (tile rows %u+%u, cols %u+%u%s)", n, s.cap_use, t.rowA0, t.nA, t.rowB0, t.nB, s.is_list ? ", list pass" : "");
+		return TWK_HIP_E_OVERFLOW;
+	}
 	if (n) {
 		// records that failed the Fisher cut-off were only marked on the device (and counted): they sort behind the rest
 		const unsigned long long dropped = std::min(s.h_n_out[1], n), kept = n - dropped;
