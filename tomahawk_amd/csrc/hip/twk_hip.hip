@@ -806,13 +806,13 @@ int run_list_block(twk_hip_ctx* c, const twk_hip_filters& f, uint32_t row0, uint
 
 // One tile, synchronously, on the spare slot; survivors end up in c->h_recs.
 int run_tile_sync(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, const twk_hip_filters& f,
-                  unsigned long long capacity, unsigned long long* n_out, bool to_host = true) {
+                  unsigned long long capacity, unsigned long long* n_out, bool to_host = true, const ColRange* cr = nullptr) {
 	Slot& s = c->slot[2];
-	int rc = enqueue_tile(c, mode, t, f, s, capacity); if (rc) return rc;
+	int rc = enqueue_tile(c, mode, t, f, s, capacity, cr); if (rc) return rc;
 	rc = finish_tile(c, s, t, n_out, to_host);
 	if (rc == TWK_HIP_E_OVERFLOW && s.cand_overflow) {       // too many candidates for the fused form: through C, for the rest of this call
 		c->fused_ok = false;
-		rc = enqueue_tile(c, mode, t, f, s, capacity); if (rc) return rc;
+		rc = enqueue_tile(c, mode, t, f, s, capacity, cr); if (rc) return rc;
 		rc = finish_tile(c, s, t, n_out, to_host);
 	}
 	return rc;
@@ -820,8 +820,9 @@ int run_tile_sync(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, const tw
 
 // A tile whose survivors overflowed the device buffer: redo it in row strips
 // that cannot overflow (strip_rows * cols <= capacity).
+// (cr: the region's column ranges - window, r2 band, list zone - so that a strip decides exactly the pairs its tile would have)
 int redo_tile_in_strips(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, const twk_hip_filters& f,
-                        unsigned long long capacity, twk_hip_record_sink sink, void* user, uint64_t* n_recs) {
+                        unsigned long long capacity, twk_hip_record_sink sink, void* user, uint64_t* n_recs, const ColRange* cr = nullptr) {
 	const uint32_t strip = (uint32_t)std::max<unsigned long long>(1, capacity / std::max<uint32_t>(t.nB, 1));
 	const bool diag = t.diag && t.rowA0 == t.rowB0;
 	for (uint32_t r0 = 0; r0 < t.nA; r0 += strip) {
@@ -840,7 +841,7 @@ int redo_tile_in_strips(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, co
 		}
 		for (int k = 0; k < np; ++k) {
 			unsigned long long n = 0;
-			int rc = run_tile_sync(c, mode, parts[k], f, (unsigned long long)parts[k].nA * parts[k].nB, &n, !c->device_sink);
+			int rc = run_tile_sync(c, mode, parts[k], f, (unsigned long long)parts[k].nA * parts[k].nB, &n, !c->device_sink, cr);
 			if (rc) return rc;
 			if (!c->device_sink && sink && n && sink(user, c->h_recs, n)) return TWK_HIP_E_INVALID;
 			*n_recs += n;
@@ -1534,11 +1535,11 @@ static int region_impl(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint3
 		rc = finish_tile(c, s, mine[done], &nrec, !c->device_sink);
 		if (rc == TWK_HIP_E_OVERFLOW && s.cand_overflow) {     // the fused form's candidate list overflowed: this tile again through C
 			c->fused_ok = false;                                 // (and the tiles not yet enqueued as well)
-			rc = run_tile_sync(c, mode, mine[done], *f, cap_default, &nrec, !c->device_sink);
+			rc = run_tile_sync(c, mode, mine[done], *f, cap_default, &nrec, !c->device_sink, windowed ? &col_range : nullptr);
 		}
 		if (rc == TWK_HIP_E_OVERFLOW) {
 			uint64_t nr = 0;
-			rc = redo_tile_in_strips(c, mode, mine[done], *f, s.cap_use, sink, user, &nr);
+			rc = redo_tile_in_strips(c, mode, mine[done], *f, s.cap_use, sink, user, &nr, windowed ? &col_range : nullptr);
 			if (rc) return rc;
 			tot_recs += nr;
 		} else if (rc) {
