@@ -1,7 +1,7 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
-mkdir -p gpurun_out/r02
+mkdir -p gpurun_out/r03
 rm -f /tmp/parity_stats.jsonl
 export TWK_PARITY_STATS=/tmp/parity_stats.jsonl
 timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -2
@@ -16,5 +16,5 @@ for r in rows:
         if isinstance(v,(int,float)) and k not in ("n_samples","records","ties","n"): agg[k]=max(agg.get(k,0.0),v)
 print("calls", len(rows), "cubic records", sum(r.get("n",0) for r in rows))
 for k in sorted(agg): print(f"  {k}: {agg[k]:.3g}")
-json.dump(agg, open("gpurun_out/r02/parity_stats_max.json","w"), indent=1)
+json.dump(agg, open("gpurun_out/r03/parity_stats_max.json","w"), indent=1)
 PY
