@@ -107,3 +107,39 @@ def test_list_pass_with_a_tiny_survivor_buffer(hip, monkeypatch):
     monkeypatch.delenv("TWK_HIP_RECORD_CAP")
     assert ta["list_launches"] > 0 and tb["list_launches"] > ta["list_launches"] and len(a) == len(b) > 500
     assert np.sort(a, order=ORDER).tobytes() == np.sort(b, order=ORDER).tobytes()
+
+
+@pytest.mark.parametrize("N,forced", [(66_000, False), (1500, True)])
+def test_unphased_list_zone_equals_dense_and_oracle(hip, monkeypatch, N, forced):
+    """`-u`: the lists hold samples with their genotype (het / rare homozygote), the merge sorts common samples into four
+    counters, HH / HQ / QH / QQ follow by which of the two variants has ALT as its major allele; candidates go through the
+    unphased list math kernel.  Same checks as the phased zone, incl. variants turned into their complements."""
+    M = 1500 if not forced else 2200
+    al = _with_flips(_cohort_alleles(M, N, 400 + N), 6)
+    data, mask = O.bitvectors_from_alleles(al)
+    variants = O.variants_from_alleles(al)
+    _run.N = N
+    mode = T.MODE_UNPHASED
+    calls = [lambda: hip.ld_all(mode, T.Filters(minR2=0.1), window=T.OPT_R2_SCREEN)[0],
+             lambda: hip.ld_all(mode, T.Filters(minR2=0.5), window=T.OPT_R2_SCREEN)[0],
+             lambda: hip.ld_all(mode, T.Filters(minR2=0.01), window=T.OPT_R2_SCREEN)[0],
+             lambda: np.concatenate([hip.ld_all(mode, T.Filters(minR2=0.1), part=k, n_parts=3, window=T.OPT_R2_SCREEN)[0] for k in range(3)])]
+    dense = _run(hip, monkeypatch, "0", data, None, variants, calls)
+    lists = _run(hip, monkeypatch, "2" if forced else "1", data, None, variants, calls)
+    for k, ((a, ta), (b, tb)) in enumerate(zip(dense, lists)):
+        assert ta["list_launches"] == 0 and tb["list_launches"] > 0 and tb["list_pairs"] > 10_000, (k, tb)
+        assert len(a) == len(b) > 20, k
+        assert np.sort(a, order=ORDER).tobytes() == np.sort(b, order=ORDER).tobytes(), k
+    ac = np.minimum(variants["ac"], 2 * N - variants["ac"])
+    rare = np.argsort(ac, kind="stable")[:300]
+    sub = np.sort(np.concatenate([rare, np.random.default_rng(2).choice(np.setdiff1d(np.arange(M), rare), size=60, replace=False)]))
+    monkeypatch.setenv("TWK_HIP_LISTS", "2")
+    hip.set_problem(N, len(sub))
+    hip.upload(data[sub], util.to_hip_meta(variants[sub]), None)
+    hip.timing_reset()
+    got, _, _ = hip.ld_all(mode, T.Filters(minR2=0.05), window=T.OPT_R2_SCREEN)
+    assert hip.timing()["list_launches"] > 0
+    monkeypatch.delenv("TWK_HIP_LISTS")
+    want = O.all_pairs(data[sub], None, variants[sub], N, O.settings(minR2=0.05, unphased=True), vector_only=False)
+    assert len(want) > 20
+    util.assert_records_match(got, want, variants[sub], n_samples=N, double_root=util.double_root_vetter(data[sub], None, variants[sub], N))

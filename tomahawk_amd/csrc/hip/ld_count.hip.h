@@ -819,7 +819,7 @@ struct ScreenCountsUnphased {
 			const double e_lo = (n11 * T2n - ra * rb) - eps;
 			const double e_hi = ((n11 + (double)hh[t]) * T2n - ra * rb) + eps;
 			const double bound = (cut * (da * ra)) * fB;
-			const bool ok = okA && okB && (!diag || vB > vA) && vB < hi && !(e_lo * e_lo < bound && e_hi * e_hi < bound);
+			const bool ok = okA && okB && (!diag || vB > vA) && vB < hi && !(vA < s.list_zone && vB < s.list_zone) && !(e_lo * e_lo < bound && e_hi * e_hi < bound);
 			m |= (ok ? 1u : 0u) << t;
 		}
 		if (__ballot(m != 0)) {

@@ -119,4 +119,115 @@ void k_list_screen(const ListWork w) {
 	}
 }
 
+// ---- the same for UnphasedMath: lists of samples with their genotype ------------------------------------------
+// rows: the allele-count-sorted unphased planes (per variant a row H = het and a row Q = hom-alt, one bit per sample).
+// A rare variant's list holds the samples that are not homozygous for its major allele, ascending, as
+// (sample << 1) | g with g = 0 for a het and g = 1 for the rare homozygote (hom-alt; hom-ref when flip[v], i.e. when ALT is
+// the major allele), then LIST_END.  len[v] <= the minor allele count.  One wave per variant.
+__global__ __launch_bounds__(256)
+void k_build_lists_unphased(const uint32_t* __restrict__ rows, uint32_t W, uint32_t W_live, uint32_t n_samples, const uint32_t* __restrict__ rowpop,
+                            uint32_t n_list, uint32_t stride, uint32_t* __restrict__ lists, uint32_t* __restrict__ len, uint32_t* __restrict__ flip) {
+	const uint32_t v = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+	if (v >= n_list) return;
+	const int lane = threadIdx.x & 63;
+	const uint32_t nh = rowpop[2 * v], nq = rowpop[2 * v + 1];
+	const bool inv = (uint64_t)nh + 2ull * nq > (uint64_t)n_samples;          // more ALT than REF alleles: the rare homozygote is 0/0
+	const uint32_t* H = rows + (size_t)(2 * v) * W;
+	const uint32_t* Q = H + W;
+	uint32_t* out = lists + (size_t)v * stride;
+	uint32_t base = 0;
+	for (uint32_t k0 = 0; k0 < W_live; k0 += 64) {
+		const uint32_t k = k0 + lane;
+		uint32_t h = 0, r = 0;
+		if (k < W_live) {
+			h = H[k];
+			const uint32_t q = Q[k];
+			if (inv) {
+				r = ~(h | q);
+				const uint32_t s0 = k * 32;                                     // samples beyond N do not exist
+				if (n_samples - s0 < 32) r &= (1u << (n_samples - s0)) - 1u;
+			} else r = q;
+		}
+		uint32_t x = h | r;
+		const unsigned long long any = __ballot(x != 0);
+		if (!any) continue;
+		const uint32_t cnt = __popc(x);
+		uint32_t incl = cnt;
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(incl, o); if (lane >= o) incl += y; }
+		uint32_t at = base + incl - cnt;
+		while (x) {
+			const int b = __ffs(x) - 1;
+			x &= x - 1;
+			if (at < stride - 1) out[at] = ((k * 32 + b) << 1) | ((r >> b) & 1u);
+			++at;
+		}
+		base += __shfl(incl, 63);
+	}
+	const uint32_t total = inv ? nh + (n_samples - nh - nq) : nh + nq;
+	if (lane == 0) { out[total < stride - 1 ? total : stride - 1] = LIST_END; len[v] = total; flip[v] = inv ? 1u : 0u; }
+}
+
+// One pair per lane, as k_list_screen: the merge runs over sample ids and sorts every common sample into one of four
+// counters by the two genotype bits (packed 16 bits each: a list has at most a few hundred entries); the four products
+// the unphased planes would have yielded follow from them and the variants' own counts -
+//     HH = x[het][het];  a rare homozygote that is hom-alt counts as Q directly, one that is hom-ref turns its row / column
+//     into "everyone else": HQ = h_A - x[het][het] - x[het][rare_B], QQ = N - |list_A u list_B| for two such variants, ...
+// - then the interval screen of the fused unphased epilogue (ld_count.hip.h), and the six-word candidate
+// (set position A, set position B, HH, HQ, QH, QQ) for k_ld_stats_list_unphased.
+__global__ __launch_bounds__(256)
+void k_list_screen_unphased(const ListWork w, uint32_t n_samples) {
+	const uint32_t i = w.row0 + blockIdx.y;
+	const uint32_t j = i + 1 + blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t limit = w.col_hi ? w.hi_b0 + w.col_hi[i - w.hi_a0] : w.n_list;
+	if (limit > w.n_list) limit = w.n_list;
+	bool keep = false;
+	uint32_t HH = 0, HQ = 0, QH = 0, QQ = 0;
+	if (j < limit) {
+		const uint32_t* a = w.lists + (size_t)i * w.stride;
+		const uint32_t* b = w.lists + (size_t)j * w.stride;
+		const uint32_t na = w.mac[i], nb = w.mac[j];
+		uint32_t ia = 0, ib = 0, va = a[0], vb = b[0];
+		unsigned long long x = 0;                      // four 16-bit counters: [gA][gB] at bit 16 * (2 gA + gB)
+		while (ia < na && ib < nb) {
+			const uint32_t sa = va >> 1, sb = vb >> 1;
+			if (sa == sb) x += 1ull << (16u * (((va & 1u) << 1) | (vb & 1u)));
+			const bool fa = sa <= sb, fb = sb <= sa;
+			ia += fa; ib += fb;
+			if (fa) va = a[ia];
+			if (fb) vb = b[ib];
+		}
+		const uint32_t x00 = (uint32_t)(x & 0xFFFFu), x01 = (uint32_t)((x >> 16) & 0xFFFFu), x10 = (uint32_t)((x >> 32) & 0xFFFFu), x11 = (uint32_t)(x >> 48);
+		const uint32_t hA = w.rowpop[2 * i], qA = w.rowpop[2 * i + 1], hB = w.rowpop[2 * j], qB = w.rowpop[2 * j + 1];
+		const bool fA = w.flip[i] != 0, fB = w.flip[j] != 0;
+		const uint32_t rA = fA ? n_samples - hA - qA : qA, rB = fB ? n_samples - hB - qB : qB;      // rare homozygotes (listed with g = 1)
+		HH = x00;
+		HQ = !fB ? x01 : hA - x00 - x01;               // het_A with hom-alt_B: listed, or everyone of het_A that is not listed in B
+		QH = !fA ? x10 : hB - x00 - x10;
+		if (!fA && !fB) QQ = x11;
+		else if (!fA && fB) QQ = rA - x10 - x11;       // hom-alt_A (listed) with hom-alt_B (not listed)
+		else if (fA && !fB) QQ = rB - x01 - x11;
+		else QQ = n_samples - ((hA + rA) + (hB + rB) - (x00 + x01 + x10 + x11));
+		// the interval screen (see ScreenCountsUnphased): T = 2N, ALT / REF allele counts, no division
+		const double T = w.two_n, eps = 1e-5 * (T * T);
+		const double da = (double)(hA + 2u * qA), db = (double)(hB + 2u * qB), ra = T - da, rb = T - db;
+		const double n11 = (ra - db) + (double)(QH + HQ + 2u * QQ);
+		const double e_lo = (n11 * T - ra * rb) - eps, e_hi = ((n11 + (double)HH) * T - ra * rb) + eps;
+		const double bound = (w.cut * (da * ra)) * (db * rb);
+		keep = !(e_lo * e_lo < bound && e_hi * e_hi < bound);
+	}
+	const unsigned long long ballot = __ballot(keep);
+	if (ballot) {
+		const int lane = threadIdx.x & 63;
+		const int leader = __ffsll((long long)ballot) - 1;
+		unsigned long long base = 0;
+		if (lane == leader) base = atomicAdd(w.n_cand, (unsigned long long)__popcll(ballot));
+		base = __shfl(base, leader);
+		if (keep) {
+			const unsigned long long slot = base + __popcll(ballot & ((1ull << lane) - 1));
+			if (slot < w.cap) { uint32_t* e = w.cand + slot * 6; e[0] = i; e[1] = j; e[2] = HH; e[3] = HQ; e[4] = QH; e[5] = QQ; }
+		}
+	}
+}
+
 }  // namespace twk

@@ -263,14 +263,16 @@ int ensure_planes(twk_hip_ctx* c, int set) {
 	const uint32_t live_rows = c->M * P;
 	hipLaunchKernelGGL(k_row_popcount, dim3((live_rows + 3) / 4), dim3(256), 0, c->s_compute, ps.rows, ps.W, live_rows, ps.rowpop);
 	HIPCHK(c, hipGetLastError());
-	if (set == PS_SORTED_P) {
+	if (set == PS_SORTED_P || set == PS_SORTED_U) {
 		// Carrier lists for the head of the set (ld_list.hip.h): worth it where a dense pair costs more than a merge of
-		// two lists, i.e. for long rows only.  list_max = W / 128 carriers (the measured break-even is ~W / 150 merge
-		// steps per side, profiles/r03_t2_list_vs_dense.txt), and not below 32 - rows shorter than 4096 words (N < 65,536)
-		// keep no lists.  TWK_HIP_LISTS=0: never; =2: always, with at least 8 carriers (test hook).
+		// two lists, i.e. for long rows only.  list_max = (phased row words) / 128 carriers (the measured break-even is
+		// ~W / 150 merge steps per side, profiles/r03_t2_list_vs_dense.txt; an unphased pair costs twice a phased one in
+		// the dense kernel and the same in a merge over samples, so the same limit is the conservative one there), and not
+		// below 32 - rows shorter than 4096 words (N < 65,536) keep no lists.  TWK_HIP_LISTS=0: never; =2: always, with at
+		// least 8 carriers (test hook).
 		const char* le = std::getenv("TWK_HIP_LISTS");
 		const int lists_env = le ? std::atoi(le) : 1;
-		uint32_t lmax = ps.W / 128;
+		uint32_t lmax = c->Wp / 128;
 		if (lists_env == 2) lmax = std::max<uint32_t>(lmax, 8);
 		if (lists_env != 0 && (lmax >= 32 || lists_env == 2)) {
 			const uint64_t T2 = 2ull * c->N;
@@ -286,8 +288,12 @@ int ensure_planes(twk_hip_ctx* c, int set) {
 				HIPCHK(c, hipMalloc((void**)&ps.lists, (size_t)n * (lmax + 1) * 4));
 				HIPCHK(c, hipMalloc((void**)&ps.list_mac, (size_t)n * 4));
 				HIPCHK(c, hipMalloc((void**)&ps.list_flip, (size_t)n * 4));
-				hipLaunchKernelGGL(k_build_lists, dim3((n + 3) / 4), dim3(256), 0, c->s_compute, (const uint32_t*)ps.rows, ps.W, ps.W_live, (uint64_t)T2,
-				                   (const uint32_t*)ps.rowpop, n, lmax + 1, ps.lists, ps.list_mac, ps.list_flip);
+				if (set == PS_SORTED_P)
+					hipLaunchKernelGGL(k_build_lists, dim3((n + 3) / 4), dim3(256), 0, c->s_compute, (const uint32_t*)ps.rows, ps.W, ps.W_live, (uint64_t)T2,
+					                   (const uint32_t*)ps.rowpop, n, lmax + 1, ps.lists, ps.list_mac, ps.list_flip);
+				else
+					hipLaunchKernelGGL(k_build_lists_unphased, dim3((n + 3) / 4), dim3(256), 0, c->s_compute, (const uint32_t*)ps.rows, ps.W, ps.W_live, c->N,
+					                   (const uint32_t*)ps.rowpop, n, lmax + 1, ps.lists, ps.list_mac, ps.list_flip);
 				HIPCHK(c, hipGetLastError());
 			}
 		}
@@ -753,17 +759,19 @@ int finish_tile(twk_hip_ctx* c, Slot& s, const twk_hip_tile_desc& t, unsigned lo
 // Rows [row0, row0 + n_rows) of the list zone of the allele-count-sorted phased set, synchronously on the spare slot: every
 // pair (i, j), i < j < zone, inside the r2 band, as an intersection of two carrier lists (ld_list.hip.h) -> candidates ->
 // the list math kernel -> Fisher -> sorted survivors (c->h_recs or the device sink, like a tile).
-int run_list_block(twk_hip_ctx* c, const twk_hip_filters& f, uint32_t row0, uint32_t n_rows, uint32_t zone, int32_t window, uint32_t l_window,
+int run_list_block(twk_hip_ctx* c, const twk_hip_filters& f, bool unphased, uint32_t row0, uint32_t n_rows, uint32_t zone, int32_t window, uint32_t l_window,
                    const ColRange& cr, unsigned long long capacity, unsigned long long* n_out, bool to_host) {
-	const PlaneSet& ps = c->planes[PS_SORTED_P];
+	const int set = unphased ? PS_SORTED_U : PS_SORTED_P;
+	const PlaneSet& ps = c->planes[set];
 	Slot& s = c->slot[2];
 	const uint64_t pairs_max = (uint64_t)n_rows * (zone - row0);
-	int rc = ensure_slot(c, s, (size_t)std::max<uint64_t>(3 * pairs_max, 1024), capacity); if (rc) return rc;
+	const unsigned cand_words = unphased ? 6 : 3;              // (A, B, ALTALT) or (A, B, HH, HQ, QH, QQ)
+	int rc = ensure_slot(c, s, (size_t)std::max<uint64_t>(cand_words * pairs_max, 1024), capacity); if (rc) return rc;
 	if (!c->d_list_stats) HIPCHK(c, hipMalloc((void**)&c->d_list_stats, sizeof(StatsParams)));
-	s.two_pass = false; s.fused = false; s.is_list = true; s.cand_overflow = false; s.cand_cap = s.C_words / 3; s.minP = f.minP;
+	s.two_pass = false; s.fused = false; s.is_list = true; s.cand_overflow = false; s.cand_cap = s.C_words / cand_words; s.minP = f.minP;
 	twk_hip_tile_desc t{};
 	t.rowA0 = row0; t.nA = n_rows; t.rowB0 = row0; t.nB = zone - row0; t.diag = 1; t.window = window; t.l_window = l_window;
-	const StatsParams sp = make_stats(c, PS_SORTED_P, t, s, true, 0, f, &cr);
+	const StatsParams sp = make_stats(c, set, t, s, !unphased, 0, f, &cr);
 	HIPCHK(c, hipMemsetAsync(s.n_out, 0, 4 * sizeof(unsigned long long), c->s_compute));
 	HIPCHK(c, hipMemcpyAsync(c->d_list_stats, &sp, sizeof(sp), hipMemcpyHostToDevice, c->s_compute));
 	ListWork w{};
@@ -785,13 +793,16 @@ int run_list_block(twk_hip_ctx* c, const twk_hip_filters& f, uint32_t row0, uint
 	}
 	HIPCHK(c, hipEventRecord(s.ev_c0, c->s_compute));
 	if (width) {
-		hipLaunchKernelGGL(k_list_screen, dim3((width + 255) / 256, n_rows), dim3(256), 0, c->s_compute, w);
+		if (unphased) hipLaunchKernelGGL(k_list_screen_unphased, dim3((width + 255) / 256, n_rows), dim3(256), 0, c->s_compute, w, c->N);
+		else hipLaunchKernelGGL(k_list_screen, dim3((width + 255) / 256, n_rows), dim3(256), 0, c->s_compute, w);
 		HIPCHK(c, hipGetLastError());
 	}
 	HIPCHK(c, hipEventRecord(s.ev_c1, c->s_compute));
 	if (width) {
-		hipLaunchKernelGGL(k_ld_stats_list, dim3(c->resident_blocks * 4), dim3(256), 0, c->s_compute, (const StatsParams*)c->d_list_stats, (const uint32_t*)s.C,
-		                   (const unsigned long long*)(s.n_out + 2), s.cand_cap);
+		if (unphased) hipLaunchKernelGGL(k_ld_stats_list_unphased, dim3(c->resident_blocks * 4), dim3(256), 0, c->s_compute, (const StatsParams*)c->d_list_stats,
+		                                 (const uint32_t*)s.C, (const unsigned long long*)(s.n_out + 2), s.cand_cap);
+		else hipLaunchKernelGGL(k_ld_stats_list, dim3(c->resident_blocks * 4), dim3(256), 0, c->s_compute, (const StatsParams*)c->d_list_stats, (const uint32_t*)s.C,
+		                        (const unsigned long long*)(s.n_out + 2), s.cand_cap);
 		HIPCHK(c, hipGetLastError());
 	}
 	{
@@ -1502,8 +1513,8 @@ static int region_impl(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint3
 	}
 	// The list zone of the allele-count-sorted phased set (long rows only): its pairs are intersected as carrier lists,
 	// block of rows after block of rows, before the tiles that are left are contracted.
-	if (screen == 1 && a0 == 0 && b0 == 0) {
-		const PlaneSet& ps = c->planes[PS_SORTED_P];
+	if (screen && a0 == 0 && b0 == 0) {
+		const PlaneSet& ps = c->planes[screen == 2 ? PS_SORTED_U : PS_SORTED_P];
 		const uint32_t zone = std::min(ps.n_list, nA);
 		if (zone >= 2 && ps.lists) {
 			col_range.list_zone = zone;
@@ -1513,7 +1524,7 @@ static int region_impl(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint3
 			for (uint32_t row = lr0; row < lr1;) {
 				const uint32_t nr = std::min(rows_per, lr1 - row);
 				unsigned long long nrec = 0;
-				rc = run_list_block(c, *f, row, nr, zone, window, l_window, col_range, cap_list, &nrec, !c->device_sink);
+				rc = run_list_block(c, *f, screen == 2, row, nr, zone, window, l_window, col_range, cap_list, &nrec, !c->device_sink);
 				if (rc == TWK_HIP_E_OVERFLOW && nr > 1) { rows_per = std::max<uint32_t>(1, nr / 2); continue; }      // more survivors than the buffer holds: fewer rows
 				if (rc == TWK_HIP_E_OVERFLOW && cap_list < zone) { cap_list = zone; continue; }                      // one row: it cannot have more than `zone` partners
 				if (rc) return rc;
