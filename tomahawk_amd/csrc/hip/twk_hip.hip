@@ -265,16 +265,17 @@ int ensure_planes(twk_hip_ctx* c, int set) {
 	HIPCHK(c, hipGetLastError());
 	if (set == PS_SORTED_P || set == PS_SORTED_U) {
 		// Carrier lists for the head of the set (ld_list.hip.h): worth it where a dense pair costs more than a merge of
-		// two lists, i.e. for long rows only.  list_max = (phased row words) / 128 carriers (the measured break-even is
-		// ~W / 150 merge steps per side, profiles/r03_t2_list_vs_dense.txt; an unphased pair costs twice a phased one in
-		// the dense kernel and the same in a merge over samples, so the same limit is the conservative one there), and not
-		// below 32 - rows shorter than 4096 words (N < 65,536) keep no lists.  TWK_HIP_LISTS=0: never; =2: always, with at
-		// least 8 carriers (test hook).
+		// two lists, i.e. for long rows only.  list_max = (phased row words) / 128 carriers for PhasedMath (the measured
+		// break-even is ~W / 150 merge steps per side, profiles/r03_t2_list_vs_dense.txt) and twice that for UnphasedMath (a
+		// dense unphased pair costs twice a phased one, a merge over samples about the same), and not below 32 - rows
+		// shorter than 4096 words (N < 65,536) keep no lists.  TWK_HIP_LISTS=0: never; =2: always, with at least 8 carriers
+		// (test hook); TWK_HIP_LIST_MAX=n: the limit itself (measurement hook).
 		const char* le = std::getenv("TWK_HIP_LISTS");
 		const int lists_env = le ? std::atoi(le) : 1;
-		uint32_t lmax = c->Wp / 128;
+		uint32_t lmax = c->Wp / (set == PS_SORTED_U ? 64 : 128);      // measured optimum at N = 1 M: 488 / 976 carriers (profiles/r03_list_max_sweep.txt)
 		if (lists_env == 2) lmax = std::max<uint32_t>(lmax, 8);
-		if (lists_env != 0 && (lmax >= 32 || lists_env == 2)) {
+		if (const char* lm = std::getenv("TWK_HIP_LIST_MAX")) { const unsigned long v = std::strtoul(lm, nullptr, 10); if (v >= 8 && v <= (1u << 20)) lmax = (uint32_t)v; }   // measurement hook
+		if (lists_env != 0 && (c->Wp / 128 >= 32 || lists_env == 2)) {
 			const uint64_t T2 = 2ull * c->N;
 			uint32_t n = 0;                                  // variants of the missing-free head with a minor allele count <= lmax
 			while (n < ps.n_front) {
