@@ -274,7 +274,7 @@ int ensure_planes(twk_hip_ctx* c, int set) {
 		const int lists_env = le ? std::atoi(le) : 1;
 		uint32_t lmax = c->Wp / (set == PS_SORTED_U ? 64 : 128);      // measured optimum at N = 1 M: 488 / 976 carriers (profiles/r03_list_max_sweep.txt)
 		if (lists_env == 2) lmax = std::max<uint32_t>(lmax, 8);
-		if (const char* lm = std::getenv("TWK_HIP_LIST_MAX")) { const unsigned long v = std::strtoul(lm, nullptr, 10); if (v >= 8 && v <= (1u << 20)) lmax = (uint32_t)v; }   // measurement hook
+		if (const char* lm = std::getenv("TWK_HIP_LIST_MAX")) { const unsigned long v = std::strtoul(lm, nullptr, 10); if (v >= 8 && v <= 60000) lmax = (uint32_t)v; }   // measurement hook (the unphased merge counts in 16 bits)
 		if (lists_env != 0 && (c->Wp / 128 >= 32 || lists_env == 2)) {
 			const uint64_t T2 = 2ull * c->N;
 			uint32_t n = 0;                                  // variants of the missing-free head with a minor allele count <= lmax
