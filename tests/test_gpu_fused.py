@@ -254,3 +254,32 @@ def test_fused_tiles_that_end_inside_a_block_tile(hip, monkeypatch, mode):
     strips, _, nrec = hip.ld_all(mode, f)
     monkeypatch.delenv("TWK_HIP_RECORD_CAP")
     assert nrec == len(whole) > 5000 and np.sort(whole, order=ORDER).tobytes() == np.sort(strips, order=ORDER).tobytes()
+
+
+@pytest.mark.parametrize("N", [10, 40, 656, 752, 1100, 2504, 100_010])
+def test_padding_behind_the_last_chunk_is_skipped_without_changing_a_count(hip, monkeypatch, N):
+    """Rows are padded to whole 32-word K-chunks; the contraction of a row's last chunk stops at the last half-slot
+    (2 words) that carries data (CountWork::last_halves).  The sample counts cover 1..15 live half-slots in both
+    layouts (2N bits phased, N bits unphased), with and without missing genotypes (the mask planes are padded alike):
+    contingency cells equal to the full contraction's and the oracle's, records of the plain and the fused path equal."""
+    M = 300 if N < 50_000 else 140
+    for miss in (0.0, 0.02):
+        al = util.mosaic_alleles(M, N, N + int(miss * 100), n_founders=6, switch=0.02, mut=0.003, miss_rate=miss, miss_variants=0.5 if miss else 0.0)
+        data, mask, variants = util.upload(hip, al)
+        rng = np.random.default_rng(N)
+        for mode, count in ((T.MODE_PHASED, O.count_phased), (T.MODE_UNPHASED, O.count_unphased)):
+            monkeypatch.setenv("TWK_HIP_SKIP_PAD", "0")
+            full = hip.count_tile(mode, 0, M, 0, M)
+            rec_full, _, _ = hip.ld_all(mode, T.Filters(minR2=0.1))
+            monkeypatch.delenv("TWK_HIP_SKIP_PAD")
+            cells = hip.count_tile(mode, 0, M, 0, M)
+            assert np.array_equal(cells, full)
+            for i, j in zip(rng.integers(0, M, 60), rng.integers(0, M, 60)):
+                mi = mask[i] if mask is not None and variants["gt_missing"][i] else None
+                mj = mask[j] if mask is not None and variants["gt_missing"][j] else None
+                assert np.array_equal(cells[i, j], count(data[i], mi, data[j], mj, N)), (mode, i, j)
+            for fused in ("0", "1"):
+                monkeypatch.setenv("TWK_HIP_FUSED", fused)
+                rec, _, _ = hip.ld_all(mode, T.Filters(minR2=0.1))
+                monkeypatch.delenv("TWK_HIP_FUSED")
+                assert len(rec) > 10 and np.sort(rec, order=ORDER).tobytes() == np.sort(rec_full, order=ORDER).tobytes()

@@ -371,6 +371,10 @@ struct CountWork {
 	// queue_begin[q + 1]); a block starts on the queue of the XCD it runs on and moves on to the next when that is empty.
 	uint32_t n_queues;
 	uint32_t queue_begin[9];
+	// Half-slots (8 bytes per row) of a row's LAST chunk that carry data, 1..16; 0 = all 16.  The padding behind
+	// them is zero in every plane, so the contraction of the last chunk stops there: at 2 504 samples an unphased
+	// row is 79 live words in 3 chunks of 32, and the last 8 half-slots of every tile are skipped (-17 %).
+	uint32_t last_halves;
 };
 
 // The unit table of a launch (host side; shared by the engine and the dev tools).  Guided self-scheduling:
@@ -584,20 +588,37 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 		// outstanding-read count is tracked by hand (LDS returns in order: lgkmcnt(12) = "everything but
 		// the 12 reads just issued has arrived").
 		const uint32_t bufbase = lds_base + (uint32_t)buf * (2 * LDS_TILE_BYTES);
-		uint2 ra[2][8], rb[2][TB];
-		read_half<TB>(ra[0], rb[0], bufbase + offA[0], bufbase + offA[4], bufbase + offB[0], bufbase + offB[4], 0);
+		const int h_end = (c + 1 == nchunks && w.last_halves) ? (int)w.last_halves : 16;     // wave-uniform
+		if (h_end == 16) {
+			uint2 ra[2][8], rb[2][TB];
+			read_half<TB>(ra[0], rb[0], bufbase + offA[0], bufbase + offA[4], bufbase + offB[0], bufbase + offB[4], 0);
 #pragma unroll
-		for (int h = 0; h < 16; ++h) {
-			if (h + 1 < 16) {
-				const int q = (h + 1) >> 1;
-				read_half<TB>(ra[(h + 1) & 1], rb[(h + 1) & 1], bufbase + offA[q], bufbase + offA[q ^ 4], bufbase + offB[q],
-				              bufbase + offB[q ^ 4], (h + 1) & 1);
-				asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
-			} else {
-				asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+			for (int h = 0; h < 16; ++h) {
+				if (h + 1 < 16) {
+					const int q = (h + 1) >> 1;
+					read_half<TB>(ra[(h + 1) & 1], rb[(h + 1) & 1], bufbase + offA[q], bufbase + offA[q ^ 4], bufbase + offB[q],
+					              bufbase + offB[q ^ 4], (h + 1) & 1);
+					asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+				} else {
+					asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+				}
+#pragma unroll
+				for (int u = 0; u < TB; ++u) contract_half<TB>(acc, u, ra[h & 1], rb[h & 1][u]);
 			}
+		} else {
+			// The last chunk of a row whose data ends before the chunk does (CountWork::last_halves): the zero padding
+			// is not contracted.  A plain loop - one such chunk per tile, the other waves of the SIMD cover its LDS
+			// waits.  offX[k] = offX[0] ^ (k << 4): the slot swizzle lives in address bits 4..6.
+#pragma unroll 1
+			for (int h = 0; h < h_end; ++h) {
+				const uint32_t q = (uint32_t)(h >> 1) << 4, hb = (uint32_t)(h & 1) << 3;
+				uint2 ra[8], rb[TB];
+				read_half<TB>(ra, rb, bufbase + (offA[0] ^ q) + hb, bufbase + (offA[0] ^ q ^ 64u) + hb, bufbase + (offB[0] ^ q) + hb,
+				              bufbase + (offB[0] ^ q ^ 64u) + hb, 0);
+				asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-			for (int u = 0; u < TB; ++u) contract_half<TB>(acc, u, ra[h & 1], rb[h & 1][u]);
+				for (int u = 0; u < TB; ++u) contract_half<TB>(acc, u, ra, rb[u]);
+			}
 		}
 
 		if (c + 1 == c_end) {          // unit done: write (whole tile) or add (part of a tile's K range) - or screen (fused form)

@@ -487,6 +487,13 @@ int launch_count(twk_hip_ctx* c, int set, const twk_hip_tile_desc& t, Slot& s, i
 		w.ticket = c->tickets + ((&s - c->slot) * 2 + which) * 8;
 		w.n_queues = n_queues;
 		for (int q = 0; q < 9; ++q) w.queue_begin[q] = queue_begin[q];
+		{
+			const char* spe = std::getenv("TWK_HIP_SKIP_PAD");      // measurement hook: 0 = contract the zero padding too
+			const bool skip_pad = !(spe && spe[0] == '0');
+			const uint32_t live_last = ps.W_live - (ps.W / KC - 1) * KC;      // live words of the last chunk, 1..KC (W = W_live rounded up to KC)
+			w.last_halves = (skip_pad && ps.W_live && ps.W_live <= ps.W && ps.W - ps.W_live < KC) ? (live_last + 1) / 2 : 0;
+			if (w.last_halves >= 16) w.last_halves = 0;
+		}
 		HIPCHK(c, hipMemsetAsync(w.ticket, 0, 8 * 4, c->s_compute));
 		if (first_split < T) {
 			hipLaunchKernelGGL(k_zero_tiles, dim3((uint32_t)T - first_split), dim3(256), 0, c->s_compute, w.tiles, first_split, w.C, w.ldc);
