@@ -257,15 +257,14 @@ int twk_hip_shard_rows(uint32_t n_rows, uint32_t n_cols, int32_t triangle, uint3
 
 /* Fisher's exact test on n caller-supplied 2x2 tables (tables[4*i + {0,1,2,3}] = n11, n12, n21, n22), two-sided P
  * into p_two_sided[i]: kt_fisher_exact (lib/fisher_math.cpp:231-267) as the pair math calls it
- * (ld_engine.cpp:1222-1226, :1656-1658), through the engine's own Fisher kernels - one_lane_per_table != 0: the
- * reference's walk, one table per lane (the kernel the pair math uses); == 0: the experimental 16-lanes-per-table
- * kernel, which evaluates every term from the log-factorial table and hands the tables it cannot reproduce the
- * reference on (underflow band, counts beyond the table) to the former.  Needs
+ * (ld_engine.cpp:1222-1226, :1656-1658), through the engine's own Fisher kernels: the reference's walk, one table per
+ * lane, behind the search for its starting points.  in_given_order == 0: as the pair math runs it, the walks in the order
+ * of their length; != 0: in the order of `tables` (same P, bit for bit: a measurement switch).  Needs
  * twk_hip_set_problem first (the log-factorial table covers counts up to 2 * n_samples + 15; larger counts take
- * lgamma itself).  *kernel_ms (may be NULL): the kernel's duration (HIP events).  A parity and measurement entry
+ * lgamma itself).  *kernel_ms (may be NULL): the kernels' duration (HIP events).  A parity and measurement entry
  * point: the pair math reaches the same kernels internally. */
 int twk_hip_fisher_exact(twk_hip_ctx* ctx, const int32_t* tables, uint64_t n, double* p_two_sided,
-                         int32_t one_lane_per_table, float* kernel_ms);
+                         int32_t in_given_order, float* kernel_ms);
 
 /* ---- measurement ------------------------------------------------------ */
 /* Cumulative device time (HIP events on the engine's own stream) and launch

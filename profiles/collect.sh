@@ -143,7 +143,7 @@ PY
 import csv
 rows = list(csv.DictReader(open("$OUT/${name}_kernel_stats.csv")))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
-for r in rows[:7]:
+for r in rows[:9]:
     print("   %-60s calls %5s  total %9.3f ms  avg %9.3f us" % (r["Name"][:60], r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3))
 print("   all kernels: %.3f ms" % (tot / 1e6))
 PY

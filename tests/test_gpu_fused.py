@@ -135,17 +135,18 @@ def test_fused_forced_on_long_rows(hip, monkeypatch):
     assert np.sort(plain, order=ORDER).tobytes() == np.sort(forced, order=ORDER).tobytes()
 
 
-def test_fisher_kernels_agree_with_each_other_and_the_oracle(hip):
-    """twk_hip_fisher_exact: the two Fisher kernels on the same tables - the reference's walk with one table per lane
-    (production) and the 16-lanes-per-table kernel (every term from the log-factorial table; tables in the underflow
-    band go through the recurrence) - against kt_fisher_exact as the oracle restates it (fisher_math.cpp:231-267):
-    rare and common margins at n = 5,008, P from 1 down through the underflow region, and tables beyond the
-    log-factorial table."""
+def test_fisher_pipeline_agrees_with_the_oracle_in_any_order(hip):
+    """twk_hip_fisher_exact: the engine's Fisher kernels (starting points -> walk-length bins -> the reference's walk, one
+    table per lane; ld_math.hip.h) against kt_fisher_exact as the oracle restates it (fisher_math.cpp:231-267): rare and
+    common margins at n = 5,008, P from 1 down through the underflow region to exactly 0, tables beyond the log-factorial
+    table, and balanced tables at n = 2,000,000 whose P runs through 1e-270 .. 1e-320.  The walks start on cells whose
+    index is a multiple of 11 - where the reference's own recurrence is re-synchronised - so every term they add is the
+    reference's own number: the agreement does not depend on the size of P.  Binned and unbinned give the same bits."""
     rng = np.random.default_rng(12)
     hip.set_problem(2504, 8)
     n = 5008
     tabs = []
-    for _ in range(3000):
+    for _ in range(6000):
         r1 = int(rng.integers(1, n)); c1 = int(rng.choice([rng.integers(1, 60), rng.integers(1, n)]))
         lo, hi = max(0, r1 + c1 - n), min(r1, c1)
         mean = r1 * c1 / n
@@ -155,13 +156,22 @@ def test_fisher_kernels_agree_with_each_other_and_the_oracle(hip):
              [1, 0, 0, 5007], [2500, 4, 4, 2500], [20_000, 5, 7, 30_000], [7_000, 6_000, 6_500, 7_200]]        # the last two: beyond the table
     tabs = np.array(tabs, dtype=np.int32)
     assert (tabs >= 0).all()
-    lane, _ = hip.fisher_exact(tabs, one_lane_per_table=True)
-    group, _ = hip.fisher_exact(tabs)
+    binned, _ = hip.fisher_exact(tabs)
+    as_given, _ = hip.fisher_exact(tabs, ordered=False)
+    assert binned.tobytes() == as_given.tobytes()
     want = np.array([O.fisher(*[int(x) for x in t])[2] for t in tabs])
-    assert (want < 1e-250).sum() > 50 and (want > 0.05).sum() > 100
-    big = want > 1e-300
-    assert np.allclose(lane[big], want[big], rtol=1e-7, atol=0) and np.allclose(group[big], want[big], rtol=1e-7, atol=0)
-    assert np.allclose(lane[~big], want[~big], rtol=1e-6, atol=1e-320) and np.allclose(group[~big], want[~big], rtol=1e-6, atol=1e-320)
+    assert ((want < 1e-250) & (want > 0)).sum() > 20 and (want > 0.05).sum() > 100 and (want == 0).sum() > 10
+    assert np.allclose(binned, want, rtol=1e-8, atol=1e-322)
+    assert (binned[want == 0] == 0).all()
+    # n = 2,000,000: q crosses the smallest normal double between these tables
+    hip.set_problem(1_000_000, 8)
+    ks = np.arange(12_600, 14_300, 50)
+    big = np.array([[500_000 + k, 500_000 - k, 500_000 - k, 500_000 + k] for k in ks], dtype=np.int32)
+    got, _ = hip.fisher_exact(np.tile(big, (40, 1)))          # (enough tables for the bins to engage)
+    assert (got.reshape(40, -1) == got[: len(big)]).all()
+    want = np.array([O.fisher(*[int(x) for x in t])[2] for t in big])
+    assert (want > 1e-290).sum() > 5 and ((want > 0) & (want < 1e-300)).sum() >= 1 and (want == 0).sum() > 3
+    assert np.allclose(got[: len(big)], want, rtol=1e-6, atol=1e-322)
 
 
 @pytest.mark.parametrize("env", [{"TWK_HIP_SEG": "64"}, {"TWK_HIP_SEG": "32", "TWK_HIP_XCD_QUEUES": "8"}, {"TWK_HIP_XCD_QUEUES": "8"},

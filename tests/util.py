@@ -25,9 +25,10 @@ COMPARED = _collections.Counter()          # "records", "cubic" (records out of 
 # First accounting run (round 3, 171 -m gpu tests): 1,245,531 records, 420,616 of them from the cubic: floor:D / Dprime /
 # R / R2 / ChiSqFisher 54 each (1.3e-4), floor:cnt 1,027 (2.4e-3: expected counts next to zero, where a relative bar means
 # nothing), tie:round 4 (1e-5), tie:roots 0, double-root 2 (5e-6), tie:fisher-stop 26 (2.1e-5 of all records), p-floor 0.
-# (Fisher's test evaluated term by term - k_ld_fisher_group - would add ~3e-4 of all records as ties where the reference's
-# recurrence starts on denormal terms, P below ~1e-280, and a few hundred on the denormal grid itself; those records are
-# therefore left to the one-lane walk, which runs the reference's recurrence and agrees with it bit for bit.)
+# (Fisher's test evaluated term by term from the log-factorial table - tried in round 3 - would add ~3e-4 of all records
+# as ties where the reference's recurrence starts on denormal terms, P below ~1e-280, and a few hundred on the denormal
+# grid itself; the device runs the reference's recurrence from the cells where the reference re-synchronises it, and
+# agrees with it down to P = 0.)
 EXEMPTION_CAPS = {"floor:D": 3e-4, "floor:Dprime": 3e-4, "floor:R": 3e-4, "floor:R2": 3e-4, "floor:ChiSqFisher": 3e-4,
                   "floor:cnt": 5e-3, "tie:roots": 1e-5, "tie:round": 3e-5, "tie:fisher-stop": 6e-5, "double-root": 1.5e-5,
                   "p-floor": 1e-5, "p-denormal": 2e-3}
@@ -278,7 +279,7 @@ def assert_records_match(gpu_recs, orc_recs, variants, n_samples=None, rtol=1e-6
             own = O.fisher(gt[0], gt[2], gt[1], gt[3])[2] if neighbour else None
             if max(abs(gP), abs(wP)) < 2.2250738585072014e-308 and abs(gP - wP) <= 2e-321:
                 # below DBL_MIN a double has no relative precision left (spacing 4.9e-324): the reference's ratio recurrence and
-                # the device's term-by-term exp() round differently on that grid - a few hundred grid steps is all that can be asked
+                # a term-by-term exp() round differently on that grid - a few hundred grid steps is all that can be asked
                 used["p-denormal"] += 1
             elif neighbour and np.isclose(g["P"], own, rtol=rtol, atol=p_floor):
                 ties.append((k, "round"))
@@ -292,7 +293,7 @@ def assert_records_match(gpu_recs, orc_recs, variants, n_samples=None, rtol=1e-6
                 # evaluation agrees with the reference to 2e-8 when it does count it).  The two P then
                 # differ by exactly q: checked here, nothing else is allowed.  (The same happens for q below
                 # ~1e-290 at any n, where the reference's recurrence starts on denormal terms; there the
-                # device runs the reference's own recurrence - k_ld_fisher - and agrees bit for bit.)
+                # device runs the reference's own recurrence - k_ld_fisher_t - from the same cells and agrees.)
                 ties.append((k, "fisher-stop"))
             elif np.isclose(gP, wP, rtol=rtol, atol=p_floor):
                 # Fisher P underflows to exactly 0 for strong associations: absolute floor for what is left

@@ -40,12 +40,15 @@ struct VariantMeta {       // SoA view of twk_hip_variant_meta on the device
 // problem with the same lgamma (k_build_lfact): the same bits, three loads instead of three evaluations.
 struct LFact { const double* lf; int n; };       // lf[0..n)
 // lgamma(i + 1); arguments outside the table (the wrapped counts of TWK_HIP_OPT_REF_COMPAT narrow to negative ints) take lgamma itself
-__device__ inline double d_lgamma1(const LFact& t, int i) { return (unsigned)i < (unsigned)t.n ? t.lf[i] : lgamma((double)(i + 1)); }
-__device__ inline double d_lbinom(const LFact& t, int n, int k) {
+// (kept out of line: inlined, libm's lgamma - three copies per log-binomial - made hipcc leave d_lbinom and d_fisher_two
+// as real calls with the table passed through scratch memory)
+__device__ __noinline__ double d_lgamma1_beyond_table(int i) { return lgamma((double)(i + 1)); }
+__device__ __forceinline__ double d_lgamma1(const LFact& t, int i) { return (unsigned)i < (unsigned)t.n ? t.lf[i] : d_lgamma1_beyond_table(i); }
+__device__ __forceinline__ double d_lbinom(const LFact& t, int n, int k) {
 	if (k == 0 || n == k) return 0;
 	return d_lgamma1(t, n) - d_lgamma1(t, k) - d_lgamma1(t, n - k);
 }
-__device__ inline double d_hypergeo(const LFact& t, int n11, int n1_, int n_1, int n) {
+__device__ __forceinline__ double d_hypergeo(const LFact& t, int n11, int n1_, int n_1, int n) {
 	return exp(d_lbinom(t, n1_, n11) + d_lbinom(t, n - n1_, n_1 - n11) - d_lbinom(t, n, n_1));
 }
 __global__ void k_build_lfact(double* __restrict__ lf, int n) {
@@ -61,11 +64,11 @@ __global__ void k_build_lfact(double* __restrict__ lf, int n) {
 struct TableWalk {
 	int k, row1, col1, total;          // current upper-left cell and the margins
 	double pmf;                        // probability of the current table
-	__device__ inline double reset(const LFact& t, int k0, int r1, int c1, int n) {      // fix the margins, evaluate cell k0 in full
+	__device__ __forceinline__ double reset(const LFact& t, int k0, int r1, int c1, int n) {      // fix the margins, evaluate cell k0 in full
 		k = k0; row1 = r1; col1 = c1; total = n;
 		return pmf = d_hypergeo(t, k, row1, col1, total);
 	}
-	__device__ inline double move_to(const LFact& t, int to) {                            // pmf of cell `to` (same margins)
+	__device__ __forceinline__ double move_to(const LFact& t, int to) {                            // pmf of cell `to` (same margins)
 		const int slack = total - row1 - col1;                                            // lower-right cell = to + slack
 		if (to % 11 != 0 && to + slack != 0) {
 			if (to == k + 1) {
@@ -89,62 +92,143 @@ struct TableWalk {
 // in the underflow band, where the reference's result hangs on the rounding of its recurrence (k_ld_fisher_group below),
 // the nearer starting point no longer reproduced it bit for bit: 9 of 1.2 M records.  Not worth it.)
 __device__ inline double d_fisher_skip_exponent(int) { return 40.0; }
-// Two-sided P only (left / right tails are not stored in the record).
-__device__ inline double d_fisher_two(const LFact& t, int n11, int n12, int n21, int n22) {
-	int i, j, max, min;
-	double p, q, left, right;
-	TableWalk w;
-	const int n1_ = n11 + n12, n_1 = n11 + n21, n = n11 + n12 + n21 + n22;
-	max = (n_1 < n1_) ? n_1 : n1_;
-	min = n1_ + n_1 - n;
-	if (min < 0) min = 0;
-	if (min == max) return 1.;
-	q = w.reset(t, n11, n1_, n_1, n);
-	// The reference walks both tails from the ends of the support (min, max) inwards until the
-	// terms reach q: up to min(n1_, n_1) steps per record, almost all of them over terms that are
-	// zero or tens of orders of magnitude below q.  Start each walk closer in instead, at a point
-	// that is *verified* (one log-pmf evaluation) to lie below q by a factor e^-40: the pmf is
-	// monotone out there, so everything skipped sums to < (max - min) * 4e-18 * q, i.e. < 1e-10
-	// of the result (P >= q) even at 2e7 haplotypes -- far inside the 1e-6 bar; the walk itself, its
-	// re-synchronisation every 11th step and its stopping rule are unchanged.  The candidate point
-	// comes from the normal approximation of the log-pmf, -(s - mean)^2 / (2 sd^2) relative to the
-	// mode: a term e^-K below q lies sqrt(dev^2 + 2 K sd^2) from the mean (dev = |n11 - mean|), a
-	// few sd beyond n11's own distance for a significant table instead of a fixed 12 sd; the
-	// approximation only proposes, the exact log-pmf decides, and a point that fails moves outwards.
-	int i0 = min, j0 = max;
-	if (q > 0 && max - min > 64) {
-		const double lq = log(q), nn = (double)n;
-		const double mean = (double)n1_ * (double)n_1 / nn;
-		const double sd = sqrt(mean * ((nn - n1_) / nn) * ((nn - n_1) / (nn - 1.0)));
-		const double lden = d_lbinom(t, n, n_1);
-		const double dev = fabs((double)n11 - mean);
-		const double K = d_fisher_skip_exponent(max - min);
-		const double D0 = sqrt(dev * dev + 2.0 * (K + 8.0) * sd * sd) + 4.0;      // K + 8 proposed, K required
-		double D = D0;
-		for (int k = 0; k < 4; ++k, D = D * 1.5 + 8.0) {
-			const double sf = floor(mean - D);
-			if (sf <= (double)min) break;
-			const int s = (int)sf;
-			if (d_lbinom(t, n1_, s) + d_lbinom(t, n - n1_, n_1 - s) - lden <= lq - K) { i0 = s; break; }
-		}
-		D = D0;
-		for (int k = 0; k < 4; ++k, D = D * 1.5 + 8.0) {
-			const double sf = ceil(mean + D);
-			if (sf >= (double)max) break;
-			const int s = (int)sf;
-			if (d_lbinom(t, n1_, s) + d_lbinom(t, n - n1_, n_1 - s) - lden <= lq - K) { j0 = s; break; }
+// ---- where the two tail walks start ------------------------------------------------------------------------
+// The reference walks both tails from the ends of the support (min, max) inwards until the terms reach q: up to
+// min(n1_, n_1) steps per record, almost all of them over terms that are zero or tens of orders of magnitude below q.
+// Each walk starts closer in instead, at a point that is *verified* (one log-pmf evaluation from the table) to lie
+// below q by a factor e^-40: the pmf is monotone out there, so everything skipped sums to < (max - min) * 4e-18 * q,
+// i.e. < 1e-10 of the result (P >= q) even at 2e7 haplotypes - far inside the 1e-6 bar; the walk itself, its
+// re-synchronisation every 11th step and its stopping rule are unchanged.
+// Finding the point (round 3; before: up to four proposals at 1, 1.5, 2.25, ... times the normal approximation's
+// distance, which on skewed tables - rare x common variants - failed once or twice and then started ten times too far
+// out: 46 terms a record on a 2,504-sample run, 208 for the longest record of a wave):
+//   1. the normal approximation's e^-40 point, sqrt(dev^2 + 2 K sd^2) from the mean;
+//   2. if the pmf there is still above q e^-40: one step outwards of (excess / |ln ratio there|) cells - the ratios
+//      only get steeper further out (the pmf is log-concave), so that point is below the target;
+//   3. one step back in of (margin / |ln ratio towards the inside|) cells - every ratio further in is flatter, so the
+//      point stays below the target.
+// The ratios are the recurrence's own ((row1-k)(col1-k) / ((k+1)(k+1+slack))), taken in float with the rounding
+// pushed to the safe side; every point is verified in FP64 against the table and a point that fails is not used
+// (the walk then starts where the reference does).  21 terms a record on the same run (the best possible start: 20.7).
+__device__ __forceinline__ double d_fisher_lpmf(const LFact& t, int s, int n1_, int n_1, int n, double lden) {
+	return d_lbinom(t, n1_, s) + d_lbinom(t, n - n1_, n_1 - s) - lden;
+}
+// |ln(pmf(s + dir) / pmf(s))| (float): the steepness of the pmf between cell s and its neighbour on the dir side
+__device__ __forceinline__ float d_fisher_steepness(int s, int dir, int n1_, int n_1, int slack) {
+	const float up = dir > 0 ? ((float)(n1_ - s) * (float)(n_1 - s)) / ((float)(s + 1) * (float)(s + 1 + slack))
+	                         : ((float)s * (float)(s + slack)) / ((float)(n1_ - s + 1) * (float)(n_1 - s + 1));
+	return -__logf(up);
+}
+__device__ __forceinline__ int d_fisher_start(const LFact& t, int dir, int n11, int n1_, int n_1, int n, int min, int max,
+                                              double mean, double reach, double target, double lden) {
+	const int end = dir < 0 ? min : max;
+	const double sf = dir < 0 ? floor(mean - reach) : ceil(mean + reach);
+	if (dir < 0 ? sf <= (double)min : sf >= (double)max) return end;
+	const int slack = n - n1_ - n_1;
+	int s = (int)sf;
+	double v = d_fisher_lpmf(t, s, n1_, n_1, n, lden);
+	if (v > target) {                                     // 2. outwards
+		const float steep = d_fisher_steepness(s, dir, n1_, n_1, slack) * 0.999f;
+		if (!(steep > 0.f)) return end;
+		const float step = ceilf((float)(v - target) / steep) + 1.f;
+		if (!(step < 1e9f)) return end;
+		const long long s1 = (long long)s + (long long)dir * (long long)step;
+		if (dir < 0 ? s1 <= (long long)min : s1 >= (long long)max) return end;
+		s = (int)s1;
+		v = d_fisher_lpmf(t, s, n1_, n_1, n, lden);
+		if (v > target) return end;
+	}
+	{	                                                   // 3. back in
+		const float steep = d_fisher_steepness(s - dir, dir, n1_, n_1, slack) * 1.001f;
+		const float step = floorf((float)(target - 0.5 - v) / steep);
+		if (steep > 0.f && step >= 1.f && step < 1e9f) {
+			const long long s1 = (long long)s - (long long)dir * (long long)step;
+			if (dir < 0 ? (s1 > (long long)min && s1 < (long long)n11) : (s1 < (long long)max && s1 > (long long)n11)) {
+				if (d_fisher_lpmf(t, (int)s1, n1_, n_1, n, lden) <= target) s = (int)s1;
+			}
 		}
 	}
-	p = w.move_to(t, i0);
-	for (left = 0., i = i0 + 1; p < 0.99999999 * q && i <= max; ++i)
-		left += p, p = w.move_to(t, i);
+	return s;
+}
+// The margins, the support and the observed table's own probability q; the walk object is left on cell n11.
+struct FisherSetup { int n1_, n_1, n, min, max; double q; };
+__device__ __forceinline__ bool d_fisher_setup(const LFact& t, TableWalk& w, int n11, int n12, int n21, int n22, FisherSetup& f) {
+	f.n1_ = n11 + n12; f.n_1 = n11 + n21; f.n = n11 + n12 + n21 + n22;
+	f.max = (f.n_1 < f.n1_) ? f.n_1 : f.n1_;
+	f.min = f.n1_ + f.n_1 - f.n;
+	if (f.min < 0) f.min = 0;
+	if (f.min == f.max) return false;        // one table only: P = 1
+	f.q = w.reset(t, n11, f.n1_, f.n_1, f.n);
+	return true;
+}
+__device__ __forceinline__ void d_fisher_starts(const LFact& t, int n11, const FisherSetup& f, int& i0, int& j0) {
+	i0 = f.min; j0 = f.max;
+	if (f.q > 0 && f.max - f.min > 64) {
+		const double lq = log(f.q), nn = (double)f.n;
+		const double mean = (double)f.n1_ * (double)f.n_1 / nn;
+		const double sd = sqrt(mean * ((nn - f.n1_) / nn) * ((nn - f.n_1) / (nn - 1.0)));
+		const double lden = d_lbinom(t, f.n, f.n_1);
+		const double dev = fabs((double)n11 - mean);
+		const double K = d_fisher_skip_exponent(f.max - f.min);
+		const double reach = sqrt(dev * dev + 2.0 * K * sd * sd) + 1.0;
+		i0 = d_fisher_start(t, -1, n11, f.n1_, f.n_1, f.n, f.min, f.max, mean, reach, lq - K, lden);
+		j0 = d_fisher_start(t, +1, n11, f.n1_, f.n_1, f.n, f.min, f.max, mean, reach, lq - K, lden);
+		// ... and from there out to the next cell whose index is a multiple of 11 (or the end of the support): the cells
+		// where the reference's own walk evaluates the pmf in full.  The walk's first value is then the very number the
+		// reference has at that cell, and so is every term after it - including the ones its stopping rule compares with
+		// q, however short the walk (a start in between carries its own rounding until the next multiple of 11: on steep
+		// tails, where a walk is a handful of terms, that decided now and then whether a term equal to q was counted).
+		i0 -= i0 % 11;
+		if (i0 < f.min) i0 = f.min;
+		j0 += (11 - j0 % 11) % 11;
+		if (j0 > f.max) j0 = f.max;
+	}
+}
+// The two walks, term for term the reference's (fisher_math.cpp:249-258) - but the lanes of a wave are lined up on the
+// recurrence's re-synchronisation first.  move_to evaluates the cell in full (nine table look-ups and an exp, several
+// times the cost of a ratio step) whenever the cell index is a multiple of 11; lanes start at unrelated cells, so in a
+// wave walking in step some lane is at a multiple of 11 at almost every step (1 - (10/11)^64) and the whole wave pays
+// for the full evaluation every time.  The starting points of d_fisher_starts are multiples of 11 themselves; a walk
+// that starts at the end of the support (cell i0, any residue) sits out its first (i0 mod 11) rounds: from then on its
+// cell index is congruent to the round number, and all lanes re-synchronise in the same rounds, one in eleven.  A lane's
+// own sequence of operations is unchanged; it waits at most ten cheap rounds.
+__device__ __forceinline__ double d_fisher_walks(const LFact& t, TableWalk& w, const FisherSetup& f, int i0, int j0) {
+	const double q = f.q;
+	double left, right;
+	double p = w.move_to(t, i0);
+	{
+		left = 0.;
+		int i = i0 + 1;
+		bool more = p < 0.99999999 * q && i <= f.max;
+		const int wait = i0 % 11;
+		for (int round = 1; __ballot(more) != 0; ++round)
+			if (more && round > wait) { left += p; p = w.move_to(t, i); ++i; more = p < 0.99999999 * q && i <= f.max; }
+	}
 	if (p < 1.00000001 * q) left += p;
 	p = w.move_to(t, j0);
-	for (right = 0., j = j0 - 1; p < 0.99999999 * q && j >= 0; --j)
-		right += p, p = w.move_to(t, j);
+	{
+		right = 0.;
+		int j = j0 - 1;
+		bool more = p < 0.99999999 * q && j >= 0;
+		const int wait = (11 - j0 % 11) % 11;          // walking down: cell index = -round (mod 11)
+		for (int round = 1; __ballot(more) != 0; ++round)
+			if (more && round > wait) { right += p; p = w.move_to(t, j); --j; more = p < 0.99999999 * q && j >= 0; }
+	}
 	if (p < 1.00000001 * q) right += p;
 	double two = left + right;
 	if (two > 1.) two = 1.;
+	return two;
+}
+// Two-sided P only (left / right tails are not stored in the record).  All lanes of the wave that are active at the
+// call take part in the walks' ballots.
+__device__ __forceinline__ double d_fisher_two(const LFact& t, int n11, int n12, int n21, int n22) {
+	TableWalk w;
+	FisherSetup f;
+	const bool walk = d_fisher_setup(t, w, n11, n12, n21, n22, f);
+	int i0 = 0, j0 = 0;
+	if (walk) d_fisher_starts(t, n11, f, i0, j0);
+	double two = 1.;
+	if (walk) two = d_fisher_walks(t, w, f, i0, j0);
 	return two;
 }
 
@@ -679,196 +763,162 @@ void k_ld_stats_list_unphased(const StatsParams* pp, const uint32_t* __restrict_
 // haplotype counts): n11 = cnt[0], n12 = cnt[2] (REFALT slot), n21 = cnt[1], n22 = cnt[3].
 // Records with P > minP are dropped (:1228, :1661): marked idxA = 0xFFFFFFFF for the host.
 #define TWK_DROPPED_RECORD 0xFFFFFFFFu
-#define TWK_FISHER_RECURRENCE_BELOW 1e-270   // observed-table probabilities below this take the reference's own recurrence (k_ld_fisher)
+// The four integer arguments of the test as the reference passes them (see above).
+__device__ __forceinline__ void d_fisher_args(const twk_hip_record* r, int& n11, int& n12, int& n21, int& n22) {
+	n11 = (r->flags & TWK_N11_IN_PAD) ? (int)r->_pad : (int)round(r->cnt[0]);
+	n12 = (int)round(r->cnt[2]); n21 = (int)round(r->cnt[1]); n22 = (int)round(r->cnt[3]);
+}
+
+// ---- the test in three passes: prepare, order, walk -------------------------------------------------------------
+// A wave of the walk kernel runs as long as its longest walk, and neighbouring survivors (one row variant, adjacent
+// columns) have walks of very different lengths.  So the work is split:
+//   k_fisher_prepare   per record: q and the two starting points (uniform work: a handful of table look-ups), parked in
+//                      the record's P field - which the test is about to fill - together with the bin of the walk's
+//                      length, now known almost exactly: start to crossing on either side (the crossing on the observed
+//                      side is n11 itself, the other one its mirror image about the mean); bins of one term up to 64
+//                      terms, of 1/8 octave beyond (exponent and three mantissa bits of the estimate as a float); the
+//                      bins' histogram
+//   k_fisher_scatter   counting sort: index[bin start + rank] = record position, any order inside a bin
+//   k_ld_fisher_t      lane k walks the k-th record in bin order
+// Only the order of evaluation changes with the bins.  Measured on the 10 M survivors of a 2,504-sample run
+// (profiles/r03_fisher_order.txt).
+constexpr int FISHER_BINS = 256;
+constexpr unsigned long long FISHER_AT_END = (1ull << 26) - 1;         // packed start: "the end of the support"
+__device__ __forceinline__ unsigned long long d_fisher_pack(int n11, int i0, int j0, const FisherSetup& f, bool walk) {
+	if (!walk) return ~0ull;                                               // P = 1 without a walk
+	const unsigned long long a = (i0 == f.min || (unsigned)(n11 - i0) >= FISHER_AT_END) ? FISHER_AT_END : (unsigned long long)(n11 - i0);
+	const unsigned long long b = (j0 == f.max || (unsigned)(j0 - n11) >= FISHER_AT_END) ? FISHER_AT_END : (unsigned long long)(j0 - n11);
+	// length of the two walks
+	float est = 0.f;
+	if (f.q > 0) {
+		const float mean = (float)f.n1_ * ((float)f.n_1 / (float)f.n), dev = fabsf((float)n11 - mean);
+		const float s0 = (float)(a == FISHER_AT_END ? f.min : i0), s1 = (float)(b == FISHER_AT_END ? f.max : j0);
+		est = fmaxf(mean - dev - s0, 0.f) + fmaxf(s1 - (mean + dev), 0.f);
+	}
+	uint32_t bin;
+	if (est < 64.f) bin = (uint32_t)est;
+	else { const int key = 64 + (int)(__float_as_uint(est) >> 20) - ((127 + 6) << 3); bin = (uint32_t)(key >= FISHER_BINS ? FISHER_BINS - 1 : key); }
+	return a << 38 | b << 12 | bin;
+}
+__device__ __forceinline__ void d_fisher_unpack(unsigned long long v, int n11, const FisherSetup& f, int& i0, int& j0) {
+	const unsigned long long a = v >> 38, b = (v >> 12) & FISHER_AT_END;
+	i0 = a == FISHER_AT_END ? f.min : n11 - (int)a;
+	j0 = b == FISHER_AT_END ? f.max : n11 + (int)b;
+}
+constexpr int FISHER_LDS_TABLE_MAX = 8192;       // 64 KiB of doubles: N <= 4,088 samples
+// LDS_TABLE: the log-factorial table is copied into LDS first (it must fit: FISHER_LDS_TABLE_MAX entries) - through the
+// vector memory path every look-up of a wave is up to 64 separate cache-line requests.
+// bins[0..256): records per bin (zeroed before the launch; only the first min(n, index_limit) records are counted).
+template <bool LDS_TABLE>
+__global__ __launch_bounds__(LDS_TABLE ? 1024 : 256)
+void k_fisher_prepare(twk_hip_record* __restrict__ recs, const unsigned long long* __restrict__ n_out, unsigned long long capacity,
+                      const LFact lfact_in, unsigned long long index_limit, uint32_t* __restrict__ bins) {
+	extern __shared__ double lf_lds[];
+	__shared__ uint32_t h[FISHER_BINS];
+	LFact lfact = lfact_in;
+	if (LDS_TABLE) {
+		for (int i = threadIdx.x; i < lfact_in.n; i += blockDim.x) lf_lds[i] = lfact_in.lf[i];
+		lfact.lf = lf_lds;
+	}
+	if (threadIdx.x < FISHER_BINS) h[threadIdx.x] = 0;
+	__syncthreads();
+	unsigned long long n = n_out[0];
+	if (n > capacity) n = capacity;
+	for (unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (unsigned long long)gridDim.x * blockDim.x) {
+		twk_hip_record* r = recs + k;
+		int n11, n12, n21, n22;
+		d_fisher_args(r, n11, n12, n21, n22);
+		TableWalk w;
+		FisherSetup f;
+		const bool walk = d_fisher_setup(lfact, w, n11, n12, n21, n22, f);
+		int i0 = 0, j0 = 0;
+		if (walk) d_fisher_starts(lfact, n11, f, i0, j0);
+		const unsigned long long v = d_fisher_pack(n11, i0, j0, f, walk);
+		reinterpret_cast<unsigned long long*>(&r->P)[0] = v;
+		if (k < index_limit) atomicAdd(&h[v & 0xFFu], 1u);
+	}
+	__syncthreads();
+	if (threadIdx.x < FISHER_BINS && h[threadIdx.x]) atomicAdd(bins + threadIdx.x, h[threadIdx.x]);
+}
+// index[bin start + rank] = record position.  bins[256..512): the bins' fill cursors (zeroed before the launch).  A block
+// takes 1024 records at a time: ranks inside the block through LDS, one global atomic per bin the batch touches.
 __global__ __launch_bounds__(256)
-void k_ld_fisher(twk_hip_record* __restrict__ recs, unsigned long long* __restrict__ n_out,
-                 unsigned long long capacity, double minP, const LFact lfact, const uint32_t* __restrict__ deferred) {
-	// deferred == null: every record; else (behind k_ld_fisher_group) the n_out[3] records that kernel listed
-	unsigned long long n = deferred ? n_out[3] : n_out[0];
-	if (!deferred && n > capacity) n = capacity;
+void k_fisher_scatter(const twk_hip_record* __restrict__ recs, const unsigned long long* __restrict__ n_out, unsigned long long capacity,
+                      unsigned long long index_limit, uint32_t* __restrict__ bins, uint32_t* __restrict__ index) {
+	__shared__ uint32_t start[FISHER_BINS], cnt[FISHER_BINS], base[FISHER_BINS], wsum[4];
+	unsigned long long n = n_out[0];
+	if (n > capacity) n = capacity;
+	if (n > index_limit) n = index_limit;
+	{	// exclusive scan of the 256 bin sizes
+		const uint32_t v = bins[threadIdx.x];
+		uint32_t incl = v;
+		for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o); if ((int)(threadIdx.x & 63) >= o) incl += t; }
+		if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+		__syncthreads();
+		uint32_t before = 0;
+		for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) before += wsum[w];
+		start[threadIdx.x] = before + incl - v;
+	}
+	for (unsigned long long k0 = (unsigned long long)blockIdx.x * 1024; k0 < n; k0 += (unsigned long long)gridDim.x * 1024) {
+		cnt[threadIdx.x] = 0;
+		__syncthreads();
+		uint32_t bin[4], rank[4];
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			const unsigned long long k = k0 + (unsigned)j * 256u + threadIdx.x;
+			bin[j] = 0; rank[j] = 0;
+			if (k < n) { bin[j] = (uint32_t)(reinterpret_cast<const unsigned long long*>(&recs[k].P)[0] & 0xFFu); rank[j] = atomicAdd(&cnt[bin[j]], 1u); }
+		}
+		__syncthreads();
+		if (cnt[threadIdx.x]) base[threadIdx.x] = start[threadIdx.x] + atomicAdd(bins + FISHER_BINS + threadIdx.x, cnt[threadIdx.x]);
+		__syncthreads();
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			const unsigned long long k = k0 + (unsigned)j * 256u + threadIdx.x;
+			if (k < n) index[base[bin[j]] + rank[j]] = (uint32_t)k;
+		}
+		__syncthreads();
+	}
+}
+// The walks over every record, in the order of `index` for the first min(n, index_limit) of them (k_fisher_scatter: a
+// permutation of those positions).  prepared: the starting points are in the record (k_fisher_prepare); else they are
+// found here.
+template <bool LDS_TABLE>
+__global__ __launch_bounds__(LDS_TABLE ? 1024 : 256)
+void k_ld_fisher_t(twk_hip_record* __restrict__ recs, unsigned long long* __restrict__ n_out,
+                   unsigned long long capacity, double minP, const LFact lfact_in, const uint32_t* __restrict__ index,
+                   unsigned long long index_limit, int prepared) {
+	extern __shared__ double lf_lds[];
+	LFact lfact = lfact_in;
+	if (LDS_TABLE) {
+		for (int i = threadIdx.x; i < lfact_in.n; i += blockDim.x) lf_lds[i] = lfact_in.lf[i];
+		__syncthreads();
+		lfact.lf = lf_lds;
+	}
+	unsigned long long n = n_out[0];
+	if (n > capacity) n = capacity;
+	const unsigned long long n_indexed = index ? (n < index_limit ? n : index_limit) : 0;
 	uint32_t dropped = 0;
 	for (unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; k < n;
 	     k += (unsigned long long)gridDim.x * blockDim.x) {
-		twk_hip_record* r = recs + (deferred ? (unsigned long long)deferred[k] : k);
-		int n11 = (int)round(r->cnt[0]);
-		if (r->flags & TWK_N11_IN_PAD) { n11 = (int)r->_pad; r->flags &= ~TWK_N11_IN_PAD; r->_pad = 0; }
-		const double both = d_fisher_two(lfact, n11, (int)round(r->cnt[2]), (int)round(r->cnt[1]), (int)round(r->cnt[3]));
+		twk_hip_record* r = recs + (k < n_indexed ? (unsigned long long)index[k] : k);
+		int n11, n12, n21, n22;
+		d_fisher_args(r, n11, n12, n21, n22);
+		if (r->flags & TWK_N11_IN_PAD) { r->flags &= ~TWK_N11_IN_PAD; r->_pad = 0; }
+		TableWalk w;
+		FisherSetup f;
+		const bool walk = d_fisher_setup(lfact, w, n11, n12, n21, n22, f);
+		int i0 = 0, j0 = 0;
+		if (walk) {
+			if (prepared) d_fisher_unpack(reinterpret_cast<const unsigned long long*>(&r->P)[0], n11, f, i0, j0);
+			else d_fisher_starts(lfact, n11, f, i0, j0);
+		}
+		double both = 1.;
+		if (walk) both = d_fisher_walks(lfact, w, f, i0, j0);
 		r->P = both;
 		if (both > minP) { r->idxA = TWK_DROPPED_RECORD; ++dropped; }
 	}
 	// how many were dropped (n_out[1]): the host cuts them off behind the sort without looking at the records
-	for (int o = 32; o > 0; o >>= 1) dropped += __shfl_xor(dropped, o);
-	if ((threadIdx.x & 63) == 0 && dropped) atomicAdd(n_out + 1, (unsigned long long)dropped);
-}
-
-// ---- Fisher's test, sixteen lanes per record ------------------------------------------------------------
-// k_ld_fisher above is the reference's walk as it stands: one record per lane, one term after the other through the
-// ratio recurrence (two FP64 divisions per term, the log-binomials again every 11th term).  A wave then runs as long
-// as its longest record, every term waits for the one before it, and the divisions alone are ~300 cycles per term:
-// 69 ms for the 33 M survivors of the 2,504-sample run.  The terms of a tail do not depend on each other, though:
-//     pmf(s) = exp( lbinom(row1, s) + lbinom(total - row1, col1 - s) - lbinom(total, col1) )
-// is what the reference itself evaluates at every 11th step, and with the log-factorial table it is four loads and one
-// exp.  So a group of 16 lanes takes one record and evaluates 16 consecutive terms of a tail at once - coalesced
-// loads, no divisions, no dependency chain - and the reference's stopping rule becomes a ballot: the walk ends at
-// the first term (from the outside) that is not below 0.99999999 q; the terms before it are summed, that term is
-// added if it is below 1.00000001 q (fisher_math.cpp:249-258).  Each term is the value the reference's recurrence
-// would be re-synchronised to at that point, so the two differ by the rounding the recurrence accumulates over at
-// most ten ratios (~1e-15 relative): the same stop decisions, P equal to ~1e-14.  The verified starting points of
-// d_fisher_two are kept, their (up to four) proposals per side evaluated by eight lanes at once.
-constexpr int FISHER_GROUP = 16;
-// What a walk needs to know about its record: the margins and the three table values that do not depend on the term.
-struct FisherMargins {
-	int row1, col1, total;             // n1_, n_1, n
-	double lf_row1, lf_rest, lb_all;   // lf[row1], lf[total - row1], lbinom(total, col1)
-};
-// log pmf(s) for fixed margins, bit for bit the exponent of d_hypergeo(t, s, row1, col1, total) - the same subtractions and
-// additions in the same order - but with the table entries loaded side by side: d_hypergeo reaches every entry through
-// its own range check (a branch per load), which strings nine memory round trips together.  Every index lies inside the
-// table: the group kernel only takes records whose margins do (the others go to k_ld_fisher), and min <= s <= max.
-__device__ __forceinline__ double d_pmf_logterm(const LFact& t, const FisherMargins& m, int s) {
-	const int i1 = s, i2 = m.row1 - s, i3 = m.col1 - s, i4 = m.total - m.row1 - m.col1 + s;
-	const double a1 = t.lf[i1], a2 = t.lf[i2], a3 = t.lf[i3], a4 = t.lf[i4];
-	const double lb1 = (i1 == 0 || i2 == 0) ? 0. : m.lf_row1 - a1 - a2;          // d_lbinom(row1, s)
-	const double lb2 = (i3 == 0 || i4 == 0) ? 0. : m.lf_rest - a3 - a4;          // d_lbinom(total - row1, col1 - s)
-	return lb1 + lb2 - m.lb_all;
-}
-// Two terms at once (one of each tail): eight loads in flight, then two exps.  A term that is not wanted comes back as 0
-// and touches nothing.
-__device__ __forceinline__ void d_pmf_term2(const LFact& t, const FisherMargins& m, int sL, bool wantL, int sR, bool wantR, double& pL, double& pR) {
-	const int l1 = sL, l2 = m.row1 - sL, l3 = m.col1 - sL, l4 = m.total - m.row1 - m.col1 + sL;
-	const int r1 = sR, r2 = m.row1 - sR, r3 = m.col1 - sR, r4 = m.total - m.row1 - m.col1 + sR;
-	double a1 = 0, a2 = 0, a3 = 0, a4 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0;
-	if (wantL) { a1 = t.lf[l1]; a2 = t.lf[l2]; a3 = t.lf[l3]; a4 = t.lf[l4]; }
-	if (wantR) { b1 = t.lf[r1]; b2 = t.lf[r2]; b3 = t.lf[r3]; b4 = t.lf[r4]; }
-	pL = 0.; pR = 0.;
-	if (wantL) {
-		const double lb1 = (l1 == 0 || l2 == 0) ? 0. : m.lf_row1 - a1 - a2;
-		const double lb2 = (l3 == 0 || l4 == 0) ? 0. : m.lf_rest - a3 - a4;
-		pL = exp(lb1 + lb2 - m.lb_all);
-	}
-	if (wantR) {
-		const double lb1 = (r1 == 0 || r2 == 0) ? 0. : m.lf_row1 - b1 - b2;
-		const double lb2 = (r3 == 0 || r4 == 0) ? 0. : m.lf_rest - b3 - b4;
-		pR = exp(lb1 + lb2 - m.lb_all);
-	}
-}
-__device__ __forceinline__ uint32_t d_group_ballot(bool pred, int g0) { return (uint32_t)(__ballot(pred) >> g0) & 0xFFFFu; }
-__device__ __forceinline__ double d_group_sum(double v) {
-#pragma unroll
-	for (int o = FISHER_GROUP / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, FISHER_GROUP);
-	return v;
-}
-
-__global__ __launch_bounds__(256)
-void k_ld_fisher_group(twk_hip_record* __restrict__ recs, unsigned long long* __restrict__ n_out,
-                       unsigned long long capacity, double minP, const LFact lfact, uint32_t* __restrict__ deferred) {
-	unsigned long long n_recs = n_out[0];
-	if (n_recs > capacity) n_recs = capacity;
-	const int lane = threadIdx.x & 63, l = lane & (FISHER_GROUP - 1), g0 = lane & ~(FISHER_GROUP - 1);
-	const unsigned long long n_groups = (unsigned long long)gridDim.x * blockDim.x / FISHER_GROUP;
-	uint32_t dropped = 0;
-	for (unsigned long long rec_i = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) / FISHER_GROUP; rec_i < n_recs; rec_i += n_groups) {
-		twk_hip_record* r = recs + rec_i;
-		// arguments as in k_ld_fisher (every lane of the group reads the same words)
-		int n11 = (int)round(r->cnt[0]);
-		const uint32_t flags = r->flags;
-		if (flags & TWK_N11_IN_PAD) n11 = (int)r->_pad;
-		const int n12 = (int)round(r->cnt[2]), n21 = (int)round(r->cnt[1]), n22 = (int)round(r->cnt[3]);
-		FisherMargins m;
-		m.row1 = n11 + n12; m.col1 = n11 + n21; m.total = n11 + n12 + n21 + n22;
-		const int n1_ = m.row1, n_1 = m.col1, n = m.total;
-		int max = (n_1 < n1_) ? n_1 : n1_;
-		int min = n1_ + n_1 - n;
-		if (min < 0) min = 0;
-		double two = 1.;
-		if (min != max) {
-			// the record's constants and q, the observed table's own probability: nine table entries side by side
-			double q;
-			{
-				const int rest = n - n1_, i2 = n1_ - n11, i3 = n_1 - n11, i4 = n - n1_ - n_1 + n11, k5 = n - n_1;
-				// every index is one of the table's cells or margins: none negative and the total inside the table means all are
-				if ((n | n1_ | rest | n_1 | k5 | n11 | i2 | i3 | i4) < 0 || n >= lfact.n) {
-					// a count beyond the log-factorial table (the wrapped counts of TWK_HIP_OPT_REF_COMPAT, sample counts past the
-					// table's limit): left to k_ld_fisher, which runs behind this kernel over the records listed here
-					if (l == 0) deferred[atomicAdd(n_out + 3, 1ull)] = (uint32_t)rec_i;
-					continue;
-				}
-				const double c1 = lfact.lf[n1_], c2 = lfact.lf[rest], c3 = lfact.lf[n], c4 = lfact.lf[n_1], c5 = lfact.lf[k5];
-				const double a1 = lfact.lf[n11], a2 = lfact.lf[i2], a3 = lfact.lf[i3], a4 = lfact.lf[i4];
-				m.lf_row1 = c1; m.lf_rest = c2;
-				m.lb_all = (n_1 == 0 || k5 == 0) ? 0. : c3 - c4 - c5;                   // d_lbinom(n, n_1)
-				const double lb1 = (n11 == 0 || i2 == 0) ? 0. : c1 - a1 - a2;
-				const double lb2 = (i3 == 0 || i4 == 0) ? 0. : c2 - a3 - a4;
-				q = exp(lb1 + lb2 - m.lb_all);
-			}
-			// Where the walk would start on denormal terms (q e^-K below ~1e-308) the reference's recurrence carries a value
-			// with a few dozen significant bits to the observed table, and whether that lands inside its 1e-8 stopping band -
-			// i.e. whether the observed table's own probability is counted in P at all - is decided by that rounding
-			// (fisher_math.cpp:249-258; e.g. the table (3741, 794, 8, 465): q = 1.103e-296, the sum of all terms <= q is
-			// 1.107e-296, the reference returns 4.0e-299).  Evaluating every term exactly does not reproduce that; the
-			// one-lane walk, which runs the same recurrence on the same values, does: such records are left to it.
-			if (q > 0 && q < TWK_FISHER_RECURRENCE_BELOW) {
-				if (l == 0) deferred[atomicAdd(n_out + 3, 1ull)] = (uint32_t)rec_i;
-				continue;
-			}
-			const double thr = 0.99999999 * q, tie = 1.00000001 * q;
-			int i0 = min, j0 = max;
-			if (q > 0 && max - min > 64) {
-				// verified starting points (see d_fisher_two): lanes 0-3 try the left proposals k = 0..3, lanes 4-7 the right ones
-				const double lq = log(q), nn = (double)n;
-				const double mean = (double)n1_ * (double)n_1 / nn;
-				const double sd = sqrt(mean * ((nn - n1_) / nn) * ((nn - n_1) / (nn - 1.0)));
-				const double dev = fabs((double)n11 - mean);
-				const double K = d_fisher_skip_exponent(max - min);
-				double D = sqrt(dev * dev + 2.0 * (K + 8.0) * sd * sd) + 4.0;
-				for (int k = 0; k < (l & 3); ++k) D = D * 1.5 + 8.0;
-				const bool right = (l & 4) != 0;
-				const double sf = right ? ceil(mean + D) : floor(mean - D);
-				const bool out = right ? sf >= (double)max : sf <= (double)min;       // the proposal left the support: stay at its end
-				const int s = out ? (right ? max : min) : (int)sf;
-				bool hit = out;
-				if (!out && l < 8) hit = d_pmf_logterm(lfact, m, s) <= lq - K;
-				const uint32_t hits = d_group_ballot(hit && l < 8, g0);
-				const uint32_t hl = hits & 0xFu, hr = (hits >> 4) & 0xFu;
-				if (hl) i0 = __shfl(s, g0 + (__ffs(hl) - 1));
-				if (hr) j0 = __shfl(s, g0 + 4 + (__ffs(hr) - 1));
-			}
-			// Both tails at once, 16 terms of each per round: the left walk takes i0, i0 + 1, ... and the right walk j0, j0 - 1, ...,
-			// each up to its first term that is not below thr (or the end of the support); a walk that is done no longer loads
-			// anything.
-			double left = 0., right = 0.;
-			bool moreL = true, moreR = true;
-			for (int baseL = i0, baseR = j0; moreL || moreR; baseL += FISHER_GROUP, baseR -= FISHER_GROUP) {
-				const int sL = baseL + l, sR = baseR - l;
-				// (the reference's right walk is bounded by 0, but it ends at the observed table at the latest, and n11 >= min: lanes
-				// beyond min would index the table with a negative cell)
-				const bool validL = moreL && sL <= max, validR = moreR && sR >= min;
-				double pL, pR;
-				d_pmf_term2(lfact, m, sL, validL, sR, validR, pL, pR);
-				if (moreL) {
-					const uint32_t stop = d_group_ballot(validL && !(pL < thr), g0);
-					const int first = stop ? __ffs(stop) - 1 : FISHER_GROUP;
-					left += d_group_sum((validL && l < first) ? pL : 0.);
-					if (stop) { const double ps = __shfl(pL, g0 + first); if (ps < tie) left += ps; moreL = false; }
-					else if (baseL + FISHER_GROUP > max) moreL = false;
-				}
-				if (moreR) {
-					const uint32_t stop = d_group_ballot(validR && !(pR < thr), g0);
-					const int first = stop ? __ffs(stop) - 1 : FISHER_GROUP;
-					right += d_group_sum((validR && l < first) ? pR : 0.);
-					if (stop) { const double ps = __shfl(pR, g0 + first); if (ps < tie) right += ps; moreR = false; }
-					else if (baseR - FISHER_GROUP < min) moreR = false;
-				}
-			}
-			two = left + right;
-			if (two > 1.) two = 1.;
-		}
-		if (l == 0) {
-			r->P = two;
-			if (flags & TWK_N11_IN_PAD) { r->flags = flags & ~TWK_N11_IN_PAD; r->_pad = 0; }
-			if (two > minP) { r->idxA = TWK_DROPPED_RECORD; ++dropped; }
-		}
-	}
 	for (int o = 32; o > 0; o >>= 1) dropped += __shfl_xor(dropped, o);
 	if ((threadIdx.x & 63) == 0 && dropped) atomicAdd(n_out + 1, (unsigned long long)dropped);
 }

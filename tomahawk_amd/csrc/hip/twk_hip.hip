@@ -103,6 +103,7 @@ struct twk_hip_ctx {
 	uint32_t *d_ac = nullptr, *d_an = nullptr, *d_pos = nullptr, *d_rid = nullptr, *d_missing = nullptr;
 	double* d_hwe = nullptr;
 	double* d_lfact = nullptr; int lfact_n = 0;    // lgamma(i + 1), i <= 2N: Fisher's log-binomials (ld_math.hip.h)
+	uint32_t* d_fisher_bins = nullptr;             // [2 * FISHER_BINS]: bin sizes and fill cursors of the walk-length order (s_compute only)
 	std::vector<twk_hip_variant_meta> h_meta;
 	std::vector<uint32_t> h_popc;  // ALT alleles per variant as counted on the device (r2 screen; empty until needed, dropped on upload)
 	PlaneSet planes[N_PLANE_SETS];
@@ -559,6 +560,36 @@ TilePlan plan_for(const twk_hip_ctx* c, int mode) {
 	return p;
 }
 
+// Fisher's exact test, one record per lane, on recs[0, min(*n_out, cap)): starting points (k_fisher_prepare), then the
+// walks (k_ld_fisher_t) - in the order of their length (k_fisher_scatter) when `scratch` (scratch_words uint32, free at
+// this point of the stream) is given; records beyond the scratch keep their place.  ld_math.hip.h.
+// TWK_HIP_FISHER_ORDER=0: walks in the order the records were appended; TWK_HIP_FISHER_LDS=0: log-factorial table read
+// from global memory also when it would fit LDS (measurement hooks).
+int launch_fisher(twk_hip_ctx* c, twk_hip_record* recs, unsigned long long* n_out, unsigned long long cap, double minP,
+                  uint32_t* scratch, size_t scratch_words) {
+	const LFact lf{c->d_lfact, c->lfact_n};
+	static const bool ordered = [] { const char* e = std::getenv("TWK_HIP_FISHER_ORDER"); return !(e && e[0] == '0'); }();
+	static const bool lds_ok = [] { const char* e = std::getenv("TWK_HIP_FISHER_LDS"); return !(e && e[0] == '0'); }();
+	const bool lds_table = lds_ok && c->lfact_n <= FISHER_LDS_TABLE_MAX;
+	const size_t lds_bytes = lds_table ? (size_t)c->lfact_n * sizeof(double) : 0;
+	if (!c->d_fisher_bins) HIPCHK(c, hipMalloc((void**)&c->d_fisher_bins, 2 * FISHER_BINS * sizeof(uint32_t)));
+	const unsigned long long limit = (ordered && scratch && scratch_words >= 4096) ? std::min<unsigned long long>(scratch_words, 0xFFFFFFFFull) : 0;
+	HIPCHK(c, hipMemsetAsync(c->d_fisher_bins, 0, 2 * FISHER_BINS * sizeof(uint32_t), c->s_compute));
+	if (lds_table) hipLaunchKernelGGL(k_fisher_prepare<true>, dim3(c->resident_blocks), dim3(1024), lds_bytes, c->s_compute, recs, (const unsigned long long*)n_out, cap, lf, limit, c->d_fisher_bins);
+	else hipLaunchKernelGGL(k_fisher_prepare<false>, dim3(c->resident_blocks * 2), dim3(256), 0, c->s_compute, recs, (const unsigned long long*)n_out, cap, lf, limit, c->d_fisher_bins);
+	if (limit) {
+		const unsigned long long bound = std::min(cap, limit);
+		const unsigned blocks = (unsigned)std::max<unsigned long long>(1, std::min<unsigned long long>(c->resident_blocks * 4ull, (bound + 1023) / 1024));
+		hipLaunchKernelGGL(k_fisher_scatter, dim3(blocks), dim3(256), 0, c->s_compute, (const twk_hip_record*)recs, (const unsigned long long*)n_out, cap, limit, c->d_fisher_bins, scratch);
+	}
+	if (lds_table) hipLaunchKernelGGL(k_ld_fisher_t<true>, dim3(c->resident_blocks), dim3(1024), lds_bytes, c->s_compute, recs, n_out, cap, minP, lf,
+	                                  (const uint32_t*)(limit ? scratch : nullptr), limit, 1);
+	else hipLaunchKernelGGL(k_ld_fisher_t<false>, dim3(c->resident_blocks * 2), dim3(256), 0, c->s_compute, recs, n_out, cap, minP, lf,
+	                        (const uint32_t*)(limit ? scratch : nullptr), limit, 1);
+	HIPCHK(c, hipGetLastError());
+	return TWK_HIP_OK;
+}
+
 int enqueue_tile(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, const twk_hip_filters& f, Slot& s,
                  unsigned long long capacity, const ColRange* cr = nullptr) {
 	const TilePlan pl = plan_for(c, mode);
@@ -610,24 +641,9 @@ int enqueue_tile(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, const twk
 		hipLaunchKernelGGL(k_ld_stats, dim3((t.nB + 255) / 256, t.nA), dim3(256), 0, c->s_compute, p);
 		HIPCHK(c, hipGetLastError());
 	}
-	{	// Fisher's exact test on the compacted survivors.  Default: the reference's walk, one record per lane (k_ld_fisher).
-		// TWK_HIP_FISHER=group: 16 lanes per record, every term from the log-factorial table (k_ld_fisher_group) - 1.3x the
-		// rate on records it can take, but the records whose observed-table probability lies in the underflow band
-		// (10 % of an LD-rich 2,504-sample run) must still go through the recurrence to agree with the reference, and
-		// the two passes together are slower than the one (tests/sweeps/fisher_kernel_bench.py, profiles/): not the default.
-		const char* fe = std::getenv("TWK_HIP_FISHER");
-		const LFact lf{c->d_lfact, c->lfact_n};
-		if (!fe || std::strcmp(fe, "group") != 0) {
-			hipLaunchKernelGGL(k_ld_fisher, dim3(c->resident_blocks * 2), dim3(256), 0, c->s_compute, s.out, s.n_out, s.cap_use, f.minP, lf, (const uint32_t*)nullptr);
-		} else {
-			// Records the group kernel does not take - a count beyond the log-factorial table, or an observed-table probability
-			// so small that the reference's recurrence runs on denormals (ld_math.hip.h) - are listed (in the slot's count
-			// buffer: the math kernels are done with it, and it has a word for every pair of the tile) and go through the
-			// one-lane walk, which ends at once when the list is empty.
-			hipLaunchKernelGGL(k_ld_fisher_group, dim3(c->resident_blocks * 8), dim3(256), 0, c->s_compute, s.out, s.n_out, s.cap_use, f.minP, lf, s.C);
-			hipLaunchKernelGGL(k_ld_fisher, dim3(c->resident_blocks * 2), dim3(256), 0, c->s_compute, s.out, s.n_out, s.cap_use, f.minP, lf, (const uint32_t*)s.C);
-		}
-	}
+	// Fisher's exact test on the compacted survivors (the slot's count / candidate buffer is free by now - the math
+	// kernels in front are done with it - and holds the walk-length order)
+	rc = launch_fisher(c, s.out, s.n_out, s.cap_use, f.minP, s.C, s.C_words); if (rc) return rc;
 	HIPCHK(c, hipGetLastError());
 	s.minP = f.minP;
 	HIPCHK(c, hipMemcpyAsync(s.h_n_out, s.n_out, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->s_compute));
@@ -813,11 +829,7 @@ int run_list_block(twk_hip_ctx* c, const twk_hip_filters& f, bool unphased, uint
 		                        (const unsigned long long*)(s.n_out + 2), s.cand_cap);
 		HIPCHK(c, hipGetLastError());
 	}
-	{
-		const LFact lf{c->d_lfact, c->lfact_n};
-		hipLaunchKernelGGL(k_ld_fisher, dim3(c->resident_blocks * 2), dim3(256), 0, c->s_compute, s.out, s.n_out, s.cap_use, f.minP, lf, (const uint32_t*)nullptr);
-		HIPCHK(c, hipGetLastError());
-	}
+	{ const int rc = launch_fisher(c, s.out, s.n_out, s.cap_use, f.minP, s.C, s.C_words); if (rc) return rc; }
 	HIPCHK(c, hipMemcpyAsync(s.h_n_out, s.n_out, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->s_compute));
 	HIPCHK(c, hipEventRecord(s.ev_s1, c->s_compute));
 	return finish_tile(c, s, t, n_out, to_host);
@@ -983,6 +995,7 @@ int twk_hip_ctx_destroy(twk_hip_ctx* c) {
 	if (c->h_recs) (void)hipHostFree(c->h_recs);
 	if (c->d_keep) (void)hipFree(c->d_keep);
 	if (c->d_list_stats) (void)hipFree(c->d_list_stats);
+	if (c->d_fisher_bins) (void)hipFree(c->d_fisher_bins);
 	if (c->d_sort_keys) (void)hipFree(c->d_sort_keys);
 	if (c->d_sort_vals) (void)hipFree(c->d_sort_vals);
 	if (c->d_sorted) (void)hipFree(c->d_sorted);
@@ -1659,7 +1672,7 @@ __global__ void k_records_to_p(const twk_hip_record* __restrict__ r, unsigned lo
 	if (i < n) p[i] = r[i].P;
 }
 
-int twk_hip_fisher_exact(twk_hip_ctx* c, const int32_t* tables, uint64_t n, double* p_two_sided, int32_t one_lane_per_table, float* kernel_ms) {
+int twk_hip_fisher_exact(twk_hip_ctx* c, const int32_t* tables, uint64_t n, double* p_two_sided, int32_t in_given_order, float* kernel_ms) {
 	if (!c || !tables || !p_two_sided || n == 0 || n > (1ull << 28)) return TWK_HIP_E_INVALID;
 	if (!c->d_lfact) return TWK_HIP_E_STATE;
 	HIPCHK(c, hipSetDevice(c->device));
@@ -1687,21 +1700,9 @@ int twk_hip_fisher_exact(twk_hip_ctx* c, const int32_t* tables, uint64_t n, doub
 		e = hipEventRecord(e0, c->s_compute);
 	}
 	if (e == hipSuccess) {
-		const LFact lf{c->d_lfact, c->lfact_n};
-		if (one_lane_per_table) hipLaunchKernelGGL(k_ld_fisher, dim3(c->resident_blocks * 2), dim3(256), 0, c->s_compute, d_r, d_n, (unsigned long long)n, 2.0, lf, (const uint32_t*)nullptr);
-		else {
-			hipLaunchKernelGGL(k_ld_fisher_group, dim3(c->resident_blocks * 8), dim3(256), 0, c->s_compute, d_r, d_n, (unsigned long long)n, 2.0, lf, (uint32_t*)d_t);   // (the tables are in the records by now)
-			if (std::getenv("TWK_HIP_FISHER_SPLIT")) {      // measurement hook: time the two passes apart (stderr)
-				hipEvent_t em = nullptr; (void)hipEventCreate(&em); (void)hipEventRecord(em, c->s_compute);
-				hipLaunchKernelGGL(k_ld_fisher, dim3(c->resident_blocks * 2), dim3(256), 0, c->s_compute, d_r, d_n, (unsigned long long)n, 2.0, lf, (const uint32_t*)d_t);
-				(void)hipEventRecord(e1, c->s_compute); (void)hipEventSynchronize(e1);
-				float a = 0, b = 0; (void)hipEventElapsedTime(&a, e0, em); (void)hipEventElapsedTime(&b, em, e1);
-				unsigned long long cnt[4] = {0, 0, 0, 0}; (void)hipMemcpy(cnt, d_n, sizeof(cnt), hipMemcpyDeviceToHost);
-				fprintf(stderr, "[fisher split] group kernel %.3f ms, one-lane pass over %llu deferred tables %.3f ms\n", a, cnt[3], b);
-				(void)hipEventDestroy(em);
-			} else
-			hipLaunchKernelGGL(k_ld_fisher, dim3(c->resident_blocks * 2), dim3(256), 0, c->s_compute, d_r, d_n, (unsigned long long)n, 2.0, lf, (const uint32_t*)d_t);
-		}
+		// as the engine runs it (walk-length order; the table buffer is free: the tables are in the records by now), or in the order given
+		const int rc = launch_fisher(c, d_r, d_n, (unsigned long long)n, 2.0, in_given_order ? nullptr : (uint32_t*)d_t, (size_t)n * 4);
+		if (rc) { cleanup(); return rc; }
 		e = hipEventRecord(e1, c->s_compute);
 	}
 	if (e == hipSuccess) {

@@ -302,13 +302,14 @@ class HipLd:
         recs = np.concatenate(chunks) if chunks else np.zeros(0, dtype=RECORD_DTYPE)
         return recs, npairs.value, nrec.value
 
-    def fisher_exact(self, tables: np.ndarray, one_lane_per_table: bool = False):
-        """Two-sided Fisher P of int32 tables [n, 4] = (n11, n12, n21, n22) through the engine's Fisher kernel
-        (twk_hip_fisher_exact).  -> (P float64[n], kernel milliseconds)."""
+    def fisher_exact(self, tables: np.ndarray, ordered: bool = True):
+        """Two-sided Fisher P of int32 tables [n, 4] = (n11, n12, n21, n22) through the engine's Fisher kernels
+        (twk_hip_fisher_exact): as the engine runs them, the walks in the order of their length, or (ordered=False) in
+        the order given - same P.  -> (P float64[n], kernel milliseconds)."""
         t = np.ascontiguousarray(tables, dtype=np.int32).reshape(-1, 4)
         out = np.zeros(len(t), dtype=np.float64)
         ms = C.c_float(0)
-        self._check(self._lib.twk_hip_fisher_exact(self._ctx, t.ctypes.data, len(t), out.ctypes.data, int(bool(one_lane_per_table)),
+        self._check(self._lib.twk_hip_fisher_exact(self._ctx, t.ctypes.data, len(t), out.ctypes.data, 0 if ordered else 1,
                                                    C.byref(ms)), "twk_hip_fisher_exact")
         return out, float(ms.value)
 
