@@ -189,4 +189,4 @@ def test_scalc_equals_the_reference_run_live(tmp_path, w, compat):
     np.testing.assert_allclose(bsel[:, 5:9] / total, a[:, 5:9] / total, rtol=0, atol=util.CUBIC_FLOOR["cnt/total"])
     for col, name in ((9, "D"), (10, "Dprime"), (11, "R"), (12, "R2")):
         np.testing.assert_allclose(bsel[:, col], a[:, col], rtol=1e-6, atol=util.CUBIC_FLOOR[name])
-    np.testing.assert_allclose(bsel[:, 13], a[:, 13], rtol=1e-6, atol=1e-290)      # P
+    np.testing.assert_allclose(bsel[:, 13], a[:, 13], rtol=1e-6, atol=1e-320)      # P

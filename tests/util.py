@@ -12,7 +12,7 @@ _STATS_PATH = _os.environ.get("TWK_PARITY_STATS", "")     # tests/sweeps: record
 # ---- bookkeeping of every exemption assert_records_match grants (reported at session end, tests/conftest.py) -------
 # kinds: "floor:<field>"   a cubic-path record passed <field> only through its absolute floor (CUBIC_FLOOR), not the 1e-6 bar
 #        "p-denormal"      Fisher's P below DBL_MIN on both sides, equal to a few hundred steps of the denormal grid
-#        "p-floor"         Fisher's P compared through the absolute underflow floor 1e-290 otherwise (both ~0)
+#        "p-floor"         Fisher's P compared through an absolute floor of 1e-320 (the denormal grid) otherwise; 1e-290 until the walks started on the reference's re-synchronisation cells
 #        "tie:roots"       root-multiplicity flag (bit 5) differs
 #        "tie:round"       round()ed expected counts differ by one: the device's P is Fisher's P of its own table
 #        "tie:fisher-stop" P differs by exactly the observed table's own probability (n >= 1e6)
@@ -192,7 +192,7 @@ def _one_term_apart(p_a, p_b, table):
     return abs(abs(p_a - p_b) - q) <= 1e-4 * q
 
 
-def assert_records_match(gpu_recs, orc_recs, variants, n_samples=None, rtol=1e-6, p_floor=1e-290,
+def assert_records_match(gpu_recs, orc_recs, variants, n_samples=None, rtol=1e-6, p_floor=1e-320,
                          double_root=None):
     """gpu_recs: tomahawk_amd.RECORD_DTYPE (variant indices); orc_recs: oracle RECORD_DTYPE (rid/pos).
 
