@@ -163,6 +163,13 @@ def test_fisher_pipeline_agrees_with_the_oracle_in_any_order(hip):
     assert ((want < 1e-250) & (want > 0)).sum() > 20 and (want > 0.05).sum() > 100 and (want == 0).sum() > 10
     assert np.allclose(binned, want, rtol=1e-8, atol=1e-322)
     assert (binned[want == 0] == 0).all()
+    # the largest problem whose log-factorial table goes into LDS, and the first one beyond it
+    for N in (4024, 4025):
+        hip.set_problem(N, 8)
+        t2 = np.array([[a, N - a, b, N - b] for a, b in zip(rng.integers(0, N, 3000), rng.integers(0, N, 3000))], dtype=np.int32)
+        got2, _ = hip.fisher_exact(t2)
+        want2 = np.array([O.fisher(*[int(x) for x in t]) [2] for t in t2])
+        assert np.allclose(got2, want2, rtol=1e-8, atol=1e-322), N
     # n = 2,000,000: q crosses the smallest normal double between these tables
     hip.set_problem(1_000_000, 8)
     ks = np.arange(12_600, 14_300, 50)

@@ -805,7 +805,7 @@ __device__ __forceinline__ void d_fisher_unpack(unsigned long long v, int n11, c
 	i0 = a == FISHER_AT_END ? f.min : n11 - (int)a;
 	j0 = b == FISHER_AT_END ? f.max : n11 + (int)b;
 }
-constexpr int FISHER_LDS_TABLE_MAX = 8192;       // 64 KiB of doubles: N <= 4,088 samples
+constexpr int FISHER_LDS_TABLE_MAX = 8064;       // 63 KiB of doubles (k_fisher_prepare keeps 1 KiB of bins beside it): N <= 4,024 samples
 // LDS_TABLE: the log-factorial table is copied into LDS first (it must fit: FISHER_LDS_TABLE_MAX entries) - through the
 // vector memory path every look-up of a wave is up to 64 separate cache-line requests.
 // bins[0..256): records per bin (zeroed before the launch; only the first min(n, index_limit) records are counted).
