@@ -181,6 +181,26 @@ def test_fisher_pipeline_agrees_with_the_oracle_in_any_order(hip):
     assert np.allclose(got[: len(big)], want, rtol=1e-6, atol=1e-322)
 
 
+@pytest.mark.parametrize("N", [2504, 6000])
+def test_fisher_order_and_table_placement_do_not_change_a_record(hip, monkeypatch, N):
+    """The records of a survivor-heavy call with the Fisher walks binned by length (default) and in the order the survivors
+    were appended, with the log-factorial table in LDS (N <= 4,024) and in global memory: the same bytes."""
+    M = 1500
+    al = _cohort_alleles(M, N, 77 + N)
+    util.upload(hip, al)
+    f = T.Filters(minR2=0.05)
+    for mode in (T.MODE_PHASED, T.MODE_UNPHASED):
+        base, _, _ = hip.ld_all(mode, f)
+        assert len(base) > 2000 and (base["P"] < 1e-20).sum() > 100
+        for env in ({"TWK_HIP_FISHER_ORDER": "0"}, {"TWK_HIP_FISHER_LDS": "0"}, {"TWK_HIP_FISHER_ORDER": "0", "TWK_HIP_FISHER_LDS": "0"}):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            got, _, _ = hip.ld_all(mode, f)
+            for k in env:
+                monkeypatch.delenv(k)
+            assert np.sort(base, order=ORDER).tobytes() == np.sort(got, order=ORDER).tobytes(), env
+
+
 @pytest.mark.parametrize("env", [{"TWK_HIP_SEG": "64"}, {"TWK_HIP_SEG": "32", "TWK_HIP_XCD_QUEUES": "8"}, {"TWK_HIP_XCD_QUEUES": "8"},
                                  {"TWK_HIP_PATCH": "16x32", "TWK_HIP_SEG": "128", "TWK_HIP_XCD_QUEUES": "4"}])
 def test_count_kernel_work_orders_give_the_same_counts(hip, monkeypatch, env):

@@ -568,8 +568,9 @@ TilePlan plan_for(const twk_hip_ctx* c, int mode) {
 int launch_fisher(twk_hip_ctx* c, twk_hip_record* recs, unsigned long long* n_out, unsigned long long cap, double minP,
                   uint32_t* scratch, size_t scratch_words) {
 	const LFact lf{c->d_lfact, c->lfact_n};
-	static const bool ordered = [] { const char* e = std::getenv("TWK_HIP_FISHER_ORDER"); return !(e && e[0] == '0'); }();
-	static const bool lds_ok = [] { const char* e = std::getenv("TWK_HIP_FISHER_LDS"); return !(e && e[0] == '0'); }();
+	const char* oe = std::getenv("TWK_HIP_FISHER_ORDER");
+	const char* le = std::getenv("TWK_HIP_FISHER_LDS");
+	const bool ordered = !(oe && oe[0] == '0'), lds_ok = !(le && le[0] == '0');
 	const bool lds_table = lds_ok && c->lfact_n <= FISHER_LDS_TABLE_MAX;
 	const size_t lds_bytes = lds_table ? (size_t)c->lfact_n * sizeof(double) : 0;
 	if (!c->d_fisher_bins) HIPCHK(c, hipMalloc((void**)&c->d_fisher_bins, 2 * FISHER_BINS * sizeof(uint32_t)));
