@@ -1,5 +1,5 @@
 """The fused count -> r2 screen -> candidate list form of the count kernel (k_count_screen_t + k_ld_stats_list,
-ld_count.hip.h / ld_math.hip.h): for short rows (<= 16 K-chunks: N <= 8192 phased) the block that counted a tile screens
+ld_count.hip.h / ld_math.hip.h): for rows of <= 128 K-chunks (N <= 65,536 phased) the block that counted a tile screens
 it in registers and only candidate pairs reach the math kernel - no count matrix in HBM, no one-thread-per-pair math
 front end.  Reference shape: the per-pair loop count -> math of lib/ld/ld_engine.cpp:1898-2015 with PhasedMath
 (:1162-1310).  The records must be those of the plain path, bit for bit, and those of the oracle."""
@@ -29,7 +29,7 @@ def _both(hip, monkeypatch, call):
     return plain, fused, tm["fused_launches"], tm["candidates"]
 
 
-@pytest.mark.parametrize("N", [64, 1000, 2504, 8192])
+@pytest.mark.parametrize("N", [64, 1000, 2504, 8192, 40_000])
 def test_fused_equals_plain_and_oracle(hip, monkeypatch, N):
     """Every phased-math route that qualifies: -p, default mode without missing data, with and without the allele-count
     band (r2 screen), a window, shards, several cut-offs incl. one placed on existing r2 values."""
@@ -118,9 +118,9 @@ def test_fused_candidate_overflow_falls_back_to_the_plain_path(hip, monkeypatch)
 
 
 def test_fused_forced_on_long_rows(hip, monkeypatch):
-    """TWK_HIP_FUSED=2 (test hook): the fused form whatever the row length - N = 60,000 phased is 118 K-chunks per
+    """TWK_HIP_FUSED=2 (test hook): the fused form whatever the row length - N = 70,000 phased is 137 K-chunks per
     tile, which the default policy would split into units near the end of a launch."""
-    N, M = 60_000, 400
+    N, M = 70_000, 400
     al = util.mosaic_alleles(M, N, 8, n_founders=6, switch=0.01, mut=0.001)
     util.upload(hip, al)
     f = T.Filters(minR2=0.3)
@@ -223,13 +223,13 @@ def test_count_kernel_work_orders_give_the_same_counts(hip, monkeypatch, env):
     assert len(base) > 50 and np.sort(base, order=ORDER).tobytes() == np.sort(got, order=ORDER).tobytes()
 
 
-@pytest.mark.parametrize("N", [64, 1000, 2504, 16_000])
+@pytest.mark.parametrize("N", [64, 1000, 2504, 16_000, 50_000])
 def test_fused_unphased_equals_plain_and_oracle(hip, monkeypatch, N):
     """The unphased form (k_count_screen_unphased_t + k_ld_stats_list_unphased): a variant pair's four products are
     gathered from four lanes with DPP moves, the screen is the interval test on the admissible haplotype frequencies
     (UnphasedMath, ld_engine.cpp:1312-1560), candidates carry HH, HQ, QH, QQ.  `-u` on data without missing genotypes, with
-    and without the allele-count band, windows, shards, small tiles, cut-offs on existing r2 values; N = 16,000 is the
-    longest row the default policy fuses (16 chunks of N bits)."""
+    and without the allele-count band, windows, shards, small tiles, cut-offs on existing r2 values; up to rows of 49
+    chunks (the default policy fuses up to 128 chunks of N bits)."""
     M = 1500 if N <= 2504 else 600
     al = _cohort_alleles(M, N, 700 + N)
     data, mask, variants = util.upload(hip, al)

@@ -332,10 +332,13 @@ int ensure_host_records(twk_hip_ctx* c, unsigned long long n) {
 	return TWK_HIP_OK;
 }
 
-// Rows of at most this many K chunks (32 words each: 2N <= 16384 bits, N <= 8192 phased) take the fused
-// count -> screen kernel: at that length a tile is never worth splitting, and the C round trip plus the
-// one-thread-per-pair math front end cost as much as the counting itself.
-constexpr uint32_t FUSED_MAX_CHUNKS = 16;
+// Rows of at most this many K chunks (32 words each: N <= 65,536 phased, N <= 131,072 unphased) take the fused
+// count -> screen kernel.  Up to 16 chunks a tile is never worth splitting, and the C round trip plus the
+// one-thread-per-pair math front end cost as much as the counting itself.  Beyond that a fused launch ends less evenly
+// (a block must hold a pair's whole count to screen it, so the last tiles cannot be cut along K: +2..6 % count kernel at
+// 40-118 chunks) but still saves several times that in the math kernel (tests/sweeps/fused_mid_n.sh,
+// profiles/r03_fused_mid_n.txt: N = 60,000 -p, 4e4 variants: 46 + 15 ms -> 49 + 2.5 ms); the two meet near 220 chunks.
+constexpr uint32_t FUSED_MAX_CHUNKS = 128;
 
 struct Geometry { uint32_t rowsA, rowsB, gx, gy, ldc; };
 Geometry tile_geometry(int P, const twk_hip_tile_desc& t) {
