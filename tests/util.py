@@ -15,7 +15,7 @@ _STATS_PATH = _os.environ.get("TWK_PARITY_STATS", "")     # tests/sweeps: record
 #        "p-floor"         Fisher's P compared through an absolute floor of 1e-320 (the denormal grid) otherwise; 1e-290 until the walks started on the reference's re-synchronisation cells
 #        "tie:roots"       root-multiplicity flag (bit 5) differs
 #        "tie:round"       round()ed expected counts differ by one: the device's P is Fisher's P of its own table
-#        "tie:fisher-stop" P differs by exactly the observed table's own probability (n >= 1e6)
+#        "tie:fisher-stop" P differs by exactly the observed table's own probability (n >= 1e6, or P on the denormal grid)
 #        "double-root"     pair reported by one side only, proved to sit on a double root of the cubic
 EXEMPTIONS = _collections.Counter()
 COMPARED = _collections.Counter()          # "records", "cubic" (records out of the unphased cubic), "calls"
@@ -283,7 +283,7 @@ def assert_records_match(gpu_recs, orc_recs, variants, n_samples=None, rtol=1e-6
                 used["p-denormal"] += 1
             elif neighbour and np.isclose(g["P"], own, rtol=rtol, atol=p_floor):
                 ties.append((k, "round"))
-            elif gt == wt and sum(gt) >= 1_000_000 and _one_term_apart(gP, wP, gt):
+            elif gt == wt and (sum(gt) >= 1_000_000 or max(gP, wP) < 1e-305) and _one_term_apart(gP, wP, gt):
                 # kt_fisher_exact stops its tail walks where a term reaches 0.99999999 q (q = the observed
                 # table's probability) and adds that term only if it is below 1.00000001 q
                 # (fisher_math.cpp:249-258).  On the observed table's own side that term IS q, recomputed
@@ -291,7 +291,10 @@ def assert_records_match(gpu_recs, orc_recs, variants, n_samples=None, rtol=1e-6
                 # band, so whether the observed table's own probability is counted in P is decided by the
                 # last bits of libm's lgamma, in the reference itself as on the device (a high-precision
                 # evaluation agrees with the reference to 2e-8 when it does count it).  The two P then
-                # differ by exactly q: checked here, nothing else is allowed.  (The same happens for q below
+                # differ by exactly q: checked here, nothing else is allowed.  The same at any n once q lies on the
+                # denormal grid (P < 1e-305): the 1e-8 band is then a fraction of a grid step to a few hundred steps wide,
+                # and one step of difference between the host's and the device's exp() decides (first seen when the
+                # absolute floor on P went from 1e-290 to 1e-320: N = 100,000, P = 3.2e-316 against 4.7e-316).  (Also for q below
                 # ~1e-290 at any n, where the reference's recurrence starts on denormal terms; there the
                 # device runs the reference's own recurrence - k_ld_fisher_t - from the same cells and agrees.)
                 ties.append((k, "fisher-stop"))
