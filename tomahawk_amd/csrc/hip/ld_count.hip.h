@@ -623,7 +623,7 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 
 		if (c + 1 == c_end) {          // unit done: write (whole tile) or add (part of a tile's K range) - or screen (fused form)
 			const uint32_t yx = __builtin_amdgcn_readfirstlane(w.tiles[tile]);
-			epilogue(acc, yx, wr, wc, li, lj, lane, seg_c0 == 0 && c_end == nchunks, meta);
+			if (EXPERIMENT != 6) epilogue(acc, yx, wr, wc, li, lj, lane, seg_c0 == 0 && c_end == nchunks, meta);      // (6: the dev tool's no-epilogue timing)
 			if (!more) {
 				if (EXPERIMENT == 5 && tid == 0) {      // probe: when did this block finish, and on which XCD / CU?
 					uint32_t xcc, hwid;
