@@ -647,6 +647,20 @@ void k_count_list_t(const CountWork w) {
 	count_list_body<NW, EXPERIMENT>(w, StoreCounts<16 / (NW / 2)>{w.C, w.ldc});
 }
 
+// Inclusive prefix sum over the 64 lanes of a wave (all active) without LDS: Hillis-Steele inside each row of 16 lanes
+// (row_shr 1, 2, 4, 8; lanes shifted in from outside a row contribute 0), then row 0's total into row 1 and row 2's into row
+// 3 (row_bcast:15), then lane 31's into rows 2 and 3 (row_bcast:31).  __shfl_up goes through ds_bpermute: six dependent LDS
+// round trips where a wave with candidates can least afford them, behind its last contraction.
+__device__ __forceinline__ uint32_t wave_scan_inclusive(uint32_t x) {
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);
+	return x;
+}
+
 // ---- fused form for short rows: count -> r2 screen -> candidate list --------------------------------------
 // With a few thousand samples a pair's whole contraction is a few hundred word pairs, and writing its count
 // to C (4 B), reading it back in the math kernel and running that kernel's FP64 front end on it - one thread
@@ -735,17 +749,15 @@ struct ScreenCounts {
 		}
 		if (__ballot(m != 0)) {          // (most tiles of unlinked variants end here)
 			const uint32_t cnt = __popc(m);
-			uint32_t incl = cnt;           // inclusive prefix sum over the wave
-#pragma unroll
-			for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o); if (lane >= o) incl += v; }
-			const uint32_t total = __shfl(incl, 63);
+			const uint32_t incl = wave_scan_inclusive(cnt);
+			const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
 			// (the pointers come out of the parameter block as generic addresses: say that they are global memory, or
 			// every candidate store becomes a flat store that also waits on the LDS queue)
 			typedef __attribute__((address_space(1))) uint32_t g_u32;
 			typedef __attribute__((address_space(1))) unsigned long long g_u64;
 			unsigned long long base = 0;
 			if (lane == 0) base = __hip_atomic_fetch_add((g_u64*)s.n_cand, (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			base = __shfl(base, 0);
+			base = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base) | (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32)) << 32;
 			unsigned long long slot = base + (incl - cnt);
 			g_u32* const cand = (g_u32*)s.cand; const unsigned long long cap = s.cap;
 #pragma unroll
@@ -815,10 +827,9 @@ struct ScreenCountsUnphased {
 		const uint32_t altB = hB + 2u * qB;
 		const double db = (double)altB, rb = T2n - db, fB = db * rb;
 		const bool diag = s.diag != 0;
-		uint32_t hh[8], hq[8], qh[8], qq[8], m = 0;
-#pragma unroll
-		for (int t = 0; t < 8; ++t) {
-			// the group's four products at slot (t, u), for every u; keep u == k
+		// the group's four products at slot (t, u), for every u; keep u == k.  (All lanes must be active: DPP reads the
+		// neighbours' registers.)
+		auto gather = [&](int t, uint32_t& hh, uint32_t& hq, uint32_t& qh, uint32_t& qq) {
 			uint32_t own = 0, p1 = 0, p8 = 0, p9 = 0;
 #pragma unroll
 			for (int u = 0; u < TB; ++u) {
@@ -828,7 +839,13 @@ struct ScreenCountsUnphased {
 			// own = (pa, pb), p1 = (pa, pb ^ 1), p8 = (pa ^ 1, pb), p9 = (pa ^ 1, pb ^ 1)
 			const uint32_t r0 = pb ? p1 : own, r1 = pb ? own : p1;        // (pa, 0), (pa, 1)
 			const uint32_t o0 = pb ? p9 : p8, o1 = pb ? p8 : p9;          // (pa ^ 1, 0), (pa ^ 1, 1)
-			hh[t] = pa ? o0 : r0; hq[t] = pa ? o1 : r1; qh[t] = pa ? r0 : o0; qq[t] = pa ? r1 : o1;
+			hh = pa ? o0 : r0; hq = pa ? o1 : r1; qh = pa ? r0 : o0; qq = pa ? r1 : o1;
+		};
+		uint32_t m = 0;
+#pragma unroll
+		for (int t = 0; t < 8; ++t) {
+			uint32_t hh, hq, qh, qq;
+			gather(t, hh, hq, qh, qq);
 			const uint32_t vA = vA0 + 4 * t;
 			const bool okA = vA < s.a0 + s.nA && vA < s.n_variants;
 			const int rowA = wr * 64 + (li & ~1) + 8 * t;
@@ -836,9 +853,9 @@ struct ScreenCountsUnphased {
 			const uint32_t hi = !okA ? 0u : (s.col_hi ? s.hi_b0 + meta[2 * TILE + wr * 32 + (li >> 1) + 4 * t] : 0xFFFFFFFFu);
 			const double da = (double)(hA + 2u * qA), ra = T2n - da;
 			// n11 = ra - b + (QH + HQ + 2 QQ): the (REF, REF) haplotypes that are certain
-			const double n11 = (ra - db) + (double)(qh[t] + hq[t] + 2u * qq[t]);
+			const double n11 = (ra - db) + (double)(qh + hq + 2u * qq);
 			const double e_lo = (n11 * T2n - ra * rb) - eps;
-			const double e_hi = ((n11 + (double)hh[t]) * T2n - ra * rb) + eps;
+			const double e_hi = ((n11 + (double)hh) * T2n - ra * rb) + eps;
 			const double bound = (cut * (da * ra)) * fB;
 			const bool ok = okA && okB && (!diag || vB > vA) && vB < hi && !(vA < s.list_zone && vB < s.list_zone) && !(e_lo * e_lo < bound && e_hi * e_hi < bound);
 			m |= (ok ? 1u : 0u) << t;
@@ -847,24 +864,27 @@ struct ScreenCountsUnphased {
 			typedef __attribute__((address_space(1))) uint32_t g_u32;
 			typedef __attribute__((address_space(1))) unsigned long long g_u64;
 			const uint32_t cnt = __popc(m);
-			uint32_t incl = cnt;
-#pragma unroll
-			for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o); if (lane >= o) incl += v; }
-			const uint32_t total = __shfl(incl, 63);
+			const uint32_t incl = wave_scan_inclusive(cnt);
+			const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
 			unsigned long long base = 0;
 			if (lane == 0) base = __hip_atomic_fetch_add((g_u64*)s.n_cand, (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			base = __shfl(base, 0);
+			base = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base) | (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32)) << 32;
 			unsigned long long slot = base + (incl - cnt);
 			g_u32* const cand = (g_u32*)s.cand; const unsigned long long cap = s.cap;
+			// (the four products are gathered again rather than kept from the screen: 32 more registers through the screen
+			// cost the kernel two spills, and the scratch traffic of a wave with candidates 30 % of a survivor-rich run)
 #pragma unroll
-			for (int t = 0; t < 8; ++t)
+			for (int t = 0; t < 8; ++t) {
+				uint32_t hh, hq, qh, qq;
+				gather(t, hh, hq, qh, qq);
 				if ((m >> t) & 1u) {
 					if (slot < cap) {
 						g_u32* e = cand + slot * 6;
-						e[0] = vA0 + 4 * t; e[1] = vB; e[2] = hh[t]; e[3] = hq[t]; e[4] = qh[t]; e[5] = qq[t];
+						e[0] = vA0 + 4 * t; e[1] = vB; e[2] = hh; e[3] = hq; e[4] = qh; e[5] = qq;
 					}
 					++slot;
 				}
+			}
 		}
 #pragma unroll
 		for (int t = 0; t < 8; ++t)
@@ -873,10 +893,19 @@ struct ScreenCountsUnphased {
 	}
 };
 
+// The phased form copies the screen's parameter block into LDS first.  It lives in device memory (in SGPRs through the K
+// loop it cost 72 spills), and read from there - by vector loads, again after every hand-written asm block, with a memory
+// round trip in front of the meta staging of every unit and of every epilogue - it cost the survivor-rich 2,504-sample run
+// 4 % of the kernel (19.4 -> 18.6 ms).  The unphased form is at its register limit: there the copy's addresses cost three
+// spills that land in the candidate loop (48 -> 115 ms on the same run), so it reads the block where it is.
+static_assert(sizeof(ScreenWork) % 4 == 0 && sizeof(ScreenWork) / 4 <= 64, "copied by the first wave, one dword per lane");
 template <int NW>
 __global__ __launch_bounds__(NW * 64, NW / 2)
 void k_count_screen_t(const CountWork w, const ScreenWork* sw) {
-	count_list_body<NW, 0>(w, ScreenCounts<16 / (NW / 2)>{sw});
+	__shared__ ScreenWork sw_lds;
+	if (threadIdx.x < sizeof(ScreenWork) / 4) reinterpret_cast<uint32_t*>(&sw_lds)[threadIdx.x] = reinterpret_cast<const uint32_t*>(sw)[threadIdx.x];
+	__syncthreads();
+	count_list_body<NW, 0>(w, ScreenCounts<16 / (NW / 2)>{&sw_lds});
 }
 template <int NW>
 __global__ __launch_bounds__(NW * 64, NW / 2)
