@@ -430,12 +430,17 @@ inline uint32_t build_count_units(uint32_t n_tiles, uint32_t nchunks, uint32_t n
 
 // What a block does with the 8 x TB counts each of its lanes holds when a unit ends.  StoreCounts is the plain form:
 // the counts go to the super-tile's C matrix (stored for a whole tile, added for a part of its K range).
+// What a wave keeps between the units it runs (fused forms: the candidate slots it has reserved and not yet used): three
+// words of LDS per wave - the first free slot (64 bits) and how many are left; in registers they were spilled.
+struct SlotWindow { uint32_t* w; };
+
 template <int TB>
 struct StoreCounts {
 	static constexpr int META_WORDS = 0;       // nothing to stage for the epilogue
 	uint32_t* C; uint32_t ldc;
 	__device__ __forceinline__ const uint32_t* meta_src(uint32_t, uint32_t) const { return nullptr; }
-	__device__ __forceinline__ void operator()(uint32_t (&acc)[8][TB], uint32_t yx, int wr, int wc, int li, int lj, int lane, bool whole, const uint32_t*) const {
+	__device__ __forceinline__ void finish(SlotWindow&, int) const {}
+	__device__ __forceinline__ void operator()(uint32_t (&acc)[8][TB], uint32_t yx, int wr, int wc, int li, int lj, int lane, bool whole, const uint32_t*, SlotWindow&) const {
 		uint32_t* Cblk = C + (size_t)((yx >> 16) * TILE + wr * 64 + li) * ldc + (yx & 0xFFFFu) * TILE + wc * 8 * TB + lj;
 		if (whole) {
 #pragma unroll
@@ -541,6 +546,9 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 	uint32_t st_row0 = stage_row0(tile);
 	stage_rows_s(w.rows, w.W, st_row0, c, st_lds, st_seg0, NSEG, voff_even, voff_odd);
 	uint32_t seg_c0 = c;
+	__shared__ uint32_t window_words[NW][4];
+	SlotWindow window{&window_words[wave_u][0]};
+	if (lane < 4) window.w[lane] = 0;           // (wave-private: no barrier)
 	int buf = 0;
 	for (;;) {
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -623,8 +631,9 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 
 		if (c + 1 == c_end) {          // unit done: write (whole tile) or add (part of a tile's K range) - or screen (fused form)
 			const uint32_t yx = __builtin_amdgcn_readfirstlane(w.tiles[tile]);
-			if (EXPERIMENT != 6) epilogue(acc, yx, wr, wc, li, lj, lane, seg_c0 == 0 && c_end == nchunks, meta);      // (6: the dev tool's no-epilogue timing)
+			if (EXPERIMENT != 6) epilogue(acc, yx, wr, wc, li, lj, lane, seg_c0 == 0 && c_end == nchunks, meta, window);      // (6: the dev tool's no-epilogue timing)
 			if (!more) {
+				epilogue.finish(window, lane);
 				if (EXPERIMENT == 5 && tid == 0) {      // probe: when did this block finish, and on which XCD / CU?
 					uint32_t xcc, hwid;
 					asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -686,12 +695,53 @@ struct ScreenWork {
 	uint32_t list_zone;                // pairs with both set positions below it belong to the carrier-list pass (ld_list.hip.h)
 	double two_n, cut;                 // 2N; minR2 * (1 - 1e-6)
 	uint32_t* cand; unsigned long long cap;            // [cap][3]: set position A, set position B, AA  (unphased form: [cap][6]: ..., HH, HQ, QH, QQ)
-	unsigned long long* n_cand;        // device counter (may run past cap: the host then redoes the tile the plain way)
+	unsigned long long* n_cand;        // device counter of the slots handed out (may run past cap: the host then redoes the tile the plain way)
+	uint32_t chunk;                    // slots a wave reserves at a time (0: exactly what a tile needs, one atomic per wave and tile)
 };
-// (Window mode's position test is left to the list kernel: the tiles of a window-mode launch are the ones the band
-// crosses, so the pairs outside the window are a corner of each, and few of those reach the r2 cut-off.  Testing it here
-// would hold four more values per row and column in registers through the epilogue for nothing.)
-
+// Slots are handed out through one counter.  One atomic per wave and tile is 3.9 M atomics on one address in the unphased
+// 2,504-sample window run - at the ~12 ns an L2 channel takes for each, as long as the whole kernel (48 ms where the same
+// tiles with a cut-off few pairs pass take 33).  So a wave reserves `chunk` slots at a time and numbers its candidates
+// from that window (SlotWindow, kept across the units it runs); what is left of its last window when the kernel ends is
+// marked CAND_UNUSED in the first word, and the list kernels skip such slots.
+constexpr uint32_t CAND_UNUSED = 0xFFFFFFFFu;
+// -> first slot of `total` consecutive ones for this wave (wave-uniform; all lanes active).  W = words per slot.
+__device__ __forceinline__ uint32_t uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+template <int W>
+__device__ __forceinline__ void mark_unused(const ScreenWork& s, unsigned long long first, uint32_t n, int lane) {
+	typedef __attribute__((address_space(1))) uint32_t g_u32;
+	g_u32* const cand = (g_u32*)s.cand;
+	for (uint32_t i = (uint32_t)lane; i < n; i += 64) { const unsigned long long k = first + i; if (k < s.cap) cand[k * W] = CAND_UNUSED; }
+}
+// A tile's candidates go into what is left of the wave's window first and into a new reservation behind that, so nothing
+// is given up when a window runs out; a reservation is four tiles' worth at the current density, `chunk` at most.
+struct SlotRange {
+	unsigned long long first, second; uint32_t n_first;      // candidate i of the wave: first + i for i < n_first, else second + (i - n_first)
+	__device__ __forceinline__ unsigned long long operator[](uint32_t i) const { return i < n_first ? first + i : second + (i - n_first); }
+};
+__device__ __forceinline__ SlotRange reserve_slots(const ScreenWork& s, SlotWindow& win, uint32_t total, int lane) {
+	typedef __attribute__((address_space(1))) unsigned long long g_u64;
+	const unsigned long long next = (unsigned long long)uniform(win.w[0]) | (unsigned long long)uniform(win.w[1]) << 32;
+	const uint32_t left = uniform(win.w[2]);
+	SlotRange r{next, 0, total};
+	unsigned long long new_next = next + total; uint32_t new_left = left - total;
+	if (total > left) {
+		const uint32_t need = total - left;
+		const uint32_t want = 4 * total < s.chunk ? 4 * total : s.chunk;
+		const uint32_t take = want > need ? want : need;
+		unsigned long long b = 0;
+		if (lane == 0) b = __hip_atomic_fetch_add((g_u64*)s.n_cand, (unsigned long long)take, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		r.second = (unsigned long long)uniform((uint32_t)b) | (unsigned long long)uniform((uint32_t)(b >> 32)) << 32;
+		r.n_first = left;
+		new_next = r.second + need; new_left = take - need;
+	}
+	if (lane == 0) { win.w[0] = (uint32_t)new_next; win.w[1] = (uint32_t)(new_next >> 32); win.w[2] = new_left; }
+	return r;
+}
+template <int W>
+__device__ __forceinline__ void release_slots(const ScreenWork& s, SlotWindow& win, int lane) {
+	const unsigned long long next = (unsigned long long)uniform(win.w[0]) | (unsigned long long)uniform(win.w[1]) << 32;
+	mark_unused<W>(s, next, uniform(win.w[2]), lane);
+}
 template <int TB>
 struct ScreenCounts {
 	static constexpr int META_WORDS = 3 * TILE;      // allele counts of the tile's 128 rows, of its 128 columns, band limits of the rows
@@ -706,7 +756,8 @@ struct ScreenCounts {
 		const uint32_t k = sA - s.hi_a0;
 		return s.col_hi + (k < s.hi_n ? k : s.hi_n - 1);
 	}
-	__device__ __forceinline__ void operator()(uint32_t (&acc)[8][TB], uint32_t yx, int wr, int wc, int li, int lj, int lane, bool, const uint32_t* meta) const {
+	__device__ __forceinline__ void finish(SlotWindow& win, int lane) const { release_slots<3>(*sp, win, lane); }
+	__device__ __forceinline__ void operator()(uint32_t (&acc)[8][TB], uint32_t yx, int wr, int wc, int li, int lj, int lane, bool, const uint32_t* meta, SlotWindow& win) const {
 		const ScreenWork& s = *sp;
 		const uint32_t r0 = (yx >> 16) * TILE + wr * 64 + li;             // this lane's rows: r0 + 8t
 		const uint32_t c0 = (yx & 0xFFFFu) * TILE + wc * 8 * TB + lj;     // and columns: c0 + 8u
@@ -754,22 +805,20 @@ struct ScreenCounts {
 			// (the pointers come out of the parameter block as generic addresses: say that they are global memory, or
 			// every candidate store becomes a flat store that also waits on the LDS queue)
 			typedef __attribute__((address_space(1))) uint32_t g_u32;
-			typedef __attribute__((address_space(1))) unsigned long long g_u64;
-			unsigned long long base = 0;
-			if (lane == 0) base = __hip_atomic_fetch_add((g_u64*)s.n_cand, (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			base = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base) | (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32)) << 32;
-			unsigned long long slot = base + (incl - cnt);
+			const SlotRange slots = reserve_slots(s, win, total, lane);
+			uint32_t mine = incl - cnt;                  // this lane's next candidate, counted over the wave
 			g_u32* const cand = (g_u32*)s.cand; const unsigned long long cap = s.cap;
 #pragma unroll
 			for (int t = 0; t < 8; ++t)
 #pragma unroll
 				for (int u = 0; u < TB; ++u)
 					if ((m >> (4 * t + u)) & 1u) {
+						const unsigned long long slot = slots[mine];
 						if (slot < cap) {
 							g_u32* e = cand + slot * 3;
 							e[0] = a0 + r0 + 8 * t; e[1] = b0 + c0 + 8 * u; e[2] = acc[t][u];
 						}
-						++slot;
+						++mine;
 					}
 		}
 #pragma unroll
@@ -809,7 +858,8 @@ struct ScreenCountsUnphased {
 		const uint32_t k = s.a0 + (yx >> 16) * (TILE / 2) + (i - 2 * TILE) - s.hi_a0;
 		return s.col_hi + (k < s.hi_n ? k : s.hi_n - 1);
 	}
-	__device__ __forceinline__ void operator()(uint32_t (&acc)[8][TB], uint32_t yx, int wr, int wc, int li, int lj, int lane, bool, const uint32_t* meta) const {
+	__device__ __forceinline__ void finish(SlotWindow& win, int lane) const { release_slots<6>(*sp, win, lane); }
+	__device__ __forceinline__ void operator()(uint32_t (&acc)[8][TB], uint32_t yx, int wr, int wc, int li, int lj, int lane, bool, const uint32_t* meta, SlotWindow& win) const {
 		static_assert(TB == 4, "four column slots per lane: one per lane of a 2 x 2 group");
 		const ScreenWork& s = *sp;
 		const int pa = li & 1, pb = lj & 1, k = 2 * pa + pb;          // my planes; the column slot I screen
@@ -862,14 +912,11 @@ struct ScreenCountsUnphased {
 		}
 		if (__ballot(m != 0)) {
 			typedef __attribute__((address_space(1))) uint32_t g_u32;
-			typedef __attribute__((address_space(1))) unsigned long long g_u64;
 			const uint32_t cnt = __popc(m);
 			const uint32_t incl = wave_scan_inclusive(cnt);
 			const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-			unsigned long long base = 0;
-			if (lane == 0) base = __hip_atomic_fetch_add((g_u64*)s.n_cand, (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			base = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base) | (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32)) << 32;
-			unsigned long long slot = base + (incl - cnt);
+			const SlotRange slots = reserve_slots(s, win, total, lane);
+			uint32_t mine = incl - cnt;
 			g_u32* const cand = (g_u32*)s.cand; const unsigned long long cap = s.cap;
 			// (the four products are gathered again rather than kept from the screen: 32 more registers through the screen
 			// cost the kernel two spills, and the scratch traffic of a wave with candidates 30 % of a survivor-rich run)
@@ -878,11 +925,12 @@ struct ScreenCountsUnphased {
 				uint32_t hh, hq, qh, qq;
 				gather(t, hh, hq, qh, qq);
 				if ((m >> t) & 1u) {
+					const unsigned long long slot = slots[mine];
 					if (slot < cap) {
 						g_u32* e = cand + slot * 6;
 						e[0] = vA0 + 4 * t; e[1] = vB; e[2] = hh; e[3] = hq; e[4] = qh; e[5] = qq;
 					}
-					++slot;
+					++mine;
 				}
 			}
 		}

@@ -708,8 +708,8 @@ void k_ld_stats(const StatsParams p) {
 }
 
 // The math on the candidate list of the fused count kernel (k_count_screen_t): one candidate (set position A, set
-// position B, AA) per lane, grid-stride; n_cand is the device counter the count kernel left (it may have run past
-// `cap`: the host then redoes the tile through C).  Everything the plain kernel tests is tested again here - the count
+// position B, AA) per lane, grid-stride; n_cand is the device counter of the slots the count kernel handed out (it may
+// have run past `cap`: the host then redoes the tile through C; slots handed out and not used are marked).  Everything the plain kernel tests is tested again here - the count
 // kernel's screen only decides what is worth looking at.
 __global__ __launch_bounds__(256)
 void k_ld_stats_list(const StatsParams* pp, const uint32_t* __restrict__ cand, const unsigned long long* __restrict__ n_cand,
@@ -728,7 +728,8 @@ void k_ld_stats_list(const StatsParams* pp, const uint32_t* __restrict__ cand, c
 		twk_hip_record rec;
 		if (k < n) {
 			const uint32_t sA = cand[3 * k], sB = cand[3 * k + 1];
-			keep = d_pair<SRC_PHASED_VALUE>(p, sA, sB, 0, 0, cand[3 * k + 2], &rec);
+			if (sA != 0xFFFFFFFFu)             // (a slot a wave reserved and did not use: CAND_UNUSED, ld_count.hip.h)
+				keep = d_pair<SRC_PHASED_VALUE>(p, sA, sB, 0, 0, cand[3 * k + 2], &rec);
 		}
 		d_append_survivor(p, keep, rec);
 	}
@@ -740,7 +741,8 @@ __device__ __noinline__ void d_list_item_unphased(const StatsParams* pp, const u
 	const StatsParams& p = *pp;
 	bool keep = false;
 	twk_hip_record rec;
-	if (valid) keep = d_pair<SRC_UNPHASED_VALUES>(p, e[0], e[1], 0, 0, e[2], &rec, e[3], e[4], e[5]);
+	if (valid && e[0] != 0xFFFFFFFFu)      // (CAND_UNUSED: a slot a wave reserved and did not use, ld_count.hip.h)
+		keep = d_pair<SRC_UNPHASED_VALUES>(p, e[0], e[1], 0, 0, e[2], &rec, e[3], e[4], e[5]);
 	d_append_survivor(p, keep, rec);
 }
 // The same over the unphased form's candidates: (set position A, set position B, HH, HQ, QH, QQ), the cubic and all.

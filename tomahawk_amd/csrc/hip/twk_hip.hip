@@ -624,6 +624,12 @@ int enqueue_tile(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, const twk
 		sw.list_zone = cr ? cr->list_zone : 0;
 		sw.two_n = 2.0 * (double)c->N; sw.cut = f.minR2 * (1.0 - 1e-6);
 		sw.cand = s.C; sw.cap = s.cand_cap; sw.n_cand = s.n_out + 2;
+		{	// slots a wave reserves at a time: what it cannot use is lost to the list, so at most an eighth of the list's
+			// capacity may be tied up in the waves' windows (small tiles: 0, i.e. one atomic per wave and tile)
+			const unsigned long long per_wave = s.cand_cap / (8ull * c->resident_blocks * (COUNT_THREADS / 64));
+			const char* ce = std::getenv("TWK_HIP_CAND_CHUNK");      // measurement hook
+			sw.chunk = ce ? (uint32_t)std::strtoul(ce, nullptr, 10) : (per_wave >= 64 ? (uint32_t)std::min<unsigned long long>(per_wave, 128) : 0u);
+		}
 	}
 	const StatsParams* d_stats = nullptr;
 	rc = launch_count(c, kind1, t, s, 0, s.ev_c0, s.ev_c1, &s.row_pairs, cr, want_fused ? &fa : nullptr, &s.fused, &d_stats); if (rc) return rc;
