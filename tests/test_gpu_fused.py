@@ -320,3 +320,32 @@ def test_padding_behind_the_last_chunk_is_skipped_without_changing_a_count(hip, 
                 rec, _, _ = hip.ld_all(mode, T.Filters(minR2=0.1))
                 monkeypatch.delenv("TWK_HIP_FUSED")
                 assert len(rec) > 10 and np.sort(rec, order=ORDER).tobytes() == np.sort(rec_full, order=ORDER).tobytes()
+
+
+@pytest.mark.parametrize("mode", [T.MODE_PHASED, T.MODE_UNPHASED])
+def test_candidate_slot_windows_of_any_size_give_the_same_records(hip, monkeypatch, mode):
+    """A wave of the fused kernels reserves candidate slots several tiles ahead (ScreenWork::chunk) and marks what it does not
+    use; the list kernels skip marked slots.  One atomic per wave and tile (0), tiny windows (3), the default and windows far
+    larger than any tile needs (100,000: most of the list is unused slots, and the list overflows where it is short - the
+    tile is then redone the plain way): the same records, and the slot counter never below the number of survivors."""
+    N, M = 2504, 1900
+    al = _cohort_alleles(M, N, 4242)
+    util.upload(hip, al)
+    f = T.Filters(minR2=0.05)
+    monkeypatch.setenv("TWK_HIP_FUSED", "0")
+    base, _, _ = hip.ld_all(mode, f, window=T.OPT_WINDOW, l_window=60_000)
+    monkeypatch.setenv("TWK_HIP_FUSED", "1")
+    assert len(base) > 5000
+    for chunk in ("0", "3", None, "700", "100000"):
+        if chunk is None:
+            monkeypatch.delenv("TWK_HIP_CAND_CHUNK", raising=False)
+        else:
+            monkeypatch.setenv("TWK_HIP_CAND_CHUNK", chunk)
+        for tv in (0, 256):
+            hip.timing_reset()
+            got, _, _ = hip.ld_all(mode, f, window=T.OPT_WINDOW, l_window=60_000, tile_variants=tv)
+            tm = hip.timing()
+            assert tm["fused_launches"] > 0 and tm["candidates"] >= len(got), (chunk, tv)
+            assert np.sort(base, order=ORDER).tobytes() == np.sort(got, order=ORDER).tobytes(), (chunk, tv)
+    monkeypatch.delenv("TWK_HIP_CAND_CHUNK", raising=False)
+    monkeypatch.delenv("TWK_HIP_FUSED")
