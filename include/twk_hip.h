@@ -280,7 +280,9 @@ typedef struct {
 	uint64_t words_per_row; /* 32-bit words contracted per row pair (unpadded)   */
 	uint64_t fused_launches;/* count launches that ran the fused count -> r2 screen form (short rows,
 	                           phased math: no count matrix, candidates only)    */
-	uint64_t candidates;    /* pairs those launches handed to the math kernel    */
+	uint64_t candidates;    /* list slots those launches handed to the math kernel:
+	                           the pairs that passed the screen, plus the slots a wave
+	                           had reserved and not used when its launch ended      */
 	double   list_ms;       /* sum of carrier-list intersection kernel durations (rare variants at very large sample
 	                           counts: the device's twk_igt_list / PhasedListVector, core.h:517-672, ld_engine.cpp:185-267) */
 	uint64_t list_launches;

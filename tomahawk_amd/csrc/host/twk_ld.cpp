@@ -640,7 +640,7 @@ bool twk_ld::twk_ld_impl::run(twk_ld_settings& settings, const Header& hdr, cons
 			          << tm.count_launches << " launches ("
 			          << (tm.count_ms > 0 ? (double)tm.row_pairs * (double)tm.words_per_row / (tm.count_ms * 1e-3) / 2.62e13 * 100.0 : 0.0)
 			          << " % of the and+bcnt issue ceiling over the tiles it contracted), math kernels " << tm.stats_ms << " ms"
-			          << (tm.fused_launches ? "; " + std::to_string(tm.fused_launches) + " launches fused count -> r2 screen, " + pretty(tm.candidates) + " candidate pairs" : std::string())
+			          << (tm.fused_launches ? "; " + std::to_string(tm.fused_launches) + " launches fused count -> r2 screen, " + pretty(tm.candidates) + " candidate slots" : std::string())
 			          << (tm.list_launches ? "; carrier-list kernel " + std::to_string(tm.list_ms) + " ms in " + std::to_string(tm.list_launches) + " launches over " + pretty(tm.list_pairs) + " rare pairs" : std::string())
 			          << std::endl;
 	}
