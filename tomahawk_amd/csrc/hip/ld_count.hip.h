@@ -567,7 +567,9 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 			if (META) {
 				if (wave_u < META / 64) {
 					const uint32_t yx_m = __builtin_amdgcn_readfirstlane(w.tiles[tile]);
-					glds4(epilogue.meta_src(yx_m, (uint32_t)(wave_u * 64 + lane)), (uint32_t)(uintptr_t)(lptr_t*)meta + (uint32_t)wave_u * 256u);
+					uint32_t mi = (uint32_t)(wave_u * 64 + lane);
+					asm volatile("" : "+v"(mi));         // (opaque: the address arithmetic on it is redone per unit, not hoisted out of the loop and spilled)
+					glds4(epilogue.meta_src(yx_m, mi), (uint32_t)(uintptr_t)(lptr_t*)meta + (uint32_t)wave_u * 256u);
 				}
 				if (c + 1 == c_end) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // a one-chunk unit needs it in this very iteration: the barrier below publishes it
 			}
