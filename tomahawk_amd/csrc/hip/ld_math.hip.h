@@ -291,7 +291,7 @@ __device__ inline bool d_phased_math(uint64_t c0, uint64_t c1, uint64_t c4, uint
 	else        dmax = g0 * g1 < h0 * h1 ? -g0 * g1 : -h0 * h1;
 	const double Dprime = D / dmax;
 	if (Dprime < f.minDprime || Dprime > f.maxDprime) return false;
-	// Fisher's exact test (:1221-1231) runs in k_ld_fisher on the compacted survivors
+	// Fisher's exact test (:1221-1231) runs in k_ld_fisher_t on the compacted survivors
 	rec->idxA = A; rec->idxB = B; rec->_pad = 0;
 	rec->cnt[0] = (double)c0; rec->cnt[1] = (double)c1; rec->cnt[2] = (double)c4; rec->cnt[3] = (double)c5;
 	rec->D = D; rec->Dprime = Dprime; rec->R = sqrt(R2); rec->R2 = R2; rec->P = 0;
@@ -299,7 +299,7 @@ __device__ inline bool d_phased_math(uint64_t c0, uint64_t c1, uint64_t c4, uint
 	rec->flags = d_common_flags(vm, A, B, rec->cnt, R2) | 1u;
 	// A REFREF count that wrapped (TWK_HIP_OPT_REF_COMPAT) no longer fits the double: the reference hands
 	// Fisher's test the uint64 narrowed to int (ld_engine.cpp:1222, fisher_math.cpp:231), i.e. its low 32
-	// bits; they ride in _pad to k_ld_fisher, which clears the marker bit again.
+	// bits; they ride in _pad to k_ld_fisher_t, which clears the marker bit again.
 	if (c0 >= (1ull << 53)) { rec->_pad = (uint32_t)c0; rec->flags |= TWK_N11_IN_PAD; }
 	return true;
 }
@@ -364,7 +364,7 @@ __device__ inline bool d_choose_f11(double total, double target, double p, doubl
 	else        dmax = p * q < (1 - p) * (1 - q) ? -p * q : -(1 - p) * (1 - q);
 	const double Dprime = D / dmax;
 	if (Dprime < f.minDprime || Dprime > f.maxDprime) return false;
-	// Fisher's exact test on the rounded counts (:1655-1664) runs in k_ld_fisher
+	// Fisher's exact test on the rounded counts (:1655-1664) runs in k_ld_fisher_t
 	rec->idxA = A; rec->idxB = B; rec->_pad = 0;
 	rec->cnt[0] = cnt[0]; rec->cnt[1] = cnt[1]; rec->cnt[2] = cnt[2]; rec->cnt[3] = cnt[3];
 	rec->D = D; rec->Dprime = Dprime; rec->R = sqrt(R2); rec->R2 = R2; rec->P = 0;
