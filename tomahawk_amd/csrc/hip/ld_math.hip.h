@@ -109,7 +109,8 @@ __device__ inline double d_fisher_skip_exponent(int) { return 40.0; }
 //      point stays below the target.
 // The ratios are the recurrence's own ((row1-k)(col1-k) / ((k+1)(k+1+slack))), taken in float with the rounding
 // pushed to the safe side; every point is verified in FP64 against the table and a point that fails is not used
-// (the walk then starts where the reference does).  21 terms a record on the same run (the best possible start: 20.7).
+// (the walk then starts where the reference does).  21 terms a record on the same run (the best possible start: 20.7),
+// before d_fisher_starts moves the point out to a multiple of 11.
 __device__ __forceinline__ double d_fisher_lpmf(const LFact& t, int s, int n1_, int n_1, int n, double lden) {
 	return d_lbinom(t, n1_, s) + d_lbinom(t, n - n1_, n_1 - s) - lden;
 }
