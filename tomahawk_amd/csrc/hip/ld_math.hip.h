@@ -682,20 +682,32 @@ __device__ __forceinline__ bool d_pair(const StatsParams& p, uint32_t sA, uint32
 	return d_unphased_math(c, p.vm, A, B, p.filt, rec);
 }
 
-// wave-level compaction of the survivors: one atomic per wave
+// Compaction of the survivors: one atomic per *block*.  (One per wave was the kernels' bound in a survivor-rich run: the
+// counter is one address, an L2 channel takes ~12 ns per atomic on it, and 574 k waves with a survivor are the 7.2 ms
+// k_ld_stats_list took for the 36 M candidates of the 2,504-sample window run - the same figure as the candidate counter
+// of the fused count kernel, ld_count.hip.h.)  Every thread of the block calls this the same number of times; blocks are
+// 256 threads.
+constexpr int STATS_THREADS = 256;
 __device__ __forceinline__ void d_append_survivor(const StatsParams& p, bool keep, const twk_hip_record& rec) {
+	__shared__ uint32_t wave_keep[STATS_THREADS / 64];
+	__shared__ unsigned long long block_base;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const unsigned long long ballot = __ballot(keep);
-	if (ballot) {
-		const int lane = threadIdx.x & 63;
-		const int leader = __ffsll((long long)ballot) - 1;
-		unsigned long long base = 0;
-		if (lane == leader) base = atomicAdd(p.n_out, (unsigned long long)__popcll(ballot));
-		base = __shfl(base, leader);
-		if (keep) {
-			const unsigned long long slot = base + __popcll(ballot & ((1ull << lane) - 1));
-			if (slot < p.capacity) p.out[slot] = rec;
-		}
+	if (lane == 0) wave_keep[wave] = (uint32_t)__popcll(ballot);
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint32_t total = 0;
+		for (int w = 0; w < STATS_THREADS / 64; ++w) total += wave_keep[w];
+		block_base = total ? atomicAdd(p.n_out, (unsigned long long)total) : 0ull;
 	}
+	__syncthreads();
+	if (keep) {
+		unsigned long long slot = block_base;
+		for (int w = 0; w < wave; ++w) slot += wave_keep[w];
+		slot += (unsigned long long)__popcll(ballot & ((1ull << lane) - 1));
+		if (slot < p.capacity) p.out[slot] = rec;
+	}
+	__syncthreads();                              // (the next call overwrites the counts)
 }
 
 __global__ __launch_bounds__(256)
@@ -718,7 +730,7 @@ void k_ld_stats_list(const StatsParams* pp, const uint32_t* __restrict__ cand, c
 	unsigned long long n = *n_cand;
 	if (n > cap) n = cap;
 	const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
-	const unsigned long long n_up = (n + 63) / 64 * 64;          // whole waves stay together for the ballot
+	const unsigned long long n_up = (n + STATS_THREADS - 1) / STATS_THREADS * STATS_THREADS;          // whole blocks stay together for the append
 #pragma unroll 1
 	for (unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; k < n_up; k += stride) {
 		// the parameter block is read from memory inside the loop (the fence keeps the loads from being hoisted: held
@@ -753,7 +765,7 @@ void k_ld_stats_list_unphased(const StatsParams* pp, const uint32_t* __restrict_
 	unsigned long long n = *n_cand;
 	if (n > cap) n = cap;
 	const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
-	const unsigned long long n_up = (n + 63) / 64 * 64;
+	const unsigned long long n_up = (n + STATS_THREADS - 1) / STATS_THREADS * STATS_THREADS;
 #pragma unroll 1
 	for (unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; k < n_up; k += stride)
 		d_list_item_unphased(pp, cand + 6 * k, k < n);
