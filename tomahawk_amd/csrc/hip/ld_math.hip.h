@@ -88,9 +88,9 @@ struct TableWalk {
 };
 // How far below q (in e-folds) a tail walk may start: everything further out is at most (max - min) terms, each below
 // q e^-K.  K = 40: the part of P that is not summed is below 4e-18 (max - min) q, < 1e-10 of P at 2e7 haplotypes.  (A
-// support-dependent K = 17.5 + ln(max - min) - 2.5e-8 of P, a third fewer terms - was measured: 5 % of the kernel, and
-// in the underflow band, where the reference's result hangs on the rounding of its recurrence (k_ld_fisher_group below),
-// the nearer starting point no longer reproduced it bit for bit: 9 of 1.2 M records.  Not worth it.)
+// support-dependent K = 17.5 + ln(max - min) - 2.5e-8 of P, a third fewer terms - was measured before the starts were
+// moved onto the reference's re-synchronisation cells: 5 % of the kernel then, and in the underflow band, where the
+// reference's result hangs on the rounding of its recurrence, 9 of 1.2 M records no longer bit for bit.  Not worth it.)
 __device__ inline double d_fisher_skip_exponent(int) { return 40.0; }
 // ---- where the two tail walks start ------------------------------------------------------------------------
 // The reference walks both tails from the ends of the support (min, max) inwards until the terms reach q: up to
