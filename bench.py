@@ -227,6 +227,8 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the from-disk `tomahawk calc` measurement (N=1, cfg3)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 counter passes behind roofline.traffic (N=1)")
     ap.add_argument("--e2e-variants", type=int, default=0, help="variants of the e2e input (0: the config's own count)")
+    ap.add_argument("--engine-option", action="append", default=[], metavar="KEY=INT", help="a switch of the engine "
+                    "(twk_hip_set_option, include/twk_hip.h; measurement runs of profiles/collect.sh)")
     ap.add_argument("--emulate-shard", default="", help="K/N: run shard K of N on this one GPU (validation of the "
                     "sharded configs on a single-GPU box; the value then covers that shard only)")
     args = ap.parse_args()
@@ -283,6 +285,9 @@ def main():
         shard_rank, shard_world = (int(x) for x in args.emulate_shard.split("/"))
 
     eng = T.HipLd(dev_index)
+    for kv in args.engine_option:
+        k, v = kv.split("=", 1)
+        eng.set_option(k, int(v))
     t0 = time.time()
     slab = None
     if window_bp:
@@ -475,6 +480,8 @@ def main():
                 cfg_args += ["--min-r2", str(args.min_r2)]
             if args.tile:
                 cfg_args += ["--tile", str(args.tile)]
+            for kv in args.engine_option:
+                cfg_args += ["--engine-option", kv]
             try:
                 tr = measure_traffic(cfg_args, log)
             except Exception as e:       # never take the GPU number down with it

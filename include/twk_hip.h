@@ -28,7 +28,8 @@ extern "C" {
 /* 2: twk_hip_timing grew (fused / carrier-list counters); new entry points twk_hip_set_device_sink,
  *    twk_hip_device_records, twk_hip_fisher_exact.  A caller built against another version must not pass
  *    its structs in: compare twk_hip_abi_version() with the header it was compiled with. */
-#define TWK_HIP_ABI_VERSION 2
+/* 3: twk_hip_set_option / twk_hip_get_option; the library no longer reads environment variables. */
+#define TWK_HIP_ABI_VERSION 3
 
 enum {
 	TWK_HIP_OK         =  0,
@@ -265,6 +266,29 @@ int twk_hip_shard_rows(uint32_t n_rows, uint32_t n_cols, int32_t triangle, uint3
  * point: the pair math reaches the same kernels internally. */
 int twk_hip_fisher_exact(twk_hip_ctx* ctx, const int32_t* tables, uint64_t n, double* p_two_sided,
                          int32_t in_given_order, float* kernel_ms);
+
+/* ---- switches ---------------------------------------------------------- */
+/* Measurement and test switches of one ctx, by name.  The library reads NO environment variable: a process that
+ * embeds it gets the documented defaults unless it calls this.  There is no reference counterpart (the reference's
+ * closest relative is the compile-time SLAVE_DEBUG_MODE / SIMD_AVAILABLE switches, lib/ld/ld_engine.h:20-24).
+ *   key                default  meaning
+ *   "fused"            1        fused count -> r2 screen kernel: 0 never, 1 rows of <= 128 K-chunks, 2 always
+ *   "lists"            1        carrier lists for the rare head of the sorted plane sets: 0 never, 1 rows of >= 4096
+ *                               words, 2 always (lists of >= 8 carriers)
+ *   "list_max"         0        longest carrier list kept (0: row words / 128, / 64 for unphased math)
+ *   "record_cap"       0        cap on a launch's survivor buffer in records (0: none) - forces the overflow path
+ *   "count_min_chunks" 8        shortest K range a tile of the count kernel is split into
+ *   "patch_rows/_cols" 8 / 8    patch of tiles in the count kernel's work order
+ *   "seg"              0        walk a patch in K segments of this many chunks (0: whole tiles)
+ *   "xcd_queues"       0        one unit queue per XCD (2..8; 0: one queue)
+ *   "skip_pad"         1        leave the zero padding behind a row's last live 8 bytes uncontracted
+ *   "fisher_order"     1        Fisher walks binned by length
+ *   "fisher_lds"       1        log-factorial table in LDS while it fits
+ *   "cand_chunk"       -1       candidate slots a wave reserves at a time (-1: sized from the list)
+ * None of them changes a record (tests/test_gpu_fused.py, test_gpu_lists.py); "lists" / "list_max" drop the derived
+ * plane sets, which are rebuilt on next use.  Unknown key or value out of range: TWK_HIP_E_INVALID. */
+int twk_hip_set_option(twk_hip_ctx* ctx, const char* key, int64_t value);
+int twk_hip_get_option(const twk_hip_ctx* ctx, const char* key, int64_t* value);
 
 /* ---- measurement ------------------------------------------------------ */
 /* Cumulative device time (HIP events on the engine's own stream) and launch

@@ -51,12 +51,13 @@ for stage in "$@"; do
 		pmc cfg3_write WRITE_SIZE --steps 1 --warmup 0 --variants 16384
 		pmc cfg3_sq "SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" --steps 1 --warmup 0 --variants 16384
 		;;
-	patch_pmc)   # HBM read traffic of the count kernel against the shape of the tile patches (TWK_HIP_PATCH) and the length of the K
-		# segments the tiles of a patch advance by (TWK_HIP_SEG, 0 = whole tiles), 16,384 variants at N = 1 M
-		# and, with segments, one unit queue per XCD (TWK_HIP_XCD_QUEUES=8: patches dealt round robin to the XCDs)
+	patch_pmc)   # HBM read traffic of the count kernel against the shape of the tile patches (engine options patch_rows / patch_cols)
+		# and the length of the K segments the tiles of a patch advance by (seg, 0 = whole tiles), 16,384 variants at N = 1 M
+		# and, with segments, one unit queue per XCD (xcd_queues=8: patches dealt round robin to the XCDs)
 		for combo in ${PATCH_COMBOS:-8x8:0:0 16x32:0:0 8x8:64:0 16x32:64:0 8x8:64:8 8x8:32:8 8x8:16:8 8x8:8:8 4x16:16:8 8x16:16:8}; do
 			shape=${combo%%:*}; rest=${combo#*:}; seg=${rest%%:*}; nq=${rest##*:}
-			TWK_HIP_PATCH=$shape TWK_HIP_SEG=$seg TWK_HIP_XCD_QUEUES=$nq pmc patch_${shape}_seg${seg}_q$nq FETCH_SIZE --steps 1 --warmup 0 --variants 16384 > /dev/null
+			pmc patch_${shape}_seg${seg}_q$nq FETCH_SIZE --steps 1 --warmup 0 --variants 16384 --engine-option patch_rows=${shape%%x*} --engine-option patch_cols=${shape##*x} \
+				--engine-option seg=$seg --engine-option xcd_queues=$nq > /dev/null
 			python3 - <<PY
 import json
 f = json.load(open("$OUT/patch_${shape}_seg${seg}_q${nq}_pmc_sums.json")); r = json.load(open("$OUT/patch_${shape}_seg${seg}_q${nq}_pmc.json"))
@@ -115,7 +116,7 @@ PY
 		;;
 	kg_prof)  # the small-N regime (the reference's published shape, 2,504 samples x 200,000 cohort-shaped variants): kernel traces of
 		# `calc -p -w 1000000` (33 M surviving pairs) and of all-vs-all `-r 0.8` without the allele-count band, each with the
-		# fused count -> r2 screen kernel (default) and without it (TWK_HIP_FUSED=0)
+		# fused count -> r2 screen kernel (default) and without it (--engine-option fused=0)
 		python3 - <<PY
 import sys, os
 sys.path.insert(0, "$R")
@@ -135,8 +136,8 @@ PY
 				[ $TWK_HIP_NO_SCREEN = 0 ] && unset TWK_HIP_NO_SCREEN
 				name=kg_${run}_fused$fused
 				rm -rf /tmp/prof_$name
-				TWK_HIP_FUSED=$fused timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -o m -- \
-					$R/tomahawk_amd/bin/tomahawk calc -i /tmp/kg_2504_200k.twk -o /tmp/o.two -t 64 $args > /dev/null 2> $OUT/${name}_under_rocprof.log
+				timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -o m -- \
+					$R/tomahawk_amd/bin/tomahawk calc -i /tmp/kg_2504_200k.twk -o /tmp/o.two -t 64 --engine-option fused=$fused $args > /dev/null 2> $OUT/${name}_under_rocprof.log
 				f=$(find /tmp/prof_$name -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/${name}_kernel_stats.csv
 				echo "== $name"; grep "Finished\|HIP\]" $OUT/${name}_under_rocprof.log | cut -c1-330
 				python3 - <<PY

@@ -23,6 +23,21 @@ def hip():
     eng.close()
 
 
+@pytest.fixture
+def opt(hip):
+    """Engine switches for one test (twk_hip_set_option through the binding); whatever a test set is back at its
+    default when the test ends, pass or fail."""
+    class Switches:
+        def set(self, key, value):
+            hip.set_option(key, int(value))
+
+        def unset(self, key):
+            hip.unset_option(key)
+    yield Switches()
+    for key in list(hip._defaults):
+        hip.unset_option(key)
+
+
 def pytest_sessionfinish(session, exitstatus):
     """Account for every exemption the parity checker granted in this session (tests/util.py): totals and rates go to
     gpurun_out/parity_exemptions.json (TWK_PARITY_EXEMPTIONS overrides the path; the round's copy is committed as

@@ -29,7 +29,7 @@ if not os.path.exists(big):
     t = time.time(); H.write_cohort_twk(big, 2504, 1_000_000, seed=21, n_threads=threads, block_size=500, spacing=100, n_contigs=4)
     print(f"wrote {big}: {os.path.getsize(big)/1e6:.0f} MB in {time.time()-t:.1f} s", flush=True)
 run("2504 x 1M, calc -w 100000 -r 0.5", big, ["-w", "100000", "-r", "0.5"])
-run("2504 x 1M, calc -w 100000 -r 0.5, 2 contexts on one GPU (slabs)", big, ["-w", "100000", "-r", "0.5"], {"TWK_HIP_GPUS": "2", "TWK_HIP_FORCE_DEVICE": "0"})
+run("2504 x 1M, calc -w 100000 -r 0.5, 2 contexts on one GPU (slabs)", big, ["-w", "100000", "-r", "0.5", "--engine-option", "force_device=0"], {"TWK_HIP_GPUS": "2"})
 mid = "/tmp/kg_2504_200k.twk"
 if not os.path.exists(mid):
     H.write_cohort_twk(mid, 2504, 200_000, seed=12, n_threads=threads, block_size=500, spacing=100)

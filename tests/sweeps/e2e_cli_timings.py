@@ -40,9 +40,9 @@ if not os.path.exists(twk):
 subprocess.run([CLI, "calc", "-i", twk, "-o", "/tmp/e2e_warm.two", "-t", str(threads)], capture_output=True)   # untimed: the input was just written, its pages are still being flushed
 for args in (["-t", str(threads)], ["-u", "-t", str(threads)], ["-p", "-t", str(threads)]):
     run(f"1M x {M1} cohort calc {' '.join(args[:1]) if args[0] != '-t' else '(default)'}", twk, args)
-run(f"1M x {M1} cohort calc (default) WITHOUT the carrier lists (TWK_HIP_LISTS=0)", twk, ["-t", str(threads)], {"TWK_HIP_LISTS": "0"})
-run(f"1M x {M1} cohort calc -u WITHOUT the carrier lists (TWK_HIP_LISTS=0)", twk, ["-u", "-t", str(threads)], {"TWK_HIP_LISTS": "0"})
-run(f"1M x {M1} cohort calc -u, 2 driver threads on one GPU", twk, ["-u", "-t", str(threads)], {"TWK_HIP_GPUS": "2", "TWK_HIP_FORCE_DEVICE": "0"})
+run(f"1M x {M1} cohort calc (default) WITHOUT the carrier lists (--engine-option lists=0)", twk, ["-t", str(threads), "--engine-option", "lists=0"])
+run(f"1M x {M1} cohort calc -u WITHOUT the carrier lists (--engine-option lists=0)", twk, ["-u", "-t", str(threads), "--engine-option", "lists=0"])
+run(f"1M x {M1} cohort calc -u, 2 driver threads on one GPU", twk, ["-u", "-t", str(threads), "--engine-option", "force_device=0"], {"TWK_HIP_GPUS": "2"})
 for args in (["-t", str(threads)], ["-u", "-t", str(threads)]):
     run(f"1M x {M1} cohort calc {' '.join(args[:1]) if args[0] != '-t' else '(default)'} WITHOUT the r2 screen", twk, args, {"TWK_HIP_NO_SCREEN": "1"})
 

@@ -20,10 +20,29 @@ def test_every_environment_switch_of_the_code_is_in_the_integration_guide():
         text = _read(path)
         names |= set(re.findall(r'getenv\("(TWK_[A-Z0-9_]+)"\)', text))
         names |= set(re.findall(r'environ(?:\.get)?[\(\[]\s*"(TWK_[A-Z0-9_]+)"', text))
-    assert len(names) > 15
+    assert len(names) >= 7
     guide = _read("INTEGRATION.md")
     missing = sorted(n for n in names if n not in guide)
     assert not missing, f"not in INTEGRATION.md: {missing}"
+
+
+def test_the_engine_library_reads_no_environment_and_its_switches_are_documented():
+    """libtwk_hip.so's sources contain no getenv at all (its switches are twk_hip_set_option keys); the host library reads
+    only placement and the two behavioural switches; every option key is in include/twk_hip.h and INTEGRATION.md."""
+    hip_dir = os.path.join(ROOT, "tomahawk_amd", "csrc", "hip")
+    for f in os.listdir(hip_dir):
+        assert "getenv" not in _read(hip_dir, f), f
+    host_dir = os.path.join(ROOT, "tomahawk_amd", "csrc", "host")
+    host_env = set()
+    for f in os.listdir(host_dir):
+        host_env |= set(re.findall(r'getenv\("([A-Z0-9_]+)"\)', _read(host_dir, f)))
+    assert host_env == {"TWK_HIP_DEVICE", "TWK_HIP_GPUS", "TWK_HIP_PART", "TWK_REF_COMPAT", "TWK_HIP_NO_SCREEN"}, host_env
+    keys = re.findall(r'\{"([a-z_]+)", &Options::', _read(hip_dir, "twk_hip.hip"))
+    assert len(keys) >= 13
+    header, guide = _read("include", "twk_hip.h"), _read("INTEGRATION.md")
+    for k in keys:
+        stem = k[:-5] if k.endswith(("_rows", "_cols")) else k          # "patch_rows/_cols" is one line of the header's table
+        assert stem in header and k in guide, k
 
 
 def test_profiles_readme_names_only_files_that_exist():

@@ -287,13 +287,13 @@ def test_rle_inflate_kernel_equals_the_oracle(hip, N):
         hip.upload_rle(buf, bad, util.to_hip_meta(variants), first=2)
 
 
-def test_split_units_on_short_rows(hip, monkeypatch):
+def test_split_units_on_short_rows(hip, opt):
     """The count kernel's split-unit path (K-ranges of a tile added with atomics) is only taken on long rows by
     default; forced onto short ones, every cell still equals the oracle's."""
     N, M = 3000, 300                                  # unphased planes: 94 words -> 3 chunks of 32
     al = util.random_alleles(M, N, 8, miss_rate=0.05, miss_variants=0.3)
     data, mask, variants = util.upload(hip, al)
-    monkeypatch.setenv("TWK_HIP_COUNT_MIN_CHUNKS", "1")
+    opt.set("count_min_chunks", 1)
     for mode, counter in ((T.MODE_PHASED, O.count_phased), (T.MODE_UNPHASED, O.count_unphased)):
         got = hip.count_tile(mode, 0, M, 0, M)
         rng = np.random.default_rng(3)
@@ -302,7 +302,7 @@ def test_split_units_on_short_rows(hip, monkeypatch):
             mj = mask[j] if variants["gt_missing"][j] else None
             assert np.array_equal(got[i, j], counter(data[i], mi, data[j], mj, N)), (mode, i, j)
     whole, _, _ = hip.ld_all(T.MODE_AUTO, T.Filters(minR2=0.0))
-    monkeypatch.delenv("TWK_HIP_COUNT_MIN_CHUNKS")
+    opt.unset("count_min_chunks")
     plain, _, _ = hip.ld_all(T.MODE_AUTO, T.Filters(minR2=0.0))
     order = ["idxA", "idxB"]
     assert np.sort(whole, order=order).tobytes() == np.sort(plain, order=order).tobytes()

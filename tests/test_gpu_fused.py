@@ -15,22 +15,22 @@ pytestmark = pytest.mark.gpu
 ORDER = ["idxA", "idxB"]
 
 
-def _both(hip, monkeypatch, call):
+def _both(hip, opt, call):
     """Run `call` with the fused form off and on -> (plain records, fused records, fused launches, candidates)."""
-    monkeypatch.setenv("TWK_HIP_FUSED", "0")
+    opt.set("fused", 0)
     hip.timing_reset()
     plain = call()
     assert hip.timing()["fused_launches"] == 0
-    monkeypatch.setenv("TWK_HIP_FUSED", "1")
+    opt.set("fused", 1)
     hip.timing_reset()
     fused = call()
     tm = hip.timing()
-    monkeypatch.delenv("TWK_HIP_FUSED")
+    opt.unset("fused")
     return plain, fused, tm["fused_launches"], tm["candidates"]
 
 
 @pytest.mark.parametrize("N", [64, 1000, 2504, 8192, 40_000])
-def test_fused_equals_plain_and_oracle(hip, monkeypatch, N):
+def test_fused_equals_plain_and_oracle(hip, opt, N):
     """Every phased-math route that qualifies: -p, default mode without missing data, with and without the allele-count
     band (r2 screen), a window, shards, several cut-offs incl. one placed on existing r2 values."""
     M = 1700 if N <= 2504 else 700
@@ -41,7 +41,7 @@ def test_fused_equals_plain_and_oracle(hip, monkeypatch, N):
         for minR2 in (0.1, 0.6, 0.004):
             for opt in (0, T.OPT_R2_SCREEN):
                 f = T.Filters(minR2=minR2)
-                (p, np0, _), (q, np1, nr1), nf, ncand = _both(hip, monkeypatch, lambda: hip.ld_all(mode, f, window=opt))
+                (p, np0, _), (q, np1, nr1), nf, ncand = _both(hip, opt, lambda: hip.ld_all(mode, f, window=opt))
                 assert nf > 0 and np0 == np1 == M * (M - 1) // 2 and nr1 == len(q) == len(p) > 20
                 assert ncand >= len(q)                          # every survivor was a candidate
                 assert ncand < 0.5 * np1 or minR2 < 0.01         # and the screen did screen
@@ -54,17 +54,17 @@ def test_fused_equals_plain_and_oracle(hip, monkeypatch, N):
     for x in r2[:: max(1, len(r2) // 5)][:5]:
         for cut in (np.nextafter(x, 0.0), x, np.nextafter(x, 1.0)):
             f = T.Filters(minR2=float(cut))
-            (p, _, _), (q, _, _), nf, _ = _both(hip, monkeypatch, lambda: hip.ld_all(T.MODE_PHASED, f))
+            (p, _, _), (q, _, _), nf, _ = _both(hip, opt, lambda: hip.ld_all(T.MODE_PHASED, f))
             assert nf > 0 and np.sort(p, order=ORDER).tobytes() == np.sort(q, order=ORDER).tobytes()
     # window mode (positions 100 bp apart) and shards of it
     f = T.Filters(minR2=0.1)
-    (p, np0, _), (q, np1, _), nf, _ = _both(hip, monkeypatch, lambda: hip.ld_all(T.MODE_PHASED, f, window=T.OPT_WINDOW, l_window=30_000))
+    (p, np0, _), (q, np1, _), nf, _ = _both(hip, opt, lambda: hip.ld_all(T.MODE_PHASED, f, window=T.OPT_WINDOW, l_window=30_000))
     assert nf > 0 and np0 == np1 and len(p) > 20 and np.sort(p, order=ORDER).tobytes() == np.sort(q, order=ORDER).tobytes()
     parts = [hip.ld_all(T.MODE_PHASED, f, part=k, n_parts=3) for k in range(3)]
     whole, _, _ = hip.ld_all(T.MODE_PHASED, f)
     assert np.sort(np.concatenate([x[0] for x in parts]), order=ORDER).tobytes() == np.sort(whole, order=ORDER).tobytes()
     # small super-tiles: diagonal + rectangle launches, two-deep pipeline
-    (p, _, _), (q, _, _), nf, _ = _both(hip, monkeypatch, lambda: hip.ld_all(T.MODE_PHASED, f, tile_variants=256))
+    (p, _, _), (q, _, _), nf, _ = _both(hip, opt, lambda: hip.ld_all(T.MODE_PHASED, f, tile_variants=256))
     assert nf > 3 and np.sort(p, order=ORDER).tobytes() == np.sort(q, order=ORDER).tobytes()
     # and the oracle agrees (sampled: it is scalar)
     sub = np.sort(np.random.default_rng(N).choice(M, size=240, replace=False))
@@ -77,7 +77,7 @@ def test_fused_equals_plain_and_oracle(hip, monkeypatch, N):
     util.assert_records_match(got, want, variants[sub])
 
 
-def test_fused_first_pass_of_default_mode_with_missing_data(hip, monkeypatch):
+def test_fused_first_pass_of_default_mode_with_missing_data(hip, opt):
     """Default mode with missing genotypes: the plain phased planes decide the pairs without missing data (fused), the
     masked unphased planes the rest (through C as before); single tiles run both passes into one survivor buffer."""
     N, M = 1500, 1300
@@ -87,7 +87,7 @@ def test_fused_first_pass_of_default_mode_with_missing_data(hip, monkeypatch):
     for call in (lambda: hip.ld_all(T.MODE_AUTO, f), lambda: hip.ld_all(T.MODE_AUTO, f, window=T.OPT_R2_SCREEN),
                  lambda: hip.ld_tile(T.MODE_AUTO, 0, M, 0, M, True, f) + (0,),
                  lambda: hip.ld_tile(T.MODE_AUTO, 130, 300, 430, 513, False, f) + (0,)):      # (a rectangle next to the diagonal: LD lives there)
-        p, q, nf, _ = _both(hip, monkeypatch, call)
+        p, q, nf, _ = _both(hip, opt, call)
         assert nf > 0 and len(p[0]) > 20
         assert np.sort(p[0], order=ORDER).tobytes() == np.sort(q[0], order=ORDER).tobytes()
     sub = np.sort(np.random.default_rng(3).choice(M, size=230, replace=False))
@@ -98,7 +98,7 @@ def test_fused_first_pass_of_default_mode_with_missing_data(hip, monkeypatch):
     util.assert_records_match(got, want, variants[sub], double_root=util.double_root_vetter(data[sub], mask[sub], variants[sub], N))
 
 
-def test_fused_candidate_overflow_falls_back_to_the_plain_path(hip, monkeypatch):
+def test_fused_candidate_overflow_falls_back_to_the_plain_path(hip, opt):
     """The candidate list lives in the slot's count-matrix buffer (a third of the pairs fit).  Haplotype-block data
     with a cut-off just above the screen's floor puts most pairs on it: the tile is redone through C, the rest of the
     call runs plain, the records are the same."""
@@ -107,7 +107,7 @@ def test_fused_candidate_overflow_falls_back_to_the_plain_path(hip, monkeypatch)
     util.upload(hip, al)
     f = T.Filters(minR2=2e-6)
     for tile in (0, 256):
-        (p, _, _), (q, _, nr), nf, ncand = _both(hip, monkeypatch, lambda: hip.ld_all(T.MODE_PHASED, f, tile_variants=tile))
+        (p, _, _), (q, _, nr), nf, ncand = _both(hip, opt, lambda: hip.ld_all(T.MODE_PHASED, f, tile_variants=tile))
         assert nf >= 1 and ncand > M * (M - 1) // 2 // 3 or tile      # the first fused tile overflowed ...
         assert len(p) == nr > 0.6 * M * (M - 1) // 2                   # ... (most pairs survive this cut-off)
         assert np.sort(p, order=ORDER).tobytes() == np.sort(q, order=ORDER).tobytes()
@@ -117,18 +117,18 @@ def test_fused_candidate_overflow_falls_back_to_the_plain_path(hip, monkeypatch)
     assert hip.timing()["fused_launches"] > 0
 
 
-def test_fused_forced_on_long_rows(hip, monkeypatch):
-    """TWK_HIP_FUSED=2 (test hook): the fused form whatever the row length - N = 70,000 phased is 137 K-chunks per
+def test_fused_forced_on_long_rows(hip, opt):
+    """option "fused" = 2 (test hook): the fused form whatever the row length - N = 70,000 phased is 137 K-chunks per
     tile, which the default policy would split into units near the end of a launch."""
     N, M = 70_000, 400
     al = util.mosaic_alleles(M, N, 8, n_founders=6, switch=0.01, mut=0.001)
     util.upload(hip, al)
     f = T.Filters(minR2=0.3)
-    monkeypatch.setenv("TWK_HIP_FUSED", "1")
+    opt.set("fused", 1)
     hip.timing_reset()
     plain, _, _ = hip.ld_all(T.MODE_PHASED, f)
     assert hip.timing()["fused_launches"] == 0           # too long for the default policy
-    monkeypatch.setenv("TWK_HIP_FUSED", "2")
+    opt.set("fused", 2)
     hip.timing_reset()
     forced, _, _ = hip.ld_all(T.MODE_PHASED, f)
     assert hip.timing()["fused_launches"] > 0 and len(plain) > 50
@@ -182,7 +182,7 @@ def test_fisher_pipeline_agrees_with_the_oracle_in_any_order(hip):
 
 
 @pytest.mark.parametrize("N", [2504, 6000])
-def test_fisher_order_and_table_placement_do_not_change_a_record(hip, monkeypatch, N):
+def test_fisher_order_and_table_placement_do_not_change_a_record(hip, opt, N):
     """The records of a survivor-heavy call with the Fisher walks binned by length (default) and in the order the survivors
     were appended, with the log-factorial table in LDS (N <= 4,024) and in global memory: the same bytes."""
     M = 1500
@@ -192,18 +192,18 @@ def test_fisher_order_and_table_placement_do_not_change_a_record(hip, monkeypatc
     for mode in (T.MODE_PHASED, T.MODE_UNPHASED):
         base, _, _ = hip.ld_all(mode, f)
         assert len(base) > 2000 and (base["P"] < 1e-20).sum() > 100
-        for env in ({"TWK_HIP_FISHER_ORDER": "0"}, {"TWK_HIP_FISHER_LDS": "0"}, {"TWK_HIP_FISHER_ORDER": "0", "TWK_HIP_FISHER_LDS": "0"}):
+        for env in ({"fisher_order": 0}, {"fisher_lds": 0}, {"fisher_order": 0, "fisher_lds": 0}):
             for k, v in env.items():
-                monkeypatch.setenv(k, v)
+                opt.set(k, v)
             got, _, _ = hip.ld_all(mode, f)
             for k in env:
-                monkeypatch.delenv(k)
+                opt.unset(k)
             assert np.sort(base, order=ORDER).tobytes() == np.sort(got, order=ORDER).tobytes(), env
 
 
-@pytest.mark.parametrize("env", [{"TWK_HIP_SEG": "64"}, {"TWK_HIP_SEG": "32", "TWK_HIP_XCD_QUEUES": "8"}, {"TWK_HIP_XCD_QUEUES": "8"},
-                                 {"TWK_HIP_PATCH": "16x32", "TWK_HIP_SEG": "128", "TWK_HIP_XCD_QUEUES": "4"}])
-def test_count_kernel_work_orders_give_the_same_counts(hip, monkeypatch, env):
+@pytest.mark.parametrize("env", [{"seg": 64}, {"seg": 32, "xcd_queues": 8}, {"xcd_queues": 8},
+                                 {"patch_rows": 16, "patch_cols": 32, "seg": 128, "xcd_queues": 4}])
+def test_count_kernel_work_orders_give_the_same_counts(hip, opt, env):
     """The measured options of the count kernel's work order (K segments per patch, one unit queue per XCD,
     patch shape) are not the default, but they stay in the kernel: contingency cells bit-exact against the oracle and
     records equal to the default order's, on rows long enough for them to engage (N = 70,000 phased: 137 K-chunks)."""
@@ -212,11 +212,11 @@ def test_count_kernel_work_orders_give_the_same_counts(hip, monkeypatch, env):
     data, mask, variants = util.upload(hip, al)
     base, _, _ = hip.ld_all(T.MODE_PHASED, T.Filters(minR2=0.2))
     for k, v in env.items():
-        monkeypatch.setenv(k, v)
+        opt.set(k, v)
     cells = hip.count_tile(T.MODE_PHASED, 0, M, 0, M)
     got, _, _ = hip.ld_all(T.MODE_PHASED, T.Filters(minR2=0.2))
     for k in env:
-        monkeypatch.delenv(k)
+        opt.unset(k)
     rng = np.random.default_rng(2)
     for i, j in zip(rng.integers(0, M, 40), rng.integers(0, M, 40)):
         assert np.array_equal(cells[i, j], O.count_phased(data[i], None, data[j], None, N)), (i, j)
@@ -224,7 +224,7 @@ def test_count_kernel_work_orders_give_the_same_counts(hip, monkeypatch, env):
 
 
 @pytest.mark.parametrize("N", [64, 1000, 2504, 16_000, 50_000])
-def test_fused_unphased_equals_plain_and_oracle(hip, monkeypatch, N):
+def test_fused_unphased_equals_plain_and_oracle(hip, opt, N):
     """The unphased form (k_count_screen_unphased_t + k_ld_stats_list_unphased): a variant pair's four products are
     gathered from four lanes with DPP moves, the screen is the interval test on the admissible haplotype frequencies
     (UnphasedMath, ld_engine.cpp:1312-1560), candidates carry HH, HQ, QH, QQ.  `-u` on data without missing genotypes, with
@@ -237,7 +237,7 @@ def test_fused_unphased_equals_plain_and_oracle(hip, monkeypatch, N):
     for minR2 in (0.1, 0.6, 0.004):
         for opt in (0, T.OPT_R2_SCREEN):
             f = T.Filters(minR2=minR2)
-            (p, np0, _), (q, np1, nr1), nf, ncand = _both(hip, monkeypatch, lambda: hip.ld_all(mode, f, window=opt))
+            (p, np0, _), (q, np1, nr1), nf, ncand = _both(hip, opt, lambda: hip.ld_all(mode, f, window=opt))
             assert nf > 0 and np0 == np1 == M * (M - 1) // 2 and nr1 == len(q) == len(p) > 20
             assert ncand >= len(q) or minR2 < 0.01                 # (at 0.004 the list may overflow and the tile be redone plain)
             assert ncand < 0.5 * np1 or minR2 < 0.05
@@ -247,19 +247,19 @@ def test_fused_unphased_equals_plain_and_oracle(hip, monkeypatch, N):
     for x in r2[:: max(1, len(r2) // 4)][:4]:
         for cut in (np.nextafter(x, 0.0), x, np.nextafter(x, 1.0)):
             f = T.Filters(minR2=float(cut))
-            (p, _, _), (q, _, _), nf, _ = _both(hip, monkeypatch, lambda: hip.ld_all(mode, f))
+            (p, _, _), (q, _, _), nf, _ = _both(hip, opt, lambda: hip.ld_all(mode, f))
             assert nf > 0 and np.sort(p, order=ORDER).tobytes() == np.sort(q, order=ORDER).tobytes()
     f = T.Filters(minR2=0.1)
-    (p, np0, _), (q, np1, _), nf, _ = _both(hip, monkeypatch, lambda: hip.ld_all(mode, f, window=T.OPT_WINDOW, l_window=30_000))
+    (p, np0, _), (q, np1, _), nf, _ = _both(hip, opt, lambda: hip.ld_all(mode, f, window=T.OPT_WINDOW, l_window=30_000))
     assert nf > 0 and np0 == np1 and len(p) > 20 and np.sort(p, order=ORDER).tobytes() == np.sort(q, order=ORDER).tobytes()
     parts = [hip.ld_all(mode, f, part=k, n_parts=3) for k in range(3)]
     whole, _, _ = hip.ld_all(mode, f)
     assert np.sort(np.concatenate([x[0] for x in parts]), order=ORDER).tobytes() == np.sort(whole, order=ORDER).tobytes()
-    (p, _, _), (q, _, _), nf, _ = _both(hip, monkeypatch, lambda: hip.ld_all(mode, f, tile_variants=256))
+    (p, _, _), (q, _, _), nf, _ = _both(hip, opt, lambda: hip.ld_all(mode, f, tile_variants=256))
     assert nf > 3 and np.sort(p, order=ORDER).tobytes() == np.sort(q, order=ORDER).tobytes()
     # odd tile origins through the single-tile entry point (plane rows start even whatever the variant index)
     for a0, nA, b0, nB, diag in ((0, M, 0, M, True), (3, M // 5 + 1, M // 4 + 2, M // 3 + 11, False), (129, 200, 129, 333, True)):
-        (p, _), (q, _), nf, _ = _both(hip, monkeypatch, lambda: hip.ld_tile(mode, a0, nA, b0, nB, diag, f))
+        (p, _), (q, _), nf, _ = _both(hip, opt, lambda: hip.ld_tile(mode, a0, nA, b0, nB, diag, f))
         assert nf > 0 and np.sort(p, order=ORDER).tobytes() == np.sort(q, order=ORDER).tobytes()
     sub = np.sort(np.random.default_rng(N).choice(M, size=220, replace=False))
     hip.set_problem(N, len(sub))
@@ -272,7 +272,7 @@ def test_fused_unphased_equals_plain_and_oracle(hip, monkeypatch, N):
 
 
 @pytest.mark.parametrize("mode", [T.MODE_PHASED, T.MODE_UNPHASED])
-def test_fused_tiles_that_end_inside_a_block_tile(hip, monkeypatch, mode):
+def test_fused_tiles_that_end_inside_a_block_tile(hip, opt, mode):
     """Tiles whose variant counts are not multiples of the 128-row block tile, in the middle of an LD-rich matrix: the
     columns (and rows) of the last block tile that lie beyond the tile's own variants belong to other tiles and must not
     become candidates (found by the overflow path, which cuts a tile into one-row strips)."""
@@ -281,20 +281,20 @@ def test_fused_tiles_that_end_inside_a_block_tile(hip, monkeypatch, mode):
     util.upload(hip, al)
     f = T.Filters(minR2=0.3)
     for a0, nA, b0, nB, diag in ((265, 1, 265, 1, True), (265, 1, 266, 100, False), (100, 70, 100, 200, True), (300, 129, 429, 131, False), (5, 3, 400, 2, False)):
-        (p, np0), (q, np1), nf, _ = _both(hip, monkeypatch, lambda: hip.ld_tile(mode, a0, nA, b0, nB, diag, f))
+        (p, np0), (q, np1), nf, _ = _both(hip, opt, lambda: hip.ld_tile(mode, a0, nA, b0, nB, diag, f))
         assert np0 == np1 and np.sort(p, order=ORDER).tobytes() == np.sort(q, order=ORDER).tobytes(), (a0, nA, b0, nB)
         assert len(q) == 0 or ((q["idxA"] >= a0) & (q["idxA"] < a0 + nA) & (q["idxB"] >= b0) & (q["idxB"] < b0 + nB)).all()
     assert len(hip.ld_tile(mode, 100, 70, 100, 200, True, f)[0]) > 100
     # and the whole run with a survivor buffer that overflows everywhere (strips of one row)
     whole, _, _ = hip.ld_all(mode, f)
-    monkeypatch.setenv("TWK_HIP_RECORD_CAP", "300")
+    opt.set("record_cap", 300)
     strips, _, nrec = hip.ld_all(mode, f)
-    monkeypatch.delenv("TWK_HIP_RECORD_CAP")
+    opt.unset("record_cap")
     assert nrec == len(whole) > 5000 and np.sort(whole, order=ORDER).tobytes() == np.sort(strips, order=ORDER).tobytes()
 
 
 @pytest.mark.parametrize("N", [10, 40, 656, 752, 1100, 2504, 100_010])
-def test_padding_behind_the_last_chunk_is_skipped_without_changing_a_count(hip, monkeypatch, N):
+def test_padding_behind_the_last_chunk_is_skipped_without_changing_a_count(hip, opt, N):
     """Rows are padded to whole 32-word K-chunks; the contraction of a row's last chunk stops at the last half-slot
     (2 words) that carries data (CountWork::last_halves).  The sample counts cover 1..15 live half-slots in both
     layouts (2N bits phased, N bits unphased), with and without missing genotypes (the mask planes are padded alike):
@@ -305,10 +305,10 @@ def test_padding_behind_the_last_chunk_is_skipped_without_changing_a_count(hip, 
         data, mask, variants = util.upload(hip, al)
         rng = np.random.default_rng(N)
         for mode, count in ((T.MODE_PHASED, O.count_phased), (T.MODE_UNPHASED, O.count_unphased)):
-            monkeypatch.setenv("TWK_HIP_SKIP_PAD", "0")
+            opt.set("skip_pad", 0)
             full = hip.count_tile(mode, 0, M, 0, M)
             rec_full, _, _ = hip.ld_all(mode, T.Filters(minR2=0.1))
-            monkeypatch.delenv("TWK_HIP_SKIP_PAD")
+            opt.unset("skip_pad")
             cells = hip.count_tile(mode, 0, M, 0, M)
             assert np.array_equal(cells, full)
             for i, j in zip(rng.integers(0, M, 60), rng.integers(0, M, 60)):
@@ -316,14 +316,14 @@ def test_padding_behind_the_last_chunk_is_skipped_without_changing_a_count(hip, 
                 mj = mask[j] if mask is not None and variants["gt_missing"][j] else None
                 assert np.array_equal(cells[i, j], count(data[i], mi, data[j], mj, N)), (mode, i, j)
             for fused in ("0", "1"):
-                monkeypatch.setenv("TWK_HIP_FUSED", fused)
+                opt.set("fused", int(fused))
                 rec, _, _ = hip.ld_all(mode, T.Filters(minR2=0.1))
-                monkeypatch.delenv("TWK_HIP_FUSED")
+                opt.unset("fused")
                 assert len(rec) > 10 and np.sort(rec, order=ORDER).tobytes() == np.sort(rec_full, order=ORDER).tobytes()
 
 
 @pytest.mark.parametrize("mode", [T.MODE_PHASED, T.MODE_UNPHASED])
-def test_candidate_slot_windows_of_any_size_give_the_same_records(hip, monkeypatch, mode):
+def test_candidate_slot_windows_of_any_size_give_the_same_records(hip, opt, mode):
     """A wave of the fused kernels reserves candidate slots several tiles ahead (ScreenWork::chunk) and marks what it does not
     use; the list kernels skip marked slots.  One atomic per wave and tile (0), tiny windows (3), the default and windows far
     larger than any tile needs (100,000: most of the list is unused slots, and the list overflows where it is short - the
@@ -332,20 +332,20 @@ def test_candidate_slot_windows_of_any_size_give_the_same_records(hip, monkeypat
     al = _cohort_alleles(M, N, 4242)
     util.upload(hip, al)
     f = T.Filters(minR2=0.05)
-    monkeypatch.setenv("TWK_HIP_FUSED", "0")
+    opt.set("fused", 0)
     base, _, _ = hip.ld_all(mode, f, window=T.OPT_WINDOW, l_window=60_000)
-    monkeypatch.setenv("TWK_HIP_FUSED", "1")
+    opt.set("fused", 1)
     assert len(base) > 5000
     for chunk in ("0", "3", None, "700", "100000"):
         if chunk is None:
-            monkeypatch.delenv("TWK_HIP_CAND_CHUNK", raising=False)
+            opt.unset("cand_chunk")
         else:
-            monkeypatch.setenv("TWK_HIP_CAND_CHUNK", chunk)
+            opt.set("cand_chunk", int(chunk))
         for tv in (0, 256):
             hip.timing_reset()
             got, _, _ = hip.ld_all(mode, f, window=T.OPT_WINDOW, l_window=60_000, tile_variants=tv)
             tm = hip.timing()
             assert tm["fused_launches"] > 0 and tm["candidates"] >= len(got), (chunk, tv)
             assert np.sort(base, order=ORDER).tobytes() == np.sort(got, order=ORDER).tobytes(), (chunk, tv)
-    monkeypatch.delenv("TWK_HIP_CAND_CHUNK", raising=False)
-    monkeypatch.delenv("TWK_HIP_FUSED")
+    opt.unset("cand_chunk")
+    opt.unset("fused")

@@ -186,8 +186,15 @@ def test_cli_window_mode(tmp_path):
     assert 0 < len(win) < len(whole) and np.array_equal(key(win), key(sel))
 
 
+def _env_and_engine_options(extra):
+    """Keys "opt:<key>" are engine switches and go on the command line (--engine-option key=value: the libraries read
+    no switch from the environment); the rest is environment (TWK_HIP_GPUS / TWK_HIP_PART / TWK_REF_COMPAT)."""
+    opts = [a for k, v in extra.items() if k.startswith("opt:") for a in ("--engine-option", f"{k[4:]}={v}")]
+    return dict(os.environ, **{k: v for k, v in extra.items() if not k.startswith("opt:")}), opts
+
+
 def test_cli_multi_gpu_driver_threads_equal_single(tmp_path):
-    """TWK_HIP_GPUS=n: one driver thread and one engine context per GPU (here all on GPU 0), one shared
+    """TWK_HIP_GPUS=n: one driver thread and one engine context per GPU (here all on GPU 0: --engine-option force_device=0), one shared
     writer; TWK_HIP_PART=k/n: this process's share of a multi-node run, merged with concat."""
     N, M = 80, 500
     al = util.random_alleles(M, N, 77, miss_rate=0.05, miss_variants=0.2)
@@ -195,11 +202,11 @@ def test_cli_multi_gpu_driver_threads_equal_single(tmp_path):
     twk = str(tmp_path / "in.twk")
     hostlib.write_twk(twk, al, pos, np.zeros(M, np.uint32), np.ones(M, np.uint8), block_size=50)
     def run(env_extra, out, extra=()):
-        env = dict(os.environ, **env_extra)
-        r = subprocess.run([hostlib.CLI_PATH, "calc", "-i", twk, "-o", out, "-r", "0.02"] + list(extra), capture_output=True, text=True, env=env)
+        env, opts = _env_and_engine_options(env_extra)
+        r = subprocess.run([hostlib.CLI_PATH, "calc", "-i", twk, "-o", out, "-r", "0.02"] + opts + list(extra), capture_output=True, text=True, env=env)
         assert r.returncode == 0, r.stderr
         return hostlib.two_as_matrix(hostlib.read_two(out)[0]), r.stderr
-    whole, log0 = run({"TWK_HIP_PROGRESS_SECONDS": "0"}, str(tmp_path / "w.two"))
+    whole, log0 = run({"opt:progress_ms": "0"}, str(tmp_path / "w.two"))
     prog = [l for l in log0.splitlines() if "[PROGRESS]" in l]
     assert "Time elapsed" in prog[0] and "Est. Time left" in prog[0] and "%" in prog[1]          # ticker lines (ld_progress.h:48-75)
     key = lambda m: m[np.lexsort((m[:, 4], m[:, 2]))]
@@ -207,14 +214,14 @@ def test_cli_multi_gpu_driver_threads_equal_single(tmp_path):
     for mode in ((), ("-u",), ("-p",)):
         one, _ = run({}, str(tmp_path / "one.two"), mode)
         # three contexts; every one is pinned to device 0 because the box has one GPU
-        multi, log = run({"TWK_HIP_GPUS": "3", "TWK_HIP_FORCE_DEVICE": "0", "TWK_HIP_PROGRESS_SECONDS": "0"}, str(tmp_path / "m.two"), mode)
+        multi, log = run({"TWK_HIP_GPUS": "3", "opt:force_device": "0", "opt:progress_ms": "0"}, str(tmp_path / "m.two"), mode)
         assert len(one) > 0 and np.array_equal(key(one), key(multi))
         assert "Using 3 GPUs" in log and "GPU 2: count kernel" in log
     # farm mode: two processes x two GPUs each = four shards, outputs merged with concat
     parts = []
     for k in range(2):
         out = str(tmp_path / f"farm{k}.two")
-        run({"TWK_HIP_GPUS": "2", "TWK_HIP_FORCE_DEVICE": "0", "TWK_HIP_PART": f"{k}/2"}, out)
+        run({"TWK_HIP_GPUS": "2", "opt:force_device": "0", "TWK_HIP_PART": f"{k}/2"}, out)
         parts.append(out)
     cat = str(tmp_path / "cat.two")
     r = subprocess.run([hostlib.CLI_PATH, "concat", "-i", parts[0], "-i", parts[1], "-o", cat], capture_output=True, text=True)
@@ -240,20 +247,21 @@ def test_cli_window_mode_slabs_per_gpu(tmp_path):
     hostlib.write_twk(twk, al, pos, rid, np.ones(M, np.uint8), n_contigs=len(sizes), block_size=37)
     key = lambda m: m[np.lexsort((m[:, 4], m[:, 3], m[:, 2], m[:, 1]))]
     def run(env_extra, out, extra):
-        r = subprocess.run([hostlib.CLI_PATH, "calc", "-i", twk, "-o", out, "-r", "0.05", "-w", "2500"] + list(extra), capture_output=True,
-                           text=True, env=dict(os.environ, **env_extra))
+        env, opts = _env_and_engine_options(env_extra)
+        r = subprocess.run([hostlib.CLI_PATH, "calc", "-i", twk, "-o", out, "-r", "0.05", "-w", "2500"] + opts + list(extra), capture_output=True,
+                           text=True, env=env)
         assert r.returncode == 0, r.stderr
         return key(hostlib.two_as_matrix(hostlib.read_two(out)[0])), r.stderr
     for mode in ((), ("-u",), ("-p",)):
         one, _ = run({}, str(tmp_path / "one.two"), mode)
-        multi, log = run({"TWK_HIP_GPUS": "4", "TWK_HIP_FORCE_DEVICE": "0"}, str(tmp_path / "m.two"), mode)
+        multi, log = run({"TWK_HIP_GPUS": "4", "opt:force_device": "0"}, str(tmp_path / "m.two"), mode)
         assert len(one) > 2000 and np.array_equal(one, multi)
         halos = [int(l.split("+ ")[1].split(" halo")[0]) for l in log.splitlines() if "halo variants" in l]
         assert len(halos) == 4 and max(halos) <= 3 * 37 + 50 and "GPU 3: rows = variants" in log        # a window of 50 variants: <= 2-3 blocks of halo
     parts = []
     for k in range(2):
         out = str(tmp_path / f"farm{k}.two")
-        run({"TWK_HIP_GPUS": "2", "TWK_HIP_FORCE_DEVICE": "0", "TWK_HIP_PART": f"{k}/2"}, out, ())
+        run({"TWK_HIP_GPUS": "2", "opt:force_device": "0", "TWK_HIP_PART": f"{k}/2"}, out, ())
         parts.append(out)
     cat = str(tmp_path / "cat.two")
     r = subprocess.run([hostlib.CLI_PATH, "concat", "-i", parts[0], "-i", parts[1], "-o", cat], capture_output=True, text=True)
@@ -263,7 +271,7 @@ def test_cli_window_mode_slabs_per_gpu(tmp_path):
     # TWK_REF_COMPAT window filter composes with the slabs (forced mode) and switches them off where it must (default mode)
     for mode in (("-u",), ()):
         one, _ = run({"TWK_REF_COMPAT": "1"}, str(tmp_path / "c1.two"), mode)
-        multi, _ = run({"TWK_REF_COMPAT": "1", "TWK_HIP_GPUS": "3", "TWK_HIP_FORCE_DEVICE": "0"}, str(tmp_path / "c3.two"), mode)
+        multi, _ = run({"TWK_REF_COMPAT": "1", "TWK_HIP_GPUS": "3", "opt:force_device": "0"}, str(tmp_path / "c3.two"), mode)
         assert len(one) > 0 and np.array_equal(one, multi)
 
 

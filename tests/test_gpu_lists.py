@@ -25,8 +25,8 @@ def _with_flips(al, seed):
     return al
 
 
-def _run(hip, monkeypatch, lists_env, data, mask, variants, calls):
-    monkeypatch.setenv("TWK_HIP_LISTS", lists_env)
+def _run(hip, opt, lists_env, data, mask, variants, calls):
+    opt.set("lists", int(lists_env))
     N = variants_n = None
     hip.set_problem(_run.N, len(variants))
     hip.upload(data, util.to_hip_meta(variants), mask)
@@ -35,13 +35,13 @@ def _run(hip, monkeypatch, lists_env, data, mask, variants, calls):
         hip.timing_reset()
         recs = call()
         out.append((recs, hip.timing()))
-    monkeypatch.delenv("TWK_HIP_LISTS")
+    opt.unset("lists")
     return out
 
 
 @pytest.mark.parametrize("N,forced", [(66_000, False), (1500, True)])
-def test_list_zone_equals_dense_and_oracle(hip, monkeypatch, N, forced):
-    """N = 66,000: rows of 4,128 words, lists of up to 32 carriers are kept by default.  N = 1,500 with TWK_HIP_LISTS=2:
+def test_list_zone_equals_dense_and_oracle(hip, opt, N, forced):
+    """N = 66,000: rows of 4,128 words, lists of up to 32 carriers are kept by default.  N = 1,500 with option "lists" = 2:
     the list pass next to the fused count kernel (short rows), whose epilogue must leave the zone's pairs alone."""
     M = 1500 if not forced else 2200
     al = _with_flips(_cohort_alleles(M, N, 900 + N), 5)
@@ -53,8 +53,8 @@ def test_list_zone_equals_dense_and_oracle(hip, monkeypatch, N, forced):
              lambda: hip.ld_all(T.MODE_PHASED, T.Filters(minR2=0.004), window=T.OPT_R2_SCREEN)[0],
              lambda: np.concatenate([hip.ld_all(T.MODE_PHASED, T.Filters(minR2=0.1), part=k, n_parts=3, window=T.OPT_R2_SCREEN)[0] for k in range(3)]),
              lambda: hip.ld_all(T.MODE_PHASED, T.Filters(minR2=0.1, minP=1e-8), window=T.OPT_R2_SCREEN)[0]]
-    dense = _run(hip, monkeypatch, "0", data, None, variants, calls)
-    lists = _run(hip, monkeypatch, "2" if forced else "1", data, None, variants, calls)
+    dense = _run(hip, opt, "0", data, None, variants, calls)
+    lists = _run(hip, opt, "2" if forced else "1", data, None, variants, calls)
     for k, ((a, ta), (b, tb)) in enumerate(zip(dense, lists)):
         assert ta["list_launches"] == 0 and tb["list_launches"] > 0 and tb["list_pairs"] > 10_000, (k, tb)
         assert len(a) == len(b) > 20, k
@@ -65,19 +65,19 @@ def test_list_zone_equals_dense_and_oracle(hip, monkeypatch, N, forced):
     ac = np.minimum(variants["ac"], 2 * N - variants["ac"])
     rare = np.argsort(ac, kind="stable")[:300]          # (a zone needs two tiles of variants: 256)
     sub = np.sort(np.concatenate([rare, np.random.default_rng(1).choice(np.setdiff1d(np.arange(M), rare), size=60, replace=False)]))
-    monkeypatch.setenv("TWK_HIP_LISTS", "2")
+    opt.set("lists", 2)
     hip.set_problem(N, len(sub))
     hip.upload(data[sub], util.to_hip_meta(variants[sub]), None)
     hip.timing_reset()
     got, _, _ = hip.ld_all(T.MODE_PHASED, T.Filters(minR2=0.05), window=T.OPT_R2_SCREEN)
     assert hip.timing()["list_launches"] > 0
-    monkeypatch.delenv("TWK_HIP_LISTS")
+    opt.unset("lists")
     want = O.all_pairs(data[sub], None, variants[sub], N, O.settings(minR2=0.05, phased=True), vector_only=False)
     assert len(want) > 20
     util.assert_records_match(got, want, variants[sub])
 
 
-def test_list_zone_with_missing_data_in_default_mode(hip, monkeypatch):
+def test_list_zone_with_missing_data_in_default_mode(hip, opt):
     """Default mode with missing genotypes: the screened stage runs over the missing-free head of the sorted set - lists
     there - and the variants with missing data go through the masked unphased planes as before."""
     N, M = 66_000, 1900
@@ -86,14 +86,14 @@ def test_list_zone_with_missing_data_in_default_mode(hip, monkeypatch):
     variants = O.variants_from_alleles(al)
     _run.N = N
     calls = [lambda: hip.ld_all(T.MODE_AUTO, T.Filters(minR2=0.2), window=T.OPT_R2_SCREEN)[0]]
-    (a, ta), = _run(hip, monkeypatch, "0", data, mask, variants, calls)
-    (b, tb), = _run(hip, monkeypatch, "1", data, mask, variants, calls)
+    (a, ta), = _run(hip, opt, "0", data, mask, variants, calls)
+    (b, tb), = _run(hip, opt, "1", data, mask, variants, calls)
     assert tb["list_launches"] > 0 and ta["list_launches"] == 0 and len(a) == len(b) > 20
     assert np.sort(a, order=ORDER).tobytes() == np.sort(b, order=ORDER).tobytes()
 
 
-def test_list_pass_with_a_tiny_survivor_buffer(hip, monkeypatch):
-    """TWK_HIP_RECORD_CAP (test hook) makes every buffer overflow: the list pass then takes fewer rows per launch, down to one
+def test_list_pass_with_a_tiny_survivor_buffer(hip, opt):
+    """option "record_cap" (test hook) makes every buffer overflow: the list pass then takes fewer rows per launch, down to one
     row with a buffer grown to the zone's width, and the dense tiles go through their strip redo - the same records."""
     N, M = 1500, 1600
     al = _cohort_alleles(M, N, 33)
@@ -101,16 +101,16 @@ def test_list_pass_with_a_tiny_survivor_buffer(hip, monkeypatch):
     variants = O.variants_from_alleles(al)
     _run.N = N
     calls = [lambda: hip.ld_all(T.MODE_PHASED, T.Filters(minR2=0.05), window=T.OPT_R2_SCREEN)[0]]
-    (a, ta), = _run(hip, monkeypatch, "2", data, None, variants, calls)
-    monkeypatch.setenv("TWK_HIP_RECORD_CAP", "40")
-    (b, tb), = _run(hip, monkeypatch, "2", data, None, variants, calls)
-    monkeypatch.delenv("TWK_HIP_RECORD_CAP")
+    (a, ta), = _run(hip, opt, "2", data, None, variants, calls)
+    opt.set("record_cap", 40)
+    (b, tb), = _run(hip, opt, "2", data, None, variants, calls)
+    opt.unset("record_cap")
     assert ta["list_launches"] > 0 and tb["list_launches"] > ta["list_launches"] and len(a) == len(b) > 500
     assert np.sort(a, order=ORDER).tobytes() == np.sort(b, order=ORDER).tobytes()
 
 
 @pytest.mark.parametrize("N,forced", [(66_000, False), (1500, True)])
-def test_unphased_list_zone_equals_dense_and_oracle(hip, monkeypatch, N, forced):
+def test_unphased_list_zone_equals_dense_and_oracle(hip, opt, N, forced):
     """`-u`: the lists hold samples with their genotype (het / rare homozygote), the merge sorts common samples into four
     counters, HH / HQ / QH / QQ follow by which of the two variants has ALT as its major allele; candidates go through the
     unphased list math kernel.  Same checks as the phased zone, incl. variants turned into their complements."""
@@ -124,8 +124,8 @@ def test_unphased_list_zone_equals_dense_and_oracle(hip, monkeypatch, N, forced)
              lambda: hip.ld_all(mode, T.Filters(minR2=0.5), window=T.OPT_R2_SCREEN)[0],
              lambda: hip.ld_all(mode, T.Filters(minR2=0.01), window=T.OPT_R2_SCREEN)[0],
              lambda: np.concatenate([hip.ld_all(mode, T.Filters(minR2=0.1), part=k, n_parts=3, window=T.OPT_R2_SCREEN)[0] for k in range(3)])]
-    dense = _run(hip, monkeypatch, "0", data, None, variants, calls)
-    lists = _run(hip, monkeypatch, "2" if forced else "1", data, None, variants, calls)
+    dense = _run(hip, opt, "0", data, None, variants, calls)
+    lists = _run(hip, opt, "2" if forced else "1", data, None, variants, calls)
     for k, ((a, ta), (b, tb)) in enumerate(zip(dense, lists)):
         assert ta["list_launches"] == 0 and tb["list_launches"] > 0 and tb["list_pairs"] > 10_000, (k, tb)
         assert len(a) == len(b) > 20, k
@@ -133,13 +133,13 @@ def test_unphased_list_zone_equals_dense_and_oracle(hip, monkeypatch, N, forced)
     ac = np.minimum(variants["ac"], 2 * N - variants["ac"])
     rare = np.argsort(ac, kind="stable")[:300]
     sub = np.sort(np.concatenate([rare, np.random.default_rng(2).choice(np.setdiff1d(np.arange(M), rare), size=60, replace=False)]))
-    monkeypatch.setenv("TWK_HIP_LISTS", "2")
+    opt.set("lists", 2)
     hip.set_problem(N, len(sub))
     hip.upload(data[sub], util.to_hip_meta(variants[sub]), None)
     hip.timing_reset()
     got, _, _ = hip.ld_all(mode, T.Filters(minR2=0.05), window=T.OPT_R2_SCREEN)
     assert hip.timing()["list_launches"] > 0
-    monkeypatch.delenv("TWK_HIP_LISTS")
+    opt.unset("lists")
     want = O.all_pairs(data[sub], None, variants[sub], N, O.settings(minR2=0.05, unphased=True), vector_only=False)
     assert len(want) > 20
     util.assert_records_match(got, want, variants[sub], n_samples=N, double_root=util.double_root_vetter(data[sub], None, variants[sub], N))

@@ -215,7 +215,7 @@ def test_overflow_is_reported_and_recovered(hip):
     assert npairs == M * (M - 1) // 2 and len(recs) > 10
 
 
-def test_ld_all_recovers_from_survivor_overflow(hip, monkeypatch):
+def test_ld_all_recovers_from_survivor_overflow(hip, opt):
     """Dense output larger than the device record buffer: the tile is redone in row strips."""
     N, M = 64, 333
     al = util.random_alleles(M, N, 52)
@@ -223,13 +223,13 @@ def test_ld_all_recovers_from_survivor_overflow(hip, monkeypatch):
     f = T.Filters(minR2=0.0)
     whole, npairs, nrec = hip.ld_all(T.MODE_PHASED, f)
     for cap in ("1000", "777", "50000"):
-        monkeypatch.setenv("TWK_HIP_RECORD_CAP", cap)
+        opt.set("record_cap", int(cap))
         got, np2, nrec2 = hip.ld_all(T.MODE_PHASED, f, tile_variants=256)
         assert np2 == npairs and nrec2 == nrec == len(got)
         key = lambda r: np.lexsort((r["idxB"], r["idxA"]))
         a, b = whole[key(whole)], got[key(got)]
         assert np.array_equal(a["idxA"], b["idxA"]) and np.array_equal(a["idxB"], b["idxB"]) and np.array_equal(a["R2"], b["R2"])
-    monkeypatch.delenv("TWK_HIP_RECORD_CAP")
+    opt.unset("record_cap")
 
 
 @pytest.mark.parametrize("N,M", [(1, 2), (3, 5), (64, 1), (31, 129)])

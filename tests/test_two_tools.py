@@ -88,10 +88,9 @@ def test_sort_properties_and_external_merge(tmp_path, monkeypatch):
         assert ridB == (blk["ridB"][0] if (blk["ridB"] == blk["ridB"][0]).all() else -1)
     for rid in range(4):
         assert ctg[rid, 0] == rid and ctg[rid, 1] == (sa["ridA"] == rid).sum() and ctg[rid, 4] == (ent[:, 0] == rid).sum()
-    # external path: runs of <= 9000 records, merged
-    monkeypatch.setenv("TWK_SORT_RUN_RECORDS", "9000")
+    # external path: a memory limit of a few kilobytes makes runs of <= 1000 records (the floor), merged
     b = str(tmp_path / "b.two")
-    H.sort_two(src, b, n_threads=2)
+    H.sort_two(src, b, memory_limit_gb=1e-6, n_threads=2)
     sb, _ = H.read_two(b)
     assert sa.tobytes() == sb.tobytes()
     assert np.array_equal(H.two_index(b)[1], ent)

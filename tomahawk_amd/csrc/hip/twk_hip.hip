@@ -91,8 +91,38 @@ struct ColRange { const uint32_t* lo = nullptr; const uint32_t* hi = nullptr; ui
 
 }  // namespace
 
+namespace {
+// Measurement and test switches (twk_hip_set_option): what used to be TWK_HIP_* environment variables.  The library
+// reads no environment variable; a host that embeds it gets the defaults below unless it says otherwise.
+struct Options {
+	long long lists = 1;             // carrier lists for the rare head of the sorted sets: 0 never, 1 rows of >= 4096 words, 2 always (>= 8 carriers)
+	long long list_max = 0;          // longest carrier list kept (0: W / 128 phased, W / 64 unphased)
+	long long patch_rows = 8, patch_cols = 8;      // shape of a patch of tiles in the count kernel's work order
+	long long count_min_chunks = 8;  // shortest K range a tile is split into
+	long long fused = 1;             // fused count -> screen kernel: 0 never, 1 rows of <= FUSED_MAX_CHUNKS chunks, 2 always
+	long long seg = 0;               // walk a patch in K segments of this many chunks (0: whole tiles)
+	long long xcd_queues = 0;        // one unit queue per XCD (2..8; 0: one queue)
+	long long skip_pad = 1;          // do not contract the zero padding behind a row's last live half-slot
+	long long fisher_order = 1;      // Fisher walks in the order of their length
+	long long fisher_lds = 1;        // log-factorial table in LDS while it fits
+	long long cand_chunk = -1;       // candidate slots a wave reserves at a time (-1: sized from the list)
+	long long record_cap = 0;        // cap on the survivor buffer of a launch (0: none): forces the overflow / strip path
+};
+struct OptionKey { const char* name; long long Options::* field; long long lo, hi; bool rebuilds_planes; };
+const OptionKey OPTION_KEYS[] = {
+	{"lists", &Options::lists, 0, 2, true}, {"list_max", &Options::list_max, 0, 60000, true},
+	{"patch_rows", &Options::patch_rows, 1, 4096, false}, {"patch_cols", &Options::patch_cols, 1, 4096, false},
+	{"count_min_chunks", &Options::count_min_chunks, 1, 1 << 20, false}, {"fused", &Options::fused, 0, 2, false},
+	{"seg", &Options::seg, 0, 1 << 20, false}, {"xcd_queues", &Options::xcd_queues, 0, 8, false},
+	{"skip_pad", &Options::skip_pad, 0, 1, false}, {"fisher_order", &Options::fisher_order, 0, 1, false},
+	{"fisher_lds", &Options::fisher_lds, 0, 1, false}, {"cand_chunk", &Options::cand_chunk, -1, 1 << 20, false},
+	{"record_cap", &Options::record_cap, 0, 1ll << 40, false},
+};
+}  // namespace
+
 struct twk_hip_ctx {
 	int device = 0;
+	Options opt;
 	hipStream_t s_compute = nullptr, s_copy = nullptr;
 	uint32_t N = 0, M = 0, M_alloc = 0;
 	uint32_t Wp = 0, Wu = 0;       // padded words per row: raw (2N bits) / unphased planes (N bits)
@@ -269,13 +299,12 @@ int ensure_planes(twk_hip_ctx* c, int set) {
 		// two lists, i.e. for long rows only.  list_max = (phased row words) / 128 carriers for PhasedMath (the measured
 		// break-even is ~W / 150 merge steps per side, profiles/r03_t2_list_vs_dense.txt) and twice that for UnphasedMath (a
 		// dense unphased pair costs twice a phased one, a merge over samples about the same), and not below 32 - rows
-		// shorter than 4096 words (N < 65,536) keep no lists.  TWK_HIP_LISTS=0: never; =2: always, with at least 8 carriers
-		// (test hook); TWK_HIP_LIST_MAX=n: the limit itself (measurement hook).
-		const char* le = std::getenv("TWK_HIP_LISTS");
-		const int lists_env = le ? std::atoi(le) : 1;
+		// shorter than 4096 words (N < 65,536) keep no lists.  Option "lists" = 0: never; 2: always, with at least 8 carriers
+		// (test hook); "list_max" = n: the limit itself (measurement hook).
+		const int lists_env = (int)c->opt.lists;
 		uint32_t lmax = c->Wp / (set == PS_SORTED_U ? 64 : 128);      // measured optimum at N = 1 M: 488 / 976 carriers (profiles/r03_list_max_sweep.txt)
 		if (lists_env == 2) lmax = std::max<uint32_t>(lmax, 8);
-		if (const char* lm = std::getenv("TWK_HIP_LIST_MAX")) { const unsigned long v = std::strtoul(lm, nullptr, 10); if (v >= 8 && v <= 60000) lmax = (uint32_t)v; }   // measurement hook (the unphased merge counts in 16 bits)
+		if (c->opt.list_max >= 8) lmax = (uint32_t)c->opt.list_max;      // measurement hook (<= 60000: the unphased merge counts in 16 bits)
 		if (lists_env != 0 && (c->Wp / 128 >= 32 || lists_env == 2)) {
 			const uint64_t T2 = 2ull * c->N;
 			uint32_t n = 0;                                  // variants of the missing-free head with a minor allele count <= lmax
@@ -353,7 +382,7 @@ Geometry tile_geometry(int P, const twk_hip_tile_desc& t) {
 // Order: 8 x 8 patches of tiles, patch by patch - the blocks pull consecutive tickets, so the ~P tiles in
 // flight at any time are a few neighbouring patches (shared row / column tiles meet in L2 and the MALL).
 void build_tile_list(const twk_hip_tile_desc& t, int P, const Geometry& g, bool diag, const ColRange* cr,
-                     std::vector<uint32_t>& out, std::vector<uint32_t>* patch_end = nullptr) {
+                     std::vector<uint32_t>& out, std::vector<uint32_t>* patch_end = nullptr, uint32_t PR = 8, uint32_t PC = 8) {
 	std::vector<uint32_t> x0(g.gy, 0), x1(g.gy, g.gx);
 	for (uint32_t by = 0; by < g.gy; ++by) {
 		if (diag) x0[by] = by;
@@ -384,12 +413,7 @@ void build_tile_list(const twk_hip_tile_desc& t, int P, const Geometry& g, bool 
 	// are spread over eight L2s by the dispatcher, so fewer distinct row tiles in flight buys nothing per L2.  What does
 	// help is giving each XCD its own patches (TWK_HIP_XCD_QUEUES=8 with 64-chunk segments: 149 GB, -42 %), at +0.5 % kernel
 	// time for the adds into C; since the kernel is VALU-bound and the fabric sees < 10 % of its rate either way, that
-	// trade is not taken by default.  (TWK_HIP_PATCH=RxC / TWK_HIP_SEG / TWK_HIP_XCD_QUEUES are the hooks of that measurement.)
-	uint32_t PR = 8, PC = 8;
-	if (const char* e = std::getenv("TWK_HIP_PATCH")) {
-		unsigned r = 0, cc = 0;
-		if (std::sscanf(e, "%ux%u", &r, &cc) == 2 && r >= 1 && cc >= 1 && r <= 4096 && cc <= 4096) { PR = r; PC = cc; }
-	}
+	// trade is not taken by default.  (Options "patch_rows" / "patch_cols" / "seg" / "xcd_queues" are the hooks of that measurement.)
 	if (patch_end) patch_end->clear();
 	for (uint32_t py = 0; py < g.gy; py += PR)
 		for (uint32_t px = 0; px < g.gx; px += PC) {
@@ -419,30 +443,23 @@ int launch_count(twk_hip_ctx* c, int set, const twk_hip_tile_desc& t, Slot& s, i
 	const bool diag = t.diag && t.rowA0 == t.rowB0;
 	const uint32_t n_blocks = c->resident_blocks;
 	std::vector<uint32_t> list, patch_end;
-	build_tile_list(t, P, g, diag, cr, list, &patch_end);
+	build_tile_list(t, P, g, diag, cr, list, &patch_end, (uint32_t)c->opt.patch_rows, (uint32_t)c->opt.patch_cols);
 	const size_t T = list.size();
 	// units of work: see build_count_units (ld_count.hip.h)
 	const uint32_t nchunks = ps.W / KC;
-	uint32_t min_chunks = 8;
-	if (const char* e = std::getenv("TWK_HIP_COUNT_MIN_CHUNKS")) {      // test hook: split short rows too
-		const unsigned long v = std::strtoul(e, nullptr, 10);
-		if (v) min_chunks = (uint32_t)v;
-	}
+	uint32_t min_chunks = (uint32_t)c->opt.count_min_chunks;      // (test hook: 1 splits short rows too)
 	bool fuse = false;
 	if (fa) {
-		const char* fe = std::getenv("TWK_HIP_FUSED");      // 0: never; 1 (default): rows of <= FUSED_MAX_CHUNKS chunks; 2: always (test hook)
-		const int fused_env = fe ? std::atoi(fe) : 1;
+		const int fused_env = (int)c->opt.fused;      // 0: never; 1 (default): rows of <= FUSED_MAX_CHUNKS chunks; 2: always (test hook)
 		fuse = fused_env == 2 || (fused_env == 1 && nchunks <= FUSED_MAX_CHUNKS);
 		if (fuse) min_chunks = nchunks + 1;          // whole tiles only: a block must hold a pair's whole count to screen it
 	}
 	if (fused) *fused = fuse;
 	std::vector<CountUnit> units;
-	uint32_t seg_chunks = 0;                    // whole tiles (see build_tile_list for the measurement behind that)
-	if (const char* e = std::getenv("TWK_HIP_SEG")) seg_chunks = (uint32_t)std::strtoul(e, nullptr, 10);     // measurement hook: K segments of this many chunks
+	uint32_t seg_chunks = (uint32_t)c->opt.seg;    // 0: whole tiles (see build_tile_list for the measurement behind that)
 	if (fuse) seg_chunks = 0;
 	uint32_t first_split = 0, n_queues = 1, queue_begin[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-	uint32_t xcd_queues = 0;
-	if (const char* e = std::getenv("TWK_HIP_XCD_QUEUES")) xcd_queues = (uint32_t)std::strtoul(e, nullptr, 10);    // measurement hook (profiles/): one unit queue per XCD
+	const uint32_t xcd_queues = (uint32_t)c->opt.xcd_queues;    // measurement hook (profiles/): one unit queue per XCD
 	if (T && !fuse && xcd_queues > 1 && xcd_queues <= 8 && nchunks >= 128 && !patch_end.empty()) {
 		// patches dealt round robin to the queues; within a queue patch after patch, each K segment by K segment
 		const uint32_t nseg = seg_chunks ? (nchunks + seg_chunks - 1) / seg_chunks : 1;
@@ -492,8 +509,7 @@ int launch_count(twk_hip_ctx* c, int set, const twk_hip_tile_desc& t, Slot& s, i
 		w.n_queues = n_queues;
 		for (int q = 0; q < 9; ++q) w.queue_begin[q] = queue_begin[q];
 		{
-			const char* spe = std::getenv("TWK_HIP_SKIP_PAD");      // measurement hook: 0 = contract the zero padding too
-			const bool skip_pad = !(spe && spe[0] == '0');
+			const bool skip_pad = c->opt.skip_pad != 0;      // measurement hook: 0 = contract the zero padding too
 			const uint32_t live_last = ps.W_live - (ps.W / KC - 1) * KC;      // live words of the last chunk, 1..KC (W = W_live rounded up to KC)
 			w.last_halves = (skip_pad && ps.W_live && ps.W_live <= ps.W && ps.W - ps.W_live < KC) ? (live_last + 1) / 2 : 0;
 			if (w.last_halves >= 16) w.last_halves = 0;
@@ -566,14 +582,12 @@ TilePlan plan_for(const twk_hip_ctx* c, int mode) {
 // Fisher's exact test, one record per lane, on recs[0, min(*n_out, cap)): starting points (k_fisher_prepare), then the
 // walks (k_ld_fisher_t) - in the order of their length (k_fisher_scatter) when `scratch` (scratch_words uint32, free at
 // this point of the stream) is given; records beyond the scratch keep their place.  ld_math.hip.h.
-// TWK_HIP_FISHER_ORDER=0: walks in the order the records were appended; TWK_HIP_FISHER_LDS=0: log-factorial table read
+// Option "fisher_order" = 0: walks in the order the records were appended; "fisher_lds" = 0: log-factorial table read
 // from global memory also when it would fit LDS (measurement hooks).
 int launch_fisher(twk_hip_ctx* c, twk_hip_record* recs, unsigned long long* n_out, unsigned long long cap, double minP,
                   uint32_t* scratch, size_t scratch_words) {
 	const LFact lf{c->d_lfact, c->lfact_n};
-	const char* oe = std::getenv("TWK_HIP_FISHER_ORDER");
-	const char* le = std::getenv("TWK_HIP_FISHER_LDS");
-	const bool ordered = !(oe && oe[0] == '0'), lds_ok = !(le && le[0] == '0');
+	const bool ordered = c->opt.fisher_order != 0, lds_ok = c->opt.fisher_lds != 0;
 	const bool lds_table = lds_ok && c->lfact_n <= FISHER_LDS_TABLE_MAX;
 	const size_t lds_bytes = lds_table ? (size_t)c->lfact_n * sizeof(double) : 0;
 	if (!c->d_fisher_bins) HIPCHK(c, hipMalloc((void**)&c->d_fisher_bins, 2 * FISHER_BINS * sizeof(uint32_t)));
@@ -627,8 +641,8 @@ int enqueue_tile(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, const twk
 		{	// slots a wave reserves at a time: what it cannot use is lost to the list, so at most an eighth of the list's
 			// capacity may be tied up in the waves' windows (small tiles: 0, i.e. one atomic per wave and tile)
 			const unsigned long long per_wave = s.cand_cap / (8ull * c->resident_blocks * (COUNT_THREADS / 64));
-			const char* ce = std::getenv("TWK_HIP_CAND_CHUNK");      // measurement hook
-			sw.chunk = ce ? (uint32_t)std::strtoul(ce, nullptr, 10) : (per_wave >= 64 ? (uint32_t)std::min<unsigned long long>(per_wave, 128) : 0u);
+			sw.chunk = c->opt.cand_chunk >= 0 ? (uint32_t)c->opt.cand_chunk      // measurement hook
+			                                  : (per_wave >= 64 ? (uint32_t)std::min<unsigned long long>(per_wave, 128) : 0u);
 		}
 	}
 	const StatsParams* d_stats = nullptr;
@@ -760,7 +774,7 @@ int finish_tile(twk_hip_ctx* c, Slot& s, const twk_hip_tile_desc& t, unsigned lo
 		c->timing.stats_launches += 1;
 	}
 	c->timing.stats_ms += ms_all;
-	c->timing.variant_pairs += pairs_in_tile(c, t);
+	if (!s.is_list) c->timing.variant_pairs += pairs_in_tile(c, t);      // (the dense tiles that cover the list zone count its pairs)
 	const unsigned long long n = *s.h_n_out;
 	*n_out = n;
 	if ((s.fused || s.is_list) && s.h_n_out[2] > s.cand_cap) {       // more candidates than the list holds
@@ -1406,9 +1420,8 @@ static int region_impl(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint3
 		// The plain path's math kernel visits every pair of the launch's rectangle, so there the block height stays near the
 		// window width; the fused path (count -> screen in the same kernel) visits the listed tiles only.
 		const TilePlan pl = plan_for(c, mode);
-		const char* fe = std::getenv("TWK_HIP_FUSED");
 		const bool fused_likely = ((pl.phased1 && set_kind(pl.set1) == PK_PHASED) || (!pl.phased1 && set_kind(pl.set1) == PK_UNPHASED)) && pl.set2 < 0
-		                          && f->minR2 > 1e-6 && f->minR2 <= 1.0 && (!fe || std::atoi(fe) != 0)
+		                          && f->minR2 > 1e-6 && f->minR2 <= 1.0 && c->opt.fused != 0
 		                          && ensure_planes(c, pl.set1) == TWK_HIP_OK && c->planes[pl.set1].W / KC <= FUSED_MAX_CHUNKS;
 		const uint32_t s_hi = fused_likely ? S : std::min<uint32_t>(S, std::max<uint32_t>(512u, round_up((uint32_t)std::min<uint64_t>(wv, 1u << 20), 64)));
 		const uint32_t s_lo = std::max<uint32_t>(128u, std::min<uint32_t>(s_hi, round_up((uint32_t)std::min<uint64_t>(wv / 8, 1u << 20), 64)));
@@ -1523,10 +1536,7 @@ static int region_impl(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint3
 		for (const auto& t : mine) worst = std::max<unsigned long long>(worst, (unsigned long long)t.nA * t.nB);
 		cap_default = std::min<unsigned long long>(worst ? worst : 1, 1ull << 24);
 	}
-	if (const char* e = std::getenv("TWK_HIP_RECORD_CAP")) {       // test hook: force the overflow / strip path
-		const unsigned long long v = std::strtoull(e, nullptr, 10);
-		if (v) cap_default = std::min(cap_default, v);
-	}
+	if (c->opt.record_cap > 0) cap_default = std::min<unsigned long long>(cap_default, (unsigned long long)c->opt.record_cap);   // test hook: force the overflow / strip path
 	int rc = TWK_HIP_OK;
 	size_t issued = 0, done = 0;
 	const size_t n = mine.size();
@@ -1742,6 +1752,31 @@ int twk_hip_device_records(twk_hip_ctx* c, const twk_hip_record** records, uint6
 	*records = c->d_keep_n ? c->d_keep : nullptr;
 	*n = c->d_keep_n;
 	return TWK_HIP_OK;
+}
+
+int twk_hip_set_option(twk_hip_ctx* c, const char* key, int64_t value) {
+	if (!c || !key) return TWK_HIP_E_INVALID;
+	for (const OptionKey& k : OPTION_KEYS) {
+		if (std::strcmp(k.name, key) != 0) continue;
+		if (value < k.lo || value > k.hi) { snprintf(c->err, sizeof(c->err), "option %s: %lld is outside [%lld, %lld]", key, (long long)value, k.lo, k.hi); return TWK_HIP_E_INVALID; }
+		if (c->opt.*(k.field) == value) return TWK_HIP_OK;
+		c->opt.*(k.field) = value;
+		if (k.rebuilds_planes && c->raw) {       // the carrier lists belong to the allele-count-sorted sets: rebuilt on next use
+			HIPCHK(c, hipSetDevice(c->device));
+			HIPCHK(c, hipDeviceSynchronize());
+			free_planes(c);
+		}
+		return TWK_HIP_OK;
+	}
+	snprintf(c->err, sizeof(c->err), "unknown option %s", key);
+	return TWK_HIP_E_INVALID;
+}
+
+int twk_hip_get_option(const twk_hip_ctx* c, const char* key, int64_t* value) {
+	if (!c || !key || !value) return TWK_HIP_E_INVALID;
+	for (const OptionKey& k : OPTION_KEYS)
+		if (std::strcmp(k.name, key) == 0) { *value = c->opt.*(k.field); return TWK_HIP_OK; }
+	return TWK_HIP_E_INVALID;
 }
 
 int twk_hip_set_progress(twk_hip_ctx* c, twk_hip_progress_cb cb, void* user) {

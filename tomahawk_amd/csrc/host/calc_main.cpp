@@ -51,6 +51,7 @@ static void calc_usage() {
 	"  -P FLOAT  Fisher's exact test / Chi-squared cutoff P-value (default: 1)\n"
 	"  -r FLOAT  Pearson's R-squared minimum cut-off value (default: 0.1)\n"
 	"  -k INT    compression level to use (default: 1, max = 22).\n"
+	"  --engine-option KEY=INT  a switch of the GPU engine (twk_hip_set_option, include/twk_hip.h; repeatable)\n"
 	"Environment: TWK_HIP_DEVICE=<n> selects the GPU (default 0); TWK_HIP_GPUS=<n> uses GPUs 0..n-1, one\n"
 	"             driver thread each (equal-area row bands, one shared output file); TWK_HIP_PART=k/n makes\n"
 	"             this process compute share k of n of a multi-node run (merge the outputs with concat).\n" << std::endl;
@@ -67,9 +68,11 @@ static int calc(int argc, char** argv) {
 		{"compression-level", optional_argument, 0, 'k'}, {"cross-chr-only", no_argument, 0, 'X'}, {"no-cross-chr", no_argument, 0, 'x'},
 		{"minP", optional_argument, 0, 'P'}, {"force-phased", no_argument, 0, 'p'}, {"force-unphased", no_argument, 0, 'u'},
 		{"samples", optional_argument, 0, 'S'}, {"minR2", optional_argument, 0, 'r'}, {"detailedProgress", no_argument, 0, 'd'},
-		{"silent", no_argument, 0, 's'}, {"windowBases", optional_argument, 0, 'w'}, {0, 0, 0, 0}};
+		{"silent", no_argument, 0, 's'}, {"windowBases", optional_argument, 0, 'w'},
+		{"engine-option", required_argument, 0, 1000}, {0, 0, 0, 0}};
 	tomahawk::twk_ld_settings settings;
 	int c, option_index = 0;
+	std::vector<std::pair<std::string, long long>> engine_options;
 	while ((c = getopt_long(argc, argv, "i:o:t:puP:a:A:r:w:S:I:sdc:C:mMb:xXk:?", long_options, &option_index)) != -1) {
 		switch (c) {
 		case 'i': settings.in = optarg; break;
@@ -114,6 +117,13 @@ static int calc(int argc, char** argv) {
 			break;
 		}
 		case 'k': settings.c_level = atoi(optarg); break;
+		case 1000: {      // --engine-option key=value (not in the reference): twk_ld::SetEngineOption
+			const std::string a(optarg);
+			const size_t eq = a.find('=');
+			if (eq == std::string::npos || eq == 0 || eq + 1 >= a.size()) { std::cerr << stamp("ERROR") << "--engine-option wants key=value" << std::endl; return 1; }
+			engine_options.emplace_back(a.substr(0, eq), atoll(a.c_str() + eq + 1));
+			break;
+		}
 		default:
 			std::cerr << stamp("ERROR") << "Unrecognized option: " << (char)c << std::endl;
 			return 1;
@@ -124,6 +134,7 @@ static int calc(int argc, char** argv) {
 	program_message();
 	std::cerr << stamp("LOG") << "Calling calc..." << std::endl;
 	tomahawk::twk_ld ld;
+	for (const auto& kv : engine_options) ld.SetEngineOption(kv.first, kv.second);
 	return ld.Compute(settings) ? 0 : 1;
 }
 

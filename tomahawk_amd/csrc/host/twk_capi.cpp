@@ -378,8 +378,6 @@ int twk_two_stream_close(void* h, uint64_t* n_records) try {
 	if (!st) return -1;
 	bool ok = st->emitter->emit(nullptr, 0, true);
 	ok = st->out.writer.close() && ok;
-	if (std::getenv("TWK_EMIT_STATS")) fprintf(stderr, "[emit] ordering %.3f s, blocks %.3f s, %llu blocks, %llu MB compressed\n", st->emitter->t_sort, st->emitter->t_blocks,
-	                                           (unsigned long long)st->out.n_blocks, (unsigned long long)(st->out.bytes_packed / 1000000));
 	if (n_records) *n_records = st->out.n_records;
 	return ok ? 0 : -3;
 } catch (...) { return -9; }

@@ -94,6 +94,11 @@ std::string twk_ld_settings::GetString() const {
 class twk_ld::twk_ld_impl {
 public:
 	uint64_t n_pairs = 0, n_records = 0;
+	std::vector<std::pair<std::string, int64_t>> engine_options;     // twk_ld::SetEngineOption, in the order given
+	int64_t option(const char* key, int64_t dflt) const {
+		for (const auto& kv : engine_options) if (kv.first == key) dflt = kv.second;
+		return dflt;
+	}
 
 	// per-variant (rid,pos) of the uploaded selection
 	std::vector<uint32_t> rid, pos;
@@ -136,6 +141,7 @@ public:
 
 twk_ld::twk_ld() : mImpl(new twk_ld_impl) {}
 twk_ld::~twk_ld() { delete mImpl; }
+void twk_ld::SetEngineOption(const std::string& key, int64_t value) { mImpl->engine_options.emplace_back(key, value); }
 uint64_t twk_ld::n_pairs() const { return mImpl->n_pairs; }
 uint64_t twk_ld::n_records() const { return mImpl->n_records; }
 
@@ -479,8 +485,10 @@ static bool part_from_env(uint32_t& part0, uint32_t& n_procs) {
 	return true;
 }
 
-static bool create_devices(DeviceCtxs& dc, int n_gpus) {
-	const char* force = std::getenv("TWK_HIP_FORCE_DEVICE");       // testing: several engine contexts on one GPU
+static bool create_devices(DeviceCtxs& dc, int n_gpus, const std::vector<std::pair<std::string, int64_t>>& options) {
+	int64_t force_device = -1;                                       // option "force_device" (testing): several engine contexts on one GPU
+	for (const auto& kv : options) if (kv.first == "force_device") force_device = kv.second;
+	const bool force = force_device >= 0;
 	const char* dev_env = std::getenv("TWK_HIP_DEVICE");
 	if (twk_hip_abi_version() != TWK_HIP_ABI_VERSION) {      // (struct layouts cross this boundary: twk_hip_timing, twk_hip_record)
 		std::cerr << stamp("ERROR", "HIP") << "libtwk_hip has ABI version " << twk_hip_abi_version() << ", this library was built against " << TWK_HIP_ABI_VERSION << "." << std::endl;
@@ -490,10 +498,14 @@ static bool create_devices(DeviceCtxs& dc, int n_gpus) {
 	if (n_dev <= 0) { std::cerr << stamp("ERROR", "HIP") << "No HIP device available (this build has no CPU path)." << std::endl; return false; }
 	if (!force && n_gpus > n_dev) { std::cerr << stamp("ERROR", "HIP") << "TWK_HIP_GPUS=" << n_gpus << " but only " << n_dev << " device(s) are visible." << std::endl; return false; }
 	for (int g = 0; g < n_gpus; ++g) {
-		const int device = force ? std::atoi(force) : (n_gpus == 1 && dev_env ? std::atoi(dev_env) : g);
+		const int device = force ? (int)force_device : (n_gpus == 1 && dev_env ? std::atoi(dev_env) : g);
 		twk_hip_ctx* c = nullptr;
 		if (!hip_ok(nullptr, twk_hip_ctx_create(device, &c), "twk_hip_ctx_create")) return false;
 		dc.ctx.push_back(c);
+		for (const auto& kv : options) {
+			if (kv.first == "force_device" || kv.first == "progress_ms") continue;       // this class's own
+			if (!hip_ok(c, twk_hip_set_option(c, kv.first.c_str(), kv.second), "twk_hip_set_option")) return false;
+		}
 	}
 	return true;
 }
@@ -559,7 +571,7 @@ bool twk_ld::twk_ld_impl::run(twk_ld_settings& settings, const Header& hdr, cons
 	} progress;
 	progress.self = this; progress.t0 = progress.last = t0; progress.n_s = n_samples;
 	progress.done.assign(n_gpus, 0); progress.base.assign(n_gpus, 0);
-	if (const char* e = std::getenv("TWK_HIP_PROGRESS_SECONDS")) progress.every = std::atof(e);      // test hook
+	progress.every = (double)option("progress_ms", (int64_t)(progress.every * 1000.0)) / 1000.0;      // (test hook)
 	progress.total = (spec.triangleA && spec.nA > 1 ? (uint64_t)spec.nA * (spec.nA - 1) / 2 : 0) + (spec.rectAB ? (uint64_t)spec.nA * spec.nB : 0);
 	if (n_procs > 1) progress.total /= n_procs;
 	std::vector<Progress::PerGpu> per_gpu(n_gpus);
@@ -706,7 +718,7 @@ bool twk_ld::Compute() {
 
 	const int n_gpus = gpus_from_env();
 	DeviceCtxs dc;
-	if (!create_devices(dc, n_gpus)) return false;
+	if (!create_devices(dc, n_gpus, mImpl->engine_options)) return false;
 	if (n_gpus > 1) std::cerr << stamp("LOG", "HIP") << "Using " << n_gpus << " GPUs: one driver thread each, equal-area row bands of the pair space..." << std::endl;
 	uint32_t part0 = 0, n_procs = 1;
 	if (!part_from_env(part0, n_procs)) return false;
@@ -835,7 +847,7 @@ bool twk_ld::ComputeSingle(bool verbose, bool) {
 	if (verbose) std::cerr << stamp("LOG") << pretty(nT) << " target and " << pretty(nO) << " surrounding variants..." << std::endl;
 
 	DeviceCtxs dc;
-	if (!create_devices(dc, 1)) return false;
+	if (!create_devices(dc, 1, mImpl->engine_options)) return false;
 	twk_hip_ctx* ctx = dc.ctx[0];
 	if (!hip_ok(ctx, twk_hip_set_problem(ctx, n_samples, M), "twk_hip_set_problem")) return false;
 	const size_t w64 = ((size_t)2 * n_samples + 63) / 64;

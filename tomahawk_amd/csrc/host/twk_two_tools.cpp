@@ -354,11 +354,7 @@ bool two_sort(two_sorter_settings& st) {
 	// Memory plan: the reference gives every thread `memory_limit` GB (two_sorter_structs.cpp);
 	// here that product bounds one in-memory run (records + keys).
 	uint64_t run_cap = (uint64_t)((double)st.memory_limit * 1e9 * T / (sizeof(TwoRecord) + sizeof(SortKey)));
-	run_cap = std::max<uint64_t>(std::min<uint64_t>(run_cap, 0xFFFFFFF0ull), 10000);
-	if (const char* e = std::getenv("TWK_SORT_RUN_RECORDS")) {          // test hook: force the external path
-		const uint64_t v = std::strtoull(e, nullptr, 10);
-		if (v) run_cap = v;
-	}
+	run_cap = std::max<uint64_t>(std::min<uint64_t>(run_cap, 0xFFFFFFF0ull), 1000);      // (a tiny -m forces the external path: tests)
 	// runs = consecutive index blocks holding <= run_cap records
 	std::vector<std::pair<size_t, size_t>> runs;
 	for (size_t b = 0; b < idx.ent.size();) {

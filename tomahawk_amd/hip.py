@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libtwk_hip.so")
 
-ABI_VERSION = 2                 # TWK_HIP_ABI_VERSION of include/twk_hip.h (struct layouts below)
+ABI_VERSION = 3                 # TWK_HIP_ABI_VERSION of include/twk_hip.h (struct layouts below)
 MODE_PHASED, MODE_UNPHASED, MODE_AUTO = 1, 2, 3
 # option bits of twk_hip_tile_desc.window / the `window` argument of ld_all / ld_region (TWK_HIP_OPT_*)
 OPT_WINDOW, OPT_KEEP_LOW_AC, OPT_REF_COMPAT, OPT_R2_SCREEN = 1, 2, 4, 8
@@ -119,6 +119,8 @@ def load_library() -> C.CDLL:
     lib.twk_hip_fisher_exact.argtypes = [p, p, C.c_uint64, p, C.c_int32, C.POINTER(C.c_float)]
     lib.twk_hip_set_device_sink.argtypes = [p, C.c_int]
     lib.twk_hip_device_records.argtypes = [p, C.POINTER(p), C.POINTER(C.c_uint64)]
+    lib.twk_hip_set_option.argtypes = [p, C.c_char_p, C.c_int64]
+    lib.twk_hip_get_option.argtypes = [p, C.c_char_p, C.POINTER(C.c_int64)]
     lib.twk_hip_timing_reset.argtypes = [p]
     lib.twk_hip_timing_get.argtypes = [p, C.POINTER(_Timing)]
     _lib = lib
@@ -161,6 +163,24 @@ class HipLd:
             raise HipError(rc, "twk_hip_ctx_create", self._lib.twk_hip_strerror(rc).decode())
         self.n_samples = 0
         self.n_variants = 0
+        self.device = device
+        self._sink_on = False
+        self._defaults = {}
+
+    # ---- switches (twk_hip_set_option: the library reads no environment variable) ----
+    def get_option(self, key: str) -> int:
+        v = C.c_int64(0)
+        self._check(self._lib.twk_hip_get_option(self._ctx, key.encode(), C.byref(v)), f"twk_hip_get_option({key})")
+        return int(v.value)
+
+    def set_option(self, key: str, value: int):
+        self._defaults.setdefault(key, self.get_option(key))
+        self._check(self._lib.twk_hip_set_option(self._ctx, key.encode(), int(value)), f"twk_hip_set_option({key})")
+
+    def unset_option(self, key: str):
+        """Back to the value the context was created with."""
+        if key in self._defaults:
+            self._check(self._lib.twk_hip_set_option(self._ctx, key.encode(), self._defaults[key]), f"twk_hip_set_option({key})")
 
     def close(self):
         if self._ctx:
@@ -275,6 +295,7 @@ class HipLd:
         cb = _SINK(sink)
         npairs, nrec = C.c_uint64(0), C.c_uint64(0)
         f = filters._c()
+        # (with the device sink on the records stay in HBM: the returned array is empty, see device_records_tensor)
         self._check(self._lib.twk_hip_ld_all(self._ctx, mode, C.byref(f), part, n_parts, tile_variants,
                                              int(window), l_window, cb, None, C.byref(npairs), C.byref(nrec)),
                     "twk_hip_ld_all")
@@ -317,6 +338,7 @@ class HipLd:
     def set_device_sink(self, on: bool = True):
         """Region / all-vs-all calls keep their survivors on the device (twk_hip_set_device_sink); empties the buffer."""
         self._check(self._lib.twk_hip_set_device_sink(self._ctx, int(bool(on))), "twk_hip_set_device_sink")
+        self._sink_on = bool(on)
 
     def device_records(self):
         """-> (device pointer, n records) of what the device sink holds (twk_hip_device_records)."""
@@ -329,7 +351,7 @@ class HipLd:
         what tomahawk_amd.dist.gather_records sends over RCCL.  Valid until the next compute call."""
         import torch
         ptr, n = self.device_records()
-        dev = torch.device("cuda", torch.cuda.current_device())
+        dev = torch.device("cuda", self.device)          # the context's own device, whatever torch's current one is
         if n == 0:
             return torch.empty(0, dtype=torch.uint8, device=dev)
 
