@@ -175,6 +175,60 @@ def test_reference_client_source_builds_against_the_shim(tmp_path):
     assert r.returncode == 1 and "No file-name provided" in r.stderr
 
 
+def test_reference_client_that_touches_record_types_builds_against_the_shim(tmp_path):
+    """`#include "ld.h"` also declares the output record and its block (reference include/core.h:756-834, 851-902, reached
+    through ld.h:30-31): a client that fills twk1_two_t records, flags them, collects them in a twk1_two_block_t, sorts it
+    and serialises it compiles against include/ alone; the 106-byte records it packs are the .two record of
+    hostlib.TWO_DTYPE (lib/core.cpp:470-490), in the order of `tomahawk sort` (core.cpp:458-468), and read back equal."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "client.cpp"
+    src.write_text(r'''#include "ld.h"
+#include <cstdio>
+#include <vector>
+static_assert(tomahawk::twk1_two_t::packed_size == 106, "packed size");
+int main() {
+    tomahawk::twk1_two_block_t blk;
+    const unsigned pos[5][4] = {{1, 0, 900, 50}, {0, 1, 7, 8}, {0, 0, 500, 20}, {0, 0, 500, 10}, {0, 0, 3, 1073741823u}};
+    for (int i = 0; i < 5; ++i) {
+        tomahawk::twk1_two_t r;
+        r.ridA = pos[i][0]; r.ridB = pos[i][1]; r.Apos = pos[i][2]; r.Bpos = pos[i][3];
+        r.Aphased = 1; r.Bmiss = i & 1;
+        r[0] = 10 + i; r[3] = 0.5 * i; r.R = -0.25 * i; r.R2 = r.R * r.R; r.D = 1e-3 * i; r.Dprime = 1; r.P = 1e-300;
+        r.ChiSqModel = 3; r.ChiSqFisher = 4;
+        r.SetUsedPhasedMath(); r.SetSameContig(r.ridA == r.ridB); r.SetInvalidHWEB(i == 2);
+        blk += r;
+    }
+    if (blk.size() != 5 || blk.m != 500) return 2;
+    blk.Sort();
+    std::vector<unsigned char> bytes(blk.packed_bytes());
+    blk.pack(bytes.data());
+    tomahawk::twk1_two_block_t back;
+    if (!back.unpack(bytes.data(), bytes.size()) || back.size() != 5) return 3;
+    for (unsigned i = 0; i < 5; ++i) if (back[i] < blk[i] || blk[i] < back[i] || back[i].P != blk[i].P || back[i].controller != blk[i].controller) return 4;
+    if (back.unpack(bytes.data(), bytes.size() - 1)) return 5;
+    fwrite(bytes.data(), 1, bytes.size(), stdout);
+    return 0;
+}
+''')
+    exe = str(tmp_path / "client")
+    r = subprocess.run([shutil.which("g++") or "g++", "-std=c++11", "-Wall", "-Werror", "-I" + os.path.join(root, "include"), str(src), "-o", exe],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe], capture_output=True)
+    assert r.returncode == 0
+    n, m = np.frombuffer(r.stdout[:8], dtype="<u4")
+    assert (n, m) == (5, 500) and len(r.stdout) == 8 + 5 * 106
+    recs = np.frombuffer(r.stdout[8:], dtype=hostlib.TWO_DTYPE)
+    assert [(int(x["ridA"]), int(x["ridB"]), int(x["packA"]) >> 2, int(x["packB"]) >> 2) for x in recs] == \
+        [(0, 0, 3, 1073741823), (0, 0, 500, 10), (0, 0, 500, 20), (0, 1, 7, 8), (1, 0, 900, 50)]
+    assert all(int(x["packA"]) & 3 == 2 for x in recs) and [int(x["packB"]) & 3 for x in recs] == [0, 1, 0, 1, 0]
+    assert [int(x["controller"]) for x in recs] == [3, 3, 3 | 8192, 1, 1]
+    assert recs["cnt"][:, 0].tolist() == [14, 13, 12, 11, 10] and recs["P"].tolist() == [1e-300] * 5
+    assert recs["ChiSqFisher"].tolist() == [4] * 5 and recs["ChiSqModel"].tolist() == [3] * 5 and recs["Dprime"].tolist() == [1] * 5
+
+
 @pytest.mark.parametrize("n_threads,b_size", [(1, 50), (3, 128), (8, 1000)])
 def test_record_stream_blocks_follow_the_flush_rule(tmp_path, n_threads, b_size):
     """hostlib.TwoStream (RecordEmitter: worker threads expand + compress, a writer thread appends in order, at most
