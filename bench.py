@@ -141,7 +141,7 @@ def measure_traffic(config_args, log):
             with open(files[0], newline="") as fh:
                 for row in csv.DictReader(fh):
                     name = row.get("Kernel_Name") or row.get("kernel_name") or ""
-                    if "k_count_list_t" in name and row.get("Counter_Name") == ctr:
+                    if ("k_count_list_t" in name or "k_count_screen" in name) and row.get("Counter_Name") == ctr:
                         total += float(row["Counter_Value"])
                         launches.add(row.get("Dispatch_Id") or row.get("dispatch_id"))
             if not launches:
@@ -237,7 +237,7 @@ def main():
     import torch.distributed as dist
     import numpy as np
     import tomahawk_amd as T
-    from tomahawk_amd.dist import gather_records, init_groups, window_slab, window_total_pairs
+    from tomahawk_amd.dist import LAST_GATHER, gather_records, init_groups, window_slab, window_total_pairs
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -328,7 +328,8 @@ def main():
                                  n_threads=min(os.cpu_count() or 1, 32))
 
     written = {"records": 0}
-    phase = {"compute": 0.0, "gather": 0.0, "write": 0.0}       # seconds, this rank, summed over the timed steps
+    phase = {"compute": 0.0, "gather": 0.0, "write": 0.0,       # seconds, this rank, summed over the timed steps
+             "xfer": 0.0, "xfer_bytes": 0}                      # rank 0: the transfers alone (after every rank has arrived) and their bytes
 
     def step(stream):
         """One pass of the hot path over this rank's shard + the gather of survivors to rank 0 + the .two blocks."""
@@ -355,6 +356,7 @@ def main():
         if world > 1:
             # RCCL: all_gather(counts) + grouped send/recv of exact sizes, HBM to HBM; rank 0 copies to host once
             recs = gather_records(recs, dst=0, device=xdev, group=gather_group)
+            phase["xfer"] += LAST_GATHER["seconds"]; phase["xfer_bytes"] += LAST_GATHER["bytes"]
         t_c = time.perf_counter()
         if rank == 0:
             stream.append(recs)
@@ -368,7 +370,7 @@ def main():
     streams = [open_stream(i) for i in range(args.steps)]
     written["records"] = 0
     for k in phase:
-        phase[k] = 0.0
+        phase[k] = 0
     barrier()
     eng.timing_reset()
     t0 = time.perf_counter()
@@ -432,8 +434,10 @@ def main():
                                     + (f", P<={filters.minP:g}" if filters.minP < 1 else "") + f"), {total_pairs} pairs/step"
                                     + (f"; EMULATED shard {args.emulate_shard} only" if args.emulate_shard else "")),
                        "n_samples": n_samples, "n_variants": n_variants, "mode": mode, "tile_variants": args.tile,
-                       "partition": f"equal-area row bands of the pair triangle over {world} GPU(s), RCCL gather of survivors, "
-                                    "rank 0 writes the .two file",
+                       "partition": (f"equal-area row bands of the pair triangle over {world} GPU(s), "
+                                     + ("no gather (one rank)" if world == 1 else "RCCL gather of survivors (HBM to HBM)" if collective == "nccl"
+                                        else f"gather of survivors over {collective.split(' ')[0]} through host memory")
+                                     + ", rank 0 writes the .two file"),
                        "collective_backend": collective,
                        "survivors_per_step": recs_all / args.steps,
                        "two_records_written_per_step": written["records"] / args.steps},
@@ -459,6 +463,8 @@ def main():
             "per_rank_ms": per_rank_ms,                                   # compute per step, every rank (balance of the bands)
             "gather_ms": phase["gather"] / max(args.steps, 1) * 1e3,      # rank 0, per step: waits for the slowest rank, then the transfers
             "write_ms": phase["write"] / max(args.steps, 1) * 1e3,        # rank 0, per step: survivors -> .two blocks -> file
+            "gather_bytes": phase["xfer_bytes"] / max(args.steps, 1),     # rank 0, per step: record bytes received from the other ranks
+            "gather_GBps": (phase["xfer_bytes"] / phase["xfer"] / 1e9) if phase["xfer"] > 0 and phase["xfer_bytes"] else None,   # over the transfers alone
             "ranks_seen": ranks_seen,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -475,9 +475,10 @@ def test_bench_orchestration_with_two_ranks_on_one_gpu(tmp_path):
     assert d2["config"]["collective_backend"].startswith("gloo (RCCL failed") and d2["config"]["survivors_per_step"] == d["config"]["survivors_per_step"]
 
 
-def _run_bench(tmp_path, world, extra, tag):
+def _run_bench(tmp_path, world, extra, tag, backend="gloo"):
     """bench.py as the driver launches it (python -m torch.distributed.run for N > 1; gloo so that the ranks can share
-    this box's one GPU) -> (JSON line, records of the .two rank 0 wrote in the last timed step)."""
+    this box's one GPU, nccl = RCCL with one GPU per rank) -> (JSON line, records of the .two rank 0 wrote in the last
+    timed step)."""
     import json
     import os
     import socket
@@ -492,7 +493,7 @@ def _run_bench(tmp_path, world, extra, tag):
     else:
         s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
-               "--master-port", str(port), os.path.join(root, "bench.py"), "--backend", "gloo"] + common
+               "--master-port", str(port), os.path.join(root, "bench.py"), "--backend", backend] + common
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, cwd=root)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -517,6 +518,7 @@ def test_bench_with_eight_ranks_on_one_gpu_equals_one_rank(tmp_path, config, ext
     d8, eight = _run_bench(tmp_path, 8, args, config)
     assert d8["n_gpus"] == 8 and d8["ranks_seen"] == list(range(8)) and len(d8["per_rank_ms"]) == 8
     assert d8["gather_ms"] >= 0 and d8["write_ms"] > 0 and all(x > 0 for x in d8["per_rank_ms"])
+    assert 0 < d8["gather_bytes"] <= 104 * d8["config"]["survivors_per_step"] and d8["gather_GBps"] > 0
     assert d8["config"]["collective_backend"] == "gloo"
     assert d1["config"]["survivors_per_step"] == d8["config"]["survivors_per_step"] > 1000
     assert len(one) == len(eight) == 2 * d1["config"]["survivors_per_step"]
@@ -524,11 +526,44 @@ def test_bench_with_eight_ranks_on_one_gpu_equals_one_rank(tmp_path, config, ext
     assert np.sort(one, order=order).tobytes() == np.sort(eight, order=order).tobytes()
 
 
+@pytest.mark.parametrize("config,extra", [
+    ("cfg3", ["--samples", "20000", "--variants", "4096", "--min-r2", "0.0002"]),
+    ("cfg5", ["--samples", "20000", "--variants", "16384", "--min-r2", "0.0002", "--min-p", "1e-3"]),
+    # survivor-rich: tens of MB per rank through the gather (the sender's payload is the engine's own HBM buffer, which
+    # the next step rewrites - torn records here would mean the transfer was not finished when gather_records returned)
+    ("cfg3", ["--samples", "2000", "--variants", "4096", "--min-r2", "0.0005", "--steps", "3"]),
+])
+def test_rccl_gather_between_gpus_equals_one_rank(tmp_path, config, extra):
+    """Runs wherever the box shows >= 2 GPUs (skipped, with the reason, on the one-GPU boxes of this pool): bench.py under
+    torch.distributed.run with the nccl backend (= RCCL), world = min(8, GPUs), one GPU per rank - the survivors leave every
+    rank's HBM over RCCL (counts all-gather + grouped send/recv of exact sizes) straight into rank 0's buffer.  The line
+    must say RCCL carried the gather and connected every rank, and the .two rank 0 wrote must hold exactly the records
+    of the 1-rank file.  Partition: SURVEY 8(e); reference analogue lib/ld/ld_balancing.h:23-80."""
+    import torch
+    n_dev = torch.cuda.device_count()
+    if n_dev < 2:
+        pytest.skip(f"RCCL between GPUs needs >= 2 devices; this box shows {n_dev} (the check runs the first time a multi-GPU box does)")
+    world = min(8, n_dev)
+    args = ["--config", config] + extra
+    d1, one = _run_bench(tmp_path, 1, args, config)
+    dn, many = _run_bench(tmp_path, world, args, config, backend="nccl")
+    assert dn["n_gpus"] == world and dn["config"]["collective_backend"] == "nccl", dn["config"]["collective_backend"]
+    assert dn["ranks_seen"] == list(range(world)) and len(dn["per_rank_ms"]) == world
+    assert "RCCL gather" in dn["config"]["partition"]
+    assert d1["config"]["survivors_per_step"] == dn["config"]["survivors_per_step"] > 1000
+    assert dn["gather_bytes"] > 0 and dn["gather_GBps"] and dn["gather_GBps"] > 0
+    assert len(one) == len(many) == 2 * d1["config"]["survivors_per_step"]
+    order = ["ridA", "packA", "ridB", "packB"]
+    assert np.sort(one, order=order).tobytes() == np.sort(many, order=order).tobytes()
+
+
 def test_rccl_itself_on_this_box(tmp_path):
     """What one GPU can show of RCCL.  (1) A world of one: the bench's own init_groups("nccl") creates the RCCL group on
     cuda:0 and the collectives of the N > 1 path (all_gather of counts / rank ids, barrier) run on it.  (2) Two ranks on
-    the one GPU with the default backend: RCCL refuses the duplicate device on both ranks, the ranks agree on gloo over
-    the control group, say why in the JSON line, and the run completes with both ranks seen."""
+    the one GPU with the default backend: the precondition of init_groups (one GPU per rank, agreed over the control group
+    before anyone enters RCCL, which would refuse the duplicate device) sends both ranks to gloo together, the JSON line
+    says why, and the run completes with both ranks seen.  (On a box with several GPUs the two ranks get one each and
+    RCCL carries the gather.)"""
     import json
     import os
     import socket
@@ -547,5 +582,9 @@ def test_rccl_itself_on_this_box(tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
-    assert d["config"]["collective_backend"].startswith("gloo (RCCL failed to initialise") and d["ranks_seen"] == [0, 1]
+    import torch
+    if torch.cuda.device_count() >= 2:
+        assert d["config"]["collective_backend"] == "nccl" and d["ranks_seen"] == [0, 1]
+    else:
+        assert d["config"]["collective_backend"].startswith("gloo (RCCL not attempted: ranks [0, 1] share one GPU") and d["ranks_seen"] == [0, 1]
     assert d["config"]["survivors_per_step"] > 1000 and d["config"]["two_records_written_per_step"] == 2 * d["config"]["survivors_per_step"]

@@ -141,6 +141,18 @@ def _worker_groups(rank, world, port, q, backend, force_fail):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     from tomahawk_amd.dist import gather_records, init_groups
+    if isinstance(force_fail, int) and not isinstance(force_fail, bool):       # RCCL "fails" on this one rank only: every rank must raise
+        if rank != force_fail:
+            import torch.distributed as d
+            real = d.new_group          # the other ranks "succeed" (no collective: the failing rank never calls new_group)
+            d.new_group = lambda *a, **k: d.group.WORLD if k.get("backend") == "nccl" else real(*a, **k)
+        try:
+            init_groups(backend, None, force_rccl_failure=(rank == force_fail) or "others", timeout_s=60)
+            q.put((rank, "no error"))
+        except RuntimeError as e:
+            q.put((rank, str(e)))
+        dist.destroy_process_group()
+        return
     group, xdev, desc = init_groups(backend, None, force_rccl_failure=force_fail, timeout_s=60)
     # the payload as bench.py hands it over: a uint8 tensor of n x 104 bytes (the engine's buffer on the GPU box)
     n = [3, 0, 7, 1][rank % 4]
@@ -162,11 +174,30 @@ def _worker_groups(rank, world, port, q, backend, force_fail):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("backend,force_fail", [("gloo", False), ("nccl", True)])
+def test_an_asymmetric_rccl_failure_is_an_error_on_every_rank():
+    """RCCL group creation fails on rank 2 only: no rank falls back to gloo on its own, every rank raises (a non-zero
+    exit of the job), and the message names the rank."""
+    world = 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_groups, args=(r, world, port, q, "nccl", 2)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(outs) == [0, 1, 2, 3]
+    for r in range(world):
+        assert "failed on ranks [2] only" in outs[r] and "not falling back" in outs[r], outs
+
+
+@pytest.mark.parametrize("backend,force_fail", [("gloo", False), ("nccl", True), ("nccl", False)])
 def test_backend_agreement_and_tensor_payload(backend, force_fail):
     """init_groups: a gloo control group, and the gather's backend agreed by all ranks.  With RCCL made to fail on
-    every rank (there is no GPU here) every rank ends up on gloo together and says why; the gather takes the uint8
-    tensor payload of the device-resident path."""
+    every rank (there is no GPU here) every rank ends up on gloo together and says why; without the hook the
+    precondition (one GPU per rank) already says no; the gather takes the uint8 tensor payload of the device-resident
+    path."""
     world = 4
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -184,6 +215,8 @@ def test_backend_agreement_and_tensor_payload(backend, force_fail):
     assert idxA == [0] * 3 + [2] * 7 + [3] * 1 and idxB == [100, 101, 102] + list(range(100, 107)) + [100]
     if force_fail:
         assert desc.startswith("gloo (RCCL failed to initialise") and "forced" in desc
+    elif backend == "nccl":
+        assert desc == "gloo (RCCL not attempted: a rank has no GPU)"
     else:
         assert desc == "gloo"
     assert all(o[1] == desc for o in outs if len(o) == 2)

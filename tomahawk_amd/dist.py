@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import datetime
 import os
+import time
 
 import numpy as np
 import torch
@@ -51,51 +52,103 @@ def window_total_pairs(n_variants: int, window_variants: int) -> int:
     return int(np.minimum(window_variants, n_variants - 1 - np.arange(n_variants, dtype=np.int64)).sum())
 
 
+def _physical_device(device) -> str:
+    """A name for the GPU behind a torch device that is the same in every process of the node, whatever each process
+    was allowed to see: its UUID or PCI address where torch exposes them, else the visible index."""
+    if device is None or device.type != "cuda":
+        return ""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    try:
+        p = torch.cuda.get_device_properties(idx)
+        uuid = getattr(p, "uuid", None)
+        if uuid is not None and str(uuid).strip("0-"):
+            return f"uuid {uuid}"
+        if hasattr(p, "pci_bus_id"):
+            return f"pci {getattr(p, 'pci_domain_id', 0):04x}:{p.pci_bus_id:02x}:{getattr(p, 'pci_device_id', 0):02x}"
+    except Exception:                   # noqa: BLE001
+        pass
+    return f"visible index {idx} ({os.environ.get('HIP_VISIBLE_DEVICES') or os.environ.get('CUDA_VISIBLE_DEVICES') or 'all'})"
+
+
 def init_groups(backend: str, device: torch.device | None, force_rccl_failure: bool = False, timeout_s: int = 300):
     """Bring up torch.distributed for the bench: a gloo group for control traffic (barriers, the statistics
     all-reduce, the agreement below) and, for backend "nccl", an RCCL group for the gather of the survivors.
 
-    Whether RCCL is usable is *agreed* before anyone depends on it: every rank tries to create the RCCL group and to
-    run one small gather + barrier on it, then the outcomes are all-reduced over gloo.  Only if every rank succeeded is
-    the RCCL group used; if every rank failed the gather runs over gloo (reported in the JSON line); ranks never end
-    up in different backends.  A rank that hangs inside RCCL while others failed is ended by the group's timeout,
-    which exits the job non-zero - an asymmetric failure is an error, not a fallback.
+    Whether RCCL is usable is *agreed* before anyone depends on it, in three steps over gloo:
+    1. a cheap precondition - every rank names the GPU it sits on, and RCCL is only attempted when no two ranks of the
+       node share one (RCCL refuses a duplicate device; found here it costs nothing, found inside `new_group` it can leave
+       the other ranks waiting for the group's timeout);
+    2. every rank creates the RCCL group and the outcomes are all-reduced;
+    3. every rank runs one small gather + barrier on it (rings and point-to-point channels are set up lazily) and the
+       outcomes are all-reduced again.
+    All ranks succeeded -> RCCL.  All ranks failed alike (or the precondition said no) -> the gather runs over gloo and
+    the JSON line says why.  Some succeeded and some failed -> RuntimeError on every rank (non-zero exit): an
+    asymmetric failure is an error, not a fallback - the ranks that did not fail have typically sat in RCCL until its
+    timeout, and a run that silently continues five minutes later on another transport measures nothing.
     -> (gather_group, tensor_device, description)"""
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")       # one node: the hostname may not resolve, loopback always does
     dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=max(timeout_s, 600)))
     cpu = torch.device("cpu")
-    if backend != "nccl":
+    world = dist.get_world_size()
+
+    def over_gloo(why):
         gather_records(np.zeros(1, dtype=RECORD_DTYPE), dst=0, device=cpu)
         dist.barrier()
-        return None, cpu, "gloo"
+        return None, cpu, "gloo" + (f" ({why[:160]})" if why else "")
+
+    if backend != "nccl":
+        return over_gloo("")
+    # 1. one distinct GPU per rank?  (the physical device: a launcher may have narrowed every rank's visibility to "cuda:0")
+    devs = [None] * world
+    dist.all_gather_object(devs, _physical_device(device) or (f"(test hook) rank {dist.get_rank()}" if force_rccl_failure else ""))
+    if not all(devs):
+        return over_gloo("RCCL not attempted: a rank has no GPU")
+    if len(set(devs)) != world:
+        dup = next(d for d in devs if devs.count(d) > 1)
+        return over_gloo(f"RCCL not attempted: ranks {[r for r, d in enumerate(devs) if d == dup]} share one GPU ({dup})")
+
+    def agreed(ok, err, stage):
+        """-> True if every rank succeeded, False if every rank failed; raises if the ranks disagree."""
+        flag = torch.tensor([ok, 1 - ok], dtype=torch.int64)
+        dist.all_reduce(flag, op=dist.ReduceOp.SUM)
+        n_ok, n_bad = int(flag[0].item()), int(flag[1].item())
+        if n_bad == 0:
+            return True
+        msgs = [None] * world
+        dist.all_gather_object(msgs, err)
+        if n_ok:
+            raise RuntimeError(f"RCCL {stage} failed on ranks {[r for r, m in enumerate(msgs) if m]} only "
+                               f"({next(m for m in msgs if m)[:200]}): not falling back")
+        agreed.why = next((m for m in msgs if m), "unknown")
+        return False
+
+    # 2. the group
     ok, err, group = 1, "", None
     try:
-        if force_rccl_failure:          # test hook
+        if force_rccl_failure is True:  # test hook (any other true value only waives the precondition: CPU tests)
             raise RuntimeError("forced by TWK_BENCH_FORCE_RCCL_FAILURE")
         group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=timeout_s), device_id=device)
     except Exception as e:              # noqa: BLE001 - whatever RCCL throws, the outcome is agreed below
         ok, err = 0, repr(e)
-    flag = torch.tensor([ok], dtype=torch.int64)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    if int(flag.item()) == 1:
-        # rings and the point-to-point channels of the gather are set up lazily on first use: once here, outside any step
-        try:
-            gather_records(np.zeros(1, dtype=RECORD_DTYPE), dst=0, device=device, group=group)
-            dist.barrier(group=group)
-        except Exception as e:          # noqa: BLE001
-            ok, err = 0, repr(e)
-        flag = torch.tensor([ok], dtype=torch.int64)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    if int(flag.item()) == 1:
-        return group, device, "nccl"
-    # at least one rank could not use RCCL: everyone gathers over gloo, and says why
-    msgs = [None] * dist.get_world_size()
-    dist.all_gather_object(msgs, err)
-    why = next((m for m in msgs if m), "unknown")
-    gather_records(np.zeros(1, dtype=RECORD_DTYPE), dst=0, device=cpu)
-    dist.barrier()
-    return None, cpu, f"gloo (RCCL failed to initialise: {why[:120]})"
+    if not agreed(ok, err, "group creation"):
+        return over_gloo(f"RCCL failed to initialise: {agreed.why}")
+    # 3. first use, outside any step
+    try:
+        gather_records(np.zeros(1, dtype=RECORD_DTYPE), dst=0, device=device, group=group)
+        dist.barrier(group=group)
+        if device is not None and device.type == "cuda":
+            torch.cuda.synchronize(device)
+    except Exception as e:              # noqa: BLE001
+        ok, err = 0, repr(e)
+    if not agreed(ok, err, "first gather"):
+        return over_gloo(f"RCCL failed to initialise: {agreed.why}")
+    return group, device, "nccl"
+
+
+# The last gather_records of this process: payload bytes that crossed between ranks (dst: received, others: sent) and the
+# seconds from the moment every rank had arrived (the counts all-gather) to the end of the transfers.
+LAST_GATHER = {"bytes": 0, "seconds": 0.0}
 
 
 def gather_records(recs, dst: int = 0, device: torch.device | None = None, group=None, to_host: bool = True):
@@ -133,6 +186,8 @@ def gather_records(recs, dst: int = 0, device: torch.device | None = None, group
     dist.all_gather(gathered, cnt, group=group)
     counts = [int(c.item()) for c in gathered]
     total = sum(counts)
+    t_counts = time.perf_counter()          # every rank has arrived: what follows is the transfer itself
+    LAST_GATHER["bytes"], LAST_GATHER["seconds"] = (total - counts[dst]) * ITEM if rank == dst else n_mine * ITEM, 0.0
     if total == 0:
         return deliver(torch.empty(0, dtype=torch.uint8, device=device)) if rank == dst else None
 
@@ -153,6 +208,13 @@ def gather_records(recs, dst: int = 0, device: torch.device | None = None, group
     if ops:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
+        if device.type == "cuda":
+            # For RCCL wait() only orders torch's current stream behind the transfer; the host runs on.  A sender's
+            # payload is the engine's own HBM buffer (HipLd.device_records_tensor), which the next compute call rewrites
+            # on the engine's streams - memory torch's allocator knows nothing about - so the transfer must have
+            # *finished* before this function returns, on senders and on the receiver alike.
+            torch.cuda.current_stream(device).synchronize()
+    LAST_GATHER["seconds"] = time.perf_counter() - t_counts
     if rank != dst:
         return None
     return deliver(out)
