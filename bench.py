@@ -156,55 +156,167 @@ def measure_traffic(config_args, log):
     return {"bytes_per_launch": per_launch, "read_bytes_per_launch": 2.0 * fetch_b / n_f, "write_bytes_per_launch": write_b / n_w, "launches": n_f}
 
 
-def e2e_from_disk(n_samples, n_variants, log):
-    """`tomahawk calc` (default mode: r2 screen on) from a cohort-shaped .twk on disk -> dict for the JSON line."""
+def _secs(txt):
+    """The CLI prints [Hh][Mm]S.sss"s" (twk_util.h elapsed_string)."""
+    mo = re.fullmatch(r"(?:(\d+)h)?(?:(\d+)m)?([0-9.]+)s\.?", txt or "")
+    return (int(mo.group(1) or 0) * 3600 + int(mo.group(2) or 0) * 60 + float(mo.group(3))) if mo else None
+
+
+def run_cli(twk, flags, threads, out):
+    """One `tomahawk calc` run -> dict parsed from its log (None if it failed): wall, load, compute + write, pairs, records,
+    the kernels' own times (HIP events, as the engine reports them) and the writer's share."""
     from tomahawk_amd import hostlib
-    threads = min(os.cpu_count() or 8, 64)
-    twk = os.path.join(tempfile.gettempdir(), f"twk_bench_cohort_{n_samples}_{n_variants}.twk")
-    if not os.path.exists(twk):
-        t0 = time.time()
-        hostlib.write_cohort_twk(twk + ".tmp", n_samples, n_variants, seed=11, n_threads=threads, block_size=128)
-        os.replace(twk + ".tmp", twk)
-        os.sync()                  # the timed runs should read the file, not compete with its write-back
-        log(f"e2e: wrote {twk} ({os.path.getsize(twk) / 1e6:.0f} MB) in {time.time() - t0:.1f}s")
-    out = os.path.join(tempfile.gettempdir(), f"twk_bench_e2e_{os.getpid()}.two")
-    res, runs = None, []
-    for attempt in ("warm-up (the input was just written)", "timed 1", "timed 2"):
-        t0 = time.time()
-        r = subprocess.run([hostlib.CLI_PATH, "calc", "-i", twk, "-o", out, "-t", str(threads)], capture_output=True, text=True)
-        wall = time.time() - t0
-        if r.returncode != 0:
-            log("e2e: tomahawk calc failed: " + r.stderr[-300:])
+    t0 = time.time()
+    r = subprocess.run([hostlib.CLI_PATH, "calc", "-i", twk, "-o", out, "-t", str(threads)] + list(flags), capture_output=True, text=True)
+    wall = time.time() - t0
+    if r.returncode != 0:
+        return {"error": r.stderr[-300:]}
+    lg = r.stderr
+    load = re.search(r"Unpacked and uploaded .* variants\. (\S+)", lg)
+    fin = re.search(r"Finished in (\S+)\. Variants: ([0-9,]+), genotypes: [0-9,]+, output: ([0-9,]+)", lg)
+    eng = re.search(r"count kernel ([0-9.e+]+) ms in (\d+) launches \(([0-9.e+-]+) % [^)]*\), math kernels ([0-9.e+]+) ms", lg)
+    lst = re.search(r"carrier-list kernel ([0-9.e+]+) ms in (\d+) launches over ([0-9,]+) rare pairs", lg)
+    fus = re.search(r"(\d+) launches fused count -> r2 screen, ([0-9,]+) candidate", lg)
+    wri = re.search(r"the producer spent ([0-9.e+-]+) s handing", lg)
+    pairs = int(fin.group(2).replace(",", "")) if fin else None
+    cw = _secs(fin.group(1)) if fin else None
+    res = {"wall_s": wall, "load_s": _secs(load.group(1)) if load else None, "compute_write_s": cw,
+           "pairs": pairs, "records": int(fin.group(3).replace(",", "")) if fin else None,
+           "pairs_per_s_compute_write": pairs / cw if pairs and cw else None,
+           "pairs_per_s_wall": pairs / wall if pairs else None,
+           "two_bytes": os.path.getsize(out) if os.path.exists(out) else None,
+           "dominant_kernel": ("twk::k_count_screen_t / k_count_screen_unphased_t" if fus else "twk::k_count_list_t"),
+           "count_kernel_ms": float(eng.group(1)) if eng else None, "count_launches": int(eng.group(2)) if eng else None,
+           "avg_launch_ms": float(eng.group(1)) / max(int(eng.group(2)), 1) if eng else None,
+           # the engine's own figure: word pairs it contracted / kernel time against 2.62e13 (and+bcnt); x 2/3 = of the lane peak
+           "and_bcnt_ceiling_frac": float(eng.group(3)) / 100.0 if eng else None,
+           "frac": float(eng.group(3)) / 100.0 * (2.0 / 3.0) if eng else None,
+           "math_kernels_ms": float(eng.group(4)) if eng else None,
+           "list_kernel_ms": float(lst.group(1)) if lst else None,
+           "pairs_decided_by_carrier_lists": int(lst.group(3).replace(",", "")) if lst else None,
+           "fused_launches": int(fus.group(1)) if fus else 0,
+           "producer_handover_s": float(wri.group(1)) if wri else None}
+    return res
+
+
+def timed_cli(tag, twk, flags, threads, log, runs=2, warm=True):
+    """`runs` timed runs (after an untimed one if `warm`) -> the faster run's dict + both walls."""
+    out = os.path.join(tempfile.gettempdir(), f"twk_bench_{tag}_{os.getpid()}.two")
+    got = []
+    for attempt in (["warm-up"] if warm else []) + [f"timed {i + 1}" for i in range(runs)]:
+        res = run_cli(twk, flags, threads, out)
+        if res is None or "error" in res:
+            log(f"{tag}: tomahawk calc failed: {res}")
             return None
-        lg = r.stderr
-        load = re.search(r"Unpacked and uploaded .* variants\. (\S+)", lg)
-        fin = re.search(r"Finished in (\S+)\. Variants: ([0-9,]+), genotypes: [0-9,]+, output: ([0-9,]+)", lg)
-        eng = re.search(r"count kernel ([0-9.e+]+) ms in (\d+) launches \(([0-9.e+-]+) % [^)]*\), math kernels ([0-9.e+]+) ms", lg)
-        lst = re.search(r"carrier-list kernel ([0-9.e+]+) ms in (\d+) launches over ([0-9,]+) rare pairs", lg)
-        def secs(txt):          # the CLI prints [Hh][Mm]S.sss"s" (twk_util.h elapsed_string)
-            mo = re.fullmatch(r"(?:(\d+)h)?(?:(\d+)m)?([0-9.]+)s\.?", txt)
-            return (int(mo.group(1) or 0) * 3600 + int(mo.group(2) or 0) * 60 + float(mo.group(3))) if mo else None
-        res = {"wall_s": wall, "load_s": secs(load.group(1)) if load else None,
-               "compute_write_s": secs(fin.group(1)) if fin else None,
-               "pairs": int(fin.group(2).replace(",", "")) if fin else None,
-               "records": int(fin.group(3).replace(",", "")) if fin else None,
-               "two_bytes": os.path.getsize(out) if os.path.exists(out) else None,
-               "screen": "on", "count_kernel_ms": float(eng.group(1)) if eng else None,
-               "math_kernels_ms": float(eng.group(4)) if eng else None,
-               "list_kernel_ms": float(lst.group(1)) if lst else None,
-               "pairs_decided_by_carrier_lists": int(lst.group(3).replace(",", "")) if lst else None,
-               "input": f"{n_samples} samples x {n_variants} cohort-shaped variants (founder mosaics, 70 % rare), "
-                        f"{os.path.getsize(twk) / 1e6:.0f} MB .twk, calc default mode -t {threads}"}
-        log(f"e2e {attempt}: wall {wall:.2f}s {res}")
+        log(f"{tag} {attempt}: wall {res['wall_s']:.2f}s compute+write {res['compute_write_s']} count {res['count_kernel_ms']} ms "
+            f"in {res['count_launches']} launches, records {res['records']}")
         if attempt.startswith("timed"):
-            runs.append(res)
+            got.append(res)
     try:
         os.remove(out)
     except OSError:
         pass
-    # the faster of the two timed runs (the page cache of a box that has just written 3.65 GB is not steady), both walls reported
-    res = min(runs, key=lambda x: x["wall_s"])
-    res["wall_s_of_both_timed_runs"] = [x["wall_s"] for x in runs]
+    best = min(got, key=lambda x: x["wall_s"])
+    best["wall_s_of_timed_runs"] = [x["wall_s"] for x in got]
+    best["command"] = "tomahawk calc " + " ".join(flags) + f" -t {threads}"
+    return best
+
+
+def cohort_twk(n_samples, n_variants, log, **kw):
+    """The cohort-shaped input of the from-disk runs, written once per box under /tmp."""
+    from tomahawk_amd import hostlib
+    threads = min(os.cpu_count() or 8, 64)
+    tag = "_".join(f"{k}{v}" for k, v in sorted(kw.items()))
+    twk = os.path.join(tempfile.gettempdir(), f"twk_bench_cohort_{n_samples}_{n_variants}{'_' + tag if tag else ''}.twk")
+    if not os.path.exists(twk):
+        t0 = time.time()
+        args = dict(seed=11, n_threads=threads, block_size=128)
+        args.update(kw)
+        hostlib.write_cohort_twk(twk + ".tmp", n_samples, n_variants, **args)
+        os.replace(twk + ".tmp", twk)
+        os.sync()                  # the timed runs should read the file, not compete with its write-back
+        log(f"wrote {twk} ({os.path.getsize(twk) / 1e6:.0f} MB) in {time.time() - t0:.1f}s")
+    return twk, threads
+
+
+def e2e_from_disk(n_samples, n_variants, log, flags=(), tag="e2e"):
+    """`tomahawk calc` (default mode: r2 screen on; flags: e.g. -u) from a cohort-shaped .twk on disk -> dict for the JSON line."""
+    twk, threads = cohort_twk(n_samples, n_variants, log)
+    res = timed_cli(tag, twk, list(flags), threads, log)
+    if res:
+        res["screen"] = "on"
+        res["input"] = (f"{n_samples} samples x {n_variants} cohort-shaped variants (founder mosaics, 70 % rare), "
+                        f"{os.path.getsize(twk) / 1e6:.0f} MB .twk")
+        res["wall_s_of_both_timed_runs"] = res["wall_s_of_timed_runs"]
+    return res
+
+
+# The reference's only published workloads (docs/tutorial.md:177-199, 252-253; BASELINE.md): 1000 Genomes chr6, 2,504 samples,
+# 531,500 variants, `calc -p` r2 >= 0.1 over all 141,245,859,250 pairs (49.9 M records; 26 m 13 s on 8 CPU threads = 89.8 M
+# pairs/s), and `calc -p -w 4000000`.  Here on a cohort-shaped synthetic .twk of the same shape: positions 322 bp apart
+# (171 Mb / 531,500), founder mosaics that switch between blocks of 500 variants.
+KG = dict(n_samples=2504, n_variants=531_500, spacing=322, block_size=500, seed=6, p_switch=0.02)
+
+
+def extra_kg(log):
+    kw = {k: v for k, v in KG.items() if k not in ("n_samples", "n_variants")}
+    twk, threads = cohort_twk(KG["n_samples"], KG["n_variants"], log, **kw)
+    out = {"input": f"{KG['n_samples']} samples x {KG['n_variants']} cohort-shaped variants, {os.path.getsize(twk) / 1e6:.0f} MB .twk "
+                    f"(the shape of the reference's tutorial run, docs/tutorial.md:177-199)",
+           "reference_published": {"all_pairs": "89.8 M pairs/s, 26 m 12.8 s, 49,870,388 records (8 CPU threads, SSE4, 1000 Genomes chr6)",
+                                   "window_4mb": "72.1 M pairs/s (4,784,608 variants)"}}
+    out["all_pairs"] = timed_cli("kg_all", twk, ["-p"], threads, log, runs=1, warm=True)
+    out["window_4mb"] = timed_cli("kg_w4m", twk, ["-p", "-w", "4000000"], threads, log, runs=1, warm=False)
+    return out
+
+
+def extra_in_process(config, log, steps, warmup, seed=42, emulate_shard=None):
+    """Another BASELINE config on this GPU through the same calls as the timed region (synthetic input in HBM) -> dict."""
+    import tomahawk_amd as T
+    from tomahawk_amd.dist import window_slab
+    n_samples, n_variants, mode = CONFIGS[config]
+    hip_mode = T.MODE_UNPHASED if mode == "unphased" else T.MODE_PHASED
+    filters = T.Filters(minP=MIN_P.get(config, 1.0))
+    window_bp = WINDOW_BP.get(config, 0)
+    eng = T.HipLd(0)
+    try:
+        t0 = time.time()
+        if window_bp:
+            k, n = emulate_shard
+            r0, r1, col_end, expected = window_slab(n_variants, window_bp // 100, k, n)
+            eng.set_problem(n_samples, col_end - r0)
+            eng.generate_synthetic(seed, first_variant=r0)
+            call = lambda: eng.ld_region(hip_mode, filters, 0, r1 - r0, 0, col_end - r0, True, window=1, l_window=window_bp)
+        else:
+            eng.set_problem(n_samples, n_variants)
+            eng.generate_synthetic(seed)
+            call = lambda: eng.ld_all(hip_mode, filters)
+        setup = time.time() - t0
+        for _ in range(warmup):
+            call()
+        eng.timing_reset()
+        t0 = time.perf_counter()
+        pairs = recs = 0
+        for _ in range(steps):
+            _, p, r = call()
+            pairs += p; recs += r
+        el = time.perf_counter() - t0
+        tm = eng.timing()
+    finally:
+        eng.close()
+    lane_ops = 2 * ((2 * n_samples + 31) // 32) if mode == "phased" else 8 * ((n_samples + 31) // 32)
+    k_s = tm["count_ms"] * 1e-3
+    res = {"workload": f"BASELINE {NAMES[config]}: {n_samples} x {n_variants} {mode}" + (f", +-{window_bp} bp, P<={filters.minP:g}, EMULATED shard {emulate_shard[0]}/{emulate_shard[1]}" if window_bp else ""),
+           "steps": steps, "warmup": warmup, "pairs_per_step": pairs // max(steps, 1), "value": pairs / el, "unit": "variant-pairs/s",
+           "ms_per_step": el / steps * 1e3, "survivors_per_step": recs / steps, "setup_s": setup,
+           "dominant_kernel": "twk::k_count_list_t", "count_launches_per_step": tm["count_launches"] / steps,
+           "avg_launch_ms": tm["count_ms"] / max(tm["count_launches"], 1), "count_kernel_ms_per_step": tm["count_ms"] / steps,
+           "math_kernels_ms_per_step": tm["stats_ms"] / steps,
+           "frac": pairs * lane_ops / k_s / VALU_LANE_PEAK if k_s > 0 else None,
+           "and_bcnt_ceiling_frac": pairs * lane_ops / 2 / k_s / VALU_PAIR_PEAK if k_s > 0 else None,
+           "executed_frac_of_and_bcnt_ceiling": tm["row_pairs"] * tm["words_per_row"] / k_s / VALU_PAIR_PEAK if k_s > 0 else None}
+    log(f"extra {config}: {res['value'] / 1e6:.1f} M pairs/s, {res['ms_per_step']:.1f} ms/step, count {res['count_kernel_ms_per_step']:.1f} ms, "
+        f"and+bcnt {res['and_bcnt_ceiling_frac']}")
     return res
 
 
@@ -226,6 +338,8 @@ def main():
     ap.add_argument("--keep-two", default="", help="rank 0 keeps the .two file of the last timed step at this path")
     ap.add_argument("--no-e2e", action="store_true", help="skip the from-disk `tomahawk calc` measurement (N=1, cfg3)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 counter passes behind roofline.traffic (N=1)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the other regimes reported under \"extra\" (N=1, cfg3): configs[1], a "
+                    "configs[4] shard, calc -u from disk, the reference's published 2,504 x 531,500 runs")
     ap.add_argument("--e2e-variants", type=int, default=0, help="variants of the e2e input (0: the config's own count)")
     ap.add_argument("--engine-option", action="append", default=[], metavar="KEY=INT", help="a switch of the engine "
                     "(twk_hip_set_option, include/twk_hip.h; measurement runs of profiles/collect.sh)")
@@ -509,6 +623,23 @@ def main():
                 e2e = None
             if e2e:
                 out["e2e"] = e2e
+        if world == 1 and not args.no_extra and args.config == "cfg3" and not args.emulate_shard and not args.variants and not args.samples:
+            # Every other regime the repository makes claims about, under the same clock as the headline (after the timed
+            # region, like cpu_baseline / e2e): each with its pairs/s, dominant kernel, average launch and roofline fraction.
+            eng.close()
+            extra = {}
+            for name, fn in (("cfg2", lambda: extra_in_process("cfg2", log, steps=20, warmup=3)),
+                             ("cfg5_shard", lambda: extra_in_process("cfg5", log, steps=1, warmup=0, emulate_shard=(3, 8))),
+                             ("e2e_u", lambda: e2e_from_disk(n_samples, args.e2e_variants or n_variants, log, flags=("-u",), tag="e2e_u")),
+                             ("kg", lambda: extra_kg(log))):
+                t_x = time.time()
+                try:
+                    extra[name] = fn()
+                except Exception as e:   # never take the GPU number down with it
+                    log(f"extra {name} failed: {e!r}")
+                    extra[name] = None
+                log(f"extra {name}: {time.time() - t_x:.1f}s")
+            out["extra"] = extra
         print(json.dumps(out), flush=True)
     eng.close()
     if world > 1:

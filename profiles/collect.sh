@@ -114,6 +114,49 @@ PY
 		for ac in 2 10 100 1000; do timeout 600 $R/build/list_vs_dense 5008 $ac 16384 3 >> $OUT/t2_list_vs_dense.txt 2>&1; done
 		cat $OUT/t2_list_vs_dense.txt
 		;;
+	small_n_pmc)   # where do short rows lose their time?  The count kernel alone (csrc/tools/count_microbench, list kernel in patch
+		# order, rectangle of 16,384 x 16,384 plane rows = 16,384 tiles) at 5, 10 and 40 K-chunks per tile - the same word pairs
+		# per tile-chunk, only the per-tile events (ticket, descriptor loads, epilogue, first LDS wait of a unit) differ in
+		# frequency - under SQ counter passes of <= 8 counters each (those this chip's rocprofv3 lists).
+		rocprofv3 -L > $OUT/rocprofv3_avail.txt 2>&1
+		want="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM SQ_ACTIVE_INST_MISC SQ_INSTS_VMEM SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_FLAT SQ_INSTS_FLAT SQ_INST_CYCLES_SALU SQ_WAVES SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_IFETCH SQ_INSTS_BRANCH SQ_INSTS_SENDMSG SQ_WAIT_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_LEVEL_WAVES SQ_INSTS_WAVE32_LDS SQ_INSTS_GDS SQ_ACTIVE_INST_EXP_GDS SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_SMEM SQ_IFETCH_LEVEL SQ_CYCLES SQ_WAVES_EQ_64 SQ_ITEMS SQ_INSTS_EXP_GDS SQ_INSTS_LDS_LOAD SQ_INSTS_LDS_STORE SQ_INSTS_LDS_ATOMIC"
+		have=""; for c in $want; do grep -qw "$c" $OUT/rocprofv3_avail.txt && have="$have $c"; done
+		echo "counters available: $have" | tee $OUT/small_n_pmc_counters.txt
+		for words in 160 320 1280; do
+			echo "== count_microbench 16384 x $words (${words}/32 chunks per tile), kernel alone"
+			ONLYMODE=2 timeout 300 $R/build/count_microbench 16384 $words 3 | tee $OUT/small_n_w${words}_time.txt
+			set -- $have; pass=0
+			while [ $# -gt 0 ]; do
+				grp=""; n=0; while [ $# -gt 0 ] && [ $n -lt 7 ]; do grp="$grp $1"; shift; n=$((n+1)); done
+				rm -rf /tmp/pmc_sn
+				ONLYMODE=2 timeout 600 rocprofv3 --pmc $grp --output-format csv -d /tmp/pmc_sn -o sn -- $R/build/count_microbench 16384 $words 1 > /dev/null 2> $OUT/small_n_w${words}_p${pass}.log
+				f=$(find /tmp/pmc_sn -name "*counter_collection.csv" | head -1)
+				[ -n "$f" ] && python3 $R/profiles/sum_counters.py "$f" > $OUT/small_n_w${words}_p${pass}_pmc_sums.json || echo "pass $pass ($grp) gave no counters: $(tail -2 $OUT/small_n_w${words}_p${pass}.log)"
+				pass=$((pass+1))
+			done
+		done
+		python3 - <<PY
+import glob, json, re
+out = {}
+for words in (160, 320, 1280):
+    row = {}
+    for f in sorted(glob.glob("$OUT/small_n_w%d_p*_pmc_sums.json" % words)):
+        d = json.load(open(f))
+        for k, v in d.items():
+            if "k_count_list_t" in k:
+                n = v.get("launches", 1)
+                for c, x in v.items():
+                    if c != "launches": row[c] = x / n
+    t = open("$OUT/small_n_w%d_time.txt" % words).read()
+    m = re.search(r"list/patch .* best ([0-9.]+) ms .*\(([0-9.]+)% of the and\+bcnt", t)
+    if m: row["best_ms"] = float(m.group(1)); row["pct_of_and_bcnt_ceiling"] = float(m.group(2))
+    out["%d chunks per tile" % (words // 32)] = row
+json.dump(out, open("$OUT/small_n_pmc.json", "w"), indent=1, sort_keys=True)
+ks = sorted({k for r in out.values() for k in r})
+print("%-28s" % "per launch" + "".join("%18s" % k for k in out))
+for k in ks: print("%-28s" % k + "".join("%18.6g" % out[c].get(k, float("nan")) for c in out))
+PY
+		;;
 	kg_prof)  # the small-N regime (the reference's published shape, 2,504 samples x 200,000 cohort-shaped variants): kernel traces of
 		# `calc -p -w 1000000` (33 M surviving pairs) and of all-vs-all `-r 0.8` without the allele-count band, each with the
 		# fused count -> r2 screen kernel (default) and without it (--engine-option fused=0)

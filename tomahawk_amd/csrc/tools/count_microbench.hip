@@ -2,6 +2,7 @@
 //   grid  k_count_tile_t   one block per 128 x 128 tile (2-D grid; the round-1 kernel)
 //   list  k_count_list_t   persistent blocks over a tile list, data-parallel rounds + stream-K tail
 // usage: count_microbench [rows=4096] [words=3136] [reps=3] [blocks=512]
+//   ONLYMODE=2: only the list kernel in patch order on the rectangle (rocprofv3 counter passes)
 //   NOSTORE=1: the list kernel without its epilogue (what the C stores cost: nothing measurable - 87.7 -> 88.3 % of the
 //   ceiling at 5 chunks a tile; the self-check then fails by design)
 #include <hip/hip_runtime.h>
@@ -61,10 +62,12 @@ int main(int argc,char**argv){
     printf("  first 16 blocks: "); for(uint32_t b=0;b<16;++b) printf("[b%u xcc%llu hw%05llx t%.0f] ",b,o[2*b+1]>>32&15,o[2*b+1]&0xFFFFF,(o[2*b]-t0)/100.0); printf("\n");
     return 0;
   }
-  for(int diag=0; diag<2; ++diag){
+  const int only_mode = getenv("ONLYMODE")? atoi(getenv("ONLYMODE")) : -1;     // counter passes: one kernel form (2 = list/patch), rectangle only
+  for(int diag=0; diag<(only_mode>=0?1:2); ++diag){
     double tiles = diag? (double)(R/128)*(R/128+1)/2 : (double)(R/128)*(R/128);
     double wordops = tiles*128*128*W;
     for(int mode=0; mode<3; ++mode){     // 0 grid, 1 list row-major, 2 list patch order, 3.. timing probes
+      if(only_mode>=0 && mode!=only_mode) continue;
       std::vector<uint32_t> list; twk::CountWork w{};
       if(mode){ list=make_list(R/128,diag,mode>=2); CK(hipMemcpy(dl,list.data(),list.size()*4,hipMemcpyHostToDevice));
         w.rows=d; w.W=W; w.rowA0=0; w.rowB0=0; w.tiles=dl; w.C=C; w.ldc=R; w.ticket=tick; first_split=twk::build_count_units((uint32_t)list.size(),W/twk::KC,P,min_chunks,units,getenv("SHAREDIV")?atoi(getenv("SHAREDIV")):8,getenv("TAILROUNDS")?atoi(getenv("TAILROUNDS")):8); CK(hipMemcpy(du,units.data(),units.size()*16,hipMemcpyHostToDevice)); w.units=du; w.n_units=(uint32_t)units.size(); w.n_queues=1; w.queue_begin[0]=0; w.queue_begin[1]=w.n_units; }
