@@ -166,6 +166,10 @@ def run_cli(twk, flags, threads, out):
     """One `tomahawk calc` run -> dict parsed from its log (None if it failed): wall, load, compute + write, pairs, records,
     the kernels' own times (HIP events, as the engine reports them) and the writer's share."""
     from tomahawk_amd import hostlib
+    try:
+        os.remove(out)             # (dropping a multi-gigabyte file of the previous run from the page cache is not part of this run)
+    except OSError:
+        pass
     t0 = time.time()
     r = subprocess.run([hostlib.CLI_PATH, "calc", "-i", twk, "-o", out, "-t", str(threads)] + list(flags), capture_output=True, text=True)
     wall = time.time() - t0
@@ -255,7 +259,9 @@ def e2e_from_disk(n_samples, n_variants, log, flags=(), tag="e2e"):
 # 531,500 variants, `calc -p` r2 >= 0.1 over all 141,245,859,250 pairs (49.9 M records; 26 m 13 s on 8 CPU threads = 89.8 M
 # pairs/s), and `calc -p -w 4000000`.  Here on a cohort-shaped synthetic .twk of the same shape: positions 322 bp apart
 # (171 Mb / 531,500), founder mosaics that switch between blocks of 500 variants.
-KG = dict(n_samples=2504, n_variants=531_500, spacing=322, block_size=500, seed=6, p_switch=0.02)
+# p_switch 0.12 (a haplotype's founder changes at 12 % of the block boundaries): 141.2 G pairs leave about as many records
+# as the reference's chr6 run did (tests/sweeps/kg_shape.py: 242 M records at 0.02, 36 M at 0.2, 22 M at 1.0).
+KG = dict(n_samples=2504, n_variants=531_500, spacing=322, block_size=500, seed=6, p_switch=0.12)
 
 
 def extra_kg(log):

@@ -157,6 +157,19 @@ print("%-28s" % "per launch" + "".join("%18s" % k for k in out))
 for k in ks: print("%-28s" % k + "".join("%18.6g" % out[c].get(k, float("nan")) for c in out))
 PY
 		;;
+	clock_probe)   # the shader clock the count kernel's blocks really run at (s_memtime against the constant 100 MHz counter, over each
+		# block's life; csrc/tools/count_microbench FINISH=1): one launch from idle, the 2nd and the 20th of launches back to back,
+		# at 5 / 10 / 40 chunks per tile (16,384 tiles) and at N = 1 M rows (977 chunks, 1,024 tiles).  The and+bcnt ceiling is
+		# quoted at 2.4 GHz; what a launch gets is in this file.
+		: > $OUT/clock_probe.txt
+		for reps in 1 2 20; do
+			for shape in "16384 160" "16384 320" "16384 1280" "4096 31264"; do
+				echo "-- FINISH_REPS=$reps count_microbench $shape" >> $OUT/clock_probe.txt
+				FINISH=1 FINISH_REPS=$reps timeout 300 $R/build/count_microbench $shape 1 2>&1 | head -2 >> $OUT/clock_probe.txt
+			done
+		done
+		cat $OUT/clock_probe.txt
+		;;
 	kg_prof)  # the small-N regime (the reference's published shape, 2,504 samples x 200,000 cohort-shaped variants): kernel traces of
 		# `calc -p -w 1000000` (33 M surviving pairs) and of all-vs-all `-r 0.8` without the allele-count band, each with the
 		# fused count -> r2 screen kernel (default) and without it (--engine-option fused=0)

@@ -349,3 +349,66 @@ def test_candidate_slot_windows_of_any_size_give_the_same_records(hip, opt, mode
             assert np.sort(base, order=ORDER).tobytes() == np.sort(got, order=ORDER).tobytes(), (chunk, tv)
     opt.unset("cand_chunk")
     opt.unset("fused")
+
+
+@pytest.mark.parametrize("mode", [T.MODE_PHASED, T.MODE_UNPHASED])
+def test_band_launches_equal_matrix_sized_tiles(hip, opt, mode):
+    """A fused launch leaves no count matrix behind, so the engine sizes it by its work: a band of rows over every column
+    the rows reach, at most 8 launches per region (twk_hip.hip region_impl; option band_launch).  Same records, bit for
+    bit, as the matrix-sized tiles of round 3 - all pairs, the allele-count band, a window, shards, a rectangle - as one
+    launch and (band_work_log2 small) as several; and when a launch outgrows its candidate list or its survivor buffer
+    (band_list_entries / record_cap small) its rows are redone as matrix-sized tiles.  The reference's shape: one pass
+    over the block pairs with nothing stored per pair (lib/ld/ld_engine.cpp:1898-2015)."""
+    N, M = 2504, 6000
+    al = _cohort_alleles(M, N, 4242)
+    util.upload(hip, al)
+    f = T.Filters(minR2=0.1)
+    calls = {
+        "all": lambda: hip.ld_all(mode, f),
+        "band": lambda: hip.ld_all(mode, f, window=T.OPT_R2_SCREEN),
+        "window": lambda: hip.ld_all(mode, f, window=T.OPT_WINDOW, l_window=40_000),
+        "shard": lambda: hip.ld_all(mode, f, part=1, n_parts=3),
+        "window shard": lambda: hip.ld_all(mode, f, part=2, n_parts=3, window=T.OPT_WINDOW, l_window=25_000),
+        "rectangle": lambda: hip.ld_region(mode, f, 100, 2000, 2500, 3300, False),
+    }
+    for name, call in calls.items():
+        opt.set("band_launch", 0)
+        hip.timing_reset()
+        base, np0, nr0 = call()
+        t0 = hip.timing()
+        assert t0["fused_launches"] == t0["count_launches"] > 1 and nr0 == len(base) > 100, name
+        want = np.sort(base, order=ORDER).tobytes()
+        opt.set("band_launch", 1)
+        for log2, n_launch in ((19, 1), (10, None), (4, 8)):
+            opt.set("band_work_log2", log2)
+            hip.timing_reset()
+            got, np1, nr1 = call()
+            t1 = hip.timing()
+            assert np1 == np0 and nr1 == nr0 and np.sort(got, order=ORDER).tobytes() == want, (name, log2)
+            assert t1["fused_launches"] == t1["count_launches"] and 1 <= t1["count_launches"] <= 8, (name, log2, t1)
+            if n_launch is not None and name in ("all", "window", "rectangle"):
+                assert t1["count_launches"] == n_launch, (name, log2, t1)
+            if name == "window":       # in (idxA, idxB) order launch after launch: the order the records reach the writer in
+                key = got["idxA"].astype(np.uint64) << np.uint64(32) | got["idxB"].astype(np.uint64)
+                assert (np.diff(key.astype(np.int64)) > 0).all(), (name, log2)
+        opt.set("band_work_log2", 19)
+        for key, value in (("band_list_entries", 1000), ("record_cap", 700)):
+            opt.set(key, value)
+            hip.timing_reset()
+            got, np1, nr1 = call()
+            t1 = hip.timing()
+            opt.unset(key)
+            assert np1 == np0 and nr1 == nr0 and np.sort(got, order=ORDER).tobytes() == want, (name, key)
+            assert t1["count_launches"] > 1, (name, key, t1)          # the band launch, then the tiles that redid it
+    # more survivors than one piece of the host staging buffer (2^20 records): they reach the sink piece by piece, in order
+    f_low = T.Filters(minR2=0.0004)
+    opt.set("band_launch", 0)
+    base, np0, nr0 = hip.ld_all(mode, f_low)
+    opt.set("band_launch", 1)
+    opt.set("band_list_entries", 1 << 25)
+    hip.timing_reset()
+    got, np1, nr1 = hip.ld_all(mode, f_low)
+    assert hip.timing()["count_launches"] == 1 and nr1 == nr0 == len(got) > (1 << 20) + 1000
+    assert np.sort(got, order=ORDER).tobytes() == np.sort(base, order=ORDER).tobytes()
+    key = got["idxA"].astype(np.uint64) << np.uint64(32) | got["idxB"].astype(np.uint64)
+    assert (np.diff(key.astype(np.int64)) > 0).all()

@@ -477,6 +477,8 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 	const int li = lane >> 3, lj = lane & 7;
 	const uint32_t nchunks = w.W / KC;
 	const uint32_t n_units = w.n_units;
+	unsigned long long probe_wall0 = 0, probe_clk0 = 0;      // EXPERIMENT == 5 only: the block's start on the constant 100 MHz clock and on the shader clock
+	if (EXPERIMENT == 5) { probe_wall0 = wall_clock64(); probe_clk0 = clock64(); }
 
 	// unit id -> (tile, first chunk, end chunk); wave-uniform (scalar loads)
 	auto decode = [&](uint32_t u, uint32_t& tl, uint32_t& c0, uint32_t& c1) {
@@ -640,8 +642,10 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 					uint32_t xcc, hwid;
 					asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
 					asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-					unsigned long long* o = reinterpret_cast<unsigned long long*>(w.C) + 2 * (size_t)blockIdx.x;
-					o[0] = wall_clock64(); o[1] = ((unsigned long long)xcc << 32) | hwid;
+					unsigned long long* o = reinterpret_cast<unsigned long long*>(w.C) + 4 * (size_t)blockIdx.x;
+					const unsigned long long wall1 = wall_clock64(), clk1 = clock64();
+					o[0] = wall1; o[1] = ((unsigned long long)xcc << 32) | hwid;
+					o[2] = wall1 - probe_wall0; o[3] = clk1 - probe_clk0;       // the block's life on both clocks: their ratio is the shader clock it ran at
 				}
 				break;
 			}

@@ -621,6 +621,9 @@ struct StatsParams {
 	twk_hip_record* out;
 	unsigned long long capacity;
 	unsigned long long* n_out; // device counter
+	// The survivors leave the device in (idxA, idxB) order (twk_hip.hip sort_records): the 64-bit sort key idxA << key_shift |
+	// idxB and the record's position are written next to the record where it is appended (null: not wanted).
+	unsigned long long* keys; uint32_t* vals; uint32_t key_shift;
 };
 
 // One pair of the super-tile: skips, window, cells -> math -> filters.  sA / sB: positions in the plane set; i / j the
@@ -705,7 +708,10 @@ __device__ __forceinline__ void d_append_survivor(const StatsParams& p, bool kee
 		unsigned long long slot = block_base;
 		for (int w = 0; w < wave; ++w) slot += wave_keep[w];
 		slot += (unsigned long long)__popcll(ballot & ((1ull << lane) - 1));
-		if (slot < p.capacity) p.out[slot] = rec;
+		if (slot < p.capacity) {
+			p.out[slot] = rec;
+			if (p.keys) { p.keys[slot] = (unsigned long long)rec.idxA << p.key_shift | rec.idxB; p.vals[slot] = (uint32_t)slot; }
+		}
 	}
 	__syncthreads();                              // (the next call overwrites the counts)
 }
@@ -902,7 +908,7 @@ template <bool LDS_TABLE>
 __global__ __launch_bounds__(LDS_TABLE ? 1024 : 256)
 void k_ld_fisher_t(twk_hip_record* __restrict__ recs, unsigned long long* __restrict__ n_out,
                    unsigned long long capacity, double minP, const LFact lfact_in, const uint32_t* __restrict__ index,
-                   unsigned long long index_limit, int prepared) {
+                   unsigned long long index_limit, int prepared, unsigned long long* __restrict__ keys) {
 	extern __shared__ double lf_lds[];
 	LFact lfact = lfact_in;
 	if (LDS_TABLE) {
@@ -931,7 +937,10 @@ void k_ld_fisher_t(twk_hip_record* __restrict__ recs, unsigned long long* __rest
 		double both = 1.;
 		if (walk) both = d_fisher_walks(lfact, w, f, i0, j0);
 		r->P = both;
-		if (both > minP) { r->idxA = TWK_DROPPED_RECORD; ++dropped; }
+		if (both > minP) {
+			r->idxA = TWK_DROPPED_RECORD; ++dropped;
+			if (keys) keys[r - recs] = ~0ull;          // sorts behind every kept record
+		}
 	}
 	// how many were dropped (n_out[1]): the host cuts them off behind the sort without looking at the records
 	for (int o = 32; o > 0; o >>= 1) dropped += __shfl_xor(dropped, o);

@@ -68,6 +68,7 @@ enum { MODE_INT_AUTO_CLEAN = 0x10,     // phased math on the plain planes; pairs
 struct Slot {                      // one in-flight tile (double buffered)
 	uint32_t* C = nullptr; size_t C_words = 0;
 	twk_hip_record* out = nullptr; unsigned long long capacity = 0;      // survivor buffer and its size (grow-only)
+	unsigned long long* keys = nullptr; uint32_t* vals = nullptr;        // [capacity]: sort key and position of every survivor, written where it is appended
 	unsigned long long cap_use = 0;               // ... of which the current launch may use this many (what the caller asked for)
 	unsigned long long* n_out = nullptr;          // device counters: [0] survivors appended, [1] of those dropped by the Fisher cut-off,
 	                                              // [2] candidates of the fused count kernel, [3] spare
@@ -107,6 +108,9 @@ struct Options {
 	long long fisher_lds = 1;        // log-factorial table in LDS while it fits
 	long long cand_chunk = -1;       // candidate slots a wave reserves at a time (-1: sized from the list)
 	long long record_cap = 0;        // cap on the survivor buffer of a launch (0: none): forces the overflow / strip path
+	long long band_launch = 1;       // fused runs: launches sized by work (a band of rows, all its columns), not by a count matrix
+	long long band_list_entries = 0; // candidate slots of such a launch (0: a sixteenth of its pairs, 4 M .. 1 G; else exactly this many): small values force its fallback
+	long long band_work_log2 = 19;   // ... and at least 2^n tile-chunks of work per launch (19: ~5 ms); small values make several launches of a small run
 };
 struct OptionKey { const char* name; long long Options::* field; long long lo, hi; bool rebuilds_planes; };
 const OptionKey OPTION_KEYS[] = {
@@ -117,6 +121,8 @@ const OptionKey OPTION_KEYS[] = {
 	{"skip_pad", &Options::skip_pad, 0, 1, false}, {"fisher_order", &Options::fisher_order, 0, 1, false},
 	{"fisher_lds", &Options::fisher_lds, 0, 1, false}, {"cand_chunk", &Options::cand_chunk, -1, 1 << 20, false},
 	{"record_cap", &Options::record_cap, 0, 1ll << 40, false},
+	{"band_launch", &Options::band_launch, 0, 1, false}, {"band_list_entries", &Options::band_list_entries, 0, 1ll << 32, false},
+	{"band_work_log2", &Options::band_work_log2, 0, 40, false},
 };
 }  // namespace
 
@@ -190,7 +196,9 @@ void free_slots(twk_hip_ctx* c) {
 	for (auto& s : c->slot) {
 		if (s.C) (void)hipFree(s.C);
 		if (s.out) (void)hipFree(s.out);
-		s.C = nullptr; s.C_words = 0; s.out = nullptr; s.capacity = 0;
+		if (s.keys) (void)hipFree(s.keys);
+		if (s.vals) (void)hipFree(s.vals);
+		s.C = nullptr; s.C_words = 0; s.out = nullptr; s.keys = nullptr; s.vals = nullptr; s.capacity = 0;
 		for (int k = 0; k < 2; ++k) {
 			if (s.h_tiles[k]) (void)hipHostFree(s.h_tiles[k]);
 			if (s.d_tiles[k]) (void)hipFree(s.d_tiles[k]);
@@ -343,8 +351,12 @@ int ensure_slot(twk_hip_ctx* c, Slot& s, size_t C_words, unsigned long long capa
 	}
 	if (s.capacity < capacity) {
 		if (s.out) (void)hipFree(s.out);
-		s.out = nullptr; s.capacity = 0;
+		if (s.keys) (void)hipFree(s.keys);
+		if (s.vals) (void)hipFree(s.vals);
+		s.out = nullptr; s.keys = nullptr; s.vals = nullptr; s.capacity = 0;
 		HIPCHK(c, hipMalloc((void**)&s.out, (size_t)capacity * sizeof(twk_hip_record)));
+		HIPCHK(c, hipMalloc((void**)&s.keys, (size_t)capacity * sizeof(unsigned long long)));
+		HIPCHK(c, hipMalloc((void**)&s.vals, (size_t)capacity * sizeof(uint32_t)));
 		s.capacity = capacity;
 	}
 	s.cap_use = capacity;
@@ -531,6 +543,9 @@ int launch_count(twk_hip_ctx* c, int set, const twk_hip_tile_desc& t, Slot& s, i
 	return TWK_HIP_OK;
 }
 
+// Bits of idxB in the sort key idxA << shift | idxB of a survivor.
+uint32_t key_shift_for(uint32_t n_variants) { uint32_t b = 1; while (b < 32 && (1ull << b) < n_variants) ++b; return b; }
+
 StatsParams make_stats(twk_hip_ctx* c, int set, const twk_hip_tile_desc& t, const Slot& s, bool phased_math,
                        int auto_select, const twk_hip_filters& f, const ColRange* cr = nullptr) {
 	const PlaneSet& ps = c->planes[set];
@@ -548,6 +563,7 @@ StatsParams make_stats(twk_hip_ctx* c, int set, const twk_hip_tile_desc& t, cons
 	p.phased_math = phased_math ? 1 : 0; p.auto_select = auto_select;
 	p.window = t.window; p.l_window = t.l_window;
 	p.filt = f; p.out = s.out; p.capacity = s.cap_use; p.n_out = s.n_out;
+	p.keys = s.keys; p.vals = s.vals; p.key_shift = key_shift_for(c->M);
 	return p;
 }
 
@@ -585,7 +601,7 @@ TilePlan plan_for(const twk_hip_ctx* c, int mode) {
 // Option "fisher_order" = 0: walks in the order the records were appended; "fisher_lds" = 0: log-factorial table read
 // from global memory also when it would fit LDS (measurement hooks).
 int launch_fisher(twk_hip_ctx* c, twk_hip_record* recs, unsigned long long* n_out, unsigned long long cap, double minP,
-                  uint32_t* scratch, size_t scratch_words) {
+                  uint32_t* scratch, size_t scratch_words, unsigned long long* keys = nullptr) {
 	const LFact lf{c->d_lfact, c->lfact_n};
 	const bool ordered = c->opt.fisher_order != 0, lds_ok = c->opt.fisher_lds != 0;
 	const bool lds_table = lds_ok && c->lfact_n <= FISHER_LDS_TABLE_MAX;
@@ -601,15 +617,29 @@ int launch_fisher(twk_hip_ctx* c, twk_hip_record* recs, unsigned long long* n_ou
 		hipLaunchKernelGGL(k_fisher_scatter, dim3(blocks), dim3(256), 0, c->s_compute, (const twk_hip_record*)recs, (const unsigned long long*)n_out, cap, limit, c->d_fisher_bins, scratch);
 	}
 	if (lds_table) hipLaunchKernelGGL(k_ld_fisher_t<true>, dim3(c->resident_blocks), dim3(1024), lds_bytes, c->s_compute, recs, n_out, cap, minP, lf,
-	                                  (const uint32_t*)(limit ? scratch : nullptr), limit, 1);
+	                                  (const uint32_t*)(limit ? scratch : nullptr), limit, 1, keys);
 	else hipLaunchKernelGGL(k_ld_fisher_t<false>, dim3(c->resident_blocks * 2), dim3(256), 0, c->s_compute, recs, n_out, cap, minP, lf,
-	                        (const uint32_t*)(limit ? scratch : nullptr), limit, 1);
+	                        (const uint32_t*)(limit ? scratch : nullptr), limit, 1, keys);
 	HIPCHK(c, hipGetLastError());
 	return TWK_HIP_OK;
 }
 
+// Would a launch of this mode run the fused count -> screen form (and nothing else: one pass)?  The same tests as
+// enqueue_tile / launch_count make, for the callers that size a launch by it.
+bool fused_form_applies(twk_hip_ctx* c, int mode, const twk_hip_filters& f) {
+	const TilePlan pl = plan_for(c, mode);
+	if (pl.set2 >= 0 || !c->fused_ok || c->opt.fused == 0) return false;
+	const int k = set_kind(pl.set1);
+	if (!((pl.phased1 && k == PK_PHASED) || (!pl.phased1 && k == PK_UNPHASED))) return false;
+	if (!(f.minR2 > 1e-6 && f.minR2 <= 1.0)) return false;
+	if (ensure_planes(c, pl.set1) != TWK_HIP_OK) return false;
+	return c->opt.fused == 2 || c->planes[pl.set1].W / KC <= FUSED_MAX_CHUNKS;
+}
+
+// list_words != 0: a band launch (region_impl) - the fused form with a candidate list of that many words and no count
+// matrix at all (its rectangle may be far beyond what a matrix could hold); it is an error if the launch does not fuse.
 int enqueue_tile(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, const twk_hip_filters& f, Slot& s,
-                 unsigned long long capacity, const ColRange* cr = nullptr) {
+                 unsigned long long capacity, const ColRange* cr = nullptr, size_t list_words = 0) {
 	const TilePlan pl = plan_for(c, mode);
 	const bool two_pass = pl.set2 >= 0;
 	const bool phased = pl.phased1;
@@ -617,7 +647,8 @@ int enqueue_tile(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, const twk
 	int rc = ensure_planes(c, kind1); if (rc) return rc;
 	if (two_pass) { rc = ensure_planes(c, kind2); if (rc) return rc; }
 	const Geometry g = tile_geometry(pl.Pmax, t);
-	rc = ensure_slot(c, s, (size_t)g.rowsA * g.rowsB, capacity); if (rc) return rc;
+	if (list_words && !fused_form_applies(c, mode, f)) return TWK_HIP_E_STATE;
+	rc = ensure_slot(c, s, list_words ? list_words : (size_t)g.rowsA * g.rowsB, capacity); if (rc) return rc;
 	s.two_pass = two_pass;
 
 	HIPCHK(c, hipMemsetAsync(s.n_out, 0, 4 * sizeof(unsigned long long), c->s_compute));
@@ -628,7 +659,7 @@ int enqueue_tile(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, const twk
 	FusedArgs fa{};
 	fa.unphased = fused_u ? 1 : 0;
 	ScreenWork& sw = fa.screen;
-	s.fused = false; s.is_list = false; s.cand_overflow = false; s.cand_cap = s.C_words / (fused_u ? 6 : 3);
+	s.fused = false; s.is_list = false; s.cand_overflow = false; s.cand_cap = (list_words ? list_words : s.C_words) / (fused_u ? 6 : 3);
 	if (want_fused) {
 		const PlaneSet& ps = c->planes[kind1];
 		fa.stats = make_stats(c, kind1, t, s, phased, pl.select1, f, cr);
@@ -667,7 +698,7 @@ int enqueue_tile(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, const twk
 	}
 	// Fisher's exact test on the compacted survivors (the slot's count / candidate buffer is free by now - the math
 	// kernels in front are done with it - and holds the walk-length order)
-	rc = launch_fisher(c, s.out, s.n_out, s.cap_use, f.minP, s.C, s.C_words); if (rc) return rc;
+	rc = launch_fisher(c, s.out, s.n_out, s.cap_use, f.minP, s.C, s.C_words, s.keys); if (rc) return rc;
 	HIPCHK(c, hipGetLastError());
 	s.minP = f.minP;
 	HIPCHK(c, hipMemcpyAsync(s.h_n_out, s.n_out, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->s_compute));
@@ -677,15 +708,9 @@ int enqueue_tile(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, const twk
 
 // Survivors are appended with an atomic counter, in no order.  They leave the device in (idxA, idxB) order
 // - the order the writer puts them in the file, which makes a one-GPU run's output deterministic - by a key
-// sort of (idxA << bits | idxB, position) and a gather; records the Fisher cut-off dropped sort behind the rest.
-__global__ void k_record_keys(const twk_hip_record* __restrict__ recs, unsigned long long n, uint32_t bits_b,
-                              unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals) {
-	const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n) return;
-	const uint32_t a = recs[i].idxA, b = recs[i].idxB;
-	keys[i] = a == TWK_DROPPED_RECORD ? ~0ull : ((unsigned long long)a << bits_b | b);
-	vals[i] = (uint32_t)i;
-}
+// sort of (idxA << bits | idxB, position) and a gather.  Key and position are written by the math kernels where the
+// record is appended (d_append_survivor); records the Fisher cut-off drops get the all-ones key from the Fisher kernel
+// and sort behind the rest.
 __global__ void k_gather_records(const twk_hip_record* __restrict__ recs, const uint32_t* __restrict__ order, unsigned long long n,
                                  twk_hip_record* __restrict__ out) {
 	constexpr uint32_t W = sizeof(twk_hip_record) / 8;              // 13 eight-byte words per record
@@ -696,8 +721,8 @@ __global__ void k_gather_records(const twk_hip_record* __restrict__ recs, const 
 }
 static_assert(sizeof(twk_hip_record) % 8 == 0, "record gather copies 8-byte words");
 
-// recs[0..n) on the device -> c->d_sorted in (idxA, idxB) order, on stream st.
-int sort_records(twk_hip_ctx* c, const twk_hip_record* recs, unsigned long long n, bool any_dropped, hipStream_t st) {
+// recs[0..n) on the device, with their keys and positions -> c->d_sorted in (idxA, idxB) order, on stream st.
+int sort_records(twk_hip_ctx* c, const twk_hip_record* recs, unsigned long long* keys_in, uint32_t* vals_in, unsigned long long n, bool any_dropped, hipStream_t st) {
 	if (n > 0xFFFFFFFFull) return TWK_HIP_E_INVALID;
 	if (c->sort_cap < n) {
 		if (c->d_sort_keys) (void)hipFree(c->d_sort_keys);
@@ -705,14 +730,14 @@ int sort_records(twk_hip_ctx* c, const twk_hip_record* recs, unsigned long long 
 		if (c->d_sorted) (void)hipFree(c->d_sorted);
 		c->d_sort_keys = nullptr; c->d_sort_vals = nullptr; c->d_sorted = nullptr; c->sort_cap = 0;
 		const unsigned long long cap = std::max<unsigned long long>(n + n / 4, 1ull << 16);
-		HIPCHK(c, hipMalloc((void**)&c->d_sort_keys, (size_t)cap * 4 * sizeof(unsigned long long)));
-		HIPCHK(c, hipMalloc((void**)&c->d_sort_vals, (size_t)cap * 2 * sizeof(uint32_t)));
+		HIPCHK(c, hipMalloc((void**)&c->d_sort_keys, (size_t)cap * sizeof(unsigned long long)));
+		HIPCHK(c, hipMalloc((void**)&c->d_sort_vals, (size_t)cap * sizeof(uint32_t)));
 		HIPCHK(c, hipMalloc((void**)&c->d_sorted, (size_t)cap * sizeof(twk_hip_record)));
 		c->sort_cap = cap;
 	}
-	unsigned long long* keys_in = c->d_sort_keys; unsigned long long* keys_out = c->d_sort_keys + c->sort_cap;
-	uint32_t* vals_in = c->d_sort_vals; uint32_t* vals_out = c->d_sort_vals + c->sort_cap;
-	uint32_t bits_b = 1; while (bits_b < 32 && (1ull << bits_b) < c->M) ++bits_b;
+	unsigned long long* keys_out = c->d_sort_keys;
+	uint32_t* vals_out = c->d_sort_vals;
+	const uint32_t bits_b = key_shift_for(c->M);
 	// dropped records (Fisher cut-off) carry the all-ones key: sort every bit when there can be any, else only the
 	// 2 * bits_b bits a (idxA, idxB) key uses
 	const unsigned end_bit = any_dropped ? 64u : 2u * bits_b;
@@ -725,8 +750,6 @@ int sort_records(twk_hip_ctx* c, const twk_hip_record* recs, unsigned long long 
 		HIPCHK(c, hipMalloc(&c->d_sort_tmp, want));
 		c->sort_tmp_bytes = want;
 	}
-	hipLaunchKernelGGL(k_record_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, recs, n, bits_b, keys_in, vals_in);
-	HIPCHK(c, hipGetLastError());
 	tmp = c->sort_tmp_bytes;
 	HIPCHK(c, rocprim::radix_sort_pairs(c->d_sort_tmp, tmp, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u, end_bit, st));
 	const unsigned long long words = n * (sizeof(twk_hip_record) / 8);
@@ -752,9 +775,13 @@ int ensure_device_keep(twk_hip_ctx* c, unsigned long long n_more) {
 	return TWK_HIP_OK;
 }
 
-// Wait for slot s, account timing, put its records in (idxA, idxB) order and fetch them into the pinned staging
-// buffer (to_host) or append them to the device sink.
-int finish_tile(twk_hip_ctx* c, Slot& s, const twk_hip_tile_desc& t, unsigned long long* n_out, bool to_host = true) {
+// Wait for slot s, account timing, put its records in (idxA, idxB) order and hand them on: appended to the device sink
+// (!to_host), or through the pinned staging buffer to the host - left there whole (sink == null: c->h_recs, for the
+// single-tile entry point), or handed to `sink` in pieces of HOST_CHUNK records, each piece while the next is being copied
+// (a launch may hold tens of millions of survivors: page-locking a buffer for all of them would cost more than the copy).
+constexpr unsigned long long HOST_CHUNK = 1ull << 20;       // records per piece (109 MB)
+int finish_tile(twk_hip_ctx* c, Slot& s, const twk_hip_tile_desc& t, unsigned long long* n_out, bool to_host = true,
+                twk_hip_record_sink sink = nullptr, void* user = nullptr) {
 	HIPCHK(c, hipEventSynchronize(s.ev_s1));
 	float ms = 0;
 	HIPCHK(c, hipEventElapsedTime(&ms, s.ev_c0, s.ev_c1));
@@ -786,20 +813,38 @@ int finish_tile(twk_hip_ctx* c, Slot& s, const twk_hip_tile_desc& t, unsigned lo
 		snprintf(c->err, sizeof(c->err), "%llu survivors for a buffer of %llu (tile rows %u+%u, cols %u+%u%s)", n, s.cap_use, t.rowA0, t.nA, t.rowB0, t.nB, s.is_list ? ", list pass" : "");
 		return TWK_HIP_E_OVERFLOW;
 	}
-	if (n) {
-		// records that failed the Fisher cut-off were only marked on the device (and counted): they sort behind the rest
-		const unsigned long long dropped = std::min(s.h_n_out[1], n), kept = n - dropped;
-		int rc = sort_records(c, s.out, n, dropped != 0, c->s_copy); if (rc) return rc;
-		if (to_host) {
-			rc = ensure_host_records(c, kept); if (rc) return rc;
-			if (kept) HIPCHK(c, hipMemcpyAsync(c->h_recs, c->d_sorted, (size_t)kept * sizeof(twk_hip_record), hipMemcpyDeviceToHost, c->s_copy));
-		} else {
-			rc = ensure_device_keep(c, kept); if (rc) return rc;
-			if (kept) HIPCHK(c, hipMemcpyAsync(c->d_keep + c->d_keep_n, c->d_sorted, (size_t)kept * sizeof(twk_hip_record), hipMemcpyDeviceToDevice, c->s_copy));
-			c->d_keep_n += kept;
-		}
+	if (!n) return TWK_HIP_OK;
+	// records that failed the Fisher cut-off were only marked on the device (and counted): they sort behind the rest
+	const unsigned long long dropped = std::min(s.h_n_out[1], n), kept = n - dropped;
+	int rc = sort_records(c, s.out, s.keys, s.vals, n, dropped != 0, c->s_copy); if (rc) return rc;
+	*n_out = kept;
+	if (!to_host) {
+		rc = ensure_device_keep(c, kept); if (rc) return rc;
+		if (kept) HIPCHK(c, hipMemcpyAsync(c->d_keep + c->d_keep_n, c->d_sorted, (size_t)kept * sizeof(twk_hip_record), hipMemcpyDeviceToDevice, c->s_copy));
+		c->d_keep_n += kept;
 		HIPCHK(c, hipStreamSynchronize(c->s_copy));
-		*n_out = kept;
+		return TWK_HIP_OK;
+	}
+	if (!sink || kept <= HOST_CHUNK) {
+		rc = ensure_host_records(c, kept); if (rc) return rc;
+		if (kept) HIPCHK(c, hipMemcpyAsync(c->h_recs, c->d_sorted, (size_t)kept * sizeof(twk_hip_record), hipMemcpyDeviceToHost, c->s_copy));
+		HIPCHK(c, hipStreamSynchronize(c->s_copy));
+		if (sink && kept && sink(user, c->h_recs, kept)) return TWK_HIP_E_INVALID;
+		return TWK_HIP_OK;
+	}
+	rc = ensure_host_records(c, 2 * HOST_CHUNK); if (rc) return rc;
+	auto copy_piece = [&](unsigned long long first) -> hipError_t {
+		const unsigned long long m = std::min(HOST_CHUNK, kept - first);
+		return hipMemcpyAsync(c->h_recs + ((first / HOST_CHUNK) & 1) * HOST_CHUNK, c->d_sorted + first, (size_t)m * sizeof(twk_hip_record), hipMemcpyDeviceToHost, c->s_copy);
+	};
+	HIPCHK(c, copy_piece(0));
+	for (unsigned long long first = 0; first < kept; first += HOST_CHUNK) {
+		HIPCHK(c, hipStreamSynchronize(c->s_copy));                                   // piece `first` has arrived
+		if (first + HOST_CHUNK < kept) HIPCHK(c, copy_piece(first + HOST_CHUNK));     // the next one travels while the sink works (into the other half)
+		if (sink(user, c->h_recs + ((first / HOST_CHUNK) & 1) * HOST_CHUNK, std::min(HOST_CHUNK, kept - first))) {
+			(void)hipStreamSynchronize(c->s_copy);
+			return TWK_HIP_E_INVALID;
+		}
 	}
 	return TWK_HIP_OK;
 }
@@ -808,7 +853,8 @@ int finish_tile(twk_hip_ctx* c, Slot& s, const twk_hip_tile_desc& t, unsigned lo
 // pair (i, j), i < j < zone, inside the r2 band, as an intersection of two carrier lists (ld_list.hip.h) -> candidates ->
 // the list math kernel -> Fisher -> sorted survivors (c->h_recs or the device sink, like a tile).
 int run_list_block(twk_hip_ctx* c, const twk_hip_filters& f, bool unphased, uint32_t row0, uint32_t n_rows, uint32_t zone, int32_t window, uint32_t l_window,
-                   const ColRange& cr, unsigned long long capacity, unsigned long long* n_out, bool to_host) {
+                   const ColRange& cr, unsigned long long capacity, unsigned long long* n_out, bool to_host,
+                   twk_hip_record_sink sink = nullptr, void* user = nullptr) {
 	const int set = unphased ? PS_SORTED_U : PS_SORTED_P;
 	const PlaneSet& ps = c->planes[set];
 	Slot& s = c->slot[2];
@@ -853,25 +899,28 @@ int run_list_block(twk_hip_ctx* c, const twk_hip_filters& f, bool unphased, uint
 		                        (const unsigned long long*)(s.n_out + 2), s.cand_cap);
 		HIPCHK(c, hipGetLastError());
 	}
-	{ const int rc = launch_fisher(c, s.out, s.n_out, s.cap_use, f.minP, s.C, s.C_words); if (rc) return rc; }
+	{ const int rc = launch_fisher(c, s.out, s.n_out, s.cap_use, f.minP, s.C, s.C_words, s.keys); if (rc) return rc; }
 	HIPCHK(c, hipMemcpyAsync(s.h_n_out, s.n_out, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->s_compute));
 	HIPCHK(c, hipEventRecord(s.ev_s1, c->s_compute));
-	return finish_tile(c, s, t, n_out, to_host);
+	return finish_tile(c, s, t, n_out, to_host, sink, user);
 }
 
-// One tile, synchronously, on the spare slot; survivors end up in c->h_recs.
+// One tile, synchronously, on the spare slot; survivors end up in c->h_recs (sink == null), with `sink`, or in the device sink.
 int run_tile_sync(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, const twk_hip_filters& f,
-                  unsigned long long capacity, unsigned long long* n_out, bool to_host = true, const ColRange* cr = nullptr) {
+                  unsigned long long capacity, unsigned long long* n_out, bool to_host = true, const ColRange* cr = nullptr,
+                  twk_hip_record_sink sink = nullptr, void* user = nullptr) {
 	Slot& s = c->slot[2];
 	int rc = enqueue_tile(c, mode, t, f, s, capacity, cr); if (rc) return rc;
-	rc = finish_tile(c, s, t, n_out, to_host);
+	rc = finish_tile(c, s, t, n_out, to_host, sink, user);
 	if (rc == TWK_HIP_E_OVERFLOW && s.cand_overflow) {       // too many candidates for the fused form: through C, for the rest of this call
 		c->fused_ok = false;
 		rc = enqueue_tile(c, mode, t, f, s, capacity, cr); if (rc) return rc;
-		rc = finish_tile(c, s, t, n_out, to_host);
+		rc = finish_tile(c, s, t, n_out, to_host, sink, user);
 	}
 	return rc;
 }
+
+int discard_records(void*, const twk_hip_record*, uint64_t) { return 0; }     // the sink of a caller that passed none
 
 // A tile whose survivors overflowed the device buffer: redo it in row strips
 // that cannot overflow (strip_rows * cols <= capacity).
@@ -896,9 +945,8 @@ int redo_tile_in_strips(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, co
 		}
 		for (int k = 0; k < np; ++k) {
 			unsigned long long n = 0;
-			int rc = run_tile_sync(c, mode, parts[k], f, (unsigned long long)parts[k].nA * parts[k].nB, &n, !c->device_sink, cr);
+			int rc = run_tile_sync(c, mode, parts[k], f, (unsigned long long)parts[k].nA * parts[k].nB, &n, !c->device_sink, cr, sink ? sink : discard_records, user);
 			if (rc) return rc;
-			if (!c->device_sink && sink && n && sink(user, c->h_recs, n)) return TWK_HIP_E_INVALID;
 			*n_recs += n;
 		}
 	}
@@ -1508,25 +1556,96 @@ static int region_impl(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint3
 		}
 		return best;
 	};
-	for (uint32_t x = r0; x < r1; x += S) {
-		const uint32_t h = std::min(S, r1 - x);
-		// triangle: the first tile of the row block starts on the diagonal (rows [x,x+h) x cols [x,x+w),
-		// w >= h, only col > row) and continues into the rectangle to its right in the same launch
-		uint32_t col = triangle ? x : 0, col_end = nB;
-		if (windowed) {       // only the columns some row of the block can reach
-			if (!triangle) col = lo[x];
-			col_end = hi[x + h - 1];
-			if (col_end <= col) continue;
+	// super-tiles sized by their count matrix, for the rows [xa, xb) of the band (appended to `mine`)
+	auto matrix_tiles = [&](uint32_t xa, uint32_t xb) {
+		for (uint32_t x = xa; x < xb; x += S) {
+			const uint32_t h = std::min(S, xb - x);
+			// triangle: the first tile of the row block starts on the diagonal (rows [x,x+h) x cols [x,x+w),
+			// w >= h, only col > row) and continues into the rectangle to its right in the same launch
+			uint32_t col = triangle ? x : 0, col_end = nB;
+			if (windowed) {       // only the columns some row of the block can reach
+				if (!triangle) col = lo[x];
+				col_end = hi[x + h - 1];
+				if (col_end <= col) continue;
+			}
+			const uint32_t sc = choose_col_step(h, col, triangle != 0);
+			bool diag = triangle != 0;
+			for (; col < col_end; col += sc, diag = false) {
+				uint32_t w = std::min(sc, col_end - col);
+				if (diag && w < h) w = std::min(h, nB - col);            // the diagonal tile must span its own rows
+				push_tile(x, h, col, w, diag ? 1 : 0);
+				if (diag && w > sc) col += w - sc;
+			}
 		}
-		const uint32_t sc = choose_col_step(h, col, triangle != 0);
-		bool diag = triangle != 0;
-		for (; col < col_end; col += sc, diag = false) {
-			uint32_t w = std::min(sc, col_end - col);
-			if (diag && w < h) w = std::min(h, nB - col);            // the diagonal tile must span its own rows
-			push_tile(x, h, col, w, diag ? 1 : 0);
-			if (diag && w > sc) col += w - sc;
+	};
+	// Band launches.  A fused launch keeps no count matrix - what it leaves behind is the list of its candidates - so
+	// nothing ties its extent to the 2 GiB a matrix may take: it is sized by its *work*.  The rows of the band are cut
+	// into at most 8 launches of at least ~2^19 tile-chunks (about 5 ms of contraction) each, every one over all the
+	// columns its rows reach: one ramp-up and one tail per ~100,000 tiles instead of per row block of 16,384 plane rows
+	// (the 2,504-sample window run of DESIGN 3.2a: 13 launches at 68 % of the ceiling), and no sort / copy kernels of the
+	// previous launch competing for the CUs for most of the launch.  More than one launch when there is work for it, so
+	// that the host's writer gets its first records while the device still counts.  A launch whose candidates or
+	// survivors outgrow their buffers is redone as matrix-sized tiles (below).
+	struct BandLaunch { uint32_t xa, xb; size_t list_words; unsigned long long cap; size_t tile_index; };
+	std::vector<BandLaunch> bands;
+	const bool band_mode = !tile_variants && c->opt.band_launch && r1 > r0 && fused_form_applies(c, mode, *f);
+	if (band_mode) {
+		const uint32_t nchunks = c->planes[plan_for(c, mode).set1].W / KC;
+		const uint32_t step = TILE;                                  // rows are cut on multiples of 128 variants
+		std::vector<uint64_t> cum_tiles(1, 0);
+		auto rb = [&](uint64_t nv) -> uint64_t { return (nv * Pmax + TILE - 1) / TILE; };
+		auto tiles_of_rows = [&](uint32_t x, uint32_t h) -> uint64_t {      // the tiles build_tile_list will list for rows [x, x + h) over all their columns
+			const uint32_t col0 = triangle ? x : (windowed ? lo[x] : 0);
+			uint64_t tiles = 0;
+			for (uint64_t by = 0, gy = rb(h); by < gy; ++by) {
+				const uint32_t v0 = x + (uint32_t)((by * TILE) / Pmax);
+				const uint32_t v1 = (uint32_t)std::min<uint64_t>((uint64_t)x + h, (uint64_t)x + ((by + 1) * TILE + Pmax - 1) / Pmax);
+				if (v0 >= v1) continue;
+				const uint32_t reach = windowed ? hi[v1 - 1] : nB;
+				if (reach <= col0) continue;
+				uint64_t c_lo = (windowed && lo[v0] > col0) ? ((uint64_t)(lo[v0] - col0) * Pmax) / TILE : 0;
+				if (triangle) c_lo = std::max<uint64_t>(c_lo, by);
+				const uint64_t c_hi = ((uint64_t)(reach - col0) * Pmax + TILE - 1) / TILE;
+				if (c_hi > c_lo) tiles += c_hi - c_lo;
+			}
+			return tiles;
+		};
+		for (uint32_t x = r0; x < r1; x += step) cum_tiles.push_back(cum_tiles.back() + tiles_of_rows(x, std::min(step, r1 - x)));
+		const uint64_t total = cum_tiles.back();
+		const uint64_t n_launch = std::max<uint64_t>(1, std::min<uint64_t>(8, total * nchunks >> c->opt.band_work_log2));
+		const uint64_t pairs_per_tile = (uint64_t)(TILE / Pmax) * (TILE / Pmax);
+		const unsigned words_per_entry = plan_for(c, mode).phased1 ? 3 : 6;
+		size_t k0 = 0;
+		for (uint64_t l = 0; l < n_launch && k0 + 1 < cum_tiles.size(); ++l) {
+			size_t k1 = cum_tiles.size() - 1;
+			if (l + 1 < n_launch) {
+				const uint64_t target = total * (l + 1) / n_launch;
+				k1 = (size_t)(std::lower_bound(cum_tiles.begin() + k0 + 1, cum_tiles.end(), target) - cum_tiles.begin());
+				k1 = std::min(k1, cum_tiles.size() - 1);
+			}
+			if (k1 <= k0) continue;
+			const uint32_t xa = r0 + (uint32_t)k0 * step, xb = std::min<uint64_t>(r1, (uint64_t)r0 + (uint64_t)k1 * step);
+			const uint64_t tiles = cum_tiles[k1] - cum_tiles[k0];
+			k0 = k1;
+			if (!tiles) continue;
+			const uint32_t col0 = triangle ? xa : (windowed ? lo[xa] : 0), col_end = windowed ? hi[xb - 1] : nB;
+			if (col_end <= col0) continue;
+			uint32_t w = col_end - col0;
+			if (triangle && w < xb - xa) w = std::min(xb - xa, nB - col0);
+			if (rb(xb - xa) > 0xFFFFu || rb(w) > 0xFFFFu) { bands.clear(); mine.clear(); break; }      // beyond a tile list's 16-bit coordinates: matrix tiles
+			// candidate slots: a sixteenth of the launch's pairs (a survivor-rich window run has 2 % candidates), 4 M at least, 1 G
+			// at most; survivors: as many records as that, 64 M at most
+			uint64_t entries = std::min<uint64_t>(std::max<uint64_t>(tiles * pairs_per_tile / 16, 1ull << 22), 1ull << 30);
+			entries = std::min<uint64_t>(entries, std::max<uint64_t>(tiles * pairs_per_tile / 3, 1024));      // (never more than a matrix tile would get)
+			if (c->opt.band_list_entries) entries = (uint64_t)c->opt.band_list_entries;      // (test / measurement: exactly this many)
+			BandLaunch b{xa, xb, (size_t)entries * words_per_entry, std::min<unsigned long long>(entries, 1ull << 26), mine.size()};
+			if (c->opt.record_cap > 0) b.cap = std::min<unsigned long long>(b.cap, (unsigned long long)c->opt.record_cap);
+			const size_t before = mine.size();
+			push_tile(xa, xb - xa, col0, w, triangle ? 1 : 0);
+			if (mine.size() > before) bands.push_back(b);
 		}
 	}
+	if (bands.empty()) matrix_tiles(r0, r1);
 
 	uint64_t tot_pairs = 0, tot_recs = 0;
 	// Worst case every pair of a tile survives; cap the device buffer and split on overflow.
@@ -1536,6 +1655,7 @@ static int region_impl(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint3
 		for (const auto& t : mine) worst = std::max<unsigned long long>(worst, (unsigned long long)t.nA * t.nB);
 		cap_default = std::min<unsigned long long>(worst ? worst : 1, 1ull << 24);
 	}
+	for (auto& b : bands) b.cap = std::min<unsigned long long>(b.cap, std::max<unsigned long long>(1, (unsigned long long)mine[b.tile_index].nA * mine[b.tile_index].nB));
 	if (c->opt.record_cap > 0) cap_default = std::min<unsigned long long>(cap_default, (unsigned long long)c->opt.record_cap);   // test hook: force the overflow / strip path
 	int rc = TWK_HIP_OK;
 	size_t issued = 0, done = 0;
@@ -1565,40 +1685,76 @@ static int region_impl(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint3
 			for (uint32_t row = lr0; row < lr1;) {
 				const uint32_t nr = std::min(rows_per, lr1 - row);
 				unsigned long long nrec = 0;
-				rc = run_list_block(c, *f, screen == 2, row, nr, zone, window, l_window, col_range, cap_list, &nrec, !c->device_sink);
+				rc = run_list_block(c, *f, screen == 2, row, nr, zone, window, l_window, col_range, cap_list, &nrec, !c->device_sink, sink ? sink : discard_records, user);
 				if (rc == TWK_HIP_E_OVERFLOW && nr > 1) { rows_per = std::max<uint32_t>(1, nr / 2); continue; }      // more survivors than the buffer holds: fewer rows
 				if (rc == TWK_HIP_E_OVERFLOW && cap_list < zone) { cap_list = zone; continue; }                      // one row: it cannot have more than `zone` partners
 				if (rc) return rc;
-				if (!c->device_sink && sink && nrec) { if (sink(user, c->h_recs, nrec)) return TWK_HIP_E_INVALID; }
 				tot_recs += nrec;
 				row += nr;
 			}
 		}
 	}
+	// One matrix-sized tile, synchronously, with its fallbacks: the fused form's candidate list overflowed -> through C (and
+	// the rest of the call as well); more survivors than the buffer holds -> row strips.
+	auto run_tile_with_fallbacks = [&](const twk_hip_tile_desc& t) -> int {
+		unsigned long long nrec = 0;
+		int r = run_tile_sync(c, mode, t, *f, cap_default, &nrec, !c->device_sink, windowed ? &col_range : nullptr, sink ? sink : discard_records, user);
+		if (r == TWK_HIP_E_OVERFLOW) {
+			uint64_t nr = 0;
+			r = redo_tile_in_strips(c, mode, t, *f, c->slot[2].cap_use, sink, user, &nr, windowed ? &col_range : nullptr);
+			nrec = nr;
+		}
+		if (r == TWK_HIP_OK) tot_recs += nrec;
+		return r;
+	};
+	// a band launch that cannot run (or has overflowed) as the matrix-sized tiles of its rows
+	auto run_band_as_matrix_tiles = [&](const BandLaunch& b) -> int {
+		std::vector<twk_hip_tile_desc> keep;
+		keep.swap(mine);
+		matrix_tiles(b.xa, b.xb);
+		std::vector<twk_hip_tile_desc> sub;
+		sub.swap(mine);
+		mine.swap(keep);
+		for (const auto& t : sub) { const int r = run_tile_with_fallbacks(t); if (r) return r; }
+		return TWK_HIP_OK;
+	};
+	auto band_of = [&](size_t i) -> const BandLaunch* { return i < bands.size() ? &bands[i] : nullptr; };       // (band launches are mine[0 .. bands.size()), in order)
+	std::vector<char> skipped(n, 0);
 	// two-deep software pipeline over the tiles of this shard
 	while (done < n) {
 		while (issued < n && issued < done + 2) {
-			rc = enqueue_tile(c, mode, mine[issued], *f, c->slot[issued & 1], cap_default, windowed ? &col_range : nullptr);
-			if (rc) return rc;
+			const BandLaunch* b = band_of(issued);
+			if (b && !c->fused_ok) skipped[issued] = 1;                 // an earlier launch gave the fused form up: this one goes the matrix way when its turn comes
+			else {
+				rc = enqueue_tile(c, mode, mine[issued], *f, c->slot[issued & 1], b ? b->cap : cap_default, windowed ? &col_range : nullptr, b ? b->list_words : 0);
+				if (rc) return rc;
+			}
 			++issued;
 		}
 		Slot& s = c->slot[done & 1];
 		unsigned long long nrec = 0;
-		rc = finish_tile(c, s, mine[done], &nrec, !c->device_sink);
-		if (rc == TWK_HIP_E_OVERFLOW && s.cand_overflow) {     // the fused form's candidate list overflowed: this tile again through C
-			c->fused_ok = false;                                 // (and the tiles not yet enqueued as well)
-			rc = run_tile_sync(c, mode, mine[done], *f, cap_default, &nrec, !c->device_sink, windowed ? &col_range : nullptr);
-		}
-		if (rc == TWK_HIP_E_OVERFLOW) {
-			uint64_t nr = 0;
-			rc = redo_tile_in_strips(c, mode, mine[done], *f, s.cap_use, sink, user, &nr, windowed ? &col_range : nullptr);
+		const BandLaunch* b = band_of(done);
+		if (b) {
+			rc = skipped[done] ? TWK_HIP_E_OVERFLOW : finish_tile(c, s, mine[done], &nrec, !c->device_sink, sink ? sink : discard_records, user);
+			if (rc == TWK_HIP_E_OVERFLOW) rc = run_band_as_matrix_tiles(*b);      // candidates or survivors beyond the launch's buffers
+			else if (rc == TWK_HIP_OK) tot_recs += nrec;
 			if (rc) return rc;
-			tot_recs += nr;
-		} else if (rc) {
-			return rc;
 		} else {
-			if (!c->device_sink && sink && nrec) { if (sink(user, c->h_recs, nrec)) return TWK_HIP_E_INVALID; }
-			tot_recs += nrec;
+			rc = finish_tile(c, s, mine[done], &nrec, !c->device_sink, sink ? sink : discard_records, user);
+			if (rc == TWK_HIP_E_OVERFLOW && s.cand_overflow) {     // the fused form's candidate list overflowed: this tile again through C
+				c->fused_ok = false;                                 // (and the tiles not yet enqueued as well)
+				rc = run_tile_sync(c, mode, mine[done], *f, cap_default, &nrec, !c->device_sink, windowed ? &col_range : nullptr, sink ? sink : discard_records, user);
+			}
+			if (rc == TWK_HIP_E_OVERFLOW) {
+				uint64_t nr = 0;
+				rc = redo_tile_in_strips(c, mode, mine[done], *f, s.cap_use, sink, user, &nr, windowed ? &col_range : nullptr);
+				if (rc) return rc;
+				tot_recs += nr;
+			} else if (rc) {
+				return rc;
+			} else {
+				tot_recs += nrec;
+			}
 		}
 		tot_pairs += pairs_in_tile(c, mine[done]);
 		++done;

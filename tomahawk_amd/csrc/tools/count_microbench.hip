@@ -52,8 +52,14 @@ int main(int argc,char**argv){
   if(getenv("FINISH")){   // probe: per-block finish times of the static list kernel (2 full rounds), by XCD
     std::vector<uint32_t> list=make_list(R/128,0,true); CK(hipMemcpy(dl,list.data(),list.size()*4,hipMemcpyHostToDevice));
     twk::CountWork w{}; w.rows=d; w.W=W; w.tiles=dl; w.C=C; w.ldc=R; w.ticket=tick; first_split=twk::build_count_units((uint32_t)list.size(),W/twk::KC,P,min_chunks,units,getenv("SHAREDIV")?atoi(getenv("SHAREDIV")):8,getenv("TAILROUNDS")?atoi(getenv("TAILROUNDS")):8); CK(hipMemcpy(du,units.data(),units.size()*16,hipMemcpyHostToDevice)); w.units=du; w.n_units=(uint32_t)units.size(); w.n_queues=1; w.queue_begin[0]=0; w.queue_begin[1]=w.n_units;
-    for(int rep=0;rep<2;++rep){ CK(hipMemset(tick,0,4)); if(first_split<list.size()) hipLaunchKernelGGL(twk::k_zero_tiles,dim3((uint32_t)list.size()-first_split),dim3(256),0,0,w.tiles,first_split,C,R); hipLaunchKernelGGL((twk::k_count_list_t<twk::COUNT_NW,5>),dim3(P),block,0,0,w); CK(hipDeviceSynchronize()); }
-    std::vector<unsigned long long> o(2*P); CK(hipMemcpy(o.data(),C,o.size()*8,hipMemcpyDeviceToHost));
+    const int probe_reps = getenv("FINISH_REPS")? atoi(getenv("FINISH_REPS")) : 2;       // launches back to back; the last one is reported
+    for(int rep=0;rep<probe_reps;++rep){ CK(hipMemset(tick,0,4)); if(first_split<list.size()) hipLaunchKernelGGL(twk::k_zero_tiles,dim3((uint32_t)list.size()-first_split),dim3(256),0,0,w.tiles,first_split,C,R); hipLaunchKernelGGL((twk::k_count_list_t<twk::COUNT_NW,5>),dim3(P),block,0,0,w); }
+    CK(hipDeviceSynchronize());
+    std::vector<unsigned long long> o4(4*P); CK(hipMemcpy(o4.data(),C,o4.size()*8,hipMemcpyDeviceToHost));
+    std::vector<unsigned long long> o(2*P); for(uint32_t b=0;b<P;++b){ o[2*b]=o4[4*b]; o[2*b+1]=o4[4*b+1]; }
+    { // the shader clock the blocks ran at: s_memtime ticks per tick of the constant 100 MHz counter, over each block's life
+      double mn=1e30,mx=0,sum=0,life=0; for(uint32_t b=0;b<P;++b){ const double f=(double)o4[4*b+3]/(double)o4[4*b+2]*100.0; mn=std::min(mn,f); mx=std::max(mx,f); sum+=f; life+=o4[4*b+2]/100.0; }
+      printf("shader clock over the blocks' lives (R=%u W=%u, second of two launches): mean %.0f MHz (min %.0f, max %.0f); mean block life %.1f us\n",R,W,sum/P,mn,mx,life/P); }
     unsigned long long t0=~0ull,t1=0; for(uint32_t b=0;b<P;++b){ t0=std::min(t0,o[2*b]); t1=std::max(t1,o[2*b]); }
     printf("finish-time spread over %u blocks: %.1f us (wall_clock64 ticks at 100 MHz)\n",P,(t1-t0)/100.0);
     for(int x=0;x<8;++x){ double mn=1e30,mx=0,sum=0; int n=0; for(uint32_t b=0;b<P;++b) if((int)(o[2*b+1]>>32&15)==x){ double t=(o[2*b]-t0)/100.0; mn=std::min(mn,t); mx=std::max(mx,t); sum+=t; ++n; }

@@ -100,13 +100,14 @@ def init_groups(backend: str, device: torch.device | None, force_rccl_failure: b
     if backend != "nccl":
         return over_gloo("")
     # 1. one distinct GPU per rank?  (the physical device: a launcher may have narrowed every rank's visibility to "cuda:0")
-    devs = [None] * world
-    dist.all_gather_object(devs, _physical_device(device) or (f"(test hook) rank {dist.get_rank()}" if force_rccl_failure else ""))
-    if not all(devs):
-        return over_gloo("RCCL not attempted: a rank has no GPU")
-    if len(set(devs)) != world:
-        dup = next(d for d in devs if devs.count(d) > 1)
-        return over_gloo(f"RCCL not attempted: ranks {[r for r, d in enumerate(devs) if d == dup]} share one GPU ({dup})")
+    if not force_rccl_failure:          # (the test hook goes straight to step 2: its failure there stands in for RCCL's own)
+        devs = [None] * world
+        dist.all_gather_object(devs, _physical_device(device))
+        if not all(devs):
+            return over_gloo("RCCL not attempted: a rank has no GPU")
+        if len(set(devs)) != world:
+            dup = next(d for d in devs if devs.count(d) > 1)
+            return over_gloo(f"RCCL not attempted: ranks {[r for r, d in enumerate(devs) if d == dup]} share one GPU ({dup})")
 
     def agreed(ok, err, stage):
         """-> True if every rank succeeded, False if every rank failed; raises if the ranks disagree."""
