@@ -17,7 +17,8 @@ for ps in switches:
     t = time.time()
     H.write_cohort_twk(twk, 2504, M, seed=6, n_threads=threads, block_size=500, spacing=322, p_switch=ps)
     log(f"p_switch {ps}: wrote {os.path.getsize(twk) / 1e6:.0f} MB in {time.time() - t:.1f} s")
-    for flags in (["-p"], ["-p", "-w", "4000000"]):
+    for flags in (["-p"], ["-p", "-w", "4000000"], ["-p", "--engine-option", "band_launch=0"], ["-p", "-w", "4000000", "--engine-option", "band_launch=0"],
+                  ["-u"], ["-u", "-w", "4000000"]):
         r = bench.run_cli(twk, flags, threads, "/tmp/kg_shape.two")
         log(f"p_switch {ps} calc {' '.join(flags)}: " + ", ".join(f"{k}={r.get(k)}" for k in ("wall_s", "load_s", "compute_write_s", "pairs", "records", "two_bytes", "count_kernel_ms", "count_launches", "and_bcnt_ceiling_frac", "math_kernels_ms", "fused_launches", "error") if r.get(k) is not None))
     os.remove(twk)
