@@ -39,9 +39,9 @@ def test_fused_equals_plain_and_oracle(hip, opt, N):
     n_fused = 0
     for mode in (T.MODE_PHASED, T.MODE_AUTO):
         for minR2 in (0.1, 0.6, 0.004):
-            for opt in (0, T.OPT_R2_SCREEN):
+            for wopt in (0, T.OPT_R2_SCREEN):
                 f = T.Filters(minR2=minR2)
-                (p, np0, _), (q, np1, nr1), nf, ncand = _both(hip, opt, lambda: hip.ld_all(mode, f, window=opt))
+                (p, np0, _), (q, np1, nr1), nf, ncand = _both(hip, opt, lambda: hip.ld_all(mode, f, window=wopt))
                 assert nf > 0 and np0 == np1 == M * (M - 1) // 2 and nr1 == len(q) == len(p) > 20
                 assert ncand >= len(q)                          # every survivor was a candidate
                 assert ncand < 0.5 * np1 or minR2 < 0.01         # and the screen did screen
@@ -235,9 +235,9 @@ def test_fused_unphased_equals_plain_and_oracle(hip, opt, N):
     data, mask, variants = util.upload(hip, al)
     mode = T.MODE_UNPHASED
     for minR2 in (0.1, 0.6, 0.004):
-        for opt in (0, T.OPT_R2_SCREEN):
+        for wopt in (0, T.OPT_R2_SCREEN):
             f = T.Filters(minR2=minR2)
-            (p, np0, _), (q, np1, nr1), nf, ncand = _both(hip, opt, lambda: hip.ld_all(mode, f, window=opt))
+            (p, np0, _), (q, np1, nr1), nf, ncand = _both(hip, opt, lambda: hip.ld_all(mode, f, window=wopt))
             assert nf > 0 and np0 == np1 == M * (M - 1) // 2 and nr1 == len(q) == len(p) > 20
             assert ncand >= len(q) or minR2 < 0.01                 # (at 0.004 the list may overflow and the tile be redone plain)
             assert ncand < 0.5 * np1 or minR2 < 0.05
@@ -354,7 +354,7 @@ def test_candidate_slot_windows_of_any_size_give_the_same_records(hip, opt, mode
 @pytest.mark.parametrize("mode", [T.MODE_PHASED, T.MODE_UNPHASED])
 def test_band_launches_equal_matrix_sized_tiles(hip, opt, mode):
     """A fused launch leaves no count matrix behind, so the engine sizes it by its work: a band of rows over every column
-    the rows reach, at most 8 launches per region (twk_hip.hip region_impl; option band_launch).  Same records, bit for
+    the rows reach, launches of ~5 ms each (twk_hip.hip region_impl; option band_launch).  Same records, bit for
     bit, as the matrix-sized tiles of round 3 - all pairs, the allele-count band, a window, shards, a rectangle - as one
     launch and (band_work_log2 small) as several; and when a launch outgrows its candidate list or its survivor buffer
     (band_list_entries / record_cap small) its rows are redone as matrix-sized tiles.  The reference's shape: one pass
@@ -376,16 +376,18 @@ def test_band_launches_equal_matrix_sized_tiles(hip, opt, mode):
         hip.timing_reset()
         base, np0, nr0 = call()
         t0 = hip.timing()
-        assert t0["fused_launches"] == t0["count_launches"] > 1 and nr0 == len(base) > 100, name
+        assert t0["fused_launches"] == t0["count_launches"] >= 1 and nr0 == len(base) > 100, name
         want = np.sort(base, order=ORDER).tobytes()
         opt.set("band_launch", 1)
-        for log2, n_launch in ((19, 1), (10, None), (4, 8)):
+        for log2, n_launch in ((19, 1), (10, None), (4, None)):
             opt.set("band_work_log2", log2)
             hip.timing_reset()
             got, np1, nr1 = call()
             t1 = hip.timing()
             assert np1 == np0 and nr1 == nr0 and np.sort(got, order=ORDER).tobytes() == want, (name, log2)
-            assert t1["fused_launches"] == t1["count_launches"] and 1 <= t1["count_launches"] <= 8, (name, log2, t1)
+            assert t1["fused_launches"] == t1["count_launches"] >= 1, (name, log2, t1)
+            if log2 < 19:
+                assert t1["count_launches"] > 1, (name, log2, t1)
             if n_launch is not None and name in ("all", "window", "rectangle"):
                 assert t1["count_launches"] == n_launch, (name, log2, t1)
             if name == "window":       # in (idxA, idxB) order launch after launch: the order the records reach the writer in

@@ -168,6 +168,30 @@ def double_root_vetter(data, mask, variants, n_samples):
         yN = a * xN ** 3 + b * xN * xN + cc * xN + dee
         yN2, h2 = yN * yN, 4 * a * a * d2 ** 3
         return abs(yN2 - h2) <= 16 * np.spacing(max(yN2, h2))
+
+    def root_error(A, B, f11):
+        """Conditioning of the cubic at the root the record carries: how far a root can move under one unit of rounding in
+        every term, |dx| = u * (|a x^3| + |b x^2| + |c x| + |d|) / |g'(x)| with u = 2^-53 (first order; next to a double
+        root g'(x) -> 0 and the bound grows as it should).  -> (dx, the terms' sum, g'(x)); dx = inf where g' vanishes."""
+        mA = mask[A] if mask is not None and variants["gt_missing"][A] else None
+        mB = mask[B] if mask is not None and variants["gt_missing"][B] else None
+        c = [float(x) for x in O.count_unphased(data[A], mA, data[B], mB, n_samples)]
+        a0, a14, a5, a1664, hets, a2169, a80, a8184, a85 = c
+        total = sum(c)
+        if total == 0:
+            return float("inf"), 0.0, 0.0
+        P = ((a0 + a14 + a5) * 2.0 + (a1664 + hets + a2169)) / (2.0 * total)
+        Q = ((a0 + a1664 + a80) * 2.0 + (a14 + hets + a8184)) / (2.0 * total)
+        n11 = 2 * a0 + a14 + a1664
+        dee = -n11 * P * Q
+        cc = -n11 * (1 - 2 * P - 2 * Q) - hets * (1 - P - Q) + 2 * total * P * Q
+        b = 2 * total * (1 - 2 * P - 2 * Q) - 2 * n11 - hets
+        a = 4 * total
+        x = float(f11)
+        terms = abs(a * x ** 3) + abs(b * x * x) + abs(cc * x) + abs(dee)
+        slope = abs(3 * a * x * x + 2 * b * x + cc)
+        return (2.0 ** -53 * terms / slope if slope > 0 else float("inf")), terms, slope
+    vet.root_error = root_error
     return vet
 
 
@@ -237,6 +261,14 @@ def assert_records_match(gpu_recs, orc_recs, variants, n_samples=None, rtol=1e-6
             dev["cnt/total"] = max(dev.get("cnt/total", 0.0), float(np.max(np.abs(g["cnt"] - w["cnt"]))) / tot)
             dev["ChiSqFisher/total"] = max(dev.get("ChiSqFisher/total", 0.0), abs(float(g["ChiSqFisher"]) - float(w["ChiSqFisher"])) / tot)
             dev["n"] = dev.get("n", 0) + 1
+            dD = abs(float(g["D"]) - float(w["D"]))
+            if dD > rtol * abs(float(w["D"])) or abs(float(g["Dprime"]) - float(w["Dprime"])) > rtol * abs(float(w["Dprime"])) or abs(float(g["R"]) - float(w["R"])) > rtol * abs(float(w["R"])):
+                item = {"k": list(k), "dD": dD, "dDp": abs(float(g["Dprime"]) - float(w["Dprime"])), "dR": abs(float(g["R"]) - float(w["R"])),
+                        "D": float(w["D"]), "Dp": float(w["Dprime"]), "R": float(w["R"]), "tot": tot, "cnt": [float(x) for x in w["cnt"]]}
+                re_fn = getattr(double_root, "root_error", None)
+                if re_fn is not None:
+                    item["root_error"] = list(re_fn(k[0], k[1], float(w["cnt"][0]) / tot))
+                dev.setdefault("beyond", []).append(item)
         if (int(g["flags"]) ^ int(w["controller"])) & ~(1 << 5):   # bit 5 (multiple roots) checked below
             bad.append((k, "flags", int(g["flags"]), int(w["controller"])))
             continue

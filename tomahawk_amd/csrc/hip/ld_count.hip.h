@@ -358,7 +358,8 @@ __device__ __forceinline__ void contract_half(uint32_t (&acc)[8][TB], int u, con
 // the next unit's ticket is drawn by thread 0 at the first chunk of a unit and handed to the other
 // waves through a two-slot LDS mailbox behind the next chunk barrier, so no extra synchronisation
 // is paid (units of a single chunk excepted).
-struct CountUnit { uint32_t tile, c0, c1, _pad; };     // chunks [c0, c1) of tiles[tile]
+struct CountUnit { uint32_t tile, c0, c1, yx; };       // chunks [c0, c1) of tiles[tile]; yx = tiles[tile], so that a block learns everything about its
+                                                       // next unit from one 16-byte scalar load (fill_unit_tiles) instead of two dependent ones
 struct CountWork {
 	const uint32_t* rows; uint32_t W;      // plane rows, row pitch in words (multiple of KC)
 	uint32_t rowA0, rowB0;                 // first plane row of the super-tile's row / column axis
@@ -428,6 +429,9 @@ inline uint32_t build_count_units(uint32_t n_tiles, uint32_t nchunks, uint32_t n
 	return segmented ? 0 : first_split;
 }
 
+template <class Vec>
+inline void fill_unit_tiles(Vec& units, const uint32_t* tiles) { for (auto& u : units) u.yx = tiles[u.tile]; }
+
 // What a block does with the 8 x TB counts each of its lanes holds when a unit ends.  StoreCounts is the plain form:
 // the counts go to the super-tile's C matrix (stored for a whole tile, added for a part of its K range).
 // What a wave keeps between the units it runs (fused forms: the candidate slots it has reserved and not yet used): three
@@ -481,9 +485,10 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 	if (EXPERIMENT == 5) { probe_wall0 = wall_clock64(); probe_clk0 = clock64(); }
 
 	// unit id -> (tile, first chunk, end chunk); wave-uniform (scalar loads)
-	auto decode = [&](uint32_t u, uint32_t& tl, uint32_t& c0, uint32_t& c1) {
+	auto decode = [&](uint32_t u, uint32_t& tl, uint32_t& c0, uint32_t& c1, uint32_t& yx) {
 		const CountUnit cu = w.units[u];
 		tl = __builtin_amdgcn_readfirstlane(cu.tile); c0 = __builtin_amdgcn_readfirstlane(cu.c0); c1 = __builtin_amdgcn_readfirstlane(cu.c1);
+		yx = __builtin_amdgcn_readfirstlane(cu.yx);
 	};
 
 	// Drawing a unit (thread 0): the next ticket of the block's queue; with one queue per XCD the queue of the XCD this
@@ -515,8 +520,8 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 	bool unit_start = true;                     // this iteration is the first of its unit
 	bool want_next = false;                     // unit_next is to be picked up from the mailbox behind the next barrier
 
-	uint32_t tile, c, c_end;
-	decode(unit, tile, c, c_end);
+	uint32_t tile, c, c_end, tile_yx;
+	decode(unit, tile, c, c_end, tile_yx);
 
 	uint32_t acc[8][TB];
 #pragma unroll
@@ -537,15 +542,14 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 	const uint32_t lds_base = (uint32_t)(uintptr_t)(lptr_t*)lds;
 	const uint32_t st_lds = lds_base + (st_isB ? (uint32_t)LDS_TILE_BYTES : 0u);
 	// first plane row this wave stages for a tile: the A rows (first half of the waves) or the B rows
-	auto stage_row0 = [&](uint32_t tl) -> uint32_t {
-		const uint32_t yx = __builtin_amdgcn_readfirstlane(w.tiles[tl]);     // wave-uniform: lives in an SGPR
+	auto stage_row0 = [&](uint32_t yx) -> uint32_t {       // (yx: wave-uniform, lives in an SGPR)
 		return st_isB ? w.rowB0 + (yx & 0xFFFFu) * TILE : w.rowA0 + (yx >> 16) * TILE;
 	};
 
 	const uint32_t lr = (uint32_t)lane >> 3, ls = (uint32_t)lane & 7u;
 	const uint32_t voff_even = (lr * w.W + ((ls ^ (lr >> 1)) << 2)) << 2;
 	const uint32_t voff_odd  = (lr * w.W + ((ls ^ (lr >> 1) ^ 4u) << 2)) << 2;
-	uint32_t st_row0 = stage_row0(tile);
+	uint32_t st_row0 = stage_row0(tile_yx);
 	stage_rows_s(w.rows, w.W, st_row0, c, st_lds, st_seg0, NSEG, voff_even, voff_odd);
 	uint32_t seg_c0 = c;
 	__shared__ uint32_t window_words[NW][4];
@@ -568,7 +572,7 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 			if (tid == 0) fetched = draw();
 			if (META) {
 				if (wave_u < META / 64) {
-					const uint32_t yx_m = __builtin_amdgcn_readfirstlane(w.tiles[tile]);
+					const uint32_t yx_m = tile_yx;
 					uint32_t mi = (uint32_t)(wave_u * 64 + lane);
 					asm volatile("" : "+v"(mi));         // (opaque: the address arithmetic on it is redone per unit, not hoisted out of the loop and spilled)
 					glds4(epilogue.meta_src(yx_m, mi), (uint32_t)(uintptr_t)(lptr_t*)meta + (uint32_t)wave_u * 256u);
@@ -585,11 +589,11 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 			unit_start = false;
 		}
 		// prefetch the chunk after this one: same unit, or the first chunk of the next unit
-		uint32_t n_tile = tile, n_c = c + 1, n_end = c_end;
+		uint32_t n_tile = tile, n_c = c + 1, n_end = c_end, n_yx = tile_yx;
 		bool more = true;
 		if (n_c == c_end) {
 			more = unit_next < n_units;
-			if (more) { decode(unit_next, n_tile, n_c, n_end); st_row0 = stage_row0(n_tile); }
+			if (more) { decode(unit_next, n_tile, n_c, n_end, n_yx); st_row0 = stage_row0(n_yx); }
 		}
 		if (more) stage_rows_s(w.rows, w.W, st_row0, n_c, st_lds + (buf ^ 1) * (2 * LDS_TILE_BYTES), st_seg0, NSEG, voff_even, voff_odd);
 		// The chunk in 16 half-slots of 8 bytes per row.  The 12 LDS reads of half-slot h + 1 (8 A rows,
@@ -634,7 +638,7 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 		}
 
 		if (c + 1 == c_end) {          // unit done: write (whole tile) or add (part of a tile's K range) - or screen (fused form)
-			const uint32_t yx = __builtin_amdgcn_readfirstlane(w.tiles[tile]);
+			const uint32_t yx = tile_yx;
 			if (EXPERIMENT != 6) epilogue(acc, yx, wr, wc, li, lj, lane, seg_c0 == 0 && c_end == nchunks, meta, window);      // (6: the dev tool's no-epilogue timing)
 			if (!more) {
 				epilogue.finish(window, lane);
@@ -651,7 +655,7 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 			}
 			unit = unit_next; seg_c0 = n_c; unit_start = true;          // the next unit starts
 		}
-		tile = n_tile; c = n_c; c_end = n_end;
+		tile = n_tile; c = n_c; c_end = n_end; tile_yx = n_yx;
 		buf ^= 1;
 	}
 }

@@ -492,6 +492,7 @@ int launch_count(twk_hip_ctx* c, int set, const twk_hip_tile_desc& t, Slot& s, i
 		first_split = T ? build_count_units((uint32_t)T, nchunks, n_blocks, min_chunks, units, 8, 8, patch_end.data(), (uint32_t)patch_end.size(), seg_chunks) : 0;
 		queue_begin[1] = (uint32_t)units.size();
 	}
+	fill_unit_tiles(units, list.data());
 	const size_t T4 = (T + 3) / 4 * 4, words_units = T4 + units.size() * 4;       // [tiles | pad | units], units 16-byte aligned
 	const size_t fa_words = (sizeof(FusedArgs) + 15) / 16 * 4;
 	const size_t words = words_units + (fuse ? fa_words : 0);                    // [... | FusedArgs] for a fused launch
@@ -524,7 +525,10 @@ int launch_count(twk_hip_ctx* c, int set, const twk_hip_tile_desc& t, Slot& s, i
 			const bool skip_pad = c->opt.skip_pad != 0;      // measurement hook: 0 = contract the zero padding too
 			const uint32_t live_last = ps.W_live - (ps.W / KC - 1) * KC;      // live words of the last chunk, 1..KC (W = W_live rounded up to KC)
 			w.last_halves = (skip_pad && ps.W_live && ps.W_live <= ps.W && ps.W - ps.W_live < KC) ? (live_last + 1) / 2 : 0;
-			if (w.last_halves >= 16) w.last_halves = 0;
+			// The shortened chunk runs a plain rolled loop (no reads in flight behind the contraction): worth it when it drops a
+			// quarter of the chunk or more, not for a half-slot or two (2,504 samples phased: 157 live words of 160, 15 half-slots
+			// of the fifth chunk - there the pipelined loop over all 16 is the faster one).
+			if (w.last_halves > 12) w.last_halves = 0;
 		}
 		HIPCHK(c, hipMemsetAsync(w.ticket, 0, 8 * 4, c->s_compute));
 		if (first_split < T) {
@@ -1580,12 +1584,12 @@ static int region_impl(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint3
 	};
 	// Band launches.  A fused launch keeps no count matrix - what it leaves behind is the list of its candidates - so
 	// nothing ties its extent to the 2 GiB a matrix may take: it is sized by its *work*.  The rows of the band are cut
-	// into at most 8 launches of at least ~2^19 tile-chunks (about 5 ms of contraction) each, every one over all the
-	// columns its rows reach: one ramp-up and one tail per ~100,000 tiles instead of per row block of 16,384 plane rows
-	// (the 2,504-sample window run of DESIGN 3.2a: 13 launches at 68 % of the ceiling), and no sort / copy kernels of the
-	// previous launch competing for the CUs for most of the launch.  More than one launch when there is work for it, so
-	// that the host's writer gets its first records while the device still counts.  A launch whose candidates or
-	// survivors outgrow their buffers is redone as matrix-sized tiles (below).
+	// into launches of ~2^19 tile-chunks (about 5 ms of contraction) each, every one over all the columns its rows
+	// reach: one ramp-up and one tail per ~100,000 tiles instead of per row block of 16,384 plane rows (the 2,504-sample
+	// window run of DESIGN 3.2a: 13 launches at 68 % of the ceiling -> 1 at 76 %).  Not longer than that: a launch of a
+	// million tiles ran at 59 % of the ceiling where the same tiles in launches of a hundred thousand ran at 79 %
+	// (2,504 x 531,500 all pairs, profiles/r04_kg_shape.txt), and the host's writer should get its first records while the
+	// device still counts.  A launch whose candidates or survivors outgrow their buffers is redone as matrix-sized tiles (below).
 	struct BandLaunch { uint32_t xa, xb; size_t list_words; unsigned long long cap; size_t tile_index; };
 	std::vector<BandLaunch> bands;
 	const bool band_mode = !tile_variants && c->opt.band_launch && r1 > r0 && fused_form_applies(c, mode, *f);
@@ -1612,7 +1616,7 @@ static int region_impl(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint3
 		};
 		for (uint32_t x = r0; x < r1; x += step) cum_tiles.push_back(cum_tiles.back() + tiles_of_rows(x, std::min(step, r1 - x)));
 		const uint64_t total = cum_tiles.back();
-		const uint64_t n_launch = std::max<uint64_t>(1, std::min<uint64_t>(8, total * nchunks >> c->opt.band_work_log2));
+		const uint64_t n_launch = std::max<uint64_t>(1, total * nchunks >> c->opt.band_work_log2);
 		const uint64_t pairs_per_tile = (uint64_t)(TILE / Pmax) * (TILE / Pmax);
 		const unsigned words_per_entry = plan_for(c, mode).phased1 ? 3 : 6;
 		size_t k0 = 0;

@@ -1,7 +1,14 @@
 // `.twk` / `.two` containers -- see twk_format.h for the reference citations.
 #include "twk_format.h"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
+#include <cerrno>
+#include <cstring>
 #include <iostream>
 
 // libzstd's stable one-shot API (zstd.h).  The image ships libzstd.so.1 but no
@@ -371,7 +378,7 @@ bool TwkReader::read_block(size_t i, Block& blk) { // twk_reader.cpp:8-44
 bool TwoWriter::put(const void* p, size_t n) { os_->write((const char*)p, n); off_ += n; return os_->good(); }
 
 bool TwoWriter::open(const std::string& path, const Header& hdr, int c_level) {
-	c_level_ = c_level; off_ = 0; n_records = n_blocks = 0;
+	c_level_ = c_level; off_ = 0; n_records = n_blocks = 0; path_ = path;
 	if (path.empty() || path == "-") os_ = &std::cout;
 	else {
 		file_.open(path, std::ios::binary | std::ios::trunc);
@@ -413,12 +420,9 @@ bool TwoWriter::pack_generic(const TwoRecord* recs, uint32_t n, int c_level, boo
 	return true;
 }
 
-bool TwoWriter::write_packed(const Packed& p) {
+void TwoWriter::add_index_entry(const Packed& p, uint64_t foff, uint64_t fend) {
 	IndexEntryOutput e = p.entry;
-	e.foff = off_;
-	const uint8_t marker = 1; const uint32_t unc = p.b_unc, cmp = (uint32_t)p.z.size();
-	if (!put(&marker, 1) || !put(&unc, 4) || !put(&cmp, 4) || !put(p.z.data(), p.z.size())) return false;
-	e.fend = off_;
+	e.foff = foff; e.fend = fend;
 	index_.ent.push_back(e);
 	if (index_.state == 2 && e.rid >= 0 && (size_t)e.rid < index_.meta.size()) {      // index.cpp:70-88
 		IndexEntryEntry& m = index_.meta[e.rid];
@@ -426,7 +430,92 @@ bool TwoWriter::write_packed(const Packed& p) {
 		m.n += e.n; m.maxpos = e.maxpos; m.fend = e.fend; ++m.nn;
 	}
 	n_records += e.n; ++n_blocks;
+}
+
+bool TwoWriter::write_packed(const Packed& p) {
+	if (mapped()) { Span at; if (!reserve(p, at)) return false; fill(at, p); return true; }
+	const uint64_t foff = off_;
+	const uint8_t marker = 1; const uint32_t unc = p.b_unc, cmp = (uint32_t)p.z.size();
+	if (!put(&marker, 1) || !put(&unc, 4) || !put(&cmp, 4) || !put(p.z.data(), p.z.size())) return false;
+	add_index_entry(p, foff, off_);
 	return true;
+}
+
+// ---- mapped mode (twk_format.h) ----
+TwoWriter::~TwoWriter() { unmap_all(); if (fd_ >= 0) ::close(fd_); }
+
+void TwoWriter::unmap_all() {
+	if (!win_) return;
+	for (uint64_t k = 0; k * WIN_BYTES < mapped_end_; ++k)
+		if (uint8_t* w = win_[k].load()) { ::munmap(w, WIN_BYTES); win_[k].store(nullptr); }
+	mapped_end_ = 0;
+}
+
+bool TwoWriter::grow_to(uint64_t end) {
+	while (mapped_end_ < end) {
+		const uint64_t k = mapped_end_ / WIN_BYTES;
+		if (k >= MAX_WINDOWS) return false;
+		// space first: fallocate where the file system has it (an error now instead of a SIGBUS at the first touch of a page
+		// the disk has no room for), else just the size
+		if (::fallocate(fd_, 0, (off_t)mapped_end_, (off_t)WIN_BYTES) != 0) {
+			if (errno != EOPNOTSUPP && errno != ENOSYS && errno != EINVAL) return false;
+			if (::ftruncate(fd_, (off_t)(mapped_end_ + WIN_BYTES)) != 0) return false;
+		}
+		void* w = ::mmap(nullptr, WIN_BYTES, PROT_READ | PROT_WRITE, MAP_SHARED, fd_, (off_t)mapped_end_);
+		if (w == MAP_FAILED) return false;
+		win_[k].store(static_cast<uint8_t*>(w));
+		mapped_end_ += WIN_BYTES;
+	}
+	return true;
+}
+
+bool TwoWriter::map_output() {
+	if (mapped()) return true;
+	if (!os_ || !file_.is_open() || path_.empty() || path_ == "-") return false;
+	file_.flush();
+	if (!file_.good()) return false;
+	struct stat st;
+	if (::stat(path_.c_str(), &st) != 0 || !S_ISREG(st.st_mode) || (uint64_t)st.st_size != off_) return false;      // a regular file holding exactly what was written so far
+	const int fd = ::open(path_.c_str(), O_RDWR);
+	if (fd < 0) return false;
+	fd_ = fd;
+	win_.reset(new std::atomic<uint8_t*>[MAX_WINDOWS]);
+	for (size_t k = 0; k < MAX_WINDOWS; ++k) win_[k].store(nullptr);
+	mapped_end_ = 0;
+	if (!grow_to(off_ + 1)) {               // the first window, which also holds the header: if this cannot be done, stay a stream
+		unmap_all();
+		if (::ftruncate(fd_, (off_t)off_) != 0) { /* the stream will overwrite what matters; the tail is cut at close */ }
+		::close(fd_); fd_ = -1; win_.reset();
+		return false;
+	}
+	return true;
+}
+
+bool TwoWriter::reserve(const Packed& p, Span& at) {
+	if (!mapped()) return false;
+	const uint64_t bytes = 9 + p.z.size();
+	if (!grow_to(off_ + bytes)) return false;
+	at.off = off_;
+	off_ += bytes;
+	add_index_entry(p, at.off, off_);
+	return true;
+}
+
+void TwoWriter::fill(const Span& at, const Packed& p) {
+	uint8_t head[9];
+	head[0] = 1;
+	const uint32_t unc = p.b_unc, cmp = (uint32_t)p.z.size();
+	std::memcpy(head + 1, &unc, 4); std::memcpy(head + 5, &cmp, 4);
+	auto copy = [&](uint64_t off, const uint8_t* src, size_t n) {          // a frame may straddle two windows
+		while (n) {
+			const uint64_t k = off / WIN_BYTES, in = off % WIN_BYTES;
+			const size_t m = (size_t)std::min<uint64_t>(n, WIN_BYTES - in);
+			std::memcpy(win_[k].load() + in, src, m);
+			off += m; src += m; n -= m;
+		}
+	};
+	copy(at.off, head, 9);
+	copy(at.off + 9, p.z.data(), p.z.size());
 }
 
 bool TwoWriter::write_raw(uint32_t b_unc, const std::vector<uint8_t>& z, IndexEntryOutput e) {
@@ -452,6 +541,14 @@ bool TwoWriter::close() { // writer.h:293-313
 	if (!zstd_compress(b.v.data(), b.v.size(), z, c_level_)) return false;
 	const uint64_t off = off_, unc = b.size(), cmp = z.size();
 	const uint8_t marker = 0;
+	if (mapped()) {
+		// the blocks are in place (every fill() has returned: the caller's business); cut the file to them and go on as a stream
+		unmap_all();
+		const bool cut = ::ftruncate(fd_, (off_t)off_) == 0;
+		::close(fd_); fd_ = -1; win_.reset();
+		file_.seekp((std::streamoff)off_);
+		if (!cut || !file_.good()) { file_.close(); os_ = nullptr; return false; }
+	}
 	put(&marker, 1); put(&unc, 8); put(&cmp, 8); put(z.data(), z.size()); put(&off, 8); put(TWK_EOF_HEX, 32);
 	os_->flush();
 	const bool ok = os_->good();

@@ -6,7 +6,9 @@
 // primitive append).  Compression: one-shot zstd frames (lib/zstd_codec.cpp:
 // 136-168).
 #pragma once
+#include <atomic>
 #include <cstdint>
+#include <memory>
 #include <cstring>
 #include <fstream>
 #include <memory>
@@ -180,6 +182,19 @@ public:
 	// extends the per-contig entry of its ridA (writer.h:384-386, index.cpp:70-88).
 	void set_state(uint8_t s) { index_.state = s; }
 	bool write_packed(const Packed& p);
+	// Mapped mode.  One thread appending through a stream moves ~5 GB/s into the page cache and that was what bound a
+	// survivor-rich calc run (the reference has the same shape: every thread's flush goes through one spinlocked stream,
+	// writer.h:70-87); positional pwrite()s from many threads are slower still (they serialise on the inode lock).  A shared
+	// mapping has no such lock: map_output(), after open(), maps the file's block area window by window (1 GiB each, space
+	// reserved with fallocate where the file system can, so that a full disk is an error here and not a SIGBUS later);
+	// reserve() - called in the order the blocks are to appear, under the caller's lock - gives a frame its place and its
+	// index entry, fill() - any thread, no lock - copies the frame there: the page faults and the copying run in parallel.
+	// map_output() returns false, and the writer stays a stream, for stdout and for files that cannot be grown and mapped.
+	struct Span { uint64_t off = 0; };
+	bool map_output();
+	bool mapped() const { return fd_ >= 0; }
+	bool reserve(const Packed& p, Span& at);
+	void fill(const Span& at, const Packed& p);
 	// Append an already compressed block under the given index entry (concat, lib/concat.h:160-175).
 	bool write_raw(uint32_t b_unc, const std::vector<uint8_t>& z, IndexEntryOutput entry);
 	int  compression_level() const { return c_level_; }
@@ -192,6 +207,21 @@ private:
 	TwoIndex index_;
 	int c_level_ = 1;
 	bool put(const void* p, size_t n);
+	void add_index_entry(const Packed& p, uint64_t foff, uint64_t fend);
+	// mapped mode
+	static constexpr uint64_t WIN_BYTES = 1ull << 30;
+	static constexpr size_t MAX_WINDOWS = 1u << 14;                  // 16 TiB
+	std::string path_;
+	int fd_ = -1;
+	uint64_t mapped_end_ = 0;                                        // file bytes [0, mapped_end_) are reserved and mapped
+	std::unique_ptr<std::atomic<uint8_t*>[]> win_;                   // window k = file bytes [k * WIN_BYTES, (k + 1) * WIN_BYTES)
+	bool grow_to(uint64_t end);
+	void unmap_all();
+public:
+	~TwoWriter();
+	TwoWriter() = default;
+	TwoWriter(const TwoWriter&) = delete;
+	TwoWriter& operator=(const TwoWriter&) = delete;
 };
 class TwoReader {         // lib/two_reader.cpp:11-160
 public:

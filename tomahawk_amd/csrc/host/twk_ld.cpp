@@ -503,7 +503,7 @@ static bool create_devices(DeviceCtxs& dc, int n_gpus, const std::vector<std::pa
 		if (!hip_ok(nullptr, twk_hip_ctx_create(device, &c), "twk_hip_ctx_create")) return false;
 		dc.ctx.push_back(c);
 		for (const auto& kv : options) {
-			if (kv.first == "force_device" || kv.first == "progress_ms") continue;       // this class's own
+			if (kv.first == "force_device" || kv.first == "progress_ms" || kv.first == "map_output" || kv.first == "emit_workers") continue;       // this class's own
 			if (!hip_ok(c, twk_hip_set_option(c, kv.first.c_str(), kv.second), "twk_hip_set_option")) return false;
 		}
 	}
@@ -519,6 +519,9 @@ bool twk_ld::twk_ld_impl::run(twk_ld_settings& settings, const Header& hdr, cons
 	using clock = std::chrono::steady_clock;
 	const RunSpec& spec = *static_cast<const RunSpec*>(spec_);
 	if (!open_output(settings, hdr, out.writer)) return false;
+	// blocks go into the file through a shared mapping, copied in by the emitter's workers in parallel (twk_format.h); a
+	// stream for stdout and wherever the file cannot be mapped.  (engine option "map_output" = 0: always a stream - A/B runs)
+	if (option("map_output", 1)) (void)out.writer.map_output();
 	out.b_size = (uint32_t)std::max(2, settings.b_size);
 	out.c_level = settings.c_level; out.rid = rid.data(); out.pos = pos.data(); out.n_variants = rid.size(); out.n_records = 0;
 	n_records = 0; n_pairs = 0;
@@ -526,7 +529,8 @@ bool twk_ld::twk_ld_impl::run(twk_ld_settings& settings, const Header& hdr, cons
 	// output workers per GPU: 32 at most - on the 2 x 64-core host of the GPU box the 33 M-survivor run writes its 3.8 GB in
 	// 0.72 s with 32, 0.82 s with 16 and 1.07 s with 64 (the threads' zstd work inflates from 10 to 25 CPU-seconds and the
 	// writer thread's copies slow down by half when every core is busy)
-	const int n_workers = std::max(1, std::min(std::max(1, settings.n_threads / n_gpus), 32));
+	int n_workers = std::max(1, std::min(std::max(1, settings.n_threads / n_gpus), 32));
+	if (option("emit_workers", 0) > 0) n_workers = (int)std::min<int64_t>(option("emit_workers", 0), 64);      // (measurement: the emitter's worker threads per GPU)
 	const int mode = settings.single ? TWK_HIP_MODE_AUTO
 	               : settings.force_phased ? TWK_HIP_MODE_PHASED : (settings.forced_unphased ? TWK_HIP_MODE_UNPHASED : TWK_HIP_MODE_AUTO);
 	twk_hip_filters f{settings.minR2, settings.maxR2, settings.minDprime, settings.maxDprime, settings.minP};

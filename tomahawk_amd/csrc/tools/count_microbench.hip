@@ -51,7 +51,7 @@ int main(int argc,char**argv){
   uint32_t* tick; CK(hipMalloc(&tick,4));
   if(getenv("FINISH")){   // probe: per-block finish times of the static list kernel (2 full rounds), by XCD
     std::vector<uint32_t> list=make_list(R/128,0,true); CK(hipMemcpy(dl,list.data(),list.size()*4,hipMemcpyHostToDevice));
-    twk::CountWork w{}; w.rows=d; w.W=W; w.tiles=dl; w.C=C; w.ldc=R; w.ticket=tick; first_split=twk::build_count_units((uint32_t)list.size(),W/twk::KC,P,min_chunks,units,getenv("SHAREDIV")?atoi(getenv("SHAREDIV")):8,getenv("TAILROUNDS")?atoi(getenv("TAILROUNDS")):8); CK(hipMemcpy(du,units.data(),units.size()*16,hipMemcpyHostToDevice)); w.units=du; w.n_units=(uint32_t)units.size(); w.n_queues=1; w.queue_begin[0]=0; w.queue_begin[1]=w.n_units;
+    twk::CountWork w{}; w.rows=d; w.W=W; w.tiles=dl; w.C=C; w.ldc=R; w.ticket=tick; first_split=twk::build_count_units((uint32_t)list.size(),W/twk::KC,P,min_chunks,units,getenv("SHAREDIV")?atoi(getenv("SHAREDIV")):8,getenv("TAILROUNDS")?atoi(getenv("TAILROUNDS")):8); twk::fill_unit_tiles(units,list.data()); CK(hipMemcpy(du,units.data(),units.size()*16,hipMemcpyHostToDevice)); w.units=du; w.n_units=(uint32_t)units.size(); w.n_queues=1; w.queue_begin[0]=0; w.queue_begin[1]=w.n_units;
     const int probe_reps = getenv("FINISH_REPS")? atoi(getenv("FINISH_REPS")) : 2;       // launches back to back; the last one is reported
     for(int rep=0;rep<probe_reps;++rep){ CK(hipMemset(tick,0,4)); if(first_split<list.size()) hipLaunchKernelGGL(twk::k_zero_tiles,dim3((uint32_t)list.size()-first_split),dim3(256),0,0,w.tiles,first_split,C,R); hipLaunchKernelGGL((twk::k_count_list_t<twk::COUNT_NW,5>),dim3(P),block,0,0,w); }
     CK(hipDeviceSynchronize());
@@ -76,7 +76,7 @@ int main(int argc,char**argv){
       if(only_mode>=0 && mode!=only_mode) continue;
       std::vector<uint32_t> list; twk::CountWork w{};
       if(mode){ list=make_list(R/128,diag,mode>=2); CK(hipMemcpy(dl,list.data(),list.size()*4,hipMemcpyHostToDevice));
-        w.rows=d; w.W=W; w.rowA0=0; w.rowB0=0; w.tiles=dl; w.C=C; w.ldc=R; w.ticket=tick; first_split=twk::build_count_units((uint32_t)list.size(),W/twk::KC,P,min_chunks,units,getenv("SHAREDIV")?atoi(getenv("SHAREDIV")):8,getenv("TAILROUNDS")?atoi(getenv("TAILROUNDS")):8); CK(hipMemcpy(du,units.data(),units.size()*16,hipMemcpyHostToDevice)); w.units=du; w.n_units=(uint32_t)units.size(); w.n_queues=1; w.queue_begin[0]=0; w.queue_begin[1]=w.n_units; }
+        w.rows=d; w.W=W; w.rowA0=0; w.rowB0=0; w.tiles=dl; w.C=C; w.ldc=R; w.ticket=tick; first_split=twk::build_count_units((uint32_t)list.size(),W/twk::KC,P,min_chunks,units,getenv("SHAREDIV")?atoi(getenv("SHAREDIV")):8,getenv("TAILROUNDS")?atoi(getenv("TAILROUNDS")):8); twk::fill_unit_tiles(units,list.data()); CK(hipMemcpy(du,units.data(),units.size()*16,hipMemcpyHostToDevice)); w.units=du; w.n_units=(uint32_t)units.size(); w.n_queues=1; w.queue_begin[0]=0; w.queue_begin[1]=w.n_units; }
       auto launch=[&](){
         if(!mode){ hipLaunchKernelGGL((twk::k_count_tile_t<twk::COUNT_NW>),grid,block,0,0,d,W,0u,0u,diag,C,R); return; }
         CK(hipMemsetAsync(tick,0,4,0));

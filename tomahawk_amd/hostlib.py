@@ -45,7 +45,7 @@ def lib():
         L.twk_hwe_exact.restype = C.c_double
         L.twk_file_header_literals.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_size_t]
         L.twk_two_stream_open.restype = C.c_void_p
-        L.twk_two_stream_open.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, p, p, C.c_uint32, C.c_int, C.c_uint32, C.c_int]
+        L.twk_two_stream_open.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, p, p, C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.c_int]
         L.twk_two_stream_append.argtypes = [p, p, C.c_uint64]
         L.twk_two_stream_close.argtypes = [p, C.POINTER(C.c_uint64)]
         L.twk_ld_compute.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
@@ -189,12 +189,12 @@ class TwoStream:
     reverse blocks with the reference's flush rule -> a .two file.  What rank 0 of a multi-process run does
     with the records gathered from the other ranks."""
 
-    def __init__(self, path, n_samples, rid, pos, n_contigs=1, c_level=1, b_size=10000, n_threads=4):
+    def __init__(self, path, n_samples, rid, pos, n_contigs=1, c_level=1, b_size=10000, n_threads=4, map_output=True):
         rid = np.ascontiguousarray(rid, dtype=np.uint32)
         pos = np.ascontiguousarray(pos, dtype=np.uint32)
         assert rid.shape == pos.shape
         self._h = lib().twk_two_stream_open(path.encode(), n_samples, n_contigs, rid.ctypes.data, pos.ctypes.data, len(rid),
-                                            c_level, b_size, n_threads)
+                                            c_level, b_size, n_threads, int(bool(map_output)))
         if not self._h:
             raise RuntimeError(f"twk_two_stream_open failed for {path}")
 
