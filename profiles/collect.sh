@@ -170,6 +170,13 @@ PY
 		done
 		cat $OUT/clock_probe.txt
 		;;
+	probe)   # K1's rare x common path, measured before built: a rare variant's carriers probing a common variant's bitvector row against the
+		# dense contraction of the same pair (csrc/tools/probe_vs_dense.hip), 2N = 2,000,000 and 2N = 131,072
+		: > $OUT/probe_vs_dense.txt
+		for ac in 2 10 30 100 300 1000; do timeout 900 $R/build/probe_vs_dense 2000000 $ac 2048 2048 3 >> $OUT/probe_vs_dense.txt 2>&1; done
+		for ac in 2 10 30 100; do timeout 900 $R/build/probe_vs_dense 131072 $ac 4096 4096 3 >> $OUT/probe_vs_dense.txt 2>&1; done
+		cat $OUT/probe_vs_dense.txt
+		;;
 	kg_prof)  # the small-N regime (the reference's published shape, 2,504 samples x 200,000 cohort-shaped variants): kernel traces of
 		# `calc -p -w 1000000` (33 M surviving pairs) and of all-vs-all `-r 0.8` without the allele-count band, each with the
 		# fused count -> r2 screen kernel (default) and without it (--engine-option fused=0)

@@ -71,6 +71,7 @@ int main(int argc, char** argv) {
 	for (uint32_t y = 0; y < g; ++y) for (uint32_t x = y; x < g; ++x) tl.push_back(y << 16 | x);
 	std::vector<twk::CountUnit> units;
 	const uint32_t first_split = twk::build_count_units((uint32_t)tl.size(), W / twk::KC, 512, 8, units);
+	twk::fill_unit_tiles(units, tl.data());
 	CK(hipMalloc(&d_tiles, tl.size() * 4)); CK(hipMalloc(&d_units, units.size() * sizeof(twk::CountUnit)));
 	CK(hipMemcpy(d_tiles, tl.data(), tl.size() * 4, hipMemcpyHostToDevice));
 	CK(hipMemcpy(d_units, units.data(), units.size() * sizeof(twk::CountUnit), hipMemcpyHostToDevice));
