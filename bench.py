@@ -179,6 +179,7 @@ def run_cli(twk, flags, threads, out):
     load = re.search(r"Unpacked and uploaded .* variants\. (\S+)", lg)
     fin = re.search(r"Finished in (\S+)\. Variants: ([0-9,]+), genotypes: [0-9,]+, output: ([0-9,]+)", lg)
     eng = re.search(r"count kernel ([0-9.e+]+) ms in (\d+) launches \(([0-9.e+-]+) % [^)]*\), math kernels ([0-9.e+]+) ms", lg)
+    mhz = re.search(r"its blocks ran at (\d+) MHz", lg)
     lst = re.search(r"carrier-list kernel ([0-9.e+]+) ms in (\d+) launches over ([0-9,]+) rare pairs", lg)
     fus = re.search(r"(\d+) launches fused count -> r2 screen, ([0-9,]+) candidate", lg)
     wri = re.search(r"the producer spent ([0-9.e+-]+) s handing", lg)
@@ -196,6 +197,7 @@ def run_cli(twk, flags, threads, out):
            "and_bcnt_ceiling_frac": float(eng.group(3)) / 100.0 if eng else None,
            "frac": float(eng.group(3)) / 100.0 * (2.0 / 3.0) if eng else None,
            "math_kernels_ms": float(eng.group(4)) if eng else None,
+           "shader_mhz": int(mhz.group(1)) if mhz else None,
            "list_kernel_ms": float(lst.group(1)) if lst else None,
            "pairs_decided_by_carrier_lists": int(lst.group(3).replace(",", "")) if lst else None,
            "fused_launches": int(fus.group(1)) if fus else 0,
@@ -320,7 +322,8 @@ def extra_in_process(config, log, steps, warmup, seed=42, emulate_shard=None):
            "math_kernels_ms_per_step": tm["stats_ms"] / steps,
            "frac": pairs * lane_ops / k_s / VALU_LANE_PEAK if k_s > 0 else None,
            "and_bcnt_ceiling_frac": pairs * lane_ops / 2 / k_s / VALU_PAIR_PEAK if k_s > 0 else None,
-           "executed_frac_of_and_bcnt_ceiling": tm["row_pairs"] * tm["words_per_row"] / k_s / VALU_PAIR_PEAK if k_s > 0 else None}
+           "executed_frac_of_and_bcnt_ceiling": tm["row_pairs"] * tm["words_per_row"] / k_s / VALU_PAIR_PEAK if k_s > 0 else None,
+           "shader_mhz": (tm["count_shader_cycles"] / tm["count_wall_ticks"] * 100.0) if tm["count_wall_ticks"] else None}
     log(f"extra {config}: {res['value'] / 1e6:.1f} M pairs/s, {res['ms_per_step']:.1f} ms/step, count {res['count_kernel_ms_per_step']:.1f} ms, "
         f"and+bcnt {res['and_bcnt_ceiling_frac']}")
     return res
@@ -566,6 +569,9 @@ def main():
                          "and_bcnt_ceiling_frac": (lane_ops_per_s / 2) / VALU_PAIR_PEAK,
                          "traffic": None,
                          "traffic_note": "not measured in this run (rocprofv3 counter passes skipped or unavailable); see profiles/ for the round's figure",
+                         # the clock the kernel's blocks really ran at (s_memtime against the constant 100 MHz counter over every block's
+                         # life); peak and ceiling above are quoted at the nominal 2.4 GHz
+                         "shader_mhz": (tm["count_shader_cycles"] / tm["count_wall_ticks"] * 100.0) if tm["count_wall_ticks"] else None,
                          "kernel": "twk::k_count_list_t", "launches": int(tm["count_launches"]),
                          "avg_launch_ms": k_ms / max(tm["count_launches"], 1),
                          "algorithmic_lane_ops_per_pair": lane_ops_per_pair,

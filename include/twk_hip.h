@@ -316,6 +316,9 @@ typedef struct {
 	                           counts: the device's twk_igt_list / PhasedListVector, core.h:517-672, ld_engine.cpp:185-267) */
 	uint64_t list_launches;
 	uint64_t list_pairs;    /* variant pairs decided by list intersection instead of the dense contraction */
+	uint64_t count_shader_cycles; /* what the count kernel's blocks lived for, summed over the blocks: shader clock cycles ...   */
+	uint64_t count_wall_ticks;    /* ... and ticks of the constant 100 MHz counter.  cycles / ticks x 100 MHz = the clock the
+	                                 launches really ran at (a chip that was idle needs ~20 ms of load to reach its 2.4 GHz) */
 } twk_hip_timing;
 /* Progress of twk_hip_ld_all / twk_hip_ld_region: `cb` runs on the calling thread after every tile
  * with the variant pairs finished so far in the current call and the tile counts.  Replaces the

@@ -281,3 +281,36 @@ def test_record_stream_blocks_follow_the_flush_rule(tmp_path, n_threads, b_size)
     assert np.array_equal(fwd["ridA"], rid[want["idxA"]]) and np.array_equal(fwd["ridB"], rid[want["idxB"]])
     assert np.array_equal(fwd["packA"] >> 2, pos[want["idxA"]]) and np.array_equal(fwd["packB"] >> 2, pos[want["idxB"]])
     assert np.array_equal(fwd["R2"], want["R2"]) and np.array_equal(fwd["cnt"], want["cnt"])
+
+
+def test_mapped_and_stream_output_write_the_same_file(tmp_path):
+    """TwoWriter's mapped mode (map_output: frames given their place by an ordered placing step, copied into a shared mapping
+    by the emitter's workers in parallel, file cut to size at close) against the stream (one append at a time): the same
+    bytes, for ragged appends on three contigs, and the index at the end reads back.  The stream is the default - the
+    mapping measured slower on the GPU box (profiles/r04_writer_ab.txt) - but stays selectable (engine option map_output)."""
+    import hashlib
+    M = 600
+    rng = np.random.default_rng(9)
+    rid = np.repeat(np.arange(3), M // 3).astype(np.uint32)
+    pos = np.concatenate([1000 + 10 * np.arange(M // 3)] * 3).astype(np.uint32)
+    recs = np.zeros(70_000, dtype=T.RECORD_DTYPE)
+    a = np.sort(rng.integers(0, M - 1, len(recs)).astype(np.uint32))
+    recs["idxA"] = a
+    recs["idxB"] = np.minimum(a + 1 + rng.integers(0, 40, len(recs)).astype(np.uint32), M - 1)
+    recs = recs[np.lexsort((recs["idxB"], recs["idxA"]))]
+    for f in ("D", "Dprime", "R", "R2", "P", "ChiSqFisher"):
+        recs[f] = rng.random(len(recs))
+    recs["cnt"] = rng.integers(0, 500, (len(recs), 4))
+    digests = {}
+    for mapped in (False, True):
+        path = str(tmp_path / f"m{int(mapped)}.two")
+        st = hostlib.TwoStream(path, 50, rid, pos, n_contigs=3, b_size=1000, n_threads=5, map_output=mapped)
+        k = 0
+        for n in (1, 999, 1000, 1001, 7, 30_000, 0, 12_345):
+            st.append(recs[k:k + n]); k += n
+        st.append(recs[k:])
+        assert st.close() == 2 * len(recs)
+        digests[mapped] = hashlib.sha256(open(path, "rb").read()).hexdigest()
+        back, info = hostlib.read_two(path)
+        assert len(back) == 2 * len(recs) and info["n_blocks"] > 100
+    assert digests[False] == digests[True]

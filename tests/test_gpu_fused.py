@@ -386,7 +386,7 @@ def test_band_launches_equal_matrix_sized_tiles(hip, opt, mode):
             t1 = hip.timing()
             assert np1 == np0 and nr1 == nr0 and np.sort(got, order=ORDER).tobytes() == want, (name, log2)
             assert t1["fused_launches"] == t1["count_launches"] >= 1, (name, log2, t1)
-            if log2 < 19:
+            if log2 < 19 and name in ("all", "band", "rectangle"):
                 assert t1["count_launches"] > 1, (name, log2, t1)
             if n_launch is not None and name in ("all", "window", "rectangle"):
                 assert t1["count_launches"] == n_launch, (name, log2, t1)

@@ -10,7 +10,7 @@ import os as _os
 _STATS_PATH = _os.environ.get("TWK_PARITY_STATS", "")     # tests/sweeps: record the observed deviations
 
 # ---- bookkeeping of every exemption assert_records_match grants (reported at session end, tests/conftest.py) -------
-# kinds: "floor:<field>"   a cubic-path record passed <field> only through its absolute floor (CUBIC_FLOOR), not the 1e-6 bar
+# kinds: "floor:<field>"   a cubic-path record passed <field> only through its own absolute floor (cubic_floors), not the 1e-6 bar
 #        "p-denormal"      Fisher's P below DBL_MIN on both sides, equal to a few hundred steps of the denormal grid
 #        "p-floor"         Fisher's P compared through an absolute floor of 1e-320 (the denormal grid) otherwise; 1e-290 until the walks started on the reference's re-synchronisation cells
 #        "tie:roots"       root-multiplicity flag (bit 5) differs
@@ -195,15 +195,35 @@ def double_root_vetter(data, mask, variants, n_samples):
     return vet
 
 
-# Absolute floors for records that come out of the unphased cubic (ld_engine.cpp:1363-1558), on top of the 1e-6
-# relative bar.  The cubic is ill-conditioned where D ~ 0 and next to a double root, so device (ocml) and reference
-# (glibc) differ in the last digits of the root there, and D = f11 - pA pB cancels: the floors are ~10x the largest
-# deviation *beyond the relative bar* seen over 867 k such records - every -m gpu test plus the four oracle sweeps of
-# tests/sweeps (TWK_PARITY_STATS, tests/sweeps/parity_stats.sh, round 2): D 3.4e-12, D' 8.8e-8, R 7.8e-10, R2 9e-14, expected
-# counts 4.3e-12 and ChiSqFisher 1.8e-11 of the table total.  The D' and R figures are one pair of
-# haplotype_block_sweep_large_n.py (N = 20,000 with missing genotypes, r2 = 3e-9, D' = 0.0063: D itself is -2.4e-7 and
-# agrees to 3.6e-12, 1.5e-5 relative); without it the worst are D' 7.5e-10 and R 1.6e-11.
-CUBIC_FLOOR = {"D": 5e-11, "Dprime": 1e-6, "R": 1e-8, "R2": 1e-10, "cnt/total": 5e-11, "ChiSqFisher/total": 2e-10}
+# Records that come out of the unphased cubic (ld_engine.cpp:1363-1558) carry the root f11 of a cubic whose coefficients
+# are O(n) while its slope at the root is O(1) or, next to a double root, far less: one unit of rounding in every term
+# moves the root by dx = 2^-53 (|a x^3| + |b x^2| + |c x| + |d|) / |g'(x)| (double_root_vetter(...).root_error).  Device
+# (ocml) and reference (glibc) differ by a fraction of that in f11, and everything else in the record follows from it:
+#     D = f11 - pA pB                        |dD|  <= dx
+#     D' = D / dmax                          |dD'| <= dx / dmax
+#     r = D / sqrt(pA qA pB qB)              |dr|  <= dx / sqrt(pA qA pB qB),  |d r2| <= 2 |r| |dr| + dr^2
+#     expected counts = f * total            |dcnt| <= dx * total;   ChiSqFisher = total * r2
+# so a record's floors are *its own*: ROOT_ERROR_FACTOR x its dx (largest deviation / dx seen: 0.42 - the pair of
+# test_cubic_record_with_cancelling_d: dx 8.6e-12, observed 3.6e-12), propagated through its own dmax and allele frequencies
+# (taken from the oracle's record).  A well-conditioned record thereby never gets more than D_FLOOR = 1e-14 on f11's scale
+# - what plain rounding leaves of a D that is zero: 50 records of the 432 k cubic records of the -m gpu suite differ
+# beyond the relative bar, by at most 1e-15 in D (profiles/r04_parity_stats_beyond.json) - and the one absolute floor of
+# round 3 that a record could hide behind (D' 1e-6, sized by a single N = 20,000 pair) is gone.  Callers that hold the
+# genotypes pass double_root=double_root_vetter(...); without it only D_FLOOR applies.
+D_FLOOR = 1e-14
+ROOT_ERROR_FACTOR = 4.0
+
+
+def cubic_floors(cnt, r, dx):
+    """Absolute floors of one cubic-path record from the uncertainty dx of its root -> dict for D, Dprime, R, R2, ChiSqFisher, cnt."""
+    tot = float(cnt[0] + cnt[1] + cnt[2] + cnt[3])
+    pA, pB = float(cnt[0] + cnt[1]) / tot, float(cnt[0] + cnt[2]) / tot
+    dmax = min(pA * pB, pA * (1 - pB), (1 - pA) * pB, (1 - pA) * (1 - pB))         # the smaller of the two dmax the sign of D selects between
+    den = (pA * (1 - pA) * pB * (1 - pB)) ** 0.5
+    inf = float("inf")
+    fR = dx / den if den > 0 else inf
+    fR2 = 2 * abs(float(r)) * fR + fR * fR
+    return dict(D=dx, Dprime=dx / dmax if dmax > 0 else inf, R=fR, R2=fR2, ChiSqFisher=tot * fR2, cnt=dx * tot)
 
 
 def _one_term_apart(p_a, p_b, table):
@@ -217,16 +237,16 @@ def _one_term_apart(p_a, p_b, table):
 
 
 def assert_records_match(gpu_recs, orc_recs, variants, n_samples=None, rtol=1e-6, p_floor=1e-320,
-                         double_root=None):
+                         double_root=None, count=True):
     """gpu_recs: tomahawk_amd.RECORD_DTYPE (variant indices); orc_recs: oracle RECORD_DTYPE (rid/pos).
 
     Bar (BASELINE.json north_star): counts bit-exact, statistics within 1e-6 relative.
       * Records produced by PhasedMath (flag bit 0: -p, or -u pairs without double hets) are held
         to exactly that: integer counts identical, every statistic within `rtol`, no floors.
       * Records produced by the unphased cubic (ld_engine.cpp:1363-1558) carry *expected* haplotype
-        counts f*2n.  The cubic is ill-conditioned where D ~ 0 and next to a double root (acos near
-        +-1), and the last digits depend on libm: those records get the absolute floors CUBIC_FLOOR
-        (~10x the largest deviation observed) on top of `rtol`.
+        counts f*2n.  The last digits of the root depend on libm, by an amount the cubic's conditioning at that
+        root bounds: those records get, on top of `rtol`, absolute floors of their own (cubic_floors: a few times the
+        root's uncertainty, propagated through the record's own dmax and allele frequencies).
     """
     pos2idx = {(int(v["rid"]), int(v["pos"])): i for i, v in enumerate(variants)}
     want = {}
@@ -248,6 +268,8 @@ def assert_records_match(gpu_recs, orc_recs, variants, n_samples=None, rtol=1e-6
             want.pop(k, None); got.pop(k, None)
     assert not missing and not extra, f"pair sets differ: missing {sorted(missing)[:5]} extra {sorted(extra)[:5]}"
     ties, bad = [], []
+    root_error = getattr(double_root, "root_error", None)
+    cnt_floor = 0.0
     dev = {}                                     # largest deviations seen on cubic-path records (TWK_PARITY_STATS)
     for k, w in want.items():
         g = got[k]
@@ -278,9 +300,13 @@ def assert_records_match(gpu_recs, orc_recs, variants, n_samples=None, rtol=1e-6
             if not np.array_equal(g["cnt"], w["cnt"]):          # integer counts, slot for slot
                 bad.append((k, "cnt", g["cnt"].tolist(), w["cnt"].tolist()))
         else:
-            floors = dict(D=CUBIC_FLOOR["D"], Dprime=CUBIC_FLOOR["Dprime"], R=CUBIC_FLOOR["R"], R2=CUBIC_FLOOR["R2"],
-                          ChiSqFisher=CUBIC_FLOOR["ChiSqFisher/total"] * total, ChiSqModel=0.0)
-            if not np.allclose(g["cnt"], w["cnt"], rtol=0.0, atol=CUBIC_FLOOR["cnt/total"] * total):
+            dx = D_FLOOR
+            if root_error is not None and total > 0:
+                dx = max(dx, ROOT_ERROR_FACTOR * root_error(k[0], k[1], float(w["cnt"][0]) / total)[0])
+            cf = cubic_floors([float(x) for x in w["cnt"]], w["R"], dx)
+            cnt_floor = cf["cnt"]
+            floors = dict(D=cf["D"], Dprime=cf["Dprime"], R=cf["R"], R2=cf["R2"], ChiSqFisher=cf["ChiSqFisher"], ChiSqModel=0.0)
+            if not np.allclose(g["cnt"], w["cnt"], rtol=0.0, atol=cnt_floor):
                 bad.append((k, "cnt", g["cnt"].tolist(), w["cnt"].tolist()))
             elif not np.allclose(g["cnt"], w["cnt"], rtol=rtol, atol=0.0):
                 used["floor:cnt"] += 1
@@ -306,7 +332,7 @@ def assert_records_match(gpu_recs, orc_recs, variants, n_samples=None, rtol=1e-6
             neighbour = (not phased_math) and gt != wt and max(abs(a - b) for a, b in zip(gt, wt)) <= 1
             # ... and every cell that rounds differently must sit on a half-integer within the cubic's tolerance
             for a, b, x in zip(gt, wt, w["cnt"]):
-                if a != b and abs(float(x) - np.floor(float(x)) - 0.5) > CUBIC_FLOOR["cnt/total"] * total:
+                if a != b and abs(float(x) - np.floor(float(x)) - 0.5) > cnt_floor:
                     neighbour = False
             own = O.fisher(gt[0], gt[2], gt[1], gt[3])[2] if neighbour else None
             if max(abs(gP), abs(wP)) < 2.2250738585072014e-308 and abs(gP - wP) <= 2e-321:
@@ -329,7 +355,7 @@ def assert_records_match(gpu_recs, orc_recs, variants, n_samples=None, rtol=1e-6
                 # absolute floor on P went from 1e-290 to 1e-320: N = 100,000, P = 3.2e-316 against 4.7e-316).  (Also for q below
                 # ~1e-290 at any n, where the reference's recurrence starts on denormal terms; there the
                 # device runs the reference's own recurrence - k_ld_fisher_t - from the same cells and agrees.)
-                ties.append((k, "fisher-stop"))
+                ties.append((k, "fisher-stop", sum(gt), max(gP, wP)))
             elif np.isclose(gP, wP, rtol=rtol, atol=p_floor):
                 # Fisher P underflows to exactly 0 for strong associations: absolute floor for what is left
                 used["p-floor"] += 1
@@ -344,12 +370,15 @@ def assert_records_match(gpu_recs, orc_recs, variants, n_samples=None, rtol=1e-6
     assert not bad, f"{len(bad)} field mismatches of {len(want)} records, first: {bad[:8]}"
     # every tie kind is argued record by record above AND capped per call, so that a systematic device error (always
     # rounding halves the other way, never counting the observed table in Fisher's sum) cannot hide behind them
-    for kind, frac in (("roots", 0.02), ("round", 0.02), ("fisher-stop", 0.25)):
+    for kind, frac in (("roots", 0.02), ("round", 0.02), ("fisher-stop", 0.15)):
         mine = [t for t in ties if t[1] == kind]
         used["tie:" + kind] += len(mine)
         assert len(mine) <= max(2, int(len(want) * frac)), f"too many {kind} ties: {len(mine)} of {len(want)}: {mine[:5]}"
+        if kind == "fisher-stop":       # only where the reference's own stopping rule is undecided: n >= 1e6, or P on the denormal grid
+            assert all(t[2] >= 1_000_000 or t[3] < 1e-305 for t in mine), mine[:5]
     used["double-root"] += n_double_root
     n_cubic = sum(1 for w in want.values() if not (int(w["controller"]) & 1))
-    EXEMPTIONS.update(used)
-    COMPARED.update({"records": len(want), "cubic": n_cubic, "calls": 1})
+    if count:                                    # (count=False: a call that is expected to fail, kept out of the session's accounting)
+        EXEMPTIONS.update(used)
+        COMPARED.update({"records": len(want), "cubic": n_cubic, "calls": 1})
     return {"records": len(want), "cubic": n_cubic, **{k: v for k, v in used.items() if v}}

@@ -376,6 +376,11 @@ struct CountWork {
 	// them is zero in every plane, so the contraction of the last chunk stops there: at 2 504 samples an unphased
 	// row is 79 live words in 3 chunks of 32, and the last 8 half-slots of every tile are skipped (-17 %).
 	uint32_t last_halves;
+	// [2] (may be null): every block adds the shader cycles (s_memtime) and the ticks of the constant 100 MHz counter
+	// (s_memrealtime) it lived for: their ratio is the clock the launch really ran at.  The and+bcnt ceiling is quoted at
+	// 2.4 GHz; a launch that starts on an idle chip runs its first ~20 ms below that (1.9 GHz for a 2 ms launch,
+	// profiles/r04_clock_probe.txt), which is most of what short-row runs lose against long ones.
+	unsigned long long* clocks;
 };
 
 // The unit table of a launch (host side; shared by the engine and the dev tools).  Guided self-scheduling:
@@ -481,8 +486,7 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 	const int li = lane >> 3, lj = lane & 7;
 	const uint32_t nchunks = w.W / KC;
 	const uint32_t n_units = w.n_units;
-	unsigned long long probe_wall0 = 0, probe_clk0 = 0;      // EXPERIMENT == 5 only: the block's start on the constant 100 MHz clock and on the shader clock
-	if (EXPERIMENT == 5) { probe_wall0 = wall_clock64(); probe_clk0 = clock64(); }
+	const unsigned long long probe_wall0 = wall_clock64(), probe_clk0 = clock64();      // the block's start on the constant 100 MHz clock and on the shader clock (scalar registers)
 
 	// unit id -> (tile, first chunk, end chunk); wave-uniform (scalar loads)
 	auto decode = [&](uint32_t u, uint32_t& tl, uint32_t& c0, uint32_t& c1, uint32_t& yx) {
@@ -642,6 +646,11 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 			if (EXPERIMENT != 6) epilogue(acc, yx, wr, wc, li, lj, lane, seg_c0 == 0 && c_end == nchunks, meta, window);      // (6: the dev tool's no-epilogue timing)
 			if (!more) {
 				epilogue.finish(window, lane);
+				if (tid == 0 && w.clocks) {
+					typedef __attribute__((address_space(1))) unsigned long long g_u64;
+					__hip_atomic_fetch_add((g_u64*)w.clocks, clock64() - probe_clk0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					__hip_atomic_fetch_add((g_u64*)w.clocks + 1, wall_clock64() - probe_wall0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				}
 				if (EXPERIMENT == 5 && tid == 0) {      // probe: when did this block finish, and on which XCD / CU?
 					uint32_t xcc, hwid;
 					asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));

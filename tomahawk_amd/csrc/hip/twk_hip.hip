@@ -65,14 +65,16 @@ enum { MODE_INT_AUTO_CLEAN = 0x10,     // phased math on the plain planes; pairs
        MODE_INT_SORTED_P   = 0x12,     // phased math on the allele-count-sorted planes (variants without missing data)
        MODE_INT_SORTED_U   = 0x13 };   // unphased math on the allele-count-sorted planes
 
+constexpr int N_SLOT_COUNTERS = 8;
 struct Slot {                      // one in-flight tile (double buffered)
 	uint32_t* C = nullptr; size_t C_words = 0;
 	twk_hip_record* out = nullptr; unsigned long long capacity = 0;      // survivor buffer and its size (grow-only)
 	unsigned long long* keys = nullptr; uint32_t* vals = nullptr;        // [capacity]: sort key and position of every survivor, written where it is appended
 	unsigned long long cap_use = 0;               // ... of which the current launch may use this many (what the caller asked for)
 	unsigned long long* n_out = nullptr;          // device counters: [0] survivors appended, [1] of those dropped by the Fisher cut-off,
-	                                              // [2] candidates of the fused count kernel, [3] spare
-	unsigned long long* h_n_out = nullptr;        // pinned host copy of all four
+	                                              // [2] candidates of the fused count kernel, [3] spare, [4] shader cycles and [5] 100 MHz ticks
+	                                              // the count kernel's blocks lived for (summed over the blocks), [6], [7] spare
+	unsigned long long* h_n_out = nullptr;        // pinned host copy of all of them
 	hipEvent_t ev_c0 = nullptr, ev_c1 = nullptr, ev_s1 = nullptr, ev_c0b = nullptr, ev_c1b = nullptr;
 	bool two_pass = false;
 	bool is_list = false;                         // the launch was a carrier-list pass (ld_list.hip.h): C holds its candidate list
@@ -520,6 +522,7 @@ int launch_count(twk_hip_ctx* c, int set, const twk_hip_tile_desc& t, Slot& s, i
 		w.C = s.C; w.ldc = g.ldc;
 		w.ticket = c->tickets + ((&s - c->slot) * 2 + which) * 8;
 		w.n_queues = n_queues;
+		w.clocks = s.n_out + 4;
 		for (int q = 0; q < 9; ++q) w.queue_begin[q] = queue_begin[q];
 		{
 			const bool skip_pad = c->opt.skip_pad != 0;      // measurement hook: 0 = contract the zero padding too
@@ -655,7 +658,7 @@ int enqueue_tile(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, const twk
 	rc = ensure_slot(c, s, list_words ? list_words : (size_t)g.rowsA * g.rowsB, capacity); if (rc) return rc;
 	s.two_pass = two_pass;
 
-	HIPCHK(c, hipMemsetAsync(s.n_out, 0, 4 * sizeof(unsigned long long), c->s_compute));
+	HIPCHK(c, hipMemsetAsync(s.n_out, 0, N_SLOT_COUNTERS * sizeof(unsigned long long), c->s_compute));
 	// The fused form: plain phased planes (one count per pair) with PhasedMath, or plain unphased planes (four products per
 	// pair, gathered in the epilogue) with UnphasedMath, and an r2 cut-off the screen can use.
 	const bool fused_u = !phased && set_kind(kind1) == PK_UNPHASED;
@@ -705,7 +708,7 @@ int enqueue_tile(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, const twk
 	rc = launch_fisher(c, s.out, s.n_out, s.cap_use, f.minP, s.C, s.C_words, s.keys); if (rc) return rc;
 	HIPCHK(c, hipGetLastError());
 	s.minP = f.minP;
-	HIPCHK(c, hipMemcpyAsync(s.h_n_out, s.n_out, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->s_compute));
+	HIPCHK(c, hipMemcpyAsync(s.h_n_out, s.n_out, N_SLOT_COUNTERS * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->s_compute));
 	HIPCHK(c, hipEventRecord(s.ev_s1, c->s_compute));
 	return TWK_HIP_OK;
 }
@@ -790,7 +793,8 @@ int finish_tile(twk_hip_ctx* c, Slot& s, const twk_hip_tile_desc& t, unsigned lo
 	float ms = 0;
 	HIPCHK(c, hipEventElapsedTime(&ms, s.ev_c0, s.ev_c1));
 	if (s.is_list) { c->timing.list_ms += ms; c->timing.list_launches += 1; c->timing.list_pairs += s.row_pairs; c->timing.candidates += s.h_n_out[2]; }
-	else { c->timing.count_ms += ms; c->timing.count_launches += 1; c->timing.row_pairs += s.row_pairs; }
+	else { c->timing.count_ms += ms; c->timing.count_launches += 1; c->timing.row_pairs += s.row_pairs;
+	       c->timing.count_shader_cycles += s.h_n_out[4]; c->timing.count_wall_ticks += s.h_n_out[5]; }
 	if (s.fused) { c->timing.fused_launches += 1; c->timing.candidates += s.h_n_out[2]; }
 	float ms_all = 0;
 	if (s.two_pass) {
@@ -870,7 +874,7 @@ int run_list_block(twk_hip_ctx* c, const twk_hip_filters& f, bool unphased, uint
 	twk_hip_tile_desc t{};
 	t.rowA0 = row0; t.nA = n_rows; t.rowB0 = row0; t.nB = zone - row0; t.diag = 1; t.window = window; t.l_window = l_window;
 	const StatsParams sp = make_stats(c, set, t, s, !unphased, 0, f, &cr);
-	HIPCHK(c, hipMemsetAsync(s.n_out, 0, 4 * sizeof(unsigned long long), c->s_compute));
+	HIPCHK(c, hipMemsetAsync(s.n_out, 0, N_SLOT_COUNTERS * sizeof(unsigned long long), c->s_compute));
 	HIPCHK(c, hipMemcpyAsync(c->d_list_stats, &sp, sizeof(sp), hipMemcpyHostToDevice, c->s_compute));
 	ListWork w{};
 	w.lists = ps.lists; w.stride = ps.list_max + 1; w.mac = ps.list_mac; w.flip = ps.list_flip; w.rowpop = ps.rowpop;
@@ -904,7 +908,7 @@ int run_list_block(twk_hip_ctx* c, const twk_hip_filters& f, bool unphased, uint
 		HIPCHK(c, hipGetLastError());
 	}
 	{ const int rc = launch_fisher(c, s.out, s.n_out, s.cap_use, f.minP, s.C, s.C_words, s.keys); if (rc) return rc; }
-	HIPCHK(c, hipMemcpyAsync(s.h_n_out, s.n_out, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->s_compute));
+	HIPCHK(c, hipMemcpyAsync(s.h_n_out, s.n_out, N_SLOT_COUNTERS * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->s_compute));
 	HIPCHK(c, hipEventRecord(s.ev_s1, c->s_compute));
 	return finish_tile(c, s, t, n_out, to_host, sink, user);
 }
@@ -1050,8 +1054,9 @@ int twk_hip_ctx_create(int device, twk_hip_ctx** out) {
 	for (auto& s : c->slot) {
 		hipEvent_t* evs[] = {&s.ev_c0, &s.ev_c1, &s.ev_s1, &s.ev_c0b, &s.ev_c1b};
 		for (auto* e : evs) if (hipEventCreate(e) != hipSuccess) return fail(TWK_HIP_E_DEVICE);
-		if (hipMalloc((void**)&s.n_out, 4 * sizeof(unsigned long long)) != hipSuccess) return fail(TWK_HIP_E_NOMEM);
-		if (hipHostMalloc((void**)&s.h_n_out, 4 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) return fail(TWK_HIP_E_NOMEM);
+		if (hipMalloc((void**)&s.n_out, N_SLOT_COUNTERS * sizeof(unsigned long long)) != hipSuccess) return fail(TWK_HIP_E_NOMEM);
+		if (hipHostMalloc((void**)&s.h_n_out, N_SLOT_COUNTERS * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) return fail(TWK_HIP_E_NOMEM);
+		std::memset(s.h_n_out, 0, N_SLOT_COUNTERS * sizeof(unsigned long long));
 	}
 	*out = c;
 	return TWK_HIP_OK;

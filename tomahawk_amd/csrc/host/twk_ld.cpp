@@ -519,9 +519,12 @@ bool twk_ld::twk_ld_impl::run(twk_ld_settings& settings, const Header& hdr, cons
 	using clock = std::chrono::steady_clock;
 	const RunSpec& spec = *static_cast<const RunSpec*>(spec_);
 	if (!open_output(settings, hdr, out.writer)) return false;
-	// blocks go into the file through a shared mapping, copied in by the emitter's workers in parallel (twk_format.h); a
-	// stream for stdout and wherever the file cannot be mapped.  (engine option "map_output" = 0: always a stream - A/B runs)
-	if (option("map_output", 1)) (void)out.writer.map_output();
+	// Engine option "map_output" = 1: blocks go into the file through a shared mapping, copied in by the emitter's workers in
+	// parallel (twk_format.h).  Built because round 3's single writer thread looked like the bound of survivor-rich runs;
+	// measured on the GPU box it is 2-3x *slower* than the stream (66 M records, 4.3 GB: 2.8-3.0 s against 1.0 s,
+	// profiles/r04_writer_ab.txt - 32 threads taking page faults in one address space do not scale there), so the stream
+	// stays the default and the mapping an option.
+	if (option("map_output", 0)) (void)out.writer.map_output();
 	out.b_size = (uint32_t)std::max(2, settings.b_size);
 	out.c_level = settings.c_level; out.rid = rid.data(); out.pos = pos.data(); out.n_variants = rid.size(); out.n_records = 0;
 	n_records = 0; n_pairs = 0;
@@ -655,7 +658,9 @@ bool twk_ld::twk_ld_impl::run(twk_ld_settings& settings, const Header& hdr, cons
 			std::cerr << stamp("LOG", "HIP") << (n_gpus > 1 ? "GPU " + std::to_string(g) + ": " : std::string()) << "count kernel " << tm.count_ms << " ms in "
 			          << tm.count_launches << " launches ("
 			          << (tm.count_ms > 0 ? (double)tm.row_pairs * (double)tm.words_per_row / (tm.count_ms * 1e-3) / 2.62e13 * 100.0 : 0.0)
-			          << " % of the and+bcnt issue ceiling over the tiles it contracted), math kernels " << tm.stats_ms << " ms"
+			          << " % of the and+bcnt issue ceiling over the tiles it contracted"
+			          << (tm.count_wall_ticks ? "; its blocks ran at " + std::to_string((int)((double)tm.count_shader_cycles / (double)tm.count_wall_ticks * 100.0 + 0.5)) + " MHz" : std::string())
+			          << "), math kernels " << tm.stats_ms << " ms"
 			          << (tm.fused_launches ? "; " + std::to_string(tm.fused_launches) + " launches fused count -> r2 screen, " + pretty(tm.candidates) + " candidate slots" : std::string())
 			          << (tm.list_launches ? "; carrier-list kernel " + std::to_string(tm.list_ms) + " ms in " + std::to_string(tm.list_launches) + " launches over " + pretty(tm.list_pairs) + " rare pairs" : std::string())
 			          << std::endl;

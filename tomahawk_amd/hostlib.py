@@ -189,7 +189,7 @@ class TwoStream:
     reverse blocks with the reference's flush rule -> a .two file.  What rank 0 of a multi-process run does
     with the records gathered from the other ranks."""
 
-    def __init__(self, path, n_samples, rid, pos, n_contigs=1, c_level=1, b_size=10000, n_threads=4, map_output=True):
+    def __init__(self, path, n_samples, rid, pos, n_contigs=1, c_level=1, b_size=10000, n_threads=4, map_output=False):
         rid = np.ascontiguousarray(rid, dtype=np.uint32)
         pos = np.ascontiguousarray(pos, dtype=np.uint32)
         assert rid.shape == pos.shape
