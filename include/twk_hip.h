@@ -276,6 +276,8 @@ int twk_hip_fisher_exact(twk_hip_ctx* ctx, const int32_t* tables, uint64_t n, do
  *   "lists"            1        carrier lists for the rare head of the sorted plane sets: 0 never, 1 rows of >= 4096
  *                               words, 2 always (lists of >= 8 carriers)
  *   "list_max"         0        longest carrier list kept (0: row words / 128, / 64 for unphased math)
+ *   "probe"            1        pairs of a listed variant with one that keeps no list: probes of its carriers into the
+ *                               partner's row instead of the dense contraction (0: dense)
  *   "record_cap"       0        cap on a launch's survivor buffer in records (0: none) - forces the overflow path
  *   "count_min_chunks" 8        shortest K range a tile of the count kernel is split into
  *   "patch_rows/_cols" 8 / 8    patch of tiles in the count kernel's work order
@@ -316,6 +318,10 @@ typedef struct {
 	                           counts: the device's twk_igt_list / PhasedListVector, core.h:517-672, ld_engine.cpp:185-267) */
 	uint64_t list_launches;
 	uint64_t list_pairs;    /* variant pairs decided by list intersection instead of the dense contraction */
+	double   probe_ms;      /* sum of the probe kernel's durations: a rare variant's carrier list against the bitvector rows of variants
+	                           that keep no list (K1's asymmetric path, ld_engine.cpp:230-242) */
+	uint64_t probe_launches;
+	uint64_t probe_pairs;   /* variant pairs decided that way */
 	uint64_t count_shader_cycles; /* what the count kernel's blocks lived for, summed over the blocks: shader clock cycles ...   */
 	uint64_t count_wall_ticks;    /* ... and ticks of the constant 100 MHz counter.  cycles / ticks x 100 MHz = the clock the
 	                                 launches really ran at (a chip that was idle needs ~20 ms of load to reach its 2.4 GHz) */

@@ -143,3 +143,44 @@ def test_unphased_list_zone_equals_dense_and_oracle(hip, opt, N, forced):
     want = O.all_pairs(data[sub], None, variants[sub], N, O.settings(minR2=0.05, unphased=True), vector_only=False)
     assert len(want) > 20
     util.assert_records_match(got, want, variants[sub], n_samples=N, double_root=util.double_root_vetter(data[sub], None, variants[sub], N))
+
+
+@pytest.mark.parametrize("mode,N,forced", [(T.MODE_PHASED, 66_000, False), (T.MODE_UNPHASED, 66_000, False), (T.MODE_PHASED, 1500, True), (T.MODE_UNPHASED, 1500, True)])
+def test_probe_pass_equals_dense_and_merges_only(hip, opt, mode, N, forced):
+    """K1's asymmetric path (lib/ld/ld_engine.cpp:230-242: walk the shorter carrier list, test the partner's bitvector): the
+    pairs of a zone variant with a variant that keeps no list are probes of its carriers into the partner's plane row(s)
+    (k_probe_screen / k_probe_screen_unphased) instead of dense contractions.  Three ways - no lists at all, merges inside the
+    zone only (option probe = 0), merges + probes - the same records bit for bit, for several cut-offs (band widths), shards,
+    a Fisher cut-off, variants turned into their complements (REF-minor lists), and with a survivor buffer that overflows; with
+    probes no tile row inside the zone is contracted."""
+    M = 1500 if not forced else 2200
+    al = _with_flips(_cohort_alleles(M, N, 1300 + N + mode), 7)
+    data, mask = O.bitvectors_from_alleles(al)
+    variants = O.variants_from_alleles(al)
+    calls = [lambda: hip.ld_all(mode, T.Filters(minR2=0.1), window=T.OPT_R2_SCREEN)[0],
+             lambda: hip.ld_all(mode, T.Filters(minR2=0.004), window=T.OPT_R2_SCREEN)[0],
+             lambda: np.concatenate([hip.ld_all(mode, T.Filters(minR2=0.02), part=k, n_parts=3, window=T.OPT_R2_SCREEN)[0] for k in range(3)]),
+             lambda: hip.ld_all(mode, T.Filters(minR2=0.05, minP=1e-6), window=T.OPT_R2_SCREEN)[0]]
+
+    def run(lists, probe, cap=0):
+        opt.set("lists", lists); opt.set("probe", probe); opt.set("record_cap", cap)
+        hip.set_problem(N, M)
+        hip.upload(data, util.to_hip_meta(variants), None)
+        out = []
+        for call in calls:
+            hip.timing_reset()
+            recs = call()
+            out.append((np.sort(recs, order=ORDER).tobytes(), len(recs), hip.timing()))
+        return out
+
+    dense = run(0, 0)
+    merges = run(2 if forced else 1, 0)
+    probes = run(2 if forced else 1, 1)
+    tiny = run(2 if forced else 1, 1, cap=60)
+    for k, (d, m, p, t) in enumerate(zip(dense, merges, probes, tiny)):
+        assert d[1] > 20 and d[0] == m[0] == p[0] == t[0], (k, d[1], m[1], p[1], t[1])
+        assert d[2]["list_launches"] == 0 and d[2]["probe_launches"] == 0
+        assert m[2]["list_launches"] > 0 and m[2]["probe_launches"] == 0
+        assert p[2]["probe_launches"] > 0 and p[2]["probe_pairs"] > 1000, (k, p[2])
+        assert p[2]["row_pairs"] < m[2]["row_pairs"] < d[2]["row_pairs"], (k, p[2]["row_pairs"], m[2]["row_pairs"], d[2]["row_pairs"])
+        assert t[2]["probe_launches"] > p[2]["probe_launches"]              # the overflowing buffer made it take fewer rows per launch

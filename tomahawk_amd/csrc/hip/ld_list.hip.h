@@ -230,4 +230,112 @@ void k_list_screen_unphased(const ListWork w, uint32_t n_samples) {
 	}
 }
 
+
+// ---- rare x common: a rare variant's carriers probing a common variant's row -----------------------------------------
+// The reference's list kernel walks the *shorter* of the two carrier lists and tests the partner's bitvector
+// (PhasedListVector, lib/ld/ld_engine.cpp:230-242: O(min carriers) per pair).  The merge kernels above need a list on both
+// sides; a pair of a zone variant with a variant *outside* the zone (more carriers than a list holds) was contracted densely
+// until round 4.  Measured (csrc/tools/probe_vs_dense.hip, profiles/r04_probe_vs_dense.txt): at 2N = 2,000,000 a probe of
+// AC carriers into a 250 KB row costs 31 / 126 / 293 / 660 / 1,485 ps per pair for AC = 2 / 10 / 30 / 100 / 300 against
+// 2,614 ps for the dense pair - it wins up to ~550 carriers, i.e. for every row of the zone (lists are kept up to W / 128 =
+// 488 carriers) - and at 2N = 131,072 up to ~80 (lists: up to 32).  Layout as measured: a wave is 64 consecutive zone rows
+// against ONE column - every lane walks its own list and reads the column's word h / 32 - and the blocks of one column run
+// next to each other (block id = column x row blocks + row block), so the column's row stays in L2 while the zone works
+// through it.  From the count on, the pair goes the way of the merge kernels: screen, candidate, list math.
+struct ProbeWork {
+	ListWork lw;                                   // lists, band, screen, candidate list (n_list: the zone; row0 / n_rows: the zone rows of this launch)
+	const uint32_t* rows; uint32_t W;              // the sorted plane set's rows (phased: one per variant; unphased: H and Q)
+	uint32_t col0, n_cols;                         // the columns of this launch: set positions [col0, col0 + n_cols), col0 >= the zone
+	uint32_t n_row_blocks;                         // ceil(n_rows / 256)
+};
+
+__device__ __forceinline__ void append_candidate3(const ListWork& w, bool keep, uint32_t i, uint32_t j, uint32_t aa) {
+	const unsigned long long ballot = __ballot(keep);
+	if (!ballot) return;
+	const int lane = threadIdx.x & 63;
+	const int leader = __ffsll((long long)ballot) - 1;
+	unsigned long long base = 0;
+	if (lane == leader) base = atomicAdd(w.n_cand, (unsigned long long)__popcll(ballot));
+	base = __shfl(base, leader);
+	if (keep) {
+		const unsigned long long slot = base + __popcll(ballot & ((1ull << lane) - 1));
+		if (slot < w.cap) { uint32_t* e = w.cand + slot * 3; e[0] = i; e[1] = j; e[2] = aa; }
+	}
+}
+
+__global__ __launch_bounds__(256)
+void k_probe_screen(const ProbeWork p) {
+	const ListWork& w = p.lw;
+	const uint32_t cb = blockIdx.x / p.n_row_blocks, rb = blockIdx.x - cb * p.n_row_blocks;
+	const uint32_t i = w.row0 + rb * 256 + threadIdx.x, j = p.col0 + cb;
+	bool keep = false;
+	uint32_t aa = 0;
+	if (i < w.row0 + w.n_rows) {
+		const uint32_t limit = w.col_hi ? w.hi_b0 + w.col_hi[i - w.hi_a0] : 0xFFFFFFFFu;
+		if (j < limit) {
+			const uint32_t* a = w.lists + (size_t)i * w.stride;
+			const uint32_t* row = p.rows + (size_t)j * p.W;
+			const uint32_t na = w.mac[i];
+			uint32_t x = 0;
+			for (uint32_t k = 0; k < na; ++k) { const uint32_t h = a[k]; x += (row[h >> 5] >> (h & 31u)) & 1u; }
+			const uint32_t acA = w.rowpop[i], acB = w.rowpop[j];
+			aa = w.flip[i] ? acB - x : x;                  // the list holds the carriers of A's minor allele: ALT, or (flip) REF - then ALT_A & ALT_B = ALT_B minus those
+			const double da = (double)acA, db = (double)acB;
+			const double dn = w.two_n * (double)aa - da * db;
+			keep = dn != 0.0 && dn * dn >= w.cut * (da * (w.two_n - da)) * (db * (w.two_n - db));
+		}
+	}
+	append_candidate3(w, keep, i, j, aa);
+}
+
+// UnphasedMath: the list holds A's samples that are not homozygous for its major allele as (sample << 1) | g (g = 0: het,
+// g = 1: the rare homozygote - hom-alt, or hom-ref when flip); the column is its H (het) and Q (hom-alt) plane rows.
+__global__ __launch_bounds__(256)
+void k_probe_screen_unphased(const ProbeWork p, uint32_t n_samples) {
+	const ListWork& w = p.lw;
+	const uint32_t cb = blockIdx.x / p.n_row_blocks, rb = blockIdx.x - cb * p.n_row_blocks;
+	const uint32_t i = w.row0 + rb * 256 + threadIdx.x, j = p.col0 + cb;
+	bool keep = false;
+	uint32_t HH = 0, HQ = 0, QH = 0, QQ = 0;
+	if (i < w.row0 + w.n_rows) {
+		const uint32_t limit = w.col_hi ? w.hi_b0 + w.col_hi[i - w.hi_a0] : 0xFFFFFFFFu;
+		if (j < limit) {
+			const uint32_t* a = w.lists + (size_t)i * w.stride;
+			const uint32_t* H = p.rows + (size_t)(2 * j) * p.W;
+			const uint32_t* Q = H + p.W;
+			const uint32_t na = w.mac[i];
+			unsigned long long x = 0;                      // four 16-bit counters: [gA][class of B: 0 het, 1 hom-alt] at bit 16 * (2 gA + class)
+			for (uint32_t k = 0; k < na; ++k) {
+				const uint32_t e = a[k], sm = e >> 1, g = e & 1u;
+				const uint32_t hb = (H[sm >> 5] >> (sm & 31u)) & 1u, qb = (Q[sm >> 5] >> (sm & 31u)) & 1u;
+				x += ((unsigned long long)hb << (32u * g)) + ((unsigned long long)qb << (32u * g + 16u));
+			}
+			const uint32_t x0h = (uint32_t)(x & 0xFFFFu), x0q = (uint32_t)((x >> 16) & 0xFFFFu), x1h = (uint32_t)((x >> 32) & 0xFFFFu), x1q = (uint32_t)(x >> 48);
+			const uint32_t hA = w.rowpop[2 * i], qA = w.rowpop[2 * i + 1], hB = w.rowpop[2 * j], qB = w.rowpop[2 * j + 1];
+			HH = x0h; HQ = x0q;
+			if (!w.flip[i]) { QH = x1h; QQ = x1q; }                                   // A's hom-alt samples are the listed rare homozygotes
+			else { QH = hB - x0h - x1h; QQ = qB - x0q - x1q; }                          // A's hom-alt samples are everyone *not* listed
+			const double T = w.two_n, eps = 1e-5 * (T * T);
+			const double da = (double)(hA + 2u * qA), db = (double)(hB + 2u * qB), ra = T - da, rbb = T - db;
+			const double n11 = (ra - db) + (double)(QH + HQ + 2u * QQ);
+			const double e_lo = (n11 * T - ra * rbb) - eps, e_hi = ((n11 + (double)HH) * T - ra * rbb) + eps;
+			const double bound = (w.cut * (da * ra)) * (db * rbb);
+			keep = !(e_lo * e_lo < bound && e_hi * e_hi < bound);
+			(void)n_samples;
+		}
+	}
+	const unsigned long long ballot = __ballot(keep);
+	if (ballot) {
+		const int lane = threadIdx.x & 63;
+		const int leader = __ffsll((long long)ballot) - 1;
+		unsigned long long base = 0;
+		if (lane == leader) base = atomicAdd(w.n_cand, (unsigned long long)__popcll(ballot));
+		base = __shfl(base, leader);
+		if (keep) {
+			const unsigned long long slot = base + __popcll(ballot & ((1ull << lane) - 1));
+			if (slot < w.cap) { uint32_t* e = w.cand + slot * 6; e[0] = i; e[1] = j; e[2] = HH; e[3] = HQ; e[4] = QH; e[5] = QQ; }
+		}
+	}
+}
+
 }  // namespace twk

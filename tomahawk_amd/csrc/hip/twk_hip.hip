@@ -78,6 +78,7 @@ struct Slot {                      // one in-flight tile (double buffered)
 	hipEvent_t ev_c0 = nullptr, ev_c1 = nullptr, ev_s1 = nullptr, ev_c0b = nullptr, ev_c1b = nullptr;
 	bool two_pass = false;
 	bool is_list = false;                         // the launch was a carrier-list pass (ld_list.hip.h): C holds its candidate list
+	bool is_probe = false;                        // ... of the probe kind (zone rows x columns outside the zone)
 	bool fused = false;                           // first launch ran the fused count -> screen kernel: C holds the candidate list
 	unsigned long long cand_cap = 0;              // ... of this many entries; n_out[2] counts them
 	bool cand_overflow = false;                   // set by finish_tile: the list did not hold them all
@@ -90,7 +91,8 @@ struct Slot {                      // one in-flight tile (double buffered)
 // Window mode: row variant a0 + r of a region reaches the columns [b0 + lo[r], b0 + hi[r]).
 struct ColRange { const uint32_t* lo = nullptr; const uint32_t* hi = nullptr; uint32_t a0 = 0, b0 = 0;
                   const uint32_t* d_hi = nullptr; uint32_t n_hi = 0;      // d_hi: device copy of hi, n_hi entries (r2 screen: the math kernel skips what was not contracted)
-                  uint32_t list_zone = 0; };           // pairs with both set positions below it are intersected as carrier lists (ld_list.hip.h), not contracted
+                  uint32_t list_zone = 0;              // pairs with both set positions below it are intersected as carrier lists (ld_list.hip.h), not contracted
+                  bool probe = false; };               // ... and so is every other pair of a row below it: its carriers probe the column's row (k_probe_screen)
 
 }  // namespace
 
@@ -110,6 +112,7 @@ struct Options {
 	long long fisher_lds = 1;        // log-factorial table in LDS while it fits
 	long long cand_chunk = -1;       // candidate slots a wave reserves at a time (-1: sized from the list)
 	long long record_cap = 0;        // cap on the survivor buffer of a launch (0: none): forces the overflow / strip path
+	long long probe = 1;             // zone rows x columns outside the zone: carrier-list probes into the column's row instead of the dense contraction (0: dense)
 	long long band_launch = 1;       // fused runs: launches sized by work (a band of rows, all its columns), not by a count matrix
 	long long band_list_entries = 0; // candidate slots of such a launch (0: a sixteenth of its pairs, 4 M .. 1 G; else exactly this many): small values force its fallback
 	long long band_work_log2 = 19;   // ... and at least 2^n tile-chunks of work per launch (19: ~5 ms); small values make several launches of a small run
@@ -123,7 +126,7 @@ const OptionKey OPTION_KEYS[] = {
 	{"skip_pad", &Options::skip_pad, 0, 1, false}, {"fisher_order", &Options::fisher_order, 0, 1, false},
 	{"fisher_lds", &Options::fisher_lds, 0, 1, false}, {"cand_chunk", &Options::cand_chunk, -1, 1 << 20, false},
 	{"record_cap", &Options::record_cap, 0, 1ll << 40, false},
-	{"band_launch", &Options::band_launch, 0, 1, false}, {"band_list_entries", &Options::band_list_entries, 0, 1ll << 32, false},
+	{"probe", &Options::probe, 0, 1, false}, {"band_launch", &Options::band_launch, 0, 1, false}, {"band_list_entries", &Options::band_list_entries, 0, 1ll << 32, false},
 	{"band_work_log2", &Options::band_work_log2, 0, 40, false},
 };
 }  // namespace
@@ -413,7 +416,8 @@ void build_tile_list(const twk_hip_tile_desc& t, int P, const Geometry& g, bool 
 		}
 		if (cr && cr->list_zone) {      // a row of tiles that lies wholly inside the list zone starts at the zone's last column tile
 			const uint64_t v1 = std::min<uint64_t>((uint64_t)t.rowA0 + t.nA, (uint64_t)t.rowA0 + ((uint64_t)(by + 1) * TILE + P - 1) / P);
-			if (v1 <= cr->list_zone && cr->list_zone > t.rowB0) {
+			if (v1 <= cr->list_zone && cr->probe) x1[by] = x0[by];        // every pair of these rows is a list merge or a probe
+			else if (v1 <= cr->list_zone && cr->list_zone > t.rowB0) {
 				x0[by] = std::max<uint32_t>(x0[by], (uint32_t)((((uint64_t)cr->list_zone - t.rowB0) * P) / TILE));
 				if (x1[by] < x0[by]) x1[by] = x0[by];
 			}
@@ -564,7 +568,7 @@ StatsParams make_stats(twk_hip_ctx* c, int set, const twk_hip_tile_desc& t, cons
 	p.vm = VariantMeta{c->d_ac, c->d_an, c->d_pos, c->d_rid, c->d_missing, c->d_hwe};
 	p.raw = c->raw; p.rawmask = c->rawmask; p.Wp = c->Wp;
 	p.col_hi = cr ? cr->d_hi : nullptr; p.hi_a0 = cr ? cr->a0 : 0; p.hi_b0 = cr ? cr->b0 : 0;
-	p.list_zone = cr ? cr->list_zone : 0;
+	p.list_zone = cr ? cr->list_zone : 0; p.list_zone_cols = cr ? (cr->probe ? 0xFFFFFFFFu : cr->list_zone) : 0;
 	p.nA = t.nA; p.nB = t.nB; p.n_variants = c->M;
 	p.diag = (t.diag && t.rowA0 == t.rowB0) ? 1 : 0;
 	p.phased_math = phased_math ? 1 : 0; p.auto_select = auto_select;
@@ -666,14 +670,14 @@ int enqueue_tile(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, const twk
 	FusedArgs fa{};
 	fa.unphased = fused_u ? 1 : 0;
 	ScreenWork& sw = fa.screen;
-	s.fused = false; s.is_list = false; s.cand_overflow = false; s.cand_cap = (list_words ? list_words : s.C_words) / (fused_u ? 6 : 3);
+	s.fused = false; s.is_list = false; s.is_probe = false; s.cand_overflow = false; s.cand_cap = (list_words ? list_words : s.C_words) / (fused_u ? 6 : 3);
 	if (want_fused) {
 		const PlaneSet& ps = c->planes[kind1];
 		fa.stats = make_stats(c, kind1, t, s, phased, pl.select1, f, cr);
 		sw.rowpop = ps.rowpop; sw.a0 = t.rowA0; sw.b0 = t.rowB0; sw.nA = t.nA; sw.nB = t.nB;
 		sw.n_variants = c->M; sw.diag = (t.diag && t.rowA0 == t.rowB0) ? 1 : 0;
 		sw.col_hi = cr ? cr->d_hi : nullptr; sw.hi_a0 = cr ? cr->a0 : 0; sw.hi_b0 = cr ? cr->b0 : 0; sw.hi_n = cr ? cr->n_hi : 0;
-		sw.list_zone = cr ? cr->list_zone : 0;
+		sw.list_zone = cr ? cr->list_zone : 0; sw.list_zone_cols = cr ? (cr->probe ? 0xFFFFFFFFu : cr->list_zone) : 0;
 		sw.two_n = 2.0 * (double)c->N; sw.cut = f.minR2 * (1.0 - 1e-6);
 		sw.cand = s.C; sw.cap = s.cand_cap; sw.n_cand = s.n_out + 2;
 		{	// slots a wave reserves at a time: what it cannot use is lost to the list, so at most an eighth of the list's
@@ -792,7 +796,8 @@ int finish_tile(twk_hip_ctx* c, Slot& s, const twk_hip_tile_desc& t, unsigned lo
 	HIPCHK(c, hipEventSynchronize(s.ev_s1));
 	float ms = 0;
 	HIPCHK(c, hipEventElapsedTime(&ms, s.ev_c0, s.ev_c1));
-	if (s.is_list) { c->timing.list_ms += ms; c->timing.list_launches += 1; c->timing.list_pairs += s.row_pairs; c->timing.candidates += s.h_n_out[2]; }
+	if (s.is_list && s.is_probe) { c->timing.probe_ms += ms; c->timing.probe_launches += 1; c->timing.probe_pairs += s.row_pairs; c->timing.candidates += s.h_n_out[2]; }
+	else if (s.is_list) { c->timing.list_ms += ms; c->timing.list_launches += 1; c->timing.list_pairs += s.row_pairs; c->timing.candidates += s.h_n_out[2]; }
 	else { c->timing.count_ms += ms; c->timing.count_launches += 1; c->timing.row_pairs += s.row_pairs;
 	       c->timing.count_shader_cycles += s.h_n_out[4]; c->timing.count_wall_ticks += s.h_n_out[5]; }
 	if (s.fused) { c->timing.fused_launches += 1; c->timing.candidates += s.h_n_out[2]; }
@@ -870,7 +875,7 @@ int run_list_block(twk_hip_ctx* c, const twk_hip_filters& f, bool unphased, uint
 	const unsigned cand_words = unphased ? 6 : 3;              // (A, B, ALTALT) or (A, B, HH, HQ, QH, QQ)
 	int rc = ensure_slot(c, s, (size_t)std::max<uint64_t>(cand_words * pairs_max, 1024), capacity); if (rc) return rc;
 	if (!c->d_list_stats) HIPCHK(c, hipMalloc((void**)&c->d_list_stats, sizeof(StatsParams)));
-	s.two_pass = false; s.fused = false; s.is_list = true; s.cand_overflow = false; s.cand_cap = s.C_words / cand_words; s.minP = f.minP;
+	s.two_pass = false; s.fused = false; s.is_list = true; s.is_probe = false; s.cand_overflow = false; s.cand_cap = s.C_words / cand_words; s.minP = f.minP;
 	twk_hip_tile_desc t{};
 	t.rowA0 = row0; t.nA = n_rows; t.rowB0 = row0; t.nB = zone - row0; t.diag = 1; t.window = window; t.l_window = l_window;
 	const StatsParams sp = make_stats(c, set, t, s, !unphased, 0, f, &cr);
@@ -908,6 +913,60 @@ int run_list_block(twk_hip_ctx* c, const twk_hip_filters& f, bool unphased, uint
 		HIPCHK(c, hipGetLastError());
 	}
 	{ const int rc = launch_fisher(c, s.out, s.n_out, s.cap_use, f.minP, s.C, s.C_words, s.keys); if (rc) return rc; }
+	HIPCHK(c, hipMemcpyAsync(s.h_n_out, s.n_out, N_SLOT_COUNTERS * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->s_compute));
+	HIPCHK(c, hipEventRecord(s.ev_s1, c->s_compute));
+	return finish_tile(c, s, t, n_out, to_host, sink, user);
+}
+
+// Zone rows [row0, row0 + n_rows) against the columns [col0, col0 + n_cols) outside the zone (col0 >= zone): every pair inside the
+// r2 band as a probe of the row variant's carrier list into the column variant's plane row(s) (k_probe_screen, ld_list.hip.h) ->
+// candidates -> the list math kernel -> Fisher -> sorted survivors, like a list block.
+int run_probe_block(twk_hip_ctx* c, const twk_hip_filters& f, bool unphased, uint32_t row0, uint32_t n_rows, uint32_t zone, uint32_t col0, uint32_t n_cols,
+                    int32_t window, uint32_t l_window, const ColRange& cr, unsigned long long capacity, unsigned long long* n_out, bool to_host,
+                    twk_hip_record_sink sink, void* user) {
+	const int set = unphased ? PS_SORTED_U : PS_SORTED_P;
+	const PlaneSet& ps = c->planes[set];
+	Slot& s = c->slot[2];
+	const uint64_t pairs_max = (uint64_t)n_rows * n_cols;
+	const unsigned cand_words = unphased ? 6 : 3;
+	int rc = ensure_slot(c, s, (size_t)std::max<uint64_t>(cand_words * pairs_max, 1024), capacity); if (rc) return rc;
+	if (!c->d_list_stats) HIPCHK(c, hipMalloc((void**)&c->d_list_stats, sizeof(StatsParams)));
+	s.two_pass = false; s.fused = false; s.is_list = true; s.is_probe = true; s.cand_overflow = false; s.cand_cap = s.C_words / cand_words; s.minP = f.minP;
+	twk_hip_tile_desc t{};
+	t.rowA0 = row0; t.nA = n_rows; t.rowB0 = col0; t.nB = n_cols; t.diag = 0; t.window = window; t.l_window = l_window;
+	const StatsParams sp = make_stats(c, set, t, s, !unphased, 0, f, &cr);
+	HIPCHK(c, hipMemsetAsync(s.n_out, 0, N_SLOT_COUNTERS * sizeof(unsigned long long), c->s_compute));
+	HIPCHK(c, hipMemcpyAsync(c->d_list_stats, &sp, sizeof(sp), hipMemcpyHostToDevice, c->s_compute));
+	ProbeWork p{};
+	ListWork& w = p.lw;
+	w.lists = ps.lists; w.stride = ps.list_max + 1; w.mac = ps.list_mac; w.flip = ps.list_flip; w.rowpop = ps.rowpop;
+	w.n_list = zone; w.row0 = row0; w.n_rows = n_rows;
+	w.col_hi = cr.d_hi; w.hi_a0 = cr.a0; w.hi_b0 = cr.b0;
+	w.two_n = 2.0 * (double)c->N; w.cut = f.minR2 * (1.0 - 1e-6);
+	w.cand = s.C; w.cap = s.cand_cap; w.n_cand = s.n_out + 2;
+	p.rows = ps.rows; p.W = ps.W; p.col0 = col0; p.n_cols = n_cols; p.n_row_blocks = (n_rows + 255) / 256;
+	s.row_pairs = 0;
+	for (uint32_t i = row0; i < row0 + n_rows; ++i) {
+		const uint32_t lim = std::min<uint64_t>((uint64_t)col0 + n_cols, cr.hi ? (uint64_t)cr.b0 + cr.hi[i - cr.a0] : (uint64_t)col0 + n_cols);
+		if (lim > col0) s.row_pairs += lim - col0;                // pairs probed (accounting only)
+	}
+	const uint64_t n_blocks = (uint64_t)p.n_row_blocks * n_cols;
+	if (n_blocks > 0x7FFFFFFFull) return TWK_HIP_E_INVALID;
+	HIPCHK(c, hipEventRecord(s.ev_c0, c->s_compute));
+	if (s.row_pairs) {
+		if (unphased) hipLaunchKernelGGL(k_probe_screen_unphased, dim3((uint32_t)n_blocks), dim3(256), 0, c->s_compute, p, c->N);
+		else hipLaunchKernelGGL(k_probe_screen, dim3((uint32_t)n_blocks), dim3(256), 0, c->s_compute, p);
+		HIPCHK(c, hipGetLastError());
+	}
+	HIPCHK(c, hipEventRecord(s.ev_c1, c->s_compute));
+	if (s.row_pairs) {
+		if (unphased) hipLaunchKernelGGL(k_ld_stats_list_unphased, dim3(c->resident_blocks * 4), dim3(256), 0, c->s_compute, (const StatsParams*)c->d_list_stats,
+		                                 (const uint32_t*)s.C, (const unsigned long long*)(s.n_out + 2), s.cand_cap);
+		else hipLaunchKernelGGL(k_ld_stats_list, dim3(c->resident_blocks * 4), dim3(256), 0, c->s_compute, (const StatsParams*)c->d_list_stats, (const uint32_t*)s.C,
+		                        (const unsigned long long*)(s.n_out + 2), s.cand_cap);
+		HIPCHK(c, hipGetLastError());
+	}
+	{ const int rc2 = launch_fisher(c, s.out, s.n_out, s.cap_use, f.minP, s.C, s.C_words, s.keys); if (rc2) return rc2; }
 	HIPCHK(c, hipMemcpyAsync(s.h_n_out, s.n_out, N_SLOT_COUNTERS * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->s_compute));
 	HIPCHK(c, hipEventRecord(s.ev_s1, c->s_compute));
 	return finish_tile(c, s, t, n_out, to_host, sink, user);
@@ -1700,6 +1759,29 @@ static int region_impl(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint3
 				if (rc) return rc;
 				tot_recs += nrec;
 				row += nr;
+			}
+			// ... and the zone's rows against the columns beyond the zone: probes of the row variant's carriers into the column
+			// variant's row (K1's asymmetric path, ld_engine.cpp:230-242; measured to win for every list the zone keeps,
+			// ld_list.hip.h), so that no tile row inside the zone is contracted at all.
+			if (c->opt.probe && zone < nB) {
+				col_range.probe = true;
+				unsigned long long cap_probe = cap_default;
+				uint32_t rows_cap = 32768;                                   // halved when a block's survivors outgrow the buffer
+				for (uint32_t row = lr0; row < lr1;) {
+					// the columns the block's rows reach (the band limit never decreases along the rows)
+					auto reach = [&](uint32_t last_row) -> uint32_t { return std::min<uint64_t>(nB, col_range.hi ? (uint64_t)col_range.b0 + col_range.hi[last_row - col_range.a0] : nB); };
+					uint32_t nr = std::min<uint32_t>(lr1 - row, rows_cap);
+					while (nr > 256 && (uint64_t)nr * (reach(row + nr - 1) > zone ? reach(row + nr - 1) - zone : 0) > (1ull << 25)) nr = std::max<uint32_t>(256, nr / 2);
+					const uint32_t lim = reach(row + nr - 1);
+					if (lim <= zone) { row += nr; continue; }
+					unsigned long long nrec = 0;
+					rc = run_probe_block(c, *f, screen == 2, row, nr, zone, zone, lim - zone, window, l_window, col_range, cap_probe, &nrec, !c->device_sink, sink ? sink : discard_records, user);
+					if (rc == TWK_HIP_E_OVERFLOW && nr > 1) { rows_cap = std::max<uint32_t>(1, nr / 2); continue; }
+					if (rc == TWK_HIP_E_OVERFLOW && cap_probe < (unsigned long long)(lim - zone)) { cap_probe = lim - zone; continue; }
+					if (rc) return rc;
+					tot_recs += nrec;
+					row += nr;
+				}
 			}
 		}
 	}

@@ -663,6 +663,7 @@ bool twk_ld::twk_ld_impl::run(twk_ld_settings& settings, const Header& hdr, cons
 			          << "), math kernels " << tm.stats_ms << " ms"
 			          << (tm.fused_launches ? "; " + std::to_string(tm.fused_launches) + " launches fused count -> r2 screen, " + pretty(tm.candidates) + " candidate slots" : std::string())
 			          << (tm.list_launches ? "; carrier-list kernel " + std::to_string(tm.list_ms) + " ms in " + std::to_string(tm.list_launches) + " launches over " + pretty(tm.list_pairs) + " rare pairs" : std::string())
+			          << (tm.probe_launches ? "; probe kernel " + std::to_string(tm.probe_ms) + " ms in " + std::to_string(tm.probe_launches) + " launches over " + pretty(tm.probe_pairs) + " rare x common pairs" : std::string())
 			          << std::endl;
 	}
 	{

@@ -51,6 +51,7 @@ class _Timing(C.Structure):
                 ("stats_launches", C.c_uint64), ("row_pairs", C.c_uint64), ("variant_pairs", C.c_uint64),
                 ("words_per_row", C.c_uint64), ("fused_launches", C.c_uint64), ("candidates", C.c_uint64),
                 ("list_ms", C.c_double), ("list_launches", C.c_uint64), ("list_pairs", C.c_uint64),
+                ("probe_ms", C.c_double), ("probe_launches", C.c_uint64), ("probe_pairs", C.c_uint64),
                 ("count_shader_cycles", C.c_uint64), ("count_wall_ticks", C.c_uint64)]
 
 
