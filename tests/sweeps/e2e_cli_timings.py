@@ -23,6 +23,7 @@ def run(tag, twk, args, env=None):
     rate = re.search(r"\] ([0-9,]+) variants/s", log)
     eng = re.findall(r"count kernel ([0-9.e+]+) ms in (\d+) launches \(([0-9.e+-]+) % [^)]*\), math kernels ([0-9.e+]+) ms", log)
     eng += re.findall(r"(carrier-list kernel [0-9.e+]+ ms in \d+ launches over [0-9,]+ rare pairs)", log)
+    eng += re.findall(r"(probe kernel [0-9.e+]+ ms in \d+ launches over [0-9,]+ rare x common pairs)", log)
     eng += re.findall(r"(\d+ launches fused count -> r2 screen, [0-9,]+ candidate pairs)", log)
     print(f"{tag}: wall {wall:.2f} s | load {load.group(1) if load else '?'} | compute+write {fin.group(1) if fin else '?'} | pairs {fin.group(2) if fin else '?'} | "
           f"records {fin.group(3) if fin else '?'} | {rate.group(1) if rate else '?'} pairs/s in the compute phase | engine {eng}", flush=True)
@@ -63,3 +64,9 @@ if not os.path.exists(twk2):
     print(f"wrote {twk2}: {os.path.getsize(twk2)/1e6:.0f} MB in {time.time()-t:.1f} s", flush=True)
 run("2504 x 200k cohort calc -p -w 1000000", twk2, ["-p", "-w", "1000000", "-t", str(threads)])
 run("2504 x 200k cohort calc -w 1000000 (default)", twk2, ["-w", "1000000", "-t", str(threads)])
+
+# K1's rare x common path (probes) and the sorted set below the screen's own threshold: calc -r 0.0009 (every pair is in the band)
+for extra, tag in (([], "default: merges + probes"), (["--engine-option", "probe=0"], "probe=0: merges only"), (["--engine-option", "lists=0"], "lists=0: dense")):
+    run(f"1M x {M1} cohort calc -r 0.0009 ({tag})", twk, ["-r", "0.0009", "-t", str(threads)] + extra)
+    run(f"1M x {M1} cohort calc (default r2 0.1) ({tag})", twk, ["-t", str(threads)] + extra)
+    run(f"1M x {M1} cohort calc -u ({tag})", twk, ["-u", "-t", str(threads)] + extra)

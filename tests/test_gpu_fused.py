@@ -394,7 +394,7 @@ def test_band_launches_equal_matrix_sized_tiles(hip, opt, mode):
                 key = got["idxA"].astype(np.uint64) << np.uint64(32) | got["idxB"].astype(np.uint64)
                 assert (np.diff(key.astype(np.int64)) > 0).all(), (name, log2)
         opt.set("band_work_log2", 19)
-        for key, value in (("band_list_entries", 1000), ("record_cap", 700)):
+        for key, value in (("band_list_entries", 64), ("record_cap", 50)):
             opt.set(key, value)
             hip.timing_reset()
             got, np1, nr1 = call()

@@ -160,7 +160,10 @@ def test_probe_pass_equals_dense_and_merges_only(hip, opt, mode, N, forced):
     calls = [lambda: hip.ld_all(mode, T.Filters(minR2=0.1), window=T.OPT_R2_SCREEN)[0],
              lambda: hip.ld_all(mode, T.Filters(minR2=0.004), window=T.OPT_R2_SCREEN)[0],
              lambda: np.concatenate([hip.ld_all(mode, T.Filters(minR2=0.02), part=k, n_parts=3, window=T.OPT_R2_SCREEN)[0] for k in range(3)]),
-             lambda: hip.ld_all(mode, T.Filters(minR2=0.05, minP=1e-6), window=T.OPT_R2_SCREEN)[0]]
+             lambda: hip.ld_all(mode, T.Filters(minR2=0.05, minP=1e-6), window=T.OPT_R2_SCREEN)[0],
+             # below the cut-off the r2 screen needs to be "worth the name" (1e-3): without lists no sorted set at all, with
+             # them the zone's pairs are still merged and probed (calc -r 0.0009 at N = 1 M: DESIGN 3.5)
+             lambda: hip.ld_all(mode, T.Filters(minR2=0.0007), window=T.OPT_R2_SCREEN)[0]]
 
     def run(lists, probe, cap=0):
         opt.set("lists", lists); opt.set("probe", probe); opt.set("record_cap", cap)

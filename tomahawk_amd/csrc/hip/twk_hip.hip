@@ -1871,7 +1871,10 @@ int twk_hip_ld_region(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint32
 	const bool whole = triangle && a0 == 0 && nA == c->M && nB == c->M;
 	// TWK_HIP_OPT_R2_SCREEN: whole-triangle runs with an r2 cut-off worth the name, outside window mode (which
 	// already prunes by position, in an order the allele-count sort would destroy)
-	const bool screen = (window & TWK_HIP_OPT_R2_SCREEN) && whole && !(window & TWK_HIP_OPT_WINDOW) && f->minR2 >= 1e-3 && c->M >= 2;
+	// ... or, at any cut-off above zero, rows long enough to keep carrier lists: the band is then (nearly) everything, but the
+	// allele-count order still puts the rare variants in a zone whose pairs are list merges and probes instead of contractions
+	const bool lists_pay = f->minR2 > 0 && c->opt.lists != 0 && (c->Wp / 128 >= 32 || c->opt.lists == 2);
+	const bool screen = (window & TWK_HIP_OPT_R2_SCREEN) && whole && !(window & TWK_HIP_OPT_WINDOW) && (f->minR2 >= 1e-3 || lists_pay) && c->M >= 2;
 	if (screen && !c->any_missing && (mode == TWK_HIP_MODE_PHASED || mode == TWK_HIP_MODE_AUTO || mode == TWK_HIP_MODE_UNPHASED))
 		return region_impl(c, mode == TWK_HIP_MODE_UNPHASED ? MODE_INT_SORTED_U : MODE_INT_SORTED_P, f, 0, c->M, 0, c->M, 1, part, n_parts,
 		                   tile_variants, window, l_window, sink, user, n_pairs, n_records);
