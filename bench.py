@@ -35,9 +35,17 @@ The JSON line also carries
                .twk of the headline size written to /tmp: load (pread + zstd + device run-length inflate), r2 screen,
                count / math kernels, device sort, .two writer - the parts of the path the survivor-free headline step
                does not exercise, under the driver's clock.
+  extra        (N=1, cfg3 only, after the timed region) the other regimes the repository makes claims about, under the same
+               clock: "cfg2" (BASELINE configs[1], 20 steps), "cfg5_shard" (configs[4], shard 3 of 8 emulated on this GPU, one
+               step), "e2e_u" (`tomahawk calc -u` from the same cohort .twk as "e2e") and "kg" - the reference's only
+               published workloads (docs/tutorial.md:177-199, 252-253): `calc -p` r2 >= 0.1 over all 141.2 G pairs of a
+               cohort-shaped 2,504 x 531,500 .twk, and `calc -p -w 4000000` on the same file.  Each with pairs/s, the dominant
+               kernel, its average launch, its own roofline fraction, records, load / compute + write split, and the shader
+               clock the count kernel's blocks really ran at (roofline.shader_mhz likewise).  --no-extra skips them.
 For N > 1 the line also carries per_rank_ms (each rank's compute time per step), gather_ms / write_ms (rank 0: the
 gather of the survivors incl. waiting for the slowest rank; packing the .two) and ranks_seen (an all-gather of the rank
-ids over the group that carried the gather).
+ids over the group that carried the gather), gather_bytes / gather_GBps (record bytes rank 0 received per step, and their
+rate over the transfers alone - from the moment every rank had arrived).
 """
 import argparse
 import ctypes

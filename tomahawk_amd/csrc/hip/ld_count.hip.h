@@ -711,8 +711,8 @@ struct ScreenWork {
 	uint32_t n_variants; int diag;
 	const uint32_t* col_hi; uint32_t hi_a0, hi_b0;       // r2 band (twk_hip.hip region_impl): row at set position a reaches columns < hi_b0 + col_hi[a - hi_a0]
 	uint32_t hi_n;                     // entries of col_hi (the region's rows)
-	uint32_t list_zone;                // pairs with the row below it and the column below list_zone_cols belong to the carrier-list passes (ld_list.hip.h)
-	uint32_t list_zone_cols;           // = list_zone (merges inside the zone), or 0xFFFFFFFF when the zone's rows probe every other column too
+	uint32_t list_zone;                // pairs with both set positions below it belong to the carrier-list merge pass (ld_list.hip.h)
+	uint32_t probe_zone;               // <= list_zone: every other pair of a row below it belongs to the probe pass
 	double two_n, cut;                 // 2N; minR2 * (1 - 1e-6)
 	uint32_t* cand; unsigned long long cap;            // [cap][3]: set position A, set position B, AA  (unphased form: [cap][6]: ..., HH, HQ, QH, QQ)
 	unsigned long long* n_cand;        // device counter of the slots handed out (may run past cap: the host then redoes the tile the plain way)
@@ -802,7 +802,7 @@ struct ScreenCounts {
 			hiA[t] = ok ? h : 0u;
 		}
 		const bool diag = s.diag != 0;
-		const uint32_t zone = s.list_zone, zone_cols = s.list_zone_cols;
+		const uint32_t zone = s.list_zone, pzone = s.probe_zone;
 		uint32_t m = 0;                  // bit 4t + u: pair (t, u) is a candidate
 #pragma unroll
 		for (int t = 0; t < 8; ++t) {
@@ -814,7 +814,7 @@ struct ScreenCounts {
 				const uint32_t sB = b0 + c0 + 8 * u;
 				const double b = (double)acB[u];
 				const double dn = two_n * (double)acc[t][u] - a * b;
-				const bool ok = (!diag || sB > sA) && sB < hiA[t] && !(sA < zone && sB < zone_cols) && dn != 0.0 && dn * dn >= fA * (b * (two_n - b));
+				const bool ok = (!diag || sB > sA) && sB < hiA[t] && !((sA < zone && sB < zone) || sA < pzone) && dn != 0.0 && dn * dn >= fA * (b * (two_n - b));
 				m |= (ok ? 1u : 0u) << (4 * t + u);
 			}
 		}
@@ -927,7 +927,7 @@ struct ScreenCountsUnphased {
 			const double e_lo = (n11 * T2n - ra * rb) - eps;
 			const double e_hi = ((n11 + (double)hh) * T2n - ra * rb) + eps;
 			const double bound = (cut * (da * ra)) * fB;
-			const bool ok = okA && okB && (!diag || vB > vA) && vB < hi && !(vA < s.list_zone && vB < s.list_zone_cols) && !(e_lo * e_lo < bound && e_hi * e_hi < bound);
+			const bool ok = okA && okB && (!diag || vB > vA) && vB < hi && !((vA < s.list_zone && vB < s.list_zone) || vA < s.probe_zone) && !(e_lo * e_lo < bound && e_hi * e_hi < bound);
 			m |= (ok ? 1u : 0u) << t;
 		}
 		if (__ballot(m != 0)) {

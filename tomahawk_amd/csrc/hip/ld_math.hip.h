@@ -609,8 +609,8 @@ struct StatsParams {
 	const uint32_t* raw; const uint32_t* rawmask; uint32_t Wp;   // raw rows (file order), for TWK_HIP_OPT_REF_COMPAT
 	const uint32_t* col_hi; uint32_t hi_a0, hi_b0;               // r2 screen: the row at set position a reaches the columns
 	                                                             // below hi_b0 + col_hi[a - hi_a0] only (others were not contracted)
-	uint32_t list_zone;       // pairs with the row's set position below it and the column's below list_zone_cols belong to the carrier-list
-	uint32_t list_zone_cols;  // passes (ld_list.hip.h): = list_zone (merges inside the zone only) or 0xFFFFFFFF (and probes for every other column)
+	uint32_t list_zone;       // pairs with both set positions below it belong to the carrier-list merge pass (ld_list.hip.h),
+	uint32_t probe_zone;      // and every other pair of a row below this (<= list_zone) to the probe pass
 	uint32_t nA, nB;          // variants in the tile
 	uint32_t n_variants;      // total (pairs beyond it do not exist)
 	int diag;                 // keep only col > row (global indices)
@@ -638,7 +638,7 @@ __device__ __forceinline__ bool d_pair(const StatsParams& p, uint32_t sA, uint32
 	bool todo = sA < p.n_variants && sB < p.n_variants && (!p.diag || sB > sA);
 	if (BY_VALUE && (sA - p.tv.a0 >= p.nA || sB - p.tv.b0 >= p.nB)) todo = false;       // (a candidate is a pair of the tile's own variants: checked again here)
 	if (todo && p.col_hi && sB >= p.hi_b0 + p.col_hi[sA - p.hi_a0]) todo = false;
-	if (!BY_VALUE && sA < p.list_zone && sB < p.list_zone_cols) todo = false;       // (the list pass hands its own pairs over by value)
+	if (!BY_VALUE && ((sA < p.list_zone && sB < p.list_zone) || sA < p.probe_zone)) todo = false;       // (the list pass hands its own pairs over by value)
 	// A regrouped plane set (ids != null) can meet a pair in either order; the record always
 	// has the variant that comes first in the file as A, like the reference's i < j loops.
 	uint32_t A = sA, B = sB;

@@ -45,6 +45,7 @@ struct PlaneSet {
 	// list_max carriers of their minor allele - positions [0, n_list), n_list a multiple of the tile edge
 	uint32_t* lists = nullptr; uint32_t* list_mac = nullptr; uint32_t* list_flip = nullptr;
 	uint32_t  n_list = 0, list_max = 0;
+	uint32_t  n_probe = 0;         // <= n_list: the leading variants whose lists are short enough for probing to beat the dense pair (ld_list.hip.h)
 };
 
 // Plane sets a context can hold: one per PlaneKind in file order, plus the masked unphased planes
@@ -92,7 +93,7 @@ struct Slot {                      // one in-flight tile (double buffered)
 struct ColRange { const uint32_t* lo = nullptr; const uint32_t* hi = nullptr; uint32_t a0 = 0, b0 = 0;
                   const uint32_t* d_hi = nullptr; uint32_t n_hi = 0;      // d_hi: device copy of hi, n_hi entries (r2 screen: the math kernel skips what was not contracted)
                   uint32_t list_zone = 0;              // pairs with both set positions below it are intersected as carrier lists (ld_list.hip.h), not contracted
-                  bool probe = false; };               // ... and so is every other pair of a row below it: its carriers probe the column's row (k_probe_screen)
+                  uint32_t probe_zone = 0; };          // <= list_zone: every other pair of a row below it is decided by probing the column's row with the row's carriers (k_probe_screen)
 
 }  // namespace
 
@@ -416,7 +417,7 @@ void build_tile_list(const twk_hip_tile_desc& t, int P, const Geometry& g, bool 
 		}
 		if (cr && cr->list_zone) {      // a row of tiles that lies wholly inside the list zone starts at the zone's last column tile
 			const uint64_t v1 = std::min<uint64_t>((uint64_t)t.rowA0 + t.nA, (uint64_t)t.rowA0 + ((uint64_t)(by + 1) * TILE + P - 1) / P);
-			if (v1 <= cr->list_zone && cr->probe) x1[by] = x0[by];        // every pair of these rows is a list merge or a probe
+			if (v1 <= cr->probe_zone) x1[by] = x0[by];                    // every pair of these rows is a list merge or a probe
 			else if (v1 <= cr->list_zone && cr->list_zone > t.rowB0) {
 				x0[by] = std::max<uint32_t>(x0[by], (uint32_t)((((uint64_t)cr->list_zone - t.rowB0) * P) / TILE));
 				if (x1[by] < x0[by]) x1[by] = x0[by];
@@ -568,7 +569,7 @@ StatsParams make_stats(twk_hip_ctx* c, int set, const twk_hip_tile_desc& t, cons
 	p.vm = VariantMeta{c->d_ac, c->d_an, c->d_pos, c->d_rid, c->d_missing, c->d_hwe};
 	p.raw = c->raw; p.rawmask = c->rawmask; p.Wp = c->Wp;
 	p.col_hi = cr ? cr->d_hi : nullptr; p.hi_a0 = cr ? cr->a0 : 0; p.hi_b0 = cr ? cr->b0 : 0;
-	p.list_zone = cr ? cr->list_zone : 0; p.list_zone_cols = cr ? (cr->probe ? 0xFFFFFFFFu : cr->list_zone) : 0;
+	p.list_zone = cr ? cr->list_zone : 0; p.probe_zone = cr ? cr->probe_zone : 0;
 	p.nA = t.nA; p.nB = t.nB; p.n_variants = c->M;
 	p.diag = (t.diag && t.rowA0 == t.rowB0) ? 1 : 0;
 	p.phased_math = phased_math ? 1 : 0; p.auto_select = auto_select;
@@ -677,7 +678,7 @@ int enqueue_tile(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, const twk
 		sw.rowpop = ps.rowpop; sw.a0 = t.rowA0; sw.b0 = t.rowB0; sw.nA = t.nA; sw.nB = t.nB;
 		sw.n_variants = c->M; sw.diag = (t.diag && t.rowA0 == t.rowB0) ? 1 : 0;
 		sw.col_hi = cr ? cr->d_hi : nullptr; sw.hi_a0 = cr ? cr->a0 : 0; sw.hi_b0 = cr ? cr->b0 : 0; sw.hi_n = cr ? cr->n_hi : 0;
-		sw.list_zone = cr ? cr->list_zone : 0; sw.list_zone_cols = cr ? (cr->probe ? 0xFFFFFFFFu : cr->list_zone) : 0;
+		sw.list_zone = cr ? cr->list_zone : 0; sw.probe_zone = cr ? cr->probe_zone : 0;
 		sw.two_n = 2.0 * (double)c->N; sw.cut = f.minR2 * (1.0 - 1e-6);
 		sw.cand = s.C; sw.cap = s.cand_cap; sw.n_cand = s.n_out + 2;
 		{	// slots a wave reserves at a time: what it cannot use is lost to the list, so at most an eighth of the list's
@@ -1763,14 +1764,16 @@ static int region_impl(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint3
 			// ... and the zone's rows against the columns beyond the zone: probes of the row variant's carriers into the column
 			// variant's row (K1's asymmetric path, ld_engine.cpp:230-242; measured to win for every list the zone keeps,
 			// ld_list.hip.h), so that no tile row inside the zone is contracted at all.
-			if (c->opt.probe && zone < nB) {
-				col_range.probe = true;
+			const uint32_t pzone = c->opt.probe ? std::min(ps.n_probe, zone) : 0;
+			if (pzone && zone < nB) {
+				col_range.probe_zone = pzone;
 				unsigned long long cap_probe = cap_default;
 				uint32_t rows_cap = 32768;                                   // halved when a block's survivors outgrow the buffer
-				for (uint32_t row = lr0; row < lr1;) {
+				const uint32_t pr0 = std::min(r0, pzone), pr1 = std::min(r1, pzone);
+				for (uint32_t row = pr0; row < pr1;) {
 					// the columns the block's rows reach (the band limit never decreases along the rows)
 					auto reach = [&](uint32_t last_row) -> uint32_t { return std::min<uint64_t>(nB, col_range.hi ? (uint64_t)col_range.b0 + col_range.hi[last_row - col_range.a0] : nB); };
-					uint32_t nr = std::min<uint32_t>(lr1 - row, rows_cap);
+					uint32_t nr = std::min<uint32_t>(pr1 - row, rows_cap);
 					while (nr > 256 && (uint64_t)nr * (reach(row + nr - 1) > zone ? reach(row + nr - 1) - zone : 0) > (1ull << 25)) nr = std::max<uint32_t>(256, nr / 2);
 					const uint32_t lim = reach(row + nr - 1);
 					if (lim <= zone) { row += nr; continue; }
