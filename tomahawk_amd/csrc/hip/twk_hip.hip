@@ -330,6 +330,17 @@ int ensure_planes(twk_hip_ctx* c, int set) {
 			n = n / TILE * TILE;                             // whole tiles: a tile is either intersected or contracted
 			if (n >= 2 * TILE) {
 				ps.n_list = n; ps.list_max = lmax;
+				// Probing (k_probe_screen) wins over the dense pair up to ~W / 114 carriers with PhasedMath (every list kept) and - two
+				// reads per listed sample against a dense pair of twice the cost - up to about as many *entries* with UnphasedMath,
+				// whose lists are twice as long: there only the shorter part of the zone probes (measured).
+				const uint32_t pmax = set == PS_SORTED_U ? std::max<uint32_t>(c->Wp / 160, 8) : lmax;
+				uint32_t np = 0;
+				while (np < n) {
+					const uint64_t ac = std::min<uint64_t>(c->h_popc[ps.h_ids[np]], T2);
+					if (std::min(ac, T2 - ac) > pmax) break;
+					++np;
+				}
+				ps.n_probe = np / TILE * TILE;
 				HIPCHK(c, hipMalloc((void**)&ps.lists, (size_t)n * (lmax + 1) * 4));
 				HIPCHK(c, hipMalloc((void**)&ps.list_mac, (size_t)n * 4));
 				HIPCHK(c, hipMalloc((void**)&ps.list_flip, (size_t)n * 4));
