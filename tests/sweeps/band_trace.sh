@@ -26,3 +26,7 @@ d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows]
 print("   launches %d, ms each: %s" % (len(d), " ".join("%.1f" % x for x in d[:40])))
 PY
 done
+# is the slow million-tile launch about its tiles or about the buffers allocated for it?  The same 2 launches with a small candidate list
+for opts in "band_work_log2=21 --engine-option band_list_entries=4194304" "band_work_log2=21"; do
+	timeout 300 $R/tomahawk_amd/bin/tomahawk calc -i /tmp/kg_2504_200k.twk -o /tmp/o.two -t 64 -p -r 0.8 --engine-option $opts 2>&1 > /dev/null | grep "HIP\]" | cut -c1-260 | sed "s/^/== $opts: /"
+done

@@ -91,6 +91,7 @@ def test_cli_calc_end_to_end(tmp_path, name, flag, tag):
     for i, f in enumerate(("D", "Dprime", "R", "R2", "P", "ChiSqFisher", "ChiSqModel")):
         got[f] = fwd[:, 9 + i]
     w = golden_as_oracle_records(want)
+    util.remember_data(al, variants)
     util.assert_records_match(got, w, variants)
     lit = hostlib.header_literals(out + ".two")
     assert "##tomahawk_calcCommand=tomahawk calc -i" in lit and "##tomahawk_calcVersion=" in lit
@@ -122,6 +123,7 @@ def test_cli_interval_slicing(tmp_path, ival, flag, tag):
     keyA, keyB = m[:, 1] * 2**32 + m[:, 2], m[:, 3] * 2**32 + m[:, 4]
     fwd = m[keyA < keyB]
     variants = O.variants_from_alleles(al, pos=z["pos"], rid=z["rid"], phase=1)
+    util.remember_data(al, variants)
     util.assert_records_match(_fwd_records(fwd, variants), golden_as_oracle_records(z["rec_" + tag]), variants)
     r = subprocess.run([hostlib.CLI_PATH, "calc", "-i", twk, "-o", out, "-I", "7"], capture_output=True, text=True)
     assert r.returncode == 1 and "Contig does not exist" in r.stderr
@@ -143,6 +145,7 @@ def test_cli_scalc_single_site(tmp_path):
     variants = O.variants_from_alleles(al, pos=z["pos"], rid=z["rid"], phase=1)
     g = _fwd_records(m[m[:, 2] == tgt_pos], variants)            # forward copies: the target is A, also for neighbours before it
     w = golden_as_oracle_records(want[want[:, 2] == tgt_pos])
+    util.remember_data(al, variants)
     util.assert_records_match(g, w, variants)
     # more neighbours than a multiple of 100: the reference drops the remainder (ld.cpp:203-205,239-244), we keep it
     r = subprocess.run([hostlib.CLI_PATH, "scalc", "-i", twk, "-o", out, "-I", "1:16001", "-w", "6000"], capture_output=True, text=True)
