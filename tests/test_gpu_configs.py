@@ -437,7 +437,7 @@ def test_cubic_record_with_cancelling_d(hip):
         got, _, _ = hip.ld_all(mode, T.Filters(minR2=0.0))
         vet = util.double_root_vetter(data, mask, variants, N)
         with pytest.raises(AssertionError):          # without the pair's own conditioning nothing excuses it
-            util.assert_records_match(got, want, variants, count=False)
+            util.assert_records_match(got, want, variants.copy(), count=False)      # (a copy: not the data set upload() remembers)
         util.assert_records_match(got, want, variants, double_root=vet)
         g = util.records_by_pair(got, "idxA", "idxB")[(33, 89)]
         assert g["R2"] < 1e-8 and abs(g["D"]) < 1e-6 and 1e-3 < abs(g["Dprime"]) < 1e-2

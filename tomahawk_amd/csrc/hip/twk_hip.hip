@@ -330,10 +330,12 @@ int ensure_planes(twk_hip_ctx* c, int set) {
 			n = n / TILE * TILE;                             // whole tiles: a tile is either intersected or contracted
 			if (n >= 2 * TILE) {
 				ps.n_list = n; ps.list_max = lmax;
-				// Probing (k_probe_screen) wins over the dense pair up to ~W / 114 carriers with PhasedMath (every list kept) and - two
-				// reads per listed sample against a dense pair of twice the cost - up to about as many *entries* with UnphasedMath,
-				// whose lists are twice as long: there only the shorter part of the zone probes (measured).
-				const uint32_t pmax = set == PS_SORTED_U ? std::max<uint32_t>(c->Wp / 160, 8) : lmax;
+				// Probing (k_probe_screen) beats the dense pair up to ~W / 114 carriers in isolation (csrc/tools/probe_vs_dense.hip) and
+				// up to about half that in a whole run, where the rows that reach beyond the zone are the ones with the longest lists and
+				// the columns are thousands of 250 KB rows (1 M x 50,000: 10-11 ps per carrier against 5; with every list probing, the
+				// default-cut-off run was 23 ms slower than without probes): PhasedMath probes lists of up to W / 256 carriers,
+				// UnphasedMath - two reads per listed sample, a dense pair of twice the cost - of up to W / 160 entries.
+				const uint32_t pmax = set == PS_SORTED_U ? std::max<uint32_t>(c->Wp / 160, 8) : std::max<uint32_t>(c->Wp / 256, 8);
 				uint32_t np = 0;
 				while (np < n) {
 					const uint64_t ac = std::min<uint64_t>(c->h_popc[ps.h_ids[np]], T2);
