@@ -577,8 +577,12 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 			if (META) {
 				if (wave_u < META / 64) {
 					const uint32_t yx_m = tile_yx;
-					uint32_t mi = (uint32_t)(wave_u * 64 + lane);
-					asm volatile("" : "+v"(mi));         // (opaque: the address arithmetic on it is redone per unit, not hoisted out of the loop and spilled)
+					// (the lane id is taken afresh from the hardware, by volatile asm: derived from threadIdx.x the compiler computed
+					// wave * 64 + lane once in front of the loop and kept it in scratch - the kernels' one spilled register, and the
+					// only reason they needed scratch memory at all)
+					uint32_t ln;
+					asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+					const uint32_t mi = (uint32_t)wave_u * 64u + ln;
 					glds4(epilogue.meta_src(yx_m, mi), (uint32_t)(uintptr_t)(lptr_t*)meta + (uint32_t)wave_u * 256u);
 				}
 				if (c + 1 == c_end) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // a one-chunk unit needs it in this very iteration: the barrier below publishes it
