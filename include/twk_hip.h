@@ -218,10 +218,13 @@ int twk_hip_ld_tile(twk_hip_ctx* ctx, int mode, const twk_hip_tile_desc* tile,
  * of the pairs (equal-area bands of the triangle, boundaries on multiples of 64
  * variants; every rank derives the same partition without communication).  This
  * replaces twk_ld_balancer::Build (ld_balancing.h:23-80) for multi-GPU sharding.
- * tile_variants = edge of a super-tile in variants (0 = choose).  Survivors
- * are handed to `sink` (may be NULL to discard) tile by tile on the calling
- * thread; the records of one call are in (idxA, idxB) order (sorted on the device)
- * and stay valid until the sink returns.  *n_pairs / *n_records (may be NULL)
+ * tile_variants = edge of a super-tile in variants (0 = choose: launches sized
+ * by their work where no count matrix is kept, see the "band_launch" switch).
+ * Survivors are handed to `sink` (may be NULL to discard) on the calling thread,
+ * launch by launch, a launch's survivors in pieces of at most 2^20 records; the
+ * records of one sink call are in (idxA, idxB) order (sorted on the device), the
+ * pieces of a launch follow each other in that order, and a piece stays valid
+ * until the sink returns.  *n_pairs / *n_records (may be NULL)
  * receive totals for this shard. */
 typedef int (*twk_hip_record_sink)(void* user, const twk_hip_record* recs, uint64_t n);
 int twk_hip_ld_all(twk_hip_ctx* ctx, int mode, const twk_hip_filters* filters,

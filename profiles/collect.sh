@@ -177,6 +177,15 @@ PY
 		for ac in 2 10 30 100; do timeout 900 $R/build/probe_vs_dense 131072 $ac 4096 4096 3 >> $OUT/probe_vs_dense.txt 2>&1; done
 		cat $OUT/probe_vs_dense.txt
 		;;
+	base_sweep)   # does the count kernel's speed depend on where its rows lie in memory?  (a whole `calc` run is now and then 1.7-1.8x
+		# slower than the same run a second earlier: r04_small_n_ab.txt, r04_band_trace.txt, r04_kg_prof.txt)
+		: > $OUT/base_sweep.txt
+		for shape in "16384 160" "16384 96" "8192 31264"; do
+			BASE_SWEEP=64 timeout 600 $R/build/count_microbench $shape 2 >> $OUT/base_sweep.txt 2>&1
+			BASE_SWEEP=64 STEP=4096 timeout 600 $R/build/count_microbench $shape 2 >> $OUT/base_sweep.txt 2>&1
+		done
+		cat $OUT/base_sweep.txt
+		;;
 	kg_prof)  # the small-N regime (the reference's published shape, 2,504 samples x 200,000 cohort-shaped variants): kernel traces of
 		# `calc -p -w 1000000` (33 M surviving pairs) and of all-vs-all `-r 0.8` without the allele-count band, each with the
 		# fused count -> r2 screen kernel (default) and without it (--engine-option fused=0)

@@ -49,6 +49,29 @@ int main(int argc,char**argv){
     return 0;
   }
   uint32_t* tick; CK(hipMalloc(&tick,4));
+  if(const char* bs=getenv("BASE_SWEEP")){   // probe: does the kernel's speed depend on where the rows lie?  The same rows at n different
+    // offsets (multiples of STEP bytes, default 2 MiB - what separates one process's allocation from another's) inside one big
+    // buffer; 3 warm launches, then the best of `reps`, per offset.
+    const int n=atoi(bs); const size_t step=getenv("STEP")? strtoull(getenv("STEP"),nullptr,10) : (2ull<<20);
+    uint8_t* big; CK(hipMalloc(&big,nw*4+(size_t)n*step));
+    std::vector<uint32_t> list=make_list(R/128,0,true); CK(hipMemcpy(dl,list.data(),list.size()*4,hipMemcpyHostToDevice));
+    twk::CountWork w{}; w.W=W; w.tiles=dl; w.C=C; w.ldc=R; w.ticket=tick;
+    first_split=twk::build_count_units((uint32_t)list.size(),W/twk::KC,P,min_chunks,units,8,8); twk::fill_unit_tiles(units,list.data());
+    CK(hipMemcpy(du,units.data(),units.size()*16,hipMemcpyHostToDevice)); w.units=du; w.n_units=(uint32_t)units.size(); w.n_queues=1; w.queue_begin[0]=0; w.queue_begin[1]=w.n_units;
+    std::vector<float> ms_all;
+    for(int o=0;o<n;++o){
+      uint32_t* base=reinterpret_cast<uint32_t*>(big+(size_t)o*step);
+      CK(hipMemcpy(base,d,nw*4,hipMemcpyDeviceToDevice)); w.rows=base;
+      float best=1e30f;
+      for(int i=0;i<3+reps;++i){ CK(hipMemsetAsync(tick,0,4,0)); if(first_split<list.size()) hipLaunchKernelGGL(twk::k_zero_tiles,dim3((uint32_t)list.size()-first_split),dim3(256),0,0,w.tiles,first_split,C,R);
+        CK(hipEventRecord(e0)); hipLaunchKernelGGL((twk::k_count_list_t<twk::COUNT_NW>),dim3(P),block,0,0,w); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms,e0,e1)); if(i>=3&&ms<best)best=ms; }
+      ms_all.push_back(best);
+    }
+    float mn=1e30f,mx=0; for(float x:ms_all){ mn=std::min(mn,x); mx=std::max(mx,x); }
+    printf("R=%u W=%u, rows at %d offsets of %zu bytes: best launch %.3f .. %.3f ms (ratio %.2f)\n  ",R,W,n,step,mn,mx,mx/mn);
+    for(int o=0;o<n;++o) printf("%.2f%s",ms_all[o],(o%16==15)?"\n  ":" "); printf("\n");
+    return 0;
+  }
   if(getenv("FINISH")){   // probe: per-block finish times of the static list kernel (2 full rounds), by XCD
     std::vector<uint32_t> list=make_list(R/128,0,true); CK(hipMemcpy(dl,list.data(),list.size()*4,hipMemcpyHostToDevice));
     twk::CountWork w{}; w.rows=d; w.W=W; w.tiles=dl; w.C=C; w.ldc=R; w.ticket=tick; first_split=twk::build_count_units((uint32_t)list.size(),W/twk::KC,P,min_chunks,units,getenv("SHAREDIV")?atoi(getenv("SHAREDIV")):8,getenv("TAILROUNDS")?atoi(getenv("TAILROUNDS")):8); twk::fill_unit_tiles(units,list.data()); CK(hipMemcpy(du,units.data(),units.size()*16,hipMemcpyHostToDevice)); w.units=du; w.n_units=(uint32_t)units.size(); w.n_queues=1; w.queue_begin[0]=0; w.queue_begin[1]=w.n_units;
