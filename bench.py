@@ -138,7 +138,7 @@ def measure_traffic(config_args, log):
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="twk_pmc_")
         cmd = [rocprof, "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
-               "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-e2e", "--no-traffic"] + config_args
+               "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-e2e", "--no-traffic", "--no-extra"] + config_args
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=tempfile.gettempdir(), env=dict(os.environ, TMPDIR=tempfile.gettempdir()))
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
