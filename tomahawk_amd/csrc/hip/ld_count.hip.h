@@ -310,25 +310,30 @@ __device__ __forceinline__ uint2 lds_read8(uint32_t addr) {
 // The 8 + TB reads of one half-slot.  addrA0 / addrA1: LDS byte address of this lane's A row for even / odd
 // t (the slot swizzle differs by 4 between them, see the offA table); likewise addrB0 / addrB1; row t is
 // 8 * t rows = t * 1024 bytes further on; HALF selects the upper 8 bytes of the 16-byte slot.
-template <int TB, int T = 0>
+// PAIRED (the unphased fused kernel): a lane's rows are not li + 8t but 2 li + (t & 1) + 16 (t >> 1) - the H and the Q plane
+// of the same four variants - so that all four products of a variant pair end up in one lane (ScreenCountsUnphased); the slot
+// swizzle ((row >> 1) & 7 = li) is then the same for every t, and both addresses are the same.
+template <bool PAIRED, int T>
+constexpr int lane_row_offset() { return PAIRED ? ((T & 1) + 16 * (T >> 1)) * (KC * 4) : T * 8 * (KC * 4); }
+template <int TB, bool PAIRED, int T = 0>
 __device__ __forceinline__ void read_half_a(uint2 (&ra)[8], uint32_t addrA0, uint32_t addrA1, int half) {
 	if constexpr (T < 8) {
-		ra[T] = half ? lds_read8<T * 8 * (KC * 4) + 8>((T & 1) ? addrA1 : addrA0) : lds_read8<T * 8 * (KC * 4)>((T & 1) ? addrA1 : addrA0);
-		read_half_a<TB, T + 1>(ra, addrA0, addrA1, half);
+		ra[T] = half ? lds_read8<lane_row_offset<PAIRED, T>() + 8>((T & 1) ? addrA1 : addrA0) : lds_read8<lane_row_offset<PAIRED, T>()>((T & 1) ? addrA1 : addrA0);
+		read_half_a<TB, PAIRED, T + 1>(ra, addrA0, addrA1, half);
 	}
 }
-template <int TB, int U = 0>
+template <int TB, bool PAIRED, int U = 0>
 __device__ __forceinline__ void read_half_b(uint2 (&rb)[TB], uint32_t addrB0, uint32_t addrB1, int half) {
 	if constexpr (U < TB) {
-		rb[U] = half ? lds_read8<U * 8 * (KC * 4) + 8>((U & 1) ? addrB1 : addrB0) : lds_read8<U * 8 * (KC * 4)>((U & 1) ? addrB1 : addrB0);
-		read_half_b<TB, U + 1>(rb, addrB0, addrB1, half);
+		rb[U] = half ? lds_read8<lane_row_offset<PAIRED, U>() + 8>((U & 1) ? addrB1 : addrB0) : lds_read8<lane_row_offset<PAIRED, U>()>((U & 1) ? addrB1 : addrB0);
+		read_half_b<TB, PAIRED, U + 1>(rb, addrB0, addrB1, half);
 	}
 }
-template <int TB>
+template <int TB, bool PAIRED = false>
 __device__ __forceinline__ void read_half(uint2 (&ra)[8], uint2 (&rb)[TB], uint32_t addrA0, uint32_t addrA1,
                                           uint32_t addrB0, uint32_t addrB1, int half) {
-	read_half_a<TB>(ra, addrA0, addrA1, half);
-	read_half_b<TB>(rb, addrB0, addrB1, half);
+	read_half_a<TB, PAIRED>(ra, addrA0, addrA1, half);
+	read_half_b<TB, PAIRED>(rb, addrB0, addrB1, half);
 }
 // acc[t][u] += popc(a[t] & b) over the two words of a half-slot, t = 0..7 (volatile: keeps its place
 // between the hand-placed LDS reads and waits).
@@ -446,6 +451,7 @@ struct SlotWindow { uint32_t* w; };
 template <int TB>
 struct StoreCounts {
 	static constexpr int META_WORDS = 0;       // nothing to stage for the epilogue
+	static constexpr bool PAIRED_ROWS = false; // a lane's rows are li + 8t (see read_half)
 	uint32_t* C; uint32_t ldc;
 	__device__ __forceinline__ const uint32_t* meta_src(uint32_t, uint32_t) const { return nullptr; }
 	__device__ __forceinline__ void finish(SlotWindow&, int) const {}
@@ -533,12 +539,19 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 #pragma unroll
 		for (int u = 0; u < TB; ++u) acc[t][u] = 0;
 
+	constexpr bool PAIRED = Epilogue::PAIRED_ROWS;
 	uint32_t offA[8], offB[8];
 #pragma unroll
 	for (int k = 0; k < 8; ++k) {
-		offA[k] = (uint32_t)((wr * 64 + li) * (KC * 4) + (((li >> 1) ^ k) << 4));
-		offB[k] = (uint32_t)(LDS_TILE_BYTES + (wc * 8 * TB + lj) * (KC * 4) + (((lj >> 1) ^ k) << 4));
+		if (PAIRED) {      // rows 2 li + (t & 1) + 16 (t >> 1): (row >> 1) & 7 = li for every t
+			offA[k] = (uint32_t)((wr * 64 + 2 * li) * (KC * 4) + ((li ^ k) << 4));
+			offB[k] = (uint32_t)(LDS_TILE_BYTES + (wc * 8 * TB + 2 * lj) * (KC * 4) + ((lj ^ k) << 4));
+		} else {
+			offA[k] = (uint32_t)((wr * 64 + li) * (KC * 4) + (((li >> 1) ^ k) << 4));
+			offB[k] = (uint32_t)(LDS_TILE_BYTES + (wc * 8 * TB + lj) * (KC * 4) + (((lj >> 1) ^ k) << 4));
+		}
 	}
+	constexpr int ODD = PAIRED ? 0 : 4;          // what the slot index of an odd t / u is XORed with (see the offA table)
 
 	const int wave_u = __builtin_amdgcn_readfirstlane(wave);
 	const bool st_isB = wave_u >= NW / 2;
@@ -615,13 +628,13 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 		const int h_end = (c + 1 == nchunks && w.last_halves) ? (int)w.last_halves : 16;     // wave-uniform
 		if (h_end == 16) {
 			uint2 ra[2][8], rb[2][TB];
-			read_half<TB>(ra[0], rb[0], bufbase + offA[0], bufbase + offA[4], bufbase + offB[0], bufbase + offB[4], 0);
+			read_half<TB, PAIRED>(ra[0], rb[0], bufbase + offA[0], bufbase + offA[ODD], bufbase + offB[0], bufbase + offB[ODD], 0);
 #pragma unroll
 			for (int h = 0; h < 16; ++h) {
 				if (h + 1 < 16) {
 					const int q = (h + 1) >> 1;
-					read_half<TB>(ra[(h + 1) & 1], rb[(h + 1) & 1], bufbase + offA[q], bufbase + offA[q ^ 4], bufbase + offB[q],
-					              bufbase + offB[q ^ 4], (h + 1) & 1);
+					read_half<TB, PAIRED>(ra[(h + 1) & 1], rb[(h + 1) & 1], bufbase + offA[q], bufbase + offA[q ^ ODD], bufbase + offB[q],
+					              bufbase + offB[q ^ ODD], (h + 1) & 1);
 					asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
 				} else {
 					asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -637,8 +650,8 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 			for (int h = 0; h < h_end; ++h) {
 				const uint32_t q = (uint32_t)(h >> 1) << 4, hb = (uint32_t)(h & 1) << 3;
 				uint2 ra[8], rb[TB];
-				read_half<TB>(ra, rb, bufbase + (offA[0] ^ q) + hb, bufbase + (offA[0] ^ q ^ 64u) + hb, bufbase + (offB[0] ^ q) + hb,
-				              bufbase + (offB[0] ^ q ^ 64u) + hb, 0);
+				read_half<TB, PAIRED>(ra, rb, bufbase + (offA[0] ^ q) + hb, bufbase + (offA[0] ^ q ^ (uint32_t)(ODD << 4)) + hb, bufbase + (offB[0] ^ q) + hb,
+				              bufbase + (offB[0] ^ q ^ (uint32_t)(ODD << 4)) + hb, 0);
 				asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
 				for (int u = 0; u < TB; ++u) contract_half<TB>(acc, u, ra, rb[u]);
@@ -768,6 +781,7 @@ __device__ __forceinline__ void release_slots(const ScreenWork& s, SlotWindow& w
 }
 template <int TB>
 struct ScreenCounts {
+	static constexpr bool PAIRED_ROWS = false;
 	static constexpr int META_WORDS = 3 * TILE;      // allele counts of the tile's 128 rows, of its 128 columns, band limits of the rows
 	const ScreenWork* sp;              // in device memory: read where it is needed, not held in registers through the K loop
 	// where word i of the staged block comes from (always a readable address; what lies outside the region is masked in the epilogue)
@@ -854,12 +868,15 @@ struct ScreenCounts {
 static_assert(16 / (8 / 2) == 4, "ScreenCounts packs (t, u) as 4t + u: TB = 4");
 
 // ---- the same for the unphased planes (two rows per variant: H = het, Q = hom-alt; no missing data) -----------
-// A variant pair's four products HH, HQ, QH, QQ sit in four lanes: a lane's rows are li + 8t and its columns lj + 8u, the
-// tile starts on an even plane row, so the parity of li / lj is the plane - lane (li, lj) holds (plane li & 1 of A) x
-// (plane lj & 1 of B), and its neighbours lane ^ 1 (other B plane), lane ^ 8 (other A plane) and lane ^ 9 hold the other
-// three products of the same variant pair at the same (t, u).  Three DPP moves per slot bring them together
-// (quad_perm [1,0,3,2] and row_ror:8 - no LDS, no shuffle through memory); of the 32 slots of such a group of four lanes
-// each lane then screens the eight with u = 2 (li & 1) + (lj & 1).
+// A variant pair has four products HH, HQ, QH, QQ.  With the plain row assignment (a lane's rows li + 8t) they sit in four
+// lanes, and round 3 brought them together with three DPP moves per slot - 96 moves and as many selects per lane and tile,
+// twice when the tile had candidates: 9 % of a 3-chunk tile before a single candidate was stored.  Round 4 gives this kernel
+// its own row assignment instead (PAIRED_ROWS, see read_half): a lane's A rows are 2 li + (t & 1) + 16 (t >> 1) and its B
+// rows 2 lj + (u & 1) + 16 (u >> 1) - the H and the Q plane of the same four row variants li + 8 s and the same two column
+// variants lj + 8 v - so that
+//     HH = acc[2s][2v],  HQ = acc[2s][2v + 1],  QH = acc[2s + 1][2v],  QQ = acc[2s + 1][2v + 1]
+// are the lane's own registers: no DPP, no selects, eight variant pairs per lane as before.  (The LDS image does not change;
+// the slot swizzle of such a row is li for every t, still eight distinct bank positions per read.)
 //
 // The screen (UnphasedMath, ld_engine.cpp:1312-1560; d_unphased_math has the same test in front of its cubic): every root the
 // reference may keep lies in [minhap - 1e-5, maxhap + 1e-5], minhap = n11 / 2N, maxhap = (n11 + HH) / 2N with
@@ -867,11 +884,9 @@ static_assert(16 / (8 / 2) == 4, "ScreenCounts packs (t, u) as 4t + u: TB = 4");
 // r2 = D^2 / (P (1 - P) Q (1 - Q)) with the REF frequencies P = 1 - (h_A + 2 q_A) / 2N, Q likewise: the pair can pass only if
 // one end of that interval reaches the cut-off.  For unlinked variants the interval is centred on P Q with half width
 // P (1 - P) Q (1 - Q), which is below any cut-off above 1/16: at the default r2 >= 0.1 only pairs in LD are candidates.
-__device__ __forceinline__ uint32_t dpp_xor1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true); }     // quad_perm [1,0,3,2]: lane ^ 1
-__device__ __forceinline__ uint32_t dpp_xor8(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, true); }    // row_ror:8: lane ^ 8
-
 template <int TB>
 struct ScreenCountsUnphased {
+	static constexpr bool PAIRED_ROWS = true;
 	static constexpr int META_WORDS = 2 * TILE + TILE / 2;     // H / Q counts of the tile's 128 plane rows, of its 128 plane columns, band limits of its 64 row variants
 	const ScreenWork* sp;
 	__device__ __forceinline__ const uint32_t* meta_src(uint32_t yx, uint32_t i) const {
@@ -884,55 +899,48 @@ struct ScreenCountsUnphased {
 	}
 	__device__ __forceinline__ void finish(SlotWindow& win, int lane) const { release_slots<6>(*sp, win, lane); }
 	__device__ __forceinline__ void operator()(uint32_t (&acc)[8][TB], uint32_t yx, int wr, int wc, int li, int lj, int lane, bool, const uint32_t* meta, SlotWindow& win) const {
-		static_assert(TB == 4, "four column slots per lane: one per lane of a 2 x 2 group");
+		static_assert(TB == 4, "two column variants per lane, two planes each");
 		const ScreenWork& s = *sp;
-		const int pa = li & 1, pb = lj & 1, k = 2 * pa + pb;          // my planes; the column slot I screen
-		// set positions (variants) of my slots: rows (li + 8t) >> 1, column (lj + 8k) >> 1 within the wave's sub-tile
-		const uint32_t vA0 = s.a0 + (yx >> 16) * (TILE / 2) + wr * 32 + (li >> 1);         // + 4t
-		const uint32_t vB = s.b0 + (yx & 0xFFFFu) * (TILE / 2) + wc * (4 * TB) + (lj >> 1) + 4 * k;
+		// set positions (variants) of the lane's pairs: rows vA0 + 8 sI (sI = 0..3), columns vB0 + 8 v (v = 0, 1)
+		const uint32_t vA0 = s.a0 + (yx >> 16) * (TILE / 2) + wr * 32 + li;
+		const uint32_t vB0 = s.b0 + (yx & 0xFFFFu) * (TILE / 2) + wc * (4 * TB) + lj;
 		// The screen without a division: with T = 2N, a / b the ALT allele counts and ra = T - a, rb = T - b the REF counts,
 		//     (f11 - P Q) T^2 = n11 T - ra rb   at f11 = minhap,   (n11 + HH) T - ra rb   at f11 = maxhap
 		// (integers, exact in FP64), the admissibility slack 1e-5 becomes 1e-5 T^2, and r2 >= cut reads
 		//     ((f11 - P Q) T^2)^2 >= cut a ra b rb.
 		const double T2n = s.two_n, cut = s.cut, eps = 1e-5 * (T2n * T2n);
-		const bool okB = vB < s.b0 + s.nB && vB < s.n_variants;
-		const int colB = TILE + wc * 8 * TB + (lj & ~1) + 8 * k;            // plane column of my variant's H row within the tile
-		const uint32_t hB = okB ? meta[colB] : 0u, qB = okB ? meta[colB + 1] : 0u;
-		const uint32_t altB = hB + 2u * qB;
-		const double db = (double)altB, rb = T2n - db, fB = db * rb;
 		const bool diag = s.diag != 0;
-		// the group's four products at slot (t, u), for every u; keep u == k.  (All lanes must be active: DPP reads the
-		// neighbours' registers.)
-		auto gather = [&](int t, uint32_t& hh, uint32_t& hq, uint32_t& qh, uint32_t& qq) {
-			uint32_t own = 0, p1 = 0, p8 = 0, p9 = 0;
+		uint32_t vB[2]; bool okB[2]; double db[2], rb[2], fB[2];
 #pragma unroll
-			for (int u = 0; u < TB; ++u) {
-				const uint32_t x = acc[t][u], x1 = dpp_xor1(x), x8 = dpp_xor8(x), x9 = dpp_xor8(x1);
-				if (u == k) { own = x; p1 = x1; p8 = x8; p9 = x9; }
-			}
-			// own = (pa, pb), p1 = (pa, pb ^ 1), p8 = (pa ^ 1, pb), p9 = (pa ^ 1, pb ^ 1)
-			const uint32_t r0 = pb ? p1 : own, r1 = pb ? own : p1;        // (pa, 0), (pa, 1)
-			const uint32_t o0 = pb ? p9 : p8, o1 = pb ? p8 : p9;          // (pa ^ 1, 0), (pa ^ 1, 1)
-			hh = pa ? o0 : r0; hq = pa ? o1 : r1; qh = pa ? r0 : o0; qq = pa ? r1 : o1;
-		};
-		uint32_t m = 0;
+		for (int v = 0; v < 2; ++v) {
+			vB[v] = vB0 + 8 * v;
+			okB[v] = vB[v] < s.b0 + s.nB && vB[v] < s.n_variants;
+			const int colB = TILE + wc * 8 * TB + 2 * lj + 16 * v;         // plane column of the variant's H row within the tile
+			const uint32_t hB = okB[v] ? meta[colB] : 0u, qB = okB[v] ? meta[colB + 1] : 0u;
+			db[v] = (double)(hB + 2u * qB); rb[v] = T2n - db[v]; fB[v] = db[v] * rb[v];
+		}
+		uint32_t m = 0;                  // bit 2 sI + v: the pair (row variant sI, column variant v) is a candidate
 #pragma unroll
-		for (int t = 0; t < 8; ++t) {
-			uint32_t hh, hq, qh, qq;
-			gather(t, hh, hq, qh, qq);
-			const uint32_t vA = vA0 + 4 * t;
+		for (int sI = 0; sI < 4; ++sI) {
+			const uint32_t vA = vA0 + 8 * sI;
 			const bool okA = vA < s.a0 + s.nA && vA < s.n_variants;
-			const int rowA = wr * 64 + (li & ~1) + 8 * t;
+			const int rowA = wr * 64 + 2 * li + 16 * sI;
 			const uint32_t hA = okA ? meta[rowA] : 0u, qA = okA ? meta[rowA + 1] : 0u;
-			const uint32_t hi = !okA ? 0u : (s.col_hi ? s.hi_b0 + meta[2 * TILE + wr * 32 + (li >> 1) + 4 * t] : 0xFFFFFFFFu);
+			const uint32_t hi = !okA ? 0u : (s.col_hi ? s.hi_b0 + meta[2 * TILE + wr * 32 + li + 8 * sI] : 0xFFFFFFFFu);
 			const double da = (double)(hA + 2u * qA), ra = T2n - da;
-			// n11 = ra - b + (QH + HQ + 2 QQ): the (REF, REF) haplotypes that are certain
-			const double n11 = (ra - db) + (double)(qh + hq + 2u * qq);
-			const double e_lo = (n11 * T2n - ra * rb) - eps;
-			const double e_hi = ((n11 + (double)hh) * T2n - ra * rb) + eps;
-			const double bound = (cut * (da * ra)) * fB;
-			const bool ok = okA && okB && (!diag || vB > vA) && vB < hi && !((vA < s.list_zone && vB < s.list_zone) || vA < s.probe_zone) && !(e_lo * e_lo < bound && e_hi * e_hi < bound);
-			m |= (ok ? 1u : 0u) << t;
+			const double fA = cut * (da * ra);
+#pragma unroll
+			for (int v = 0; v < 2; ++v) {
+				const uint32_t hh = acc[2 * sI][2 * v], hq = acc[2 * sI][2 * v + 1], qh = acc[2 * sI + 1][2 * v], qq = acc[2 * sI + 1][2 * v + 1];
+				// n11 = ra - b + (QH + HQ + 2 QQ): the (REF, REF) haplotypes that are certain
+				const double n11 = (ra - db[v]) + (double)(qh + hq + 2u * qq);
+				const double e_lo = (n11 * T2n - ra * rb[v]) - eps;
+				const double e_hi = ((n11 + (double)hh) * T2n - ra * rb[v]) + eps;
+				const double bound = fA * fB[v];
+				const bool ok = okA && okB[v] && (!diag || vB[v] > vA) && vB[v] < hi && !((vA < s.list_zone && vB[v] < s.list_zone) || vA < s.probe_zone)
+				                && !(e_lo * e_lo < bound && e_hi * e_hi < bound);
+				m |= (ok ? 1u : 0u) << (2 * sI + v);
+			}
 		}
 		if (__ballot(m != 0)) {
 			typedef __attribute__((address_space(1))) uint32_t g_u32;
@@ -942,21 +950,19 @@ struct ScreenCountsUnphased {
 			const SlotRange slots = reserve_slots(s, win, total, lane);
 			uint32_t mine = incl - cnt;
 			g_u32* const cand = (g_u32*)s.cand; const unsigned long long cap = s.cap;
-			// (the four products are gathered again rather than kept from the screen: 32 more registers through the screen
-			// cost the kernel two spills, and the scratch traffic of a wave with candidates 30 % of a survivor-rich run)
 #pragma unroll
-			for (int t = 0; t < 8; ++t) {
-				uint32_t hh, hq, qh, qq;
-				gather(t, hh, hq, qh, qq);
-				if ((m >> t) & 1u) {
-					const unsigned long long slot = slots[mine];
-					if (slot < cap) {
-						g_u32* e = cand + slot * 6;
-						e[0] = vA0 + 4 * t; e[1] = vB; e[2] = hh; e[3] = hq; e[4] = qh; e[5] = qq;
+			for (int sI = 0; sI < 4; ++sI)
+#pragma unroll
+				for (int v = 0; v < 2; ++v)
+					if ((m >> (2 * sI + v)) & 1u) {
+						const unsigned long long slot = slots[mine];
+						if (slot < cap) {
+							g_u32* e = cand + slot * 6;
+							e[0] = vA0 + 8 * sI; e[1] = vB[v];
+							e[2] = acc[2 * sI][2 * v]; e[3] = acc[2 * sI][2 * v + 1]; e[4] = acc[2 * sI + 1][2 * v]; e[5] = acc[2 * sI + 1][2 * v + 1];
+						}
+						++mine;
 					}
-					++mine;
-				}
-			}
 		}
 #pragma unroll
 		for (int t = 0; t < 8; ++t)
