@@ -67,6 +67,11 @@ enum { MODE_INT_AUTO_CLEAN = 0x10,     // phased math on the plain planes; pairs
        MODE_INT_SORTED_U   = 0x13 };   // unphased math on the allele-count-sorted planes
 
 constexpr int N_SLOT_COUNTERS = 8;
+// Launches of a region call in flight.  Three, not two: the survivors of launch t are sorted on the copy stream, where they
+// wait for a CU until the persistent count kernel of launch t + 1 lets go; with only t + 1 enqueued the device then idled
+// until the host had sorted, copied and handed over launch t and come back with launch t + 2 (2,504 x 531,500, all pairs:
+// 39 launches of 13 ms took 1.25 s).  With t + 2 already queued the count kernels run back to back.
+constexpr int PIPE_SLOTS = 3, SYNC_SLOT = PIPE_SLOTS;
 struct Slot {                      // one in-flight tile (double buffered)
 	uint32_t* C = nullptr; size_t C_words = 0;
 	twk_hip_record* out = nullptr; unsigned long long capacity = 0;      // survivor buffer and its size (grow-only)
@@ -149,7 +154,7 @@ struct twk_hip_ctx {
 	std::vector<twk_hip_variant_meta> h_meta;
 	std::vector<uint32_t> h_popc;  // ALT alleles per variant as counted on the device (r2 screen; empty until needed, dropped on upload)
 	PlaneSet planes[N_PLANE_SETS];
-	Slot slot[3];                  // [0],[1]: ld_all pipeline; [2]: synchronous single-tile calls
+	Slot slot[PIPE_SLOTS + 1];     // [0 .. PIPE_SLOTS): the pipeline of region calls; [SYNC_SLOT]: synchronous single-tile calls
 	twk_hip_record* h_recs = nullptr; unsigned long long h_recs_cap = 0;   // pinned staging
 	// twk_hip_set_device_sink: the survivors of region calls stay on the device, appended here tile by tile
 	StatsParams* d_list_stats = nullptr;          // parameter block of the list pass's math kernel (device copy)
@@ -165,7 +170,7 @@ struct twk_hip_ctx {
 	twk_hip_progress_cb progress_cb = nullptr; void* progress_user = nullptr;
 	bool progress_muted = false;       // second stage of a default-mode run: its pairs were already counted
 	uint32_t resident_blocks = 512;   // count-kernel blocks the chip holds at once (2 per CU)
-	uint32_t* tickets = nullptr;      // [6][8] work tickets of the count launches: one set of queues per (slot, launch)
+	uint32_t* tickets = nullptr;      // [2 * (PIPE_SLOTS + 1)][8] work tickets of the count launches: one set of queues per (slot, launch)
 	// staging of twk_hip_upload_rle (grow-only): run bytes, descriptors, status word
 	uint8_t* d_rle = nullptr; size_t d_rle_cap = 0;
 	uint8_t* d_rle_desc = nullptr; size_t d_rle_desc_cap = 0;
@@ -884,7 +889,7 @@ int run_list_block(twk_hip_ctx* c, const twk_hip_filters& f, bool unphased, uint
                    twk_hip_record_sink sink = nullptr, void* user = nullptr) {
 	const int set = unphased ? PS_SORTED_U : PS_SORTED_P;
 	const PlaneSet& ps = c->planes[set];
-	Slot& s = c->slot[2];
+	Slot& s = c->slot[SYNC_SLOT];
 	const uint64_t pairs_max = (uint64_t)n_rows * (zone - row0);
 	const unsigned cand_words = unphased ? 6 : 3;              // (A, B, ALTALT) or (A, B, HH, HQ, QH, QQ)
 	int rc = ensure_slot(c, s, (size_t)std::max<uint64_t>(cand_words * pairs_max, 1024), capacity); if (rc) return rc;
@@ -940,7 +945,7 @@ int run_probe_block(twk_hip_ctx* c, const twk_hip_filters& f, bool unphased, uin
                     twk_hip_record_sink sink, void* user) {
 	const int set = unphased ? PS_SORTED_U : PS_SORTED_P;
 	const PlaneSet& ps = c->planes[set];
-	Slot& s = c->slot[2];
+	Slot& s = c->slot[SYNC_SLOT];
 	const uint64_t pairs_max = (uint64_t)n_rows * n_cols;
 	const unsigned cand_words = unphased ? 6 : 3;
 	int rc = ensure_slot(c, s, (size_t)std::max<uint64_t>(cand_words * pairs_max, 1024), capacity); if (rc) return rc;
@@ -990,7 +995,7 @@ int run_probe_block(twk_hip_ctx* c, const twk_hip_filters& f, bool unphased, uin
 int run_tile_sync(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, const twk_hip_filters& f,
                   unsigned long long capacity, unsigned long long* n_out, bool to_host = true, const ColRange* cr = nullptr,
                   twk_hip_record_sink sink = nullptr, void* user = nullptr) {
-	Slot& s = c->slot[2];
+	Slot& s = c->slot[SYNC_SLOT];
 	int rc = enqueue_tile(c, mode, t, f, s, capacity, cr); if (rc) return rc;
 	rc = finish_tile(c, s, t, n_out, to_host, sink, user);
 	if (rc == TWK_HIP_E_OVERFLOW && s.cand_overflow) {       // too many candidates for the fused form: through C, for the rest of this call
@@ -1123,7 +1128,7 @@ int twk_hip_ctx_create(int device, twk_hip_ctx** out) {
 	}
 	if (hipStreamCreateWithFlags(&c->s_compute, hipStreamNonBlocking) != hipSuccess) return fail(TWK_HIP_E_DEVICE);
 	if (hipStreamCreateWithFlags(&c->s_copy, hipStreamNonBlocking) != hipSuccess) return fail(TWK_HIP_E_DEVICE);
-	if (hipMalloc((void**)&c->tickets, 6 * 8 * sizeof(uint32_t)) != hipSuccess) return fail(TWK_HIP_E_NOMEM);
+	if (hipMalloc((void**)&c->tickets, 2 * (PIPE_SLOTS + 1) * 8 * sizeof(uint32_t)) != hipSuccess) return fail(TWK_HIP_E_NOMEM);
 	for (auto& s : c->slot) {
 		hipEvent_t* evs[] = {&s.ev_c0, &s.ev_c1, &s.ev_s1, &s.ev_c0b, &s.ev_c1b};
 		for (auto* e : evs) if (hipEventCreate(e) != hipSuccess) return fail(TWK_HIP_E_DEVICE);
@@ -1404,7 +1409,7 @@ int twk_hip_count_tile(twk_hip_ctx* c, int mode, const twk_hip_tile_desc* t, uin
 	const bool phased = mode == TWK_HIP_MODE_PHASED;
 	const int kind = plane_kind_for(c, phased);
 	int rc = ensure_planes(c, kind); if (rc) return rc;
-	Slot& s = c->slot[2];
+	Slot& s = c->slot[SYNC_SLOT];
 	const Geometry g = tile_geometry(planes_per_variant(kind), *t);
 	rc = ensure_slot(c, s, (size_t)g.rowsA * g.rowsB, 1); if (rc) return rc;
 	uint64_t rp = 0;
@@ -1808,7 +1813,7 @@ static int region_impl(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint3
 		int r = run_tile_sync(c, mode, t, *f, cap_default, &nrec, !c->device_sink, windowed ? &col_range : nullptr, sink ? sink : discard_records, user);
 		if (r == TWK_HIP_E_OVERFLOW) {
 			uint64_t nr = 0;
-			r = redo_tile_in_strips(c, mode, t, *f, c->slot[2].cap_use, sink, user, &nr, windowed ? &col_range : nullptr);
+			r = redo_tile_in_strips(c, mode, t, *f, c->slot[SYNC_SLOT].cap_use, sink, user, &nr, windowed ? &col_range : nullptr);
 			nrec = nr;
 		}
 		if (r == TWK_HIP_OK) tot_recs += nrec;
@@ -1827,18 +1832,18 @@ static int region_impl(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint3
 	};
 	auto band_of = [&](size_t i) -> const BandLaunch* { return i < bands.size() ? &bands[i] : nullptr; };       // (band launches are mine[0 .. bands.size()), in order)
 	std::vector<char> skipped(n, 0);
-	// two-deep software pipeline over the tiles of this shard
+	// software pipeline over the launches of this shard, PIPE_SLOTS deep
 	while (done < n) {
-		while (issued < n && issued < done + 2) {
+		while (issued < n && issued < done + PIPE_SLOTS) {
 			const BandLaunch* b = band_of(issued);
 			if (b && !c->fused_ok) skipped[issued] = 1;                 // an earlier launch gave the fused form up: this one goes the matrix way when its turn comes
 			else {
-				rc = enqueue_tile(c, mode, mine[issued], *f, c->slot[issued & 1], b ? b->cap : cap_default, windowed ? &col_range : nullptr, b ? b->list_words : 0);
+				rc = enqueue_tile(c, mode, mine[issued], *f, c->slot[issued % PIPE_SLOTS], b ? b->cap : cap_default, windowed ? &col_range : nullptr, b ? b->list_words : 0);
 				if (rc) return rc;
 			}
 			++issued;
 		}
-		Slot& s = c->slot[done & 1];
+		Slot& s = c->slot[done % PIPE_SLOTS];
 		unsigned long long nrec = 0;
 		const BandLaunch* b = band_of(done);
 		if (b) {
