@@ -291,9 +291,9 @@ int twk_hip_fisher_exact(twk_hip_ctx* ctx, const int32_t* tables, uint64_t n, do
  *   "fisher_lds"       1        log-factorial table in LDS while it fits
  *   "cand_chunk"       -1       candidate slots a wave reserves at a time (-1: sized from the list)
  *   "band_launch"      1        fused runs: launches sized by their work (a band of rows over all the columns it reaches,
- *                               of about 5 ms of work each) instead of by a count matrix; 0: matrix-sized tiles only
+ *                               at most 8 per region, at least ~5 ms of work each) instead of by a count matrix; 0: matrix-sized tiles only
  *   "band_work_log2"   19       ... of at least 2^n tile-chunks each (19: about 5 ms of contraction)
- *   "band_list_entries" 0       candidate slots of such a launch (0: a sixteenth of its pairs, 4 M .. 1 G); a launch that
+ *   "band_list_entries" 0       candidate slots of such a launch (0: 1/32 of its pairs, 4 M .. 256 M); a launch that
  *                               outgrows them, or its survivor buffer, is redone as matrix-sized tiles
  * None of them changes a record (tests/test_gpu_fused.py, test_gpu_lists.py); "lists" / "list_max" drop the derived
  * plane sets, which are rebuilt on next use.  Unknown key or value out of range: TWK_HIP_E_INVALID. */

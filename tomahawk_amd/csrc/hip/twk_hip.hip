@@ -1127,7 +1127,14 @@ int twk_hip_ctx_create(int device, twk_hip_ctx** out) {
 		if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->resident_blocks = 2u * (uint32_t)cus;
 	}
 	if (hipStreamCreateWithFlags(&c->s_compute, hipStreamNonBlocking) != hipSuccess) return fail(TWK_HIP_E_DEVICE);
-	if (hipStreamCreateWithFlags(&c->s_copy, hipStreamNonBlocking) != hipSuccess) return fail(TWK_HIP_E_DEVICE);
+	{	// The copy stream carries the sort of a launch's survivors and their copy to the host, beside the next launch's persistent
+		// count kernel on the compute stream.  At normal priority each of the sort's half-dozen dependent kernels had to wait for
+		// the CUs the previous one freed, and lost them to the count kernel's waiting blocks every time - one sort kernel per gap
+		// between count launches; at the highest priority its blocks are placed first.
+		int lo = 0, hi = 0;
+		if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = hi = 0; }
+		if (hipStreamCreateWithPriority(&c->s_copy, hipStreamNonBlocking, hi) != hipSuccess) return fail(TWK_HIP_E_DEVICE);
+	}
 	if (hipMalloc((void**)&c->tickets, 2 * (PIPE_SLOTS + 1) * 8 * sizeof(uint32_t)) != hipSuccess) return fail(TWK_HIP_E_NOMEM);
 	for (auto& s : c->slot) {
 		hipEvent_t* evs[] = {&s.ev_c0, &s.ev_c1, &s.ev_s1, &s.ev_c0b, &s.ev_c1b};
@@ -1667,12 +1674,14 @@ static int region_impl(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint3
 	};
 	// Band launches.  A fused launch keeps no count matrix - what it leaves behind is the list of its candidates - so
 	// nothing ties its extent to the 2 GiB a matrix may take: it is sized by its *work*.  The rows of the band are cut
-	// into launches of ~2^19 tile-chunks (about 5 ms of contraction) each, every one over all the columns its rows
-	// reach: one ramp-up and one tail per ~100,000 tiles instead of per row block of 16,384 plane rows (the 2,504-sample
-	// window run of DESIGN 3.2a: 13 launches at 68 % of the ceiling -> 1 at 76 %).  Not longer than that: a launch of a
-	// million tiles ran at 59 % of the ceiling where the same tiles in launches of a hundred thousand ran at 79 %
-	// (2,504 x 531,500 all pairs, profiles/r04_kg_shape.txt), and the host's writer should get its first records while the
-	// device still counts.  A launch whose candidates or survivors outgrow their buffers is redone as matrix-sized tiles (below).
+	// into launches of at least ~2^19 tile-chunks (about 5 ms of contraction), at most 8 per region, every one over all the
+	// columns its rows reach: one ramp-up and one tail per launch instead of per row block of 16,384 plane rows (the
+	// 2,504-sample window run of DESIGN 3.2a: 13 launches at 68 % of the ceiling -> 1 at 77 %), and a handful of sorts, copies
+	// and hand-overs per region on the host instead of dozens (2,504 x 531,500, all pairs: 1.28 s of compute + write in 39
+	// launches, 1.03 s in 9).  More than one launch when there is work for it: the host's writer gets its first records while
+	// the device still counts.  (A launch of a million tiles needed the unit table's entries to carry their tile - one scalar
+	// load per unit instead of two dependent ones - to run like one of a hundred thousand: 59 % -> 83 % of the ceiling.)
+	// A launch whose candidates or survivors outgrow their buffers is redone as matrix-sized tiles (below).
 	struct BandLaunch { uint32_t xa, xb; size_t list_words; unsigned long long cap; size_t tile_index; };
 	std::vector<BandLaunch> bands;
 	const bool band_mode = !tile_variants && c->opt.band_launch && r1 > r0 && fused_form_applies(c, mode, *f);
@@ -1699,7 +1708,7 @@ static int region_impl(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint3
 		};
 		for (uint32_t x = r0; x < r1; x += step) cum_tiles.push_back(cum_tiles.back() + tiles_of_rows(x, std::min(step, r1 - x)));
 		const uint64_t total = cum_tiles.back();
-		const uint64_t n_launch = std::max<uint64_t>(1, total * nchunks >> c->opt.band_work_log2);
+		const uint64_t n_launch = std::max<uint64_t>(1, std::min<uint64_t>(8, total * nchunks >> c->opt.band_work_log2));
 		const uint64_t pairs_per_tile = (uint64_t)(TILE / Pmax) * (TILE / Pmax);
 		const unsigned words_per_entry = plan_for(c, mode).phased1 ? 3 : 6;
 		size_t k0 = 0;
@@ -1720,12 +1729,12 @@ static int region_impl(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint3
 			uint32_t w = col_end - col0;
 			if (triangle && w < xb - xa) w = std::min(xb - xa, nB - col0);
 			if (rb(xb - xa) > 0xFFFFu || rb(w) > 0xFFFFu) { bands.clear(); mine.clear(); break; }      // beyond a tile list's 16-bit coordinates: matrix tiles
-			// candidate slots: a sixteenth of the launch's pairs (a survivor-rich window run has 2 % candidates), 4 M at least, 1 G
-			// at most; survivors: as many records as that, 64 M at most
-			uint64_t entries = std::min<uint64_t>(std::max<uint64_t>(tiles * pairs_per_tile / 16, 1ull << 22), 1ull << 30);
+			// candidate slots: 1/32 of the launch's pairs (a survivor-rich window run has 2 % candidates), 4 M at least, 256 M
+			// at most; survivors: as many records as that, 48 M at most
+			uint64_t entries = std::min<uint64_t>(std::max<uint64_t>(tiles * pairs_per_tile / 32, 1ull << 22), 1ull << 28);
 			entries = std::min<uint64_t>(entries, std::max<uint64_t>(tiles * pairs_per_tile / 3, 1024));      // (never more than a matrix tile would get)
 			if (c->opt.band_list_entries) entries = (uint64_t)c->opt.band_list_entries;      // (test / measurement: exactly this many)
-			BandLaunch b{xa, xb, (size_t)entries * words_per_entry, std::min<unsigned long long>(entries, 1ull << 26), mine.size()};
+			BandLaunch b{xa, xb, (size_t)entries * words_per_entry, std::min<unsigned long long>(entries, 48ull << 20), mine.size()};
 			if (c->opt.record_cap > 0) b.cap = std::min<unsigned long long>(b.cap, (unsigned long long)c->opt.record_cap);
 			const size_t before = mine.size();
 			push_tile(xa, xb - xa, col0, w, triangle ? 1 : 0);
