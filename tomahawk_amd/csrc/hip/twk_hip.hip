@@ -85,6 +85,11 @@ struct Slot {                      // one in-flight tile (double buffered)
 	bool two_pass = false;
 	bool is_list = false;                         // the launch was a carrier-list pass (ld_list.hip.h): C holds its candidate list
 	bool is_probe = false;                        // ... of the probe kind (zone rows x columns outside the zone)
+	// a band launch (region_impl): its pair math is enqueued once its candidate count is known (enqueue_band_math)
+	bool deferred = false; bool deferred_unphased = false;
+	bool was_deferred = false;                    // (this slot's launch was one: its math runs between ev_c0b and ev_s1, not right behind the count kernel)
+	StatsParams* d_stats_dev = nullptr;           // the math kernel's parameter block on the device (behind the launch's tile list)
+	StatsParams stats_host;                       // ... and the host's copy, patched with the survivor buffer before it is sent again
 	bool fused = false;                           // first launch ran the fused count -> screen kernel: C holds the candidate list
 	unsigned long long cand_cap = 0;              // ... of this many entries; n_out[2] counts them
 	bool cand_overflow = false;                   // set by finish_tile: the list did not hold them all
@@ -707,7 +712,19 @@ int enqueue_tile(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, const twk
 		}
 	}
 	const StatsParams* d_stats = nullptr;
+	s.deferred = false; s.was_deferred = false;
 	rc = launch_count(c, kind1, t, s, 0, s.ev_c0, s.ev_c1, &s.row_pairs, cr, want_fused ? &fa : nullptr, &s.fused, &d_stats); if (rc) return rc;
+	if (list_words) {
+		// A band launch stops here for now: how many survivors it can have is how many candidates it found, and only the count
+		// kernel knows.  The counters travel to the host behind it; enqueue_band_math sizes the survivor buffer by them and
+		// enqueues the rest (sizing it by a guess - 1/32 of the launch's pairs - meant gigabytes of allocation per slot, a
+		// tenth of a second each, for launches that then kept a few thousand records).
+		if (!s.fused) return TWK_HIP_E_STATE;
+		s.deferred = true; s.was_deferred = true; s.deferred_unphased = fused_u; s.d_stats_dev = const_cast<StatsParams*>(d_stats); s.stats_host = fa.stats; s.minP = f.minP;
+		HIPCHK(c, hipMemcpyAsync(s.h_n_out, s.n_out, N_SLOT_COUNTERS * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->s_compute));
+		HIPCHK(c, hipEventRecord(s.ev_c1b, c->s_compute));
+		return TWK_HIP_OK;
+	}
 	if (s.fused) {
 		if (d_stats && fused_u)
 			hipLaunchKernelGGL(k_ld_stats_list_unphased, dim3(c->resident_blocks * 4), dim3(256), 0, c->s_compute, d_stats, (const uint32_t*)s.C,
@@ -731,6 +748,39 @@ int enqueue_tile(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, const twk
 	rc = launch_fisher(c, s.out, s.n_out, s.cap_use, f.minP, s.C, s.C_words, s.keys); if (rc) return rc;
 	HIPCHK(c, hipGetLastError());
 	s.minP = f.minP;
+	HIPCHK(c, hipMemcpyAsync(s.h_n_out, s.n_out, N_SLOT_COUNTERS * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->s_compute));
+	HIPCHK(c, hipEventRecord(s.ev_s1, c->s_compute));
+	return TWK_HIP_OK;
+}
+
+// The second half of a band launch (see enqueue_tile): wait for its count kernel, size the survivor buffer by the candidates it
+// found (no pair that was not a candidate can survive), enqueue the list math, Fisher's test and the counters' copy.
+int enqueue_band_math(twk_hip_ctx* c, Slot& s) {
+	if (!s.deferred) return TWK_HIP_E_STATE;
+	s.deferred = false;
+	HIPCHK(c, hipEventSynchronize(s.ev_c1b));
+	const unsigned long long cand = s.h_n_out[2];
+	const bool overflow = cand > s.cand_cap;                 // finish_tile reports it; nothing to compute here
+	unsigned long long need = overflow ? 1 : std::max<unsigned long long>(cand, 1);
+	if (c->opt.record_cap > 0) need = std::min<unsigned long long>(need, (unsigned long long)c->opt.record_cap);      // (test hook: forces the overflow path)
+	if (s.capacity < need) {       // grow with some room: the next launch of the region will be about as rich
+		int rc = ensure_slot(c, s, s.C_words, need + need / 4); if (rc) return rc;
+	}
+	s.cap_use = need;
+	HIPCHK(c, hipEventRecord(s.ev_c0b, c->s_compute));
+	if (s.d_stats_dev && !overflow) {
+		s.stats_host.out = s.out; s.stats_host.capacity = s.cap_use; s.stats_host.n_out = s.n_out;
+		s.stats_host.keys = s.keys; s.stats_host.vals = s.vals;
+		HIPCHK(c, hipMemcpyAsync(s.d_stats_dev, &s.stats_host, sizeof(StatsParams), hipMemcpyHostToDevice, c->s_compute));
+		if (s.deferred_unphased)
+			hipLaunchKernelGGL(k_ld_stats_list_unphased, dim3(c->resident_blocks * 4), dim3(256), 0, c->s_compute, (const StatsParams*)s.d_stats_dev, (const uint32_t*)s.C,
+			                   (const unsigned long long*)(s.n_out + 2), s.cand_cap);
+		else
+			hipLaunchKernelGGL(k_ld_stats_list, dim3(c->resident_blocks * 4), dim3(256), 0, c->s_compute, (const StatsParams*)s.d_stats_dev, (const uint32_t*)s.C,
+			                   (const unsigned long long*)(s.n_out + 2), s.cand_cap);
+		HIPCHK(c, hipGetLastError());
+	}
+	{ const int rc = launch_fisher(c, s.out, s.n_out, s.cap_use, s.minP, s.C, s.C_words, s.keys); if (rc) return rc; }
 	HIPCHK(c, hipMemcpyAsync(s.h_n_out, s.n_out, N_SLOT_COUNTERS * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->s_compute));
 	HIPCHK(c, hipEventRecord(s.ev_s1, c->s_compute));
 	return TWK_HIP_OK;
@@ -829,7 +879,7 @@ int finish_tile(twk_hip_ctx* c, Slot& s, const twk_hip_tile_desc& t, unsigned lo
 		HIPCHK(c, hipEventElapsedTime(&m2, s.ev_c1b, s.ev_s1));
 		ms_all = m1 + m2; c->timing.stats_launches += 2;
 	} else {
-		HIPCHK(c, hipEventElapsedTime(&ms_all, s.ev_c1, s.ev_s1));
+		HIPCHK(c, hipEventElapsedTime(&ms_all, s.was_deferred ? s.ev_c0b : s.ev_c1, s.ev_s1));
 		c->timing.stats_launches += 1;
 	}
 	c->timing.stats_ms += ms_all;
@@ -894,7 +944,7 @@ int run_list_block(twk_hip_ctx* c, const twk_hip_filters& f, bool unphased, uint
 	const unsigned cand_words = unphased ? 6 : 3;              // (A, B, ALTALT) or (A, B, HH, HQ, QH, QQ)
 	int rc = ensure_slot(c, s, (size_t)std::max<uint64_t>(cand_words * pairs_max, 1024), capacity); if (rc) return rc;
 	if (!c->d_list_stats) HIPCHK(c, hipMalloc((void**)&c->d_list_stats, sizeof(StatsParams)));
-	s.two_pass = false; s.fused = false; s.is_list = true; s.is_probe = false; s.cand_overflow = false; s.cand_cap = s.C_words / cand_words; s.minP = f.minP;
+	s.two_pass = false; s.fused = false; s.is_list = true; s.is_probe = false; s.was_deferred = false; s.cand_overflow = false; s.cand_cap = s.C_words / cand_words; s.minP = f.minP;
 	twk_hip_tile_desc t{};
 	t.rowA0 = row0; t.nA = n_rows; t.rowB0 = row0; t.nB = zone - row0; t.diag = 1; t.window = window; t.l_window = l_window;
 	const StatsParams sp = make_stats(c, set, t, s, !unphased, 0, f, &cr);
@@ -950,7 +1000,7 @@ int run_probe_block(twk_hip_ctx* c, const twk_hip_filters& f, bool unphased, uin
 	const unsigned cand_words = unphased ? 6 : 3;
 	int rc = ensure_slot(c, s, (size_t)std::max<uint64_t>(cand_words * pairs_max, 1024), capacity); if (rc) return rc;
 	if (!c->d_list_stats) HIPCHK(c, hipMalloc((void**)&c->d_list_stats, sizeof(StatsParams)));
-	s.two_pass = false; s.fused = false; s.is_list = true; s.is_probe = true; s.cand_overflow = false; s.cand_cap = s.C_words / cand_words; s.minP = f.minP;
+	s.two_pass = false; s.fused = false; s.is_list = true; s.is_probe = true; s.was_deferred = false; s.cand_overflow = false; s.cand_cap = s.C_words / cand_words; s.minP = f.minP;
 	twk_hip_tile_desc t{};
 	t.rowA0 = row0; t.nA = n_rows; t.rowB0 = col0; t.nB = n_cols; t.diag = 0; t.window = window; t.l_window = l_window;
 	const StatsParams sp = make_stats(c, set, t, s, !unphased, 0, f, &cr);
@@ -1682,7 +1732,7 @@ static int region_impl(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint3
 	// the device still counts.  (A launch of a million tiles needed the unit table's entries to carry their tile - one scalar
 	// load per unit instead of two dependent ones - to run like one of a hundred thousand: 59 % -> 83 % of the ceiling.)
 	// A launch whose candidates or survivors outgrow their buffers is redone as matrix-sized tiles (below).
-	struct BandLaunch { uint32_t xa, xb; size_t list_words; unsigned long long cap; size_t tile_index; };
+	struct BandLaunch { uint32_t xa, xb; size_t list_words; size_t tile_index; };
 	std::vector<BandLaunch> bands;
 	const bool band_mode = !tile_variants && c->opt.band_launch && r1 > r0 && fused_form_applies(c, mode, *f);
 	if (band_mode) {
@@ -1730,12 +1780,11 @@ static int region_impl(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint3
 			if (triangle && w < xb - xa) w = std::min(xb - xa, nB - col0);
 			if (rb(xb - xa) > 0xFFFFu || rb(w) > 0xFFFFu) { bands.clear(); mine.clear(); break; }      // beyond a tile list's 16-bit coordinates: matrix tiles
 			// candidate slots: 1/32 of the launch's pairs (a survivor-rich window run has 2 % candidates), 4 M at least, 256 M
-			// at most; survivors: as many records as that, 48 M at most
+			// at most; the survivor buffer is sized once the candidates are counted (enqueue_band_math)
 			uint64_t entries = std::min<uint64_t>(std::max<uint64_t>(tiles * pairs_per_tile / 32, 1ull << 22), 1ull << 28);
 			entries = std::min<uint64_t>(entries, std::max<uint64_t>(tiles * pairs_per_tile / 3, 1024));      // (never more than a matrix tile would get)
 			if (c->opt.band_list_entries) entries = (uint64_t)c->opt.band_list_entries;      // (test / measurement: exactly this many)
-			BandLaunch b{xa, xb, (size_t)entries * words_per_entry, std::min<unsigned long long>(entries, 48ull << 20), mine.size()};
-			if (c->opt.record_cap > 0) b.cap = std::min<unsigned long long>(b.cap, (unsigned long long)c->opt.record_cap);
+			BandLaunch b{xa, xb, (size_t)entries * words_per_entry, mine.size()};
 			const size_t before = mine.size();
 			push_tile(xa, xb - xa, col0, w, triangle ? 1 : 0);
 			if (mine.size() > before) bands.push_back(b);
@@ -1751,7 +1800,7 @@ static int region_impl(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint3
 		for (const auto& t : mine) worst = std::max<unsigned long long>(worst, (unsigned long long)t.nA * t.nB);
 		cap_default = std::min<unsigned long long>(worst ? worst : 1, 1ull << 24);
 	}
-	for (auto& b : bands) b.cap = std::min<unsigned long long>(b.cap, std::max<unsigned long long>(1, (unsigned long long)mine[b.tile_index].nA * mine[b.tile_index].nB));
+
 	if (c->opt.record_cap > 0) cap_default = std::min<unsigned long long>(cap_default, (unsigned long long)c->opt.record_cap);   // test hook: force the overflow / strip path
 	int rc = TWK_HIP_OK;
 	size_t issued = 0, done = 0;
@@ -1842,16 +1891,25 @@ static int region_impl(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint3
 	auto band_of = [&](size_t i) -> const BandLaunch* { return i < bands.size() ? &bands[i] : nullptr; };       // (band launches are mine[0 .. bands.size()), in order)
 	std::vector<char> skipped(n, 0);
 	// software pipeline over the launches of this shard, PIPE_SLOTS deep
+	size_t math_issued = 0;                    // band launches [0, math_issued) have had the second half of their work enqueued
+	auto band_math = [&](size_t i) -> int {
+		if (band_of(i) && !skipped[i]) return enqueue_band_math(c, c->slot[i % PIPE_SLOTS]);
+		return TWK_HIP_OK;
+	};
 	while (done < n) {
 		while (issued < n && issued < done + PIPE_SLOTS) {
 			const BandLaunch* b = band_of(issued);
 			if (b && !c->fused_ok) skipped[issued] = 1;                 // an earlier launch gave the fused form up: this one goes the matrix way when its turn comes
 			else {
-				rc = enqueue_tile(c, mode, mine[issued], *f, c->slot[issued % PIPE_SLOTS], b ? b->cap : cap_default, windowed ? &col_range : nullptr, b ? b->list_words : 0);
+				rc = enqueue_tile(c, mode, mine[issued], *f, c->slot[issued % PIPE_SLOTS], b ? 1 : cap_default, windowed ? &col_range : nullptr, b ? b->list_words : 0);
 				if (rc) return rc;
 			}
 			++issued;
+			// the pair math of a band launch follows once its count kernel is done - with the next launch's count kernel already
+			// queued behind it, so that the device has work while the host waits for the candidate count
+			while (math_issued + 1 < issued) { rc = band_math(math_issued); if (rc) return rc; ++math_issued; }
 		}
+		while (math_issued <= done && math_issued < issued) { rc = band_math(math_issued); if (rc) return rc; ++math_issued; }
 		Slot& s = c->slot[done % PIPE_SLOTS];
 		unsigned long long nrec = 0;
 		const BandLaunch* b = band_of(done);
