@@ -293,6 +293,9 @@ int twk_hip_fisher_exact(twk_hip_ctx* ctx, const int32_t* tables, uint64_t n, do
  *   "band_launch"      1        fused runs: launches sized by their work (a band of rows over all the columns it reaches,
  *                               at most 8 per region, at least ~5 ms of work each) instead of by a count matrix; 0: matrix-sized tiles only
  *   "band_work_log2"   19       ... of at least 2^n tile-chunks each (19: about 5 ms of contraction)
+ *   "band_max_launches" 8       ... and at most this many per region
+ *   "band_reverse"     1        allele-count-sorted runs: the last band (commonest variants, most survivors) first
+ *   "timeline"         0        1: the host's steps through a region's launch pipeline, with times, on stderr
  *   "band_list_entries" 0       candidate slots of such a launch (0: 1/32 of its pairs, 4 M .. 256 M); a launch that
  *                               outgrows them, or its survivor buffer, is redone as matrix-sized tiles
  * None of them changes a record (tests/test_gpu_fused.py, test_gpu_lists.py); "lists" / "list_max" drop the derived

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <new>
 #include <vector>
+#include <chrono>
 #include <string.h>
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -90,6 +91,8 @@ struct Slot {                      // one in-flight tile (double buffered)
 	bool was_deferred = false;                    // (this slot's launch was one: its math runs between ev_c0b and ev_s1, not right behind the count kernel)
 	StatsParams* d_stats_dev = nullptr;           // the math kernel's parameter block on the device (behind the launch's tile list)
 	StatsParams stats_host;                       // ... and the host's copy, patched with the survivor buffer before it is sent again
+	twk_hip_record* sorted = nullptr; unsigned long long sorted_cap = 0;      // band launches: the survivors in (idxA, idxB) order, sorted on the
+	bool presorted = false;                                                   // compute stream right behind Fisher's test (enqueue_band_math)
 	bool fused = false;                           // first launch ran the fused count -> screen kernel: C holds the candidate list
 	unsigned long long cand_cap = 0;              // ... of this many entries; n_out[2] counts them
 	bool cand_overflow = false;                   // set by finish_tile: the list did not hold them all
@@ -126,6 +129,9 @@ struct Options {
 	long long probe = 1;             // zone rows x columns outside the zone: carrier-list probes into the column's row instead of the dense contraction (0: dense)
 	long long band_launch = 1;       // fused runs: launches sized by work (a band of rows, all its columns), not by a count matrix
 	long long band_list_entries = 0; // candidate slots of such a launch (0: a sixteenth of its pairs, 4 M .. 1 G; else exactly this many): small values force its fallback
+	long long band_max_launches = 8; // ... at most this many per region
+	long long band_reverse = 1;      // allele-count-sorted runs: the last band (the commonest variants, most survivors) first
+	long long timeline = 0;          // 1: the host's steps through the launch pipeline of a region, with times, on stderr (measurement)
 	long long band_work_log2 = 19;   // ... and at least 2^n tile-chunks of work per launch (19: ~5 ms); small values make several launches of a small run
 };
 struct OptionKey { const char* name; long long Options::* field; long long lo, hi; bool rebuilds_planes; };
@@ -138,7 +144,7 @@ const OptionKey OPTION_KEYS[] = {
 	{"fisher_lds", &Options::fisher_lds, 0, 1, false}, {"cand_chunk", &Options::cand_chunk, -1, 1 << 20, false},
 	{"record_cap", &Options::record_cap, 0, 1ll << 40, false},
 	{"probe", &Options::probe, 0, 1, false}, {"band_launch", &Options::band_launch, 0, 1, false}, {"band_list_entries", &Options::band_list_entries, 0, 1ll << 32, false},
-	{"band_work_log2", &Options::band_work_log2, 0, 40, false},
+	{"band_work_log2", &Options::band_work_log2, 0, 40, false}, {"band_max_launches", &Options::band_max_launches, 1, 64, false}, {"timeline", &Options::timeline, 0, 1, false}, {"band_reverse", &Options::band_reverse, 0, 1, false},
 };
 }  // namespace
 
@@ -171,6 +177,11 @@ struct twk_hip_ctx {
 	unsigned long long* d_sort_keys = nullptr; uint32_t* d_sort_vals = nullptr; twk_hip_record* d_sorted = nullptr;
 	unsigned long long sort_cap = 0;
 	void* d_sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
+	// the same for the sorts of band launches, which run on the compute stream (one at a time, in stream order) while a sort of
+	// the other kind may be running on the copy stream
+	unsigned long long* d_band_keys = nullptr; uint32_t* d_band_vals = nullptr; unsigned long long band_sort_cap = 0;
+	void* d_band_tmp = nullptr; size_t band_tmp_bytes = 0;
+	std::vector<void*> graveyard;      // device buffers outgrown while launches were in flight: hipFree waits for the device, so they are freed when the call ends
 	twk_hip_timing timing{};
 	twk_hip_progress_cb progress_cb = nullptr; void* progress_user = nullptr;
 	bool progress_muted = false;       // second stage of a default-mode run: its pairs were already counted
@@ -214,7 +225,8 @@ void free_slots(twk_hip_ctx* c) {
 		if (s.out) (void)hipFree(s.out);
 		if (s.keys) (void)hipFree(s.keys);
 		if (s.vals) (void)hipFree(s.vals);
-		s.C = nullptr; s.C_words = 0; s.out = nullptr; s.keys = nullptr; s.vals = nullptr; s.capacity = 0;
+		if (s.sorted) (void)hipFree(s.sorted);
+		s.C = nullptr; s.C_words = 0; s.out = nullptr; s.keys = nullptr; s.vals = nullptr; s.capacity = 0; s.sorted = nullptr; s.sorted_cap = 0;
 		for (int k = 0; k < 2; ++k) {
 			if (s.h_tiles[k]) (void)hipHostFree(s.h_tiles[k]);
 			if (s.d_tiles[k]) (void)hipFree(s.d_tiles[k]);
@@ -712,7 +724,7 @@ int enqueue_tile(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, const twk
 		}
 	}
 	const StatsParams* d_stats = nullptr;
-	s.deferred = false; s.was_deferred = false;
+	s.deferred = false; s.was_deferred = false; s.presorted = false;
 	rc = launch_count(c, kind1, t, s, 0, s.ev_c0, s.ev_c1, &s.row_pairs, cr, want_fused ? &fa : nullptr, &s.fused, &d_stats); if (rc) return rc;
 	if (list_words) {
 		// A band launch stops here for now: how many survivors it can have is how many candidates it found, and only the count
@@ -753,39 +765,6 @@ int enqueue_tile(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, const twk
 	return TWK_HIP_OK;
 }
 
-// The second half of a band launch (see enqueue_tile): wait for its count kernel, size the survivor buffer by the candidates it
-// found (no pair that was not a candidate can survive), enqueue the list math, Fisher's test and the counters' copy.
-int enqueue_band_math(twk_hip_ctx* c, Slot& s) {
-	if (!s.deferred) return TWK_HIP_E_STATE;
-	s.deferred = false;
-	HIPCHK(c, hipEventSynchronize(s.ev_c1b));
-	const unsigned long long cand = s.h_n_out[2];
-	const bool overflow = cand > s.cand_cap;                 // finish_tile reports it; nothing to compute here
-	unsigned long long need = overflow ? 1 : std::max<unsigned long long>(cand, 1);
-	if (c->opt.record_cap > 0) need = std::min<unsigned long long>(need, (unsigned long long)c->opt.record_cap);      // (test hook: forces the overflow path)
-	if (s.capacity < need) {       // grow with some room: the next launch of the region will be about as rich
-		int rc = ensure_slot(c, s, s.C_words, need + need / 4); if (rc) return rc;
-	}
-	s.cap_use = need;
-	HIPCHK(c, hipEventRecord(s.ev_c0b, c->s_compute));
-	if (s.d_stats_dev && !overflow) {
-		s.stats_host.out = s.out; s.stats_host.capacity = s.cap_use; s.stats_host.n_out = s.n_out;
-		s.stats_host.keys = s.keys; s.stats_host.vals = s.vals;
-		HIPCHK(c, hipMemcpyAsync(s.d_stats_dev, &s.stats_host, sizeof(StatsParams), hipMemcpyHostToDevice, c->s_compute));
-		if (s.deferred_unphased)
-			hipLaunchKernelGGL(k_ld_stats_list_unphased, dim3(c->resident_blocks * 4), dim3(256), 0, c->s_compute, (const StatsParams*)s.d_stats_dev, (const uint32_t*)s.C,
-			                   (const unsigned long long*)(s.n_out + 2), s.cand_cap);
-		else
-			hipLaunchKernelGGL(k_ld_stats_list, dim3(c->resident_blocks * 4), dim3(256), 0, c->s_compute, (const StatsParams*)s.d_stats_dev, (const uint32_t*)s.C,
-			                   (const unsigned long long*)(s.n_out + 2), s.cand_cap);
-		HIPCHK(c, hipGetLastError());
-	}
-	{ const int rc = launch_fisher(c, s.out, s.n_out, s.cap_use, s.minP, s.C, s.C_words, s.keys); if (rc) return rc; }
-	HIPCHK(c, hipMemcpyAsync(s.h_n_out, s.n_out, N_SLOT_COUNTERS * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->s_compute));
-	HIPCHK(c, hipEventRecord(s.ev_s1, c->s_compute));
-	return TWK_HIP_OK;
-}
-
 // Survivors are appended with an atomic counter, in no order.  They leave the device in (idxA, idxB) order
 // - the order the writer puts them in the file, which makes a one-GPU run's output deterministic - by a key
 // sort of (idxA << bits | idxB, position) and a gather.  Key and position are written by the math kernels where the
@@ -799,6 +778,88 @@ __global__ void k_gather_records(const twk_hip_record* __restrict__ recs, const 
 	const unsigned long long r = i / W; const uint32_t w = (uint32_t)(i % W);
 	reinterpret_cast<unsigned long long*>(out)[i] = reinterpret_cast<const unsigned long long*>(recs + order[r])[w];
 }
+
+// Replace *p (cap items of `item` bytes) by a buffer of at least `need` items without waiting for the device: the old buffer goes to
+// the graveyard (freed when the call ends).  Contents are not kept.
+int regrow(twk_hip_ctx* c, void** p, unsigned long long* cap, unsigned long long need, size_t item) {
+	if (*cap >= need) return TWK_HIP_OK;
+	const unsigned long long want = need + need / 4;
+	void* q = nullptr;
+	HIPCHK(c, hipMalloc(&q, (size_t)want * item));
+	if (*p) c->graveyard.push_back(*p);
+	*p = q; *cap = want;
+	return TWK_HIP_OK;
+}
+
+// The second half of a band launch (see enqueue_tile): wait for its count kernel, size the survivor buffers by the candidates it
+// found (no pair that was not a candidate can survive), enqueue the list math, Fisher's test, the sort of the survivors and the
+// counters' copy - all on the compute stream.  The sort is over as many slots as there were candidates (unused slots carry the
+// all-ones key, like records the Fisher cut-off drops: they sort behind the survivors): it does not need the survivor count, so it
+// need not wait for the host - on the copy stream (finish_tile's sort_records) it waited for a CU until the *next* launch's
+// persistent count kernel was through, 60 ms per launch of the 2,504 x 531,500 run.
+int enqueue_band_math(twk_hip_ctx* c, Slot& s) {
+	if (!s.deferred) return TWK_HIP_E_STATE;
+	s.deferred = false;
+	HIPCHK(c, hipEventSynchronize(s.ev_c1b));
+	const unsigned long long cand = s.h_n_out[2];
+	const bool overflow = cand > s.cand_cap;                 // finish_tile reports it; nothing to compute here
+	unsigned long long need = overflow ? 1 : std::max<unsigned long long>(cand, 1);
+	if (c->opt.record_cap > 0) need = std::min<unsigned long long>(need, (unsigned long long)c->opt.record_cap);      // (test hook: forces the overflow path)
+	if (need > 0xFFFFFFFFull) return TWK_HIP_E_INVALID;
+	if (s.capacity < need) {       // (with some room: the next launch of the region will be about as rich)
+		unsigned long long c1 = s.capacity, c2 = s.capacity, c3 = s.capacity;
+		int rc = regrow(c, (void**)&s.out, &c1, need, sizeof(twk_hip_record)); if (rc) return rc;
+		rc = regrow(c, (void**)&s.keys, &c2, need, sizeof(unsigned long long)); if (rc) return rc;
+		rc = regrow(c, (void**)&s.vals, &c3, need, sizeof(uint32_t)); if (rc) return rc;
+		s.capacity = std::min(c1, std::min(c2, c3));
+	}
+	{ int rc = regrow(c, (void**)&s.sorted, &s.sorted_cap, need, sizeof(twk_hip_record)); if (rc) return rc; }
+	if (c->band_sort_cap < need) {
+		unsigned long long c1 = c->band_sort_cap, c2 = c->band_sort_cap;
+		int rc = regrow(c, (void**)&c->d_band_keys, &c1, need, sizeof(unsigned long long)); if (rc) return rc;
+		rc = regrow(c, (void**)&c->d_band_vals, &c2, need, sizeof(uint32_t)); if (rc) return rc;
+		c->band_sort_cap = std::min(c1, c2);
+	}
+	size_t tmp = 0;
+	HIPCHK(c, rocprim::radix_sort_pairs(nullptr, tmp, s.keys, c->d_band_keys, s.vals, c->d_band_vals, (size_t)need, 0u, 64u, c->s_compute));
+	if (!c->d_band_tmp || tmp > c->band_tmp_bytes) {
+		unsigned long long cap = c->band_tmp_bytes;
+		int rc = regrow(c, &c->d_band_tmp, &cap, std::max<size_t>(tmp, 4096), 1); if (rc) return rc;
+		c->band_tmp_bytes = (size_t)cap;
+	}
+	s.cap_use = need;
+	HIPCHK(c, hipEventRecord(s.ev_c0b, c->s_compute));
+	if (!overflow) {
+		HIPCHK(c, hipMemsetAsync(s.keys, 0xFF, (size_t)need * sizeof(unsigned long long), c->s_compute));
+		HIPCHK(c, hipMemsetAsync(s.vals, 0, (size_t)need * sizeof(uint32_t), c->s_compute));
+	}
+	if (s.d_stats_dev && !overflow) {
+		s.stats_host.out = s.out; s.stats_host.capacity = s.cap_use; s.stats_host.n_out = s.n_out;
+		s.stats_host.keys = s.keys; s.stats_host.vals = s.vals;
+		HIPCHK(c, hipMemcpyAsync(s.d_stats_dev, &s.stats_host, sizeof(StatsParams), hipMemcpyHostToDevice, c->s_compute));
+		if (s.deferred_unphased)
+			hipLaunchKernelGGL(k_ld_stats_list_unphased, dim3(c->resident_blocks * 4), dim3(256), 0, c->s_compute, (const StatsParams*)s.d_stats_dev, (const uint32_t*)s.C,
+			                   (const unsigned long long*)(s.n_out + 2), s.cand_cap);
+		else
+			hipLaunchKernelGGL(k_ld_stats_list, dim3(c->resident_blocks * 4), dim3(256), 0, c->s_compute, (const StatsParams*)s.d_stats_dev, (const uint32_t*)s.C,
+			                   (const unsigned long long*)(s.n_out + 2), s.cand_cap);
+		HIPCHK(c, hipGetLastError());
+	}
+	{ const int rc = launch_fisher(c, s.out, s.n_out, s.cap_use, s.minP, s.C, s.C_words, s.keys); if (rc) return rc; }
+	s.presorted = false;
+	if (!overflow) {
+		size_t bytes = c->band_tmp_bytes;
+		HIPCHK(c, rocprim::radix_sort_pairs(c->d_band_tmp, bytes, s.keys, c->d_band_keys, s.vals, c->d_band_vals, (size_t)need, 0u, 64u, c->s_compute));
+		const unsigned long long words = need * (sizeof(twk_hip_record) / 8);
+		hipLaunchKernelGGL(k_gather_records, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, c->s_compute, (const twk_hip_record*)s.out, (const uint32_t*)c->d_band_vals, need, s.sorted);
+		HIPCHK(c, hipGetLastError());
+		s.presorted = true;
+	}
+	HIPCHK(c, hipMemcpyAsync(s.h_n_out, s.n_out, N_SLOT_COUNTERS * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->s_compute));
+	HIPCHK(c, hipEventRecord(s.ev_s1, c->s_compute));
+	return TWK_HIP_OK;
+}
+
 static_assert(sizeof(twk_hip_record) % 8 == 0, "record gather copies 8-byte words");
 
 // recs[0..n) on the device, with their keys and positions -> c->d_sorted in (idxA, idxB) order, on stream st.
@@ -862,7 +923,11 @@ int ensure_device_keep(twk_hip_ctx* c, unsigned long long n_more) {
 constexpr unsigned long long HOST_CHUNK = 1ull << 20;       // records per piece (109 MB)
 int finish_tile(twk_hip_ctx* c, Slot& s, const twk_hip_tile_desc& t, unsigned long long* n_out, bool to_host = true,
                 twk_hip_record_sink sink = nullptr, void* user = nullptr) {
+	const auto tl0 = std::chrono::steady_clock::now();
+	double tl_copy = 0, tl_sink = 0;
+	auto since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
 	HIPCHK(c, hipEventSynchronize(s.ev_s1));
+	const double tl_wait = since(tl0);
 	float ms = 0;
 	HIPCHK(c, hipEventElapsedTime(&ms, s.ev_c0, s.ev_c1));
 	if (s.is_list && s.is_probe) { c->timing.probe_ms += ms; c->timing.probe_launches += 1; c->timing.probe_pairs += s.row_pairs; c->timing.candidates += s.h_n_out[2]; }
@@ -898,18 +963,20 @@ int finish_tile(twk_hip_ctx* c, Slot& s, const twk_hip_tile_desc& t, unsigned lo
 	if (!n) return TWK_HIP_OK;
 	// records that failed the Fisher cut-off were only marked on the device (and counted): they sort behind the rest
 	const unsigned long long dropped = std::min(s.h_n_out[1], n), kept = n - dropped;
-	int rc = sort_records(c, s.out, s.keys, s.vals, n, dropped != 0, c->s_copy); if (rc) return rc;
+	int rc = TWK_HIP_OK;
+	if (!s.presorted) { rc = sort_records(c, s.out, s.keys, s.vals, n, dropped != 0, c->s_copy); if (rc) return rc; }
+	const twk_hip_record* sorted = s.presorted ? s.sorted : c->d_sorted;      // (a band launch sorted its own behind Fisher's test: enqueue_band_math)
 	*n_out = kept;
 	if (!to_host) {
 		rc = ensure_device_keep(c, kept); if (rc) return rc;
-		if (kept) HIPCHK(c, hipMemcpyAsync(c->d_keep + c->d_keep_n, c->d_sorted, (size_t)kept * sizeof(twk_hip_record), hipMemcpyDeviceToDevice, c->s_copy));
+		if (kept) HIPCHK(c, hipMemcpyAsync(c->d_keep + c->d_keep_n, sorted, (size_t)kept * sizeof(twk_hip_record), hipMemcpyDeviceToDevice, c->s_copy));
 		c->d_keep_n += kept;
 		HIPCHK(c, hipStreamSynchronize(c->s_copy));
 		return TWK_HIP_OK;
 	}
 	if (!sink || kept <= HOST_CHUNK) {
 		rc = ensure_host_records(c, kept); if (rc) return rc;
-		if (kept) HIPCHK(c, hipMemcpyAsync(c->h_recs, c->d_sorted, (size_t)kept * sizeof(twk_hip_record), hipMemcpyDeviceToHost, c->s_copy));
+		if (kept) HIPCHK(c, hipMemcpyAsync(c->h_recs, sorted, (size_t)kept * sizeof(twk_hip_record), hipMemcpyDeviceToHost, c->s_copy));
 		HIPCHK(c, hipStreamSynchronize(c->s_copy));
 		if (sink && kept && sink(user, c->h_recs, kept)) return TWK_HIP_E_INVALID;
 		return TWK_HIP_OK;
@@ -917,17 +984,21 @@ int finish_tile(twk_hip_ctx* c, Slot& s, const twk_hip_tile_desc& t, unsigned lo
 	rc = ensure_host_records(c, 2 * HOST_CHUNK); if (rc) return rc;
 	auto copy_piece = [&](unsigned long long first) -> hipError_t {
 		const unsigned long long m = std::min(HOST_CHUNK, kept - first);
-		return hipMemcpyAsync(c->h_recs + ((first / HOST_CHUNK) & 1) * HOST_CHUNK, c->d_sorted + first, (size_t)m * sizeof(twk_hip_record), hipMemcpyDeviceToHost, c->s_copy);
+		return hipMemcpyAsync(c->h_recs + ((first / HOST_CHUNK) & 1) * HOST_CHUNK, sorted + first, (size_t)m * sizeof(twk_hip_record), hipMemcpyDeviceToHost, c->s_copy);
 	};
 	HIPCHK(c, copy_piece(0));
 	for (unsigned long long first = 0; first < kept; first += HOST_CHUNK) {
+		auto t1 = std::chrono::steady_clock::now();
 		HIPCHK(c, hipStreamSynchronize(c->s_copy));                                   // piece `first` has arrived
 		if (first + HOST_CHUNK < kept) HIPCHK(c, copy_piece(first + HOST_CHUNK));     // the next one travels while the sink works (into the other half)
+		tl_copy += since(t1); t1 = std::chrono::steady_clock::now();
 		if (sink(user, c->h_recs + ((first / HOST_CHUNK) & 1) * HOST_CHUNK, std::min(HOST_CHUNK, kept - first))) {
 			(void)hipStreamSynchronize(c->s_copy);
 			return TWK_HIP_E_INVALID;
 		}
+		tl_sink += since(t1);
 	}
+	if (c->opt.timeline) fprintf(stderr, "[timeline]   inside: waited %.3f ms for the launch, %.3f ms for copies, %.3f ms in the sink (%llu records)\n", tl_wait, tl_copy, tl_sink, kept);
 	return TWK_HIP_OK;
 }
 
@@ -944,7 +1015,7 @@ int run_list_block(twk_hip_ctx* c, const twk_hip_filters& f, bool unphased, uint
 	const unsigned cand_words = unphased ? 6 : 3;              // (A, B, ALTALT) or (A, B, HH, HQ, QH, QQ)
 	int rc = ensure_slot(c, s, (size_t)std::max<uint64_t>(cand_words * pairs_max, 1024), capacity); if (rc) return rc;
 	if (!c->d_list_stats) HIPCHK(c, hipMalloc((void**)&c->d_list_stats, sizeof(StatsParams)));
-	s.two_pass = false; s.fused = false; s.is_list = true; s.is_probe = false; s.was_deferred = false; s.cand_overflow = false; s.cand_cap = s.C_words / cand_words; s.minP = f.minP;
+	s.two_pass = false; s.fused = false; s.is_list = true; s.is_probe = false; s.was_deferred = false; s.presorted = false; s.cand_overflow = false; s.cand_cap = s.C_words / cand_words; s.minP = f.minP;
 	twk_hip_tile_desc t{};
 	t.rowA0 = row0; t.nA = n_rows; t.rowB0 = row0; t.nB = zone - row0; t.diag = 1; t.window = window; t.l_window = l_window;
 	const StatsParams sp = make_stats(c, set, t, s, !unphased, 0, f, &cr);
@@ -1000,7 +1071,7 @@ int run_probe_block(twk_hip_ctx* c, const twk_hip_filters& f, bool unphased, uin
 	const unsigned cand_words = unphased ? 6 : 3;
 	int rc = ensure_slot(c, s, (size_t)std::max<uint64_t>(cand_words * pairs_max, 1024), capacity); if (rc) return rc;
 	if (!c->d_list_stats) HIPCHK(c, hipMalloc((void**)&c->d_list_stats, sizeof(StatsParams)));
-	s.two_pass = false; s.fused = false; s.is_list = true; s.is_probe = true; s.was_deferred = false; s.cand_overflow = false; s.cand_cap = s.C_words / cand_words; s.minP = f.minP;
+	s.two_pass = false; s.fused = false; s.is_list = true; s.is_probe = true; s.was_deferred = false; s.presorted = false; s.cand_overflow = false; s.cand_cap = s.C_words / cand_words; s.minP = f.minP;
 	twk_hip_tile_desc t{};
 	t.rowA0 = row0; t.nA = n_rows; t.rowB0 = col0; t.nB = n_cols; t.diag = 0; t.window = window; t.l_window = l_window;
 	const StatsParams sp = make_stats(c, set, t, s, !unphased, 0, f, &cr);
@@ -1216,6 +1287,11 @@ int twk_hip_ctx_destroy(twk_hip_ctx* c) {
 	if (c->d_sort_vals) (void)hipFree(c->d_sort_vals);
 	if (c->d_sorted) (void)hipFree(c->d_sorted);
 	if (c->d_sort_tmp) (void)hipFree(c->d_sort_tmp);
+	if (c->d_band_keys) (void)hipFree(c->d_band_keys);
+	if (c->d_band_vals) (void)hipFree(c->d_band_vals);
+	if (c->d_band_tmp) (void)hipFree(c->d_band_tmp);
+	for (void* p : c->graveyard) (void)hipFree(p);
+	c->graveyard.clear();
 	if (c->tickets) (void)hipFree(c->tickets);
 	if (c->d_rle) (void)hipFree(c->d_rle);
 	if (c->d_rle_desc) (void)hipFree(c->d_rle_desc);
@@ -1758,7 +1834,7 @@ static int region_impl(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint3
 		};
 		for (uint32_t x = r0; x < r1; x += step) cum_tiles.push_back(cum_tiles.back() + tiles_of_rows(x, std::min(step, r1 - x)));
 		const uint64_t total = cum_tiles.back();
-		const uint64_t n_launch = std::max<uint64_t>(1, std::min<uint64_t>(8, total * nchunks >> c->opt.band_work_log2));
+		const uint64_t n_launch = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)c->opt.band_max_launches, total * nchunks >> c->opt.band_work_log2));
 		const uint64_t pairs_per_tile = (uint64_t)(TILE / Pmax) * (TILE / Pmax);
 		const unsigned words_per_entry = plan_for(c, mode).phased1 ? 3 : 6;
 		size_t k0 = 0;
@@ -1791,6 +1867,14 @@ static int region_impl(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint3
 		}
 	}
 	if (bands.empty()) matrix_tiles(r0, r1);
+	else if (screen && c->opt.band_reverse) {
+		// Allele-count order: the survivors of a run concentrate in the last bands (common variants: 18 M of the 25.7 M pairs of
+		// the 2,504 x 531,500 run come from the last two launches of eight).  Last band first, so that the host compresses
+		// those while the device counts the poor ones, instead of after it has finished (profiles/r04_band_timeline.txt).
+		std::reverse(bands.begin(), bands.end());
+		std::reverse(mine.begin(), mine.begin() + (ptrdiff_t)bands.size());
+		for (size_t i = 0; i < bands.size(); ++i) bands[i].tile_index = i;
+	}
 
 	uint64_t tot_pairs = 0, tot_recs = 0;
 	// Worst case every pair of a tile survives; cap the device buffer and split on overflow.
@@ -1892,8 +1976,18 @@ static int region_impl(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint3
 	std::vector<char> skipped(n, 0);
 	// software pipeline over the launches of this shard, PIPE_SLOTS deep
 	size_t math_issued = 0;                    // band launches [0, math_issued) have had the second half of their work enqueued
+	const auto t_origin = std::chrono::steady_clock::now();
+	auto mark = [&](const char* what, size_t i, unsigned long long x = 0) {       // "timeline" option: where the host's time goes
+		if (!c->opt.timeline) return;
+		fprintf(stderr, "[timeline] %9.3f ms  %s %zu  %llu\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_origin).count(), what, i, x);
+	};
 	auto band_math = [&](size_t i) -> int {
-		if (band_of(i) && !skipped[i]) return enqueue_band_math(c, c->slot[i % PIPE_SLOTS]);
+		if (band_of(i) && !skipped[i]) {
+			mark("math: wait for count of launch", i);
+			const int r = enqueue_band_math(c, c->slot[i % PIPE_SLOTS]);
+			mark("math enqueued for launch", i, c->slot[i % PIPE_SLOTS].h_n_out[2]);
+			return r;
+		}
 		return TWK_HIP_OK;
 	};
 	while (done < n) {
@@ -1901,8 +1995,10 @@ static int region_impl(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint3
 			const BandLaunch* b = band_of(issued);
 			if (b && !c->fused_ok) skipped[issued] = 1;                 // an earlier launch gave the fused form up: this one goes the matrix way when its turn comes
 			else {
+				mark("enqueue launch", issued);
 				rc = enqueue_tile(c, mode, mine[issued], *f, c->slot[issued % PIPE_SLOTS], b ? 1 : cap_default, windowed ? &col_range : nullptr, b ? b->list_words : 0);
 				if (rc) return rc;
+				mark("enqueued launch", issued);
 			}
 			++issued;
 			// the pair math of a band launch follows once its count kernel is done - with the next launch's count kernel already
@@ -1913,8 +2009,10 @@ static int region_impl(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint3
 		Slot& s = c->slot[done % PIPE_SLOTS];
 		unsigned long long nrec = 0;
 		const BandLaunch* b = band_of(done);
+		mark("finish: wait for launch", done);
 		if (b) {
 			rc = skipped[done] ? TWK_HIP_E_OVERFLOW : finish_tile(c, s, mine[done], &nrec, !c->device_sink, sink ? sink : discard_records, user);
+			mark("finished (records delivered) launch", done, nrec);
 			if (rc == TWK_HIP_E_OVERFLOW) rc = run_band_as_matrix_tiles(*b);      // candidates or survivors beyond the launch's buffers
 			else if (rc == TWK_HIP_OK) tot_recs += nrec;
 			if (rc) return rc;
@@ -1946,10 +2044,28 @@ static int region_impl(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint3
 	return TWK_HIP_OK;
 }
 
+static int region_dispatch(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint32_t a0, uint32_t nA,
+                           uint32_t b0, uint32_t nB, int32_t triangle, uint32_t part, uint32_t n_parts,
+                           uint32_t tile_variants, int32_t window, uint32_t l_window, twk_hip_record_sink sink,
+                           void* user, uint64_t* n_pairs, uint64_t* n_records);
+
 int twk_hip_ld_region(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint32_t a0, uint32_t nA,
                       uint32_t b0, uint32_t nB, int32_t triangle, uint32_t part, uint32_t n_parts,
                       uint32_t tile_variants, int32_t window, uint32_t l_window, twk_hip_record_sink sink,
                       void* user, uint64_t* n_pairs, uint64_t* n_records) {
+	const int rc = region_dispatch(c, mode, f, a0, nA, b0, nB, triangle, part, n_parts, tile_variants, window, l_window, sink, user, n_pairs, n_records);
+	if (c && !c->graveyard.empty()) {       // buffers outgrown during the call (regrow): nothing is in flight any more
+		(void)hipSetDevice(c->device);
+		for (void* p : c->graveyard) (void)hipFree(p);
+		c->graveyard.clear();
+	}
+	return rc;
+}
+
+static int region_dispatch(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint32_t a0, uint32_t nA,
+                           uint32_t b0, uint32_t nB, int32_t triangle, uint32_t part, uint32_t n_parts,
+                           uint32_t tile_variants, int32_t window, uint32_t l_window, twk_hip_record_sink sink,
+                           void* user, uint64_t* n_pairs, uint64_t* n_records) {
 	if (!c || !f || !valid_mode(mode) || n_parts == 0 || part >= n_parts) return TWK_HIP_E_INVALID;
 	if (!c->raw) return TWK_HIP_E_STATE;
 	if (nA == 0 || nB == 0 || (uint64_t)a0 + nA > c->M || (uint64_t)b0 + nB > c->M) return TWK_HIP_E_INVALID;

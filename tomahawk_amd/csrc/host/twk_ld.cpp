@@ -503,7 +503,7 @@ static bool create_devices(DeviceCtxs& dc, int n_gpus, const std::vector<std::pa
 		if (!hip_ok(nullptr, twk_hip_ctx_create(device, &c), "twk_hip_ctx_create")) return false;
 		dc.ctx.push_back(c);
 		for (const auto& kv : options) {
-			if (kv.first == "force_device" || kv.first == "progress_ms" || kv.first == "map_output" || kv.first == "emit_workers") continue;       // this class's own
+			if (kv.first == "force_device" || kv.first == "progress_ms" || kv.first == "map_output" || kv.first == "emit_workers" || kv.first == "emit_backlog_mb") continue;       // this class's own
 			if (!hip_ok(c, twk_hip_set_option(c, kv.first.c_str(), kv.second), "twk_hip_set_option")) return false;
 		}
 	}
@@ -589,7 +589,7 @@ bool twk_ld::twk_ld_impl::run(twk_ld_settings& settings, const Header& hdr, cons
 		std::vector<twk_hip_record> kept;      // declared before the emitter: its workers read it until they are joined
 		RecordEmitter emitter; bool write_failed = false; uint64_t pairs = 0; int rc = TWK_HIP_OK;
 		uint32_t shift = 0;
-		Driver(twk_ld_impl* s, int workers) : self(s), emitter(s->out, workers) {}
+		Driver(twk_ld_impl* s, int workers, size_t backlog) : self(s), emitter(s->out, workers, backlog) {}
 		static int sink(void* user, const twk_hip_record* recs, uint64_t n) {
 			auto* d = static_cast<Driver*>(user);
 			if (d->shift || d->self->cw.on) {
@@ -607,7 +607,9 @@ bool twk_ld::twk_ld_impl::run(twk_ld_settings& settings, const Header& hdr, cons
 		}
 	};
 	std::vector<std::unique_ptr<Driver>> drivers;
-	for (int g = 0; g < n_gpus; ++g) drivers.emplace_back(new Driver(this, n_workers));
+	// expanded blocks that may wait in memory for the compressing workers, per GPU (twk_record_sink.h; measurement: none pays)
+	const size_t backlog = (size_t)std::max<int64_t>(0, option("emit_backlog_mb", 0)) << 20;
+	for (int g = 0; g < n_gpus; ++g) drivers.emplace_back(new Driver(this, n_workers, backlog));
 	auto drive = [&](int g) {
 		Driver& d = *drivers[g];
 		twk_hip_ctx* ctx = ctxs[g];

@@ -54,7 +54,15 @@ struct TwoOutput {
 
 class RecordEmitter {
 public:
-	RecordEmitter(TwoOutput& out, int n_workers) : out_(out), n_workers_(std::max(1, std::min(n_workers, 64))) {
+	// backlog_bytes: how much expanded-but-not-yet-written output may wait in memory (the blocks between the producer and
+	// the file) beyond the 6 blocks per worker that keep the workers busy.  The producer only waits until its records are
+	// *expanded* out of its buffer - work the workers do before any compressing - so with room for a backlog a burst of
+	// survivors costs the producer a copy, not the burst's compression.  Measured on the GPU box over the 2,504 x 531,500 run
+	// (profiles/r04_band_sort_ab.txt): 0.25 - 2 GB change nothing (the run is bound by the compression itself, ~10 GB/s of
+	// records on that host), 4 GB gain 0.2 s of 1.6 s for `-u` (13 M survivors of one launch no longer hold the launch loop
+	// up) and lose 0.25 s of 0.55 s for `-p -w 4000000` (4 GB of freshly faulted memory) - hence none by default.
+	RecordEmitter(TwoOutput& out, int n_workers, size_t backlog_bytes = 0)
+	    : out_(out), n_workers_(std::max(1, std::min(n_workers, 64))), backlog_bytes_(backlog_bytes) {
 		window_ = (size_t)n_workers_ * 6;
 		slots_.resize(window_);
 		for (int t = 0; t < n_workers_; ++t) th_.emplace_back([this] { worker(); });
@@ -109,6 +117,11 @@ public:
 		// hand the closed blocks to the workers; wait until they are out of the producer's buffer
 		{
 			std::unique_lock<std::mutex> lk(mu_);
+			if (next_seq_ == 0 && n_closed) {       // first blocks: the window of blocks in flight, by the backlog it may hold (nobody is using the slots yet)
+				const size_t per_block = 2 * (8 + (size_t)out_.b_size * sizeof(TwoRecord));
+				window_ = std::max<size_t>((size_t)n_workers_ * 6, std::min<size_t>(backlog_bytes_ / std::max<size_t>(per_block, 1), 1u << 16));
+				slots_.resize(window_);
+			}
 			expanding_ = 0;
 			for (size_t b = 0; b < n_closed; ++b) {
 				const uint64_t seq = next_seq_;
@@ -120,7 +133,7 @@ public:
 				s.src_a = lo < nc ? carry_.data() + lo : nullptr; s.n_a = lo < nc ? std::min(hi, nc) - lo : 0;
 				s.src_b = hi > nc ? recs + (std::max(lo, nc) - nc) : nullptr; s.n_b = hi > nc ? hi - std::max(lo, nc) : 0;
 				s.n = (uint32_t)(hi - lo); s.state = Slot::QUEUED;
-				jobs_.push_back(seq);
+				expand_jobs_.push_back(seq);
 				++next_seq_; ++expanding_;
 				cv_job_.notify_one();
 			}
@@ -142,7 +155,7 @@ public:
 
 private:
 	struct Slot {
-		enum State { FREE, QUEUED, PACKED, PLACED, DONE } state = FREE;      // PLACED: its frames have their place in the file; DONE: and are there
+		enum State { FREE, QUEUED, EXPANDED, PACKED, PLACED, DONE } state = FREE;      // EXPANDED: out of the producer's buffer, waiting to be compressed; PLACED: its frames have their place in the file; DONE: and are there
 		TwoWriter::Span at_f, at_v;
 		const twk_hip_record* src_a = nullptr; const twk_hip_record* src_b = nullptr;   // the block = src_a[0..n_a) ++ src_b[0..n_b)
 		uint64_t n_a = 0, n_b = 0;
@@ -152,12 +165,14 @@ private:
 	};
 	TwoOutput& out_;
 	int n_workers_;
+	size_t backlog_bytes_;
 	size_t window_ = 6;
 	std::vector<Slot> slots_;             // block seq lives in slot seq % window_
 	std::vector<std::thread> th_;
 	std::mutex mu_;
 	std::condition_variable cv_job_, cv_expanded_, cv_room_;
-	std::deque<uint64_t> jobs_;           // under mu_: blocks to expand + compress, and (with a mapped output) placed blocks to copy in
+	std::deque<uint64_t> expand_jobs_;    // under mu_: blocks to expand (they hold the producer up: taken first) ...
+	std::deque<uint64_t> jobs_;           // ... expanded blocks to compress, and (with a mapped output) placed blocks to copy in
 	uint64_t next_seq_ = 0, written_ = 0; // under mu_: blocks handed out / in the file (every block below written_ is)
 	uint64_t placed_ = 0;                 // under mu_: blocks [0, placed_) have their place in the file
 	bool placing_ = false;                // under mu_: some worker is running the placing step
@@ -211,30 +226,39 @@ private:
 	void worker() {
 		for (;;) {
 			uint64_t seq;
+			bool expand_it;
 			{
 				std::unique_lock<std::mutex> lk(mu_);
-				cv_job_.wait(lk, [&] { return stop_ || !jobs_.empty(); });
-				if (jobs_.empty()) return;             // stop_
-				seq = jobs_.front(); jobs_.pop_front();
+				cv_job_.wait(lk, [&] { return stop_ || !expand_jobs_.empty() || !jobs_.empty(); });
+				expand_it = !expand_jobs_.empty();
+				if (expand_it) { seq = expand_jobs_.front(); expand_jobs_.pop_front(); }
+				else if (!jobs_.empty()) { seq = jobs_.front(); jobs_.pop_front(); }
+				else return;                           // stop_
 			}
 			Slot& s = slots_[seq % window_];
 			if (s.state == Slot::PLACED) { copy_in(s); continue; }      // (a slot's state only changes under mu_, and only this thread holds the job)
 			const uint32_t m = s.n;
-			s.f.resize(8 + (size_t)m * sizeof(TwoRecord)); s.v.resize(8 + (size_t)m * sizeof(TwoRecord));       // u32 n, u32 n, records (core.cpp:626-631)
-			std::memcpy(s.f.data(), &m, 4); std::memcpy(s.f.data() + 4, &m, 4);
-			std::memcpy(s.v.data(), &m, 4); std::memcpy(s.v.data() + 4, &m, 4);
-			TwoRecord* f = reinterpret_cast<TwoRecord*>(s.f.data() + 8);
-			TwoRecord* v = reinterpret_cast<TwoRecord*>(s.v.data() + 8);
-			const auto w0 = std::chrono::steady_clock::now();
-			for (uint64_t i = 0; i < s.n_a; ++i) expand(s.src_a[i], f[i], v[i]);
-			for (uint64_t i = 0; i < s.n_b; ++i) expand(s.src_b[i], f[s.n_a + i], v[s.n_a + i]);
-			{
+			if (expand_it) {
+				s.f.resize(8 + (size_t)m * sizeof(TwoRecord)); s.v.resize(8 + (size_t)m * sizeof(TwoRecord));       // u32 n, u32 n, records (core.cpp:626-631)
+				std::memcpy(s.f.data(), &m, 4); std::memcpy(s.f.data() + 4, &m, 4);
+				std::memcpy(s.v.data(), &m, 4); std::memcpy(s.v.data() + 4, &m, 4);
+				TwoRecord* f = reinterpret_cast<TwoRecord*>(s.f.data() + 8);
+				TwoRecord* v = reinterpret_cast<TwoRecord*>(s.v.data() + 8);
+				const auto w0 = std::chrono::steady_clock::now();
+				for (uint64_t i = 0; i < s.n_a; ++i) expand(s.src_a[i], f[i], v[i]);
+				for (uint64_t i = 0; i < s.n_b; ++i) expand(s.src_b[i], f[s.n_a + i], v[s.n_a + i]);
+				ns_expand += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - w0).count();
 				std::lock_guard<std::mutex> lk(mu_);
 				if (--expanding_ == 0) cv_expanded_.notify_all();
+				if (!expand_jobs_.empty()) {           // more blocks hold the producer up: this one waits its turn to be compressed
+					s.state = Slot::EXPANDED;
+					jobs_.push_back(seq);
+					cv_job_.notify_one();
+					continue;
+				}
 			}
 			const auto w1 = std::chrono::steady_clock::now();
 			const bool ok = TwoWriter::pack_block(s.f.data(), m, out_.c_level, s.pf) && TwoWriter::pack_block(s.v.data(), m, out_.c_level, s.pv);
-			ns_expand += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(w1 - w0).count();
 			ns_pack += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - w1).count();
 			std::unique_lock<std::mutex> lk(mu_);
 			if (!ok) fail_locked();
