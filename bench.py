@@ -49,6 +49,7 @@ rate over the transfers alone - from the moment every rank had arrived).
 """
 import argparse
 import ctypes
+import datetime
 import json
 import os
 import re
@@ -184,6 +185,12 @@ def run_cli(twk, flags, threads, out):
     if r.returncode != 0:
         return {"error": r.stderr[-300:]}
     lg = r.stderr
+    stamps = []
+    for m in re.findall(r"^\[(\d{4}-\d\d-\d\d \d\d:\d\d:\d\d,\d{3})\]", lg, re.M):
+        try:
+            stamps.append(datetime.datetime.strptime(m, "%Y-%m-%d %H:%M:%S,%f").timestamp())
+        except ValueError:
+            pass
     load = re.search(r"Unpacked and uploaded .* variants\. (\S+)", lg)
     fin = re.search(r"Finished in (\S+)\. Variants: ([0-9,]+), genotypes: [0-9,]+, output: ([0-9,]+)", lg)
     eng = re.search(r"count kernel ([0-9.e+]+) ms in (\d+) launches \(([0-9.e+-]+) % [^)]*\), math kernels ([0-9.e+]+) ms", lg)
@@ -209,7 +216,10 @@ def run_cli(twk, flags, threads, out):
            "list_kernel_ms": float(lst.group(1)) if lst else None,
            "pairs_decided_by_carrier_lists": int(lst.group(3).replace(",", "")) if lst else None,
            "fused_launches": int(fus.group(1)) if fus else 0,
-           "producer_handover_s": float(wri.group(1)) if wri else None}
+           "producer_handover_s": float(wri.group(1)) if wri else None,
+           # the wall outside the log's phases: process start -> first log line, last log line -> exit (runtime teardown)
+           "wall_before_first_log_line_s": round(stamps[0] - t0, 3) if stamps else None,
+           "wall_after_last_log_line_s": round(t0 + wall - stamps[-1], 3) if stamps else None}
     return res
 
 

@@ -309,7 +309,7 @@ int twk_hip_get_option(const twk_hip_ctx* ctx, const char* key, int64_t* value);
  * last reset, plus the algorithmic units they processed. */
 typedef struct {
 	double   count_ms;      /* sum of count-kernel durations                     */
-	double   stats_ms;      /* sum of math/filter-kernel durations               */
+	double   stats_ms;      /* sum of math/filter-kernel durations (a band launch: up to and including the sort of its survivors) */
 	uint64_t count_launches;
 	uint64_t stats_launches;
 	uint64_t row_pairs;     /* plane-row pairs contracted by the count kernel    */

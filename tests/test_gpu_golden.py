@@ -357,3 +357,27 @@ def test_cli_full_chain_import_calc_sort_view(tmp_path):
     rows = [l.split("\t") for l in r.stdout.splitlines()[1:]]
     sel = a[(a["packA"] >> 2 >= 1000) & (a["packA"] >> 2 <= 3000) & ((a["packA"] >> 2) < (a["packB"] >> 2))]
     assert len(rows) == len(sel) > 0 and all(row[1] == "20" and 1001 <= int(row[2]) <= 3001 for row in rows)
+
+
+@pytest.mark.gpu
+def test_cli_hand_off_queue_writes_the_same_file(tmp_path):
+    """Between the engine's thread and the record emitter `tomahawk calc` keeps a queue of copied pieces (engine option
+    emit_queue_pieces, 8 buffers of 2^20 survivors by default; 0: the engine's thread feeds the emitter itself).  2.4 M surviving
+    pairs - three pieces - with no queue, a queue of one buffer (the sink waits for it every time) and the default: one
+    GPU's output is deterministic, so the three files hold the same records in the same blocks."""
+    import hashlib
+    N, M = 64, 2200
+    al = util.random_alleles(M, N, 5)
+    twk = str(tmp_path / "in.twk")
+    hostlib.write_twk(twk, al, (1000 + 10 * np.arange(M)).astype(np.uint32), np.zeros(M, np.uint32), np.ones(M, np.uint8), block_size=100)
+    digests = {}
+    for pieces in (0, 1, 8):
+        out = str(tmp_path / f"q{pieces}.two")
+        r = subprocess.run([hostlib.CLI_PATH, "calc", "-i", twk, "-o", out, "-p", "-r", "0", "-P", "1", "--engine-option", f"emit_queue_pieces={pieces}"],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert "output: " in r.stderr
+        recs, info = hostlib.read_two(out)           # (the files themselves differ in the command line their headers quote)
+        digests[pieces] = (hashlib.sha256(recs.tobytes()).hexdigest(), info["n_blocks"])
+        assert len(recs) > 2 * (1 << 20)             # (both copies of) more than one full piece
+    assert digests[0] == digests[1] == digests[8]

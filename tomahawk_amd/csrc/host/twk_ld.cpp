@@ -503,7 +503,7 @@ static bool create_devices(DeviceCtxs& dc, int n_gpus, const std::vector<std::pa
 		if (!hip_ok(nullptr, twk_hip_ctx_create(device, &c), "twk_hip_ctx_create")) return false;
 		dc.ctx.push_back(c);
 		for (const auto& kv : options) {
-			if (kv.first == "force_device" || kv.first == "progress_ms" || kv.first == "map_output" || kv.first == "emit_workers" || kv.first == "emit_backlog_mb") continue;       // this class's own
+			if (kv.first == "force_device" || kv.first == "progress_ms" || kv.first == "map_output" || kv.first == "emit_workers" || kv.first == "emit_backlog_mb" || kv.first == "emit_queue_pieces") continue;       // this class's own
 			if (!hip_ok(c, twk_hip_set_option(c, kv.first.c_str(), kv.second), "twk_hip_set_option")) return false;
 		}
 	}
@@ -589,10 +589,98 @@ bool twk_ld::twk_ld_impl::run(twk_ld_settings& settings, const Header& hdr, cons
 		std::vector<twk_hip_record> kept;      // declared before the emitter: its workers read it until they are joined
 		RecordEmitter emitter; bool write_failed = false; uint64_t pairs = 0; int rc = TWK_HIP_OK;
 		uint32_t shift = 0;
-		Driver(twk_ld_impl* s, int workers, size_t backlog) : self(s), emitter(s->out, workers, backlog) {}
+		// The hand-off between the engine's thread and the emitter.  emit() holds its caller until the workers have taken the
+		// piece out of the engine's page-locked buffer - and when the workers are behind with their compressing, that is the
+		// speed of the compression (24 ms per 2^20 survivors on the GPU box), paid by the one thread that also keeps the device
+		// supplied with launches.  So the sink only copies the piece (3-4 ms) into a buffer of its own and a second thread feeds
+		// the emitter; at most `cap` such buffers (109 MB each) exist, and only as many as a burst ever needed.
+		enum : uint64_t { PIECE = 1ull << 20 };             // records per buffer: what the engine hands over at most (twk_hip.h)
+		struct Piece { twk_hip_record* recs; uint64_t n; };
+		std::mutex mu; std::condition_variable cv;
+		std::deque<Piece> queue;                // under mu: copied pieces, in order
+		std::vector<twk_hip_record*> spare;     // under mu: buffers not in use (last in, first out: the warm ones)
+		size_t made = 0, cap = 0;               // buffers allocated / at most (0: no hand-off, the sink calls emit() itself)
+		bool feeding = false, stop = false;     // under mu
+		std::atomic<bool> feed_failed{false};
+		std::thread feeder;
+		double t_copy = 0;                      // seconds the engine's thread spent copying pieces / waiting for a buffer
+		Driver(twk_ld_impl* s, int workers, size_t backlog, size_t pieces) : self(s), emitter(s->out, workers, backlog), cap(pieces) {
+			if (cap) feeder = std::thread([this] { feed(); });
+		}
+		~Driver() {
+			if (feeder.joinable()) {
+				{ std::lock_guard<std::mutex> lk(mu); stop = true; }
+				cv.notify_all();
+				feeder.join();
+			}
+			for (auto& p : queue) free(p.recs);
+			for (auto* p : spare) free(p);
+		}
+		void feed() {
+			for (;;) {
+				Piece p;
+				{
+					std::unique_lock<std::mutex> lk(mu);
+					cv.wait(lk, [&] { return stop || !queue.empty(); });
+					if (queue.empty()) return;
+					p = queue.front(); queue.pop_front(); feeding = true;
+				}
+				const bool ok = feed_failed.load() || emitter.emit(p.recs, p.n, false, true);      // (the engine's survivors come sorted)
+				std::lock_guard<std::mutex> lk(mu);
+				if (!ok) feed_failed.store(true);
+				spare.push_back(p.recs); feeding = false;
+				cv.notify_all();
+			}
+		}
+		// every piece handed over so far is with the emitter
+		bool drain() {
+			if (!cap) return !write_failed;
+			std::unique_lock<std::mutex> lk(mu);
+			cv.wait(lk, [&] { return queue.empty() && !feeding; });
+			if (feed_failed.load()) write_failed = true;
+			return !write_failed;
+		}
 		static int sink(void* user, const twk_hip_record* recs, uint64_t n) {
 			auto* d = static_cast<Driver*>(user);
-			if (d->shift || d->self->cw.on) {
+			const bool edit = d->shift || d->self->cw.on;
+			if (d->cap && n <= PIECE) {
+				if (d->feed_failed.load()) { d->write_failed = true; return 1; }
+				const auto t_in = std::chrono::steady_clock::now();
+				twk_hip_record* buf = nullptr;
+				{
+					std::unique_lock<std::mutex> lk(d->mu);
+					d->cv.wait(lk, [&] { return !d->spare.empty() || d->made < d->cap; });
+					if (!d->spare.empty()) { buf = d->spare.back(); d->spare.pop_back(); }
+					else ++d->made;
+				}
+				if (!buf) buf = static_cast<twk_hip_record*>(malloc(PIECE * sizeof(twk_hip_record)));
+				if (!buf) { d->write_failed = true; return 1; }
+				uint64_t m = 0;
+				if (edit) {
+					for (uint64_t i = 0; i < n; ++i) {
+						twk_hip_record r = recs[i];
+						r.idxA += d->shift; r.idxB += d->shift;
+						if (!d->self->cw.on || d->self->compat_keep(r.idxA, r.idxB)) buf[m++] = r;
+					}
+				} else {
+					// four threads' worth of memcpy for a full piece (one thread moves ~10 GB/s on this host)
+					const int T = n >= (1u << 18) ? 4 : 1;
+					std::vector<std::thread> th;
+					for (int t = 1; t < T; ++t) th.emplace_back([=] { std::memcpy(buf + n * t / T, recs + n * t / T, (size_t)(n * (t + 1) / T - n * t / T) * sizeof(twk_hip_record)); });
+					std::memcpy(buf, recs, (size_t)(n / T) * sizeof(twk_hip_record));
+					for (auto& x : th) x.join();
+					m = n;
+				}
+				{
+					std::lock_guard<std::mutex> lk(d->mu);
+					d->queue.push_back(Piece{buf, m});
+				}
+				d->cv.notify_all();
+				d->t_copy += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_in).count();
+				return 0;
+			}
+			if (!d->drain()) return 1;           // (a piece larger than a buffer: in order behind what is queued)
+			if (edit) {
 				// slab-local variant indices -> positions in the run's rid / pos arrays; TWK_REF_COMPAT window filter
 				d->kept.clear();
 				for (uint64_t i = 0; i < n; ++i) {
@@ -609,7 +697,11 @@ bool twk_ld::twk_ld_impl::run(twk_ld_settings& settings, const Header& hdr, cons
 	std::vector<std::unique_ptr<Driver>> drivers;
 	// expanded blocks that may wait in memory for the compressing workers, per GPU (twk_record_sink.h; measurement: none pays)
 	const size_t backlog = (size_t)std::max<int64_t>(0, option("emit_backlog_mb", 0)) << 20;
-	for (int g = 0; g < n_gpus; ++g) drivers.emplace_back(new Driver(this, n_workers, backlog));
+	// buffers of the hand-off between the engine's thread and the emitter, per GPU (Driver above; 0: none, the sink feeds the emitter itself)
+	// (8: 2,504 x 531,500 `-p` 1.02 -> 0.86 s, `-u` 1.57 -> 1.42 s of compute + write; 32 and 64 no better; window runs, which wait
+	// for the compression whatever the queue holds, within their noise - profiles/r04_band_sort_ab.txt)
+	const size_t pieces = (size_t)std::max<int64_t>(0, option("emit_queue_pieces", 8));
+	for (int g = 0; g < n_gpus; ++g) drivers.emplace_back(new Driver(this, n_workers, backlog, pieces));
 	auto drive = [&](int g) {
 		Driver& d = *drivers[g];
 		twk_hip_ctx* ctx = ctxs[g];
@@ -635,6 +727,7 @@ bool twk_ld::twk_ld_impl::run(twk_ld_settings& settings, const Header& hdr, cons
 			d.pairs += np;
 		}
 		twk_hip_set_progress(ctx, nullptr, nullptr);
+		if (!d.drain()) d.write_failed = true;
 		if (d.rc == TWK_HIP_OK && !d.write_failed && !d.emitter.emit(nullptr, 0, true)) d.write_failed = true;     // close the open blocks
 	};
 	if (n_gpus == 1) drive(0);
@@ -672,7 +765,7 @@ bool twk_ld::twk_ld_impl::run(twk_ld_settings& settings, const Header& hdr, cons
 		double t_sort = 0, t_blocks = 0;
 		for (int g = 0; g < n_gpus; ++g) { t_sort = std::max(t_sort, drivers[g]->emitter.t_sort); t_blocks = std::max(t_blocks, drivers[g]->emitter.t_blocks); }
 		std::cerr << stamp("LOG", "WRITER") << pretty(out.n_blocks) << " blocks, " << out.bytes_packed / 1000000 << " MB compressed; the producer spent "
-		          << t_sort + t_blocks << " s handing its survivors over; workers: expanding " << drivers[0]->emitter.ns_expand.load() * 1e-9 << " s, compressing "
+		          << t_sort + t_blocks << " s handing its survivors over (the engine's thread " << drivers[0]->t_copy << " s copying them out of its buffer); workers: expanding " << drivers[0]->emitter.ns_expand.load() * 1e-9 << " s, compressing "
 		          << drivers[0]->emitter.ns_pack.load() * 1e-9 << " s in all; writer thread " << drivers[0]->emitter.ns_write.load() * 1e-9 << " s" << (n_gpus > 1 ? " (slowest GPU's emitter)" : "") << std::endl;
 	}
 	if (!out.writer.close()) { std::cerr << stamp("ERROR", "WRITER") << "Failed to write final block!" << std::endl; return false; }
