@@ -22,7 +22,7 @@ HOST_LIB_SRC := $(filter-out %/calc_main.cpp,$(HOST_SRC))
 HOST_DEPS := $(wildcard $(PKG)/csrc/host/*.h) include/twk_hip.h
 CXXFLAGS := -O2 -std=c++17 -fPIC -Wall -pthread -Iinclude -I$(PKG)/csrc/host
 
-.PHONY: all hip host cli oracle tools clean asan asan-test
+.PHONY: all hip host cli oracle tools clean asan asan-test tsan
 all: hip host cli oracle
 
 hip: $(LIBDIR)/libtwk_hip.so
@@ -61,6 +61,14 @@ asan: $(LIBDIR)/libtwk_hip.so
 asan-test: asan
 	LD_PRELOAD=$$($(CXX) -print-file-name=libasan.so):$$($(CXX) -print-file-name=libubsan.so) ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1 \
 	TWK_HOST_LIB=$(abspath $(ASAN_DIR))/libtomahawk_amd.so TWK_CLI=$(abspath $(ASAN_DIR))/tomahawk python -m pytest tests -x -q -m "not gpu"
+
+# ThreadSanitizer run of the record emitter (worker pool, ordered placing step, backlog, mapped output): the format and
+# emitter sources with -fsanitize=thread around csrc/tools/emitter_tsan.cpp
+tsan:
+	@mkdir -p build
+	$(CXX) -O1 -g -std=c++17 -pthread -fsanitize=thread -Iinclude -I$(PKG)/csrc/host $(PKG)/csrc/tools/emitter_tsan.cpp $(PKG)/csrc/host/twk_format.cpp \
+		-o build/emitter_tsan $(ZSTD_LIB) $(ZLIB)
+	TSAN_OPTIONS=halt_on_error=1 ./build/emitter_tsan
 
 clean:
 	rm -rf $(LIBDIR) $(BINDIR) $(ASAN_DIR) build

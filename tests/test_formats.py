@@ -2,6 +2,7 @@
 import ctypes
 import os
 import re
+import subprocess
 
 import numpy as np
 import pytest
@@ -314,3 +315,14 @@ def test_mapped_and_stream_output_write_the_same_file(tmp_path):
         back, info = hostlib.read_two(path)
         assert len(back) == 2 * len(recs) and info["n_blocks"] > 100
     assert digests[False] == digests[True]
+
+
+def test_record_emitter_and_hand_off_queue_are_clean_under_tsan():
+    """`make tsan`: the format + emitter sources built with -fsanitize=thread around csrc/tools/emitter_tsan.cpp - ragged
+    pieces of sorted survivors through RecordEmitter with 1 / 5 / 16 workers, with and without a backlog of expanded
+    blocks, the mapped output and the hand-off queue (RecordHandOff, what `tomahawk calc` puts between the engine's thread
+    and the emitter); a data race fails the run (halt_on_error), so does a record count that is off."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["make", "-C", root, "tsan"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+    assert "24 configurations, 0 bad" in r.stdout

@@ -588,105 +588,31 @@ bool twk_ld::twk_ld_impl::run(twk_ld_settings& settings, const Header& hdr, cons
 		twk_ld_impl* self;
 		std::vector<twk_hip_record> kept;      // declared before the emitter: its workers read it until they are joined
 		RecordEmitter emitter; bool write_failed = false; uint64_t pairs = 0; int rc = TWK_HIP_OK;
+		RecordHandOff handoff;                 // between the engine's thread (sink below) and the emitter (twk_record_sink.h)
 		uint32_t shift = 0;
-		// The hand-off between the engine's thread and the emitter.  emit() holds its caller until the workers have taken the
-		// piece out of the engine's page-locked buffer - and when the workers are behind with their compressing, that is the
-		// speed of the compression (24 ms per 2^20 survivors on the GPU box), paid by the one thread that also keeps the device
-		// supplied with launches.  So the sink only copies the piece (3-4 ms) into a buffer of its own and a second thread feeds
-		// the emitter; at most `cap` such buffers (109 MB each) exist, and only as many as a burst ever needed.
-		enum : uint64_t { PIECE = 1ull << 20 };             // records per buffer: what the engine hands over at most (twk_hip.h)
-		struct Piece { twk_hip_record* recs; uint64_t n; };
-		std::mutex mu; std::condition_variable cv;
-		std::deque<Piece> queue;                // under mu: copied pieces, in order
-		std::vector<twk_hip_record*> spare;     // under mu: buffers not in use (last in, first out: the warm ones)
-		size_t made = 0, cap = 0;               // buffers allocated / at most (0: no hand-off, the sink calls emit() itself)
-		bool feeding = false, stop = false;     // under mu
-		std::atomic<bool> feed_failed{false};
-		std::thread feeder;
-		double t_copy = 0;                      // seconds the engine's thread spent copying pieces / waiting for a buffer
-		Driver(twk_ld_impl* s, int workers, size_t backlog, size_t pieces) : self(s), emitter(s->out, workers, backlog), cap(pieces) {
-			if (cap) feeder = std::thread([this] { feed(); });
-		}
-		~Driver() {
-			if (feeder.joinable()) {
-				{ std::lock_guard<std::mutex> lk(mu); stop = true; }
-				cv.notify_all();
-				feeder.join();
-			}
-			for (auto& p : queue) free(p.recs);
-			for (auto* p : spare) free(p);
-		}
-		void feed() {
-			for (;;) {
-				Piece p;
-				{
-					std::unique_lock<std::mutex> lk(mu);
-					cv.wait(lk, [&] { return stop || !queue.empty(); });
-					if (queue.empty()) return;
-					p = queue.front(); queue.pop_front(); feeding = true;
-				}
-				const bool ok = feed_failed.load() || emitter.emit(p.recs, p.n, false, true);      // (the engine's survivors come sorted)
-				std::lock_guard<std::mutex> lk(mu);
-				if (!ok) feed_failed.store(true);
-				spare.push_back(p.recs); feeding = false;
-				cv.notify_all();
-			}
-		}
-		// every piece handed over so far is with the emitter
+		Driver(twk_ld_impl* s, int workers, size_t backlog, size_t pieces) : self(s), emitter(s->out, workers, backlog), handoff(emitter, pieces) {}
 		bool drain() {
-			if (!cap) return !write_failed;
-			std::unique_lock<std::mutex> lk(mu);
-			cv.wait(lk, [&] { return queue.empty() && !feeding; });
-			if (feed_failed.load()) write_failed = true;
+			if (!handoff.drain()) write_failed = true;
 			return !write_failed;
 		}
 		static int sink(void* user, const twk_hip_record* recs, uint64_t n) {
 			auto* d = static_cast<Driver*>(user);
 			const bool edit = d->shift || d->self->cw.on;
-			if (d->cap && n <= PIECE) {
-				if (d->feed_failed.load()) { d->write_failed = true; return 1; }
-				const auto t_in = std::chrono::steady_clock::now();
-				twk_hip_record* buf = nullptr;
-				{
-					std::unique_lock<std::mutex> lk(d->mu);
-					d->cv.wait(lk, [&] { return !d->spare.empty() || d->made < d->cap; });
-					if (!d->spare.empty()) { buf = d->spare.back(); d->spare.pop_back(); }
-					else ++d->made;
-				}
-				if (!buf) buf = static_cast<twk_hip_record*>(malloc(PIECE * sizeof(twk_hip_record)));
-				if (!buf) { d->write_failed = true; return 1; }
-				uint64_t m = 0;
-				if (edit) {
-					for (uint64_t i = 0; i < n; ++i) {
-						twk_hip_record r = recs[i];
-						r.idxA += d->shift; r.idxB += d->shift;
-						if (!d->self->cw.on || d->self->compat_keep(r.idxA, r.idxB)) buf[m++] = r;
-					}
-				} else {
-					// four threads' worth of memcpy for a full piece (one thread moves ~10 GB/s on this host)
-					const int T = n >= (1u << 18) ? 4 : 1;
-					std::vector<std::thread> th;
-					for (int t = 1; t < T; ++t) th.emplace_back([=] { std::memcpy(buf + n * t / T, recs + n * t / T, (size_t)(n * (t + 1) / T - n * t / T) * sizeof(twk_hip_record)); });
-					std::memcpy(buf, recs, (size_t)(n / T) * sizeof(twk_hip_record));
-					for (auto& x : th) x.join();
-					m = n;
-				}
-				{
-					std::lock_guard<std::mutex> lk(d->mu);
-					d->queue.push_back(Piece{buf, m});
-				}
-				d->cv.notify_all();
-				d->t_copy += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_in).count();
+			// slab-local variant indices -> positions in the run's rid / pos arrays; TWK_REF_COMPAT window filter
+			auto fix = [d](twk_hip_record& r) -> bool {
+				r.idxA += d->shift; r.idxB += d->shift;
+				return !d->self->cw.on || d->self->compat_keep(r.idxA, r.idxB);
+			};
+			if (d->handoff.takes(n)) {
+				if (!(edit ? d->handoff.put(recs, n, fix) : d->handoff.put(recs, n))) { d->write_failed = true; return 1; }
 				return 0;
 			}
-			if (!d->drain()) return 1;           // (a piece larger than a buffer: in order behind what is queued)
+			if (!d->drain()) return 1;           // (no queue, or a piece larger than its buffers: in order behind what is queued)
 			if (edit) {
-				// slab-local variant indices -> positions in the run's rid / pos arrays; TWK_REF_COMPAT window filter
 				d->kept.clear();
 				for (uint64_t i = 0; i < n; ++i) {
 					twk_hip_record r = recs[i];
-					r.idxA += d->shift; r.idxB += d->shift;
-					if (!d->self->cw.on || d->self->compat_keep(r.idxA, r.idxB)) d->kept.push_back(r);
+					if (fix(r)) d->kept.push_back(r);
 				}
 				recs = d->kept.data(); n = d->kept.size();
 			}
@@ -765,7 +691,7 @@ bool twk_ld::twk_ld_impl::run(twk_ld_settings& settings, const Header& hdr, cons
 		double t_sort = 0, t_blocks = 0;
 		for (int g = 0; g < n_gpus; ++g) { t_sort = std::max(t_sort, drivers[g]->emitter.t_sort); t_blocks = std::max(t_blocks, drivers[g]->emitter.t_blocks); }
 		std::cerr << stamp("LOG", "WRITER") << pretty(out.n_blocks) << " blocks, " << out.bytes_packed / 1000000 << " MB compressed; the producer spent "
-		          << t_sort + t_blocks << " s handing its survivors over (the engine's thread " << drivers[0]->t_copy << " s copying them out of its buffer); workers: expanding " << drivers[0]->emitter.ns_expand.load() * 1e-9 << " s, compressing "
+		          << t_sort + t_blocks << " s handing its survivors over (the engine's thread " << drivers[0]->handoff.t_copy << " s copying them out of its buffer); workers: expanding " << drivers[0]->emitter.ns_expand.load() * 1e-9 << " s, compressing "
 		          << drivers[0]->emitter.ns_pack.load() * 1e-9 << " s in all; writer thread " << drivers[0]->emitter.ns_write.load() * 1e-9 << " s" << (n_gpus > 1 ? " (slowest GPU's emitter)" : "") << std::endl;
 	}
 	if (!out.writer.close()) { std::cerr << stamp("ERROR", "WRITER") << "Failed to write final block!" << std::endl; return false; }

@@ -27,6 +27,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <functional>
@@ -311,6 +312,116 @@ private:
 	void fail_locked() {
 		failed_.store(true);
 		cv_room_.notify_all(); cv_expanded_.notify_all();
+	}
+};
+
+// The hand-off between the thread that receives the engine's survivors and a RecordEmitter.  emit() holds its caller until
+// the workers have taken the piece out of the caller's buffer - and when the workers are behind with their compressing, that
+// is the speed of the compression (24 ms per 2^20 survivors on the GPU box), paid by the one thread that also keeps the device
+// supplied with launches.  put() only copies the piece (3-4 ms) into a buffer of the queue's own and a second thread feeds
+// the emitter, in order; at most `cap` such buffers (109 MB each) exist, and only as many as a burst ever needed.
+// cap == 0: no queue (takes() is false, the caller feeds the emitter itself).
+class RecordHandOff {
+public:
+	enum : uint64_t { PIECE = 1ull << 20 };        // records per buffer: what the engine hands over at most (twk_hip.h)
+	RecordHandOff(RecordEmitter& emitter, size_t cap) : emitter_(emitter), cap_(cap) {
+		if (cap_) feeder_ = std::thread([this] { feed(); });
+	}
+	~RecordHandOff() {
+		if (feeder_.joinable()) {
+			{ std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+			cv_.notify_all();
+			feeder_.join();
+		}
+		for (auto& p : queue_) free(p.recs);
+		for (auto* p : spare_) free(p);
+	}
+	RecordHandOff(const RecordHandOff&) = delete;
+	RecordHandOff& operator=(const RecordHandOff&) = delete;
+
+	double t_copy = 0;                            // seconds put() spent copying / waiting for a buffer
+	bool takes(uint64_t n) const { return cap_ != 0 && n <= PIECE; }
+	// Queue a copy of recs[0..n) (n <= PIECE); with `edit`, of the records it returns true for, as it leaves them.
+	// -> false once the emitter has failed.
+	bool put(const twk_hip_record* recs, uint64_t n) { return put_impl(recs, n, nullptr); }
+	template <class Edit> bool put(const twk_hip_record* recs, uint64_t n, Edit edit) {
+		const std::function<bool(twk_hip_record&)> f(edit);
+		return put_impl(recs, n, &f);
+	}
+	// every piece handed over so far is with the emitter; -> false if the emitter failed
+	bool drain() {
+		if (!cap_) return true;
+		std::unique_lock<std::mutex> lk(mu_);
+		cv_.wait(lk, [&] { return queue_.empty() && !feeding_; });
+		return !failed_.load();
+	}
+
+private:
+	struct Piece { twk_hip_record* recs; uint64_t n; };
+	RecordEmitter& emitter_;
+	size_t cap_, made_ = 0;                     // buffers at most / allocated (under mu_)
+	std::mutex mu_; std::condition_variable cv_;
+	std::deque<Piece> queue_;                   // under mu_: copied pieces, in order
+	std::vector<twk_hip_record*> spare_;        // under mu_: buffers not in use (last in, first out: the warm ones)
+	bool feeding_ = false, stop_ = false;       // under mu_
+	std::atomic<bool> failed_{false};
+	std::thread feeder_;
+
+	bool put_impl(const twk_hip_record* recs, uint64_t n, const std::function<bool(twk_hip_record&)>* edit) {
+		if (failed_.load() || !takes(n)) return false;
+		const auto t_in = std::chrono::steady_clock::now();
+		twk_hip_record* buf = nullptr;
+		{
+			std::unique_lock<std::mutex> lk(mu_);
+			cv_.wait(lk, [&] { return !spare_.empty() || made_ < cap_; });
+			if (!spare_.empty()) { buf = spare_.back(); spare_.pop_back(); }
+			else ++made_;
+		}
+		if (!buf) buf = static_cast<twk_hip_record*>(malloc(PIECE * sizeof(twk_hip_record)));
+		if (!buf) {
+			std::lock_guard<std::mutex> lk(mu_);
+			--made_; failed_.store(true);
+			return false;
+		}
+		uint64_t m = 0;
+		if (edit) {
+			for (uint64_t i = 0; i < n; ++i) {
+				twk_hip_record r = recs[i];
+				if ((*edit)(r)) buf[m++] = r;
+			}
+		} else {
+			// four threads' worth of memcpy for a full piece (one thread moves ~10 GB/s on the GPU box's host)
+			const int T = n >= (1u << 18) ? 4 : 1;
+			std::vector<std::thread> th;
+			for (int t = 1; t < T; ++t)
+				th.emplace_back([=] { std::memcpy(buf + n * t / T, recs + n * t / T, (size_t)(n * (t + 1) / T - n * t / T) * sizeof(twk_hip_record)); });
+			std::memcpy(buf, recs, (size_t)(n / T) * sizeof(twk_hip_record));
+			for (auto& x : th) x.join();
+			m = n;
+		}
+		{
+			std::lock_guard<std::mutex> lk(mu_);
+			queue_.push_back(Piece{buf, m});
+		}
+		cv_.notify_all();
+		t_copy += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_in).count();
+		return true;
+	}
+	void feed() {
+		for (;;) {
+			Piece p;
+			{
+				std::unique_lock<std::mutex> lk(mu_);
+				cv_.wait(lk, [&] { return stop_ || !queue_.empty(); });
+				if (queue_.empty()) return;
+				p = queue_.front(); queue_.pop_front(); feeding_ = true;
+			}
+			const bool ok = !failed_.load() && emitter_.emit(p.recs, p.n, false, true);      // (the engine's survivors come sorted)
+			std::lock_guard<std::mutex> lk(mu_);
+			if (!ok) failed_.store(true);
+			spare_.push_back(p.recs); feeding_ = false;
+			cv_.notify_all();
+		}
 	}
 };
 
