@@ -366,15 +366,19 @@ def test_band_launches_equal_matrix_sized_tiles(hip, opt, mode):
     calls = {
         "all": lambda: hip.ld_all(mode, f),
         "band": lambda: hip.ld_all(mode, f, window=T.OPT_R2_SCREEN),
+        # a Fisher cut-off that splits the survivors: the dropped ones sort behind the kept (with the unused slots of a band launch's sort)
+        "band, P cut-off": lambda: hip.ld_all(mode, T.Filters(minR2=0.1, minP=1e-300), window=T.OPT_R2_SCREEN),
         "window": lambda: hip.ld_all(mode, f, window=T.OPT_WINDOW, l_window=40_000),
         "shard": lambda: hip.ld_all(mode, f, part=1, n_parts=3),
         "window shard": lambda: hip.ld_all(mode, f, part=2, n_parts=3, window=T.OPT_WINDOW, l_window=25_000),
         "rectangle": lambda: hip.ld_region(mode, f, 100, 2000, 2500, 3300, False),
     }
+    sizes = {}
     for name, call in calls.items():
         opt.set("band_launch", 0)
         hip.timing_reset()
         base, np0, nr0 = call()
+        sizes[name] = nr0
         t0 = hip.timing()
         assert t0["fused_launches"] == t0["count_launches"] >= 1 and nr0 == len(base) > 100, name
         want = np.sort(base, order=ORDER).tobytes()
@@ -386,7 +390,7 @@ def test_band_launches_equal_matrix_sized_tiles(hip, opt, mode):
             t1 = hip.timing()
             assert np1 == np0 and nr1 == nr0 and np.sort(got, order=ORDER).tobytes() == want, (name, log2)
             assert t1["fused_launches"] == t1["count_launches"] and 1 <= t1["count_launches"] <= 8, (name, log2, t1)
-            if log2 < 19 and name in ("all", "band", "rectangle"):
+            if log2 < 19 and name in ("all", "band", "band, P cut-off", "rectangle"):
                 assert t1["count_launches"] > 1, (name, log2, t1)
             if n_launch is not None and name in ("all", "window", "rectangle"):
                 assert t1["count_launches"] == n_launch, (name, log2, t1)
@@ -394,6 +398,13 @@ def test_band_launches_equal_matrix_sized_tiles(hip, opt, mode):
                 key = got["idxA"].astype(np.uint64) << np.uint64(32) | got["idxB"].astype(np.uint64)
                 assert (np.diff(key.astype(np.int64)) > 0).all(), (name, log2)
         opt.set("band_work_log2", 19)
+        if name.startswith("band"):        # allele-count order: last band first by default, first band first gives the same records
+            opt.set("band_reverse", 0)
+            opt.set("band_work_log2", 10)
+            got, np1, nr1 = call()
+            opt.unset("band_reverse")
+            opt.set("band_work_log2", 19)
+            assert np1 == np0 and nr1 == nr0 and np.sort(got, order=ORDER).tobytes() == want, (name, "band_reverse=0")
         for key, value in (("band_list_entries", 64), ("record_cap", 50)):
             opt.set(key, value)
             hip.timing_reset()
@@ -402,6 +413,7 @@ def test_band_launches_equal_matrix_sized_tiles(hip, opt, mode):
             opt.unset(key)
             assert np1 == np0 and nr1 == nr0 and np.sort(got, order=ORDER).tobytes() == want, (name, key)
             assert t1["count_launches"] > 1, (name, key, t1)          # the band launch, then the tiles that redid it
+    assert 100 < sizes["band, P cut-off"] < sizes["band"]          # the cut-off dropped some and kept some
     # more survivors than one piece of the host staging buffer (2^20 records): they reach the sink piece by piece, in order
     f_low = T.Filters(minR2=0.0004)
     opt.set("band_launch", 0)
