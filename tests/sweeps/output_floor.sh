@@ -21,4 +21,16 @@ for out in /tmp/of.two /dev/shm/of.two /tmp/null.two; do
 		echo "== calc $args -o $out: $(grep -o 'Finished in [0-9.]*s' /tmp/of.err) $(grep -o 'handover[^;]*' /tmp/of.err | head -1)"
 	done
 done
-rm -f /tmp/of.two /dev/shm/of.two
+rm -f /dev/shm/of.two
+# (3) is it the compression or the one append stream?  The window run (count kernel 49 ms: nothing but the host's work) with
+# 16 / 32 / 64 emitter threads, into a file and into /dev/null
+for out in /tmp/of.two /tmp/null.two; do
+	for w in 16 32 64; do
+		for rep in 1 2; do
+			[ $out != /tmp/null.two ] && rm -f $out
+			$R/tomahawk_amd/bin/tomahawk calc -i $F -o $out -t 64 -p -w 4000000 --engine-option emit_workers=$w > /dev/null 2> /tmp/of.err
+		done
+		echo "== calc -p -w 4000000 -o $out emit_workers=$w: $(grep -o 'Finished in [0-9.]*s' /tmp/of.err) $(grep -o 'workers: expanding.*' /tmp/of.err | cut -c1-120)"
+	done
+done
+rm -f /tmp/of.two
