@@ -120,6 +120,8 @@ def cpu_baseline(n_samples, mode, seed, log):
     if not rate:
         rate = pairs / wall
     return {"value": rate, "unit": "variant-pairs/s", "cores": cores, "kind": "reference",
+            # CPUs the container may really use (affinity mask, CFS quota): `cores` threads share them
+            "host_cpus_usable": hostlib.usable_cpus(),
             "sample": f"first {m} variants of the same synthetic input ({pairs} pairs, N={n_samples}, calc {flag} "
                       f"-t {cores}, {block} variants/block, SSE4.2 build of the reference, {wall:.1f}s wall)"}
 

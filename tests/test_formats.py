@@ -326,3 +326,22 @@ def test_record_emitter_and_hand_off_queue_are_clean_under_tsan():
     r = subprocess.run(["make", "-C", root, "tsan"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
     assert "24 configurations, 0 bad" in r.stdout
+
+
+def test_usable_cpus_respects_affinity_and_the_cgroup_quota():
+    """Thread pools on the host side are sized by util::usable_cpus (twk_util.h): hardware threads, cut to the scheduler
+    affinity mask and to the container's CFS quota - beyond the quota every thread of the container is frozen until the
+    next period, the one feeding the GPU included (the GPU boxes of this pool: 256 hardware threads, a quota of 16)."""
+    n = hostlib.usable_cpus()
+    want = len(os.sched_getaffinity(0))
+    for quota_file, period_file in (("/sys/fs/cgroup/cpu.max", None), ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us")):
+        try:
+            words = open(quota_file).read().split()
+            quota = -1 if words[0] == "max" else int(words[0])
+            period = int(words[1]) if period_file is None else int(open(period_file).read().split()[0])
+        except (OSError, IndexError, ValueError):
+            continue
+        if quota > 0 and period > 0:
+            want = min(want, -(-quota // period))
+        break
+    assert n == max(1, want)

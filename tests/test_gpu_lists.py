@@ -27,6 +27,8 @@ def _with_flips(al, seed):
 
 def _run(hip, opt, lists_env, data, mask, variants, calls):
     opt.set("lists", int(lists_env))
+    opt.set("probe_zone", 0)            # these tests are about the merges: the zone's own pairs stay with them
+                                        # (test_probe_pass_equals_dense_and_merges_only covers the default)
     N = variants_n = None
     hip.set_problem(_run.N, len(variants))
     hip.upload(data, util.to_hip_meta(variants), mask)
@@ -35,7 +37,7 @@ def _run(hip, opt, lists_env, data, mask, variants, calls):
         hip.timing_reset()
         recs = call()
         out.append((recs, hip.timing()))
-    opt.unset("lists")
+    opt.unset("lists"); opt.unset("probe_zone")
     return out
 
 
@@ -70,7 +72,7 @@ def test_list_zone_equals_dense_and_oracle(hip, opt, N, forced):
     hip.upload(data[sub], util.to_hip_meta(variants[sub]), None)
     hip.timing_reset()
     got, _, _ = hip.ld_all(T.MODE_PHASED, T.Filters(minR2=0.05), window=T.OPT_R2_SCREEN)
-    assert hip.timing()["list_launches"] > 0
+    assert hip.timing()["list_launches"] + hip.timing()["probe_launches"] > 0      # (the zone's pairs: probes where the row's list is short, merges else)
     opt.unset("lists")
     want = O.all_pairs(data[sub], None, variants[sub], N, O.settings(minR2=0.05, phased=True), vector_only=False)
     assert len(want) > 20
@@ -138,7 +140,7 @@ def test_unphased_list_zone_equals_dense_and_oracle(hip, opt, N, forced):
     hip.upload(data[sub], util.to_hip_meta(variants[sub]), None)
     hip.timing_reset()
     got, _, _ = hip.ld_all(mode, T.Filters(minR2=0.05), window=T.OPT_R2_SCREEN)
-    assert hip.timing()["list_launches"] > 0
+    assert hip.timing()["list_launches"] + hip.timing()["probe_launches"] > 0      # (probes where the row's list is short, merges else)
     opt.unset("lists")
     want = O.all_pairs(data[sub], None, variants[sub], N, O.settings(minR2=0.05, unphased=True), vector_only=False)
     assert len(want) > 20
@@ -150,7 +152,8 @@ def test_probe_pass_equals_dense_and_merges_only(hip, opt, mode, N, forced):
     """K1's asymmetric path (lib/ld/ld_engine.cpp:230-242: walk the shorter carrier list, test the partner's bitvector): the
     pairs of a zone variant with a variant that keeps no list are probes of its carriers into the partner's plane row(s)
     (k_probe_screen / k_probe_screen_unphased) instead of dense contractions.  Three ways - no lists at all, merges inside the
-    zone only (option probe = 0), merges + probes - the same records bit for bit, for several cut-offs (band widths), shards,
+    zone only (option probe = 0), merges + probes (with the probing rows taking the zone's own columns too, the default, or
+    only the columns beyond the zone: option probe_zone) - the same records bit for bit, for several cut-offs (band widths), shards,
     a Fisher cut-off, variants turned into their complements (REF-minor lists), and with a survivor buffer that overflows; with
     probes no tile row inside the zone is contracted."""
     M = 1500 if not forced else 2200
@@ -165,8 +168,8 @@ def test_probe_pass_equals_dense_and_merges_only(hip, opt, mode, N, forced):
              # them the zone's pairs are still merged and probed (calc -r 0.0009 at N = 1 M: DESIGN 3.5)
              lambda: hip.ld_all(mode, T.Filters(minR2=0.0007), window=T.OPT_R2_SCREEN)[0]]
 
-    def run(lists, probe, cap=0):
-        opt.set("lists", lists); opt.set("probe", probe); opt.set("record_cap", cap)
+    def run(lists, probe, cap=0, probe_zone=1):
+        opt.set("lists", lists); opt.set("probe", probe); opt.set("record_cap", cap); opt.set("probe_zone", probe_zone)
         hip.set_problem(N, M)
         hip.upload(data, util.to_hip_meta(variants), None)
         out = []
@@ -180,8 +183,11 @@ def test_probe_pass_equals_dense_and_merges_only(hip, opt, mode, N, forced):
     merges = run(2 if forced else 1, 0)
     probes = run(2 if forced else 1, 1)
     tiny = run(2 if forced else 1, 1, cap=60)
-    for k, (d, m, p, t) in enumerate(zip(dense, merges, probes, tiny)):
-        assert d[1] > 20 and d[0] == m[0] == p[0] == t[0], (k, d[1], m[1], p[1], t[1])
+    # probes for the columns beyond the zone only: the zone's own pairs are merges of two lists (round 4's first form)
+    outer = run(2 if forced else 1, 1, probe_zone=0)
+    for k, (d, m, p, t, o) in enumerate(zip(dense, merges, probes, tiny, outer)):
+        assert d[1] > 20 and d[0] == m[0] == p[0] == t[0] == o[0], (k, d[1], m[1], p[1], t[1], o[1])
+        assert o[2]["list_pairs"] > p[2]["list_pairs"] and o[2]["probe_pairs"] < p[2]["probe_pairs"], (k, o[2], p[2])
         assert d[2]["list_launches"] == 0 and d[2]["probe_launches"] == 0
         assert m[2]["list_launches"] > 0 and m[2]["probe_launches"] == 0
         assert p[2]["probe_launches"] > 0 and p[2]["probe_pairs"] > 1000, (k, p[2])

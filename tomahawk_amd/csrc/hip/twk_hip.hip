@@ -130,6 +130,7 @@ struct Options {
 	long long band_launch = 1;       // fused runs: launches sized by work (a band of rows, all its columns), not by a count matrix
 	long long band_list_entries = 0; // candidate slots of such a launch (0: a sixteenth of its pairs, 4 M .. 1 G; else exactly this many): small values force its fallback
 	long long band_max_launches = 8; // ... at most this many per region
+	long long probe_zone = 1;        // rows with a list short enough to probe take *every* column behind them that way, the zone's own included (0: zone x zone pairs are list merges)
 	long long band_reverse = 1;      // allele-count-sorted runs: the last band (the commonest variants, most survivors) first
 	long long timeline = 0;          // 1: the host's steps through the launch pipeline of a region, with times, on stderr (measurement)
 	long long band_work_log2 = 19;   // ... and at least 2^n tile-chunks of work per launch (19: ~5 ms); small values make several launches of a small run
@@ -144,7 +145,7 @@ const OptionKey OPTION_KEYS[] = {
 	{"fisher_lds", &Options::fisher_lds, 0, 1, false}, {"cand_chunk", &Options::cand_chunk, -1, 1 << 20, false},
 	{"record_cap", &Options::record_cap, 0, 1ll << 40, false},
 	{"probe", &Options::probe, 0, 1, false}, {"band_launch", &Options::band_launch, 0, 1, false}, {"band_list_entries", &Options::band_list_entries, 0, 1ll << 32, false},
-	{"band_work_log2", &Options::band_work_log2, 0, 40, false}, {"band_max_launches", &Options::band_max_launches, 1, 64, false}, {"timeline", &Options::timeline, 0, 1, false}, {"band_reverse", &Options::band_reverse, 0, 1, false},
+	{"band_work_log2", &Options::band_work_log2, 0, 40, false}, {"band_max_launches", &Options::band_max_launches, 1, 64, false}, {"timeline", &Options::timeline, 0, 1, false}, {"band_reverse", &Options::band_reverse, 0, 1, false}, {"probe_zone", &Options::probe_zone, 0, 1, false},
 };
 }  // namespace
 
@@ -1088,7 +1089,8 @@ int run_probe_block(twk_hip_ctx* c, const twk_hip_filters& f, bool unphased, uin
 	s.row_pairs = 0;
 	for (uint32_t i = row0; i < row0 + n_rows; ++i) {
 		const uint32_t lim = std::min<uint64_t>((uint64_t)col0 + n_cols, cr.hi ? (uint64_t)cr.b0 + cr.hi[i - cr.a0] : (uint64_t)col0 + n_cols);
-		if (lim > col0) s.row_pairs += lim - col0;                // pairs probed (accounting only)
+		const uint32_t first = std::max(col0, i + 1);             // (columns inside the zone: those behind the row)
+		if (lim > first) s.row_pairs += lim - first;              // pairs probed (accounting only)
 	}
 	const uint64_t n_blocks = (uint64_t)p.n_row_blocks * n_cols;
 	if (n_blocks > 0x7FFFFFFFull) return TWK_HIP_E_INVALID;
@@ -1592,11 +1594,18 @@ static int region_impl(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint3
                        uint32_t b0, uint32_t nB, int32_t triangle, uint32_t part, uint32_t n_parts,
                        uint32_t tile_variants, int32_t window, uint32_t l_window, twk_hip_record_sink sink,
                        void* user, uint64_t* n_pairs, uint64_t* n_records) {
+	const auto t_origin = std::chrono::steady_clock::now();
+	auto mark = [&](const char* what, size_t i, unsigned long long x = 0) {       // "timeline" option: where the host's time goes
+		if (!c->opt.timeline) return;
+		fprintf(stderr, "[timeline] %9.3f ms  %s %zu  %llu\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_origin).count(), what, i, x);
+	};
+	mark("region: mode", (size_t)mode, nA);
 	const uint32_t* ids = nullptr;
 	if (mode == MODE_INT_GROUPED || mode == MODE_INT_SORTED_P || mode == MODE_INT_SORTED_U) {
 		const int set = mode == MODE_INT_GROUPED ? PS_GROUPED : mode == MODE_INT_SORTED_P ? PS_SORTED_P : PS_SORTED_U;
 		int rc = ensure_planes(c, set); if (rc) return rc;
 		ids = c->planes[set].h_ids.data();
+		mark("plane set ready", (size_t)set);
 	}
 	// r2 screen (TWK_HIP_OPT_R2_SCREEN): this region is a triangle over the leading, missing-free part of an
 	// allele-count-sorted set.  1: PhasedMath's r2, 2: UnphasedMath's.
@@ -1908,7 +1917,12 @@ static int region_impl(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint3
 		const uint32_t zone = std::min(ps.n_list, nA);
 		if (zone >= 2 && ps.lists) {
 			col_range.list_zone = zone;
-			const uint32_t lr0 = std::min(r0, zone), lr1 = std::min(r1, zone);
+			// rows whose list is short enough to probe with (the first n_probe of the zone) take every column behind them as probes,
+			// the zone's own included ("probe_zone": a probe walks one list and tests bits of the partner's row, a merge walks two
+			// lists in step - 0.28 against 1.05 ns a pair on the unphased zone of the 1 M x 50 k cohort run); the merges are left
+			// with the zone's last rows
+			const uint32_t pz_first = (c->opt.probe && c->opt.probe_zone) ? std::min(ps.n_probe, zone) : 0;
+			const uint32_t lr0 = std::min(std::max(r0, pz_first), zone), lr1 = std::min(r1, zone);
 			uint32_t rows_per = (uint32_t)std::max<uint64_t>(64, std::min<uint64_t>(32768, (1ull << 25) / zone));
 			unsigned long long cap_list = cap_default;
 			for (uint32_t row = lr0; row < lr1;) {
@@ -1921,11 +1935,13 @@ static int region_impl(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint3
 				tot_recs += nrec;
 				row += nr;
 			}
+			mark("carrier-list pass done, zone", zone, tot_recs);
 			// ... and the zone's rows against the columns beyond the zone: probes of the row variant's carriers into the column
 			// variant's row (K1's asymmetric path, ld_engine.cpp:230-242; measured to win for every list the zone keeps,
 			// ld_list.hip.h), so that no tile row inside the zone is contracted at all.
 			const uint32_t pzone = c->opt.probe ? std::min(ps.n_probe, zone) : 0;
-			if (pzone && zone < nB) {
+			const bool zone_cols = c->opt.probe_zone != 0;             // the probes' columns start behind the row, not behind the zone
+			if (pzone && (zone < nB || zone_cols)) {
 				col_range.probe_zone = pzone;
 				unsigned long long cap_probe = cap_default;
 				uint32_t rows_cap = 32768;                                   // halved when a block's survivors outgrow the buffer
@@ -1934,20 +1950,23 @@ static int region_impl(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint3
 					// the columns the block's rows reach (the band limit never decreases along the rows)
 					auto reach = [&](uint32_t last_row) -> uint32_t { return std::min<uint64_t>(nB, col_range.hi ? (uint64_t)col_range.b0 + col_range.hi[last_row - col_range.a0] : nB); };
 					uint32_t nr = std::min<uint32_t>(pr1 - row, rows_cap);
-					while (nr > 256 && (uint64_t)nr * (reach(row + nr - 1) > zone ? reach(row + nr - 1) - zone : 0) > (1ull << 25)) nr = std::max<uint32_t>(256, nr / 2);
+					const uint32_t first = zone_cols ? row + 1 : zone;       // first column of the block (a row's own start at row + 1: the kernel's j > i)
+					while (nr > 256 && (uint64_t)nr * (reach(row + nr - 1) > first ? reach(row + nr - 1) - first : 0) > (1ull << 25)) nr = std::max<uint32_t>(256, nr / 2);
 					const uint32_t lim = reach(row + nr - 1);
-					if (lim <= zone) { row += nr; continue; }
+					if (lim <= first) { row += nr; continue; }
 					unsigned long long nrec = 0;
-					rc = run_probe_block(c, *f, screen == 2, row, nr, zone, zone, lim - zone, window, l_window, col_range, cap_probe, &nrec, !c->device_sink, sink ? sink : discard_records, user);
+					rc = run_probe_block(c, *f, screen == 2, row, nr, zone, first, lim - first, window, l_window, col_range, cap_probe, &nrec, !c->device_sink, sink ? sink : discard_records, user);
 					if (rc == TWK_HIP_E_OVERFLOW && nr > 1) { rows_cap = std::max<uint32_t>(1, nr / 2); continue; }
-					if (rc == TWK_HIP_E_OVERFLOW && cap_probe < (unsigned long long)(lim - zone)) { cap_probe = lim - zone; continue; }
+					if (rc == TWK_HIP_E_OVERFLOW && cap_probe < (unsigned long long)(lim - first)) { cap_probe = lim - first; continue; }
 					if (rc) return rc;
 					tot_recs += nrec;
 					row += nr;
 				}
+				mark("probe pass done, zone", pzone, tot_recs);
 			}
 		}
 	}
+	mark("tiles listed", mine.size());
 	// One matrix-sized tile, synchronously, with its fallbacks: the fused form's candidate list overflowed -> through C (and
 	// the rest of the call as well); more survivors than the buffer holds -> row strips.
 	auto run_tile_with_fallbacks = [&](const twk_hip_tile_desc& t) -> int {
@@ -1976,11 +1995,6 @@ static int region_impl(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint3
 	std::vector<char> skipped(n, 0);
 	// software pipeline over the launches of this shard, PIPE_SLOTS deep
 	size_t math_issued = 0;                    // band launches [0, math_issued) have had the second half of their work enqueued
-	const auto t_origin = std::chrono::steady_clock::now();
-	auto mark = [&](const char* what, size_t i, unsigned long long x = 0) {       // "timeline" option: where the host's time goes
-		if (!c->opt.timeline) return;
-		fprintf(stderr, "[timeline] %9.3f ms  %s %zu  %llu\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_origin).count(), what, i, x);
-	};
 	auto band_math = [&](size_t i) -> int {
 		if (band_of(i) && !skipped[i]) {
 			mark("math: wait for count of launch", i);
@@ -2034,6 +2048,7 @@ static int region_impl(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint3
 			}
 		}
 		tot_pairs += pairs_in_tile(c, mine[done]);
+		if (!b) mark("finished (records delivered) launch", done, tot_recs);
 		++done;
 		if (c->progress_cb && !c->progress_muted) c->progress_cb(c->progress_user, tot_pairs, (uint32_t)done, (uint32_t)n);
 	}

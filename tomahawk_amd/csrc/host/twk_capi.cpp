@@ -61,7 +61,7 @@ int twk_file_write_synthetic_twk(const char* path, uint32_t n_samples, uint32_t 
 	TwkWriter w;
 	if (!w.open(path, hdr, c_level)) return -2;
 	const size_t w64 = ((size_t)2 * n_samples + 63) / 64;
-	const uint32_t T = (uint32_t)std::max(1, n_threads);
+	const uint32_t T = (uint32_t)std::max(1, std::min(n_threads, util::usable_cpus()));
 	for (uint32_t v0 = 0; v0 < n_variants; v0 += block_size) {
 		const uint32_t nb = std::min(block_size, n_variants - v0);
 		Block blk; blk.rid = 0; blk.rcds.resize(nb);
@@ -108,7 +108,7 @@ int twk_file_write_cohort_twk(const char* path, uint32_t n_samples, uint32_t n_v
 	TwkWriter w;
 	if (!w.open(path, hdr, c_level)) return -2;
 	const size_t H = (size_t)2 * n_samples;
-	const uint32_t T = (uint32_t)std::max(1, n_threads);
+	const uint32_t T = (uint32_t)std::max(1, std::min(n_threads, util::usable_cpus()));
 	const uint32_t per_contig = (n_variants + n_contigs - 1) / n_contigs;
 	std::vector<uint8_t> state(H);
 	for (size_t h = 0; h < H; ++h) state[h] = (uint8_t)(cmix(seed ^ (0xA5A5ull << 32) ^ h) % n_founders);
@@ -348,6 +348,10 @@ struct TwoStream {
 	std::unique_ptr<RecordEmitter> emitter;
 };
 }
+// CPUs the host side sizes its thread pools by: hardware threads, cut to the affinity mask and the container's CFS quota
+// (twk_util.h usable_cpus).
+int twk_usable_cpus(void) { return util::usable_cpus(); }
+
 void* twk_two_stream_open(const char* path, uint32_t n_samples, uint32_t n_contigs, const uint32_t* rid, const uint32_t* pos,
                           uint32_t n_variants, int c_level, uint32_t b_size, int n_threads, int map_output) try {
 	if (!path || !rid || !pos || n_variants == 0 || b_size < 2) return nullptr;

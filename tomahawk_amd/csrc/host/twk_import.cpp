@@ -466,7 +466,7 @@ bool twk_variant_importer::Import(void) {
 	};
 
 	// ---- records: read rounds of lines, parse them on T threads, consume in file order ----
-	const int T = std::max(1, settings.n_threads > 0 ? settings.n_threads : (int)std::thread::hardware_concurrency());
+	const int T = std::max(1, std::min(settings.n_threads > 0 ? settings.n_threads : (int)std::thread::hardware_concurrency(), util::usable_cpus()));
 	const size_t round_bytes = 64u << 20;
 	std::vector<std::string> lines, next_lines;
 	std::vector<Site> sites;

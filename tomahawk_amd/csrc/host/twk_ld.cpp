@@ -532,7 +532,8 @@ bool twk_ld::twk_ld_impl::run(twk_ld_settings& settings, const Header& hdr, cons
 	// output workers per GPU: 32 at most - on the 2 x 64-core host of the GPU box the 33 M-survivor run writes its 3.8 GB in
 	// 0.72 s with 32, 0.82 s with 16 and 1.07 s with 64 (the threads' zstd work inflates from 10 to 25 CPU-seconds and the
 	// writer thread's copies slow down by half when every core is busy)
-	int n_workers = std::max(1, std::min(std::max(1, settings.n_threads / n_gpus), 32));
+	// (and never more threads than the process has CPUs - its affinity mask, its container's quota: util::usable_cpus)
+	int n_workers = std::max(1, std::min(std::max(1, std::min(settings.n_threads, util::usable_cpus()) / n_gpus), 32));
 	if (option("emit_workers", 0) > 0) n_workers = (int)std::min<int64_t>(option("emit_workers", 0), 64);      // (measurement: the emitter's worker threads per GPU)
 	const int mode = settings.single ? TWK_HIP_MODE_AUTO
 	               : settings.force_phased ? TWK_HIP_MODE_PHASED : (settings.forced_unphased ? TWK_HIP_MODE_UNPHASED : TWK_HIP_MODE_AUTO);
@@ -756,8 +757,9 @@ bool twk_ld::Compute() {
 	const uint32_t n_parts = n_procs * (uint32_t)n_gpus;
 	RunSpec spec;
 	const auto t_load = clock::now();
-	const uint32_t T = (uint32_t)std::max(1, settings.n_threads);
-	std::cerr << stamp("LOG", "THREAD") << "Unpacking using " << T << " threads..." << std::endl;
+	const uint32_t T = (uint32_t)std::max(1, std::min(settings.n_threads, util::usable_cpus()));
+	std::cerr << stamp("LOG", "THREAD") << "Unpacking using " << T << " threads..."
+	          << (T < (uint32_t)settings.n_threads ? " (of " + std::to_string(settings.n_threads) + " asked for: the process may use " + std::to_string(util::usable_cpus()) + " CPUs)" : std::string()) << std::endl;
 	// Window mode on several GPUs (or processes): a GPU needs only the blocks of its band of rows plus the blocks its
 	// window reaches beyond it (the reference's ticker prunes block pairs the same way, ld_balancing.h:176-203) -
 	// for BASELINE configs[4] that is 75 GB per GPU instead of 500 GB.  Bands are cut at block boundaries with equal

@@ -11,6 +11,8 @@
 #include <thread>
 #include <vector>
 
+#include "twk_util.h"
+
 namespace tomahawk {
 namespace par {
 
@@ -20,7 +22,7 @@ template <class Slot>
 inline bool ordered_parallel(size_t n, int T, const std::function<bool(size_t, Slot&)>& produce,
                       const std::function<bool(size_t, Slot&)>& consume) {
 	if (n == 0) return true;
-	const int hw = (int)std::max(1u, std::thread::hardware_concurrency());
+	const int hw = util::usable_cpus();
 	// more threads than cores only starves the consumer; beyond ~64 the single consumer (file
 	// write) or the memory system is the limit and extra workers cost more than they add
 	T = std::max(1, std::min<int>(std::min(std::min(T, hw), 64), (int)std::min<size_t>(n, 1024)));
@@ -107,7 +109,7 @@ struct SortKey {
 inline void parallel_sort(Raw<SortKey>& k, int T) {
 	const size_t n = k.size();
 	T = std::max(1, std::min<int>(T, (int)(n / 8192 + 1)));
-	T = std::min<int>(T, (int)std::max(1u, std::thread::hardware_concurrency()));
+	T = std::min<int>(T, util::usable_cpus());
 	if (T == 1) { std::stable_sort(k.begin(), k.end()); return; }
 	std::vector<size_t> cut(T + 1);
 	for (int t = 0; t <= T; ++t) cut[t] = n * (size_t)t / T;

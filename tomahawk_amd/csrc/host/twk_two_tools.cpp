@@ -338,7 +338,7 @@ bool two_sort(two_sorter_settings& st) {
 	std::cerr << stamp("LOG") << "Uncompressed size: " << pretty(b_unc) << " b" << std::endl;
 	std::cerr << stamp("LOG") << "Sorting " << pretty(n_recs) << " records..." << std::endl;
 	if (b_unc == 0) { std::cerr << stamp("ERROR") << "Cannot sort empty file..." << std::endl; return false; }
-	const int T = std::max(1, st.n_threads);
+	const int T = std::max(1, std::min(st.n_threads, util::usable_cpus()));
 
 	// Output (two_reader.cpp:313-340)
 	const bool to_stdout = st.out.empty() || st.out == "-";

@@ -1,13 +1,17 @@
 // Small host utilities shared by the CLI-facing translation units: log stamps, pretty numbers,
 // path pieces (reference lib/utility.cpp:68-144) and the command line that ends up in headers.
 #pragma once
+#include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <cstdio>
 #include <ctime>
 #include <iomanip>
+#include <sched.h>
 #include <sstream>
 #include <string>
 #include <sys/time.h>
+#include <thread>
 
 #ifndef TWK_AMD_VERSION
 #define TWK_AMD_VERSION "0.7.0-mi355x"
@@ -55,6 +59,38 @@ inline std::string elapsed_string(double sec) {
 	if (s >= 60) o << (s % 3600) / 60 << "m";
 	o << std::fixed << std::setprecision(3) << (sec - (double)(s / 60 * 60)) << "s";
 	return o.str();
+}
+
+// CPUs this process may really use: the hardware's threads, cut down to the scheduler affinity mask and to the
+// container's CFS quota (cgroup v2 cpu.max, v1 cpu.cfs_quota_us / cpu.cfs_period_us).  Thread pools sized beyond it gain
+// nothing and lose a lot: when the quota of a period is spent, *every* thread of the container is frozen until the next
+// period - the one that feeds the GPU with launches included.  (The GPU boxes of this pool have 256 hardware threads and
+// a quota of 16 CPUs: 16 emitter threads compress 3.95 GB in 6.3 CPU-seconds, 64 threads in 19.8-34 "CPU-seconds" of
+// which most is waiting for the next period - profiles/r04_output_floor.txt.)
+inline int usable_cpus() {
+	static const int cached = [] {
+		int n = (int)std::max(1u, std::thread::hardware_concurrency());
+		cpu_set_t set;
+		if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int a = CPU_COUNT(&set); if (a > 0) n = std::min(n, a); }
+		auto read_two = [](const char* path, long long& a, long long& b) -> int {
+			FILE* f = fopen(path, "r");
+			if (!f) return 0;
+			char w1[64] = {0}, w2[64] = {0};
+			const int got = fscanf(f, "%63s %63s", w1, w2);
+			fclose(f);
+			if (got >= 1) a = (w1[0] == 'm') ? -1 : atoll(w1);      // "max"
+			if (got >= 2) b = atoll(w2);
+			return got;
+		};
+		long long quota = -1, period = 0, dummy = 0;
+		if (read_two("/sys/fs/cgroup/cpu.max", quota, period) < 2) {
+			quota = -1; period = 0;
+			if (read_two("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", quota, dummy) >= 1) read_two("/sys/fs/cgroup/cpu/cpu.cfs_period_us", period, dummy);
+		}
+		if (quota > 0 && period > 0) n = std::min<long long>(n, std::max<long long>(1, (quota + period - 1) / period));
+		return std::max(1, n);
+	}();
+	return cached;
 }
 
 }  // namespace util

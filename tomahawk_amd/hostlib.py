@@ -161,6 +161,11 @@ def import_vcf(path_in, path_out, threshold_miss=0.9, hwe=0.0, remove_univariate
     return dict(zip(IMPORT_COUNTERS, (int(x) for x in cnt)))
 
 
+def usable_cpus() -> int:
+    """CPUs the host side sizes its thread pools by (hardware threads, affinity mask, the container's CFS quota)."""
+    return int(lib().twk_usable_cpus())
+
+
 def hwe_exact(hom1, het, hom2):
     return float(lib().twk_hwe_exact(hom1, het, hom2))
 
