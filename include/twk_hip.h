@@ -294,6 +294,8 @@ int twk_hip_fisher_exact(twk_hip_ctx* ctx, const int32_t* tables, uint64_t n, do
  *                               at most 8 per region, at least ~5 ms of work each) instead of by a count matrix; 0: matrix-sized tiles only
  *   "band_work_log2"   19       ... of at least 2^n tile-chunks each (19: about 5 ms of contraction)
  *   "band_max_launches" 8       ... and at most this many per region
+ *   "probe_zone"       1        rows with a list short enough to probe take every column behind them that way, the list
+ *                               zone's own included (0: pairs inside the zone are merges of two lists)
  *   "band_reverse"     1        allele-count-sorted runs: the last band (commonest variants, most survivors) first
  *   "timeline"         0        1: the host's steps through a region's launch pipeline, with times, on stderr
  *   "band_list_entries" 0       candidate slots of such a launch (0: 1/32 of its pairs, 4 M .. 256 M); a launch that
