@@ -198,6 +198,7 @@ def run_cli(twk, flags, threads, out):
     eng = re.search(r"count kernel ([0-9.e+]+) ms in (\d+) launches \(([0-9.e+-]+) % [^)]*\), math kernels ([0-9.e+]+) ms", lg)
     mhz = re.search(r"its blocks ran at (\d+) MHz", lg)
     lst = re.search(r"carrier-list kernel ([0-9.e+]+) ms in (\d+) launches over ([0-9,]+) rare pairs", lg)
+    prb = re.search(r"probe kernel ([0-9.e+]+) ms in (\d+) launches over ([0-9,]+) rare x common pairs", lg)
     fus = re.search(r"(\d+) launches fused count -> r2 screen, ([0-9,]+) candidate", lg)
     wri = re.search(r"the producer spent ([0-9.e+-]+) s handing", lg)
     pairs = int(fin.group(2).replace(",", "")) if fin else None
@@ -217,6 +218,8 @@ def run_cli(twk, flags, threads, out):
            "shader_mhz": int(mhz.group(1)) if mhz else None,
            "list_kernel_ms": float(lst.group(1)) if lst else None,
            "pairs_decided_by_carrier_lists": int(lst.group(3).replace(",", "")) if lst else None,
+           "probe_kernel_ms": float(prb.group(1)) if prb else None,
+           "pairs_decided_by_probes": int(prb.group(3).replace(",", "")) if prb else None,
            "fused_launches": int(fus.group(1)) if fus else 0,
            "producer_handover_s": float(wri.group(1)) if wri else None,
            # the wall outside the log's phases: process start -> first log line, last log line -> exit (runtime teardown)
