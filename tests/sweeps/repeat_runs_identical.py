@@ -6,6 +6,8 @@ t1 = "/tmp/kg_2504_60k.twk"
 if not os.path.exists(t1): H.write_cohort_twk(t1, 2504, 60_000, seed=12, n_threads=64, block_size=500, spacing=100)
 cases.append((t1, ["-p", "-w", "1000000", "-t", "64"], 12))
 cases.append((t1, ["-w", "300000", "-t", "17"], 10))
+cases.append((t1, ["-p", "-r", "0.05", "-t", "64"], 8))        # all pairs: band launches last band first, the hand-off queue
+cases.append((t1, ["-u", "-r", "0.2", "-t", "64"], 6))
 t2 = "/tmp/c5k.twk"
 if not os.path.exists(t2): H.write_cohort_twk(t2, 300_000, 6000, seed=11, n_threads=64, block_size=128)
 cases.append((t2, ["-t", "64"], 15))
