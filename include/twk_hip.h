@@ -296,6 +296,7 @@ int twk_hip_fisher_exact(twk_hip_ctx* ctx, const int32_t* tables, uint64_t n, do
  *   "band_max_launches" 8       ... and at most this many per region
  *   "probe_zone"       1        rows with a list short enough to probe take every column behind them that way, the list
  *                               zone's own included (0: pairs inside the zone are merges of two lists)
+ *   "probe_unroll"     4        list entries the unphased probe kernel takes at a time (1, 2, 4: their loads in flight together)
  *   "band_reverse"     1        allele-count-sorted runs: the last band (commonest variants, most survivors) first
  *   "timeline"         0        1: the host's steps through a region's launch pipeline, with times, on stderr
  *   "band_list_entries" 0       candidate slots of such a launch (0: 1/32 of its pairs, 4 M .. 256 M); a launch that

@@ -188,16 +188,18 @@ void k_list_screen_unphased(const ListWork w, uint32_t n_samples) {
 		const uint32_t* b = w.lists + (size_t)j * w.stride;
 		const uint32_t na = w.mac[i], nb = w.mac[j];
 		uint32_t ia = 0, ib = 0, va = a[0], vb = b[0];
-		unsigned long long x = 0;                      // four 16-bit counters: [gA][gB] at bit 16 * (2 gA + gB)
+		uint32_t xa0 = 0, xa1 = 0;                     // four 16-bit counters [gA][gB], two to a word (no 64-bit shifts: see k_probe_screen_unphased_t)
 		while (ia < na && ib < nb) {
 			const uint32_t sa = va >> 1, sb = vb >> 1;
-			if (sa == sb) x += 1ull << (16u * (((va & 1u) << 1) | (vb & 1u)));
+			const uint32_t inc = (sa == sb) ? (1u << (16u * (vb & 1u))) : 0u;
+			xa0 += (va & 1u) ? 0u : inc;
+			xa1 += (va & 1u) ? inc : 0u;
 			const bool fa = sa <= sb, fb = sb <= sa;
 			ia += fa; ib += fb;
 			if (fa) va = a[ia];
 			if (fb) vb = b[ib];
 		}
-		const uint32_t x00 = (uint32_t)(x & 0xFFFFu), x01 = (uint32_t)((x >> 16) & 0xFFFFu), x10 = (uint32_t)((x >> 32) & 0xFFFFu), x11 = (uint32_t)(x >> 48);
+		const uint32_t x00 = xa0 & 0xFFFFu, x01 = xa0 >> 16, x10 = xa1 & 0xFFFFu, x11 = xa1 >> 16;
 		const uint32_t hA = w.rowpop[2 * i], qA = w.rowpop[2 * i + 1], hB = w.rowpop[2 * j], qB = w.rowpop[2 * j + 1];
 		const bool fA = w.flip[i] != 0, fB = w.flip[j] != 0;
 		const uint32_t rA = fA ? n_samples - hA - qA : qA, rB = fB ? n_samples - hB - qB : qB;      // rare homozygotes (listed with g = 1)
@@ -290,8 +292,9 @@ void k_probe_screen(const ProbeWork p) {
 
 // UnphasedMath: the list holds A's samples that are not homozygous for its major allele as (sample << 1) | g (g = 0: het,
 // g = 1: the rare homozygote - hom-alt, or hom-ref when flip); the column is its H (het) and Q (hom-alt) plane rows.
+template <int UNROLL>
 __global__ __launch_bounds__(256)
-void k_probe_screen_unphased(const ProbeWork p, uint32_t n_samples) {
+void k_probe_screen_unphased_t(const ProbeWork p, uint32_t n_samples) {
 	const ListWork& w = p.lw;
 	const uint32_t cb = blockIdx.x / p.n_row_blocks, rb = blockIdx.x - cb * p.n_row_blocks;
 	const uint32_t i = w.row0 + rb * 256 + threadIdx.x, j = p.col0 + cb;
@@ -304,16 +307,35 @@ void k_probe_screen_unphased(const ProbeWork p, uint32_t n_samples) {
 			const uint32_t* H = p.rows + (size_t)(2 * j) * p.W;
 			const uint32_t* Q = H + p.W;
 			const uint32_t na = w.mac[i];
-			unsigned long long x = 0;                      // four 16-bit counters: [gA][class of B: 0 het, 1 hom-alt] at bit 16 * (2 gA + class)
-			// (A form of this loop that takes four entries at a time - twelve loads in flight - ran the probes of the 1 M x 50 k cohort
-			// run 28 % faster and, on the GPU box, gave one column per run wrong counts, a different column every run; its ISA reads
-			// correctly and the phased kernel's passed every test.  Not understood, so neither kernel uses it.)
-			for (uint32_t k = 0; k < na; ++k) {
-				const uint32_t e = a[k], sm = e >> 1, g = e & 1u;
-				const uint32_t hb = (H[sm >> 5] >> (sm & 31u)) & 1u, qb = (Q[sm >> 5] >> (sm & 31u)) & 1u;
-				x += ((unsigned long long)hb << (32u * g)) + ((unsigned long long)qb << (32u * g + 16u));
+			// Four 16-bit counters [gA][class of B: 0 het, 1 hom-alt], two to a 32-bit word: x0 for A's hets, x1 for its rare
+			// homozygotes.  (Not one 64-bit word shifted by 16 * (2 gA + class): a v_lshlrev_b64 whose shift amount the register
+			// allocator happens to put into the *last VGPR the wave owns* gives wrong results on the MI355X boxes of this pool - the
+			// "shift64 high register" erratum LLVM works around for gfx90a only.  Found when an unrolled form of this loop moved the
+			// amount into v31 of 32 / v47 of 48 and one group of rows per run came out wrong; tests/test_build.py scans every
+			// kernel of the library for that pattern.)
+			uint32_t x0 = 0, x1 = 0;
+			auto tally = [&](uint32_t e, uint32_t hw, uint32_t qw) {
+				const uint32_t sm = (e >> 1) & 31u;
+				const uint32_t add = ((hw >> sm) & 1u) | (((qw >> sm) & 1u) << 16);
+				x0 += (e & 1u) ? 0u : add;
+				x1 += (e & 1u) ? add : 0u;
+			};
+			// UNROLL list entries at a time: their probes do not depend on each other, and with the loads of four entries in flight
+			// a lane waits for memory once where it waited four times (the probes of the 1 M x 50 k cohort run: 314 -> 227 ms)
+			uint32_t k = 0;
+			if (UNROLL > 1) {
+				for (; k + UNROLL <= na; k += UNROLL) {
+					uint32_t e[UNROLL], hw[UNROLL], qw[UNROLL];
+#pragma unroll
+					for (int u = 0; u < UNROLL; ++u) e[u] = a[k + u];
+#pragma unroll
+					for (int u = 0; u < UNROLL; ++u) { hw[u] = H[e[u] >> 6]; qw[u] = Q[e[u] >> 6]; }
+#pragma unroll
+					for (int u = 0; u < UNROLL; ++u) tally(e[u], hw[u], qw[u]);
+				}
 			}
-			const uint32_t x0h = (uint32_t)(x & 0xFFFFu), x0q = (uint32_t)((x >> 16) & 0xFFFFu), x1h = (uint32_t)((x >> 32) & 0xFFFFu), x1q = (uint32_t)(x >> 48);
+			for (; k < na; ++k) { const uint32_t e = a[k]; tally(e, H[e >> 6], Q[e >> 6]); }
+			const uint32_t x0h = x0 & 0xFFFFu, x0q = x0 >> 16, x1h = x1 & 0xFFFFu, x1q = x1 >> 16;
 			const uint32_t hA = w.rowpop[2 * i], qA = w.rowpop[2 * i + 1], hB = w.rowpop[2 * j], qB = w.rowpop[2 * j + 1];
 			HH = x0h; HQ = x0q;
 			if (!w.flip[i]) { QH = x1h; QQ = x1q; }                                   // A's hom-alt samples are the listed rare homozygotes

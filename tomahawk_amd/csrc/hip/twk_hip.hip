@@ -130,6 +130,7 @@ struct Options {
 	long long band_launch = 1;       // fused runs: launches sized by work (a band of rows, all its columns), not by a count matrix
 	long long band_list_entries = 0; // candidate slots of such a launch (0: a sixteenth of its pairs, 4 M .. 1 G; else exactly this many): small values force its fallback
 	long long band_max_launches = 8; // ... at most this many per region
+	long long probe_unroll = 4;      // list entries the unphased probe kernel takes at a time (1, 2, 4: their loads in flight together; ld_list.hip.h)
 	long long probe_zone = 1;        // rows with a list short enough to probe take *every* column behind them that way, the zone's own included (0: zone x zone pairs are list merges)
 	long long band_reverse = 1;      // allele-count-sorted runs: the last band (the commonest variants, most survivors) first
 	long long timeline = 0;          // 1: the host's steps through the launch pipeline of a region, with times, on stderr (measurement)
@@ -145,7 +146,7 @@ const OptionKey OPTION_KEYS[] = {
 	{"fisher_lds", &Options::fisher_lds, 0, 1, false}, {"cand_chunk", &Options::cand_chunk, -1, 1 << 20, false},
 	{"record_cap", &Options::record_cap, 0, 1ll << 40, false},
 	{"probe", &Options::probe, 0, 1, false}, {"band_launch", &Options::band_launch, 0, 1, false}, {"band_list_entries", &Options::band_list_entries, 0, 1ll << 32, false},
-	{"band_work_log2", &Options::band_work_log2, 0, 40, false}, {"band_max_launches", &Options::band_max_launches, 1, 64, false}, {"timeline", &Options::timeline, 0, 1, false}, {"band_reverse", &Options::band_reverse, 0, 1, false}, {"probe_zone", &Options::probe_zone, 0, 1, false},
+	{"band_work_log2", &Options::band_work_log2, 0, 40, false}, {"band_max_launches", &Options::band_max_launches, 1, 64, false}, {"timeline", &Options::timeline, 0, 1, false}, {"band_reverse", &Options::band_reverse, 0, 1, false}, {"probe_zone", &Options::probe_zone, 0, 1, false}, {"probe_unroll", &Options::probe_unroll, 1, 4, false},
 };
 }  // namespace
 
@@ -1096,7 +1097,9 @@ int run_probe_block(twk_hip_ctx* c, const twk_hip_filters& f, bool unphased, uin
 	if (n_blocks > 0x7FFFFFFFull) return TWK_HIP_E_INVALID;
 	HIPCHK(c, hipEventRecord(s.ev_c0, c->s_compute));
 	if (s.row_pairs) {
-		if (unphased) hipLaunchKernelGGL(k_probe_screen_unphased, dim3((uint32_t)n_blocks), dim3(256), 0, c->s_compute, p, c->N);
+		if (unphased && c->opt.probe_unroll == 4) hipLaunchKernelGGL(k_probe_screen_unphased_t<4>, dim3((uint32_t)n_blocks), dim3(256), 0, c->s_compute, p, c->N);
+		else if (unphased && c->opt.probe_unroll == 2) hipLaunchKernelGGL(k_probe_screen_unphased_t<2>, dim3((uint32_t)n_blocks), dim3(256), 0, c->s_compute, p, c->N);
+		else if (unphased) hipLaunchKernelGGL(k_probe_screen_unphased_t<1>, dim3((uint32_t)n_blocks), dim3(256), 0, c->s_compute, p, c->N);
 		else hipLaunchKernelGGL(k_probe_screen, dim3((uint32_t)n_blocks), dim3(256), 0, c->s_compute, p);
 		HIPCHK(c, hipGetLastError());
 	}
