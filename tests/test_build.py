@@ -54,7 +54,8 @@ def test_no_kernel_shifts_64_bits_by_an_amount_in_its_last_vgpr(tmp_path):
     """On the MI355X boxes of this pool a 64-bit shift whose amount the register allocator puts into the last VGPR a wave owns
     returns wrong results (the "shift64 high register" erratum; LLVM works around it for gfx90a only).  It cost round 4 an
     afternoon: an unrolled unphased probe loop had its amount in v31 of 32 (v47 of 48) and gave one group of rows per run wrong
-    counts, while every form that kept the amount elsewhere was right (ld_list.hip.h).  The kernels that shifted
+    counts, while every form that kept the amount elsewhere was right (ld_list.hip.h; stand-alone reproducer:
+    csrc/tools/shift64_probe.hip, profiles/r04_shift64_probe.txt - 88 % of a million lanes wrong).  The kernels that shifted
     64-bit counters by a variable now use 32-bit ones; this test compiles the library's device code the way `make hip` does
     and looks at every kernel for the pattern, so that a later change (or a later compiler) cannot bring it back unseen."""
     out = str(tmp_path / "twk_hip.s")
