@@ -279,7 +279,13 @@ void k_probe_screen(const ProbeWork p) {
 			const uint32_t* row = p.rows + (size_t)j * p.W;
 			const uint32_t na = w.mac[i];
 			uint32_t x = 0;
-			for (uint32_t k = 0; k < na; ++k) { const uint32_t h = a[k]; x += (row[h >> 5] >> (h & 31u)) & 1u; }
+			uint32_t k = 0;
+			for (; k + 4 <= na; k += 4) {                  // four entries' loads in flight together (see k_probe_screen_unphased_t)
+				const uint32_t h0 = a[k], h1 = a[k + 1], h2 = a[k + 2], h3 = a[k + 3];
+				const uint32_t r0 = row[h0 >> 5], r1 = row[h1 >> 5], r2 = row[h2 >> 5], r3 = row[h3 >> 5];
+				x += ((r0 >> (h0 & 31u)) & 1u) + ((r1 >> (h1 & 31u)) & 1u) + ((r2 >> (h2 & 31u)) & 1u) + ((r3 >> (h3 & 31u)) & 1u);
+			}
+			for (; k < na; ++k) { const uint32_t h = a[k]; x += (row[h >> 5] >> (h & 31u)) & 1u; }
 			const uint32_t acA = w.rowpop[i], acB = w.rowpop[j];
 			aa = w.flip[i] ? acB - x : x;                  // the list holds the carriers of A's minor allele: ALT, or (flip) REF - then ALT_A & ALT_B = ALT_B minus those
 			const double da = (double)acA, db = (double)acB;
