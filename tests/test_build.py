@@ -63,7 +63,8 @@ def test_no_kernel_shifts_64_bits_by_an_amount_in_its_last_vgpr(tmp_path):
     flags = re.search(r"^HIPFLAGS\s*:=\s*(.*)$", make, re.M).group(1).replace("$(ARCH)", "gfx950").split()
     flags = [f for f in flags if f not in ("-fPIC",)]
     r = subprocess.run([HIPCC] + flags + ["-Iinclude", "-S", "--cuda-device-only", "-o", out, "tomahawk_amd/csrc/hip/twk_hip.hip"],
-                       cwd=ROOT, capture_output=True, text=True, timeout=900)
+                       cwd=ROOT, capture_output=True, text=True, timeout=900,
+                       env={k: v for k, v in os.environ.items() if k not in ("LD_PRELOAD", "ASAN_OPTIONS", "UBSAN_OPTIONS")})
     assert r.returncode == 0, r.stderr[-2000:]
     asm = open(out).read()
     hits, counts = shift64_amount_in_the_last_vgpr(asm)

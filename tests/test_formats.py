@@ -323,7 +323,8 @@ def test_record_emitter_and_hand_off_queue_are_clean_under_tsan():
     blocks, the mapped output and the hand-off queue (RecordHandOff, what `tomahawk calc` puts between the engine's thread
     and the emitter); a data race fails the run (halt_on_error), so does a record count that is off."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run(["make", "-C", root, "tsan"], capture_output=True, text=True, timeout=600)
+    env = {k: v for k, v in os.environ.items() if k not in ("LD_PRELOAD", "ASAN_OPTIONS", "UBSAN_OPTIONS")}     # (`make asan-test` preloads another sanitiser's runtime)
+    r = subprocess.run(["make", "-C", root, "tsan"], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
     assert "24 configurations, 0 bad" in r.stdout
 
