@@ -84,7 +84,8 @@ def cpu_baseline(n_samples, mode, seed, log):
     from tomahawk_amd import hostlib
     # 32 threads maximise the reference on the 256-thread GPU-box host (tests/sweeps/cpu_baseline_threads.py,
     # profiles/r02_cpu_baseline_threads.txt: 223 k pairs/s at 32 threads, 203 k at 64, 187 k at 128, 137 k at 256 -
-    # its block-pair ticket is a spinlock and its output path a second one)
+    # its block-pair ticket is a spinlock and its output path a second one - and, found in round 4, the container has a CFS
+    # quota of 16 CPUs: what those thread counts share; `host_cpus_usable` in the result says so)
     cores = min(os.cpu_count() or 1, 32)
     if not O.have_ref():
         return None

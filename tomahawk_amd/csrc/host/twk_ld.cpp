@@ -529,9 +529,7 @@ bool twk_ld::twk_ld_impl::run(twk_ld_settings& settings, const Header& hdr, cons
 	out.c_level = settings.c_level; out.rid = rid.data(); out.pos = pos.data(); out.n_variants = rid.size(); out.n_records = 0;
 	n_records = 0; n_pairs = 0;
 	const int n_gpus = (int)ctxs.size();
-	// output workers per GPU: 32 at most - on the 2 x 64-core host of the GPU box the 33 M-survivor run writes its 3.8 GB in
-	// 0.72 s with 32, 0.82 s with 16 and 1.07 s with 64 (the threads' zstd work inflates from 10 to 25 CPU-seconds and the
-	// writer thread's copies slow down by half when every core is busy)
+	// output workers per GPU: 32 at most (beyond that the one placing step and the memory system are the limit)
 	// (and never more threads than the process has CPUs - its affinity mask, its container's quota: util::usable_cpus)
 	int n_workers = std::max(1, std::min(std::max(1, std::min(settings.n_threads, util::usable_cpus()) / n_gpus), 32));
 	if (option("emit_workers", 0) > 0) n_workers = (int)std::min<int64_t>(option("emit_workers", 0), 64);      // (measurement: the emitter's worker threads per GPU)
