@@ -317,8 +317,8 @@ void k_probe_screen_unphased_t(const ProbeWork p, uint32_t n_samples) {
 			// homozygotes.  (Not one 64-bit word shifted by 16 * (2 gA + class): a v_lshlrev_b64 whose shift amount the register
 			// allocator happens to put into the *last VGPR the wave owns* gives wrong results on the MI355X boxes of this pool - the
 			// "shift64 high register" erratum LLVM works around for gfx90a only.  Found when an unrolled form of this loop moved the
-			// amount into v31 of 32 / v47 of 48 and one group of rows per run came out wrong; tests/test_build.py scans every
-			// kernel of the library for that pattern.)
+			// amount into v31 of 32 / v47 of 48 and one group of rows per run came out wrong; csrc/tools/shift64_probe.hip reproduces
+			// it with three instructions, tests/test_build.py scans every kernel of the library for the pattern.)
 			uint32_t x0 = 0, x1 = 0;
 			auto tally = [&](uint32_t e, uint32_t hw, uint32_t qw) {
 				const uint32_t sm = (e >> 1) & 31u;
@@ -327,7 +327,7 @@ void k_probe_screen_unphased_t(const ProbeWork p, uint32_t n_samples) {
 				x1 += (e & 1u) ? add : 0u;
 			};
 			// UNROLL list entries at a time: their probes do not depend on each other, and with the loads of four entries in flight
-			// a lane waits for memory once where it waited four times (the probes of the 1 M x 50 k cohort run: 314 -> 227 ms)
+			// a lane waits for memory once where it waited four times (the probes of the 1 M x 50 k cohort run: 314 -> 230 ms)
 			uint32_t k = 0;
 			if (UNROLL > 1) {
 				for (; k + UNROLL <= na; k += UNROLL) {
