@@ -366,7 +366,7 @@ void* twk_two_stream_open(const char* path, uint32_t n_samples, uint32_t n_conti
 	if (map_output) (void)st->out.writer.map_output();       // (0: through a stream also where the file could be mapped - A/B runs and tests of both paths)
 	st->out.b_size = b_size; st->out.c_level = c_level > 0 ? c_level : 1;
 	st->out.rid = st->rid.data(); st->out.pos = st->pos.data(); st->out.n_variants = st->rid.size();
-	st->emitter.reset(new RecordEmitter(st->out, n_threads > 0 ? n_threads : 1));
+	st->emitter.reset(new RecordEmitter(st->out, n_threads > 0 ? std::min(n_threads, util::usable_cpus()) : 1));
 	return st.release();
 } catch (...) { return nullptr; }
 
