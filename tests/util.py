@@ -36,8 +36,11 @@ EXEMPTION_CAPS = {"floor:D": 3e-4, "floor:Dprime": 3e-4, "floor:R": 3e-4, "floor
 
 def exemption_summary():
     """Session totals + whether every kind stays under its cap -> (dict, list of violations)."""
-    out = {"compared": dict(COMPARED), "exemptions": dict(EXEMPTIONS), "rates": {}, "caps": dict(EXEMPTION_CAPS)}
+    out = {"compared": dict(COMPARED), "exemptions": dict(EXEMPTIONS), "rates": {}, "caps": dict(EXEMPTION_CAPS),
+           "largest_floor": {"dx_f11_scale": LARGEST_FLOOR["dx"], "ceiling": DX_CEILING}}
     bad = []
+    if LARGEST_FLOOR["dx"] > DX_CEILING:
+        bad.append(f"largest cubic floor granted {LARGEST_FLOOR['dx']:.3g} > ceiling {DX_CEILING:g}")
     for kind, cap in EXEMPTION_CAPS.items():
         denom = COMPARED["records"] if kind in ("p-floor", "p-denormal", "tie:fisher-stop") else COMPARED["cubic"]
         rate = EXEMPTIONS[kind] / denom if denom else 0.0
@@ -243,6 +246,14 @@ def double_root_vetter(data, mask, variants, n_samples):
 # genotypes pass double_root=double_root_vetter(...); without it only D_FLOOR applies.
 D_FLOOR = 1e-14
 ROOT_ERROR_FACTOR = 4.0
+# ... and never more than DX_CEILING, however badly conditioned the cubic: root_error() grows without bound as the slope at
+# the root goes to zero (a double root: dx = inf), and an unbounded floor would accept any device value exactly where the
+# trigonometric solver is most likely to be wrong.  2e-10 on f11's scale is forty times the largest deviation of any cubic
+# record seen so far (4.3e-12, profiles/r04_parity_sweeps.txt) and below the fixed floor of round 3 (D 5e-11 x 4); a
+# pair that needs more is a double-root pair and has to go through the explicit vetter (counted, capped).  The largest floor
+# a session actually granted is written to parity_exemptions.json ("largest_floor") and held to the same ceiling there.
+DX_CEILING = 2e-10
+LARGEST_FLOOR = {"dx": 0.0}          # largest dx (f11 scale) behind a floor that a comparison actually needed
 
 
 def cubic_floors(cnt, r, dx):
@@ -339,7 +350,7 @@ def assert_records_match(gpu_recs, orc_recs, variants, n_samples=None, rtol=1e-6
         else:
             dx = D_FLOOR
             if root_error is not None and total > 0:
-                dx = max(dx, ROOT_ERROR_FACTOR * root_error(k[0], k[1], float(w["cnt"][0]) / total)[0])
+                dx = min(max(dx, ROOT_ERROR_FACTOR * root_error(k[0], k[1], float(w["cnt"][0]) / total)[0]), DX_CEILING)
             cf = cubic_floors([float(x) for x in w["cnt"]], w["R"], dx)
             cnt_floor = cf["cnt"]
             floors = dict(D=cf["D"], Dprime=cf["Dprime"], R=cf["R"], R2=cf["R2"], ChiSqFisher=cf["ChiSqFisher"], ChiSqModel=0.0)
@@ -355,6 +366,8 @@ def assert_records_match(gpu_recs, orc_recs, variants, n_samples=None, rtol=1e-6
                 bad.append((k, f, float(g[f]), float(w[f])))
             elif atol and not np.isclose(g[f], w[f], rtol=rtol, atol=0.0):
                 used["floor:" + f] += 1
+                if count and f == "D":
+                    LARGEST_FLOOR["dx"] = max(LARGEST_FLOOR["dx"], float(atol))
         # Fisher P underflows to exactly 0 for strong associations: absolute floor.
         # UnphasedMath runs Fisher on round(expected counts) (ld_engine.cpp:1656).  The expected counts
         # are only as good as the cubic root (above), so when one of them lies within that error of a

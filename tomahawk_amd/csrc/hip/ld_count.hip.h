@@ -345,6 +345,86 @@ __device__ __forceinline__ void contract_half(uint32_t (&acc)[8][TB], int u, con
 	           a[0].y, a[1].y, a[2].y, a[3].y, a[4].y, a[5].y, a[6].y, a[7].y, b.y);
 }
 
+// ---- three-product form for the plain unphased planes (rows H, Q of a variant; PAIRED lane rows) ----------------
+// What UnphasedMath's r2 screen reads of a pair is HH = popc(H_A & H_B) and S = QH + HQ + 2 QQ (ScreenCountsUnphased below,
+// d_unphased_math), not the four products one by one, and with C = H | Q (the carriers)
+//     S = popc(Q_A & C_B) + popc(C_A & Q_B)            (H and Q are disjoint: Q_A & C_B = QH + QQ, C_A & Q_B = HQ + QQ)
+// - three AND+popcounts per word and variant pair into two accumulators (v_bcnt adds, so both halves of S land in one
+// register) instead of four into four.  The reference does the like in its list kernel: one popcount, the other cells from
+// the margins (ld_engine.cpp:244-246).  C is formed in registers behind the LDS read: 4 + 2 v_or per word for the lane's
+// 4 x 2 variant pairs, 12 cycles next to the 24 x 6 of the products (the planes in HBM and the LDS image stay what they are).
+// Only pairs that pass the screen need HQ, QH and QQ themselves: k_recount_unphased (below) counts those few from their rows.
+// One B variant against the lane's four A variants, one word: hh[s] += popc(hA[s] & hB), ss[s] += popc(qA[s] & cB) +
+// popc(cA[s] & qB) with cB = hB | qB formed here; same (AND, s_nop, BCNT) issue pattern as and_bcnt8v.
+__device__ __forceinline__ void and_bcnt12v(uint32_t& hh0, uint32_t& hh1, uint32_t& hh2, uint32_t& hh3,
+                                            uint32_t& ss0, uint32_t& ss1, uint32_t& ss2, uint32_t& ss3,
+                                            uint32_t h0, uint32_t h1, uint32_t h2, uint32_t h3,
+                                            uint32_t q0, uint32_t q1, uint32_t q2, uint32_t q3,
+                                            uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t hb, uint32_t qb) {
+	uint32_t t0, t1, cb;
+	asm volatile("v_or_b32 %10, %23, %24\n\t"
+	    "v_and_b32 %8, %11, %23\n\t"
+	    "s_nop 0\n\t"
+	    "v_bcnt_u32_b32 %0, %8, %0\n\t"
+	    "v_and_b32 %9, %12, %23\n\t"
+	    "s_nop 0\n\t"
+	    "v_bcnt_u32_b32 %1, %9, %1\n\t"
+	    "v_and_b32 %8, %13, %23\n\t"
+	    "s_nop 0\n\t"
+	    "v_bcnt_u32_b32 %2, %8, %2\n\t"
+	    "v_and_b32 %9, %14, %23\n\t"
+	    "s_nop 0\n\t"
+	    "v_bcnt_u32_b32 %3, %9, %3\n\t"
+	    "v_and_b32 %8, %15, %10\n\t"
+	    "s_nop 0\n\t"
+	    "v_bcnt_u32_b32 %4, %8, %4\n\t"
+	    "v_and_b32 %9, %16, %10\n\t"
+	    "s_nop 0\n\t"
+	    "v_bcnt_u32_b32 %5, %9, %5\n\t"
+	    "v_and_b32 %8, %17, %10\n\t"
+	    "s_nop 0\n\t"
+	    "v_bcnt_u32_b32 %6, %8, %6\n\t"
+	    "v_and_b32 %9, %18, %10\n\t"
+	    "s_nop 0\n\t"
+	    "v_bcnt_u32_b32 %7, %9, %7\n\t"
+	    "v_and_b32 %8, %19, %24\n\t"
+	    "s_nop 0\n\t"
+	    "v_bcnt_u32_b32 %4, %8, %4\n\t"
+	    "v_and_b32 %9, %20, %24\n\t"
+	    "s_nop 0\n\t"
+	    "v_bcnt_u32_b32 %5, %9, %5\n\t"
+	    "v_and_b32 %8, %21, %24\n\t"
+	    "s_nop 0\n\t"
+	    "v_bcnt_u32_b32 %6, %8, %6\n\t"
+	    "v_and_b32 %9, %22, %24\n\t"
+	    "s_nop 0\n\t"
+	    "v_bcnt_u32_b32 %7, %9, %7"
+	    : "+v"(hh0), "+v"(hh1), "+v"(hh2), "+v"(hh3), "+v"(ss0), "+v"(ss1), "+v"(ss2), "+v"(ss3), "=&v"(t0), "=&v"(t1), "=&v"(cb)
+	    : "v"(h0), "v"(h1), "v"(h2), "v"(h3), "v"(q0), "v"(q1), "v"(q2), "v"(q3), "v"(c0), "v"(c1), "v"(c2), "v"(c3), "v"(hb), "v"(qb));
+}
+// The carriers of the lane's four A variants, one word (volatile: keeps its place in front of the products that read them).
+__device__ __forceinline__ void or4v(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t h0, uint32_t q0, uint32_t h1, uint32_t q1,
+                                     uint32_t h2, uint32_t q2, uint32_t h3, uint32_t q3) {
+	asm volatile("v_or_b32 %0, %4, %5\n\tv_or_b32 %1, %6, %7\n\tv_or_b32 %2, %8, %9\n\tv_or_b32 %3, %10, %11"
+	    : "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(c3) : "v"(h0), "v"(q0), "v"(h1), "v"(q1), "v"(h2), "v"(q2), "v"(h3), "v"(q3));
+}
+// One half-slot (two words) of the three-product form.  a[2s] / a[2s + 1]: the H / Q words of the lane's A variant s, b[2v] /
+// b[2v + 1] of its B variant v (PAIRED lane rows); HH of the pair (s, v) accumulates in acc[2s][2v], S in acc[2s + 1][2v + 1]
+// (the registers acc[2s][2v + 1] and acc[2s + 1][2v] of the four-product form are never touched and cost nothing).
+__device__ __forceinline__ void contract3_half(uint32_t (&acc)[8][4], const uint2 (&a)[8], const uint2 (&b)[4]) {
+	uint32_t c0, c1, c2, c3;
+	or4v(c0, c1, c2, c3, a[0].x, a[1].x, a[2].x, a[3].x, a[4].x, a[5].x, a[6].x, a[7].x);
+	and_bcnt12v(acc[0][0], acc[2][0], acc[4][0], acc[6][0], acc[1][1], acc[3][1], acc[5][1], acc[7][1],
+	            a[0].x, a[2].x, a[4].x, a[6].x, a[1].x, a[3].x, a[5].x, a[7].x, c0, c1, c2, c3, b[0].x, b[1].x);
+	and_bcnt12v(acc[0][2], acc[2][2], acc[4][2], acc[6][2], acc[1][3], acc[3][3], acc[5][3], acc[7][3],
+	            a[0].x, a[2].x, a[4].x, a[6].x, a[1].x, a[3].x, a[5].x, a[7].x, c0, c1, c2, c3, b[2].x, b[3].x);
+	or4v(c0, c1, c2, c3, a[0].y, a[1].y, a[2].y, a[3].y, a[4].y, a[5].y, a[6].y, a[7].y);
+	and_bcnt12v(acc[0][0], acc[2][0], acc[4][0], acc[6][0], acc[1][1], acc[3][1], acc[5][1], acc[7][1],
+	            a[0].y, a[2].y, a[4].y, a[6].y, a[1].y, a[3].y, a[5].y, a[7].y, c0, c1, c2, c3, b[0].y, b[1].y);
+	and_bcnt12v(acc[0][2], acc[2][2], acc[4][2], acc[6][2], acc[1][3], acc[3][3], acc[5][3], acc[7][3],
+	            a[0].y, a[2].y, a[4].y, a[6].y, a[1].y, a[3].y, a[5].y, a[7].y, c0, c1, c2, c3, b[2].y, b[3].y);
+}
+
 // ---- persistent work-list form of the same contraction ------------------------------------
 // One launch = a list of 128 x 128 tiles of one super-tile (only the tiles that hold wanted pairs:
 // on/above the diagonal, inside the window band, ...) run by P persistent blocks, P = the number
@@ -452,6 +532,7 @@ template <int TB>
 struct StoreCounts {
 	static constexpr int META_WORDS = 0;       // nothing to stage for the epilogue
 	static constexpr bool PAIRED_ROWS = false; // a lane's rows are li + 8t (see read_half)
+	static constexpr bool THREE_PRODUCTS = false;
 	uint32_t* C; uint32_t ldc;
 	__device__ __forceinline__ const uint32_t* meta_src(uint32_t, uint32_t) const { return nullptr; }
 	__device__ __forceinline__ void finish(SlotWindow&, int) const {}
@@ -468,6 +549,33 @@ struct StoreCounts {
 #pragma unroll
 				for (int u = 0; u < TB; ++u) { atomicAdd(&Cblk[(size_t)(8 * t) * ldc + 8 * u], acc[t][u]); acc[t][u] = 0; }
 		}
+	}
+};
+
+// The three-product form's plain epilogue: (HH, S) of the variant pair (A, B) of the super-tile go to C[A * ldc + 2 B + {0, 1}]
+// - the count matrix of the four-product form is rows x rows words, this one half of that: variants x 2 variants (ldc = plane
+// rows of the super-tile's column axis, as before).  A tile is 64 x 64 variant pairs = 64 rows of 128 words.
+template <int TB>
+struct StoreCounts3 {
+	static constexpr int META_WORDS = 0;
+	static constexpr bool PAIRED_ROWS = true;
+	static constexpr bool THREE_PRODUCTS = true;
+	uint32_t* C; uint32_t ldc;
+	__device__ __forceinline__ const uint32_t* meta_src(uint32_t, uint32_t) const { return nullptr; }
+	__device__ __forceinline__ void finish(SlotWindow&, int) const {}
+	__device__ __forceinline__ void operator()(uint32_t (&acc)[8][TB], uint32_t yx, int wr, int wc, int li, int lj, int lane, bool whole, const uint32_t*, SlotWindow&) const {
+		static_assert(TB == 4, "two column variants per lane");
+		// the lane's variant pairs: rows vA + 8 s (s = 0..3), columns vB + 8 v (v = 0, 1), as in ScreenCountsUnphased
+		uint32_t* Cblk = C + (size_t)((yx >> 16) * (TILE / 2) + wr * 32 + li) * ldc + 2 * ((yx & 0xFFFFu) * (TILE / 2) + wc * 16 + lj);
+#pragma unroll
+		for (int s = 0; s < 4; ++s)
+#pragma unroll
+			for (int v = 0; v < 2; ++v) {
+				uint32_t* e = Cblk + (size_t)(8 * s) * ldc + 16 * v;
+				if (whole) *reinterpret_cast<uint2*>(e) = make_uint2(acc[2 * s][2 * v], acc[2 * s + 1][2 * v + 1]);
+				else { atomicAdd(e, acc[2 * s][2 * v]); atomicAdd(e + 1, acc[2 * s + 1][2 * v + 1]); }
+				acc[2 * s][2 * v] = 0; acc[2 * s + 1][2 * v + 1] = 0;
+			}
 	}
 };
 
@@ -540,6 +648,8 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 		for (int u = 0; u < TB; ++u) acc[t][u] = 0;
 
 	constexpr bool PAIRED = Epilogue::PAIRED_ROWS;
+	constexpr bool THREE = Epilogue::THREE_PRODUCTS;      // the three-product form of the plain unphased planes (contract3_half)
+	static_assert(!THREE || (PAIRED && TB == 4), "the three-product form needs a variant's H and Q rows in one lane");
 	uint32_t offA[8], offB[8];
 #pragma unroll
 	for (int k = 0; k < 8; ++k) {
@@ -639,8 +749,11 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 				} else {
 					asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 				}
+				if constexpr (THREE) contract3_half(acc, ra[h & 1], rb[h & 1]);
+				else {
 #pragma unroll
-				for (int u = 0; u < TB; ++u) contract_half<TB>(acc, u, ra[h & 1], rb[h & 1][u]);
+					for (int u = 0; u < TB; ++u) contract_half<TB>(acc, u, ra[h & 1], rb[h & 1][u]);
+				}
 			}
 		} else {
 			// The last chunk of a row whose data ends before the chunk does (CountWork::last_halves): the zero padding
@@ -653,8 +766,11 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 				read_half<TB, PAIRED>(ra, rb, bufbase + (offA[0] ^ q) + hb, bufbase + (offA[0] ^ q ^ (uint32_t)(ODD << 4)) + hb, bufbase + (offB[0] ^ q) + hb,
 				              bufbase + (offB[0] ^ q ^ (uint32_t)(ODD << 4)) + hb, 0);
 				asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+				if constexpr (THREE) contract3_half(acc, ra, rb);
+				else {
 #pragma unroll
-				for (int u = 0; u < TB; ++u) contract_half<TB>(acc, u, ra, rb[u]);
+					for (int u = 0; u < TB; ++u) contract_half<TB>(acc, u, ra, rb[u]);
+				}
 			}
 		}
 
@@ -690,6 +806,12 @@ template <int NW, int EXPERIMENT = 0>
 __global__ __launch_bounds__(NW * 64, NW / 2)
 void k_count_list_t(const CountWork w) {
 	count_list_body<NW, EXPERIMENT>(w, StoreCounts<16 / (NW / 2)>{w.C, w.ldc});
+}
+
+template <int NW, int EXPERIMENT = 0>
+__global__ __launch_bounds__(NW * 64, NW / 2)
+void k_count3_list_t(const CountWork w) {
+	count_list_body<NW, EXPERIMENT>(w, StoreCounts3<16 / (NW / 2)>{w.C, w.ldc});
 }
 
 // Inclusive prefix sum over the 64 lanes of a wave (all active) without LDS: Hillis-Steele inside each row of 16 lanes
@@ -782,6 +904,7 @@ __device__ __forceinline__ void release_slots(const ScreenWork& s, SlotWindow& w
 template <int TB>
 struct ScreenCounts {
 	static constexpr bool PAIRED_ROWS = false;
+	static constexpr bool THREE_PRODUCTS = false;
 	static constexpr int META_WORDS = 3 * TILE;      // allele counts of the tile's 128 rows, of its 128 columns, band limits of the rows
 	const ScreenWork* sp;              // in device memory: read where it is needed, not held in registers through the K loop
 	// where word i of the staged block comes from (always a readable address; what lies outside the region is masked in the epilogue)
@@ -887,6 +1010,7 @@ static_assert(16 / (8 / 2) == 4, "ScreenCounts packs (t, u) as 4t + u: TB = 4");
 template <int TB>
 struct ScreenCountsUnphased {
 	static constexpr bool PAIRED_ROWS = true;
+	static constexpr bool THREE_PRODUCTS = false;
 	static constexpr int META_WORDS = 2 * TILE + TILE / 2;     // H / Q counts of the tile's 128 plane rows, of its 128 plane columns, band limits of its 64 row variants
 	const ScreenWork* sp;
 	__device__ __forceinline__ const uint32_t* meta_src(uint32_t yx, uint32_t i) const {
@@ -991,13 +1115,14 @@ void k_count_screen_unphased_t(const CountWork w, const ScreenWork* sw) {
 	count_list_body<NW, 0>(w, ScreenCountsUnphased<16 / (NW / 2)>{sw});
 }
 
-// Zero the tiles [first, n_tiles) of the list (the ones whose K range is split into several units).
+// Zero the tiles [first, n_tiles) of the list (the ones whose K range is split into several units).  tile_rows: rows of C a
+// tile covers - TILE, or TILE / 2 in the three-product form's matrix (StoreCounts3).
 __global__ __launch_bounds__(256)
-void k_zero_tiles(const uint32_t* __restrict__ tiles, uint32_t first, uint32_t* __restrict__ C, uint32_t ldc) {
+void k_zero_tiles(const uint32_t* __restrict__ tiles, uint32_t first, uint32_t* __restrict__ C, uint32_t ldc, uint32_t tile_rows = TILE) {
 	const uint32_t yx = tiles[first + blockIdx.x];
-	uint32_t* Cblk = C + (size_t)((yx >> 16) * TILE) * ldc + (yx & 0xFFFFu) * TILE;
+	uint32_t* Cblk = C + (size_t)((yx >> 16) * tile_rows) * ldc + (yx & 0xFFFFu) * TILE;
 	const uint4 z = make_uint4(0, 0, 0, 0);
-	for (int i = threadIdx.x; i < TILE * TILE / 4; i += 256) {
+	for (int i = threadIdx.x; i < (int)tile_rows * TILE / 4; i += 256) {
 		const int r = i / (TILE / 4), q = i % (TILE / 4);
 		*reinterpret_cast<uint4*>(Cblk + (size_t)r * ldc + q * 4) = z;
 	}

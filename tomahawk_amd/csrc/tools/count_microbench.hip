@@ -91,6 +91,34 @@ int main(int argc,char**argv){
     printf("  first 16 blocks: "); for(uint32_t b=0;b<16;++b) printf("[b%u xcc%llu hw%05llx t%.0f] ",b,o[2*b+1]>>32&15,o[2*b+1]&0xFFFFF,(o[2*b]-t0)/100.0); printf("\n");
     return 0;
   }
+  if(getenv("THREE")){   // the three-product form of the unphased planes (rows 2v / 2v + 1 = H / Q of variant v): k_count3_list_t against k_count_list_t on
+    // the same rows, patch order, rectangle; checked against the host on sampled variant pairs
+    std::vector<uint32_t> list=make_list(R/128,0,true); CK(hipMemcpy(dl,list.data(),list.size()*4,hipMemcpyHostToDevice));
+    twk::CountWork w{}; w.rows=d; w.W=W; w.tiles=dl; w.C=C; w.ldc=R; w.ticket=tick;
+    first_split=twk::build_count_units((uint32_t)list.size(),W/twk::KC,P,min_chunks,units,8,8); twk::fill_unit_tiles(units,list.data());
+    CK(hipMemcpy(du,units.data(),units.size()*16,hipMemcpyHostToDevice)); w.units=du; w.n_units=(uint32_t)units.size(); w.n_queues=1; w.queue_begin[0]=0; w.queue_begin[1]=w.n_units;
+    const double tiles=(double)list.size(), wordops=tiles*128*128*W;
+    for(int three=0; three<2; ++three){
+      auto launch=[&](){ CK(hipMemsetAsync(tick,0,4,0));
+        if(first_split<list.size()) hipLaunchKernelGGL(twk::k_zero_tiles,dim3((uint32_t)list.size()-first_split),dim3(256),0,0,w.tiles,first_split,C,R,three?64u:128u);
+        if(three) hipLaunchKernelGGL((twk::k_count3_list_t<twk::COUNT_NW>),dim3(P),block,0,0,w); else hipLaunchKernelGGL((twk::k_count_list_t<twk::COUNT_NW>),dim3(P),block,0,0,w); };
+      CK(hipMemset(C,0xff,(size_t)R*R*4)); launch(); CK(hipDeviceSynchronize());
+      if(three){ std::vector<uint32_t> hc((size_t)R*R/2); CK(hipMemcpy(hc.data(),C,hc.size()*4,hipMemcpyDeviceToHost)); int bad=0; std::mt19937 r2(7);
+        for(int s=0;s<2000;++s){ const uint32_t a=r2()%(R/2), b=r2()%(R/2); uint32_t hh=0, ss=0;
+          for(uint32_t k=0;k<W;++k){ const uint32_t ha=h[(size_t)(2*a)*W+k], qa=h[(size_t)(2*a+1)*W+k], hb=h[(size_t)(2*b)*W+k], qb=h[(size_t)(2*b+1)*W+k];
+            hh+=__builtin_popcount(ha&hb); ss+=__builtin_popcount(qa&(hb|qb))+__builtin_popcount((ha|qa)&qb); }
+          const uint32_t g0=hc[(size_t)a*R+2*b], g1=hc[(size_t)a*R+2*b+1];
+          if(g0!=hh||g1!=ss){ if(bad<5) printf("MISMATCH three (%u,%u) ref %u %u got %u %u\n",a,b,hh,ss,g0,g1); ++bad; } }
+        printf("check three-product: %d mismatches\n",bad); bad_total+=bad; }
+      else check("four-product",0);
+      float best=1e30f;
+      for(int i=0;i<reps;++i){ CK(hipEventRecord(e0)); launch(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms,e0,e1)); if(ms<best)best=ms; }
+      const double exec=three? wordops*0.75 : wordops;
+      printf("%-13s R=%u W=%u P=%u tiles=%.0f whole=%u units=%u best %.3f ms  variant pairs/s %.4e  executed word-pairs/s %.3e (%.1f%% of the and+bcnt ceiling 2.62e13)\n",
+             three?"three-product":"four-product",R,W,P,tiles,first_split,w.n_units,best,tiles*64*64/best*1e3,exec/best*1e3,exec/best*1e3/2.6214e13*100);
+    }
+    return bad_total!=0;
+  }
   const int only_mode = getenv("ONLYMODE")? atoi(getenv("ONLYMODE")) : -1;     // counter passes: one kernel form (2 = list/patch), rectangle only
   for(int diag=0; diag<(only_mode>=0?1:2); ++diag){
     double tiles = diag? (double)(R/128)*(R/128+1)/2 : (double)(R/128)*(R/128);
