@@ -29,7 +29,8 @@ extern "C" {
  *    twk_hip_device_records, twk_hip_fisher_exact.  A caller built against another version must not pass
  *    its structs in: compare twk_hip_abi_version() with the header it was compiled with. */
 /* 3: twk_hip_set_option / twk_hip_get_option; the library no longer reads environment variables. */
-#define TWK_HIP_ABI_VERSION 3
+/* 4: twk_hip_timing grew (three-product launches); option "three". */
+#define TWK_HIP_ABI_VERSION 4
 
 enum {
 	TWK_HIP_OK         =  0,
@@ -301,6 +302,9 @@ int twk_hip_fisher_exact(twk_hip_ctx* ctx, const int32_t* tables, uint64_t n, do
  *   "timeline"         0        1: the host's steps through a region's launch pipeline, with times, on stderr
  *   "band_list_entries" 0       candidate slots of such a launch (0: 1/32 of its pairs, 4 M .. 256 M); a launch that
  *                               outgrows them, or its survivor buffer, is redone as matrix-sized tiles
+ *   "three"            1        UnphasedMath on planes without missing genotypes, r2 cut-off > 1e-6: contract three products per
+ *                               pair (HH and S = QH + HQ + 2 QQ, all the screen reads) and recount the four products of the pairs
+ *                               that pass; 0: four products for every pair; 2: keep to it even when a launch was candidate-rich
  * None of them changes a record (tests/test_gpu_fused.py, test_gpu_lists.py); "lists" / "list_max" drop the derived
  * plane sets, which are rebuilt on next use.  Unknown key or value out of range: TWK_HIP_E_INVALID. */
 int twk_hip_set_option(twk_hip_ctx* ctx, const char* key, int64_t value);
@@ -334,6 +338,14 @@ typedef struct {
 	uint64_t count_shader_cycles; /* what the count kernel's blocks lived for, summed over the blocks: shader clock cycles ...   */
 	uint64_t count_wall_ticks;    /* ... and ticks of the constant 100 MHz counter.  cycles / ticks x 100 MHz = the clock the
 	                                 launches really ran at (a chip that was idle needs ~20 ms of load to reach its 2.4 GHz) */
+	uint64_t three_launches;      /* count launches that ran the three-product form of the plain unphased planes: per word and
+	                                 variant pair HH = popc(H_A & H_B) and S = popc(Q_A & C_B) + popc(C_A & Q_B), C = H | Q - what
+	                                 UnphasedMath's r2 screen reads (ld_engine.cpp:1363-1375 via minhap / maxhap) - instead of the four
+	                                 products HH, HQ, QH, QQ; the reference's list kernel likewise takes one popcount and the other
+	                                 cells from the margins (ld_engine.cpp:244-246) */
+	uint64_t three_row_pairs;     /* ... and the plane-row pairs of those launches (of row_pairs): they executed 3/4 of the
+	                                 AND+popcounts row_pairs x words_per_row stands for, plus 6 v_or per 24 of them */
+	uint64_t recount_candidates;  /* pairs that passed the three-product screen and had their four products counted afresh */
 } twk_hip_timing;
 /* Progress of twk_hip_ld_all / twk_hip_ld_region: `cb` runs on the calling thread after every tile
  * with the variant pairs finished so far in the current call and the tile counts.  Replaces the

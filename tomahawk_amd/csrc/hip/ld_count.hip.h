@@ -1007,10 +1007,12 @@ static_assert(16 / (8 / 2) == 4, "ScreenCounts packs (t, u) as 4t + u: TB = 4");
 // r2 = D^2 / (P (1 - P) Q (1 - Q)) with the REF frequencies P = 1 - (h_A + 2 q_A) / 2N, Q likewise: the pair can pass only if
 // one end of that interval reaches the cut-off.  For unlinked variants the interval is centred on P Q with half width
 // P (1 - P) Q (1 - Q), which is below any cut-off above 1/16: at the default r2 >= 0.1 only pairs in LD are candidates.
-template <int TB>
+// THREE: the three-product contraction (contract3_half) - the lane holds HH and S = QH + HQ + 2 QQ of a pair, which is all the
+// screen reads; a candidate's entry then carries (A, B, HH, S, -, -) and k_recount_unphased fills in the four products.
+template <int TB, bool THREE = false>
 struct ScreenCountsUnphased {
 	static constexpr bool PAIRED_ROWS = true;
-	static constexpr bool THREE_PRODUCTS = false;
+	static constexpr bool THREE_PRODUCTS = THREE;
 	static constexpr int META_WORDS = 2 * TILE + TILE / 2;     // H / Q counts of the tile's 128 plane rows, of its 128 plane columns, band limits of its 64 row variants
 	const ScreenWork* sp;
 	__device__ __forceinline__ const uint32_t* meta_src(uint32_t yx, uint32_t i) const {
@@ -1055,9 +1057,10 @@ struct ScreenCountsUnphased {
 			const double fA = cut * (da * ra);
 #pragma unroll
 			for (int v = 0; v < 2; ++v) {
-				const uint32_t hh = acc[2 * sI][2 * v], hq = acc[2 * sI][2 * v + 1], qh = acc[2 * sI + 1][2 * v], qq = acc[2 * sI + 1][2 * v + 1];
+				const uint32_t hh = acc[2 * sI][2 * v];
+				const uint32_t s_sum = THREE ? acc[2 * sI + 1][2 * v + 1] : acc[2 * sI + 1][2 * v] + acc[2 * sI][2 * v + 1] + 2u * acc[2 * sI + 1][2 * v + 1];      // QH + HQ + 2 QQ
 				// n11 = ra - b + (QH + HQ + 2 QQ): the (REF, REF) haplotypes that are certain
-				const double n11 = (ra - db[v]) + (double)(qh + hq + 2u * qq);
+				const double n11 = (ra - db[v]) + (double)s_sum;
 				const double e_lo = (n11 * T2n - ra * rb[v]) - eps;
 				const double e_hi = ((n11 + (double)hh) * T2n - ra * rb[v]) + eps;
 				const double bound = fA * fB[v];
@@ -1083,7 +1086,7 @@ struct ScreenCountsUnphased {
 						if (slot < cap) {
 							g_u32* e = cand + slot * 6;
 							e[0] = vA0 + 8 * sI; e[1] = vB[v];
-							e[2] = acc[2 * sI][2 * v]; e[3] = acc[2 * sI][2 * v + 1]; e[4] = acc[2 * sI + 1][2 * v]; e[5] = acc[2 * sI + 1][2 * v + 1];
+							e[2] = acc[2 * sI][2 * v]; e[3] = acc[2 * sI][2 * v + 1]; e[4] = acc[2 * sI + 1][2 * v]; e[5] = acc[2 * sI + 1][2 * v + 1];      // (THREE: HH, 0, 0, S - replaced by k_recount_unphased)
 						}
 						++mine;
 					}
@@ -1113,6 +1116,12 @@ template <int NW>
 __global__ __launch_bounds__(NW * 64, NW / 2)
 void k_count_screen_unphased_t(const CountWork w, const ScreenWork* sw) {
 	count_list_body<NW, 0>(w, ScreenCountsUnphased<16 / (NW / 2)>{sw});
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64, NW / 2)
+void k_count3_screen_unphased_t(const CountWork w, const ScreenWork* sw) {
+	count_list_body<NW, 0>(w, ScreenCountsUnphased<16 / (NW / 2), true>{sw});
 }
 
 // Zero the tiles [first, n_tiles) of the list (the ones whose K range is split into several units).  tile_rows: rows of C a

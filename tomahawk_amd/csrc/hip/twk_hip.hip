@@ -4,6 +4,7 @@
 //   prep  (ld_prep.hip.h)  reference bitvectors -> contraction planes
 //   count (ld_count.hip.h) LDS-tiled AND+popcount contraction  [dominant kernel]
 //   math  (ld_math.hip.h)  cells -> D/D'/r2/Fisher -> filters -> compaction
+//   (ld_three.hip.h: screen + recount behind the three-product form of the unphased contraction)
 // over super-tiles of the variant-pair triangle.  Device memory lives in the
 // ctx; nothing here falls back to the CPU.
 #include <hip/hip_runtime.h>
@@ -22,6 +23,7 @@
 #include "ld_prep.hip.h"
 #include "ld_math.hip.h"
 #include "ld_list.hip.h"
+#include "ld_three.hip.h"
 
 using namespace twk;
 
@@ -94,6 +96,10 @@ struct Slot {                      // one in-flight tile (double buffered)
 	twk_hip_record* sorted = nullptr; unsigned long long sorted_cap = 0;      // band launches: the survivors in (idxA, idxB) order, sorted on the
 	bool presorted = false;                                                   // compute stream right behind Fisher's test (enqueue_band_math)
 	bool fused = false;                           // first launch ran the fused count -> screen kernel: C holds the candidate list
+	bool three = false;                           // ... in the three-product form (HH + S; the candidates' four products are recounted): fused, or
+	bool three_plain = false;                     // through a count matrix (long rows): C holds the (HH, S) matrix and, behind it, the candidate list
+	uint32_t* cand = nullptr;                     // the candidate list of the launch (in C)
+	int plane_set = 0;                            // the plane set the launch contracted
 	unsigned long long cand_cap = 0;              // ... of this many entries; n_out[2] counts them
 	bool cand_overflow = false;                   // set by finish_tile: the list did not hold them all
 	double minP = 1.0;
@@ -135,6 +141,8 @@ struct Options {
 	long long band_reverse = 1;      // allele-count-sorted runs: the last band (the commonest variants, most survivors) first
 	long long timeline = 0;          // 1: the host's steps through the launch pipeline of a region, with times, on stderr (measurement)
 	long long band_work_log2 = 19;   // ... and at least 2^n tile-chunks of work per launch (19: ~5 ms); small values make several launches of a small run
+	long long three = 1;             // UnphasedMath on the plain unphased planes with an r2 cut-off: the three-product contraction (HH + S, ld_count.hip.h) and a
+	                                 // recount of the candidates' four products; 0: the four-product forms; 2: also when a launch turned out candidate-rich
 };
 struct OptionKey { const char* name; long long Options::* field; long long lo, hi; bool rebuilds_planes; };
 const OptionKey OPTION_KEYS[] = {
@@ -147,6 +155,7 @@ const OptionKey OPTION_KEYS[] = {
 	{"record_cap", &Options::record_cap, 0, 1ll << 40, false},
 	{"probe", &Options::probe, 0, 1, false}, {"band_launch", &Options::band_launch, 0, 1, false}, {"band_list_entries", &Options::band_list_entries, 0, 1ll << 32, false},
 	{"band_work_log2", &Options::band_work_log2, 0, 40, false}, {"band_max_launches", &Options::band_max_launches, 1, 64, false}, {"timeline", &Options::timeline, 0, 1, false}, {"band_reverse", &Options::band_reverse, 0, 1, false}, {"probe_zone", &Options::probe_zone, 0, 1, false}, {"probe_unroll", &Options::probe_unroll, 1, 4, false},
+	{"three", &Options::three, 0, 2, false},
 };
 }  // namespace
 
@@ -172,6 +181,7 @@ struct twk_hip_ctx {
 	// twk_hip_set_device_sink: the survivors of region calls stay on the device, appended here tile by tile
 	StatsParams* d_list_stats = nullptr;          // parameter block of the list pass's math kernel (device copy)
 	bool fused_ok = true;           // cleared for the rest of a call when a fused tile's candidate list overflowed
+	bool three_ok = true;           // cleared for the rest of a call when a three-product launch had too many candidates for the recount to stay cheap
 	bool device_sink = false;
 	twk_hip_record* d_keep = nullptr; unsigned long long d_keep_n = 0, d_keep_cap = 0;
 	// the survivors of a tile leave in (idxA, idxB) order: sort keys / permutation (double-buffered), the
@@ -487,10 +497,12 @@ void build_tile_list(const twk_hip_tile_desc& t, int P, const Geometry& g, bool 
 // The two parameter blocks of a fused launch travel to the device behind the tile list and the unit table (one copy
 // per launch as before): the kernels read them from memory where they need them instead of holding ~60 more scalar
 // registers through the contraction loop / the candidate loop.
+// three: the three-product form (fa->unphased) - fused where the launch fuses, else k_count3_list_t into an (HH, S) matrix; the parameter
+// blocks travel in both cases (*d_screen / *d_stats: where they landed).
 struct FusedArgs { ScreenWork screen; StatsParams stats; int unphased; };
 int launch_count(twk_hip_ctx* c, int set, const twk_hip_tile_desc& t, Slot& s, int which, hipEvent_t e0, hipEvent_t e1,
                  uint64_t* row_pairs, const ColRange* cr = nullptr, const FusedArgs* fa = nullptr, bool* fused = nullptr,
-                 const StatsParams** d_stats = nullptr) {
+                 const StatsParams** d_stats = nullptr, bool three = false, const ScreenWork** d_screen = nullptr) {
 	const PlaneSet& ps = c->planes[set];
 	const int P = planes_per_variant(set_kind(set));
 	const Geometry g = tile_geometry(P, t);
@@ -511,6 +523,7 @@ int launch_count(twk_hip_ctx* c, int set, const twk_hip_tile_desc& t, Slot& s, i
 		if (fuse) min_chunks = nchunks + 1;          // whole tiles only: a block must hold a pair's whole count to screen it
 	}
 	if (fused) *fused = fuse;
+	const bool with_args = fuse || (three && fa);       // the parameter blocks go to the device behind the unit table
 	std::vector<CountUnit> units;
 	uint32_t seg_chunks = (uint32_t)c->opt.seg;    // 0: whole tiles (see build_tile_list for the measurement behind that)
 	if (fuse) seg_chunks = 0;
@@ -539,7 +552,7 @@ int launch_count(twk_hip_ctx* c, int set, const twk_hip_tile_desc& t, Slot& s, i
 	fill_unit_tiles(units, list.data());
 	const size_t T4 = (T + 3) / 4 * 4, words_units = T4 + units.size() * 4;       // [tiles | pad | units], units 16-byte aligned
 	const size_t fa_words = (sizeof(FusedArgs) + 15) / 16 * 4;
-	const size_t words = words_units + (fuse ? fa_words : 0);                    // [... | FusedArgs] for a fused launch
+	const size_t words = words_units + (with_args ? fa_words : 0);               // [... | FusedArgs] for a fused or three-product launch
 	if (s.tiles_cap[which] < words) {
 		if (s.h_tiles[which]) (void)hipHostFree(s.h_tiles[which]);
 		if (s.d_tiles[which]) (void)hipFree(s.d_tiles[which]);
@@ -552,7 +565,7 @@ int launch_count(twk_hip_ctx* c, int set, const twk_hip_tile_desc& t, Slot& s, i
 	if (T) {
 		std::memcpy(s.h_tiles[which], list.data(), T * 4);
 		std::memcpy(s.h_tiles[which] + T4, units.data(), units.size() * sizeof(CountUnit));
-		if (fuse) std::memcpy(s.h_tiles[which] + words_units, fa, sizeof(FusedArgs));
+		if (with_args) std::memcpy(s.h_tiles[which] + words_units, fa, sizeof(FusedArgs));
 		HIPCHK(c, hipMemcpyAsync(s.d_tiles[which], s.h_tiles[which], words * 4, hipMemcpyHostToDevice, c->s_compute));
 	}
 	HIPCHK(c, hipEventRecord(e0, c->s_compute));
@@ -577,12 +590,15 @@ int launch_count(twk_hip_ctx* c, int set, const twk_hip_tile_desc& t, Slot& s, i
 		}
 		HIPCHK(c, hipMemsetAsync(w.ticket, 0, 8 * 4, c->s_compute));
 		if (first_split < T) {
-			hipLaunchKernelGGL(k_zero_tiles, dim3((uint32_t)T - first_split), dim3(256), 0, c->s_compute, w.tiles, first_split, w.C, w.ldc);
+			hipLaunchKernelGGL(k_zero_tiles, dim3((uint32_t)T - first_split), dim3(256), 0, c->s_compute, w.tiles, first_split, w.C, w.ldc, (uint32_t)(three ? TILE / 2 : TILE));
 			HIPCHK(c, hipGetLastError());
 		}
 		const FusedArgs* d_fa = reinterpret_cast<const FusedArgs*>(s.d_tiles[which] + words_units);
-		if (fuse && d_stats) *d_stats = &d_fa->stats;
-		if (fuse && fa->unphased) hipLaunchKernelGGL((k_count_screen_unphased_t<COUNT_NW>), dim3(std::min(n_blocks, w.n_units)), dim3(COUNT_THREADS), 0, c->s_compute, w, &d_fa->screen);
+		if (with_args && d_stats) *d_stats = &d_fa->stats;
+		if (with_args && d_screen) *d_screen = &d_fa->screen;
+		if (fuse && fa->unphased && three) hipLaunchKernelGGL((k_count3_screen_unphased_t<COUNT_NW>), dim3(std::min(n_blocks, w.n_units)), dim3(COUNT_THREADS), 0, c->s_compute, w, &d_fa->screen);
+		else if (three) hipLaunchKernelGGL((k_count3_list_t<COUNT_NW>), dim3(std::min(n_blocks, w.n_units)), dim3(COUNT_THREADS), 0, c->s_compute, w);
+		else if (fuse && fa->unphased) hipLaunchKernelGGL((k_count_screen_unphased_t<COUNT_NW>), dim3(std::min(n_blocks, w.n_units)), dim3(COUNT_THREADS), 0, c->s_compute, w, &d_fa->screen);
 		else if (fuse) hipLaunchKernelGGL((k_count_screen_t<COUNT_NW>), dim3(std::min(n_blocks, w.n_units)), dim3(COUNT_THREADS), 0, c->s_compute, w, &d_fa->screen);
 		else hipLaunchKernelGGL((k_count_list_t<COUNT_NW>), dim3(std::min(n_blocks, w.n_units)), dim3(COUNT_THREADS), 0, c->s_compute, w);
 		HIPCHK(c, hipGetLastError());
@@ -685,6 +701,21 @@ bool fused_form_applies(twk_hip_ctx* c, int mode, const twk_hip_filters& f) {
 	return c->opt.fused == 2 || c->planes[pl.set1].W / KC <= FUSED_MAX_CHUNKS;
 }
 
+// The four products of the candidates of a three-product launch (k_recount_unphased), on the compute stream: a wave per candidate for
+// long rows, a DPP row of 16 lanes for rows of up to 1024 words.  The recount also checks the contraction: a candidate whose (HH, S)
+// disagrees with its own four products is counted in n_out[3], and finish_tile fails the call on it.
+int launch_recount(twk_hip_ctx* c, int set, Slot& s) {
+	const PlaneSet& ps = c->planes[set];
+	if (ps.W_live <= 1024)
+		hipLaunchKernelGGL(k_recount_unphased<16>, dim3(c->resident_blocks * 4), dim3(256), 0, c->s_compute, (const uint32_t*)ps.rows, ps.W, ps.W_live, s.cand,
+		                   (const unsigned long long*)(s.n_out + 2), s.cand_cap, s.n_out + 3);
+	else
+		hipLaunchKernelGGL(k_recount_unphased<64>, dim3(c->resident_blocks * 4), dim3(256), 0, c->s_compute, (const uint32_t*)ps.rows, ps.W, ps.W_live, s.cand,
+		                   (const unsigned long long*)(s.n_out + 2), s.cand_cap, s.n_out + 3);
+	HIPCHK(c, hipGetLastError());
+	return TWK_HIP_OK;
+}
+
 // list_words != 0: a band launch (region_impl) - the fused form with a candidate list of that many words and no count
 // matrix at all (its rectangle may be far beyond what a matrix could hold); it is an error if the launch does not fuse.
 int enqueue_tile(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, const twk_hip_filters& f, Slot& s,
@@ -709,6 +740,20 @@ int enqueue_tile(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, const twk
 	fa.unphased = fused_u ? 1 : 0;
 	ScreenWork& sw = fa.screen;
 	s.fused = false; s.is_list = false; s.is_probe = false; s.cand_overflow = false; s.cand_cap = (list_words ? list_words : s.C_words) / (fused_u ? 6 : 3);
+	s.three = false; s.three_plain = false; s.cand = s.C;
+	// The three-product form (ld_count.hip.h): UnphasedMath on the plain unphased planes with a cut-off the screen can use.  Where the launch
+	// does not fuse (long rows: tiles are split along K) the (HH, S) matrix takes the first half of the slot's count buffer and the candidate
+	// list the room behind it - at most 1/128 of the tile's pairs: a candidate's recount streams its four rows once more, ~25 pairs' worth of
+	// contraction, so a launch with more candidates than that is cheaper in the four-product form (overflow -> three_ok = false -> redone).
+	const bool want_three = want_fused && fused_u && c->three_ok && c->opt.three != 0;
+	const bool fuses = want_fused && (c->opt.fused == 2 || (c->opt.fused == 1 && c->planes[kind1].W / KC <= FUSED_MAX_CHUNKS));      // (launch_count's own test)
+	if (want_three && !fuses) {
+		const size_t c2_words = (size_t)(g.rowsA / 2) * g.rowsB;
+		const unsigned long long room = s.C_words > c2_words ? (s.C_words - c2_words) / 6 : 0;
+		const unsigned long long pairs = (unsigned long long)t.nA * t.nB;
+		s.cand = s.C + c2_words;
+		s.cand_cap = std::min<unsigned long long>(room, c->opt.three == 2 ? room : std::max<unsigned long long>(pairs / 128, 4096));
+	}
 	if (want_fused) {
 		const PlaneSet& ps = c->planes[kind1];
 		fa.stats = make_stats(c, kind1, t, s, phased, pl.select1, f, cr);
@@ -717,7 +762,7 @@ int enqueue_tile(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, const twk
 		sw.col_hi = cr ? cr->d_hi : nullptr; sw.hi_a0 = cr ? cr->a0 : 0; sw.hi_b0 = cr ? cr->b0 : 0; sw.hi_n = cr ? cr->n_hi : 0;
 		sw.list_zone = cr ? cr->list_zone : 0; sw.probe_zone = cr ? cr->probe_zone : 0;
 		sw.two_n = 2.0 * (double)c->N; sw.cut = f.minR2 * (1.0 - 1e-6);
-		sw.cand = s.C; sw.cap = s.cand_cap; sw.n_cand = s.n_out + 2;
+		sw.cand = s.cand; sw.cap = s.cand_cap; sw.n_cand = s.n_out + 2;
 		{	// slots a wave reserves at a time: what it cannot use is lost to the list, so at most an eighth of the list's
 			// capacity may be tied up in the waves' windows (small tiles: 0, i.e. one atomic per wave and tile)
 			const unsigned long long per_wave = s.cand_cap / (8ull * c->resident_blocks * (COUNT_THREADS / 64));
@@ -725,9 +770,10 @@ int enqueue_tile(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, const twk
 			                                  : (per_wave >= 64 ? (uint32_t)std::min<unsigned long long>(per_wave, 128) : 0u);
 		}
 	}
-	const StatsParams* d_stats = nullptr;
+	const StatsParams* d_stats = nullptr; const ScreenWork* d_screen = nullptr;
 	s.deferred = false; s.was_deferred = false; s.presorted = false;
-	rc = launch_count(c, kind1, t, s, 0, s.ev_c0, s.ev_c1, &s.row_pairs, cr, want_fused ? &fa : nullptr, &s.fused, &d_stats); if (rc) return rc;
+	rc = launch_count(c, kind1, t, s, 0, s.ev_c0, s.ev_c1, &s.row_pairs, cr, want_fused ? &fa : nullptr, &s.fused, &d_stats, want_three, &d_screen); if (rc) return rc;
+	s.three = want_three; s.three_plain = want_three && !s.fused; s.plane_set = kind1;
 	if (list_words) {
 		// A band launch stops here for now: how many survivors it can have is how many candidates it found, and only the count
 		// kernel knows.  The counters travel to the host behind it; enqueue_band_math sizes the survivor buffer by them and
@@ -739,7 +785,17 @@ int enqueue_tile(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, const twk
 		HIPCHK(c, hipEventRecord(s.ev_c1b, c->s_compute));
 		return TWK_HIP_OK;
 	}
-	if (s.fused) {
+	if (s.three_plain && d_stats) {
+		// (HH, S) matrix -> screen -> candidates -> their four products -> the list math
+		hipLaunchKernelGGL(k_screen3_pairs, dim3((t.nB + SCREEN3_THREADS - 1) / SCREEN3_THREADS, t.nA), dim3(SCREEN3_THREADS), 0, c->s_compute, d_screen, d_stats, (const uint32_t*)s.C, g.ldc);
+		HIPCHK(c, hipGetLastError());
+		rc = launch_recount(c, kind1, s); if (rc) return rc;
+		hipLaunchKernelGGL(k_ld_stats_list_unphased, dim3(c->resident_blocks * 4), dim3(256), 0, c->s_compute, d_stats, (const uint32_t*)s.cand,
+		                   (const unsigned long long*)(s.n_out + 2), s.cand_cap);
+	} else if (s.three_plain) {
+		// (no tiles, no launch, no candidates)
+	} else if (s.fused) {
+		if (d_stats && s.three) { rc = launch_recount(c, kind1, s); if (rc) return rc; }
 		if (d_stats && fused_u)
 			hipLaunchKernelGGL(k_ld_stats_list_unphased, dim3(c->resident_blocks * 4), dim3(256), 0, c->s_compute, d_stats, (const uint32_t*)s.C,
 			                   (const unsigned long long*)(s.n_out + 2), s.cand_cap);
@@ -839,6 +895,7 @@ int enqueue_band_math(twk_hip_ctx* c, Slot& s) {
 		s.stats_host.out = s.out; s.stats_host.capacity = s.cap_use; s.stats_host.n_out = s.n_out;
 		s.stats_host.keys = s.keys; s.stats_host.vals = s.vals;
 		HIPCHK(c, hipMemcpyAsync(s.d_stats_dev, &s.stats_host, sizeof(StatsParams), hipMemcpyHostToDevice, c->s_compute));
+		if (s.three) { const int rc = launch_recount(c, s.plane_set, s); if (rc) return rc; }
 		if (s.deferred_unphased)
 			hipLaunchKernelGGL(k_ld_stats_list_unphased, dim3(c->resident_blocks * 4), dim3(256), 0, c->s_compute, (const StatsParams*)s.d_stats_dev, (const uint32_t*)s.C,
 			                   (const unsigned long long*)(s.n_out + 2), s.cand_cap);
@@ -937,6 +994,16 @@ int finish_tile(twk_hip_ctx* c, Slot& s, const twk_hip_tile_desc& t, unsigned lo
 	else { c->timing.count_ms += ms; c->timing.count_launches += 1; c->timing.row_pairs += s.row_pairs;
 	       c->timing.count_shader_cycles += s.h_n_out[4]; c->timing.count_wall_ticks += s.h_n_out[5]; }
 	if (s.fused) { c->timing.fused_launches += 1; c->timing.candidates += s.h_n_out[2]; }
+	if (s.three) {
+		c->timing.three_launches += 1; c->timing.three_row_pairs += s.row_pairs; c->timing.recount_candidates += std::min<unsigned long long>(s.h_n_out[2], s.cand_cap);
+		if (s.three_plain) c->timing.candidates += s.h_n_out[2];
+		if (s.h_n_out[3]) {      // the recount disagrees with the contraction: never to be papered over
+			snprintf(c->err, sizeof(c->err), "three-product contraction: %llu candidates whose (HH, S) differ from their recounted products (tile rows %u+%u, cols %u+%u)", s.h_n_out[3], t.rowA0, t.nA, t.rowB0, t.nB);
+			return TWK_HIP_E_DEVICE;
+		}
+		// a launch this rich in candidates pays more for their recount than the fourth product costs: the rest of the call in the four-product forms
+		if (c->opt.three != 2 && s.h_n_out[2] > std::max<unsigned long long>(pairs_in_tile(c, t) / 32, 4096)) c->three_ok = false;
+	}
 	float ms_all = 0;
 	if (s.two_pass) {
 		HIPCHK(c, hipEventElapsedTime(&ms, s.ev_c0b, s.ev_c1b));
@@ -953,7 +1020,7 @@ int finish_tile(twk_hip_ctx* c, Slot& s, const twk_hip_tile_desc& t, unsigned lo
 	if (!s.is_list) c->timing.variant_pairs += pairs_in_tile(c, t);      // (the dense tiles that cover the list zone count its pairs)
 	const unsigned long long n = *s.h_n_out;
 	*n_out = n;
-	if ((s.fused || s.is_list) && s.h_n_out[2] > s.cand_cap) {       // more candidates than the list holds
+	if ((s.fused || s.is_list || s.three_plain) && s.h_n_out[2] > s.cand_cap) {       // more candidates than the list holds
 		s.cand_overflow = true;
 		snprintf(c->err, sizeof(c->err), "%llu candidates for a list of %llu (tile rows %u+%u, cols %u+%u)", s.h_n_out[2], s.cand_cap, t.rowA0, t.nA, t.rowB0, t.nB);
 		return TWK_HIP_E_OVERFLOW;
@@ -1124,8 +1191,8 @@ int run_tile_sync(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, const tw
 	Slot& s = c->slot[SYNC_SLOT];
 	int rc = enqueue_tile(c, mode, t, f, s, capacity, cr); if (rc) return rc;
 	rc = finish_tile(c, s, t, n_out, to_host, sink, user);
-	if (rc == TWK_HIP_E_OVERFLOW && s.cand_overflow) {       // too many candidates for the fused form: through C, for the rest of this call
-		c->fused_ok = false;
+	if (rc == TWK_HIP_E_OVERFLOW && s.cand_overflow) {       // too many candidates for the fused / three-product form: through C, four products, for the rest of this call
+		c->fused_ok = false; c->three_ok = false;
 		rc = enqueue_tile(c, mode, t, f, s, capacity, cr); if (rc) return rc;
 		rc = finish_tile(c, s, t, n_out, to_host, sink, user);
 	}
@@ -1572,7 +1639,7 @@ int twk_hip_ld_tile(twk_hip_ctx* c, int mode, const twk_hip_tile_desc* t, const 
 	if (!c->raw) return TWK_HIP_E_STATE;
 	if (!valid_tile(c, t)) return TWK_HIP_E_INVALID;
 	HIPCHK(c, hipSetDevice(c->device));
-	c->fused_ok = true;
+	c->fused_ok = true; c->three_ok = true;
 	unsigned long long n = 0;
 	int rc = run_tile_sync(c, mode, *t, *f, std::max<unsigned long long>(capacity, 1), &n);
 	*n_out = n;
@@ -2036,7 +2103,7 @@ static int region_impl(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint3
 		} else {
 			rc = finish_tile(c, s, mine[done], &nrec, !c->device_sink, sink ? sink : discard_records, user);
 			if (rc == TWK_HIP_E_OVERFLOW && s.cand_overflow) {     // the fused form's candidate list overflowed: this tile again through C
-				c->fused_ok = false;                                 // (and the tiles not yet enqueued as well)
+				c->fused_ok = false; c->three_ok = false;            // (and the tiles not yet enqueued as well)
 				rc = run_tile_sync(c, mode, mine[done], *f, cap_default, &nrec, !c->device_sink, windowed ? &col_range : nullptr, sink ? sink : discard_records, user);
 			}
 			if (rc == TWK_HIP_E_OVERFLOW) {
@@ -2089,7 +2156,7 @@ static int region_dispatch(twk_hip_ctx* c, int mode, const twk_hip_filters* f, u
 	if (nA == 0 || nB == 0 || (uint64_t)a0 + nA > c->M || (uint64_t)b0 + nB > c->M) return TWK_HIP_E_INVALID;
 	if (triangle && (a0 != b0 || nB < nA)) return TWK_HIP_E_INVALID;
 	HIPCHK(c, hipSetDevice(c->device));
-	c->fused_ok = true;
+	c->fused_ok = true; c->three_ok = true;
 	const bool whole = triangle && a0 == 0 && nA == c->M && nB == c->M;
 	// TWK_HIP_OPT_R2_SCREEN: whole-triangle runs with an r2 cut-off worth the name, outside window mode (which
 	// already prunes by position, in an order the allele-count sort would destroy)

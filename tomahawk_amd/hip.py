@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libtwk_hip.so")
 
-ABI_VERSION = 3                 # TWK_HIP_ABI_VERSION of include/twk_hip.h (struct layouts below)
+ABI_VERSION = 4                 # TWK_HIP_ABI_VERSION of include/twk_hip.h (struct layouts below)
 MODE_PHASED, MODE_UNPHASED, MODE_AUTO = 1, 2, 3
 # option bits of twk_hip_tile_desc.window / the `window` argument of ld_all / ld_region (TWK_HIP_OPT_*)
 OPT_WINDOW, OPT_KEEP_LOW_AC, OPT_REF_COMPAT, OPT_R2_SCREEN = 1, 2, 4, 8
@@ -52,7 +52,8 @@ class _Timing(C.Structure):
                 ("words_per_row", C.c_uint64), ("fused_launches", C.c_uint64), ("candidates", C.c_uint64),
                 ("list_ms", C.c_double), ("list_launches", C.c_uint64), ("list_pairs", C.c_uint64),
                 ("probe_ms", C.c_double), ("probe_launches", C.c_uint64), ("probe_pairs", C.c_uint64),
-                ("count_shader_cycles", C.c_uint64), ("count_wall_ticks", C.c_uint64)]
+                ("count_shader_cycles", C.c_uint64), ("count_wall_ticks", C.c_uint64),
+                ("three_launches", C.c_uint64), ("three_row_pairs", C.c_uint64), ("recount_candidates", C.c_uint64)]
 
 
 @dataclass
