@@ -15,8 +15,11 @@ sizes) and rank 0 packs them into a real .two file; `value` is total pairs / max
 total work is fixed, so "scaling" is "strong".
 
 The JSON line also carries
-  roofline     the dominant kernel (twk::k_count_list_t), timed live with HIP events on the engine's
-               own stream.  The kernel tiles 128 x 128 plane rows through LDS, so each streamed row is
+  roofline     the dominant kernel (twk::k_count3_list_t: the three-product form of the unphased contraction - HH and
+               S = QH + HQ + 2 QQ per pair, all UnphasedMath's r2 screen reads; the four products of the pairs that pass are
+               recounted; twk::k_count_list_t where that form does not apply), timed live with HIP events on the engine's
+               own stream.  `frac` counts the lane-ops the kernel EXECUTED (v_and + v_bcnt per product, the v_or of the
+               three-product form); `algorithmic_frac` SURVEY 8(d)'s four products per unphased pair over the same time.  The kernel tiles 128 x 128 plane rows through LDS, so each streamed row is
                reused 128x and HBM is not what binds it: the binding unit is the VALU (v_and_b32 +
                v_bcnt_u32_b32 per 32-bit word pair, no MFMA as the north star requires).  bound="valu":
                achieved = algorithmic lane-ops (2*ceil(2N/32) per pair phased,
@@ -76,6 +79,23 @@ MIN_P = {"cfg5": 1e-6}
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
 VALU_LANE_PEAK = 256 * 4 * 32 * 2.4e9         # SIMD-32 lane-ops/s (MI355X_MICROARCH.md: v_fma_f32 wave64 = 2 cycles)
 VALU_PAIR_PEAK = 256 * 4 * 64 / 6.0 * 2.4e9   # and(2 cyc)+bcnt(4 cyc) per wave64 word pair, 2.4 GHz
+
+
+def executed_work(tm):
+    """What the count launches issued, from the engine's timing: AND+popcount products (one per word of a plane-row pair; three for
+    every four of them in the three-product form of UnphasedMath's contraction) and the v_or that form adds (one per four of its
+    products) -> (products, ors, name of the kernel, name of the form)."""
+    words = tm["words_per_row"]
+    four = (tm["row_pairs"] - tm["three_row_pairs"]) * words
+    three = tm["three_row_pairs"] * words * 0.75
+    kernel = "twk::k_count_list_t"
+    form = "four products per pair (HH, HQ, QH, QQ)"
+    if tm["three_launches"]:
+        kernel = "twk::k_count3_list_t" if not tm["fused_launches"] else "twk::k_count3_screen_unphased_t"
+        form = "three products per pair (HH and S = QH + HQ + 2 QQ; the four products of screened-in pairs recounted)"
+        if tm["three_launches"] < tm["count_launches"]:
+            form += f" in {tm['three_launches']} of {tm['count_launches']} launches"
+    return four + three, three / 4.0, kernel, form
 
 
 def cpu_baseline(n_samples, mode, seed, log):
@@ -153,7 +173,7 @@ def measure_traffic(config_args, log):
             with open(files[0], newline="") as fh:
                 for row in csv.DictReader(fh):
                     name = row.get("Kernel_Name") or row.get("kernel_name") or ""
-                    if ("k_count_list_t" in name or "k_count_screen" in name) and row.get("Counter_Name") == ctr:
+                    if ("k_count_list_t" in name or "k_count_screen" in name or "k_count3" in name) and row.get("Counter_Name") == ctr:
                         total += float(row["Counter_Value"])
                         launches.add(row.get("Dispatch_Id") or row.get("dispatch_id"))
             if not launches:
@@ -302,7 +322,7 @@ def extra_kg(log):
     return out
 
 
-def extra_in_process(config, log, steps, warmup, seed=42, emulate_shard=None):
+def extra_in_process(config, log, steps, warmup, seed=42, emulate_shard=None, options=()):
     """Another BASELINE config on this GPU through the same calls as the timed region (synthetic input in HBM) -> dict."""
     import tomahawk_amd as T
     from tomahawk_amd.dist import window_slab
@@ -311,6 +331,8 @@ def extra_in_process(config, log, steps, warmup, seed=42, emulate_shard=None):
     filters = T.Filters(minP=MIN_P.get(config, 1.0))
     window_bp = WINDOW_BP.get(config, 0)
     eng = T.HipLd(0)
+    for k_, v_ in options:
+        eng.set_option(k_, int(v_))
     try:
         t0 = time.time()
         if window_bp:
@@ -338,15 +360,20 @@ def extra_in_process(config, log, steps, warmup, seed=42, emulate_shard=None):
         eng.close()
     lane_ops = 2 * ((2 * n_samples + 31) // 32) if mode == "phased" else 8 * ((n_samples + 31) // 32)
     k_s = tm["count_ms"] * 1e-3
+    products, ors, kernel, form = executed_work(tm)
     res = {"workload": f"BASELINE {NAMES[config]}: {n_samples} x {n_variants} {mode}" + (f", +-{window_bp} bp, P<={filters.minP:g}, EMULATED shard {emulate_shard[0]}/{emulate_shard[1]}" if window_bp else ""),
            "steps": steps, "warmup": warmup, "pairs_per_step": pairs // max(steps, 1), "value": pairs / el, "unit": "variant-pairs/s",
            "ms_per_step": el / steps * 1e3, "survivors_per_step": recs / steps, "setup_s": setup,
-           "dominant_kernel": "twk::k_count_list_t", "count_launches_per_step": tm["count_launches"] / steps,
+           "dominant_kernel": kernel, "form": form, "count_launches_per_step": tm["count_launches"] / steps,
            "avg_launch_ms": tm["count_ms"] / max(tm["count_launches"], 1), "count_kernel_ms_per_step": tm["count_ms"] / steps,
            "math_kernels_ms_per_step": tm["stats_ms"] / steps,
-           "frac": pairs * lane_ops / k_s / VALU_LANE_PEAK if k_s > 0 else None,
+           # frac: executed lane-ops (v_and + v_bcnt per product, the three-product form's v_or) against the lane peak;
+           # algorithmic_frac: SURVEY 8(d)'s four products per unphased pair, whatever was executed
+           "frac": (2 * products + ors) / k_s / VALU_LANE_PEAK if k_s > 0 else None,
+           "algorithmic_frac": pairs * lane_ops / k_s / VALU_LANE_PEAK if k_s > 0 else None,
            "and_bcnt_ceiling_frac": pairs * lane_ops / 2 / k_s / VALU_PAIR_PEAK if k_s > 0 else None,
-           "executed_frac_of_and_bcnt_ceiling": tm["row_pairs"] * tm["words_per_row"] / k_s / VALU_PAIR_PEAK if k_s > 0 else None,
+           "executed_frac_of_and_bcnt_ceiling": products / k_s / VALU_PAIR_PEAK if k_s > 0 else None,
+           "executed_frac_of_issue_ceiling": (products + ors / 3.0) / k_s / VALU_PAIR_PEAK if k_s > 0 else None,
            "shader_mhz": (tm["count_shader_cycles"] / tm["count_wall_ticks"] * 100.0) if tm["count_wall_ticks"] else None}
     log(f"extra {config}: {res['value'] / 1e6:.1f} M pairs/s, {res['ms_per_step']:.1f} ms/step, count {res['count_kernel_ms_per_step']:.1f} ms, "
         f"and+bcnt {res['and_bcnt_ceiling_frac']}")
@@ -567,9 +594,12 @@ def main():
         lane_ops_per_s = k_pairs * lane_ops_per_pair / k_s if k_ms > 0 else 0.0
         hbm_alg = k_pairs * bytes_per_pair / k_s / 1e9 if k_ms > 0 else 0.0
         words = tm["words_per_row"]
-        # what the kernel actually contracted (whole 128 x 128 tiles: includes the lower half of diagonal
-        # tiles, row padding and, in window mode, the tile corners outside the window)
-        word_pairs_per_s = tm["row_pairs"] * words / k_s if k_ms > 0 else 0.0
+        # what the kernel actually executed (whole 128 x 128 tiles: includes the lower half of diagonal
+        # tiles, row padding and, in window mode, the tile corners outside the window): AND+popcount products and,
+        # in the three-product form, the v_or that form the carrier words
+        products, ors, kernel_name, form = executed_work(tm)
+        word_pairs_per_s = products / k_s if k_ms > 0 else 0.0
+        executed_lane_ops_per_s = (2 * products + ors) / k_s if k_ms > 0 else 0.0
         out = {
             "metric": "variant-pairs/sec all-vs-all LD, 1M samples; achieved HBM GB/s vs roofline",
             "value": value, "unit": "variant-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -578,7 +608,7 @@ def main():
             "config": {"workload": (f"BASELINE {NAMES[args.config]}: {n_samples} samples x {n_variants} variants, "
                                     + (f"windowed +-{window_bp} bp" if window_bp else "all-vs-all")
                                     + f" {mode} genotype LD (calc {'-u' if mode == 'unphased' else '-p'}, r2>={filters.minR2:g}"
-                                    + (f", P<={filters.minP:g}" if filters.minP < 1 else "") + f"), {total_pairs} pairs/step"
+                                    + (f", P<={filters.minP:g}" if filters.minP < 1 else "") + f"), {total_pairs} pairs/step; contraction: {form}"
                                     + (f"; EMULATED shard {args.emulate_shard} only" if args.emulate_shard else "")),
                        "n_samples": n_samples, "n_variants": n_variants, "mode": mode, "tile_variants": args.tile,
                        "partition": (f"equal-area row bands of the pair triangle over {world} GPU(s), "
@@ -588,19 +618,27 @@ def main():
                        "collective_backend": collective,
                        "survivors_per_step": recs_all / args.steps,
                        "two_records_written_per_step": written["records"] / args.steps},
-            "roofline": {"bound": "valu", "achieved": lane_ops_per_s / 1e12, "peak": VALU_LANE_PEAK / 1e12,
-                         "unit": "Tlane-op/s", "frac": lane_ops_per_s / VALU_LANE_PEAK,
+            # achieved / frac: lane-ops the kernel EXECUTED (v_and + v_bcnt per product, plus the three-product form's v_or) - it cannot grow by
+            # counting work that was not done; algorithmic_*: SURVEY 8(d)'s figure per pair (four products per unphased pair) over the same time
+            "roofline": {"bound": "valu", "achieved": executed_lane_ops_per_s / 1e12, "peak": VALU_LANE_PEAK / 1e12,
+                         "unit": "Tlane-op/s", "frac": executed_lane_ops_per_s / VALU_LANE_PEAK,
+                         "algorithmic_achieved": lane_ops_per_s / 1e12, "algorithmic_frac": lane_ops_per_s / VALU_LANE_PEAK,
                          "and_bcnt_ceiling_frac": (lane_ops_per_s / 2) / VALU_PAIR_PEAK,
+                         "contraction_form": form,
                          "traffic": None,
                          "traffic_note": "not measured in this run (rocprofv3 counter passes skipped or unavailable); see profiles/ for the round's figure",
                          # the clock the kernel's blocks really ran at (s_memtime against the constant 100 MHz counter over every block's
                          # life); peak and ceiling above are quoted at the nominal 2.4 GHz
                          "shader_mhz": (tm["count_shader_cycles"] / tm["count_wall_ticks"] * 100.0) if tm["count_wall_ticks"] else None,
-                         "kernel": "twk::k_count_list_t", "launches": int(tm["count_launches"]),
+                         "kernel": kernel_name, "launches": int(tm["count_launches"]),
+                         "three_product_launches": int(tm["three_launches"]), "recounted_candidates": int(tm["recount_candidates"]),
                          "avg_launch_ms": k_ms / max(tm["count_launches"], 1),
                          "algorithmic_lane_ops_per_pair": lane_ops_per_pair,
                          "executed_word_pairs_per_s": word_pairs_per_s,
                          "executed_frac_of_and_bcnt_ceiling": word_pairs_per_s / VALU_PAIR_PEAK,
+                         # ... with the v_or priced at their 2 cycles (a product: 6): the share of the SIMDs' issue cycles the loop's own instructions fill
+                         "executed_frac_of_issue_ceiling": (word_pairs_per_s + (ors / k_s if k_ms > 0 else 0.0) / 3.0) / VALU_PAIR_PEAK,
+                         "executed_or_ops_per_s": ors / k_s if k_ms > 0 else 0.0,
                          "words_per_row": int(words),
                          "hbm_algorithmic": {"achieved": hbm_alg, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                              "frac": hbm_alg / HBM_PEAK_GBS, "bytes_per_pair": bytes_per_pair,
@@ -648,7 +686,7 @@ def main():
                 out["roofline"]["traffic_detail"] = tr
                 out["roofline"]["traffic_note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes over one step of this workload, run "
                                                    "as child processes after the timed region), FETCH_SIZE x2 (gfx950), bytes per launch of "
-                                                   "twk::k_count_list_t; FETCH_SIZE counts the L2s' fabric requests (Infinity-Cache hits "
+                                                   "the count kernel; FETCH_SIZE counts the L2s' fabric requests (Infinity-Cache hits "
                                                    "included): an upper bound on HBM reads")
         if world == 1 and not args.no_e2e and args.config == "cfg3" and not args.emulate_shard:
             eng.close()                  # the CLI gets the whole GPU
@@ -664,7 +702,8 @@ def main():
             # region, like cpu_baseline / e2e): each with its pairs/s, dominant kernel, average launch and roofline fraction.
             eng.close()
             extra = {}
-            for name, fn in (("cfg2", lambda: extra_in_process("cfg2", log, steps=20, warmup=3)),
+            for name, fn in (("cfg3_four_product", lambda: extra_in_process("cfg3", log, steps=2, warmup=1, options=(("three", 0),))),
+                             ("cfg2", lambda: extra_in_process("cfg2", log, steps=20, warmup=3)),
                              ("cfg5_shard", lambda: extra_in_process("cfg5", log, steps=1, warmup=0, emulate_shard=(3, 8))),
                              ("e2e_u", lambda: e2e_from_disk(n_samples, args.e2e_variants or n_variants, log, flags=("-u",), tag="e2e_u")),
                              ("kg", lambda: extra_kg(log))):

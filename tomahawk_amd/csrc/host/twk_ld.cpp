@@ -677,11 +677,14 @@ bool twk_ld::twk_ld_impl::run(twk_ld_settings& settings, const Header& hdr, cons
 		if (twk_hip_timing_get(ctxs[g], &tm) == TWK_HIP_OK)
 			std::cerr << stamp("LOG", "HIP") << (n_gpus > 1 ? "GPU " + std::to_string(g) + ": " : std::string()) << "count kernel " << tm.count_ms << " ms in "
 			          << tm.count_launches << " launches ("
-			          << (tm.count_ms > 0 ? (double)tm.row_pairs * (double)tm.words_per_row / (tm.count_ms * 1e-3) / 2.62e13 * 100.0 : 0.0)
+			          // what the launches issued: one AND+popcount (6 cycles per wave) per word of a plane-row pair - three for every four of them in
+			          // the three-product form, plus one v_or (2 cycles) per four of its products
+			          << (tm.count_ms > 0 ? ((double)(tm.row_pairs - tm.three_row_pairs) + (double)tm.three_row_pairs * (0.75 + 0.75 / 4.0 / 3.0)) * (double)tm.words_per_row / (tm.count_ms * 1e-3) / 2.62e13 * 100.0 : 0.0)
 			          << " % of the and+bcnt issue ceiling over the tiles it contracted"
 			          << (tm.count_wall_ticks ? "; its blocks ran at " + std::to_string((int)((double)tm.count_shader_cycles / (double)tm.count_wall_ticks * 100.0 + 0.5)) + " MHz" : std::string())
 			          << "), math kernels " << tm.stats_ms << " ms"
 			          << (tm.fused_launches ? "; " + std::to_string(tm.fused_launches) + " launches fused count -> r2 screen, " + pretty(tm.candidates) + " candidate slots" : std::string())
+			          << (tm.three_launches ? "; " + std::to_string(tm.three_launches) + " launches in the three-product form (HH + S), " + pretty(tm.recount_candidates) + " candidates recounted" : std::string())
 			          << (tm.list_launches ? "; carrier-list kernel " + std::to_string(tm.list_ms) + " ms in " + std::to_string(tm.list_launches) + " launches over " + pretty(tm.list_pairs) + " rare pairs" : std::string())
 			          << (tm.probe_launches ? "; probe kernel " + std::to_string(tm.probe_ms) + " ms in " + std::to_string(tm.probe_launches) + " launches over " + pretty(tm.probe_pairs) + " rare x common pairs" : std::string())
 			          << std::endl;
