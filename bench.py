@@ -380,6 +380,88 @@ def extra_in_process(config, log, steps, warmup, seed=42, emulate_shard=None, op
     return res
 
 
+def record_hashes(recs):
+    """One 64-bit hash per 104-byte record (numpy, wrap-around arithmetic): every 8-byte word multiplied by its own odd
+    constant, folded, summed over the record's 13 words and mixed again.  A set of records is summarised by the wrap-around SUM
+    of these - independent of the order the records arrive in, additive over shards."""
+    import numpy as np
+    w = np.ascontiguousarray(recs).view(np.uint64).reshape(len(recs), -1)
+    k = (np.arange(1, w.shape[1] + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)) | np.uint64(1)
+    with np.errstate(over="ignore"):
+        x = w * k
+        x ^= x >> np.uint64(29)
+        x *= np.uint64(0xBF58476D1CE4E5B9)
+        h = x.sum(axis=1, dtype=np.uint64)
+        h ^= h >> np.uint64(32)
+        h *= np.uint64(0x94D049BB133111EB)
+    return h
+
+
+def gather_check(eng, rank, world, xdev, gather_group, collective, seed, log):
+    """N > 1, after the timed region: does the gather move records, and the right ones?  The headline workload has no survivors
+    (iid genotypes, r2 >= 0.1), so its gather carries one count per rank and nothing else.  Here one step of a small, survivor-rich
+    workload (2,000 samples x 4,096 variants, r2 >= 0.0005) runs through the same calls as a timed step - row band of this rank,
+    survivors kept in HBM, gathered to rank 0 over the group that carried the timed gathers (RCCL when it came up) - and the result is
+    checked against what every rank knows by itself: each rank copies its own survivors to its own host memory (plain D2H, no
+    collective), hashes them, and the per-rank counts and hash sums travel over the gloo control group; rank 0 hashes every
+    rank's slice of the gathered buffer and compares.  -> dict for extra.gather_check (rank 0), None elsewhere."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import tomahawk_amd as T
+    from tomahawk_amd.dist import LAST_GATHER, gather_records
+    n_samples, n_variants = 2000, 4096
+    t0 = time.perf_counter()
+    eng.set_problem(n_samples, n_variants)
+    eng.generate_synthetic(seed)
+    eng.set_device_sink(True)
+    filters = T.Filters(minR2=0.0005)
+    _, npairs, nrec = eng.ld_all(T.MODE_UNPHASED, filters, part=rank, n_parts=world)
+    dev_recs = eng.device_records_tensor()
+    assert dev_recs.numel() == nrec * T.RECORD_DTYPE.itemsize
+    torch.cuda.synchronize()
+    own = dev_recs.cpu().numpy().view(T.RECORD_DTYPE).copy()            # this rank's survivors, by its own D2H copy
+    with np.errstate(over="ignore"):
+        own_sum = int(record_hashes(own).sum(dtype=np.uint64)) if len(own) else 0
+    dist.barrier()
+    t1 = time.perf_counter()
+    got = gather_records(dev_recs, dst=0, device=xdev, group=gather_group)
+    t2 = time.perf_counter()
+    xfer_s, xfer_bytes = LAST_GATHER["seconds"], LAST_GATHER["bytes"]
+    # what every rank knows of its own shard, over the control group (int64 carries the 64 bits)
+    mine = torch.tensor([len(own), own_sum - (1 << 64) if own_sum >= (1 << 63) else own_sum, npairs], dtype=torch.int64)
+    every = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine)
+    me = torch.tensor([rank], dtype=torch.int64, device=xdev)
+    seen = [torch.zeros_like(me) for _ in range(world)]
+    dist.all_gather(seen, me, group=gather_group)
+    eng.set_device_sink(False)
+    if rank != 0:
+        return None
+    counts = [int(e[0].item()) for e in every]
+    sums = [int(e[1].item()) % (1 << 64) for e in every]
+    pairs = sum(int(e[2].item()) for e in every)
+    equal_per_rank, off = [], 0
+    ok_len = got is not None and len(got) == sum(counts)
+    for r in range(world):
+        if not ok_len:
+            equal_per_rank.append(False)
+            continue
+        sl = got[off:off + counts[r]]
+        off += counts[r]
+        with np.errstate(over="ignore"):
+            h = int(record_hashes(sl).sum(dtype=np.uint64)) if len(sl) else 0
+        equal_per_rank.append(h == sums[r])
+    res = {"workload": f"{n_samples} samples x {n_variants} variants, calc -u, r2>={filters.minR2:g}: one step after the timed region",
+           "backend": collective, "ranks_seen": sorted(int(x.item()) for x in seen), "pairs": pairs, "records": sum(counts),
+           "records_per_rank": counts, "bytes": xfer_bytes, "seconds": xfer_s, "GBps": (xfer_bytes / xfer_s / 1e9) if xfer_s > 0 and xfer_bytes else None,
+           "equal": bool(ok_len and all(equal_per_rank)), "equal_per_rank": equal_per_rank,
+           "hash": "per rank: wrap-around sum of a 64-bit hash per 104-byte record, own D2H copy vs that rank's slice of the gathered buffer",
+           "wall_s": time.perf_counter() - t0, "gather_wall_s": t2 - t1}
+    log(f"gather_check: {res['records']} records, {xfer_bytes / 1e6:.1f} MB over {collective.split(' ')[0]} in {xfer_s * 1e3:.1f} ms, equal={res['equal']}")
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -400,6 +482,7 @@ def main():
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 counter passes behind roofline.traffic (N=1)")
     ap.add_argument("--no-extra", action="store_true", help="skip the other regimes reported under \"extra\" (N=1, cfg3): configs[1], a "
                     "configs[4] shard, calc -u from disk, the reference's published 2,504 x 531,500 runs")
+    ap.add_argument("--no-gather-check", action="store_true", help="skip the survivor-rich gather self-check that follows the timed region when N > 1")
     ap.add_argument("--e2e-variants", type=int, default=0, help="variants of the e2e input (0: the config's own count)")
     ap.add_argument("--engine-option", action="append", default=[], metavar="KEY=INT", help="a switch of the engine "
                     "(twk_hip_set_option, include/twk_hip.h; measurement runs of profiles/collect.sh)")
@@ -577,6 +660,13 @@ def main():
         seen = [torch.zeros_like(me) for _ in range(world)]
         dist.all_gather(seen, me, group=gather_group)
         ranks_seen = sorted(int(x.item()) for x in seen)
+    gcheck = None
+    if world > 1 and not args.no_gather_check:
+        try:
+            gcheck = gather_check(eng, rank, world, xdev, gather_group, collective, args.seed, log)
+        except Exception as e:           # a failed check is reported, on every rank alike, not hidden
+            gcheck = {"equal": False, "error": repr(e)[:300]} if rank == 0 else None
+            log(f"gather_check failed: {e!r}")
     elapsed_max, count_ms_max, stats_ms_max = (float(x) for x in stats.tolist())
     pairs_all, recs_all, launches_all, row_pairs_all = (float(x) for x in sums.tolist())
     if not args.emulate_shard:
@@ -655,6 +745,8 @@ def main():
             "gather_GBps": (phase["xfer_bytes"] / phase["xfer"] / 1e9) if phase["xfer"] > 0 and phase["xfer_bytes"] else None,   # over the transfers alone
             "ranks_seen": ranks_seen,
         }
+        if gcheck is not None:
+            out["extra"] = {"gather_check": gcheck}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 cb = cpu_baseline(n_samples, mode, args.seed, log)

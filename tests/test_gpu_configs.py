@@ -525,6 +525,13 @@ def test_bench_with_eight_ranks_on_one_gpu_equals_one_rank(tmp_path, config, ext
     assert d8["gather_ms"] >= 0 and d8["write_ms"] > 0 and all(x > 0 for x in d8["per_rank_ms"])
     assert 0 < d8["gather_bytes"] <= 104 * d8["config"]["survivors_per_step"] and d8["gather_GBps"] > 0
     assert d8["config"]["collective_backend"] == "gloo"
+    # the survivor-rich self-check that follows the timed region of every N > 1 run (bench.py gather_check): what the driver's
+    # multi-GPU run will show of the gather even though the headline workload has no survivors to send
+    gc = d8["extra"]["gather_check"]
+    assert gc["equal"] is True and gc["equal_per_rank"] == [True] * 8 and gc["ranks_seen"] == list(range(8)), gc
+    assert gc["records"] == sum(gc["records_per_rank"]) > 10_000 and gc["bytes"] == 104 * (gc["records"] - gc["records_per_rank"][0]) and gc["GBps"] > 0
+    assert gc["pairs"] == 4096 * 4095 // 2 and gc["wall_s"] < 20 and gc["backend"] == "gloo"
+    assert "extra" not in d1
     assert d1["config"]["survivors_per_step"] == d8["config"]["survivors_per_step"] > 1000
     assert len(one) == len(eight) == 2 * d1["config"]["survivors_per_step"]
     order = ["ridA", "packA", "ridB", "packB"]
@@ -557,6 +564,8 @@ def test_rccl_gather_between_gpus_equals_one_rank(tmp_path, config, extra):
     assert "RCCL gather" in dn["config"]["partition"]
     assert d1["config"]["survivors_per_step"] == dn["config"]["survivors_per_step"] > 1000
     assert dn["gather_bytes"] > 0 and dn["gather_GBps"] and dn["gather_GBps"] > 0
+    gc = dn["extra"]["gather_check"]
+    assert gc["equal"] is True and gc["backend"] == "nccl" and gc["ranks_seen"] == list(range(world)) and gc["bytes"] > 0, gc
     assert len(one) == len(many) == 2 * d1["config"]["survivors_per_step"]
     order = ["ridA", "packA", "ridB", "packB"]
     assert np.sort(one, order=order).tobytes() == np.sort(many, order=order).tobytes()
