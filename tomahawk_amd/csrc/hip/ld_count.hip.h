@@ -596,7 +596,8 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 	const int tid  = threadIdx.x;
 	const int lane = tid & 63;
 	const int wave = tid >> 6;
-	const int wr = wave / WC, wc = wave % WC;
+	const int wave_u = __builtin_amdgcn_readfirstlane(wave);      // (wave-uniform: lives in a scalar register, and so do the wave's tile coordinates)
+	const int wr = wave_u / WC, wc = wave_u % WC;
 	const int li = lane >> 3, lj = lane & 7;
 	const uint32_t nchunks = w.W / KC;
 	const uint32_t n_units = w.n_units;
@@ -650,20 +651,36 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 	constexpr bool PAIRED = Epilogue::PAIRED_ROWS;
 	constexpr bool THREE = Epilogue::THREE_PRODUCTS;      // the three-product form of the plain unphased planes (contract3_half)
 	static_assert(!THREE || (PAIRED && TB == 4), "the three-product form needs a variant's H and Q rows in one lane");
-	uint32_t offA[8], offB[8];
+	// The per-lane LDS read offsets and DMA source offsets of the K loop.  For the fused epilogues they are recomputed when a unit ends
+	// instead of being held through the epilogue: the epilogue is where the kernels' register demand peaks, and what the allocator evicts
+	// there it reloads from scratch inside the K loop (round 5: sixteen spilled offsets, scratch loads between the half-slots).  The lane
+	// id comes fresh from the hardware (volatile asm), so the recomputation is not hoisted back in front of the loop.
+	uint32_t offA[8], offB[8], voff_even, voff_odd;
+	auto lane_offsets = [&](bool fresh) {
+		uint32_t ln = (uint32_t)lane;
+		if (fresh) asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+		const uint32_t li_ = ln >> 3, lj_ = ln & 7u;
 #pragma unroll
-	for (int k = 0; k < 8; ++k) {
-		if (PAIRED) {      // rows 2 li + (t & 1) + 16 (t >> 1): (row >> 1) & 7 = li for every t
-			offA[k] = (uint32_t)((wr * 64 + 2 * li) * (KC * 4) + ((li ^ k) << 4));
-			offB[k] = (uint32_t)(LDS_TILE_BYTES + (wc * 8 * TB + 2 * lj) * (KC * 4) + ((lj ^ k) << 4));
-		} else {
-			offA[k] = (uint32_t)((wr * 64 + li) * (KC * 4) + (((li >> 1) ^ k) << 4));
-			offB[k] = (uint32_t)(LDS_TILE_BYTES + (wc * 8 * TB + lj) * (KC * 4) + (((lj >> 1) ^ k) << 4));
+		for (int k = 0; k < 8; ++k) {
+			if (PAIRED) {      // rows 2 li + (t & 1) + 16 (t >> 1): (row >> 1) & 7 = li for every t
+				offA[k] = (uint32_t)((wr * 64 + 2 * li_) * (KC * 4) + ((li_ ^ k) << 4));
+				offB[k] = (uint32_t)(LDS_TILE_BYTES + (wc * 8 * TB + 2 * lj_) * (KC * 4) + ((lj_ ^ k) << 4));
+			} else {
+				offA[k] = (uint32_t)((wr * 64 + li_) * (KC * 4) + (((li_ >> 1) ^ k) << 4));
+				offB[k] = (uint32_t)(LDS_TILE_BYTES + (wc * 8 * TB + lj_) * (KC * 4) + (((lj_ >> 1) ^ k) << 4));
+			}
 		}
-	}
+		// DMA source offsets: lane's row within an 8-row segment and its (swizzled) 16-byte slot, see stage_rows_s
+		voff_even = (li_ * w.W + ((lj_ ^ (li_ >> 1)) << 2)) << 2;
+		voff_odd  = (li_ * w.W + ((lj_ ^ (li_ >> 1) ^ 4u) << 2)) << 2;
+	};
+	lane_offsets(false);
 	constexpr int ODD = PAIRED ? 0 : 4;          // what the slot index of an odd t / u is XORed with (see the offA table)
 
-	const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+	// The lane id, fresh from the hardware: what the loop needs of it per unit (thread 0's ticket, the epilogue's rows and columns) is
+	// derived where it is used instead of being held in registers through the K loop.
+	auto fresh_lane = [&]() -> uint32_t { uint32_t ln; asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln)); return ln; };
+	auto thread0 = [&]() -> bool { return wave_u == 0 && fresh_lane() == 0; };
 	const bool st_isB = wave_u >= NW / 2;
 	const int st_seg0 = (wave_u % (NW / 2)) * NSEG;
 	const uint32_t lds_base = (uint32_t)(uintptr_t)(lptr_t*)lds;
@@ -673,9 +690,6 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 		return st_isB ? w.rowB0 + (yx & 0xFFFFu) * TILE : w.rowA0 + (yx >> 16) * TILE;
 	};
 
-	const uint32_t lr = (uint32_t)lane >> 3, ls = (uint32_t)lane & 7u;
-	const uint32_t voff_even = (lr * w.W + ((ls ^ (lr >> 1)) << 2)) << 2;
-	const uint32_t voff_odd  = (lr * w.W + ((ls ^ (lr >> 1) ^ 4u) << 2)) << 2;
 	uint32_t st_row0 = stage_row0(tile_yx);
 	stage_rows_s(w.rows, w.W, st_row0, c, st_lds, st_seg0, NSEG, voff_even, voff_odd);
 	uint32_t seg_c0 = c;
@@ -686,7 +700,7 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 	for (;;) {
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		// the ticket fetched one iteration ago has arrived with everything else: publish it
-		if (want_next && tid == 0) mbox[n_started & 1u] = fetched;
+		if (want_next && thread0()) mbox[n_started & 1u] = fetched;
 		__syncthreads();
 		if (want_next) { unit_next = __builtin_amdgcn_readfirstlane(mbox[n_started & 1u]); want_next = false; }
 		if (unit_start) {
@@ -696,7 +710,7 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 			// unit has to wait for it here.  A block thus never holds more than its current and next unit,
 			// which keeps the slow block of a CU from sitting on big units drawn long ago.
 			++n_started;
-			if (tid == 0) fetched = draw();
+			if (thread0()) fetched = draw();
 			if (META) {
 				if (wave_u < META / 64) {
 					const uint32_t yx_m = tile_yx;
@@ -711,7 +725,7 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 				if (c + 1 == c_end) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // a one-chunk unit needs it in this very iteration: the barrier below publishes it
 			}
 			if (c + 1 == c_end) {
-				if (tid == 0) mbox[n_started & 1u] = fetched;
+				if (thread0()) mbox[n_started & 1u] = fetched;
 				__syncthreads();
 				unit_next = __builtin_amdgcn_readfirstlane(mbox[n_started & 1u]);
 			} else {
@@ -776,15 +790,19 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 
 		if (c + 1 == c_end) {          // unit done: write (whole tile) or add (part of a tile's K range) - or screen (fused form)
 			const uint32_t yx = tile_yx;
-			if (EXPERIMENT != 6) epilogue(acc, yx, wr, wc, li, lj, lane, seg_c0 == 0 && c_end == nchunks, meta, window);      // (6: the dev tool's no-epilogue timing)
+			if (EXPERIMENT != 6) {      // (6: the dev tool's no-epilogue timing)
+				const uint32_t ln = META ? fresh_lane() : (uint32_t)lane;
+				epilogue(acc, yx, wr, wc, (int)(ln >> 3), (int)(ln & 7u), (int)ln, seg_c0 == 0 && c_end == nchunks, meta, window);
+			}
+			if (META) lane_offsets(true);
 			if (!more) {
-				epilogue.finish(window, lane);
-				if (tid == 0 && w.clocks) {
+				epilogue.finish(window, (int)fresh_lane());
+				if (thread0() && w.clocks) {
 					typedef __attribute__((address_space(1))) unsigned long long g_u64;
 					__hip_atomic_fetch_add((g_u64*)w.clocks, clock64() - probe_clk0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 					__hip_atomic_fetch_add((g_u64*)w.clocks + 1, wall_clock64() - probe_wall0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				}
-				if (EXPERIMENT == 5 && tid == 0) {      // probe: when did this block finish, and on which XCD / CU?
+				if (EXPERIMENT == 5 && thread0()) {      // probe: when did this block finish, and on which XCD / CU?
 					uint32_t xcc, hwid;
 					asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
 					asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
@@ -959,6 +977,9 @@ struct ScreenCounts {
 				m |= (ok ? 1u : 0u) << (4 * t + u);
 			}
 		}
+		// (Round 5 tried an FP32 prefilter in front of this test, as ScreenCountsUnphased has one: with six FP64 operations per pair there is
+		// too little to save - the all-pairs run of 2,504 x 200,000 went from 145.1 to 147.0 ms, the survivor-rich window run from 15.5 to
+		// 16.7 ms, profiles/r05_fused_epilogue.txt - so PhasedMath's screen stays exact from the start.)
 		if (__ballot(m != 0)) {          // (most tiles of unlinked variants end here)
 			const uint32_t cnt = __popc(m);
 			const uint32_t incl = wave_scan_inclusive(cnt);
@@ -1036,37 +1057,72 @@ struct ScreenCountsUnphased {
 		//     ((f11 - P Q) T^2)^2 >= cut a ra b rb.
 		const double T2n = s.two_n, cut = s.cut, eps = 1e-5 * (T2n * T2n);
 		const bool diag = s.diag != 0;
-		uint32_t vB[2]; bool okB[2]; double db[2], rb[2], fB[2];
+		// Prefilter in FP32 (round 5, as in ScreenCounts).  Divided by T the two ends of the interval read
+		//     e_lo / T = S - da db / T - eps',   e_hi / T = e_lo / T + HH + 2 eps'      (eps' = 1e-5 T; n11 - ra rb / T = S - da db / T),
+		// and the pair can pass only if max(e_hi, -e_lo) / T >= sqrt(cut da ra db rb) / T = sA * sB[v]: two converts, one fma, three adds, a
+		// max, a multiply and a compare per pair.  S, HH, da, db <= 2N are exact in FP32 below 2^24; the rest is covered by `slack` as there.
+		// Only pairs the prefilter lets through reach the exact FP64 test, so the candidates are those of the exact test alone.
+		const float Tf = (float)T2n, invT = __builtin_amdgcn_rcpf(Tf), epsf = 1e-5f * Tf, slack = 0.5f + Tf * (1.0f / 1048576.0f);
+		// (everything the lane needs of the staged block in one go, as in ScreenCounts)
+		uint32_t rawB[2][2], rawA[4][2], rawH[4];
+#pragma unroll
+		for (int v = 0; v < 2; ++v) { const int colB = TILE + wc * 8 * TB + 2 * lj + 16 * v; rawB[v][0] = meta[colB]; rawB[v][1] = meta[colB + 1]; }      // plane columns of the variant's H / Q rows within the tile
+#pragma unroll
+		for (int sI = 0; sI < 4; ++sI) { const int rowA = wr * 64 + 2 * li + 16 * sI; rawA[sI][0] = meta[rowA]; rawA[sI][1] = meta[rowA + 1]; rawH[sI] = meta[2 * TILE + wr * 32 + li + 8 * sI]; }
+		const bool banded = s.col_hi != nullptr;
+		const uint32_t hi_b0 = s.hi_b0, endA = s.a0 + s.nA, endB = s.b0 + s.nB, n_variants = s.n_variants, list_zone = s.list_zone, probe_zone = s.probe_zone;
+		uint32_t vB[2]; float dbf[2], sBf[2];
 #pragma unroll
 		for (int v = 0; v < 2; ++v) {
 			vB[v] = vB0 + 8 * v;
-			okB[v] = vB[v] < s.b0 + s.nB && vB[v] < s.n_variants;
-			const int colB = TILE + wc * 8 * TB + 2 * lj + 16 * v;         // plane column of the variant's H row within the tile
-			const uint32_t hB = okB[v] ? meta[colB] : 0u, qB = okB[v] ? meta[colB + 1] : 0u;
-			db[v] = (double)(hB + 2u * qB); rb[v] = T2n - db[v]; fB[v] = db[v] * rb[v];
+			const bool okB = vB[v] < endB && vB[v] < n_variants;
+			dbf[v] = (float)(okB ? rawB[v][0] + 2u * rawB[v][1] : 0u);
+			sBf[v] = __builtin_amdgcn_sqrtf(dbf[v] * (Tf - dbf[v]));
+			if (!okB) vB[v] = 0xFFFFFFFFu;                                  // (beyond every row's reach)
 		}
-		uint32_t m = 0;                  // bit 2 sI + v: the pair (row variant sI, column variant v) is a candidate
+		uint32_t mp = 0;                 // bit 2 sI + v: the pair passes the prefilter
 #pragma unroll
 		for (int sI = 0; sI < 4; ++sI) {
 			const uint32_t vA = vA0 + 8 * sI;
-			const bool okA = vA < s.a0 + s.nA && vA < s.n_variants;
-			const int rowA = wr * 64 + 2 * li + 16 * sI;
-			const uint32_t hA = okA ? meta[rowA] : 0u, qA = okA ? meta[rowA + 1] : 0u;
-			const uint32_t hi = !okA ? 0u : (s.col_hi ? s.hi_b0 + meta[2 * TILE + wr * 32 + li + 8 * sI] : 0xFFFFFFFFu);
-			const double da = (double)(hA + 2u * qA), ra = T2n - da;
-			const double fA = cut * (da * ra);
+			const bool okA = vA < endA && vA < n_variants;
+			const float daf = (float)(okA ? rawA[sI][0] + 2u * rawA[sI][1] : 0u), paf = daf * invT;
+			const float sAf = __builtin_amdgcn_sqrtf((float)cut * (daf * (Tf - daf))) * invT * (1.0f - 1.0f / 65536.0f);
+			uint32_t hi = banded ? hi_b0 + rawH[sI] : 0xFFFFFFFFu;
+			if (!okA || vA < probe_zone) hi = 0;
+			uint32_t lo = diag ? vA + 1 : 0u;
+			if (vA < list_zone && lo < list_zone) lo = list_zone;
+			const uint32_t width = hi > lo ? hi - lo : 0u;
 #pragma unroll
 			for (int v = 0; v < 2; ++v) {
 				const uint32_t hh = acc[2 * sI][2 * v];
 				const uint32_t s_sum = THREE ? acc[2 * sI + 1][2 * v + 1] : acc[2 * sI + 1][2 * v] + acc[2 * sI][2 * v + 1] + 2u * acc[2 * sI + 1][2 * v + 1];      // QH + HQ + 2 QQ
-				// n11 = ra - b + (QH + HQ + 2 QQ): the (REF, REF) haplotypes that are certain
-				const double n11 = (ra - db[v]) + (double)s_sum;
-				const double e_lo = (n11 * T2n - ra * rb[v]) - eps;
-				const double e_hi = ((n11 + (double)hh) * T2n - ra * rb[v]) + eps;
-				const double bound = fA * fB[v];
-				const bool ok = okA && okB[v] && (!diag || vB[v] > vA) && vB[v] < hi && !((vA < s.list_zone && vB[v] < s.list_zone) || vA < s.probe_zone)
-				                && !(e_lo * e_lo < bound && e_hi * e_hi < bound);
-				m |= (ok ? 1u : 0u) << (2 * sI + v);
+				const float q = __builtin_fmaf(-paf, dbf[v], (float)s_sum);      // S - da db / T
+				const float e = __builtin_fmaxf(q + ((float)hh + epsf), epsf - q);
+				const bool ok = (vB[v] - lo) < width && e + slack >= sAf * sBf[v];
+				mp |= (ok ? 1u : 0u) << (2 * sI + v);
+			}
+		}
+		uint32_t m = 0;                  // bit 2 sI + v: the pair (row variant sI, column variant v) is a candidate
+		if (__ballot(mp != 0)) {
+#pragma unroll
+			for (int sI = 0; sI < 4; ++sI) {
+				if (!((mp >> (2 * sI)) & 3u)) continue;
+				const double da = (double)(rawA[sI][0] + 2u * rawA[sI][1]), ra = T2n - da;
+				const double fA = cut * (da * ra);
+#pragma unroll
+				for (int v = 0; v < 2; ++v) {
+					if (!((mp >> (2 * sI + v)) & 1u)) continue;
+					const uint32_t hh = acc[2 * sI][2 * v];
+					const uint32_t s_sum = THREE ? acc[2 * sI + 1][2 * v + 1] : acc[2 * sI + 1][2 * v] + acc[2 * sI][2 * v + 1] + 2u * acc[2 * sI + 1][2 * v + 1];
+					// n11 = ra - b + (QH + HQ + 2 QQ): the (REF, REF) haplotypes that are certain
+					const double dbv = (double)dbf[v], rbv = T2n - dbv;
+					const double n11 = (ra - dbv) + (double)s_sum;
+					const double e_lo = (n11 * T2n - ra * rbv) - eps;
+					const double e_hi = ((n11 + (double)hh) * T2n - ra * rbv) + eps;
+					const double bound = fA * (dbv * rbv);
+					const bool ok = !(e_lo * e_lo < bound && e_hi * e_hi < bound);
+					m |= (ok ? 1u : 0u) << (2 * sI + v);
+				}
 			}
 		}
 		if (__ballot(m != 0)) {
@@ -1104,24 +1160,24 @@ struct ScreenCountsUnphased {
 // 4 % of the kernel (19.4 -> 18.6 ms).  The unphased form is at its register limit: there the copy's addresses cost three
 // spills that land in the candidate loop (48 -> 115 ms on the same run), so it reads the block where it is.
 static_assert(sizeof(ScreenWork) % 4 == 0 && sizeof(ScreenWork) / 4 <= 64, "copied by the first wave, one dword per lane");
-template <int NW>
+template <int NW, int EXPERIMENT = 0>      // (EXPERIMENT == 6: the dev tool's no-epilogue timing)
 __global__ __launch_bounds__(NW * 64, NW / 2)
 void k_count_screen_t(const CountWork w, const ScreenWork* sw) {
-	__shared__ ScreenWork sw_lds;
+	__shared__ ScreenWork sw_lds;      // (re-measured in round 5 against reading the block where it lies: 84.6 against 84.1 % at five chunks a tile, 76.9 against 75.5 % at three)
 	if (threadIdx.x < sizeof(ScreenWork) / 4) reinterpret_cast<uint32_t*>(&sw_lds)[threadIdx.x] = reinterpret_cast<const uint32_t*>(sw)[threadIdx.x];
 	__syncthreads();
-	count_list_body<NW, 0>(w, ScreenCounts<16 / (NW / 2)>{&sw_lds});
+	count_list_body<NW, EXPERIMENT>(w, ScreenCounts<16 / (NW / 2)>{&sw_lds});
 }
-template <int NW>
+template <int NW, int EXPERIMENT = 0>
 __global__ __launch_bounds__(NW * 64, NW / 2)
 void k_count_screen_unphased_t(const CountWork w, const ScreenWork* sw) {
-	count_list_body<NW, 0>(w, ScreenCountsUnphased<16 / (NW / 2)>{sw});
+	count_list_body<NW, EXPERIMENT>(w, ScreenCountsUnphased<16 / (NW / 2)>{sw});
 }
 
-template <int NW>
+template <int NW, int EXPERIMENT = 0>
 __global__ __launch_bounds__(NW * 64, NW / 2)
 void k_count3_screen_unphased_t(const CountWork w, const ScreenWork* sw) {
-	count_list_body<NW, 0>(w, ScreenCountsUnphased<16 / (NW / 2), true>{sw});
+	count_list_body<NW, EXPERIMENT>(w, ScreenCountsUnphased<16 / (NW / 2), true>{sw});
 }
 
 // Zero the tiles [first, n_tiles) of the list (the ones whose K range is split into several units).  tile_rows: rows of C a

@@ -1001,8 +1001,12 @@ int finish_tile(twk_hip_ctx* c, Slot& s, const twk_hip_tile_desc& t, unsigned lo
 			snprintf(c->err, sizeof(c->err), "three-product contraction: %llu candidates whose (HH, S) differ from their recounted products (tile rows %u+%u, cols %u+%u)", s.h_n_out[3], t.rowA0, t.nA, t.rowB0, t.nB);
 			return TWK_HIP_E_DEVICE;
 		}
-		// a launch this rich in candidates pays more for their recount than the fourth product costs: the rest of the call in the four-product forms
-		if (c->opt.three != 2 && s.h_n_out[2] > std::max<unsigned long long>(pairs_in_tile(c, t) / 32, 4096)) c->three_ok = false;
+		// A launch this rich in candidates pays more for their recount than the fourth product costs: the rest of the call in the four-product
+		// forms.  Measured at 2,504 samples, -u -w 1000000 (2.9 % of the pairs candidates): count kernel 32.1 -> 27.3 ms, but 58 M recounts at
+		// 0.16 ns each (four 320-byte rows from L2 per candidate: 8 TB/s) add 9.3 ms to the math; the two meet near 1.2 %.
+		// (against the variant pairs of the tiles the launch contracted - four plane-row pairs each - not the launch's rectangle: a window
+		// launch's rectangle is mostly outside the window)
+		if (c->opt.three != 2 && s.h_n_out[2] > std::max<unsigned long long>(s.row_pairs / 4 / 128, 4096)) c->three_ok = false;
 	}
 	float ms_all = 0;
 	if (s.two_pass) {

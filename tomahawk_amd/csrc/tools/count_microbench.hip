@@ -27,6 +27,8 @@ int main(int argc,char**argv){
   uint32_t P = argc>4? atoi(argv[4]) : 512;      // persistent blocks
   size_t nw=(size_t)R*W;
   std::vector<uint32_t> h(nw); std::mt19937 rng(1); for(auto&x:h) x=rng();
+  if(getenv("FUSED") && getenv("LIVE")) for(uint32_t r=0;r<R;++r) for(uint32_t k=atoi(getenv("LIVE"));k<W;++k) h[(size_t)r*W+k]=0;      // zero padding behind the live words
+  if(getenv("FUSED")) for(uint32_t r=1;r<R;r+=2) for(uint32_t k=0;k<W;++k) h[(size_t)r*W+k] &= ~h[(size_t)(r-1)*W+k];   // rows 2v / 2v + 1 as a variant's H / Q planes: disjoint
   uint32_t *d,*C,*dl; twk::CountUnit* du; CK(hipMalloc(&d,nw*4)); CK(hipMalloc(&C,(size_t)R*R*4)); CK(hipMalloc(&dl,(size_t)(R/128)*(R/128)*4)); CK(hipMalloc(&du,(size_t)(R/128)*(R/128)*64*16+65536));
   const uint32_t min_chunks = getenv("MINCHUNKS")? atoi(getenv("MINCHUNKS")) : 8; uint32_t first_split=0; std::vector<twk::CountUnit> units;
   CK(hipMemcpy(d,h.data(),nw*4,hipMemcpyHostToDevice)); CK(hipMemset(C,0xff,(size_t)R*R*4));
@@ -89,6 +91,41 @@ int main(int argc,char**argv){
       printf("  XCD %d: %3d blocks, finish offset min %.1f mean %.1f max %.1f us\n",x,n,mn,n?sum/n:0,mx); }
     // same-CU pairs
     printf("  first 16 blocks: "); for(uint32_t b=0;b<16;++b) printf("[b%u xcc%llu hw%05llx t%.0f] ",b,o[2*b+1]>>32&15,o[2*b+1]&0xFFFFF,(o[2*b]-t0)/100.0); printf("\n");
+    return 0;
+  }
+  if(getenv("FUSED")){   // the fused count -> screen kernels on whole tiles (short rows), with their epilogue and without it (EXPERIMENT 6):
+    // what does the screen cost next to the K loop?  Random rows, so nothing passes the screen.  LIVE=<words>: the row's live words (last chunk cut short)
+    std::vector<uint32_t> list=make_list(R/128,0,true); CK(hipMemcpy(dl,list.data(),list.size()*4,hipMemcpyHostToDevice));
+    const uint32_t live = getenv("LIVE")? atoi(getenv("LIVE")) : W;
+    twk::CountWork w{}; w.rows=d; w.W=W; w.tiles=dl; w.C=C; w.ldc=R; w.ticket=tick;
+    { const uint32_t live_last = live - (W/twk::KC - 1)*twk::KC; w.last_halves = (live<W && W-live<twk::KC) ? (live_last+1)/2 : 0; if(w.last_halves>12) w.last_halves=0; }
+    twk::build_count_units((uint32_t)list.size(),W/twk::KC,P,W/twk::KC+1,units,8,8); twk::fill_unit_tiles(units,list.data());
+    CK(hipMemcpy(du,units.data(),units.size()*16,hipMemcpyHostToDevice)); w.units=du; w.n_units=(uint32_t)units.size(); w.n_queues=1; w.queue_begin[0]=0; w.queue_begin[1]=w.n_units;
+    std::vector<uint32_t> pop(R+256); for(uint32_t r=0;r<R;++r){ uint32_t c=0; for(uint32_t k=0;k<W;++k) c+=__builtin_popcount(h[(size_t)r*W+k]); pop[r]=c; }
+    uint32_t* dpop; CK(hipMalloc(&dpop,pop.size()*4)); CK(hipMemcpy(dpop,pop.data(),pop.size()*4,hipMemcpyHostToDevice));
+    unsigned long long* dn; CK(hipMalloc(&dn,64)); CK(hipMemset(dn,0,64));
+    twk::ScreenWork sw{}; sw.rowpop=dpop; sw.a0=0; sw.b0=0; sw.n_variants=R; sw.diag=0; sw.col_hi=nullptr; sw.list_zone=0; sw.probe_zone=0; sw.cut=0.1*(1.0-1e-6);
+    sw.cand=C; sw.cap=(unsigned long long)R*R/8; sw.n_cand=dn; sw.chunk=64;
+    twk::ScreenWork* dsw; CK(hipMalloc(&dsw,sizeof(sw)));
+    const double tiles=(double)list.size();
+    for(int form=0; form<3; ++form){   // 0 phased (rows = variants), 1 unphased four products, 2 unphased three products (rows 2v, 2v+1 = H, Q)
+      sw.nA=sw.nB= form? R/2 : R; sw.n_variants=sw.nA; sw.two_n = form? 2.0*W*32 : 1.0*W*32;
+      CK(hipMemcpy(dsw,&sw,sizeof(sw),hipMemcpyHostToDevice));
+      for(int noepi=0; noepi<2; ++noepi){
+        auto launch=[&](){ CK(hipMemsetAsync(tick,0,4,0)); CK(hipMemsetAsync(dn,0,8,0));
+          if(form==0){ if(noepi) hipLaunchKernelGGL((twk::k_count_screen_t<twk::COUNT_NW,6>),dim3(P),block,0,0,w,dsw); else hipLaunchKernelGGL((twk::k_count_screen_t<twk::COUNT_NW,0>),dim3(P),block,0,0,w,dsw); }
+          else if(form==1){ if(noepi) hipLaunchKernelGGL((twk::k_count_screen_unphased_t<twk::COUNT_NW,6>),dim3(P),block,0,0,w,dsw); else hipLaunchKernelGGL((twk::k_count_screen_unphased_t<twk::COUNT_NW,0>),dim3(P),block,0,0,w,dsw); }
+          else { if(noepi) hipLaunchKernelGGL((twk::k_count3_screen_unphased_t<twk::COUNT_NW,6>),dim3(P),block,0,0,w,dsw); else hipLaunchKernelGGL((twk::k_count3_screen_unphased_t<twk::COUNT_NW,0>),dim3(P),block,0,0,w,dsw); } };
+        launch(); launch(); CK(hipDeviceSynchronize());
+        float best=1e30f;
+        for(int i=0;i<reps;++i){ CK(hipEventRecord(e0)); launch(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms,e0,e1)); if(ms<best)best=ms; }
+        unsigned long long nc=0; CK(hipMemcpy(&nc,dn,8,hipMemcpyDeviceToHost));
+        const uint32_t words_done = w.last_halves? (W/twk::KC-1)*twk::KC + 2*w.last_halves : W;
+        const double prod = tiles*128*128*words_done*(form==2?0.75:1.0), equiv = prod*(form==2? 0.8125/0.75 : 1.0);
+        printf("fused %-22s %-12s R=%u W=%u live=%u tiles=%.0f best %.3f ms  products/s %.3e  (%.1f%% of the issue ceiling 2.62e13, v_or priced)  candidates %llu\n",
+               form==0?"phased":form==1?"unphased four-product":"unphased three-product", noepi?"no epilogue":"with screen", R,W,live,tiles,best,prod/best*1e3,equiv/best*1e3/2.6214e13*100,nc);
+      }
+    }
     return 0;
   }
   if(getenv("THREE")){   // the three-product form of the unphased planes (rows 2v / 2v + 1 = H / Q of variant v): k_count3_list_t against k_count_list_t on
