@@ -70,3 +70,30 @@ def test_no_kernel_shifts_64_bits_by_an_amount_in_its_last_vgpr(tmp_path):
     hits, counts = shift64_amount_in_the_last_vgpr(asm)
     assert len(counts) > 20 and any("k_count_list_t" in k for k in counts)         # the scan saw the library's kernels
     assert not hits, hits
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_count_kernels_use_no_scratch_memory(tmp_path):
+    """Every count kernel (plain, three-product, fused) must keep its loop state in registers: a spilled per-lane offset is
+    reloaded from scratch *inside* the K loop (round 5: an epilogue that grew by a dozen registers cost the fused phased
+    kernel 16 spills and 10 % of its rate before the offsets were recomputed per unit, profiles/r05_fused_epilogue.txt)."""
+    out = str(tmp_path / "twk_hip.s")
+    make = open(os.path.join(ROOT, "Makefile")).read()
+    flags = re.search(r"^HIPFLAGS\s*:=\s*(.*)$", make, re.M).group(1).replace("$(ARCH)", "gfx950").split()
+    flags = [f for f in flags if f not in ("-fPIC",)]
+    r = subprocess.run([HIPCC] + flags + ["-Iinclude", "-S", "--cuda-device-only", "-o", out, "tomahawk_amd/csrc/hip/twk_hip.hip"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900,
+                       env={k: v for k, v in os.environ.items() if k not in ("LD_PRELOAD", "ASAN_OPTIONS", "UBSAN_OPTIONS")})
+    assert r.returncode == 0, r.stderr[-2000:]
+    asm = open(out).read()
+    seen = 0
+    for name, body in re.findall(r"\.name:\s+(\S+)\n((?:(?!\s*\.name:).*\n)*)", asm):
+        if "k_count" not in name:
+            continue
+        seen += 1
+        scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", body).group(1))
+        spills = int(re.search(r"\.vgpr_spill_count:\s+(\d+)", body).group(1))
+        vgprs = int(re.search(r"\.vgpr_count:\s+(\d+)", body).group(1))
+        assert scratch == 0 and spills == 0, (name, scratch, spills)
+        assert vgprs <= 128, (name, vgprs)            # four waves per SIMD
+    assert seen >= 5
