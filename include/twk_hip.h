@@ -302,6 +302,10 @@ int twk_hip_fisher_exact(twk_hip_ctx* ctx, const int32_t* tables, uint64_t n, do
  *   "timeline"         0        1: the host's steps through a region's launch pipeline, with times, on stderr
  *   "band_list_entries" 0       candidate slots of such a launch (0: 1/32 of its pairs, 4 M .. 256 M); a launch that
  *                               outgrows them, or its survivor buffer, is redone as matrix-sized tiles
+ *   "probe_lds"        1        probe kernels: the column rows are staged into LDS segment by segment and the carriers tested there
+ *                               (512 zone rows x 4 columns a block; 2 columns of unphased planes); 0: gathers from L2, as chosen by
+ *   "probe_cols"       0        ... a strip of 2 / 4 / 8 / 16 columns a block, every list entry probing all of them (unphased planes: half as
+ *                               many); 0: one column per block (the round-4 kernels)
  *   "three"            1        UnphasedMath on planes without missing genotypes, r2 cut-off > 1e-6: contract three products per
  *                               pair (HH and S = QH + HQ + 2 QQ, all the screen reads) and recount the four products of the pairs
  *                               that pass; 0: four products for every pair; 2: keep to it even when a launch was candidate-rich

@@ -141,6 +141,8 @@ struct Options {
 	long long band_reverse = 1;      // allele-count-sorted runs: the last band (the commonest variants, most survivors) first
 	long long timeline = 0;          // 1: the host's steps through the launch pipeline of a region, with times, on stderr (measurement)
 	long long band_work_log2 = 19;   // ... and at least 2^n tile-chunks of work per launch (19: ~5 ms); small values make several launches of a small run
+	long long probe_lds = 1;         // probes through LDS: column rows staged segment by segment, carriers tested there (ld_list.hip.h k_probe_lds_t); 0: gathers from L2
+	long long probe_cols = 0;        // probes: columns a block takes (2, 4, 8, 16: phased planes; unphased planes half of it; ld_list.hip.h k_probe_strip_t); 0: one column per block
 	long long three = 1;             // UnphasedMath on the plain unphased planes with an r2 cut-off: the three-product contraction (HH + S, ld_count.hip.h) and a
 	                                 // recount of the candidates' four products; 0: the four-product forms; 2: also when a launch turned out candidate-rich
 };
@@ -155,7 +157,7 @@ const OptionKey OPTION_KEYS[] = {
 	{"record_cap", &Options::record_cap, 0, 1ll << 40, false},
 	{"probe", &Options::probe, 0, 1, false}, {"band_launch", &Options::band_launch, 0, 1, false}, {"band_list_entries", &Options::band_list_entries, 0, 1ll << 32, false},
 	{"band_work_log2", &Options::band_work_log2, 0, 40, false}, {"band_max_launches", &Options::band_max_launches, 1, 64, false}, {"timeline", &Options::timeline, 0, 1, false}, {"band_reverse", &Options::band_reverse, 0, 1, false}, {"probe_zone", &Options::probe_zone, 0, 1, false}, {"probe_unroll", &Options::probe_unroll, 1, 4, false},
-	{"three", &Options::three, 0, 2, false},
+	{"three", &Options::three, 0, 2, false}, {"probe_cols", &Options::probe_cols, 0, 16, false}, {"probe_lds", &Options::probe_lds, 0, 1, false},
 };
 }  // namespace
 
@@ -1157,18 +1159,39 @@ int run_probe_block(twk_hip_ctx* c, const twk_hip_filters& f, bool unphased, uin
 	w.col_hi = cr.d_hi; w.hi_a0 = cr.a0; w.hi_b0 = cr.b0;
 	w.two_n = 2.0 * (double)c->N; w.cut = f.minR2 * (1.0 - 1e-6);
 	w.cand = s.C; w.cap = s.cand_cap; w.n_cand = s.n_out + 2;
-	p.rows = ps.rows; p.W = ps.W; p.col0 = col0; p.n_cols = n_cols; p.n_row_blocks = (n_rows + 255) / 256;
+	// through LDS (k_probe_lds_t: 512 rows x 4 columns a block, 2 columns of unphased planes), option probe_lds = 0: straight from L2 (a strip
+	// of probe_cols columns a block, or one)
+	const bool via_lds = c->opt.probe_lds != 0;
+	p.rows = ps.rows; p.W = ps.W; p.col0 = col0; p.n_cols = n_cols; p.n_row_blocks = via_lds ? (n_rows + PROBE_ROWS - 1) / PROBE_ROWS : (n_rows + 255) / 256;
 	s.row_pairs = 0;
 	for (uint32_t i = row0; i < row0 + n_rows; ++i) {
 		const uint32_t lim = std::min<uint64_t>((uint64_t)col0 + n_cols, cr.hi ? (uint64_t)cr.b0 + cr.hi[i - cr.a0] : (uint64_t)col0 + n_cols);
 		const uint32_t first = std::max(col0, i + 1);             // (columns inside the zone: those behind the row)
 		if (lim > first) s.row_pairs += lim - first;              // pairs probed (accounting only)
 	}
-	const uint64_t n_blocks = (uint64_t)p.n_row_blocks * n_cols;
+	// a strip of columns per block (k_probe_strip_t; option probe_cols = columns of a strip, phased planes - unphased planes take half as many,
+	// two rows each); 0: one column per block (the round-4 kernels)
+	constexpr uint32_t LDS_COLS_P = 4, LDS_COLS_U = 2;
+	const uint32_t strip_cols = via_lds ? (unphased ? LDS_COLS_U : LDS_COLS_P) : unphased ? (uint32_t)c->opt.probe_cols / 2 : (uint32_t)c->opt.probe_cols;
+	const bool strips = strip_cols >= 2;
+	const uint64_t n_blocks = (uint64_t)p.n_row_blocks * (strips ? (n_cols + strip_cols - 1) / strip_cols : n_cols);
 	if (n_blocks > 0x7FFFFFFFull) return TWK_HIP_E_INVALID;
 	HIPCHK(c, hipEventRecord(s.ev_c0, c->s_compute));
 	if (s.row_pairs) {
-		if (unphased && c->opt.probe_unroll == 4) hipLaunchKernelGGL(k_probe_screen_unphased_t<4>, dim3((uint32_t)n_blocks), dim3(256), 0, c->s_compute, p, c->N);
+		const dim3 grid((uint32_t)n_blocks), blk(256);
+		if (via_lds && unphased) hipLaunchKernelGGL(k_probe_lds_unphased_t<LDS_COLS_U>, grid, dim3(PROBE_ROWS), 0, c->s_compute, p);
+		else if (via_lds) hipLaunchKernelGGL(k_probe_lds_t<LDS_COLS_P>, grid, dim3(PROBE_ROWS), 0, c->s_compute, p);
+		else if (strips && unphased) {
+			if (strip_cols == 2) hipLaunchKernelGGL(k_probe_strip_unphased_t<2>, grid, blk, 0, c->s_compute, p);
+			else if (strip_cols == 4) hipLaunchKernelGGL(k_probe_strip_unphased_t<4>, grid, blk, 0, c->s_compute, p);
+			else hipLaunchKernelGGL(k_probe_strip_unphased_t<8>, grid, blk, 0, c->s_compute, p);
+		} else if (strips) {
+			if (strip_cols == 2) hipLaunchKernelGGL(k_probe_strip_t<2>, grid, blk, 0, c->s_compute, p);
+			else if (strip_cols == 4) hipLaunchKernelGGL(k_probe_strip_t<4>, grid, blk, 0, c->s_compute, p);
+			else if (strip_cols == 8) hipLaunchKernelGGL(k_probe_strip_t<8>, grid, blk, 0, c->s_compute, p);
+			else hipLaunchKernelGGL(k_probe_strip_t<16>, grid, blk, 0, c->s_compute, p);
+		}
+		else if (unphased && c->opt.probe_unroll == 4) hipLaunchKernelGGL(k_probe_screen_unphased_t<4>, dim3((uint32_t)n_blocks), dim3(256), 0, c->s_compute, p, c->N);
 		else if (unphased && c->opt.probe_unroll == 2) hipLaunchKernelGGL(k_probe_screen_unphased_t<2>, dim3((uint32_t)n_blocks), dim3(256), 0, c->s_compute, p, c->N);
 		else if (unphased) hipLaunchKernelGGL(k_probe_screen_unphased_t<1>, dim3((uint32_t)n_blocks), dim3(256), 0, c->s_compute, p, c->N);
 		else hipLaunchKernelGGL(k_probe_screen, dim3((uint32_t)n_blocks), dim3(256), 0, c->s_compute, p);
