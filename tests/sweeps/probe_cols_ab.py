@@ -12,7 +12,7 @@ M = int(sys.argv[1]) if len(sys.argv) > 1 else 50_000
 twk, threads = bench.cohort_twk(1_000_000, M, log)
 O = lambda *kv: [x for k in kv for x in ("--engine-option", k)]
 for flags, tag in (([], "default"), (["-u"], "-u")):
-    for cols in ("lds", 0, 16, "lds", 0):
+    for cols in ("lds", "lds"):
         r = bench.run_cli(twk, flags + (O("probe_lds=1") if cols == "lds" else O("probe_lds=0", f"probe_cols={cols}")), threads, "/tmp/ab.two")
         if "error" in r:
             log(f"{tag} probe_cols={cols}: FAILED {r['error']}"); continue

@@ -47,10 +47,16 @@ def test_three_product_equals_four_product_and_oracle(hip, opt, N, fused):
     data, mask, variants = util.upload(hip, al)
     opt.set("fused", fused)
     mode = T.MODE_UNPHASED
+    # (through the matrix the engine first samples the region's candidate density and keeps to four products on data as rich in LD as this
+    # cohort - test_sampling_decides_...; three = 2 takes the form regardless)
+    on = 1 if fused else 2
+    _b = _both
+    def _both_on(hip, opt, call, expect_three=True):
+        return _b(hip, opt, call, expect_three, on=on)
     for minR2 in (0.1, 0.6, 0.004):
         for wopt in (0, T.OPT_R2_SCREEN):
             f = T.Filters(minR2=minR2)
-            (p, np0, _), (q, np1, nr1), tm = _both(hip, opt, lambda: hip.ld_all(mode, f, window=wopt))
+            (p, np0, _), (q, np1, nr1), tm = _both_on(hip, opt, lambda: hip.ld_all(mode, f, window=wopt), expect_three=(minR2 >= 0.1))
             assert np0 == np1 == M * (M - 1) // 2 and nr1 == len(q) == len(p) > 20
             assert _same(p, q), (minR2, wopt)
             if minR2 >= 0.1:                        # the screen screens, and every survivor was recounted
@@ -60,25 +66,26 @@ def test_three_product_equals_four_product_and_oracle(hip, opt, N, fused):
     for x in r2[:: max(1, len(r2) // 4)][:4]:
         for cut in (np.nextafter(x, 0.0), x, np.nextafter(x, 1.0)):
             f = T.Filters(minR2=float(cut))
-            (p, _, _), (q, _, _), _ = _both(hip, opt, lambda: hip.ld_all(mode, f))
+            (p, _, _), (q, _, _), _ = _both_on(hip, opt, lambda: hip.ld_all(mode, f))
             assert _same(p, q), cut
     f = T.Filters(minR2=0.1)
-    (p, np0, _), (q, np1, _), _ = _both(hip, opt, lambda: hip.ld_all(mode, f, window=T.OPT_WINDOW, l_window=30_000))
+    (p, np0, _), (q, np1, _), _ = _both_on(hip, opt, lambda: hip.ld_all(mode, f, window=T.OPT_WINDOW, l_window=30_000))
     assert np0 == np1 and len(p) > 20 and _same(p, q)
-    opt.set("three", 1)
+    opt.set("three", on)
     parts = [hip.ld_all(mode, f, part=k, n_parts=3) for k in range(3)]
     whole, _, _ = hip.ld_all(mode, f)
     assert _same(np.concatenate([x[0] for x in parts]), whole)
-    (p, _, _), (q, _, _), tm = _both(hip, opt, lambda: hip.ld_all(mode, f, tile_variants=256))
+    (p, _, _), (q, _, _), tm = _both_on(hip, opt, lambda: hip.ld_all(mode, f, tile_variants=256))
     assert tm["three_launches"] > 3 and _same(p, q)
     for a0, nA, b0, nB, diag in ((0, M, 0, M, True), (3, M // 5 + 1, M // 4 + 2, M // 3 + 11, False), (129, 200, 129, 333, True)):
-        (p, _), (q, _), _ = _both(hip, opt, lambda: hip.ld_tile(mode, a0, nA, b0, nB, diag, f))
+        (p, _), (q, _), _ = _both_on(hip, opt, lambda: hip.ld_tile(mode, a0, nA, b0, nB, diag, f))
         assert _same(p, q), (a0, nA, b0, nB)
     # and the oracle agrees (sampled: it is scalar)
     sub = np.sort(np.random.default_rng(N).choice(M, size=220, replace=False))
     hip.set_problem(N, len(sub))
     hip.upload(data[sub], util.to_hip_meta(variants[sub]), None)
     want = O.all_pairs(data[sub], None, variants[sub], N, O.settings(minR2=0.1, unphased=True), vector_only=False)
+    opt.set("three", on)
     hip.timing_reset()
     got, _, _ = hip.ld_all(mode, T.Filters(minR2=0.1))
     tm = hip.timing()
@@ -96,9 +103,9 @@ def test_three_product_on_long_rows_with_tiles_split_along_k(hip, opt, min_chunk
     opt.set("count_min_chunks", min_chunks)
     for minR2, wopt in ((0.1, 0), (0.3, T.OPT_R2_SCREEN), (0.02, 0)):
         f = T.Filters(minR2=minR2)
-        (p, np0, _), (q, np1, nr), tm = _both(hip, opt, lambda: hip.ld_all(T.MODE_UNPHASED, f, window=wopt))
+        (p, np0, _), (q, np1, nr), tm = _both(hip, opt, lambda: hip.ld_all(T.MODE_UNPHASED, f, window=wopt), expect_three=(minR2 >= 0.1), on=2)
         assert tm["fused_launches"] == 0 and np0 == np1 and nr == len(q) == len(p) > 20 and _same(p, q), (minR2, wopt)
-    (p, _, _), (q, _, _), tm = _both(hip, opt, lambda: hip.ld_all(T.MODE_UNPHASED, T.Filters(minR2=0.1), tile_variants=128))
+    (p, _, _), (q, _, _), tm = _both(hip, opt, lambda: hip.ld_all(T.MODE_UNPHASED, T.Filters(minR2=0.1), tile_variants=128), on=2)
     assert tm["three_launches"] >= 6 and _same(p, q)
 
 
@@ -143,3 +150,24 @@ def test_three_product_band_launches_and_probe_zone(hip, opt):
         (p, np0, _), (q, np1, nr), tm = _both(hip, opt, lambda: hip.ld_all(T.MODE_UNPHASED, f, window=wopt, l_window=lw), on=2)      # (2: this cohort is rich in LD)
         assert tm["three_launches"] >= (2 if wopt == 0 else 1) and tm["fused_launches"] == tm["three_launches"], (wopt, tm)
         assert np0 == np1 and nr == len(q) == len(p) > 100 and _same(p, q), wopt
+
+
+def test_sampling_decides_between_three_and_four_products_on_long_rows(hip, opt):
+    """Through the count matrix (rows too long to fuse) a region first samples its candidate density (a sub-tile
+    of its own middle for every launch) and takes the three-product form only where candidates are few: unlinked variants
+    (the headline's synthetic input) -> three products in every launch; a cohort rich in LD -> four, with no launch wasted.
+    Same records either way."""
+    N = 300_000
+    rng = np.random.default_rng(5)
+    M = 700
+    iid = (rng.random((M, N, 2)) < rng.uniform(0.05, 0.5, size=M)[:, None, None]).astype(np.int8)
+    iid[5] = iid[4]; iid[300] = iid[299]; iid[650, :, 0] = iid[649, :, 1]; iid[650, :, 1] = iid[649, :, 0]       # a few pairs in perfect LD
+    util.upload(hip, iid)
+    f = T.Filters(minR2=0.1)
+    (p, np0, _), (q, np1, nr), tm = _both(hip, opt, lambda: hip.ld_all(T.MODE_UNPHASED, f, tile_variants=256))
+    assert tm["three_launches"] == tm["count_launches"] >= 6 and tm["fused_launches"] == 0
+    assert np0 == np1 and nr == len(q) == len(p) >= 3 and _same(p, q) and tm["recount_candidates"] >= 3
+    al = _cohort_alleles(420, N, 4242)
+    util.upload(hip, al)
+    (p, _, _), (q, _, nr), tm = _both(hip, opt, lambda: hip.ld_all(T.MODE_UNPHASED, f, tile_variants=128), expect_three=False)
+    assert tm["three_launches"] == 0 and tm["count_launches"] >= 6 and nr == len(q) == len(p) > 100 and _same(p, q)

@@ -769,8 +769,8 @@ __device__ __noinline__ void d_list_item_unphased(const StatsParams* pp, const u
 __global__ __launch_bounds__(256)
 void k_ld_stats_list_unphased(const StatsParams* pp, const uint32_t* __restrict__ cand, const unsigned long long* __restrict__ n_cand,
                               unsigned long long cap) {
-	unsigned long long n = *n_cand;
-	if (n > cap) n = cap;
+	const unsigned long long n = *n_cand;
+	if (n > cap) return;                                    // (an overflowed list: the host redoes the launch another way and keeps nothing of this one)
 	const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
 	const unsigned long long n_up = (n + STATS_THREADS - 1) / STATS_THREADS * STATS_THREADS;
 #pragma unroll 1

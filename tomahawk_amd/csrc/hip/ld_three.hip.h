@@ -80,8 +80,8 @@ __global__ __launch_bounds__(256)
 void k_recount_unphased(const uint32_t* __restrict__ rows, uint32_t W, uint32_t W_live, uint32_t* __restrict__ cand,
                         const unsigned long long* __restrict__ n_cand, unsigned long long cap, unsigned long long* __restrict__ mismatches) {
 	static_assert(LANES == 64 || LANES == 16, "a wave or a DPP row per candidate");
-	unsigned long long n = *n_cand;
-	if (n > cap) n = cap;
+	const unsigned long long n = *n_cand;
+	if (n > cap) return;                                    // the list overflowed: the host redoes the launch with four products, nothing of this one is kept
 	const uint32_t lane = threadIdx.x & (LANES - 1);
 	const unsigned long long group = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) / LANES;
 	const unsigned long long n_groups = (unsigned long long)gridDim.x * blockDim.x / LANES;

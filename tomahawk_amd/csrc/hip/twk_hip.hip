@@ -2088,6 +2088,43 @@ static int region_impl(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint3
 		for (const auto& t : sub) { const int r = run_tile_with_fallbacks(t); if (r) return r; }
 		return TWK_HIP_OK;
 	};
+	// The three-product form through a count matrix (long rows) pays only where candidates are few: a launch whose list overflows is redone
+	// with four products, three-product launches already in flight behind it included (1 M x 50,000 cohort run, calc -u: 977 -> 1,426 ms of
+	// count kernel with three such launches wasted), and how many pairs are candidates differs from launch to launch - in allele-count order
+	// the launches over the common variants hold nearly all of them.  So every launch is decided by a sample of its own, taken before the
+	// pipeline starts: a sub-tile of at most 384 x 384 variants from its middle through the same kernels (half a millisecond), three
+	// products if at most 1 pair in 256 of the sample is a candidate.  (Regions of more than 64 launches sample every k-th one; the others
+	// follow their nearest sampled neighbour.)
+	std::vector<char> want_three(n, 1);
+	if (!mine.empty() && c->three_ok && c->opt.three == 1) {
+		const TilePlan pl = plan_for(c, mode);
+		const bool eligible = !pl.phased1 && pl.set2 < 0 && set_kind(pl.set1) == PK_UNPHASED && f->minR2 > 1e-6 && f->minR2 <= 1.0 && !fused_form_applies(c, mode, *f);
+		if (eligible) {
+			const size_t step = (n + 63) / 64;
+			for (size_t i0 = 0; i0 < n; i0 += step) {
+				const size_t pick = std::min(n - 1, i0 + step / 2);
+				const twk_hip_tile_desc& t0 = mine[pick];
+				twk_hip_tile_desc st = t0;
+				const uint32_t h = std::min<uint32_t>(384, t0.nA), row_c = t0.rowA0 + (t0.nA - h) / 2;
+				st.rowA0 = row_c; st.nA = h;
+				if (t0.diag && t0.rowA0 == t0.rowB0) { st.rowB0 = row_c; st.nB = std::min<uint32_t>(h, t0.rowB0 + t0.nB - row_c); st.diag = 1; }
+				else { const uint32_t wv = std::min<uint32_t>(384, t0.nB); st.rowB0 = t0.rowB0 + (t0.nB - wv) / 2; st.nB = wv; st.diag = 0; }
+				const twk_hip_timing keep_timing = c->timing;
+				Slot& ss = c->slot[SYNC_SLOT];
+				unsigned long long nrec = 0;
+				rc = enqueue_tile(c, mode, st, *f, ss, std::max<unsigned long long>((unsigned long long)st.nA * st.nB, 1), windowed ? &col_range : nullptr);
+				if (rc == TWK_HIP_OK) rc = finish_tile(c, ss, st, &nrec, true, discard_records, nullptr);
+				const unsigned long long cand = ss.h_n_out[2], sample_pairs = std::max<uint64_t>(pairs_in_tile(c, st), 1);
+				c->timing = keep_timing;
+				c->three_ok = true;                      // (a sample's own overflow decides its launch, not the call)
+				const bool dense = rc == TWK_HIP_E_OVERFLOW || (rc == TWK_HIP_OK && cand * 256 > sample_pairs);
+				if (rc != TWK_HIP_OK && rc != TWK_HIP_E_OVERFLOW) return rc;
+				for (size_t i = i0; i < std::min(n, i0 + step); ++i) want_three[i] = dense ? 0 : 1;
+				mark("three-product sample of launch: candidates", pick, cand);
+				rc = TWK_HIP_OK;
+			}
+		}
+	}
 	auto band_of = [&](size_t i) -> const BandLaunch* { return i < bands.size() ? &bands[i] : nullptr; };       // (band launches are mine[0 .. bands.size()), in order)
 	std::vector<char> skipped(n, 0);
 	// software pipeline over the launches of this shard, PIPE_SLOTS deep
@@ -2107,7 +2144,10 @@ static int region_impl(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint3
 			if (b && !c->fused_ok) skipped[issued] = 1;                 // an earlier launch gave the fused form up: this one goes the matrix way when its turn comes
 			else {
 				mark("enqueue launch", issued);
+				const bool three_was = c->three_ok;
+				c->three_ok = three_was && want_three[issued] != 0;       // (the launch's own sample)
 				rc = enqueue_tile(c, mode, mine[issued], *f, c->slot[issued % PIPE_SLOTS], b ? 1 : cap_default, windowed ? &col_range : nullptr, b ? b->list_words : 0);
+				c->three_ok = three_was;
 				if (rc) return rc;
 				mark("enqueued launch", issued);
 			}
