@@ -98,6 +98,25 @@ def executed_work(tm):
     return four + three, three / 4.0, kernel, form
 
 
+def launch_spread(eng):
+    """The count launches of the timed region one by one (twk_hip_launch_log): how far the slowest launch's time per unit of work lies
+    above the median's - a run that silently took 1.7 x as long (round 4 saw such runs) shows here - and what the engine's outlier watch
+    flagged.  -> dict for the JSON line."""
+    stats, seen = eng.launch_log()
+    cost = [x["ms"] / (x["row_pairs"] * x["words_per_row"] * (0.8125 if x["kind"] in (1, 4) else 1.0)) for x in stats if x["row_pairs"] and x["ms"] >= 0.3]
+    if not cost:
+        return {"launches": seen}
+    srt = sorted(cost)
+    med = srt[len(srt) // 2]
+    ms = sorted(x["ms"] for x in stats)
+    return {"launches": seen, "launch_ms_max": ms[-1], "launch_ms_median": ms[len(ms) // 2],
+            "launch_cost_max_over_median": srt[-1] / med if med > 0 else None, "launch_cost_min_over_median": srt[0] / med if med > 0 else None,
+            "outlier_launches": sum(1 for x in stats if x["outlier"]),
+            "shader_mhz_min": min((x["shader_mhz"] for x in stats if x["shader_mhz"]), default=None),
+            "xcd_finish_spread_us_max": max((x["xcd_finish_spread_us"] for x in stats), default=None),
+            "note": "cost = launch time per AND+popcount issued (launches differ in size: diagonal tiles, band edges); outlier: > 1.4 x the median of its peers"}
+
+
 def cpu_baseline(n_samples, mode, seed, log):
     """Time the reference's SSE4.2 calc path (oracle/_ref) on a bounded sample of the same workload."""
     from oracle import oracle as O
@@ -644,6 +663,7 @@ def main():
             shutil.copyfile(os.path.join(out_dir, f"step{args.steps - 1}.two"), args.keep_two)
         shutil.rmtree(out_dir, ignore_errors=True)
     tm = eng.timing()
+    spread = launch_spread(eng)
 
     stats = torch.tensor([elapsed, tm["count_ms"], tm["stats_ms"]], dtype=torch.float64)
     sums = torch.tensor([my_pairs, my_recs, tm["count_launches"], tm["row_pairs"]], dtype=torch.float64)
@@ -723,6 +743,7 @@ def main():
                          "kernel": kernel_name, "launches": int(tm["count_launches"]),
                          "three_product_launches": int(tm["three_launches"]), "recounted_candidates": int(tm["recount_candidates"]),
                          "avg_launch_ms": k_ms / max(tm["count_launches"], 1),
+                         "launch_spread": spread,
                          "algorithmic_lane_ops_per_pair": lane_ops_per_pair,
                          "executed_word_pairs_per_s": word_pairs_per_s,
                          "executed_frac_of_and_bcnt_ceiling": word_pairs_per_s / VALU_PAIR_PEAK,

@@ -260,6 +260,33 @@ int twk_hip_device_records(twk_hip_ctx* ctx, const twk_hip_record** records, uin
 int twk_hip_shard_rows(uint32_t n_rows, uint32_t n_cols, int32_t triangle, uint32_t part, uint32_t n_parts,
                        uint32_t* row_begin, uint32_t* row_end, uint64_t* n_pairs);
 
+/* The planner behind twk_hip_ld_region on caller-supplied arrays - pure host arithmetic, no device, no ctx (csrc/hip/ld_plan.h): the
+ * shard's rows, the columns every row reaches (window: same contig, |dpos| <= l_window; r2 band: from the allele counts `popc`, positions
+ * in order of minor allele count), and the launches (tile descriptors) that cover them; the first *n_band_launches of them are band
+ * launches (fused form: rows x all the columns they reach).  meta / popc: one entry per position of the index space [0, n_variants).
+ * tiles: room for `capacity` descriptors (TWK_HIP_E_OVERFLOW with *n_tiles = the number needed); lo / hi: nA entries each or NULL (filled
+ * in window / band mode: row a0 + r reaches columns [b0 + lo[r], b0 + hi[r])).  Replaces twk_ld_balancer::Build and the block-pair
+ * ticker (lib/ld/ld_balancing.h:23-80, 176-233) for one GPU's share; exported so that the partition can be tested and inspected
+ * without a GPU (tests/test_plan.py). */
+typedef struct {
+	uint32_t n_samples;
+	int32_t  planes_per_variant;  /* plane rows per variant of the mode's plane set: 1 phased, 2 unphased (masked: 2 / 3) */
+	uint32_t k_chunks;            /* 128-byte chunks of a plane row (band launches are sized by tiles x chunks)            */
+	uint32_t resident_blocks;     /* count-kernel blocks the chip holds at once (2 per CU: 512)                          */
+	int32_t  screen;              /* 0 none, 1 r2 band for PhasedMath, 2 for UnphasedMath                                 */
+	int32_t  fused;               /* the mode's launches run the fused count -> screen form                              */
+	int32_t  phased_math;
+	int32_t  band_launch, band_reverse;   /* the options of the same names */
+	int32_t  _pad;
+	int64_t  band_work_log2, band_max_launches;
+	double   minR2;
+} twk_hip_plan_env;
+int twk_hip_plan_region(const twk_hip_plan_env* env, const twk_hip_variant_meta* meta, const uint32_t* popc, uint32_t n_variants,
+                        uint32_t a0, uint32_t nA, uint32_t b0, uint32_t nB, int32_t triangle, uint32_t part, uint32_t n_parts,
+                        uint32_t tile_variants, int32_t window, uint32_t l_window,
+                        twk_hip_tile_desc* tiles, uint32_t capacity, uint32_t* n_tiles, uint32_t* n_band_launches,
+                        uint32_t* row_begin, uint32_t* row_end, uint64_t* n_pairs, uint32_t* lo, uint32_t* hi);
+
 /* Fisher's exact test on n caller-supplied 2x2 tables (tables[4*i + {0,1,2,3}] = n11, n12, n21, n22), two-sided P
  * into p_two_sided[i]: kt_fisher_exact (lib/fisher_math.cpp:231-267) as the pair math calls it
  * (ld_engine.cpp:1222-1226, :1656-1658), through the engine's own Fisher kernels: the reference's walk, one table per
@@ -282,7 +309,8 @@ int twk_hip_fisher_exact(twk_hip_ctx* ctx, const int32_t* tables, uint64_t n, do
  *   "list_max"         0        longest carrier list kept (0: row words / 128, / 64 for unphased math)
  *   "probe"            1        pairs of a listed variant with one that keeps no list: probes of its carriers into the
  *                               partner's row instead of the dense contraction (0: dense)
- *   "record_cap"       0        cap on a launch's survivor buffer in records (0: none) - forces the overflow path
+ *   "record_cap"       0        cap on a launch's survivor buffer in records (0: none) - forces the overflow path: a matrix-sized tile
+ *                               is redone in row strips, a band launch as matrix-sized tiles
  *   "count_min_chunks" 8        shortest K range a tile of the count kernel is split into
  *   "patch_rows/_cols" 8 / 8    patch of tiles in the count kernel's work order
  *   "seg"              0        walk a patch in K segments of this many chunks (0: whole tiles)
@@ -309,6 +337,8 @@ int twk_hip_fisher_exact(twk_hip_ctx* ctx, const int32_t* tables, uint64_t n, do
  *   "three"            1        UnphasedMath on planes without missing genotypes, r2 cut-off > 1e-6: contract three products per
  *                               pair (HH and S = QH + HQ + 2 QQ, all the screen reads) and recount the four products of the pairs
  *                               that pass; 0: four products for every pair; 2: keep to it even when a launch was candidate-rich
+ * Keys of the host side (`tomahawk calc --engine-option`, twk_ld::SetEngineOption - handled in csrc/host/twk_ld.cpp, unknown to this
+ * function): "force_device", "progress_ms", "map_output", "emit_workers", "emit_backlog_mb", "emit_queue_pieces" (INTEGRATION.md 1).
  * None of them changes a record (tests/test_gpu_fused.py, test_gpu_lists.py); "lists" / "list_max" drop the derived
  * plane sets, which are rebuilt on next use.  Unknown key or value out of range: TWK_HIP_E_INVALID. */
 int twk_hip_set_option(twk_hip_ctx* ctx, const char* key, int64_t value);
@@ -350,6 +380,7 @@ typedef struct {
 	uint64_t three_row_pairs;     /* ... and the plane-row pairs of those launches (of row_pairs): they executed 3/4 of the
 	                                 AND+popcounts row_pairs x words_per_row stands for, plus 6 v_or per 24 of them */
 	uint64_t recount_candidates;  /* pairs that passed the three-product screen and had their four products counted afresh */
+	uint64_t outlier_launches;    /* count launches the outlier watch flagged (twk_hip_launch_log)                          */
 } twk_hip_timing;
 /* Progress of twk_hip_ld_all / twk_hip_ld_region: `cb` runs on the calling thread after every tile
  * with the variant pairs finished so far in the current call and the tile counts.  Replaces the
@@ -357,6 +388,26 @@ typedef struct {
  * cb == NULL switches it off. */
 typedef void (*twk_hip_progress_cb)(void* user, uint64_t pairs_done, uint32_t tiles_done, uint32_t tiles_total);
 int twk_hip_set_progress(twk_hip_ctx* ctx, twk_hip_progress_cb cb, void* user);
+
+/* The count launches one by one, since the last twk_hip_timing_reset (a ring of the last 4096): what the engine's outlier watch
+ * looks at.  A launch is an outlier when its time per unit of work (row_pairs x words_per_row, the three-product form's at 13/16)
+ * exceeds 1.4 x the median of the launches of its own kind and row length before it (at least 8 of them, launches of >= 0.3 ms);
+ * option "timeline" >= 1 prints such a launch - with the shader clock its blocks ran at and how far apart the XCDs finished - on
+ * stderr as it is found.  Measurement integrity (round 4 saw the same run take 1.7 x as long now and then); no reference counterpart. */
+typedef struct {
+	double   ms;                  /* HIP events around the count kernel                                        */
+	double   shader_mhz;          /* clock the blocks ran at (0: not measured)                                 */
+	double   xcd_finish_spread_us;/* last block of the last XCD to finish minus last block of the first one    */
+	uint64_t row_pairs;           /* plane-row pairs contracted                                                */
+	uint64_t candidates;          /* fused / three-product launches: pairs that passed the screen              */
+	uint32_t words_per_row;
+	uint32_t kind;                /* 0 four products -> matrix, 1 three products -> matrix, 2 fused PhasedMath,
+	                                 3 fused UnphasedMath four products, 4 fused UnphasedMath three products   */
+	uint32_t outlier;             /* != 0: flagged by the watch                                                */
+	uint32_t _pad;
+} twk_hip_launch_stat;
+/* Copies the most recent min(capacity, launches kept) entries, oldest first; *n_total: launches seen since the reset. */
+int twk_hip_launch_log(twk_hip_ctx* ctx, twk_hip_launch_stat* out, uint32_t capacity, uint32_t* n_copied, uint64_t* n_total);
 
 int twk_hip_timing_reset(twk_hip_ctx* ctx);
 int twk_hip_timing_get(twk_hip_ctx* ctx, twk_hip_timing* out);

@@ -461,7 +461,8 @@ struct CountWork {
 	// them is zero in every plane, so the contraction of the last chunk stops there: at 2 504 samples an unphased
 	// row is 79 live words in 3 chunks of 32, and the last 8 half-slots of every tile are skipped (-17 %).
 	uint32_t last_halves;
-	// [2] (may be null): every block adds the shader cycles (s_memtime) and the ticks of the constant 100 MHz counter
+	// [2 + 2 + 8] (may be null): [4 + x]: the latest tick of the 100 MHz counter at which a block on XCD x finished (how far apart
+	// the XCDs end a launch: the outlier watch of twk_hip.hip); [0], [1]: every block adds the shader cycles (s_memtime) and the ticks of the constant 100 MHz counter
 	// (s_memrealtime) it lived for: their ratio is the clock the launch really ran at.  The and+bcnt ceiling is quoted at
 	// 2.4 GHz; a launch that starts on an idle chip runs its first ~20 ms below that (1.9 GHz for a 2 ms launch,
 	// profiles/r04_clock_probe.txt), which is most of what short-row runs lose against long ones.
@@ -801,6 +802,9 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 					typedef __attribute__((address_space(1))) unsigned long long g_u64;
 					__hip_atomic_fetch_add((g_u64*)w.clocks, clock64() - probe_clk0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 					__hip_atomic_fetch_add((g_u64*)w.clocks + 1, wall_clock64() - probe_wall0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					uint32_t xcc_id;
+					asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+					__hip_atomic_fetch_max((g_u64*)w.clocks + 4 + (xcc_id & 7u), wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				}
 				if (EXPERIMENT == 5 && thread0()) {      // probe: when did this block finish, and on which XCD / CU?
 					uint32_t xcc, hwid;

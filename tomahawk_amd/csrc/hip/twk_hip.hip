@@ -24,6 +24,7 @@
 #include "ld_math.hip.h"
 #include "ld_list.hip.h"
 #include "ld_three.hip.h"
+#include "ld_plan.h"
 
 using namespace twk;
 
@@ -69,7 +70,7 @@ enum { MODE_INT_AUTO_CLEAN = 0x10,     // phased math on the plain planes; pairs
        MODE_INT_SORTED_P   = 0x12,     // phased math on the allele-count-sorted planes (variants without missing data)
        MODE_INT_SORTED_U   = 0x13 };   // unphased math on the allele-count-sorted planes
 
-constexpr int N_SLOT_COUNTERS = 8;
+constexpr int N_SLOT_COUNTERS = 16;      // (see Slot::n_out)
 // Launches of a region call in flight.  Three, not two: the survivors of launch t are sorted on the copy stream, where they
 // wait for a CU until the persistent count kernel of launch t + 1 lets go; with only t + 1 enqueued the device then idled
 // until the host had sorted, copied and handed over launch t and come back with launch t + 2 (2,504 x 531,500, all pairs:
@@ -81,8 +82,9 @@ struct Slot {                      // one in-flight tile (double buffered)
 	unsigned long long* keys = nullptr; uint32_t* vals = nullptr;        // [capacity]: sort key and position of every survivor, written where it is appended
 	unsigned long long cap_use = 0;               // ... of which the current launch may use this many (what the caller asked for)
 	unsigned long long* n_out = nullptr;          // device counters: [0] survivors appended, [1] of those dropped by the Fisher cut-off,
-	                                              // [2] candidates of the fused count kernel, [3] spare, [4] shader cycles and [5] 100 MHz ticks
-	                                              // the count kernel's blocks lived for (summed over the blocks), [6], [7] spare
+	                                              // [2] candidates of the fused count kernel, [3] three-product candidates whose recount disagrees, [4] shader cycles and
+	                                              // [5] 100 MHz ticks the count kernel's blocks lived for (summed over the blocks), [6], [7] spare, [8 + x] the 100 MHz
+	                                              // tick at which the last block on XCD x finished
 	unsigned long long* h_n_out = nullptr;        // pinned host copy of all of them
 	hipEvent_t ev_c0 = nullptr, ev_c1 = nullptr, ev_s1 = nullptr, ev_c0b = nullptr, ev_c1b = nullptr;
 	bool two_pass = false;
@@ -102,6 +104,8 @@ struct Slot {                      // one in-flight tile (double buffered)
 	int plane_set = 0;                            // the plane set the launch contracted
 	unsigned long long cand_cap = 0;              // ... of this many entries; n_out[2] counts them
 	bool cand_overflow = false;                   // set by finish_tile: the list did not hold them all
+	bool band_too_big = false;                    // a band launch whose candidates need more survivor / sort buffers than it may have (or could get): finish_tile reports
+	                                              // it as an overflow and the launch's rows are redone as matrix-sized tiles
 	double minP = 1.0;
 	uint64_t row_pairs = 0, row_pairs_b = 0;
 	// work lists of the (up to two) count launches of the tile: pinned host copy + device copy
@@ -134,7 +138,7 @@ struct Options {
 	long long record_cap = 0;        // cap on the survivor buffer of a launch (0: none): forces the overflow / strip path
 	long long probe = 1;             // zone rows x columns outside the zone: carrier-list probes into the column's row instead of the dense contraction (0: dense)
 	long long band_launch = 1;       // fused runs: launches sized by work (a band of rows, all its columns), not by a count matrix
-	long long band_list_entries = 0; // candidate slots of such a launch (0: a sixteenth of its pairs, 4 M .. 1 G; else exactly this many): small values force its fallback
+	long long band_list_entries = 0; // candidate slots of such a launch (0: 1/32 of its pairs, 4 M .. 256 M; else exactly this many): small values force its fallback
 	long long band_max_launches = 8; // ... at most this many per region
 	long long probe_unroll = 4;      // list entries the unphased probe kernel takes at a time (1, 2, 4: their loads in flight together; ld_list.hip.h)
 	long long probe_zone = 1;        // rows with a list short enough to probe take *every* column behind them that way, the zone's own included (0: zone x zone pairs are list merges)
@@ -197,6 +201,7 @@ struct twk_hip_ctx {
 	void* d_band_tmp = nullptr; size_t band_tmp_bytes = 0;
 	std::vector<void*> graveyard;      // device buffers outgrown while launches were in flight: hipFree waits for the device, so they are freed when the call ends
 	twk_hip_timing timing{};
+	std::vector<twk_hip_launch_stat> launch_ring; uint64_t launches_seen = 0;      // the outlier watch's log (twk_hip_launch_log): the last LAUNCH_RING count launches
 	twk_hip_progress_cb progress_cb = nullptr; void* progress_user = nullptr;
 	bool progress_muted = false;       // second stage of a default-mode run: its pairs were already counted
 	uint32_t resident_blocks = 512;   // count-kernel blocks the chip holds at once (2 per CU)
@@ -742,7 +747,7 @@ int enqueue_tile(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, const twk
 	fa.unphased = fused_u ? 1 : 0;
 	ScreenWork& sw = fa.screen;
 	s.fused = false; s.is_list = false; s.is_probe = false; s.cand_overflow = false; s.cand_cap = (list_words ? list_words : s.C_words) / (fused_u ? 6 : 3);
-	s.three = false; s.three_plain = false; s.cand = s.C;
+	s.three = false; s.three_plain = false; s.cand = s.C; s.band_too_big = false;
 	// The three-product form (ld_count.hip.h): UnphasedMath on the plain unphased planes with a cut-off the screen can use.  Where the launch
 	// does not fuse (long rows: tiles are split along K) the (HH, S) matrix takes the first half of the slot's count buffer and the candidate
 	// list the room behind it - at most 1/128 of the tile's pairs: a candidate's recount streams its four rows once more, ~25 pairs' worth of
@@ -862,30 +867,47 @@ int enqueue_band_math(twk_hip_ctx* c, Slot& s) {
 	s.deferred = false;
 	HIPCHK(c, hipEventSynchronize(s.ev_c1b));
 	const unsigned long long cand = s.h_n_out[2];
-	const bool overflow = cand > s.cand_cap;                 // finish_tile reports it; nothing to compute here
+	// Every candidate may survive: the survivor, key and sort buffers are sized by the candidates (220 bytes each).  Beyond 2^26 of them -
+	// 15 GB per slot - or when the device cannot give the memory, the launch is treated like one whose list overflowed: its rows are redone
+	// as matrix-sized tiles, which split further on their own overflow (the round-4 code returned E_NOMEM and took the run down).
+	constexpr unsigned long long BAND_MAX_SURVIVORS = 1ull << 26;
+	s.band_too_big = false;
+	bool overflow = cand > s.cand_cap;                       // finish_tile reports it; nothing to compute here
+	if (!overflow && cand > BAND_MAX_SURVIVORS) { s.band_too_big = true; overflow = true; }
 	unsigned long long need = overflow ? 1 : std::max<unsigned long long>(cand, 1);
 	if (c->opt.record_cap > 0) need = std::min<unsigned long long>(need, (unsigned long long)c->opt.record_cap);      // (test hook: forces the overflow path)
-	if (need > 0xFFFFFFFFull) return TWK_HIP_E_INVALID;
-	if (s.capacity < need) {       // (with some room: the next launch of the region will be about as rich)
-		unsigned long long c1 = s.capacity, c2 = s.capacity, c3 = s.capacity;
-		int rc = regrow(c, (void**)&s.out, &c1, need, sizeof(twk_hip_record)); if (rc) return rc;
-		rc = regrow(c, (void**)&s.keys, &c2, need, sizeof(unsigned long long)); if (rc) return rc;
-		rc = regrow(c, (void**)&s.vals, &c3, need, sizeof(uint32_t)); if (rc) return rc;
-		s.capacity = std::min(c1, std::min(c2, c3));
-	}
-	{ int rc = regrow(c, (void**)&s.sorted, &s.sorted_cap, need, sizeof(twk_hip_record)); if (rc) return rc; }
-	if (c->band_sort_cap < need) {
-		unsigned long long c1 = c->band_sort_cap, c2 = c->band_sort_cap;
-		int rc = regrow(c, (void**)&c->d_band_keys, &c1, need, sizeof(unsigned long long)); if (rc) return rc;
-		rc = regrow(c, (void**)&c->d_band_vals, &c2, need, sizeof(uint32_t)); if (rc) return rc;
-		c->band_sort_cap = std::min(c1, c2);
-	}
-	size_t tmp = 0;
-	HIPCHK(c, rocprim::radix_sort_pairs(nullptr, tmp, s.keys, c->d_band_keys, s.vals, c->d_band_vals, (size_t)need, 0u, 64u, c->s_compute));
-	if (!c->d_band_tmp || tmp > c->band_tmp_bytes) {
-		unsigned long long cap = c->band_tmp_bytes;
-		int rc = regrow(c, &c->d_band_tmp, &cap, std::max<size_t>(tmp, 4096), 1); if (rc) return rc;
-		c->band_tmp_bytes = (size_t)cap;
+	auto grow_all = [&]() -> int {
+		if (s.capacity < need) {       // (with some room: the next launch of the region will be about as rich)
+			unsigned long long c1 = s.capacity, c2 = s.capacity, c3 = s.capacity;
+			int rc = regrow(c, (void**)&s.out, &c1, need, sizeof(twk_hip_record)); if (rc) return rc;
+			rc = regrow(c, (void**)&s.keys, &c2, need, sizeof(unsigned long long)); if (rc) return rc;
+			rc = regrow(c, (void**)&s.vals, &c3, need, sizeof(uint32_t)); if (rc) return rc;
+			s.capacity = std::min(c1, std::min(c2, c3));
+		}
+		{ const int rc = regrow(c, (void**)&s.sorted, &s.sorted_cap, need, sizeof(twk_hip_record)); if (rc) return rc; }
+		if (c->band_sort_cap < need) {
+			unsigned long long c1 = c->band_sort_cap, c2 = c->band_sort_cap;
+			int rc = regrow(c, (void**)&c->d_band_keys, &c1, need, sizeof(unsigned long long)); if (rc) return rc;
+			rc = regrow(c, (void**)&c->d_band_vals, &c2, need, sizeof(uint32_t)); if (rc) return rc;
+			c->band_sort_cap = std::min(c1, c2);
+		}
+		size_t tmp = 0;
+		HIPCHK(c, rocprim::radix_sort_pairs(nullptr, tmp, s.keys, c->d_band_keys, s.vals, c->d_band_vals, (size_t)need, 0u, 64u, c->s_compute));
+		if (!c->d_band_tmp || tmp > c->band_tmp_bytes) {
+			unsigned long long cap = c->band_tmp_bytes;
+			const int rc = regrow(c, &c->d_band_tmp, &cap, std::max<size_t>(tmp, 4096), 1); if (rc) return rc;
+			c->band_tmp_bytes = (size_t)cap;
+		}
+		return TWK_HIP_OK;
+	};
+	{
+		int rc = grow_all();
+		if (rc == TWK_HIP_E_NOMEM && !overflow) {            // no room for this many survivors: the fallback's tiles need far less at a time
+			(void)hipGetLastError();
+			s.band_too_big = true; overflow = true; need = 1;
+			rc = grow_all();
+		}
+		if (rc) return rc;
 	}
 	s.cap_use = need;
 	HIPCHK(c, hipEventRecord(s.ev_c0b, c->s_compute));
@@ -977,6 +999,40 @@ int ensure_device_keep(twk_hip_ctx* c, unsigned long long n_more) {
 	return TWK_HIP_OK;
 }
 
+// The outlier watch: every count launch goes into a ring with its time per unit of work, and is compared with the median of the launches
+// of its own kind and row length before it.  (Round 4 saw the same run take 1.7 x as long now and then, cause unknown; the watch names
+// the launch, the clock its blocks ran at and how far apart the XCDs finished.)
+constexpr size_t LAUNCH_RING = 4096;
+void watch_launch(twk_hip_ctx* c, const Slot& s, float ms, const twk_hip_tile_desc& t) {
+	twk_hip_launch_stat st{};
+	st.ms = ms; st.row_pairs = s.row_pairs; st.candidates = (s.fused || s.three) ? s.h_n_out[2] : 0;
+	st.shader_mhz = s.h_n_out[5] ? (double)s.h_n_out[4] / (double)s.h_n_out[5] * 100.0 : 0.0;
+	st.words_per_row = c->planes[s.plane_set].W_live;
+	st.kind = s.fused ? (s.three ? 4u : (c->planes[s.plane_set].rows && set_kind(s.plane_set) == PK_UNPHASED ? 3u : 2u)) : (s.three_plain ? 1u : 0u);
+	unsigned long long lo = ~0ull, hi = 0;
+	for (int x = 0; x < 8; ++x) if (s.h_n_out[8 + x]) { lo = std::min(lo, s.h_n_out[8 + x]); hi = std::max(hi, s.h_n_out[8 + x]); }
+	st.xcd_finish_spread_us = hi ? (double)(hi - lo) / 100.0 : 0.0;
+	auto cost = [](const twk_hip_launch_stat& x) { return x.row_pairs ? x.ms / ((double)x.row_pairs * (double)x.words_per_row * ((x.kind == 1 || x.kind == 4) ? 0.8125 : 1.0)) : 0.0; };
+	if (st.ms >= 0.3 && st.row_pairs) {
+		std::vector<double> peers;
+		for (const auto& x : c->launch_ring)
+			if (x.kind == st.kind && x.words_per_row == st.words_per_row && x.ms >= 0.3 && !x.outlier) peers.push_back(cost(x));
+		if (peers.size() >= 8) {
+			std::nth_element(peers.begin(), peers.begin() + peers.size() / 2, peers.end());
+			const double med = peers[peers.size() / 2];
+			if (cost(st) > 1.4 * med) {
+				st.outlier = 1; c->timing.outlier_launches += 1;
+				if (c->opt.timeline) fprintf(stderr, "[outlier] count launch #%llu (kind %u, rows %u+%u x cols %u+%u, %llu row pairs of %u words): %.3f ms = %.2f x the median cost of its %zu peers; "
+				                             "blocks ran at %.0f MHz; XCDs finished %.1f us apart; %llu candidates\n", (unsigned long long)c->launches_seen, st.kind, t.rowA0, t.nA, t.rowB0, t.nB,
+				                             (unsigned long long)st.row_pairs, st.words_per_row, st.ms, cost(st) / med, peers.size(), st.shader_mhz, st.xcd_finish_spread_us, (unsigned long long)st.candidates);
+			}
+		}
+	}
+	if (c->launch_ring.size() < LAUNCH_RING) c->launch_ring.push_back(st);
+	else c->launch_ring[c->launches_seen % LAUNCH_RING] = st;
+	c->launches_seen += 1;
+}
+
 // Wait for slot s, account timing, put its records in (idxA, idxB) order and hand them on: appended to the device sink
 // (!to_host), or through the pinned staging buffer to the host - left there whole (sink == null: c->h_recs, for the
 // single-tile entry point), or handed to `sink` in pieces of HOST_CHUNK records, each piece while the next is being copied
@@ -991,6 +1047,7 @@ int finish_tile(twk_hip_ctx* c, Slot& s, const twk_hip_tile_desc& t, unsigned lo
 	const double tl_wait = since(tl0);
 	float ms = 0;
 	HIPCHK(c, hipEventElapsedTime(&ms, s.ev_c0, s.ev_c1));
+	if (!s.is_list) watch_launch(c, s, ms, t);
 	if (s.is_list && s.is_probe) { c->timing.probe_ms += ms; c->timing.probe_launches += 1; c->timing.probe_pairs += s.row_pairs; c->timing.candidates += s.h_n_out[2]; }
 	else if (s.is_list) { c->timing.list_ms += ms; c->timing.list_launches += 1; c->timing.list_pairs += s.row_pairs; c->timing.candidates += s.h_n_out[2]; }
 	else { c->timing.count_ms += ms; c->timing.count_launches += 1; c->timing.row_pairs += s.row_pairs;
@@ -1026,6 +1083,10 @@ int finish_tile(twk_hip_ctx* c, Slot& s, const twk_hip_tile_desc& t, unsigned lo
 	if (!s.is_list) c->timing.variant_pairs += pairs_in_tile(c, t);      // (the dense tiles that cover the list zone count its pairs)
 	const unsigned long long n = *s.h_n_out;
 	*n_out = n;
+	if (s.was_deferred && s.band_too_big) {          // (enqueue_band_math: more candidates than a band launch may keep survivors for)
+		snprintf(c->err, sizeof(c->err), "%llu candidates: beyond the survivor buffers of a band launch (tile rows %u+%u, cols %u+%u)", s.h_n_out[2], t.rowA0, t.nA, t.rowB0, t.nB);
+		return TWK_HIP_E_OVERFLOW;
+	}
 	if ((s.fused || s.is_list || s.three_plain) && s.h_n_out[2] > s.cand_cap) {       // more candidates than the list holds
 		s.cand_overflow = true;
 		snprintf(c->err, sizeof(c->err), "%llu candidates for a list of %llu (tile rows %u+%u, cols %u+%u)", s.h_n_out[2], s.cand_cap, t.rowA0, t.nA, t.rowB0, t.nB);
@@ -1257,24 +1318,6 @@ int redo_tile_in_strips(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, co
 		}
 	}
 	return TWK_HIP_OK;
-}
-
-// Rows [0, r) of a triangle (or trapezoid: nB >= nA columns, col > row) hold r*nB - r(r+1)/2
-// pairs; of an nA x nB rectangle r*nB.
-uint64_t band_pairs_before(uint64_t r, uint64_t nA, uint64_t nB, bool triangle) {
-	return triangle ? r * nB - r * (r + 1) / 2 : r * nB;      // triangle: row i pairs with cols (i, nB)
-}
-// First row of shard k: equal-area bands, boundaries on multiples of 64 variants.
-uint32_t band_boundary(uint32_t k, uint32_t n_parts, uint32_t nA, uint32_t nB, bool triangle) {
-	if (k == 0) return 0;
-	if (k >= n_parts) return nA;
-	const long double target = (long double)band_pairs_before(nA, nA, nB, triangle) * k / n_parts;
-	uint32_t lo = 0, hi = nA;
-	while (lo < hi) {
-		const uint32_t mid = lo + (hi - lo) / 2;
-		if ((long double)band_pairs_before(mid, nA, nB, triangle) < target) lo = mid + 1; else hi = mid;
-	}
-	return std::min(nA, (lo + 32) / 64 * 64);
 }
 
 // Per-variant metadata of variants [first, first + count): device SoA + host mirror (synchronous copies).
@@ -1685,409 +1728,110 @@ int twk_hip_ld_all(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint32_t 
 	                         sink, user, n_pairs, n_records);
 }
 
-// One region in one index space: the file order, or (mode MODE_INT_GROUPED) the order of the
-// regrouped plane set.  a0/b0/nA/nB and the tiles are positions in that space.
-static int region_impl(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint32_t a0, uint32_t nA,
-                       uint32_t b0, uint32_t nB, int32_t triangle, uint32_t part, uint32_t n_parts,
-                       uint32_t tile_variants, int32_t window, uint32_t l_window, twk_hip_record_sink sink,
-                       void* user, uint64_t* n_pairs, uint64_t* n_records) {
-	const auto t_origin = std::chrono::steady_clock::now();
-	auto mark = [&](const char* what, size_t i, unsigned long long x = 0) {       // "timeline" option: where the host's time goes
+// ---- one region in one index space ------------------------------------------------------------------------------------------
+// (the file order, or - modes MODE_INT_GROUPED / MODE_INT_SORTED_* - the order of a regrouped / sorted plane set; a0 / b0 / nA / nB and
+// the tiles are positions in that space).  region_impl asks the planner (ld_plan.h: shard, reach of every row, launches - host-only
+// arithmetic, tested without a GPU) and hands the plan to a RegionRun, which executes it: zone passes, the decision between three and
+// four products, the launch pipeline with its fallbacks.
+namespace {
+
+struct RegionRun {
+	twk_hip_ctx* c; int mode; const twk_hip_filters* f;
+	const PlanGeom& g; const PlanEnv& env; RegionPlan& plan;
+	twk_hip_record_sink sink; void* user;
+	std::chrono::steady_clock::time_point t_origin = std::chrono::steady_clock::now();
+	ColRange col_range;
+	unsigned long long cap_default = 1ull << 24;
+	uint64_t tot_pairs = 0, tot_recs = 0;
+	std::vector<char> want_three;             // per launch: the three-product form may be used (decide_three_by_samples)
+
+	RegionRun(twk_hip_ctx* c_, int mode_, const twk_hip_filters* f_, const PlanGeom& g_, const PlanEnv& e_, RegionPlan& p_, twk_hip_record_sink sink_, void* user_)
+		: c(c_), mode(mode_), f(f_), g(g_), env(e_), plan(p_), sink(sink_ ? sink_ : discard_records), user(user_) {}
+
+	void mark(const char* what, size_t i, unsigned long long x = 0) const {       // "timeline" option: where the host's time goes
 		if (!c->opt.timeline) return;
 		fprintf(stderr, "[timeline] %9.3f ms  %s %zu  %llu\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_origin).count(), what, i, x);
-	};
-	mark("region: mode", (size_t)mode, nA);
-	const uint32_t* ids = nullptr;
-	if (mode == MODE_INT_GROUPED || mode == MODE_INT_SORTED_P || mode == MODE_INT_SORTED_U) {
-		const int set = mode == MODE_INT_GROUPED ? PS_GROUPED : mode == MODE_INT_SORTED_P ? PS_SORTED_P : PS_SORTED_U;
-		int rc = ensure_planes(c, set); if (rc) return rc;
-		ids = c->planes[set].h_ids.data();
-		mark("plane set ready", (size_t)set);
 	}
-	// r2 screen (TWK_HIP_OPT_R2_SCREEN): this region is a triangle over the leading, missing-free part of an
-	// allele-count-sorted set.  1: PhasedMath's r2, 2: UnphasedMath's.
-	const int screen = (mode == MODE_INT_SORTED_P) ? 1 : (mode == MODE_INT_SORTED_U) ? 2 : 0;
-	auto meta_at = [&](uint32_t i) -> const twk_hip_variant_meta& { return c->h_meta[ids ? ids[i] : i]; };
-	// ---- shard: a contiguous band of rows holding 1/n_parts of the region's pairs ----------
-	// Row i of a triangle has nA-1-i pairs, of a rectangle nB.  Equal-area bands, boundaries
-	// on multiples of 64 variants, derived identically (and without communication) by every rank.
-	// Replaces the reference's square-chunk farm partition (ld_balancing.h:59-78) for GPUs.
-	const bool windowed = (window & TWK_HIP_OPT_WINDOW) != 0 || screen != 0;      // rows reach a column range only
-	// Window mode: the columns a row can reach, [lo[r], hi[r]) relative to b0 (same contig,
-	// |dpos| <= l_window; variants are sorted by (rid,pos) like every .twk, so both ends only
-	// move forward).  They drive the shard boundaries (equal in-window pairs), the tile edge and
-	// the column range of every row block; the exact test itself stays in the math kernel.
-	std::vector<uint32_t> lo, hi;
-	std::vector<uint64_t> cum;           // cum[r] = in-window pairs of rows [0, r)
-	if (screen) {
-		// With a and b the minor allele frequencies of two variants, a <= b, no 2x2 table with those margins has
-		// r2 above a(1-b) / ((1-a)b): |D| <= a(1-b), r2 = D^2 / (a(1-a)b(1-b)).  In order of minor allele count the
-		// pairs that can reach the cut-off are therefore a band above the diagonal: row r needs the columns
-		// (r, hi[r]) only, hi non-decreasing.  UnphasedMath estimates the haplotype frequency from genotypes and
-		// admits roots up to 1e-5 outside [minhap, maxhap] (ld_engine.h:37, ld_engine.cpp:1429-1558), so its |D|
-		// is bounded by a(1-b) + 1e-5.  The cut-off is lowered by a part in 1e6 against rounding in the
-		// reference's formula; pairs inside the band still go through that formula, so the survivors are the same.
-		lo.resize(nA); hi.resize(nA); cum.assign((size_t)nA + 1, 0);
-		const long double T2 = 2.0L * c->N, cut = (long double)f->minR2 * (1.0L - 1e-6L);
-		{ const int rc = ensure_popcounts(c); if (rc) return rc; }
-		auto mac = [&](uint32_t i) -> long double {      // minor allele count as the device counts it (see ensure_popcounts)
-			const long double ac = std::min<long double>(c->h_popc[ids ? ids[i] : i], T2);
-			return std::min(ac, T2 - ac);
-		};
-		auto reach = [&](long double ma, long double mb) -> bool {        // can a pair with these minor counts (ma <= mb) pass?
-			if (ma <= 0 || mb <= 0) return screen == 2;                     // a monomorphic site: PhasedMath drops it (D == 0)
-			if (screen == 1) return ma * (T2 - mb) >= cut * (T2 - ma) * mb;
-			const long double a = ma / T2, b = mb / T2, d = a * (1 - b) + 1e-5L;
-			return d * d >= cut * a * (1 - a) * b * (1 - b);
-		};
-		uint32_t h = 0;
-		for (uint32_t r = 0; r < nA; ++r) {
-			const long double mr = mac(a0 + r);
-			if (h < r + 1) h = std::min(r + 1, nB);
-			while (h < nB && reach(mr, mac(b0 + h))) ++h;
-			lo[r] = std::min(r + 1, nB);
-			hi[r] = std::max(h, lo[r]);
-			cum[r + 1] = cum[r] + (hi[r] - lo[r]);
-		}
-	} else if (windowed) {
-		lo.resize(nA); hi.resize(nA); cum.assign((size_t)nA + 1, 0);
-		uint32_t l = 0, h = 0;
-		for (uint32_t r = 0; r < nA; ++r) {
-			const twk_hip_variant_meta& R = meta_at(a0 + r);
-			auto before = [&](uint32_t j) { const twk_hip_variant_meta& B = meta_at(b0 + j);
-				return B.rid < R.rid || (B.rid == R.rid && (uint64_t)B.pos + l_window < R.pos); };
-			auto within = [&](uint32_t j) { const twk_hip_variant_meta& B = meta_at(b0 + j);
-				return B.rid < R.rid || (B.rid == R.rid && B.pos <= (uint64_t)R.pos + l_window); };
-			while (l < nB && before(l)) ++l;
-			if (h < l) h = l;
-			while (h < nB && within(h)) ++h;
-			lo[r] = triangle ? std::min(std::max(l, r + 1), nB) : l;
-			hi[r] = std::max(h, lo[r]);
-			cum[r + 1] = cum[r] + (hi[r] - lo[r]);
-		}
-	}
-	auto window_boundary = [&](uint32_t k) -> uint32_t {
-		if (k == 0) return 0;
-		if (k >= n_parts) return nA;
-		const long double target = (long double)cum[nA] * k / n_parts;
-		const uint32_t r = (uint32_t)(std::lower_bound(cum.begin(), cum.end(), (uint64_t)target) - cum.begin());
-		return std::min(nA, (r + 32) / 64 * 64);
-	};
-	const uint32_t r0 = windowed ? window_boundary(part) : band_boundary(part, n_parts, nA, nB, triangle != 0);
-	const uint32_t r1 = windowed ? window_boundary(part + 1) : band_boundary(part + 1, n_parts, nA, nB, triangle != 0);
+	const ColRange* cr() const { return plan.windowed ? &col_range : nullptr; }
 
-	// ---- super-tiles of the band --------------------------------------------------------------
-	// Edge S in variants (multiple of 128).  Default: ~16384 plane rows per tile edge so that a
-	// launch holds >= 16 rounds of resident blocks and the partial last round costs < 3 %.
-	// Window mode: about a quarter of the window (in variants), so that the corners a row block
-	// computes outside the window stay near 10 % of its work.
-	const int Pmax = plan_for(c, mode).Pmax;
-	uint32_t S = tile_variants ? tile_variants : (16384u / (uint32_t)Pmax);
-	if (windowed && !tile_variants && r1 > r0) {
-		// Search the row-block height.  A launch over rows [x, x + h) holds, per row of tiles, the tiles from the diagonal
-		// (or the first column its rows reach) to the last column they reach - what build_tile_list lists - and costs
-		// ceil(tiles / resident blocks) rounds plus about half a round of launch, ramp-up and tail; the sum over the
-		// band's row blocks is minimised.  (The first version priced a launch as the whole rectangle out to the farthest
-		// column of its last row, which overstates tall blocks by up to half and made it choose ~1.7 rounds per launch
-		// for a 10,000-variant window at N = 2,504: 143 launches at 50 % of the kernel's rate.)
-		const uint64_t wv = std::max<uint64_t>(1, (cum[r1] - cum[r0]) / (r1 - r0));   // mean partners per row
-		// The plain path's math kernel visits every pair of the launch's rectangle, so there the block height stays near the
-		// window width; the fused path (count -> screen in the same kernel) visits the listed tiles only.
-		const TilePlan pl = plan_for(c, mode);
-		const bool fused_likely = ((pl.phased1 && set_kind(pl.set1) == PK_PHASED) || (!pl.phased1 && set_kind(pl.set1) == PK_UNPHASED)) && pl.set2 < 0
-		                          && f->minR2 > 1e-6 && f->minR2 <= 1.0 && c->opt.fused != 0
-		                          && ensure_planes(c, pl.set1) == TWK_HIP_OK && c->planes[pl.set1].W / KC <= FUSED_MAX_CHUNKS;
-		const uint32_t s_hi = fused_likely ? S : std::min<uint32_t>(S, std::max<uint32_t>(512u, round_up((uint32_t)std::min<uint64_t>(wv, 1u << 20), 64)));
-		const uint32_t s_lo = std::max<uint32_t>(128u, std::min<uint32_t>(s_hi, round_up((uint32_t)std::min<uint64_t>(wv / 8, 1u << 20), 64)));
-		const uint64_t R = c->resident_blocks;
-		auto rb = [&](uint64_t nv) -> uint64_t { return (nv * Pmax + TILE - 1) / TILE; };
-		auto launch_tiles = [&](uint32_t x, uint32_t h) -> uint64_t {
-			const uint32_t col0 = triangle ? x : lo[x];
-			const uint64_t gy = rb(h);
-			uint64_t tiles = 0;
-			for (uint64_t by = 0; by < gy; ++by) {
-				const uint32_t v0 = x + (uint32_t)((by * TILE) / Pmax);
-				const uint32_t v1 = (uint32_t)std::min<uint64_t>((uint64_t)x + h, (uint64_t)x + ((by + 1) * TILE + Pmax - 1) / Pmax);
-				if (v0 >= v1 || hi[v1 - 1] <= col0) continue;
-				uint64_t c_lo = lo[v0] > col0 ? ((uint64_t)(lo[v0] - col0) * Pmax) / TILE : 0;
-				if (triangle) c_lo = std::max<uint64_t>(c_lo, by);
-				const uint64_t c_hi = ((uint64_t)(hi[v1 - 1] - col0) * Pmax + TILE - 1) / TILE;
-				if (c_hi > c_lo) tiles += c_hi - c_lo;
-			}
-			return tiles;
-		};
-		uint32_t best = s_lo; uint64_t best_cost = ~0ull;
-		for (uint32_t cand = s_lo; cand <= s_hi; cand += 64) {
-			uint64_t cost = 0;                    // in half rounds
-			for (uint32_t x = r0; x < r1; x += cand) {
-				const uint64_t tiles = launch_tiles(x, std::min(cand, r1 - x));
-				if (tiles) cost += 2 * ((tiles + R - 1) / R) + 1;
-			}
-			if (cost < best_cost || (cost == best_cost && cand > best)) { best_cost = cost; best = cand; }
-		}
-		S = best;
-	}
-	S = std::max<uint32_t>(TILE, std::min<uint32_t>(S / TILE * TILE, 32768u));
-	S = std::min(S, round_up(std::max(nA, nB), TILE));
-
-	std::vector<twk_hip_tile_desc> mine;
-	auto push_tile = [&](uint32_t ra, uint32_t na, uint32_t cb, uint32_t nb_, int diag) {
-		twk_hip_tile_desc t{};
-		t.rowA0 = a0 + ra; t.nA = na; t.rowB0 = b0 + cb; t.nB = nb_; t.diag = diag; t.window = window; t.l_window = l_window;
-		if ((window & TWK_HIP_OPT_WINDOW) && !diag) {
-			// Each axis of a tile is sorted by (rid, pos) (file order, or one group of the regrouped set),
-			// but the two axes are in no particular order relative to each other (regrouped rectangle: the
-			// rows are the variants with missing data, the columns the rest).  A tile can only be skipped
-			// when both of its axes lie on one contig each and either the contigs differ or the position
-			// intervals are more than the window apart, in whichever direction (the reference's ticker
-			// skips the rest of a row on the same grounds, ld_balancing.h:191).
-			const twk_hip_variant_meta& firstA = meta_at(t.rowA0);
-			const twk_hip_variant_meta& lastA  = meta_at(t.rowA0 + t.nA - 1);
-			const twk_hip_variant_meta& firstB = meta_at(t.rowB0);
-			const twk_hip_variant_meta& lastB  = meta_at(t.rowB0 + t.nB - 1);
-			if (firstA.rid == lastA.rid && firstB.rid == lastB.rid) {
-				if (firstA.rid != firstB.rid) return;
-				if ((uint64_t)firstB.pos > (uint64_t)lastA.pos + l_window) return;      // columns wholly after the rows' reach
-				if ((uint64_t)firstA.pos > (uint64_t)lastB.pos + l_window) return;      // columns wholly before it
-			}
-		}
-		mine.push_back(t);
-	};
-	// Column step per row block.  A launch of B blocks takes ceil(B / resident) rounds of (equal
-	// length) blocks, so the partial last round is pure loss.  With the default tiling the column
-	// step is chosen, per row block, to minimise the total number of rounds (ties: fewer launches);
-	// it matters for the thin bands of a multi-GPU shard.  C stays <= 2 GiB per tile.
-	auto rows_of = [&](uint32_t nv) -> uint64_t { return ((uint64_t)nv * Pmax + TILE - 1) / TILE; };
-	// blocks of a launch: a diagonal tile only runs the blocks on and above its diagonal
-	auto blocks_of = [&](uint32_t h, uint32_t w, bool diag) -> uint64_t {
-		const uint64_t ra = rows_of(h), rb = rows_of(w);
-		return diag ? ra * (ra + 1) / 2 + ra * (rb - ra) : ra * rb;
-	};
-	auto choose_col_step = [&](uint32_t h, uint32_t col0, bool first_is_diag) -> uint32_t {
-		if (tile_variants || col0 >= nB) return std::max(S, h);
-		const uint64_t R = c->resident_blocks, ra = rows_of(h);
-		const uint64_t max_rows_b = std::min<uint64_t>(((2ull << 30) / 4) / (ra * TILE), 32768ull * Pmax / TILE);   // blocks
-		// window mode: the column range of a row block is already cut to what it can reach: one launch
-		// (or as few as the 2 GiB bound on C allows)
-		if (windowed)
-			return std::max<uint32_t>(h, (uint32_t)std::min<uint64_t>(32768ull, max_rows_b * TILE / Pmax / 64 * 64));
-		uint32_t best = std::max(S, h); uint64_t best_cost = ~0ull;
-		for (uint32_t sc = round_up(h, 64); sc <= 32768; sc += 64) {
-			if (rows_of(sc) > max_rows_b) break;
-			if (sc * 4 < S) continue;                               // keep launches reasonably large
-			uint64_t cost = 0; bool diag = first_is_diag;
-			for (uint32_t col = col0; col < nB; col += sc, diag = false)
-				cost += (blocks_of(h, std::min(sc, nB - col), diag) + R - 1) / R;
-			if (cost < best_cost || (cost == best_cost && sc > best)) { best_cost = cost; best = sc; }
-		}
-		return best;
-	};
-	// super-tiles sized by their count matrix, for the rows [xa, xb) of the band (appended to `mine`)
-	auto matrix_tiles = [&](uint32_t xa, uint32_t xb) {
-		for (uint32_t x = xa; x < xb; x += S) {
-			const uint32_t h = std::min(S, xb - x);
-			// triangle: the first tile of the row block starts on the diagonal (rows [x,x+h) x cols [x,x+w),
-			// w >= h, only col > row) and continues into the rectangle to its right in the same launch
-			uint32_t col = triangle ? x : 0, col_end = nB;
-			if (windowed) {       // only the columns some row of the block can reach
-				if (!triangle) col = lo[x];
-				col_end = hi[x + h - 1];
-				if (col_end <= col) continue;
-			}
-			const uint32_t sc = choose_col_step(h, col, triangle != 0);
-			bool diag = triangle != 0;
-			for (; col < col_end; col += sc, diag = false) {
-				uint32_t w = std::min(sc, col_end - col);
-				if (diag && w < h) w = std::min(h, nB - col);            // the diagonal tile must span its own rows
-				push_tile(x, h, col, w, diag ? 1 : 0);
-				if (diag && w > sc) col += w - sc;
-			}
-		}
-	};
-	// Band launches.  A fused launch keeps no count matrix - what it leaves behind is the list of its candidates - so
-	// nothing ties its extent to the 2 GiB a matrix may take: it is sized by its *work*.  The rows of the band are cut
-	// into launches of at least ~2^19 tile-chunks (about 5 ms of contraction), at most 8 per region, every one over all the
-	// columns its rows reach: one ramp-up and one tail per launch instead of per row block of 16,384 plane rows (the
-	// 2,504-sample window run of DESIGN 3.2a: 13 launches at 68 % of the ceiling -> 1 at 77 %), and a handful of sorts, copies
-	// and hand-overs per region on the host instead of dozens (2,504 x 531,500, all pairs: 1.28 s of compute + write in 39
-	// launches, 1.03 s in 9).  More than one launch when there is work for it: the host's writer gets its first records while
-	// the device still counts.  (A launch of a million tiles needed the unit table's entries to carry their tile - one scalar
-	// load per unit instead of two dependent ones - to run like one of a hundred thousand: 59 % -> 83 % of the ceiling.)
-	// A launch whose candidates or survivors outgrow their buffers is redone as matrix-sized tiles (below).
-	struct BandLaunch { uint32_t xa, xb; size_t list_words; size_t tile_index; };
-	std::vector<BandLaunch> bands;
-	const bool band_mode = !tile_variants && c->opt.band_launch && r1 > r0 && fused_form_applies(c, mode, *f);
-	if (band_mode) {
-		const uint32_t nchunks = c->planes[plan_for(c, mode).set1].W / KC;
-		const uint32_t step = TILE;                                  // rows are cut on multiples of 128 variants
-		std::vector<uint64_t> cum_tiles(1, 0);
-		auto rb = [&](uint64_t nv) -> uint64_t { return (nv * Pmax + TILE - 1) / TILE; };
-		auto tiles_of_rows = [&](uint32_t x, uint32_t h) -> uint64_t {      // the tiles build_tile_list will list for rows [x, x + h) over all their columns
-			const uint32_t col0 = triangle ? x : (windowed ? lo[x] : 0);
-			uint64_t tiles = 0;
-			for (uint64_t by = 0, gy = rb(h); by < gy; ++by) {
-				const uint32_t v0 = x + (uint32_t)((by * TILE) / Pmax);
-				const uint32_t v1 = (uint32_t)std::min<uint64_t>((uint64_t)x + h, (uint64_t)x + ((by + 1) * TILE + Pmax - 1) / Pmax);
-				if (v0 >= v1) continue;
-				const uint32_t reach = windowed ? hi[v1 - 1] : nB;
-				if (reach <= col0) continue;
-				uint64_t c_lo = (windowed && lo[v0] > col0) ? ((uint64_t)(lo[v0] - col0) * Pmax) / TILE : 0;
-				if (triangle) c_lo = std::max<uint64_t>(c_lo, by);
-				const uint64_t c_hi = ((uint64_t)(reach - col0) * Pmax + TILE - 1) / TILE;
-				if (c_hi > c_lo) tiles += c_hi - c_lo;
-			}
-			return tiles;
-		};
-		for (uint32_t x = r0; x < r1; x += step) cum_tiles.push_back(cum_tiles.back() + tiles_of_rows(x, std::min(step, r1 - x)));
-		const uint64_t total = cum_tiles.back();
-		const uint64_t n_launch = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)c->opt.band_max_launches, total * nchunks >> c->opt.band_work_log2));
-		const uint64_t pairs_per_tile = (uint64_t)(TILE / Pmax) * (TILE / Pmax);
-		const unsigned words_per_entry = plan_for(c, mode).phased1 ? 3 : 6;
-		size_t k0 = 0;
-		for (uint64_t l = 0; l < n_launch && k0 + 1 < cum_tiles.size(); ++l) {
-			size_t k1 = cum_tiles.size() - 1;
-			if (l + 1 < n_launch) {
-				const uint64_t target = total * (l + 1) / n_launch;
-				k1 = (size_t)(std::lower_bound(cum_tiles.begin() + k0 + 1, cum_tiles.end(), target) - cum_tiles.begin());
-				k1 = std::min(k1, cum_tiles.size() - 1);
-			}
-			if (k1 <= k0) continue;
-			const uint32_t xa = r0 + (uint32_t)k0 * step, xb = std::min<uint64_t>(r1, (uint64_t)r0 + (uint64_t)k1 * step);
-			const uint64_t tiles = cum_tiles[k1] - cum_tiles[k0];
-			k0 = k1;
-			if (!tiles) continue;
-			const uint32_t col0 = triangle ? xa : (windowed ? lo[xa] : 0), col_end = windowed ? hi[xb - 1] : nB;
-			if (col_end <= col0) continue;
-			uint32_t w = col_end - col0;
-			if (triangle && w < xb - xa) w = std::min(xb - xa, nB - col0);
-			if (rb(xb - xa) > 0xFFFFu || rb(w) > 0xFFFFu) { bands.clear(); mine.clear(); break; }      // beyond a tile list's 16-bit coordinates: matrix tiles
-			// candidate slots: 1/32 of the launch's pairs (a survivor-rich window run has 2 % candidates), 4 M at least, 256 M
-			// at most; the survivor buffer is sized once the candidates are counted (enqueue_band_math)
-			uint64_t entries = std::min<uint64_t>(std::max<uint64_t>(tiles * pairs_per_tile / 32, 1ull << 22), 1ull << 28);
-			entries = std::min<uint64_t>(entries, std::max<uint64_t>(tiles * pairs_per_tile / 3, 1024));      // (never more than a matrix tile would get)
-			if (c->opt.band_list_entries) entries = (uint64_t)c->opt.band_list_entries;      // (test / measurement: exactly this many)
-			BandLaunch b{xa, xb, (size_t)entries * words_per_entry, mine.size()};
-			const size_t before = mine.size();
-			push_tile(xa, xb - xa, col0, w, triangle ? 1 : 0);
-			if (mine.size() > before) bands.push_back(b);
-		}
-	}
-	if (bands.empty()) matrix_tiles(r0, r1);
-	else if (screen && c->opt.band_reverse) {
-		// Allele-count order: the survivors of a run concentrate in the last bands (common variants: 18 M of the 25.7 M pairs of
-		// the 2,504 x 531,500 run come from the last two launches of eight).  Last band first, so that the host compresses
-		// those while the device counts the poor ones, instead of after it has finished (profiles/r04_band_timeline.txt).
-		std::reverse(bands.begin(), bands.end());
-		std::reverse(mine.begin(), mine.begin() + (ptrdiff_t)bands.size());
-		for (size_t i = 0; i < bands.size(); ++i) bands[i].tile_index = i;
-	}
-
-	uint64_t tot_pairs = 0, tot_recs = 0;
-	// Worst case every pair of a tile survives; cap the device buffer and split on overflow.
-	unsigned long long cap_default = 1ull << 24;
-	{
+	// Survivor buffer of a launch (worst case every pair of a tile survives: capped, split on overflow) and the reach of the rows on the device.
+	int prepare() {
 		unsigned long long worst = 0;
-		for (const auto& t : mine) worst = std::max<unsigned long long>(worst, (unsigned long long)t.nA * t.nB);
+		for (const auto& t : plan.mine) worst = std::max<unsigned long long>(worst, (unsigned long long)t.nA * t.nB);
 		cap_default = std::min<unsigned long long>(worst ? worst : 1, 1ull << 24);
+		if (c->opt.record_cap > 0) cap_default = std::min<unsigned long long>(cap_default, (unsigned long long)c->opt.record_cap);   // test hook: force the overflow / strip path
+		if (plan.windowed) { col_range.lo = plan.lo.data(); col_range.hi = plan.hi.data(); col_range.a0 = g.a0; col_range.b0 = g.b0; }
+		if (env.screen && g.nA) {
+			if (c->d_col_hi_cap < g.nA) {
+				if (c->d_col_hi) (void)hipFree(c->d_col_hi);
+				c->d_col_hi = nullptr; c->d_col_hi_cap = 0;
+				HIPCHK(c, hipMalloc((void**)&c->d_col_hi, (size_t)g.nA * 4));
+				c->d_col_hi_cap = g.nA;
+			}
+			HIPCHK(c, hipMemcpy(c->d_col_hi, plan.hi.data(), (size_t)g.nA * 4, hipMemcpyHostToDevice));
+			col_range.d_hi = c->d_col_hi; col_range.n_hi = g.nA;
+		}
+		return TWK_HIP_OK;
 	}
 
-	if (c->opt.record_cap > 0) cap_default = std::min<unsigned long long>(cap_default, (unsigned long long)c->opt.record_cap);   // test hook: force the overflow / strip path
-	int rc = TWK_HIP_OK;
-	size_t issued = 0, done = 0;
-	const size_t n = mine.size();
-	ColRange col_range;
-	if (windowed) { col_range.lo = lo.data(); col_range.hi = hi.data(); col_range.a0 = a0; col_range.b0 = b0; }
-	if (screen && nA) {
-		if (c->d_col_hi_cap < nA) {
-			if (c->d_col_hi) (void)hipFree(c->d_col_hi);
-			c->d_col_hi = nullptr; c->d_col_hi_cap = 0;
-			HIPCHK(c, hipMalloc((void**)&c->d_col_hi, (size_t)nA * 4));
-			c->d_col_hi_cap = nA;
+	// The list zone of an allele-count-sorted set (long rows only): its pairs are intersected as carrier lists, block of rows after
+	// block of rows, and the rows with the shortest lists probe every column behind them, before the tiles that are left are contracted.
+	int run_zone_passes() {
+		if (!(env.screen && g.a0 == 0 && g.b0 == 0)) return TWK_HIP_OK;
+		const bool unphased = env.screen == 2;
+		const PlaneSet& ps = c->planes[unphased ? PS_SORTED_U : PS_SORTED_P];
+		const uint32_t zone = std::min(ps.n_list, g.nA), r0 = plan.r0, r1 = plan.r1;
+		if (!(zone >= 2 && ps.lists)) return TWK_HIP_OK;
+		col_range.list_zone = zone;
+		// rows whose list is short enough to probe with (the first n_probe of the zone) take every column behind them as probes,
+		// the zone's own included ("probe_zone": a probe walks one list and tests bits of the partner's row, a merge walks two
+		// lists in step - 0.28 against 1.05 ns a pair on the unphased zone of the 1 M x 50 k cohort run); the merges are left
+		// with the zone's last rows
+		const uint32_t pz_first = (c->opt.probe && c->opt.probe_zone) ? std::min(ps.n_probe, zone) : 0;
+		const uint32_t lr0 = std::min(std::max(r0, pz_first), zone), lr1 = std::min(r1, zone);
+		uint32_t rows_per = (uint32_t)std::max<uint64_t>(64, std::min<uint64_t>(32768, (1ull << 25) / zone));
+		unsigned long long cap_list = cap_default;
+		for (uint32_t row = lr0; row < lr1;) {
+			const uint32_t nr = std::min(rows_per, lr1 - row);
+			unsigned long long nrec = 0;
+			const int rc = run_list_block(c, *f, unphased, row, nr, zone, g.window, g.l_window, col_range, cap_list, &nrec, !c->device_sink, sink, user);
+			if (rc == TWK_HIP_E_OVERFLOW && nr > 1) { rows_per = std::max<uint32_t>(1, nr / 2); continue; }      // more survivors than the buffer holds: fewer rows
+			if (rc == TWK_HIP_E_OVERFLOW && cap_list < zone) { cap_list = zone; continue; }                      // one row: it cannot have more than `zone` partners
+			if (rc) return rc;
+			tot_recs += nrec;
+			row += nr;
 		}
-		HIPCHK(c, hipMemcpy(c->d_col_hi, hi.data(), (size_t)nA * 4, hipMemcpyHostToDevice));
-		col_range.d_hi = c->d_col_hi; col_range.n_hi = nA;
-	}
-	// The list zone of the allele-count-sorted phased set (long rows only): its pairs are intersected as carrier lists,
-	// block of rows after block of rows, before the tiles that are left are contracted.
-	if (screen && a0 == 0 && b0 == 0) {
-		const PlaneSet& ps = c->planes[screen == 2 ? PS_SORTED_U : PS_SORTED_P];
-		const uint32_t zone = std::min(ps.n_list, nA);
-		if (zone >= 2 && ps.lists) {
-			col_range.list_zone = zone;
-			// rows whose list is short enough to probe with (the first n_probe of the zone) take every column behind them as probes,
-			// the zone's own included ("probe_zone": a probe walks one list and tests bits of the partner's row, a merge walks two
-			// lists in step - 0.28 against 1.05 ns a pair on the unphased zone of the 1 M x 50 k cohort run); the merges are left
-			// with the zone's last rows
-			const uint32_t pz_first = (c->opt.probe && c->opt.probe_zone) ? std::min(ps.n_probe, zone) : 0;
-			const uint32_t lr0 = std::min(std::max(r0, pz_first), zone), lr1 = std::min(r1, zone);
-			uint32_t rows_per = (uint32_t)std::max<uint64_t>(64, std::min<uint64_t>(32768, (1ull << 25) / zone));
-			unsigned long long cap_list = cap_default;
-			for (uint32_t row = lr0; row < lr1;) {
-				const uint32_t nr = std::min(rows_per, lr1 - row);
-				unsigned long long nrec = 0;
-				rc = run_list_block(c, *f, screen == 2, row, nr, zone, window, l_window, col_range, cap_list, &nrec, !c->device_sink, sink ? sink : discard_records, user);
-				if (rc == TWK_HIP_E_OVERFLOW && nr > 1) { rows_per = std::max<uint32_t>(1, nr / 2); continue; }      // more survivors than the buffer holds: fewer rows
-				if (rc == TWK_HIP_E_OVERFLOW && cap_list < zone) { cap_list = zone; continue; }                      // one row: it cannot have more than `zone` partners
-				if (rc) return rc;
-				tot_recs += nrec;
-				row += nr;
-			}
-			mark("carrier-list pass done, zone", zone, tot_recs);
-			// ... and the zone's rows against the columns beyond the zone: probes of the row variant's carriers into the column
-			// variant's row (K1's asymmetric path, ld_engine.cpp:230-242; measured to win for every list the zone keeps,
-			// ld_list.hip.h), so that no tile row inside the zone is contracted at all.
-			const uint32_t pzone = c->opt.probe ? std::min(ps.n_probe, zone) : 0;
-			const bool zone_cols = c->opt.probe_zone != 0;             // the probes' columns start behind the row, not behind the zone
-			if (pzone && (zone < nB || zone_cols)) {
-				col_range.probe_zone = pzone;
-				unsigned long long cap_probe = cap_default;
-				uint32_t rows_cap = 32768;                                   // halved when a block's survivors outgrow the buffer
-				const uint32_t pr0 = std::min(r0, pzone), pr1 = std::min(r1, pzone);
-				for (uint32_t row = pr0; row < pr1;) {
-					// the columns the block's rows reach (the band limit never decreases along the rows)
-					auto reach = [&](uint32_t last_row) -> uint32_t { return std::min<uint64_t>(nB, col_range.hi ? (uint64_t)col_range.b0 + col_range.hi[last_row - col_range.a0] : nB); };
-					uint32_t nr = std::min<uint32_t>(pr1 - row, rows_cap);
-					const uint32_t first = zone_cols ? row + 1 : zone;       // first column of the block (a row's own start at row + 1: the kernel's j > i)
-					while (nr > 256 && (uint64_t)nr * (reach(row + nr - 1) > first ? reach(row + nr - 1) - first : 0) > (1ull << 25)) nr = std::max<uint32_t>(256, nr / 2);
-					const uint32_t lim = reach(row + nr - 1);
-					if (lim <= first) { row += nr; continue; }
-					unsigned long long nrec = 0;
-					rc = run_probe_block(c, *f, screen == 2, row, nr, zone, first, lim - first, window, l_window, col_range, cap_probe, &nrec, !c->device_sink, sink ? sink : discard_records, user);
-					if (rc == TWK_HIP_E_OVERFLOW && nr > 1) { rows_cap = std::max<uint32_t>(1, nr / 2); continue; }
-					if (rc == TWK_HIP_E_OVERFLOW && cap_probe < (unsigned long long)(lim - first)) { cap_probe = lim - first; continue; }
-					if (rc) return rc;
-					tot_recs += nrec;
-					row += nr;
-				}
-				mark("probe pass done, zone", pzone, tot_recs);
-			}
+		mark("carrier-list pass done, zone", zone, tot_recs);
+		// ... and the zone's rows against the columns beyond the zone: probes of the row variant's carriers into the column
+		// variant's row (K1's asymmetric path, ld_engine.cpp:230-242; measured to win for every list the zone keeps,
+		// ld_list.hip.h), so that no tile row inside the zone is contracted at all.
+		const uint32_t pzone = c->opt.probe ? std::min(ps.n_probe, zone) : 0;
+		const bool zone_cols = c->opt.probe_zone != 0;             // the probes' columns start behind the row, not behind the zone
+		if (!(pzone && (zone < g.nB || zone_cols))) return TWK_HIP_OK;
+		col_range.probe_zone = pzone;
+		unsigned long long cap_probe = cap_default;
+		uint32_t rows_cap = 32768;                                   // halved when a block's survivors outgrow the buffer
+		const uint32_t pr0 = std::min(r0, pzone), pr1 = std::min(r1, pzone);
+		// the columns a block's rows reach (the band limit never decreases along the rows)
+		auto reach = [&](uint32_t last_row) -> uint32_t { return (uint32_t)std::min<uint64_t>(g.nB, col_range.hi ? (uint64_t)col_range.b0 + col_range.hi[last_row - col_range.a0] : g.nB); };
+		for (uint32_t row = pr0; row < pr1;) {
+			uint32_t nr = std::min<uint32_t>(pr1 - row, rows_cap);
+			const uint32_t first = zone_cols ? row + 1 : zone;       // first column of the block (a row's own start at row + 1: the kernel's j > i)
+			while (nr > 256 && (uint64_t)nr * (reach(row + nr - 1) > first ? reach(row + nr - 1) - first : 0) > (1ull << 25)) nr = std::max<uint32_t>(256, nr / 2);
+			const uint32_t lim = reach(row + nr - 1);
+			if (lim <= first) { row += nr; continue; }
+			unsigned long long nrec = 0;
+			const int rc = run_probe_block(c, *f, unphased, row, nr, zone, first, lim - first, g.window, g.l_window, col_range, cap_probe, &nrec, !c->device_sink, sink, user);
+			if (rc == TWK_HIP_E_OVERFLOW && nr > 1) { rows_cap = std::max<uint32_t>(1, nr / 2); continue; }
+			if (rc == TWK_HIP_E_OVERFLOW && cap_probe < (unsigned long long)(lim - first)) { cap_probe = lim - first; continue; }
+			if (rc) return rc;
+			tot_recs += nrec;
+			row += nr;
 		}
-	}
-	mark("tiles listed", mine.size());
-	// One matrix-sized tile, synchronously, with its fallbacks: the fused form's candidate list overflowed -> through C (and
-	// the rest of the call as well); more survivors than the buffer holds -> row strips.
-	auto run_tile_with_fallbacks = [&](const twk_hip_tile_desc& t) -> int {
-		unsigned long long nrec = 0;
-		int r = run_tile_sync(c, mode, t, *f, cap_default, &nrec, !c->device_sink, windowed ? &col_range : nullptr, sink ? sink : discard_records, user);
-		if (r == TWK_HIP_E_OVERFLOW) {
-			uint64_t nr = 0;
-			r = redo_tile_in_strips(c, mode, t, *f, c->slot[SYNC_SLOT].cap_use, sink, user, &nr, windowed ? &col_range : nullptr);
-			nrec = nr;
-		}
-		if (r == TWK_HIP_OK) tot_recs += nrec;
-		return r;
-	};
-	// a band launch that cannot run (or has overflowed) as the matrix-sized tiles of its rows
-	auto run_band_as_matrix_tiles = [&](const BandLaunch& b) -> int {
-		std::vector<twk_hip_tile_desc> keep;
-		keep.swap(mine);
-		matrix_tiles(b.xa, b.xb);
-		std::vector<twk_hip_tile_desc> sub;
-		sub.swap(mine);
-		mine.swap(keep);
-		for (const auto& t : sub) { const int r = run_tile_with_fallbacks(t); if (r) return r; }
+		mark("probe pass done, zone", pzone, tot_recs);
 		return TWK_HIP_OK;
-	};
+	}
+
 	// The three-product form through a count matrix (long rows) pays only where candidates are few: a launch whose list overflows is redone
 	// with four products, three-product launches already in flight behind it included (1 M x 50,000 cohort run, calc -u: 977 -> 1,426 ms of
 	// count kernel with three such launches wasted), and how many pairs are candidates differs from launch to launch - in allele-count order
@@ -2095,104 +1839,186 @@ static int region_impl(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint3
 	// pipeline starts: a sub-tile of at most 384 x 384 variants from its middle through the same kernels (half a millisecond), three
 	// products if at most 1 pair in 256 of the sample is a candidate.  (Regions of more than 64 launches sample every k-th one; the others
 	// follow their nearest sampled neighbour.)
-	std::vector<char> want_three(n, 1);
-	if (!mine.empty() && c->three_ok && c->opt.three == 1) {
+	int decide_three_by_samples() {
+		const std::vector<twk_hip_tile_desc>& mine = plan.mine;
+		const size_t n = mine.size();
+		want_three.assign(n, 1);
+		if (mine.empty() || !c->three_ok || c->opt.three != 1) return TWK_HIP_OK;
 		const TilePlan pl = plan_for(c, mode);
-		const bool eligible = !pl.phased1 && pl.set2 < 0 && set_kind(pl.set1) == PK_UNPHASED && f->minR2 > 1e-6 && f->minR2 <= 1.0 && !fused_form_applies(c, mode, *f);
-		if (eligible) {
-			const size_t step = (n + 63) / 64;
-			for (size_t i0 = 0; i0 < n; i0 += step) {
-				const size_t pick = std::min(n - 1, i0 + step / 2);
-				const twk_hip_tile_desc& t0 = mine[pick];
-				twk_hip_tile_desc st = t0;
-				const uint32_t h = std::min<uint32_t>(384, t0.nA), row_c = t0.rowA0 + (t0.nA - h) / 2;
-				st.rowA0 = row_c; st.nA = h;
-				if (t0.diag && t0.rowA0 == t0.rowB0) { st.rowB0 = row_c; st.nB = std::min<uint32_t>(h, t0.rowB0 + t0.nB - row_c); st.diag = 1; }
-				else { const uint32_t wv = std::min<uint32_t>(384, t0.nB); st.rowB0 = t0.rowB0 + (t0.nB - wv) / 2; st.nB = wv; st.diag = 0; }
-				const twk_hip_timing keep_timing = c->timing;
-				Slot& ss = c->slot[SYNC_SLOT];
-				unsigned long long nrec = 0;
-				rc = enqueue_tile(c, mode, st, *f, ss, std::max<unsigned long long>((unsigned long long)st.nA * st.nB, 1), windowed ? &col_range : nullptr);
-				if (rc == TWK_HIP_OK) rc = finish_tile(c, ss, st, &nrec, true, discard_records, nullptr);
-				const unsigned long long cand = ss.h_n_out[2], sample_pairs = std::max<uint64_t>(pairs_in_tile(c, st), 1);
-				c->timing = keep_timing;
-				c->three_ok = true;                      // (a sample's own overflow decides its launch, not the call)
-				const bool dense = rc == TWK_HIP_E_OVERFLOW || (rc == TWK_HIP_OK && cand * 256 > sample_pairs);
-				if (rc != TWK_HIP_OK && rc != TWK_HIP_E_OVERFLOW) return rc;
-				for (size_t i = i0; i < std::min(n, i0 + step); ++i) want_three[i] = dense ? 0 : 1;
-				mark("three-product sample of launch: candidates", pick, cand);
-				rc = TWK_HIP_OK;
-			}
+		const bool eligible = !pl.phased1 && pl.set2 < 0 && set_kind(pl.set1) == PK_UNPHASED && f->minR2 > 1e-6 && f->minR2 <= 1.0 && !env.fused;
+		if (!eligible) return TWK_HIP_OK;
+		const size_t step = (n + 63) / 64;
+		for (size_t i0 = 0; i0 < n; i0 += step) {
+			const size_t pick = std::min(n - 1, i0 + step / 2);
+			const twk_hip_tile_desc& t0 = mine[pick];
+			twk_hip_tile_desc st = t0;
+			const uint32_t h = std::min<uint32_t>(384, t0.nA), row_c = t0.rowA0 + (t0.nA - h) / 2;
+			st.rowA0 = row_c; st.nA = h;
+			if (t0.diag && t0.rowA0 == t0.rowB0) { st.rowB0 = row_c; st.nB = std::min<uint32_t>(h, t0.rowB0 + t0.nB - row_c); st.diag = 1; }
+			else { const uint32_t wv = std::min<uint32_t>(384, t0.nB); st.rowB0 = t0.rowB0 + (t0.nB - wv) / 2; st.nB = wv; st.diag = 0; }
+			const twk_hip_timing keep_timing = c->timing;
+			const size_t keep_ring = c->launch_ring.size(); const uint64_t keep_seen = c->launches_seen;
+			Slot& ss = c->slot[SYNC_SLOT];
+			unsigned long long nrec = 0;
+			int rc = enqueue_tile(c, mode, st, *f, ss, std::max<unsigned long long>((unsigned long long)st.nA * st.nB, 1), cr());
+			if (rc == TWK_HIP_OK) rc = finish_tile(c, ss, st, &nrec, true, discard_records, nullptr);
+			const unsigned long long cand = ss.h_n_out[2], sample_pairs = std::max<uint64_t>(pairs_in_tile(c, st), 1);
+			c->timing = keep_timing;                 // (a sample is not a launch of the run: neither in the timing nor in the launch log)
+			if (c->launch_ring.size() > keep_ring && c->launches_seen == keep_seen + 1 && keep_seen < LAUNCH_RING) c->launch_ring.pop_back();
+			c->launches_seen = keep_seen;
+			c->three_ok = true;                      // (a sample's own overflow decides its launch, not the call)
+			const bool dense = rc == TWK_HIP_E_OVERFLOW || (rc == TWK_HIP_OK && cand * 256 > sample_pairs);
+			if (rc != TWK_HIP_OK && rc != TWK_HIP_E_OVERFLOW) return rc;
+			for (size_t i = i0; i < std::min(n, i0 + step); ++i) want_three[i] = dense ? 0 : 1;
+			mark("three-product sample of launch: candidates", pick, cand);
 		}
+		return TWK_HIP_OK;
 	}
-	auto band_of = [&](size_t i) -> const BandLaunch* { return i < bands.size() ? &bands[i] : nullptr; };       // (band launches are mine[0 .. bands.size()), in order)
-	std::vector<char> skipped(n, 0);
-	// software pipeline over the launches of this shard, PIPE_SLOTS deep
-	size_t math_issued = 0;                    // band launches [0, math_issued) have had the second half of their work enqueued
-	auto band_math = [&](size_t i) -> int {
-		if (band_of(i) && !skipped[i]) {
+
+	// One matrix-sized tile, synchronously, with its fallbacks: the fused form's candidate list overflowed -> through C (and
+	// the rest of the call as well); more survivors than the buffer holds -> row strips.
+	int run_tile_with_fallbacks(const twk_hip_tile_desc& t) {
+		unsigned long long nrec = 0;
+		int r = run_tile_sync(c, mode, t, *f, cap_default, &nrec, !c->device_sink, cr(), sink, user);
+		if (r == TWK_HIP_E_OVERFLOW) {
+			uint64_t nr = 0;
+			r = redo_tile_in_strips(c, mode, t, *f, c->slot[SYNC_SLOT].cap_use, sink, user, &nr, cr());
+			nrec = nr;
+		}
+		if (r == TWK_HIP_OK) tot_recs += nrec;
+		return r;
+	}
+	// a band launch that cannot run (or has overflowed) as the matrix-sized tiles of its rows
+	int run_band_as_matrix_tiles(const BandLaunch& b) {
+		std::vector<twk_hip_tile_desc> sub;
+		plan_matrix_tiles(env, g, plan, b.xa, b.xb, sub);
+		for (const auto& t : sub) { const int r = run_tile_with_fallbacks(t); if (r) return r; }
+		return TWK_HIP_OK;
+	}
+
+	// The second half of band launch i (its pair math: once the count kernel's candidate count is known).
+	int band_math(size_t i, const std::vector<char>& skipped) {
+		if (i < plan.bands.size() && !skipped[i]) {
 			mark("math: wait for count of launch", i);
 			const int r = enqueue_band_math(c, c->slot[i % PIPE_SLOTS]);
 			mark("math enqueued for launch", i, c->slot[i % PIPE_SLOTS].h_n_out[2]);
 			return r;
 		}
 		return TWK_HIP_OK;
-	};
-	while (done < n) {
-		while (issued < n && issued < done + PIPE_SLOTS) {
-			const BandLaunch* b = band_of(issued);
-			if (b && !c->fused_ok) skipped[issued] = 1;                 // an earlier launch gave the fused form up: this one goes the matrix way when its turn comes
-			else {
-				mark("enqueue launch", issued);
-				const bool three_was = c->three_ok;
-				c->three_ok = three_was && want_three[issued] != 0;       // (the launch's own sample)
-				rc = enqueue_tile(c, mode, mine[issued], *f, c->slot[issued % PIPE_SLOTS], b ? 1 : cap_default, windowed ? &col_range : nullptr, b ? b->list_words : 0);
-				c->three_ok = three_was;
-				if (rc) return rc;
-				mark("enqueued launch", issued);
-			}
-			++issued;
-			// the pair math of a band launch follows once its count kernel is done - with the next launch's count kernel already
-			// queued behind it, so that the device has work while the host waits for the candidate count
-			while (math_issued + 1 < issued) { rc = band_math(math_issued); if (rc) return rc; ++math_issued; }
-		}
-		while (math_issued <= done && math_issued < issued) { rc = band_math(math_issued); if (rc) return rc; ++math_issued; }
+	}
+
+	// Launch `done` has been waited for: deliver its records, or run its fallbacks.
+	int finish_launch(size_t done, const std::vector<char>& skipped) {
+		const std::vector<twk_hip_tile_desc>& mine = plan.mine;
 		Slot& s = c->slot[done % PIPE_SLOTS];
 		unsigned long long nrec = 0;
-		const BandLaunch* b = band_of(done);
+		const BandLaunch* b = done < plan.bands.size() ? &plan.bands[done] : nullptr;
 		mark("finish: wait for launch", done);
+		int rc;
 		if (b) {
-			rc = skipped[done] ? TWK_HIP_E_OVERFLOW : finish_tile(c, s, mine[done], &nrec, !c->device_sink, sink ? sink : discard_records, user);
+			rc = skipped[done] ? TWK_HIP_E_OVERFLOW : finish_tile(c, s, mine[done], &nrec, !c->device_sink, sink, user);
 			mark("finished (records delivered) launch", done, nrec);
 			if (rc == TWK_HIP_E_OVERFLOW) rc = run_band_as_matrix_tiles(*b);      // candidates or survivors beyond the launch's buffers
 			else if (rc == TWK_HIP_OK) tot_recs += nrec;
-			if (rc) return rc;
-		} else {
-			rc = finish_tile(c, s, mine[done], &nrec, !c->device_sink, sink ? sink : discard_records, user);
-			if (rc == TWK_HIP_E_OVERFLOW && s.cand_overflow) {     // the fused form's candidate list overflowed: this tile again through C
-				c->fused_ok = false; c->three_ok = false;            // (and the tiles not yet enqueued as well)
-				rc = run_tile_sync(c, mode, mine[done], *f, cap_default, &nrec, !c->device_sink, windowed ? &col_range : nullptr, sink ? sink : discard_records, user);
-			}
-			if (rc == TWK_HIP_E_OVERFLOW) {
-				uint64_t nr = 0;
-				rc = redo_tile_in_strips(c, mode, mine[done], *f, s.cap_use, sink, user, &nr, windowed ? &col_range : nullptr);
-				if (rc) return rc;
-				tot_recs += nr;
-			} else if (rc) {
-				return rc;
-			} else {
-				tot_recs += nrec;
-			}
+			return rc;
 		}
-		tot_pairs += pairs_in_tile(c, mine[done]);
-		if (!b) mark("finished (records delivered) launch", done, tot_recs);
-		++done;
-		if (c->progress_cb && !c->progress_muted) c->progress_cb(c->progress_user, tot_pairs, (uint32_t)done, (uint32_t)n);
+		rc = finish_tile(c, s, mine[done], &nrec, !c->device_sink, sink, user);
+		if (rc == TWK_HIP_E_OVERFLOW && s.cand_overflow) {     // the fused / three-product form's candidate list overflowed: this tile again through C, four products
+			c->fused_ok = false; c->three_ok = false;            // (and the tiles not yet enqueued as well)
+			rc = run_tile_sync(c, mode, mine[done], *f, cap_default, &nrec, !c->device_sink, cr(), sink, user);
+		}
+		if (rc == TWK_HIP_E_OVERFLOW) {
+			uint64_t nr = 0;
+			rc = redo_tile_in_strips(c, mode, mine[done], *f, s.cap_use, sink, user, &nr, cr());
+			if (rc) return rc;
+			tot_recs += nr;
+		} else if (rc) {
+			return rc;
+		} else {
+			tot_recs += nrec;
+		}
+		mark("finished (records delivered) launch", done, tot_recs);
+		return TWK_HIP_OK;
 	}
-	if (screen) tot_pairs = band_pairs_before(r1, nA, nB, true) - band_pairs_before(r0, nA, nB, true);   // every pair of the band is decided
-	else if (windowed) tot_pairs = cum[r1] - cum[r0];       // pairs inside the window: the ones the math evaluates
-	if (n_pairs) *n_pairs = tot_pairs;
-	if (n_records) *n_records = tot_recs;
+
+	// Software pipeline over the launches of this shard, PIPE_SLOTS deep.  The pair math of a band launch follows once its count kernel is
+	// done - with the next launch's count kernel already queued behind it, so that the device has work while the host waits for the
+	// candidate count.
+	int run_pipeline() {
+		const std::vector<twk_hip_tile_desc>& mine = plan.mine;
+		const size_t n = mine.size();
+		std::vector<char> skipped(n, 0);
+		size_t issued = 0, done = 0, math_issued = 0;      // band launches [0, math_issued) have had the second half of their work enqueued
+		int rc = TWK_HIP_OK;
+		while (done < n) {
+			while (issued < n && issued < done + PIPE_SLOTS) {
+				const BandLaunch* b = issued < plan.bands.size() ? &plan.bands[issued] : nullptr;
+				if (b && !c->fused_ok) skipped[issued] = 1;                 // an earlier launch gave the fused form up: this one goes the matrix way when its turn comes
+				else {
+					mark("enqueue launch", issued);
+					const bool three_was = c->three_ok;
+					c->three_ok = three_was && want_three[issued] != 0;       // (the launch's own sample)
+					rc = enqueue_tile(c, mode, mine[issued], *f, c->slot[issued % PIPE_SLOTS], b ? 1 : cap_default, cr(), b ? b->list_words : 0);
+					c->three_ok = three_was;
+					if (rc) return rc;
+					mark("enqueued launch", issued);
+				}
+				++issued;
+				while (math_issued + 1 < issued) { rc = band_math(math_issued, skipped); if (rc) return rc; ++math_issued; }
+			}
+			while (math_issued <= done && math_issued < issued) { rc = band_math(math_issued, skipped); if (rc) return rc; ++math_issued; }
+			rc = finish_launch(done, skipped);
+			if (rc) return rc;
+			tot_pairs += pairs_in_tile(c, mine[done]);
+			++done;
+			if (c->progress_cb && !c->progress_muted) c->progress_cb(c->progress_user, tot_pairs, (uint32_t)done, (uint32_t)n);
+		}
+		return TWK_HIP_OK;
+	}
+};
+
+// What the planner needs to know of the context for this mode.
+int plan_env_for(twk_hip_ctx* c, int mode, const twk_hip_filters* f, PlanEnv& env) {
+	env = PlanEnv();
+	if (mode == MODE_INT_GROUPED || mode == MODE_INT_SORTED_P || mode == MODE_INT_SORTED_U) {
+		const int set = mode == MODE_INT_GROUPED ? PS_GROUPED : mode == MODE_INT_SORTED_P ? PS_SORTED_P : PS_SORTED_U;
+		const int rc = ensure_planes(c, set); if (rc) return rc;
+		env.ids = c->planes[set].h_ids.data();
+	}
+	// r2 screen (TWK_HIP_OPT_R2_SCREEN): the region is a triangle over the leading, missing-free part of an allele-count-sorted set
+	env.screen = (mode == MODE_INT_SORTED_P) ? 1 : (mode == MODE_INT_SORTED_U) ? 2 : 0;
+	if (env.screen) { const int rc = ensure_popcounts(c); if (rc) return rc; env.popc = c->h_popc.data(); }
+	const TilePlan pl = plan_for(c, mode);
+	env.n_samples = c->N; env.Pmax = pl.Pmax; env.resident_blocks = c->resident_blocks; env.minR2 = f->minR2; env.phased_math = pl.phased1;
+	env.meta = c->h_meta.data();
+	env.fused = fused_form_applies(c, mode, *f);
+	if (env.fused) env.nchunks = c->planes[pl.set1].W / KC;
+	env.band_launch = c->opt.band_launch != 0; env.band_reverse = c->opt.band_reverse != 0;
+	env.band_work_log2 = c->opt.band_work_log2; env.band_max_launches = c->opt.band_max_launches; env.band_list_entries = c->opt.band_list_entries;
+	return TWK_HIP_OK;
+}
+
+}  // namespace
+
+static int region_impl(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint32_t a0, uint32_t nA,
+                       uint32_t b0, uint32_t nB, int32_t triangle, uint32_t part, uint32_t n_parts,
+                       uint32_t tile_variants, int32_t window, uint32_t l_window, twk_hip_record_sink sink,
+                       void* user, uint64_t* n_pairs, uint64_t* n_records) {
+	const PlanGeom g{a0, nA, b0, nB, triangle, part, n_parts, tile_variants, window, l_window};
+	PlanEnv env;
+	int rc = plan_env_for(c, mode, f, env); if (rc) return rc;
+	RegionPlan plan;
+	plan_region(env, g, plan);
+	RegionRun run(c, mode, f, g, env, plan, sink, user);
+	run.mark("region: mode", (size_t)mode, nA);
+	rc = run.prepare(); if (rc) return rc;
+	rc = run.run_zone_passes(); if (rc) return rc;
+	run.mark("tiles listed", plan.mine.size());
+	rc = run.decide_three_by_samples(); if (rc) return rc;
+	rc = run.run_pipeline(); if (rc) return rc;
+	if (plan.windowed) run.tot_pairs = plan.pairs;      // screen: every pair of the band is decided; window: the pairs inside it, the ones the math evaluates
+	if (n_pairs) *n_pairs = run.tot_pairs;
+	if (n_records) *n_records = run.tot_recs;
 	return TWK_HIP_OK;
 }
 
@@ -2231,9 +2057,31 @@ static int region_dispatch(twk_hip_ctx* c, int mode, const twk_hip_filters* f, u
 	// allele-count order still puts the rare variants in a zone whose pairs are list merges and probes instead of contractions
 	const bool lists_pay = f->minR2 > 0 && c->opt.lists != 0 && (c->Wp / 128 >= 32 || c->opt.lists == 2);
 	const bool screen = (window & TWK_HIP_OPT_R2_SCREEN) && whole && !(window & TWK_HIP_OPT_WINDOW) && (f->minR2 >= 1e-3 || lists_pay) && c->M >= 2;
-	if (screen && !c->any_missing && (mode == TWK_HIP_MODE_PHASED || mode == TWK_HIP_MODE_AUTO || mode == TWK_HIP_MODE_UNPHASED))
-		return region_impl(c, mode == TWK_HIP_MODE_UNPHASED ? MODE_INT_SORTED_U : MODE_INT_SORTED_P, f, 0, c->M, 0, c->M, 1, part, n_parts,
-		                   tile_variants, window, l_window, sink, user, n_pairs, n_records);
+	if (screen && !c->any_missing && (mode == TWK_HIP_MODE_PHASED || mode == TWK_HIP_MODE_AUTO || mode == TWK_HIP_MODE_UNPHASED)) {
+		// Below the cut-off that makes a band worth having the sorted order is only taken for its carrier lists: when the set turns out to
+		// keep none (too few rare variants), the sorted copy of the planes is dropped again and the run goes the file-order way (it used to
+		// run the plain matrix path in sorted order with a band that covers everything: twice the plane memory for nothing).
+		const int sset = mode == TWK_HIP_MODE_UNPHASED ? PS_SORTED_U : PS_SORTED_P;
+		bool keep_sorted = true;
+		if (f->minR2 < 1e-3) {
+			const int rc = ensure_planes(c, sset); if (rc) return rc;
+			if (c->planes[sset].n_list < 2) {
+				keep_sorted = false;
+				HIPCHK(c, hipDeviceSynchronize());
+				PlaneSet& ps = c->planes[sset];
+				if (ps.owns_rows && ps.rows) (void)hipFree(ps.rows);
+				if (ps.rowpop) (void)hipFree(ps.rowpop);
+				if (ps.ids) (void)hipFree(ps.ids);
+				if (ps.lists) (void)hipFree(ps.lists);
+				if (ps.list_mac) (void)hipFree(ps.list_mac);
+				if (ps.list_flip) (void)hipFree(ps.list_flip);
+				ps = PlaneSet();
+			}
+		}
+		if (keep_sorted)
+			return region_impl(c, mode == TWK_HIP_MODE_UNPHASED ? MODE_INT_SORTED_U : MODE_INT_SORTED_P, f, 0, c->M, 0, c->M, 1, part, n_parts,
+			                   tile_variants, window, l_window, sink, user, n_pairs, n_records);
+	}
 	if (!(mode == TWK_HIP_MODE_AUTO && c->any_missing && whole))
 		return region_impl(c, mode, f, a0, nA, b0, nB, triangle, part, n_parts, tile_variants, window, l_window,
 		                   sink, user, n_pairs, n_records);
@@ -2281,6 +2129,38 @@ int twk_hip_shard_rows(uint32_t n_rows, uint32_t n_cols, int32_t triangle, uint3
 	if (row_begin) *row_begin = r0;
 	if (row_end) *row_end = r1;
 	if (n_pairs) *n_pairs = band_pairs_before(r1, n_rows, n_cols, triangle != 0) - band_pairs_before(r0, n_rows, n_cols, triangle != 0);
+	return TWK_HIP_OK;
+}
+
+int twk_hip_plan_region(const twk_hip_plan_env* pe, const twk_hip_variant_meta* meta, const uint32_t* popc, uint32_t n_variants,
+                        uint32_t a0, uint32_t nA, uint32_t b0, uint32_t nB, int32_t triangle, uint32_t part, uint32_t n_parts,
+                        uint32_t tile_variants, int32_t window, uint32_t l_window,
+                        twk_hip_tile_desc* tiles, uint32_t capacity, uint32_t* n_tiles, uint32_t* n_band_launches,
+                        uint32_t* row_begin, uint32_t* row_end, uint64_t* n_pairs, uint32_t* lo, uint32_t* hi) {
+	if (!pe || !meta || !n_tiles || (capacity && !tiles) || n_parts == 0 || part >= n_parts) return TWK_HIP_E_INVALID;
+	if (nA == 0 || nB == 0 || (uint64_t)a0 + nA > n_variants || (uint64_t)b0 + nB > n_variants) return TWK_HIP_E_INVALID;
+	if (triangle && (a0 != b0 || nB < nA)) return TWK_HIP_E_INVALID;
+	if (pe->screen && (!popc || !triangle)) return TWK_HIP_E_INVALID;
+	if (pe->planes_per_variant < 1 || pe->planes_per_variant > 3 || pe->n_samples == 0) return TWK_HIP_E_INVALID;
+	PlanEnv env;
+	env.n_samples = pe->n_samples; env.Pmax = pe->planes_per_variant; env.nchunks = std::max<uint32_t>(pe->k_chunks, 1); env.resident_blocks = std::max<uint32_t>(pe->resident_blocks, 1);
+	env.screen = pe->screen; env.minR2 = pe->minR2; env.fused = pe->fused != 0; env.phased_math = pe->phased_math != 0;
+	env.meta = meta; env.ids = nullptr; env.popc = popc;
+	env.band_launch = pe->band_launch != 0; env.band_reverse = pe->band_reverse != 0; env.band_work_log2 = pe->band_work_log2; env.band_max_launches = std::max<long long>(pe->band_max_launches, 1);
+	const PlanGeom g{a0, nA, b0, nB, triangle, part, n_parts, tile_variants, window, l_window};
+	RegionPlan plan;
+	plan_region(env, g, plan);
+	*n_tiles = (uint32_t)plan.mine.size();
+	if (n_band_launches) *n_band_launches = (uint32_t)plan.bands.size();
+	if (row_begin) *row_begin = plan.r0;
+	if (row_end) *row_end = plan.r1;
+	if (n_pairs) *n_pairs = plan.pairs;
+	if (plan.windowed) {
+		if (lo) std::copy(plan.lo.begin(), plan.lo.end(), lo);
+		if (hi) std::copy(plan.hi.begin(), plan.hi.end(), hi);
+	}
+	if (plan.mine.size() > capacity) return TWK_HIP_E_OVERFLOW;
+	std::copy(plan.mine.begin(), plan.mine.end(), tiles);
 	return TWK_HIP_OK;
 }
 
@@ -2391,8 +2271,20 @@ int twk_hip_set_progress(twk_hip_ctx* c, twk_hip_progress_cb cb, void* user) {
 	return TWK_HIP_OK;
 }
 
+int twk_hip_launch_log(twk_hip_ctx* c, twk_hip_launch_stat* out, uint32_t capacity, uint32_t* n_copied, uint64_t* n_total) {
+	if (!c || (capacity && !out)) return TWK_HIP_E_INVALID;
+	const size_t have = c->launch_ring.size(), n = std::min<size_t>(have, capacity);
+	// oldest first: the ring's write position is launches_seen % LAUNCH_RING once it has wrapped
+	const size_t start = have < LAUNCH_RING ? 0 : (size_t)(c->launches_seen % LAUNCH_RING);
+	for (size_t k = 0; k < n; ++k) out[k] = c->launch_ring[(start + (have - n) + k) % have];
+	if (n_copied) *n_copied = (uint32_t)n;
+	if (n_total) *n_total = c->launches_seen;
+	return TWK_HIP_OK;
+}
+
 int twk_hip_timing_reset(twk_hip_ctx* c) {
 	if (!c) return TWK_HIP_E_INVALID;
+	c->launch_ring.clear(); c->launches_seen = 0;
 	const uint64_t w = c->timing.words_per_row;
 	c->timing = twk_hip_timing{};
 	c->timing.words_per_row = w;

@@ -82,12 +82,37 @@ inline int usable_cpus() {
 			if (got >= 2) b = atoll(w2);
 			return got;
 		};
-		long long quota = -1, period = 0, dummy = 0;
-		if (read_two("/sys/fs/cgroup/cpu.max", quota, period) < 2) {
-			quota = -1; period = 0;
-			if (read_two("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", quota, dummy) >= 1) read_two("/sys/fs/cgroup/cpu/cpu.cfs_period_us", period, dummy);
+		// The quota may sit on the process's own cgroup or on any of its ancestors (a systemd slice, a container started with the host's
+		// cgroup namespace): /proc/self/cgroup names the process's path below each hierarchy's mount, and the smallest quota from there
+		// up to the root counts.  (Inside a cgroup namespace the path is "/" and the mount root is the container's own group.)
+		auto apply = [&](long long quota, long long period) { if (quota > 0 && period > 0) n = (int)std::min<long long>(n, std::max<long long>(1, (quota + period - 1) / period)); };
+		std::string v2_path = "/", v1_path = "/";
+		if (FILE* f = fopen("/proc/self/cgroup", "r")) {
+			char line[4096];
+			while (fgets(line, sizeof(line), f)) {
+				std::string l(line);
+				while (!l.empty() && (l.back() == '\n' || l.back() == '\r')) l.pop_back();
+				const size_t c1 = l.find(':'), c2 = c1 == std::string::npos ? c1 : l.find(':', c1 + 1);
+				if (c2 == std::string::npos) continue;
+				const std::string ctrl = l.substr(c1 + 1, c2 - c1 - 1), path = l.substr(c2 + 1);
+				if (ctrl.empty()) v2_path = path;                                   // "0::/path" - the unified hierarchy
+				else if (("," + ctrl + ",").find(",cpu,") != std::string::npos) v1_path = path;
+			}
+			fclose(f);
 		}
-		if (quota > 0 && period > 0) n = std::min<long long>(n, std::max<long long>(1, (quota + period - 1) / period));
+		auto walk = [&](const std::string& mount, std::string path, bool v2) {
+			for (;;) {
+				const std::string dir = mount + (path == "/" ? std::string() : path);
+				long long quota = -1, period = 0, dummy = 0;
+				if (v2) { if (read_two((dir + "/cpu.max").c_str(), quota, period) >= 2) apply(quota, period); }
+				else if (read_two((dir + "/cpu.cfs_quota_us").c_str(), quota, dummy) >= 1 && read_two((dir + "/cpu.cfs_period_us").c_str(), period, dummy) >= 1) apply(quota, period);
+				if (path == "/" || path.empty()) break;
+				const size_t slash = path.find_last_of('/');
+				path = slash == 0 || slash == std::string::npos ? "/" : path.substr(0, slash);
+			}
+		};
+		walk("/sys/fs/cgroup", v2_path, true);
+		walk("/sys/fs/cgroup/cpu", v1_path, false);
 		return std::max(1, n);
 	}();
 	return cached;

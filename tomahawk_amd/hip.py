@@ -53,7 +53,50 @@ class _Timing(C.Structure):
                 ("list_ms", C.c_double), ("list_launches", C.c_uint64), ("list_pairs", C.c_uint64),
                 ("probe_ms", C.c_double), ("probe_launches", C.c_uint64), ("probe_pairs", C.c_uint64),
                 ("count_shader_cycles", C.c_uint64), ("count_wall_ticks", C.c_uint64),
-                ("three_launches", C.c_uint64), ("three_row_pairs", C.c_uint64), ("recount_candidates", C.c_uint64)]
+                ("three_launches", C.c_uint64), ("three_row_pairs", C.c_uint64), ("recount_candidates", C.c_uint64),
+                ("outlier_launches", C.c_uint64)]
+
+
+class _PlanEnv(C.Structure):         # twk_hip_plan_env
+    _fields_ = [("n_samples", C.c_uint32), ("planes_per_variant", C.c_int32), ("k_chunks", C.c_uint32), ("resident_blocks", C.c_uint32),
+                ("screen", C.c_int32), ("fused", C.c_int32), ("phased_math", C.c_int32), ("band_launch", C.c_int32), ("band_reverse", C.c_int32),
+                ("_pad", C.c_int32), ("band_work_log2", C.c_int64), ("band_max_launches", C.c_int64), ("minR2", C.c_double)]
+
+
+TILE_DTYPE = np.dtype([("rowA0", "<u4"), ("nA", "<u4"), ("rowB0", "<u4"), ("nB", "<u4"), ("diag", "<i4"), ("window", "<i4"),
+                       ("l_window", "<u4"), ("_pad", "<u4")])       # twk_hip_tile_desc
+
+
+def plan_region(meta, n_samples, a0, nA, b0, nB, triangle=True, part=0, n_parts=1, tile_variants=0, window=0, l_window=0,
+                popc=None, screen=0, minR2=0.1, planes_per_variant=1, k_chunks=1, fused=False, phased_math=True,
+                resident_blocks=512, band_launch=True, band_reverse=True, band_work_log2=19, band_max_launches=8):
+    """The engine's planner (twk_hip_plan_region: host arithmetic, needs no GPU) -> dict(tiles=TILE_DTYPE array, n_band_launches,
+    row_begin, row_end, n_pairs, lo, hi).  meta: META_DTYPE per position of the index space."""
+    lib = load_library()
+    meta = np.ascontiguousarray(meta, dtype=META_DTYPE)
+    env = _PlanEnv(n_samples, planes_per_variant, k_chunks, resident_blocks, screen, int(fused), int(phased_math), int(band_launch),
+                   int(band_reverse), 0, band_work_log2, band_max_launches, float(minR2))
+    pc = None if popc is None else np.ascontiguousarray(popc, dtype=np.uint32)
+    lo = np.zeros(nA, dtype=np.uint32); hi = np.zeros(nA, dtype=np.uint32)
+    n_tiles, n_bands, r0, r1, pairs = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0), C.c_uint32(0), C.c_uint64(0)
+    cap = 1024
+    while True:
+        tiles = np.zeros(cap, dtype=TILE_DTYPE)
+        rc = lib.twk_hip_plan_region(C.byref(env), meta.ctypes.data, None if pc is None else pc.ctypes.data, len(meta), a0, nA, b0, nB,
+                                     int(bool(triangle)), part, n_parts, tile_variants, window, l_window, tiles.ctypes.data, cap,
+                                     C.byref(n_tiles), C.byref(n_bands), C.byref(r0), C.byref(r1), C.byref(pairs), lo.ctypes.data, hi.ctypes.data)
+        if rc == -4 and n_tiles.value > cap:
+            cap = n_tiles.value
+            continue
+        if rc != 0:
+            raise HipError(rc, "twk_hip_plan_region", lib.twk_hip_strerror(rc).decode())
+        break
+    return dict(tiles=tiles[:n_tiles.value], n_band_launches=n_bands.value, row_begin=r0.value, row_end=r1.value, n_pairs=pairs.value, lo=lo, hi=hi)
+
+
+class _LaunchStat(C.Structure):      # twk_hip_launch_stat
+    _fields_ = [("ms", C.c_double), ("shader_mhz", C.c_double), ("xcd_finish_spread_us", C.c_double), ("row_pairs", C.c_uint64),
+                ("candidates", C.c_uint64), ("words_per_row", C.c_uint32), ("kind", C.c_uint32), ("outlier", C.c_uint32), ("_pad", C.c_uint32)]
 
 
 @dataclass
@@ -119,6 +162,9 @@ def load_library() -> C.CDLL:
                                       C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.twk_hip_shard_rows.argtypes = [C.c_uint32, C.c_uint32, C.c_int32, C.c_uint32, C.c_uint32,
                                        C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
+    lib.twk_hip_plan_region.argtypes = [p, p, p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, C.c_uint32, C.c_uint32,
+                                        C.c_uint32, C.c_int32, C.c_uint32, p, C.c_uint32, p, p, p, p, p, p, p]
+    lib.twk_hip_launch_log.argtypes = [p, p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
     lib.twk_hip_fisher_exact.argtypes = [p, p, C.c_uint64, p, C.c_int32, C.POINTER(C.c_float)]
     lib.twk_hip_set_device_sink.argtypes = [p, C.c_int]
     lib.twk_hip_device_records.argtypes = [p, C.POINTER(p), C.POINTER(C.c_uint64)]
@@ -365,6 +411,13 @@ class HipLd:
     # ---- measurement ----
     def timing_reset(self):
         self._check(self._lib.twk_hip_timing_reset(self._ctx), "twk_hip_timing_reset")
+
+    def launch_log(self, capacity: int = 4096):
+        """The count launches since the last timing_reset, oldest first (twk_hip_launch_log) -> (list of dicts, launches seen)."""
+        buf = (_LaunchStat * capacity)()
+        n, total = C.c_uint32(0), C.c_uint64(0)
+        self._check(self._lib.twk_hip_launch_log(self._ctx, buf, capacity, C.byref(n), C.byref(total)), "twk_hip_launch_log")
+        return [{k: getattr(buf[i], k) for k, _ in _LaunchStat._fields_ if k != "_pad"} for i in range(n.value)], total.value
 
     def timing(self) -> dict:
         t = _Timing()
