@@ -109,8 +109,13 @@ def launch_spread(eng):
     srt = sorted(cost)
     med = srt[len(srt) // 2]
     ms = sorted(x["ms"] for x in stats)
+    # the same in shader cycles (cost x the clock the launch's blocks ran at): a launch that is slow in milliseconds and ordinary in cycles ran
+    # at a low clock - the one cause the watch has caught so far (profiles/r05_outliers.txt: 1.1-1.6 GHz for seconds, 1.47-1.76 x the time)
+    cyc = sorted(x["ms"] * x["shader_mhz"] / (x["row_pairs"] * x["words_per_row"] * (0.8125 if x["kind"] in (1, 4) else 1.0))
+                 for x in stats if x["row_pairs"] and x["ms"] >= 0.3 and x["shader_mhz"])
     return {"launches": seen, "launch_ms_max": ms[-1], "launch_ms_median": ms[len(ms) // 2],
             "launch_cost_max_over_median": srt[-1] / med if med > 0 else None, "launch_cost_min_over_median": srt[0] / med if med > 0 else None,
+            "launch_cycles_max_over_median": (cyc[-1] / cyc[len(cyc) // 2]) if cyc and cyc[len(cyc) // 2] > 0 else None,
             "outlier_launches": sum(1 for x in stats if x["outlier"]),
             "shader_mhz_min": min((x["shader_mhz"] for x in stats if x["shader_mhz"]), default=None),
             "xcd_finish_spread_us_max": max((x["xcd_finish_spread_us"] for x in stats), default=None),

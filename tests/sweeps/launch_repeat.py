@@ -12,7 +12,7 @@ import tomahawk_amd as T
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 eng = T.HipLd(0)
-eng.set_option("timeline", 1)
+eng.set_option("timeline", int(os.environ.get("TIMELINE", "0")))       # 1: the engine prints flagged launches (and the host's steps) as they happen
 for name, N, M, mode, n in (("2,504 x 200,000 -p", 2504, 200_000, T.MODE_PHASED, reps), ("2,504 x 200,000 -u", 2504, 200_000, T.MODE_UNPHASED, reps // 2),
                             ("1,000,000 x 12,288 -u", 1_000_000, 12_288, T.MODE_UNPHASED, max(3, reps // 20))):
     eng.set_problem(N, M)
@@ -35,5 +35,15 @@ for name, N, M, mode, n in (("2,504 x 200,000 -p", 2504, 200_000, T.MODE_PHASED,
           f"XCD finish spread max {max(x['xcd_finish_spread_us'] for x in stats):.1f} us", flush=True)
     slow = [i for i, x in enumerate(per_run) if x > 1.2 * np.median(pr)]
     if slow:
-        print(f"  runs more than 1.2 x the median: {[(i, round(per_run[i], 2)) for i in slow[:20]]}")
+        print(f"  runs more than 1.2 x the median: {[(i, round(per_run[i], 2)) for i in slow[:40]]}")
+        med = np.median(cost)
+        rows = [(i, x) for i, x in enumerate(stats) if x["row_pairs"] and x["ms"] >= 0.3 and x["ms"] / (x["row_pairs"] * x["words_per_row"] * (0.8125 if x["kind"] in (1, 4) else 1.0)) > 1.2 * med]
+        print(f"  launches more than 1.2 x the median cost: {len(rows)}; launch #, ms, cost / median, shader MHz, XCD finish spread us, candidates:")
+        for i, x in rows[:60]:
+            cst = x["ms"] / (x["row_pairs"] * x["words_per_row"] * (0.8125 if x["kind"] in (1, 4) else 1.0))
+            print(f"    #{i:5d} {x['ms']:8.3f} ms  {cst / med:5.2f} x  {x['shader_mhz']:6.0f} MHz  {x['xcd_finish_spread_us']:7.1f} us  {x['candidates']}")
+        ok = [x for i, x in enumerate(stats) if x["ms"] >= 0.3 and all(i != j for j, _ in rows)]
+        if ok:
+            print(f"  the other launches: shader clock {min(x['shader_mhz'] for x in ok):.0f} .. {max(x['shader_mhz'] for x in ok):.0f} MHz; "
+                  f"cost x clock of the slow launches relative to the median launch: {np.median([x['ms'] / (x['row_pairs'] * x['words_per_row'] * (0.8125 if x['kind'] in (1, 4) else 1.0)) * x['shader_mhz'] for _, x in rows]) / np.median([x['ms'] / (x['row_pairs'] * x['words_per_row'] * (0.8125 if x['kind'] in (1, 4) else 1.0)) * x['shader_mhz'] for x in ok]):.3f}")
 eng.close()
