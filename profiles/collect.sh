@@ -46,6 +46,9 @@ for stage in "$@"; do
 		;;
 	cfg3)  timeout 600 python3 $R/bench.py --steps 2 --warmup 1 > $OUT/bench_cfg3.json 2> $OUT/bench_cfg3.log; cat $OUT/bench_cfg3.json ;;
 	cfg3_stats) stats cfg3 --steps 2 --warmup 1 ;;
+	cfg3_sq)   # the work-is-done check of the headline kernel, every round: VALU instructions issued against the products + v_or the launches stand for
+		pmc cfg3_sq "SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" --steps 1 --warmup 0
+		;;
 	cfg3_pmc)
 		pmc cfg3_fetch FETCH_SIZE --steps 1 --warmup 0 --variants 16384
 		pmc cfg3_write WRITE_SIZE --steps 1 --warmup 0 --variants 16384

@@ -43,3 +43,65 @@ run("level 1 (the default)", level=1)
 for lv in (-1, -3, 2, 3): run(f"level {lv}", level=lv)
 for k, vals in (("minMatch", (5, 7)), ("hashLog", (12, 16, 17)), ("windowLog", (17, 21)), ("targetLength", (2, 4)), ("literalCompressionMode", (2,)), ("strategy", (2,))):
     for v in vals: run(f"level 1, {k} {v}", level=1, **{k: v})
+
+
+# ---- round 5: would a GPU encoder that only entropy-codes (Huffman literals, no sequences) be close enough? ------------------
+# A zstd frame whose blocks carry all bytes as Huffman-compressed literals and zero sequences is valid and needs no match search -
+# the part of the format a GPU can produce at memory speed (histogram -> code lengths -> four interleaved streams per 128 KiB
+# block).  Its size is the order-0 Huffman cost of every 128 KiB block (code lengths limited to 11 bits, as zstd's literals
+# are) plus ~150 bytes of table and headers per block.  Measured on the same records, also with the records' bytes transposed
+# (byte k of every record together: what a columnar pre-pass could feed the coder - not the reference's format, shown for scale).
+import heapq
+import numpy as np
+
+
+def huffman_bits(hist, limit=11):
+    """Total bits of a length-limited Huffman code for the histogram (package-merge replaced by the usual heuristic: lengths
+    above the limit are clamped and the Kraft sum repaired by lengthening the rarest symbols still below it)."""
+    sym = [(int(c), i) for i, c in enumerate(hist) if c]
+    if len(sym) == 1:
+        return sym[0][0]
+    heap = [(c, i, None, None) for c, i in sym]
+    heapq.heapify(heap)
+    nxt = 256
+    while len(heap) > 1:
+        a = heapq.heappop(heap); b = heapq.heappop(heap)
+        heapq.heappush(heap, (a[0] + b[0], nxt, a, b)); nxt += 1
+    lengths = {}
+    stack = [(heap[0], 0)]
+    while stack:
+        (c, i, l, r), d = stack.pop()
+        if l is None:
+            lengths[i] = max(d, 1)
+        else:
+            stack.append((l, d + 1)); stack.append((r, d + 1))
+    ln = {i: min(l, limit) for i, l in lengths.items()}
+    kraft = sum(2.0 ** -l for l in ln.values())
+    order = sorted(ln, key=lambda i: hist[i])          # rarest first
+    k = 0
+    while kraft > 1.0 + 1e-12:
+        i = order[k % len(order)]
+        if ln[i] < limit:
+            kraft -= 2.0 ** -ln[i] / 2; ln[i] += 1
+        k += 1
+    return sum(int(hist[i]) * l for i, l in ln.items())
+
+
+def entropy_only(name, data_blocks):
+    out = 0
+    t = time.perf_counter()
+    for b in data_blocks:
+        a = np.frombuffer(b, dtype=np.uint8)
+        for k in range(0, len(a), 131072):
+            h = np.bincount(a[k:k + 131072], minlength=256)
+            out += (huffman_bits(h) + 7) // 8 + 150
+    print(f"{name:36s} {'(estimate)':>12s}  ratio {total / out:5.2f}  {out / 1e6:7.2f} MB   ({time.perf_counter() - t:.1f} s in python)")
+
+
+entropy_only("Huffman literals only, record order", blocks)
+transposed = []
+for b in blocks:
+    a = np.frombuffer(b[8:], dtype=np.uint8).reshape(-1, 106)
+    transposed.append(b[:8] + a.T.tobytes())
+entropy_only("Huffman literals only, bytes transposed", transposed)
+run("level 1 on transposed bytes (for scale)", level=1) if False else None
