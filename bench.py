@@ -197,6 +197,8 @@ def measure_traffic(config_args, log):
             with open(files[0], newline="") as fh:
                 for row in csv.DictReader(fh):
                     name = row.get("Kernel_Name") or row.get("kernel_name") or ""
+                    if ", 1>(" in name:          # k_count3_list_t<8, 1>: the engine's half-millisecond density samples, not launches of the run
+                        continue
                     if ("k_count_list_t" in name or "k_count_screen" in name or "k_count3" in name) and row.get("Counter_Name") == ctr:
                         total += float(row["Counter_Value"])
                         launches.add(row.get("Dispatch_Id") or row.get("dispatch_id"))

@@ -188,6 +188,8 @@ struct twk_hip_ctx {
 	StatsParams* d_list_stats = nullptr;          // parameter block of the list pass's math kernel (device copy)
 	bool fused_ok = true;           // cleared for the rest of a call when a fused tile's candidate list overflowed
 	bool three_ok = true;           // cleared for the rest of a call when a three-product launch had too many candidates for the recount to stay cheap
+	bool sampling = false;          // the launch being enqueued is a density sample (RegionRun::decide_three_by_samples): its count kernel runs under its own name
+	                                // (k_count3_list_t<.., 1>), so that a kernel trace's statistics of the real launches are not diluted by half-millisecond ones
 	bool device_sink = false;
 	twk_hip_record* d_keep = nullptr; unsigned long long d_keep_n = 0, d_keep_cap = 0;
 	// the survivors of a tile leave in (idxA, idxB) order: sort keys / permutation (double-buffered), the
@@ -604,6 +606,7 @@ int launch_count(twk_hip_ctx* c, int set, const twk_hip_tile_desc& t, Slot& s, i
 		if (with_args && d_stats) *d_stats = &d_fa->stats;
 		if (with_args && d_screen) *d_screen = &d_fa->screen;
 		if (fuse && fa->unphased && three) hipLaunchKernelGGL((k_count3_screen_unphased_t<COUNT_NW>), dim3(std::min(n_blocks, w.n_units)), dim3(COUNT_THREADS), 0, c->s_compute, w, &d_fa->screen);
+		else if (three && c->sampling) hipLaunchKernelGGL((k_count3_list_t<COUNT_NW, 1>), dim3(std::min(n_blocks, w.n_units)), dim3(COUNT_THREADS), 0, c->s_compute, w);
 		else if (three) hipLaunchKernelGGL((k_count3_list_t<COUNT_NW>), dim3(std::min(n_blocks, w.n_units)), dim3(COUNT_THREADS), 0, c->s_compute, w);
 		else if (fuse && fa->unphased) hipLaunchKernelGGL((k_count_screen_unphased_t<COUNT_NW>), dim3(std::min(n_blocks, w.n_units)), dim3(COUNT_THREADS), 0, c->s_compute, w, &d_fa->screen);
 		else if (fuse) hipLaunchKernelGGL((k_count_screen_t<COUNT_NW>), dim3(std::min(n_blocks, w.n_units)), dim3(COUNT_THREADS), 0, c->s_compute, w, &d_fa->screen);
@@ -1860,7 +1863,9 @@ struct RegionRun {
 			const size_t keep_ring = c->launch_ring.size(); const uint64_t keep_seen = c->launches_seen;
 			Slot& ss = c->slot[SYNC_SLOT];
 			unsigned long long nrec = 0;
+			c->sampling = true;
 			int rc = enqueue_tile(c, mode, st, *f, ss, std::max<unsigned long long>((unsigned long long)st.nA * st.nB, 1), cr());
+			c->sampling = false;
 			if (rc == TWK_HIP_OK) rc = finish_tile(c, ss, st, &nrec, true, discard_records, nullptr);
 			const unsigned long long cand = ss.h_n_out[2], sample_pairs = std::max<uint64_t>(pairs_in_tile(c, st), 1);
 			c->timing = keep_timing;                 // (a sample is not a launch of the run: neither in the timing nor in the launch log)
