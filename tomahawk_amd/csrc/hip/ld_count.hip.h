@@ -741,11 +741,9 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 			more = unit_next < n_units;
 			if (more) { decode(unit_next, n_tile, n_c, n_end, n_yx); st_row0 = stage_row0(n_yx); }
 		}
-#ifndef TWK_DMA_LATE
+		// (issued here, in front of the chunk's LDS reads; behind the first or the third half-slot's contraction it is neither faster nor
+		// slower - 18.31 / 18.31 / 18.26 ms on the 1 M-sample microbenchmark, round 5)
 		if (more) stage_rows_s(w.rows, w.W, st_row0, n_c, st_lds + (buf ^ 1) * (2 * LDS_TILE_BYTES), st_seg0, NSEG, voff_even, voff_odd);
-#else
-		if (more && !(c + 1 == nchunks && w.last_halves)) {} else if (more) stage_rows_s(w.rows, w.W, st_row0, n_c, st_lds + (buf ^ 1) * (2 * LDS_TILE_BYTES), st_seg0, NSEG, voff_even, voff_odd);
-#endif
 		// The chunk in 16 half-slots of 8 bytes per row.  The 12 LDS reads of half-slot h + 1 (8 A rows,
 		// TB B rows, ds_read_b64) are issued before the contraction of half-slot h, into the other
 		// register set, so the contraction never waits for LDS except at the first half-slot of a chunk.
@@ -773,9 +771,6 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 #pragma unroll
 					for (int u = 0; u < TB; ++u) contract_half<TB>(acc, u, ra[h & 1], rb[h & 1][u]);
 				}
-#ifdef TWK_DMA_LATE
-				if (h == TWK_DMA_LATE && more) stage_rows_s(w.rows, w.W, st_row0, n_c, st_lds + (buf ^ 1) * (2 * LDS_TILE_BYTES), st_seg0, NSEG, voff_even, voff_odd);
-#endif
 			}
 		} else {
 			// The last chunk of a row whose data ends before the chunk does (CountWork::last_halves): the zero padding
