@@ -656,20 +656,20 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 	// instead of being held through the epilogue: the epilogue is where the kernels' register demand peaks, and what the allocator evicts
 	// there it reloads from scratch inside the K loop (round 5: sixteen spilled offsets, scratch loads between the half-slots).  The lane
 	// id comes fresh from the hardware (volatile asm), so the recomputation is not hoisted back in front of the loop.
-	uint32_t offA[8], offB[8], voff_even, voff_odd;
+	// (One offset per operand: slot k of the lane's rows lies at off ^ (k << 4) - the swizzle lives in address bits 4..6 - and the buffer's
+	// base, a multiple of 32 KiB, can be added first: (bufbase + off) ^ (k << 4).  A table of all eight per operand cost 14 more registers
+	// for the same number of VALU operations per read address.)
+	uint32_t offA, offB, voff_even, voff_odd;
 	auto lane_offsets = [&](bool fresh) {
 		uint32_t ln = (uint32_t)lane;
 		if (fresh) asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
 		const uint32_t li_ = ln >> 3, lj_ = ln & 7u;
-#pragma unroll
-		for (int k = 0; k < 8; ++k) {
-			if (PAIRED) {      // rows 2 li + (t & 1) + 16 (t >> 1): (row >> 1) & 7 = li for every t
-				offA[k] = (uint32_t)((wr * 64 + 2 * li_) * (KC * 4) + ((li_ ^ k) << 4));
-				offB[k] = (uint32_t)(LDS_TILE_BYTES + (wc * 8 * TB + 2 * lj_) * (KC * 4) + ((lj_ ^ k) << 4));
-			} else {
-				offA[k] = (uint32_t)((wr * 64 + li_) * (KC * 4) + (((li_ >> 1) ^ k) << 4));
-				offB[k] = (uint32_t)(LDS_TILE_BYTES + (wc * 8 * TB + lj_) * (KC * 4) + (((lj_ >> 1) ^ k) << 4));
-			}
+		if (PAIRED) {      // rows 2 li + (t & 1) + 16 (t >> 1): (row >> 1) & 7 = li for every t
+			offA = (uint32_t)((wr * 64 + 2 * li_) * (KC * 4) + (li_ << 4));
+			offB = (uint32_t)(LDS_TILE_BYTES + (wc * 8 * TB + 2 * lj_) * (KC * 4) + (lj_ << 4));
+		} else {
+			offA = (uint32_t)((wr * 64 + li_) * (KC * 4) + ((li_ >> 1) << 4));
+			offB = (uint32_t)(LDS_TILE_BYTES + (wc * 8 * TB + lj_) * (KC * 4) + ((lj_ >> 1) << 4));
 		}
 		// DMA source offsets: lane's row within an 8-row segment and its (swizzled) 16-byte slot, see stage_rows_s
 		voff_even = (li_ * w.W + ((lj_ ^ (li_ >> 1)) << 2)) << 2;
@@ -755,13 +755,14 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 		const int h_end = (c + 1 == nchunks && w.last_halves) ? (int)w.last_halves : 16;     // wave-uniform
 		if (h_end == 16) {
 			uint2 ra[2][8], rb[2][TB];
-			read_half<TB, PAIRED>(ra[0], rb[0], bufbase + offA[0], bufbase + offA[ODD], bufbase + offB[0], bufbase + offB[ODD], 0);
+			const uint32_t baseA = bufbase + offA, baseB = bufbase + offB;
+			read_half<TB, PAIRED>(ra[0], rb[0], baseA, baseA ^ (uint32_t)(ODD << 4), baseB, baseB ^ (uint32_t)(ODD << 4), 0);
 #pragma unroll
 			for (int h = 0; h < 16; ++h) {
 				if (h + 1 < 16) {
 					const int q = (h + 1) >> 1;
-					read_half<TB, PAIRED>(ra[(h + 1) & 1], rb[(h + 1) & 1], bufbase + offA[q], bufbase + offA[q ^ ODD], bufbase + offB[q],
-					              bufbase + offB[q ^ ODD], (h + 1) & 1);
+					read_half<TB, PAIRED>(ra[(h + 1) & 1], rb[(h + 1) & 1], baseA ^ (uint32_t)(q << 4), baseA ^ (uint32_t)((q ^ ODD) << 4), baseB ^ (uint32_t)(q << 4),
+					              baseB ^ (uint32_t)((q ^ ODD) << 4), (h + 1) & 1);
 					asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
 				} else {
 					asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -780,8 +781,8 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 			for (int h = 0; h < h_end; ++h) {
 				const uint32_t q = (uint32_t)(h >> 1) << 4, hb = (uint32_t)(h & 1) << 3;
 				uint2 ra[8], rb[TB];
-				read_half<TB, PAIRED>(ra, rb, bufbase + (offA[0] ^ q) + hb, bufbase + (offA[0] ^ q ^ (uint32_t)(ODD << 4)) + hb, bufbase + (offB[0] ^ q) + hb,
-				              bufbase + (offB[0] ^ q ^ (uint32_t)(ODD << 4)) + hb, 0);
+				read_half<TB, PAIRED>(ra, rb, bufbase + (offA ^ q) + hb, bufbase + (offA ^ q ^ (uint32_t)(ODD << 4)) + hb, bufbase + (offB ^ q) + hb,
+				              bufbase + (offB ^ q ^ (uint32_t)(ODD << 4)) + hb, 0);
 				asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 				if constexpr (THREE) contract3_half(acc, ra, rb);
 				else {
@@ -948,26 +949,71 @@ struct ScreenCounts {
 		const uint32_t c0 = (yx & 0xFFFFu) * TILE + wc * 8 * TB + lj;     // and columns: c0 + 8u
 		const double two_n = s.two_n, cut = s.cut;
 		const uint32_t a0 = s.a0, b0 = s.b0;
+		// everything the lane needs of the staged block in one go (twenty LDS reads in flight, one wait)
+		uint32_t rawB[TB], rawA[8], rawH[8];
+#pragma unroll
+		for (int u = 0; u < TB; ++u) rawB[u] = meta[TILE + wc * 8 * TB + lj + 8 * u];
+#pragma unroll
+		for (int t = 0; t < 8; ++t) { rawA[t] = meta[wr * 64 + li + 8 * t]; rawH[t] = meta[2 * TILE + wr * 64 + li + 8 * t]; }
+		const uint32_t first_reach = meta[2 * TILE];                        // band limit of the tile's first row (the limits never decrease along the rows)
+		const bool diag = s.diag != 0, banded = s.col_hi != nullptr;
+		const uint32_t zone = s.list_zone, pzone = s.probe_zone, nA = s.nA, nB = s.nB, n_variants = s.n_variants, hi_b0 = s.hi_b0;
+		// Fast way out (round 5; csrc/tools/count_microbench.hip FUSED=1: the epilogue was 7.5 % of a five-chunk tile's time and 13 % of a
+		// three-chunk tile's, and most of it is not the screen's arithmetic but the structural tests and the candidate mask built per pair,
+		// ~600 instructions per lane and tile).  A tile that lies wholly inside what its rows take - all 128 x 128 pairs are wanted pairs:
+		// inside the matrix, strictly above the diagonal, below the first row's band limit, outside the list / probe zones - needs none of
+		// them, and whether ANY of the lane's 32 pairs can be a candidate is one FP32 test per pair: with a' = a / T
+		//     |AA - a' b| + slack >= sqrt(cut a (T - a)) / T * sqrt(b (T - b)) * (1 - 2^-16)
+		// (AA, a, b <= 2N exact in FP32 below 2^24; v_rcp / v_sqrt are good to 1 ulp; slack = 0.5 + T 2^-20 counts is four times the worst
+		// rounding of the left side at any T: no pair the exact test below passes fails this one).  No lane of the wave with such a pair - the
+		// rule for unlinked variants - and the wave is done; otherwise the full path runs as before.
+		{
+			const uint32_t rA0 = a0 + (yx >> 16) * TILE, cB0 = b0 + (yx & 0xFFFFu) * TILE;        // set positions of the tile's first row / column
+			const uint32_t endA = a0 + nA < n_variants ? a0 + nA : n_variants, endB = b0 + nB < n_variants ? b0 + nB : n_variants;
+			const bool interior = rA0 + TILE <= endA && cB0 + TILE <= endB && (!diag || cB0 >= rA0 + TILE) && rA0 >= pzone && !(rA0 < zone && cB0 < zone)
+			                      && (!banded || hi_b0 + first_reach >= cB0 + TILE);
+			// (not when the wave's previous tile had candidates - win.w[3]: where pairs are in LD their neighbours are too, and a fast way out
+			// that fails is paid on top of the full path: the survivor-rich window run of 2,504 samples lost 4 % to it before this test)
+			if (interior && uniform(win.w[3]) == 0) {
+				const float Tf = (float)two_n, invT = __builtin_amdgcn_rcpf(Tf), cutf = (float)cut, slack = 0.5f + Tf * (1.0f / 1048576.0f);
+				float bf[TB], sBf[TB];
+#pragma unroll
+				for (int u = 0; u < TB; ++u) { bf[u] = (float)rawB[u]; sBf[u] = __builtin_amdgcn_sqrtf(bf[u] * (Tf - bf[u])) * (1.0f - 1.0f / 65536.0f); }
+				bool any = false;
+#pragma unroll
+				for (int t = 0; t < 8; ++t) {
+					const float af = (float)rawA[t], apf = af * invT;
+					const float sAf = __builtin_amdgcn_sqrtf(cutf * (af * (Tf - af))) * invT;
+#pragma unroll
+					for (int u = 0; u < TB; ++u) any |= __builtin_fabsf(__builtin_fmaf(-apf, bf[u], (float)acc[t][u])) + slack >= sAf * sBf[u];
+				}
+				if (!__ballot(any)) {
+#pragma unroll
+					for (int t = 0; t < 8; ++t)
+#pragma unroll
+						for (int u = 0; u < TB; ++u) acc[t][u] = 0;
+					return;
+				}
+			}
+		}
 		// allele counts of the lane's rows and columns; hiA: first column the row does not reach (0 for a row outside the
 		// tile's variants: reaches nothing) - the columns outside the tile's variants lie beyond every row's reach
 		uint32_t acB[TB], acA[8], hiA[8];
 #pragma unroll
 		for (int u = 0; u < TB; ++u) {
 			const uint32_t cu = c0 + 8 * u, sB = b0 + cu;
-			acB[u] = (cu < s.nB && sB < s.n_variants) ? meta[TILE + wc * 8 * TB + lj + 8 * u] : 0u;
+			acB[u] = (cu < nB && sB < n_variants) ? rawB[u] : 0u;
 		}
 #pragma unroll
 		for (int t = 0; t < 8; ++t) {
 			const uint32_t rt = r0 + 8 * t, sA = a0 + rt;
-			const bool ok = rt < s.nA && sA < s.n_variants;
-			acA[t] = ok ? meta[wr * 64 + li + 8 * t] : 0u;
+			const bool ok = rt < nA && sA < n_variants;
+			acA[t] = ok ? rawA[t] : 0u;
 			// first column the row does not reach: the end of the tile's columns, of the matrix, of the row's r2 band
-			uint32_t h = s.b0 + s.nB < s.n_variants ? s.b0 + s.nB : s.n_variants;
-			if (s.col_hi) { const uint32_t hb = s.hi_b0 + meta[2 * TILE + wr * 64 + li + 8 * t]; h = hb < h ? hb : h; }
+			uint32_t h = b0 + nB < n_variants ? b0 + nB : n_variants;
+			if (banded) { const uint32_t hb = hi_b0 + rawH[t]; h = hb < h ? hb : h; }
 			hiA[t] = ok ? h : 0u;
 		}
-		const bool diag = s.diag != 0;
-		const uint32_t zone = s.list_zone, pzone = s.probe_zone;
 		uint32_t m = 0;                  // bit 4t + u: pair (t, u) is a candidate
 #pragma unroll
 		for (int t = 0; t < 8; ++t) {
@@ -983,10 +1029,11 @@ struct ScreenCounts {
 				m |= (ok ? 1u : 0u) << (4 * t + u);
 			}
 		}
-		// (Round 5 tried an FP32 prefilter in front of this test, as ScreenCountsUnphased has one: with six FP64 operations per pair there is
-		// too little to save - the all-pairs run of 2,504 x 200,000 went from 145.1 to 147.0 ms, the survivor-rich window run from 15.5 to
-		// 16.7 ms, profiles/r05_fused_epilogue.txt - so PhasedMath's screen stays exact from the start.)
-		if (__ballot(m != 0)) {          // (most tiles of unlinked variants end here)
+		// (A per-pair FP32 prefilter in front of this test - with the structural tests and the mask still built per pair - was tried first and
+		// cost more than it saved: 145.1 -> 147.0 ms on the all-pairs run of 2,504 x 200,000, profiles/r05_fused_epilogue.txt.)
+		const bool wave_has = __ballot(m != 0) != 0;
+		if (lane == 0) win.w[3] = wave_has ? 1u : 0u;
+		if (wave_has) {          // (most tiles of unlinked variants end here)
 			const uint32_t cnt = __popc(m);
 			const uint32_t incl = wave_scan_inclusive(cnt);
 			const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
@@ -1077,6 +1124,40 @@ struct ScreenCountsUnphased {
 		for (int sI = 0; sI < 4; ++sI) { const int rowA = wr * 64 + 2 * li + 16 * sI; rawA[sI][0] = meta[rowA]; rawA[sI][1] = meta[rowA + 1]; rawH[sI] = meta[2 * TILE + wr * 32 + li + 8 * sI]; }
 		const bool banded = s.col_hi != nullptr;
 		const uint32_t hi_b0 = s.hi_b0, endA = s.a0 + s.nA, endB = s.b0 + s.nB, n_variants = s.n_variants, list_zone = s.list_zone, probe_zone = s.probe_zone;
+		// Fast way out, as in ScreenCounts: a tile wholly inside what its rows take (64 x 64 variant pairs, all wanted) needs no structural
+		// test and no mask - one FP32 test per pair tells whether the lane has a candidate at all, and a wave without one is done.
+		{
+			const uint32_t vrA0 = s.a0 + (yx >> 16) * (TILE / 2), vcB0 = s.b0 + (yx & 0xFFFFu) * (TILE / 2);        // the tile's first row / column variant
+			const uint32_t lastA = endA < n_variants ? endA : n_variants, lastB = endB < n_variants ? endB : n_variants;
+			const uint32_t first_reach = meta[2 * TILE];                       // band limit of the tile's first row variant (never decreasing along the rows)
+			const bool interior = vrA0 + TILE / 2 <= lastA && vcB0 + TILE / 2 <= lastB && (!diag || vcB0 >= vrA0 + TILE / 2) && vrA0 >= probe_zone
+			                      && !(vrA0 < list_zone && vcB0 < list_zone) && (!banded || hi_b0 + first_reach >= vcB0 + TILE / 2);
+			if (interior && uniform(win.w[3]) == 0) {      // (see ScreenCounts: not behind a tile that had candidates)
+				float dbf_[2], sBf_[2];
+#pragma unroll
+				for (int v = 0; v < 2; ++v) { dbf_[v] = (float)(rawB[v][0] + 2u * rawB[v][1]); sBf_[v] = __builtin_amdgcn_sqrtf(dbf_[v] * (Tf - dbf_[v])) * (1.0f - 1.0f / 65536.0f); }
+				bool any = false;
+#pragma unroll
+				for (int sI = 0; sI < 4; ++sI) {
+					const float daf = (float)(rawA[sI][0] + 2u * rawA[sI][1]), paf = daf * invT;
+					const float sAf = __builtin_amdgcn_sqrtf((float)cut * (daf * (Tf - daf))) * invT;
+#pragma unroll
+					for (int v = 0; v < 2; ++v) {
+						const uint32_t hh = acc[2 * sI][2 * v];
+						const uint32_t s_sum = THREE ? acc[2 * sI + 1][2 * v + 1] : acc[2 * sI + 1][2 * v] + acc[2 * sI][2 * v + 1] + 2u * acc[2 * sI + 1][2 * v + 1];
+						const float q = __builtin_fmaf(-paf, dbf_[v], (float)s_sum);
+						any |= __builtin_fmaxf(q + ((float)hh + epsf), epsf - q) + slack >= sAf * sBf_[v];
+					}
+				}
+				if (!__ballot(any)) {
+#pragma unroll
+					for (int t = 0; t < 8; ++t)
+#pragma unroll
+						for (int u = 0; u < TB; ++u) acc[t][u] = 0;
+					return;
+				}
+			}
+		}
 		uint32_t vB[2]; float dbf[2], sBf[2];
 #pragma unroll
 		for (int v = 0; v < 2; ++v) {
@@ -1131,7 +1212,9 @@ struct ScreenCountsUnphased {
 				}
 			}
 		}
-		if (__ballot(m != 0)) {
+		const bool wave_has = __ballot(m != 0) != 0;
+		if (lane == 0) win.w[3] = wave_has ? 1u : 0u;
+		if (wave_has) {
 			typedef __attribute__((address_space(1))) uint32_t g_u32;
 			const uint32_t cnt = __popc(m);
 			const uint32_t incl = wave_scan_inclusive(cnt);
