@@ -171,3 +171,21 @@ def test_sampling_decides_between_three_and_four_products_on_long_rows(hip, opt)
     util.upload(hip, al)
     (p, _, _), (q, _, nr), tm = _both(hip, opt, lambda: hip.ld_all(T.MODE_UNPHASED, f, tile_variants=128), expect_three=False)
     assert tm["three_launches"] == 0 and tm["count_launches"] >= 6 and nr == len(q) == len(p) > 100 and _same(p, q)
+
+
+@pytest.mark.parametrize("N", [2080, 2208, 2272, 2336, 2400, 2504, 2816])
+def test_three_product_rows_that_end_inside_their_last_chunk(hip, opt, N):
+    """The fused three-product kernel walks a row's last, partly filled chunk in pairs of half-slots with the next half-slot's
+    reads in flight (the padding behind the last live 8 bytes is not contracted): 1, 3, 4, 5, 6, 8 and 12 live half-slots - odd
+    and even counts, the shortest and the longest the skip is taken for.  Records against the four-product kernel's."""
+    live_halves = (((N + 31) // 32 - 1) % 32 + 2) // 2
+    assert 1 <= live_halves <= 12
+    M = 900
+    al = _cohort_alleles(M, N, 77 + N)
+    util.upload(hip, al)
+    f = T.Filters(minR2=0.15)
+    (p, np0, _), (q, np1, nr), tm = _both(hip, opt, lambda: hip.ld_all(T.MODE_UNPHASED, f), on=2)
+    assert tm["fused_launches"] == tm["three_launches"] >= 1 and np0 == np1 and nr == len(q) == len(p) > 50 and _same(p, q), (N, live_halves)
+    opt.set("skip_pad", 0)
+    r, _, _ = hip.ld_all(T.MODE_UNPHASED, f)
+    assert _same(p, r)

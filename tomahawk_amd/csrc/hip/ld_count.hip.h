@@ -774,18 +774,37 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 				}
 			}
 		} else {
-			// The last chunk of a row whose data ends before the chunk does (CountWork::last_halves): the zero padding
-			// is not contracted.  A plain loop - one such chunk per tile, the other waves of the SIMD cover its LDS
-			// waits.  offX[k] = offX[0] ^ (k << 4): the slot swizzle lives in address bits 4..6.
-#pragma unroll 1
-			for (int h = 0; h < h_end; ++h) {
+			// The last chunk of a row whose data ends before the chunk does (CountWork::last_halves): the zero padding is not contracted.
+			// A rolled loop - one such chunk per tile.  Slot k of the lane's rows lies at off ^ (k << 4): the swizzle lives in address bits 4..6.
+			auto rd = [&](uint2 (&a)[8], uint2 (&b)[TB], int h) {
 				const uint32_t q = (uint32_t)(h >> 1) << 4, hb = (uint32_t)(h & 1) << 3;
-				uint2 ra[8], rb[TB];
-				read_half<TB, PAIRED>(ra, rb, bufbase + (offA ^ q) + hb, bufbase + (offA ^ q ^ (uint32_t)(ODD << 4)) + hb, bufbase + (offB ^ q) + hb,
+				read_half<TB, PAIRED>(a, b, bufbase + (offA ^ q) + hb, bufbase + (offA ^ q ^ (uint32_t)(ODD << 4)) + hb, bufbase + (offB ^ q) + hb,
 				              bufbase + (offB ^ q ^ (uint32_t)(ODD << 4)) + hb, 0);
-				asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-				if constexpr (THREE) contract3_half(acc, ra, rb);
-				else {
+			};
+			if constexpr (THREE) {
+				// The three-product kernels have the registers for it: pairs of half-slots, pipelined like the unrolled loop (the reads of the
+				// next half-slot behind the contraction of this one, two register sets).  At 2,504 samples an unphased row's third chunk is 8 of
+				// a tile's 40 half-slots; waiting for every half-slot's reads in turn made them a third slower than the rest.  (In the
+				// four-product kernels the second register set costs spills: they keep the plain loop.)
+				uint2 ra[2][8], rb[2][TB];
+				rd(ra[0], rb[0], 0);
+#pragma unroll 1
+				for (int h = 0; h < h_end; h += 2) {
+					if (h + 1 < h_end) { rd(ra[1], rb[1], h + 1); asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory"); }
+					else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+					contract3_half(acc, ra[0], rb[0]);
+					if (h + 1 < h_end) {
+						if (h + 2 < h_end) { rd(ra[0], rb[0], h + 2); asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory"); }
+						else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+						contract3_half(acc, ra[1], rb[1]);
+					}
+				}
+			} else {
+#pragma unroll 1
+				for (int h = 0; h < h_end; ++h) {
+					uint2 ra[8], rb[TB];
+					rd(ra, rb, h);
+					asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
 					for (int u = 0; u < TB; ++u) contract_half<TB>(acc, u, ra, rb[u]);
 				}
