@@ -175,9 +175,9 @@ def test_sampling_decides_between_three_and_four_products_on_long_rows(hip, opt)
 
 @pytest.mark.parametrize("N", [2080, 2208, 2272, 2336, 2400, 2504, 2816])
 def test_three_product_rows_that_end_inside_their_last_chunk(hip, opt, N):
-    """The fused three-product kernel walks a row's last, partly filled chunk in pairs of half-slots with the next half-slot's
-    reads in flight (the padding behind the last live 8 bytes is not contracted): 1, 3, 4, 5, 6, 8 and 12 live half-slots - odd
-    and even counts, the shortest and the longest the skip is taken for.  Records against the four-product kernel's."""
+    """The fused three-product kernel on rows whose last chunk is partly filled (the padding behind the last live 8 bytes is not
+    contracted): 1, 3, 4, 5, 6, 8 and 12 live half-slots - odd and even counts, the shortest and the longest the skip is taken
+    for.  Records against the four-product kernel's, and against the run that contracts the padding too."""
     live_halves = (((N + 31) // 32 - 1) % 32 + 2) // 2
     assert 1 <= live_halves <= 12
     M = 900

@@ -781,30 +781,15 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 				read_half<TB, PAIRED>(a, b, bufbase + (offA ^ q) + hb, bufbase + (offA ^ q ^ (uint32_t)(ODD << 4)) + hb, bufbase + (offB ^ q) + hb,
 				              bufbase + (offB ^ q ^ (uint32_t)(ODD << 4)) + hb, 0);
 			};
-			if constexpr (THREE) {
-				// The three-product kernels have the registers for it: pairs of half-slots, pipelined like the unrolled loop (the reads of the
-				// next half-slot behind the contraction of this one, two register sets).  At 2,504 samples an unphased row's third chunk is 8 of
-				// a tile's 40 half-slots; waiting for every half-slot's reads in turn made them a third slower than the rest.  (In the
-				// four-product kernels the second register set costs spills: they keep the plain loop.)
-				uint2 ra[2][8], rb[2][TB];
-				rd(ra[0], rb[0], 0);
+			// (Pipelined in pairs of half-slots - the next half-slot's reads behind this one's contraction, two register sets - it was slower, not
+			// faster: 240.7 -> 246.8 ms on the 2,504-sample -u run, the three-product kernels at 124 registers instead of 100; round 5.)
 #pragma unroll 1
-				for (int h = 0; h < h_end; h += 2) {
-					if (h + 1 < h_end) { rd(ra[1], rb[1], h + 1); asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory"); }
-					else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-					contract3_half(acc, ra[0], rb[0]);
-					if (h + 1 < h_end) {
-						if (h + 2 < h_end) { rd(ra[0], rb[0], h + 2); asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory"); }
-						else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-						contract3_half(acc, ra[1], rb[1]);
-					}
-				}
-			} else {
-#pragma unroll 1
-				for (int h = 0; h < h_end; ++h) {
-					uint2 ra[8], rb[TB];
-					rd(ra, rb, h);
-					asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+			for (int h = 0; h < h_end; ++h) {
+				uint2 ra[8], rb[TB];
+				rd(ra, rb, h);
+				asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+				if constexpr (THREE) contract3_half(acc, ra, rb);
+				else {
 #pragma unroll
 					for (int u = 0; u < TB; ++u) contract_half<TB>(acc, u, ra, rb[u]);
 				}
