@@ -47,9 +47,9 @@ def test_three_product_equals_four_product_and_oracle(hip, opt, N, fused):
     data, mask, variants = util.upload(hip, al)
     opt.set("fused", fused)
     mode = T.MODE_UNPHASED
-    # (through the matrix the engine first samples the region's candidate density and keeps to four products on data as rich in LD as this
-    # cohort - test_sampling_decides_...; three = 2 takes the form regardless)
-    on = 1 if fused else 2
+    # (the engine samples every launch's candidate density first and keeps to four products on data as rich in LD as this cohort -
+    # test_sampling_decides_...; three = 2 takes the form regardless)
+    on = 2
     _b = _both
     def _both_on(hip, opt, call, expect_three=True):
         return _b(hip, opt, call, expect_three, on=on)
@@ -156,7 +156,7 @@ def test_sampling_decides_between_three_and_four_products_on_long_rows(hip, opt)
     """Through the count matrix (rows too long to fuse) a region first samples its candidate density (a sub-tile
     of its own middle for every launch) and takes the three-product form only where candidates are few: unlinked variants
     (the headline's synthetic input) -> three products in every launch; a cohort rich in LD -> four, with no launch wasted.
-    Same records either way."""
+    Same records either way.  Fused launches (short rows) are sampled the same way."""
     N = 300_000
     rng = np.random.default_rng(5)
     M = 700
@@ -171,6 +171,15 @@ def test_sampling_decides_between_three_and_four_products_on_long_rows(hip, opt)
     util.upload(hip, al)
     (p, _, _), (q, _, nr), tm = _both(hip, opt, lambda: hip.ld_all(T.MODE_UNPHASED, f, tile_variants=128), expect_three=False)
     assert tm["three_launches"] == 0 and tm["count_launches"] >= 6 and nr == len(q) == len(p) > 100 and _same(p, q)
+    # short rows (fused launches): the same decision
+    N2 = 2504
+    iid2 = (rng.random((3000, N2, 2)) < rng.uniform(0.05, 0.5, size=3000)[:, None, None]).astype(np.int8)
+    util.upload(hip, iid2)
+    (p, _, _), (q, _, nr), tm = _both(hip, opt, lambda: hip.ld_all(T.MODE_UNPHASED, f))
+    assert tm["fused_launches"] == tm["three_launches"] == tm["count_launches"] >= 1 and _same(p, q)
+    util.upload(hip, _cohort_alleles(3000, N2, 99))
+    (p, _, _), (q, _, nr), tm = _both(hip, opt, lambda: hip.ld_all(T.MODE_UNPHASED, f), expect_three=False)
+    assert tm["three_launches"] == 0 and tm["fused_launches"] == tm["count_launches"] >= 1 and nr == len(q) == len(p) > 100 and _same(p, q)
 
 
 @pytest.mark.parametrize("N", [2080, 2208, 2272, 2336, 2400, 2504, 2816])

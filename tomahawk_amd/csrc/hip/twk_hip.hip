@@ -605,7 +605,8 @@ int launch_count(twk_hip_ctx* c, int set, const twk_hip_tile_desc& t, Slot& s, i
 		const FusedArgs* d_fa = reinterpret_cast<const FusedArgs*>(s.d_tiles[which] + words_units);
 		if (with_args && d_stats) *d_stats = &d_fa->stats;
 		if (with_args && d_screen) *d_screen = &d_fa->screen;
-		if (fuse && fa->unphased && three) hipLaunchKernelGGL((k_count3_screen_unphased_t<COUNT_NW>), dim3(std::min(n_blocks, w.n_units)), dim3(COUNT_THREADS), 0, c->s_compute, w, &d_fa->screen);
+		if (fuse && fa->unphased && three && c->sampling) hipLaunchKernelGGL((k_count3_screen_unphased_t<COUNT_NW, 1>), dim3(std::min(n_blocks, w.n_units)), dim3(COUNT_THREADS), 0, c->s_compute, w, &d_fa->screen);
+		else if (fuse && fa->unphased && three) hipLaunchKernelGGL((k_count3_screen_unphased_t<COUNT_NW>), dim3(std::min(n_blocks, w.n_units)), dim3(COUNT_THREADS), 0, c->s_compute, w, &d_fa->screen);
 		else if (three && c->sampling) hipLaunchKernelGGL((k_count3_list_t<COUNT_NW, 1>), dim3(std::min(n_blocks, w.n_units)), dim3(COUNT_THREADS), 0, c->s_compute, w);
 		else if (three) hipLaunchKernelGGL((k_count3_list_t<COUNT_NW>), dim3(std::min(n_blocks, w.n_units)), dim3(COUNT_THREADS), 0, c->s_compute, w);
 		else if (fuse && fa->unphased) hipLaunchKernelGGL((k_count_screen_unphased_t<COUNT_NW>), dim3(std::min(n_blocks, w.n_units)), dim3(COUNT_THREADS), 0, c->s_compute, w, &d_fa->screen);
@@ -1840,7 +1841,7 @@ struct RegionRun {
 	// count kernel with three such launches wasted), and how many pairs are candidates differs from launch to launch - in allele-count order
 	// the launches over the common variants hold nearly all of them.  So every launch is decided by a sample of its own, taken before the
 	// pipeline starts: a sub-tile of at most 384 x 384 variants from its middle through the same kernels (half a millisecond), three
-	// products if at most 1 pair in 256 of the sample is a candidate.  (Regions of more than 64 launches sample every k-th one; the others
+	// products if at most 1 pair in 256 of the sample is a candidate (1 in 128 for fused launches, whose recount reads short rows from L2).  (Regions of more than 64 launches sample every k-th one; the others
 	// follow their nearest sampled neighbour.)
 	int decide_three_by_samples() {
 		const std::vector<twk_hip_tile_desc>& mine = plan.mine;
@@ -1848,8 +1849,12 @@ struct RegionRun {
 		want_three.assign(n, 1);
 		if (mine.empty() || !c->three_ok || c->opt.three != 1) return TWK_HIP_OK;
 		const TilePlan pl = plan_for(c, mode);
-		const bool eligible = !pl.phased1 && pl.set2 < 0 && set_kind(pl.set1) == PK_UNPHASED && f->minR2 > 1e-6 && f->minR2 <= 1.0 && !env.fused;
+		const bool eligible = !pl.phased1 && pl.set2 < 0 && set_kind(pl.set1) == PK_UNPHASED && f->minR2 > 1e-6 && f->minR2 <= 1.0;
 		if (!eligible) return TWK_HIP_OK;
+		// (fused launches - short rows - are sampled as well: they keep their candidates whatever their number, but past ~1.2 % of the pairs
+		// the recount costs more than the third product saves: 2,504 samples, -u -w 1000000, 2.9 % candidates: 27.4 + 30.3 ms of count kernel and
+		// math with three products in the first of two launches, 30 + 21 ms with four in both)
+		const unsigned long long dense_one_in = env.fused ? 128 : 256;
 		const size_t step = (n + 63) / 64;
 		for (size_t i0 = 0; i0 < n; i0 += step) {
 			const size_t pick = std::min(n - 1, i0 + step / 2);
@@ -1872,7 +1877,7 @@ struct RegionRun {
 			if (c->launch_ring.size() > keep_ring && c->launches_seen == keep_seen + 1 && keep_seen < LAUNCH_RING) c->launch_ring.pop_back();
 			c->launches_seen = keep_seen;
 			c->three_ok = true;                      // (a sample's own overflow decides its launch, not the call)
-			const bool dense = rc == TWK_HIP_E_OVERFLOW || (rc == TWK_HIP_OK && cand * 256 > sample_pairs);
+			const bool dense = rc == TWK_HIP_E_OVERFLOW || (rc == TWK_HIP_OK && cand * dense_one_in > sample_pairs);
 			if (rc != TWK_HIP_OK && rc != TWK_HIP_E_OVERFLOW) return rc;
 			for (size_t i = i0; i < std::min(n, i0 + step); ++i) want_three[i] = dense ? 0 : 1;
 			mark("three-product sample of launch: candidates", pick, cand);
