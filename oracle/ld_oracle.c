@@ -454,18 +454,26 @@ int orc_pair(const uint64_t* a, const uint64_t* ma, const orc_variant* A,
 	return orc_unphased_math(o, A, B, st, rec);
 }
 
-uint64_t orc_all_pairs(const uint64_t* data, const uint64_t* mask, const orc_variant* vars,
-                       uint32_t n_variants, uint32_t n_samples, const orc_settings* st,
-                       int vector_only, orc_record* recs) {
+/* rows [row0, row1) of the pair triangle, every row against the variants behind it; records in pair order.
+   No state outside the arguments: tests/ call disjoint row ranges from several threads (oracle.py). */
+uint64_t orc_all_pairs_rows(const uint64_t* data, const uint64_t* mask, const orc_variant* vars,
+                            uint32_t n_variants, uint32_t n_samples, const orc_settings* st,
+                            int vector_only, uint32_t row0, uint32_t row1, orc_record* recs) {
 	const uint32_t w = orc_words64(n_samples);
 	uint64_t n = 0;
-	for (uint32_t i = 0; i < n_variants; ++i)
+	for (uint32_t i = row0; i < row1 && i < n_variants; ++i)
 		for (uint32_t j = i + 1; j < n_variants; ++j)
 			if (orc_pair(data + (size_t)i * w, mask ? mask + (size_t)i * w : NULL, &vars[i],
 			             data + (size_t)j * w, mask ? mask + (size_t)j * w : NULL, &vars[j],
 			             n_samples, st, vector_only, &recs[n]))
 				++n;
 	return n;
+}
+
+uint64_t orc_all_pairs(const uint64_t* data, const uint64_t* mask, const orc_variant* vars,
+                       uint32_t n_variants, uint32_t n_samples, const orc_settings* st,
+                       int vector_only, orc_record* recs) {
+	return orc_all_pairs_rows(data, mask, vars, n_variants, n_samples, st, vector_only, 0, n_variants, recs);
 }
 
 /* ---- O1: lib/core.cpp:470-490 ------------------------------------------ */

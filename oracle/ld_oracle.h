@@ -109,6 +109,11 @@ int orc_pair(const uint64_t* a, const uint64_t* ma, const orc_variant* A,
 uint64_t orc_all_pairs(const uint64_t* data, const uint64_t* mask, const orc_variant* vars,
                        uint32_t n_variants, uint32_t n_samples, const orc_settings* st,
                        int vector_only, orc_record* recs);
+/* The same for rows [row0, row1) of the triangle only (re-entrant: the test harness runs disjoint row
+ * ranges on several host threads); recs must hold the pairs of those rows. */
+uint64_t orc_all_pairs_rows(const uint64_t* data, const uint64_t* mask, const orc_variant* vars,
+                            uint32_t n_variants, uint32_t n_samples, const orc_settings* st,
+                            int vector_only, uint32_t row0, uint32_t row1, orc_record* recs);
 
 /* O1 serialiser of twk1_two_t (lib/core.cpp:470-490): 106 bytes. */
 void orc_pack_record(const orc_record* r, uint8_t out[106]);

@@ -57,6 +57,8 @@ def lib() -> C.CDLL:
         L.orc_unphased_math.argtypes = [p, p, p, C.POINTER(Settings), p]
         L.orc_all_pairs.restype = C.c_uint64
         L.orc_all_pairs.argtypes = [p, p, p, C.c_uint32, C.c_uint32, C.POINTER(Settings), C.c_int, p]
+        L.orc_all_pairs_rows.restype = C.c_uint64
+        L.orc_all_pairs_rows.argtypes = [p, p, p, C.c_uint32, C.c_uint32, C.POINTER(Settings), C.c_int, C.c_uint32, C.c_uint32, p]
         L.orc_pack_record.argtypes = [p, p]
         _lib = L
     return _lib
@@ -139,18 +141,56 @@ def unphased_math(c9, A, B, st):
     return (rec[0] if ok else None)
 
 
+def _threads() -> int:
+    """Host threads for all_pairs: the CPUs this process may run on, 8 at most (TWK_ORACLE_THREADS overrides)."""
+    env = os.environ.get("TWK_ORACLE_THREADS")
+    if env:
+        return max(1, int(env))
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(8, n))
+
+
 def all_pairs(data, mask, variants, n_samples, st, vector_only=True) -> np.ndarray:
+    """Records of all pairs i < j in pair order.  Large problems are cut into row ranges of equal pair
+    count and run on several host threads (ctypes drops the GIL; orc_all_pairs_rows keeps no state);
+    the ranges are joined in row order, so the result is the serial loop's."""
     M = data.shape[0]
     data = np.ascontiguousarray(data, dtype=np.uint64)
     variants = np.ascontiguousarray(variants, dtype=VARIANT_DTYPE)
-    recs = np.zeros(max(M * (M - 1) // 2, 1), dtype=RECORD_DTYPE)
+    total = M * (M - 1) // 2
+    recs = np.zeros(max(total, 1), dtype=RECORD_DTYPE)
     mptr = None
     if mask is not None:
         mask = np.ascontiguousarray(mask, dtype=np.uint64)
         mptr = mask.ctypes.data
-    n = lib().orc_all_pairs(data.ctypes.data, mptr, variants.ctypes.data, M, n_samples, C.byref(st),
+    L = lib()
+    nt = _threads()
+    if nt == 1 or total * data.shape[1] < (1 << 18):
+        n = L.orc_all_pairs(data.ctypes.data, mptr, variants.ctypes.data, M, n_samples, C.byref(st),
                             int(vector_only), recs.ctypes.data)
-    return recs[:n].copy()
+        return recs[:n].copy()
+    before = lambda r: r * (2 * M - r - 1) // 2             # pairs of the rows in front of row r
+    cuts = [0]
+    for k in range(1, 4 * nt):
+        r = cuts[-1]
+        while r < M and before(r) < total * k // (4 * nt):
+            r += 1
+        cuts.append(r)
+    cuts.append(M)
+    ranges = [(a, b) for a, b in zip(cuts, cuts[1:]) if b > a]
+
+    def run(rng):
+        r0, r1 = rng
+        return L.orc_all_pairs_rows(data.ctypes.data, mptr, variants.ctypes.data, M, n_samples, C.byref(st),
+                                    int(vector_only), r0, r1, recs[before(r0):].ctypes.data)
+
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(nt) as pool:
+        counts = list(pool.map(run, ranges))
+    return np.concatenate([recs[before(r0):before(r0) + n] for (r0, _), n in zip(ranges, counts)] or [recs[:0]])
 
 
 def pack_record(rec) -> bytes:
