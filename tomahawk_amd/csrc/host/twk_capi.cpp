@@ -14,6 +14,7 @@
 #include "twk_two_tools.h"
 #include "twk_import.h"
 #include "twk_record_sink.h"
+#include "twk_repcodec.h"
 
 using namespace tomahawk;
 
@@ -351,6 +352,15 @@ struct TwoStream {
 // CPUs the host side sizes its thread pools by: hardware threads, cut to the affinity mask and the container's CFS quota
 // (twk_util.h usable_cpus).
 int twk_usable_cpus(void) { return util::usable_cpus(); }
+
+// The records' own zstd encoder (twk_repcodec.h) on a buffer: -> frame size, 0 if dst is too small (twk_record_codec_bound(n)
+// always suffices).  Tests decode the frame with libzstd.
+uint64_t twk_record_codec_bound(uint64_t n) { return repcodec::bound(n); }
+uint64_t twk_record_codec_compress(const uint8_t* src, uint64_t n, uint32_t stride, uint8_t* dst, uint64_t cap) try {
+	if ((!src && n) || !dst || stride == 0 || cap < repcodec::bound(n) || (n >> 32)) return 0;
+	std::unique_ptr<repcodec::Work> w(new repcodec::Work);
+	return repcodec::compress_frame(dst, src, n, stride, *w);
+} catch (...) { return 0; }
 
 void* twk_two_stream_open(const char* path, uint32_t n_samples, uint32_t n_contigs, const uint32_t* rid, const uint32_t* pos,
                           uint32_t n_variants, int c_level, uint32_t b_size, int n_threads, int map_output) try {

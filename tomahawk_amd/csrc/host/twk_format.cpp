@@ -10,6 +10,9 @@
 #include <cerrno>
 #include <cstring>
 #include <iostream>
+#include <memory>
+
+#include "twk_repcodec.h"
 
 // libzstd's stable one-shot API (zstd.h).  The image ships libzstd.so.1 but no
 // system header, so the six prototypes we use are declared here.
@@ -40,10 +43,26 @@ struct CCtxHolder { ZSTD_CCtx* c = ZSTD_createCCtx(); ~CCtxHolder() { if (c) ZST
 }
 bool zstd_compress(const uint8_t* src, size_t n, std::vector<uint8_t>& dst, int level) {
 	static thread_local CCtxHolder ctx;
+	if (is_record_codec(level)) level -= RECORD_CODEC_LEVEL;      // (a writer opened with the records' codec: its header and index frames, its fallback)
 	dst.resize(ZSTD_compressBound(n));
 	const size_t r = ctx.c ? ZSTD_compressCCtx(ctx.c, dst.data(), dst.size(), src, n, level) : ZSTD_compress(dst.data(), dst.size(), src, n, level);
 	if (ZSTD_isError(r)) { std::cerr << "[zstd] " << ZSTD_getErrorName(r) << std::endl; return false; }
 	dst.resize(r);
+	return true;
+}
+bool record_codec_compress(const uint8_t* src, size_t n, std::vector<uint8_t>& dst, uint32_t stride, int fallback_level) {
+	static thread_local std::unique_ptr<repcodec::Work> work(new repcodec::Work);
+	enum : size_t { SAMPLE = 32768 };
+	if (n >> 32) return false;                              // (the frame header written here holds a 4-byte content size)
+	if (n < 4 * SAMPLE) return zstd_compress(src, n, dst, fallback_level);      // small blocks are not where the time goes
+	dst.resize(repcodec::bound(n));
+	{                                                       // is this the kind of block the encoder is for?  Its head, both ways
+		static thread_local std::vector<uint8_t> z;
+		const size_t mine = repcodec::compress_frame(dst.data(), src, SAMPLE, stride, *work);
+		if (!zstd_compress(src, SAMPLE, z, 1)) return false;
+		if (4 * mine > 5 * z.size()) return zstd_compress(src, n, dst, fallback_level);
+	}
+	dst.resize(repcodec::compress_frame(dst.data(), src, n, stride, *work));
 	return true;
 }
 bool zstd_decompress(const uint8_t* src, size_t n, std::vector<uint8_t>& dst, size_t n_unc) {
@@ -403,7 +422,7 @@ bool TwoWriter::pack(const TwoRecord* recs, uint32_t n, int c_level, Packed& out
 bool TwoWriter::pack_block(const uint8_t* block, uint32_t n, int c_level, Packed& out) {
 	const TwoRecord* recs = reinterpret_cast<const TwoRecord*>(block + 8);      // (packed struct: no alignment)
 	const size_t bytes = 8 + (size_t)n * sizeof(TwoRecord);
-	if (!zstd_compress(block, bytes, out.z, c_level)) return false;
+	if (!(is_record_codec(c_level) ? record_codec_compress(block, bytes, out.z, (uint32_t)sizeof(TwoRecord), c_level - RECORD_CODEC_LEVEL) : zstd_compress(block, bytes, out.z, c_level))) return false;
 	IndexEntryOutput& e = out.entry;                      // ld_engine.cpp:1270-1288,1757-1763
 	e = IndexEntryOutput();
 	e.rid = (int32_t)recs[0].ridA; e.ridB = (int32_t)recs[0].ridB;

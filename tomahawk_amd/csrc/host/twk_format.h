@@ -40,6 +40,15 @@ public:
 };
 
 bool zstd_compress(const uint8_t* src, size_t n, std::vector<uint8_t>& dst, int level);
+// The records' own zstd encoder (twk_repcodec.h): frames any zstd decoder reads, made by comparing every byte with the byte one
+// record back - 2-3 x as fast as libzstd's level 1 on the .two blocks of a large cohort and 5-8 % larger.  On records whose
+// values repeat (small cohorts) or that do not follow each other (a shuffled file) a general match search finds far more, so
+// every frame is first tried on its leading 32 KiB, both ways, and goes through libzstd when the encoder's sample is more than
+// a quarter larger.  TwoWriter::pack_block takes this path when the compression level is RECORD_CODEC_LEVEL + k, k the libzstd
+// level of the fallback (`tomahawk calc --engine-option record_codec=1`; -k keeps its meaning).
+enum : int { RECORD_CODEC_LEVEL = 1 << 20 };
+inline bool is_record_codec(int level) { return level >= RECORD_CODEC_LEVEL - 1000; }
+bool record_codec_compress(const uint8_t* src, size_t n, std::vector<uint8_t>& dst, uint32_t stride, int fallback_level);
 bool zstd_decompress(const uint8_t* src, size_t n, std::vector<uint8_t>& dst, size_t n_uncompressed);
 // The same into caller-owned memory of exactly n_uncompressed bytes (quiet: returns false on any mismatch).
 bool zstd_decompress_into(const uint8_t* src, size_t n, uint8_t* dst, size_t n_uncompressed);

@@ -503,7 +503,7 @@ static bool create_devices(DeviceCtxs& dc, int n_gpus, const std::vector<std::pa
 		if (!hip_ok(nullptr, twk_hip_ctx_create(device, &c), "twk_hip_ctx_create")) return false;
 		dc.ctx.push_back(c);
 		for (const auto& kv : options) {
-			if (kv.first == "force_device" || kv.first == "progress_ms" || kv.first == "map_output" || kv.first == "emit_workers" || kv.first == "emit_backlog_mb" || kv.first == "emit_queue_pieces") continue;       // this class's own
+			if (kv.first == "force_device" || kv.first == "progress_ms" || kv.first == "map_output" || kv.first == "emit_workers" || kv.first == "emit_backlog_mb" || kv.first == "emit_queue_pieces" || kv.first == "record_codec") continue;       // this class's own
 			if (!hip_ok(c, twk_hip_set_option(c, kv.first.c_str(), kv.second), "twk_hip_set_option")) return false;
 		}
 	}
@@ -526,7 +526,10 @@ bool twk_ld::twk_ld_impl::run(twk_ld_settings& settings, const Header& hdr, cons
 	// stays the default and the mapping an option.
 	if (option("map_output", 0)) (void)out.writer.map_output();
 	out.b_size = (uint32_t)std::max(2, settings.b_size);
-	out.c_level = settings.c_level; out.rid = rid.data(); out.pos = pos.data(); out.n_variants = rid.size(); out.n_records = 0;
+	// Engine option "record_codec" = 1: the blocks' zstd frames come from the records' own encoder (twk_repcodec.h) instead of
+	// libzstd at level -k: what binds a survivor-rich run is level 1 itself (section 4 of DESIGN.md).
+	out.c_level = option("record_codec", 0) ? (int)RECORD_CODEC_LEVEL + std::max(-999, std::min(settings.c_level, 999)) : settings.c_level;
+	out.rid = rid.data(); out.pos = pos.data(); out.n_variants = rid.size(); out.n_records = 0;
 	n_records = 0; n_pairs = 0;
 	const int n_gpus = (int)ctxs.size();
 	// output workers per GPU: 32 at most (beyond that the one placing step and the memory system are the limit)

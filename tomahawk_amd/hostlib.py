@@ -43,6 +43,10 @@ def lib():
         L.twk_import_vcf.argtypes = [C.c_char_p, C.c_char_p, C.c_double, C.c_double, C.c_int, C.c_uint32, C.c_int, C.c_int, p]
         L.twk_hwe_exact.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
         L.twk_hwe_exact.restype = C.c_double
+        L.twk_record_codec_bound.restype = C.c_uint64
+        L.twk_record_codec_bound.argtypes = [C.c_uint64]
+        L.twk_record_codec_compress.restype = C.c_uint64
+        L.twk_record_codec_compress.argtypes = [p, C.c_uint64, C.c_uint32, p, C.c_uint64]
         L.twk_file_header_literals.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_size_t]
         L.twk_two_stream_open.restype = C.c_void_p
         L.twk_two_stream_open.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, p, p, C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.c_int]
@@ -164,6 +168,19 @@ def import_vcf(path_in, path_out, threshold_miss=0.9, hwe=0.0, remove_univariate
 def usable_cpus() -> int:
     """CPUs the host side sizes its thread pools by (hardware threads, affinity mask, the container's CFS quota)."""
     return int(lib().twk_usable_cpus())
+
+
+RECORD_CODEC_LEVEL = (1 << 20) + 1  # as a compression level of a .two writer: the records' own zstd encoder (twk_repcodec.h), libzstd level 1 where it does not fit
+
+
+def record_codec_compress(data: bytes, stride: int = 106) -> bytes:
+    """One zstd frame of `data` from the records' own encoder (matches only against the byte `stride` back)."""
+    src = np.frombuffer(data, dtype=np.uint8) if len(data) else np.zeros(1, np.uint8)
+    dst = np.zeros(int(lib().twk_record_codec_bound(len(data))), dtype=np.uint8)
+    n = int(lib().twk_record_codec_compress(src.ctypes.data, len(data), stride, dst.ctypes.data, len(dst)))
+    if n == 0:
+        raise RuntimeError("twk_record_codec_compress failed")
+    return dst[:n].tobytes()
 
 
 def hwe_exact(hom1, het, hom2):
