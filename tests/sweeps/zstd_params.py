@@ -105,3 +105,23 @@ for b in blocks:
     transposed.append(b[:8] + a.T.tobytes())
 entropy_only("Huffman literals only, bytes transposed", transposed)
 run("level 1 on transposed bytes (for scale)", level=1) if False else None
+
+
+# ---- round 5, second look: what level 1 finds in these records is runs of bytes that equal the previous record's -----------
+# (tomahawk_amd/csrc/host/twk_repcodec.h: matches only against the byte 106 back, raw literals, FSE tables per frame)
+from tomahawk_amd import hostlib as H2
+zd = C.CDLL("/usr/lib/x86_64-linux-gnu/libzstd.so.1")
+zd.ZSTD_decompress.restype = C.c_size_t; zd.ZSTD_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+frames = [H2.record_codec_compress(b, 106) for b in blocks]
+back = C.create_string_buffer(len(blocks[0]))
+for b, f in zip(blocks, frames):
+    assert zd.ZSTD_decompress(back, len(back), f, len(f)) == len(b) and back.raw[:len(b)] == b
+src = [np.frombuffer(b, np.uint8) for b in blocks]
+dstb = np.zeros(int(H2.lib().twk_record_codec_bound(len(blocks[0]))), np.uint8)
+best = None
+for _ in range(3):
+    t = time.perf_counter()
+    for s in src: H2.lib().twk_record_codec_compress(s.ctypes.data, len(s), 106, dstb.ctypes.data, len(dstb))
+    best = min(best or 1e9, time.perf_counter() - t)
+out = sum(len(f) for f in frames)
+print(f"{'the records own encoder (decoded by libzstd)':36s} {total / best / 1e6:7.1f} MB/s  ratio {total / out:5.2f}  {out / 1e6:7.2f} MB")
