@@ -269,6 +269,7 @@ def run_cli(twk, flags, threads, out):
            "pairs_decided_by_probes": int(prb.group(3).replace(",", "")) if prb else None,
            "fused_launches": int(fus.group(1)) if fus else 0,
            "producer_handover_s": float(wri.group(1)) if wri else None,
+           "writer_line": next((l.split("] ", 1)[-1] for l in lg.splitlines() if "handing its survivors over" in l), None),
            # the wall outside the log's phases: process start -> first log line, last log line -> exit (runtime teardown)
            "wall_before_first_log_line_s": round(stamps[0] - t0, 3) if stamps else None,
            "wall_after_last_log_line_s": round(t0 + wall - stamps[-1], 3) if stamps else None}
@@ -345,6 +346,9 @@ def extra_kg(log):
                                    "window_4mb": "72.1 M pairs/s (4,784,608 variants)"}}
     out["all_pairs"] = timed_cli("kg_all", twk, ["-p"], threads, log, runs=1, warm=True)
     out["window_4mb"] = timed_cli("kg_w4m", twk, ["-p", "-w", "4000000"], threads, log, runs=1, warm=False)
+    # the same run with the output blocks' zstd frames from the records' own encoder (csrc/host/twk_repcodec.h; off by default:
+    # the file is a few per cent larger than libzstd level 1 makes it) - what is left is the one stream into the file
+    out["window_4mb_record_codec"] = timed_cli("kg_w4m_codec", twk, ["-p", "-w", "4000000", "--engine-option", "record_codec=1"], threads, log, runs=1, warm=False)
     return out
 
 

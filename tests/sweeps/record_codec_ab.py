@@ -12,7 +12,7 @@ threads = 64
 log = lambda m: print("[codec] " + m, flush=True)
 big, _ = bench.cohort_twk(bench.KG["n_samples"], bench.KG["n_variants"], log, **{k: v for k, v in bench.KG.items() if k not in ("n_samples", "n_variants")})
 outs = {}
-for flags in (["-p", "-w", "4000000"], ["-p"], ["-u", "-w", "1000000"]):
+for flags in ([["-p", "-w", "4000000"]] if "--short" in sys.argv else [["-p", "-w", "4000000"], ["-p"], ["-u", "-w", "1000000"]]):
     for codec in (0, 1):
         best = None
         out = f"/tmp/codec_ab_{codec}.two"
@@ -21,10 +21,11 @@ for flags in (["-p", "-w", "4000000"], ["-p"], ["-u", "-w", "1000000"]):
             if "error" in r: log(str(r)); break
             if best is None or r["compute_write_s"] < best["compute_write_s"]: best = r
         if best:
+            if True: log(f"  record_codec={codec} writer: " + best.get("writer_line", ""))
             log(f"record_codec={codec} {' '.join(flags)}: wall {best['wall_s']:.2f} s, compute + write {best['compute_write_s']:.3f} s, count kernel {best['count_kernel_ms']:.1f} ms, "
                 f"records {best['records']:,}, file {best['two_bytes'] / 1e9:.3f} GB")
     if O.have_ref() and flags == ["-p", "-w", "4000000"]:
         # the reference reads both files: same text
-        a = subprocess.run(f"timeout 600 {O.REF_BIN} view -i /tmp/codec_ab_0.two | grep -v '^##tomahawk_viewCommand' | md5sum", shell=True, capture_output=True, text=True).stdout.split()[0]
-        b = subprocess.run(f"timeout 600 {O.REF_BIN} view -i /tmp/codec_ab_1.two | grep -v '^##tomahawk_viewCommand' | md5sum", shell=True, capture_output=True, text=True).stdout.split()[0]
+        a = subprocess.run(f"timeout 600 {O.REF_BIN} view -i /tmp/codec_ab_0.two | grep -v '^#' | md5sum", shell=True, capture_output=True, text=True).stdout.split()[0]
+        b = subprocess.run(f"timeout 600 {O.REF_BIN} view -i /tmp/codec_ab_1.two | grep -v '^#' | md5sum", shell=True, capture_output=True, text=True).stdout.split()[0]
         log(f"reference `view` of both files: md5 {a} / {b} -> {'equal' if a == b else 'DIFFERENT'}")

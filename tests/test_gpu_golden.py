@@ -381,3 +381,35 @@ def test_cli_hand_off_queue_writes_the_same_file(tmp_path):
         digests[pieces] = (hashlib.sha256(recs.tobytes()).hexdigest(), info["n_blocks"])
         assert len(recs) > 2 * (1 << 20)             # (both copies of) more than one full piece
     assert digests[0] == digests[1] == digests[8]
+
+
+@pytest.mark.gpu
+def test_cli_record_codec_writes_the_same_records_and_the_reference_reads_them(tmp_path):
+    """`--engine-option record_codec=1`: the output blocks' zstd frames come from the records' own encoder
+    (csrc/host/twk_repcodec.h) or, where its 32 KiB sample comes out a quarter larger than libzstd's, from libzstd as before.
+    Two inputs: 1,200 samples (noisy statistics: the encoder's kind of block - the file must differ from the default's and stay
+    within 15 % of it) and 64 samples (few distinct values: left to libzstd, same size).  Either way the records, the blocks and
+    the index are the default run's, and the compiled reference's `view` prints the same lines from both files."""
+    import hashlib
+    for N, M, want_codec in ((1200, 900, True), (64, 1500, False)):
+        al = util.mosaic_alleles(M, N, 8, n_founders=10, switch=0.05, mut=0.01) if want_codec else util.random_alleles(M, N, 5)
+        twk = str(tmp_path / f"in{N}.twk")
+        hostlib.write_twk(twk, al, (1000 + 10 * np.arange(M)).astype(np.uint32), np.zeros(M, np.uint32), np.ones(M, np.uint8), block_size=100)
+        got = {}
+        for codec in (0, 1):
+            out = str(tmp_path / f"c{N}_{codec}.two")
+            r = subprocess.run([hostlib.CLI_PATH, "calc", "-i", twk, "-o", out, "-p", "-r", "0", "-P", "1", "--engine-option", f"record_codec={codec}"],
+                               capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr
+            recs, info = hostlib.read_two(out)
+            state, ent, _ = hostlib.two_index(out)
+            got[codec] = (hashlib.sha256(recs.tobytes()).hexdigest(), info["n_blocks"], ent[:, :5].tolist(), os.path.getsize(out), out)
+            assert len(recs) > 300_000
+        assert got[0][:3] == got[1][:3]
+        if want_codec:
+            assert got[0][3] != got[1][3] and got[1][3] < 1.15 * got[0][3]
+        else:
+            assert abs(got[0][3] - got[1][3]) < 200          # (the headers quote different command lines)
+        if O.have_ref():
+            lines = [[l for l in O.run_ref(["view", "-i", g[4]]).stdout.splitlines() if not l.startswith("#")] for g in (got[0], got[1])]
+            assert lines[0] == lines[1] and len(lines[0]) > 300_000
