@@ -220,12 +220,13 @@ def _secs(txt):
     return (int(mo.group(1) or 0) * 3600 + int(mo.group(2) or 0) * 60 + float(mo.group(3))) if mo else None
 
 
-def run_cli(twk, flags, threads, out):
+def run_cli(twk, flags, threads, out, keep_out=False):
     """One `tomahawk calc` run -> dict parsed from its log (None if it failed): wall, load, compute + write, pairs, records,
     the kernels' own times (HIP events, as the engine reports them) and the writer's share."""
     from tomahawk_amd import hostlib
     try:
-        os.remove(out)             # (dropping a multi-gigabyte file of the previous run from the page cache is not part of this run)
+        if not keep_out:           # (keep_out: `out` is a symlink to /dev/null, tests/sweeps/record_codec_floor.py)
+            os.remove(out)         # (dropping a multi-gigabyte file of the previous run from the page cache is not part of this run)
     except OSError:
         pass
     t0 = time.time()

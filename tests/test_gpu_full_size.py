@@ -17,7 +17,9 @@ SEED = 42
 
 
 def _rows(N, ids):
-    return np.stack([T.synth_bitvector(SEED, N, int(v))[0] for v in ids])
+    from concurrent.futures import ThreadPoolExecutor          # (0.1 s a row at N = 1 M; the generator is a C call: no GIL)
+    with ThreadPoolExecutor(8) as pool:
+        return np.stack(list(pool.map(lambda v: T.synth_bitvector(SEED, N, int(v))[0], ids)))
 
 
 def _variants(N, ids, data):
