@@ -53,8 +53,8 @@ bool zstd_compress(const uint8_t* src, size_t n, std::vector<uint8_t>& dst, int 
 bool record_codec_compress(const uint8_t* src, size_t n, std::vector<uint8_t>& dst, uint32_t stride, int fallback_level) {
 	static thread_local std::unique_ptr<repcodec::Work> work(new repcodec::Work);
 	enum : size_t { SAMPLE = 32768 };
-	if (n >> 32) return false;                              // (the frame header written here holds a 4-byte content size)
-	if (n < 4 * SAMPLE) return zstd_compress(src, n, dst, fallback_level);      // small blocks are not where the time goes
+	// small blocks are not where the time goes; the frame header written by the encoder holds a 4-byte content size
+	if (n < 4 * SAMPLE || (n >> 32)) return zstd_compress(src, n, dst, fallback_level);
 	dst.resize(repcodec::bound(n));
 	{                                                       // is this the kind of block the encoder is for?  Its head, both ways
 		static thread_local std::vector<uint8_t> z;
