@@ -338,7 +338,7 @@ int twk_hip_fisher_exact(twk_hip_ctx* ctx, const int32_t* tables, uint64_t n, do
  *                               pair (HH and S = QH + HQ + 2 QQ, all the screen reads) and recount the four products of the pairs
  *                               that pass; 0: four products for every pair; 2: keep to it even when a launch was candidate-rich
  * Keys of the host side (`tomahawk calc --engine-option`, twk_ld::SetEngineOption - handled in csrc/host/twk_ld.cpp, unknown to this
- * function): "force_device", "progress_ms", "map_output", "emit_workers", "emit_backlog_mb", "emit_queue_pieces", "record_codec" (INTEGRATION.md 1).
+ * function): "force_device", "progress_ms", "map_output", "emit_workers", "emit_backlog_mb", "emit_queue_pieces", "record_codec", "direct_output" (INTEGRATION.md 1).
  * None of them changes a record (tests/test_gpu_fused.py, test_gpu_lists.py); "lists" / "list_max" drop the derived
  * plane sets, which are rebuilt on next use.  Unknown key or value out of range: TWK_HIP_E_INVALID. */
 int twk_hip_set_option(twk_hip_ctx* ctx, const char* key, int64_t value);

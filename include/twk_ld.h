@@ -65,7 +65,7 @@ public:
 	// class's own: "force_device" (every context on GPU n: several contexts on one GPU), "progress_ms" (period of
 	// the progress line) "map_output" (1: the .two is written through a shared mapping by the emitter's workers instead of a stream) and "emit_workers" (threads that
 	// expand, compress and place the output blocks, per GPU; default min(-t, 32)) and "emit_backlog_mb" (expanded blocks that may wait in memory for those threads, per GPU;
-	// default 0: six blocks per thread) and "emit_queue_pieces" (buffers of 2^20 survivors between the engine's thread and the emitter, per GPU; default 8, 0: none) and "record_codec" (1: output blocks compressed by the records' own zstd encoder instead of libzstd at level -k; default 0).  `tomahawk calc --engine-option key=value` ends here.  Nothing is read from the environment
+	// default 0: six blocks per thread) and "emit_queue_pieces" (buffers of 2^20 survivors between the engine's thread and the emitter, per GPU; default 8, 0: none) and "record_codec" (1: output blocks compressed by the records' own zstd encoder instead of libzstd at level -k; default 0) and "direct_output" (1: block frames written with pwritev() and space reserved ahead instead of through the iostream; default 0).  `tomahawk calc --engine-option key=value` ends here.  Nothing is read from the environment
 	// except TWK_HIP_DEVICE / TWK_HIP_GPUS / TWK_HIP_PART (placement), TWK_REF_COMPAT and TWK_HIP_NO_SCREEN.
 	void SetEngineOption(const std::string& key, int64_t value);
 

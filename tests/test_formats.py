@@ -303,7 +303,7 @@ def test_mapped_and_stream_output_write_the_same_file(tmp_path):
         recs[f] = rng.random(len(recs))
     recs["cnt"] = rng.integers(0, 500, (len(recs), 4))
     digests = {}
-    for mapped in (False, True):
+    for mapped in (False, True, 2):                        # 2: direct mode (one pwritev a frame, space reserved ahead; twk_format.h)
         path = str(tmp_path / f"m{int(mapped)}.two")
         st = hostlib.TwoStream(path, 50, rid, pos, n_contigs=3, b_size=1000, n_threads=5, map_output=mapped)
         k = 0
@@ -314,7 +314,7 @@ def test_mapped_and_stream_output_write_the_same_file(tmp_path):
         digests[mapped] = hashlib.sha256(open(path, "rb").read()).hexdigest()
         back, info = hostlib.read_two(path)
         assert len(back) == 2 * len(recs) and info["n_blocks"] > 100
-    assert digests[False] == digests[True]
+    assert digests[False] == digests[True] == digests[2]
 
 
 def test_record_emitter_and_hand_off_queue_are_clean_under_tsan():

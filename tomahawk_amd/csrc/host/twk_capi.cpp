@@ -373,7 +373,8 @@ void* twk_two_stream_open(const char* path, uint32_t n_samples, uint32_t n_conti
 	st->rid.assign(rid, rid + n_variants); st->pos.assign(pos, pos + n_variants);
 	for (uint32_t v = 0; v < n_variants; ++v) if (st->rid[v] >= n_contigs) return nullptr;
 	if (!st->out.writer.open(path, hdr, c_level > 0 ? c_level : 1)) return nullptr;
-	if (map_output) (void)st->out.writer.map_output();       // (0: through a stream also where the file could be mapped - A/B runs and tests of both paths)
+	if (map_output == 1) (void)st->out.writer.map_output();       // (0: through a stream also where the file could be mapped - A/B runs and tests of both paths)
+	else if (map_output == 2) (void)st->out.writer.direct_output();      // (2: frames by pwritev, space reserved ahead)
 	st->out.b_size = b_size; st->out.c_level = c_level > 0 ? c_level : 1;
 	st->out.rid = st->rid.data(); st->out.pos = st->pos.data(); st->out.n_variants = st->rid.size();
 	st->emitter.reset(new RecordEmitter(st->out, n_threads > 0 ? std::min(n_threads, util::usable_cpus()) : 1));

@@ -4,6 +4,7 @@
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <sys/uio.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -394,7 +395,18 @@ bool TwkReader::read_block(size_t i, Block& blk) { // twk_reader.cpp:8-44
 }
 
 // ---- .two writer / reader ------------------------------------------------------------
-bool TwoWriter::put(const void* p, size_t n) { os_->write((const char*)p, n); off_ += n; return os_->good(); }
+bool TwoWriter::put(const void* p, size_t n) {
+	if (direct()) {
+		for (size_t done = 0; done < n;) {
+			const ssize_t w = ::pwrite(dfd_, static_cast<const char*>(p) + done, n - done, (off_t)(off_ + done));
+			if (w < 0) { if (errno == EINTR) continue; return false; }
+			done += (size_t)w;
+		}
+		off_ += n;
+		return true;
+	}
+	os_->write((const char*)p, n); off_ += n; return os_->good();
+}
 
 bool TwoWriter::open(const std::string& path, const Header& hdr, int c_level) {
 	c_level_ = c_level; off_ = 0; n_records = n_blocks = 0; path_ = path;
@@ -455,13 +467,50 @@ bool TwoWriter::write_packed(const Packed& p) {
 	if (mapped()) { Span at; if (!reserve(p, at)) return false; fill(at, p); return true; }
 	const uint64_t foff = off_;
 	const uint8_t marker = 1; const uint32_t unc = p.b_unc, cmp = (uint32_t)p.z.size();
+	if (direct()) {
+		uint8_t head[9];
+		head[0] = marker; std::memcpy(head + 1, &unc, 4); std::memcpy(head + 5, &cmp, 4);
+		const uint64_t bytes = 9 + p.z.size();
+		while (reserved_end_ < off_ + bytes) {               // space ahead of the writes (a hint: where it cannot be had the writes allocate as they go)
+			if (::fallocate(dfd_, FALLOC_FL_KEEP_SIZE, (off_t)reserved_end_, (off_t)(1ull << 30)) != 0 && errno == ENOSPC) return false;
+			reserved_end_ += 1ull << 30;
+		}
+		struct iovec iov[2] = {{head, 9}, {const_cast<uint8_t*>(p.z.data()), p.z.size()}};
+		uint64_t done = 0;
+		while (done < bytes) {
+			struct iovec part[2]; int n = 0;
+			uint64_t skip = done;
+			for (int k = 0; k < 2; ++k) {
+				if (skip >= iov[k].iov_len) { skip -= iov[k].iov_len; continue; }
+				part[n].iov_base = static_cast<uint8_t*>(iov[k].iov_base) + skip; part[n].iov_len = iov[k].iov_len - skip; ++n; skip = 0;
+			}
+			const ssize_t w = ::pwritev(dfd_, part, n, (off_t)(off_ + done));
+			if (w < 0) { if (errno == EINTR) continue; return false; }
+			done += (uint64_t)w;
+		}
+		off_ += bytes;
+		add_index_entry(p, foff, off_);
+		return true;
+	}
 	if (!put(&marker, 1) || !put(&unc, 4) || !put(&cmp, 4) || !put(p.z.data(), p.z.size())) return false;
 	add_index_entry(p, foff, off_);
 	return true;
 }
 
 // ---- mapped mode (twk_format.h) ----
-TwoWriter::~TwoWriter() { unmap_all(); if (fd_ >= 0) ::close(fd_); }
+TwoWriter::~TwoWriter() { unmap_all(); if (fd_ >= 0) ::close(fd_); if (dfd_ >= 0) ::close(dfd_); }
+
+bool TwoWriter::direct_output() {
+	if (direct()) return true;
+	if (mapped() || !os_ || !file_.is_open() || path_.empty() || path_ == "-") return false;
+	file_.flush();
+	if (!file_.good()) return false;
+	struct stat st;
+	if (::stat(path_.c_str(), &st) != 0 || !S_ISREG(st.st_mode) || (uint64_t)st.st_size != off_) return false;      // a regular file holding exactly what was written so far
+	dfd_ = ::open(path_.c_str(), O_WRONLY);
+	reserved_end_ = off_;
+	return dfd_ >= 0;
+}
 
 void TwoWriter::unmap_all() {
 	if (!win_) return;
@@ -565,6 +614,13 @@ bool TwoWriter::close() { // writer.h:293-313
 		unmap_all();
 		const bool cut = ::ftruncate(fd_, (off_t)off_) == 0;
 		::close(fd_); fd_ = -1; win_.reset();
+		file_.seekp((std::streamoff)off_);
+		if (!cut || !file_.good()) { file_.close(); os_ = nullptr; return false; }
+	}
+	if (direct()) {
+		// the frames are in the file; give back what was reserved beyond them and go on as a stream
+		const bool cut = ::ftruncate(dfd_, (off_t)off_) == 0;
+		::close(dfd_); dfd_ = -1;
 		file_.seekp((std::streamoff)off_);
 		if (!cut || !file_.good()) { file_.close(); os_ = nullptr; return false; }
 	}

@@ -204,6 +204,13 @@ public:
 	bool mapped() const { return fd_ >= 0; }
 	bool reserve(const Packed& p, Span& at);
 	void fill(const Span& at, const Packed& p);
+	// Direct mode (round 5).  With the blocks' compression cheap (record codec) the one stream into the file is what a
+	// survivor-rich run waits for; direct_output(), after open(), takes the block frames out of the iostream: one pwritev()
+	// per frame (head + payload) at the writer's own offset, with the file's space reserved 1 GiB ahead (fallocate, size kept)
+	// where the file system can.  Same bytes as the stream; close() cuts the reservation and writes the index through the
+	// stream again.  Returns false, and the writer stays a stream, for stdout and files that cannot be reopened.
+	bool direct_output();
+	bool direct() const { return dfd_ >= 0; }
 	// Append an already compressed block under the given index entry (concat, lib/concat.h:160-175).
 	bool write_raw(uint32_t b_unc, const std::vector<uint8_t>& z, IndexEntryOutput entry);
 	int  compression_level() const { return c_level_; }
@@ -222,6 +229,8 @@ private:
 	static constexpr size_t MAX_WINDOWS = 1u << 14;                  // 16 TiB
 	std::string path_;
 	int fd_ = -1;
+	int dfd_ = -1;                                                   // direct mode's descriptor
+	uint64_t reserved_end_ = 0;                                      // file bytes below it are preallocated
 	uint64_t mapped_end_ = 0;                                        // file bytes [0, mapped_end_) are reserved and mapped
 	std::unique_ptr<std::atomic<uint8_t*>[]> win_;                   // window k = file bytes [k * WIN_BYTES, (k + 1) * WIN_BYTES)
 	bool grow_to(uint64_t end);

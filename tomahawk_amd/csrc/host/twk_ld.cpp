@@ -503,7 +503,7 @@ static bool create_devices(DeviceCtxs& dc, int n_gpus, const std::vector<std::pa
 		if (!hip_ok(nullptr, twk_hip_ctx_create(device, &c), "twk_hip_ctx_create")) return false;
 		dc.ctx.push_back(c);
 		for (const auto& kv : options) {
-			if (kv.first == "force_device" || kv.first == "progress_ms" || kv.first == "map_output" || kv.first == "emit_workers" || kv.first == "emit_backlog_mb" || kv.first == "emit_queue_pieces" || kv.first == "record_codec") continue;       // this class's own
+			if (kv.first == "force_device" || kv.first == "progress_ms" || kv.first == "map_output" || kv.first == "emit_workers" || kv.first == "emit_backlog_mb" || kv.first == "emit_queue_pieces" || kv.first == "record_codec" || kv.first == "direct_output") continue;       // this class's own
 			if (!hip_ok(c, twk_hip_set_option(c, kv.first.c_str(), kv.second), "twk_hip_set_option")) return false;
 		}
 	}
@@ -525,6 +525,9 @@ bool twk_ld::twk_ld_impl::run(twk_ld_settings& settings, const Header& hdr, cons
 	// profiles/r04_writer_ab.txt - 32 threads taking page faults in one address space do not scale there), so the stream
 	// stays the default and the mapping an option.
 	if (option("map_output", 0)) (void)out.writer.map_output();
+	// Engine option "direct_output" = 1: the block frames go into the file with one pwritev() each, its space reserved ahead
+	// (twk_format.h) - with the record codec the one stream into the file is what a survivor-rich run waits for.
+	else if (option("direct_output", 0)) (void)out.writer.direct_output();
 	out.b_size = (uint32_t)std::max(2, settings.b_size);
 	// Engine option "record_codec" = 1: the blocks' zstd frames come from the records' own encoder (twk_repcodec.h) instead of
 	// libzstd at level -k: what binds a survivor-rich run is level 1 itself (section 4 of DESIGN.md).

@@ -216,7 +216,7 @@ class TwoStream:
         pos = np.ascontiguousarray(pos, dtype=np.uint32)
         assert rid.shape == pos.shape
         self._h = lib().twk_two_stream_open(path.encode(), n_samples, n_contigs, rid.ctypes.data, pos.ctypes.data, len(rid),
-                                            c_level, b_size, n_threads, int(bool(map_output)))
+                                            c_level, b_size, n_threads, int(map_output))      # 0 stream, 1 (True) mapped, 2 direct (pwritev, space reserved ahead)
         if not self._h:
             raise RuntimeError(f"twk_two_stream_open failed for {path}")
 
