@@ -221,8 +221,11 @@ int twk_hip_ld_tile(twk_hip_ctx* ctx, int mode, const twk_hip_tile_desc* tile,
  * replaces twk_ld_balancer::Build (ld_balancing.h:23-80) for multi-GPU sharding.
  * tile_variants = edge of a super-tile in variants (0 = choose: launches sized
  * by their work where no count matrix is kept, see the "band_launch" switch).
- * Survivors are handed to `sink` (may be NULL to discard) on the calling thread,
- * launch by launch, a launch's survivors in pieces of at most 2^20 records; the
+ * Survivors are handed to `sink` (may be NULL to discard) launch by launch, one
+ * call at a time, all of them before this function returns - from a second
+ * thread of the engine while the calling thread runs the launches (option
+ * "async_delivery", default 1; 0: on the calling thread) -
+ * a launch's survivors in pieces of at most 2^20 records; the
  * records of one sink call are in (idxA, idxB) order (sorted on the device), the
  * pieces of a launch follow each other in that order, and a piece stays valid
  * until the sink returns.  *n_pairs / *n_records (may be NULL)
@@ -337,6 +340,10 @@ int twk_hip_fisher_exact(twk_hip_ctx* ctx, const int32_t* tables, uint64_t n, do
  *   "three"            1        UnphasedMath on planes without missing genotypes, r2 cut-off > 1e-6: contract three products per
  *                               pair (HH and S = QH + HQ + 2 QQ, all the screen reads) and recount the four products of the pairs
  *                               that pass; 0: four products for every pair; 2: keep to it even when a launch was candidate-rich
+ *   "async_delivery"   1        region calls with a sink: a finished launch's sorted survivors are copied aside on the device and
+ *                               a second thread of the engine takes them to the host and calls the sink - in the launches' order,
+ *                               one call at a time - while the calling thread goes on enqueueing launches; 0: the calling thread
+ *                               does both (round 4)
  * Keys of the host side (`tomahawk calc --engine-option`, twk_ld::SetEngineOption - handled in csrc/host/twk_ld.cpp, unknown to this
  * function): "force_device", "progress_ms", "map_output", "emit_workers", "emit_backlog_mb", "emit_queue_pieces", "record_codec", "direct_output" (INTEGRATION.md 1).
  * None of them changes a record (tests/test_gpu_fused.py, test_gpu_lists.py); "lists" / "list_max" drop the derived

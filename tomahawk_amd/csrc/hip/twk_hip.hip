@@ -13,6 +13,12 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <vector>
 #include <chrono>
 #include <string.h>
@@ -146,6 +152,7 @@ struct Options {
 	long long timeline = 0;          // 1: the host's steps through the launch pipeline of a region, with times, on stderr (measurement)
 	long long band_work_log2 = 19;   // ... and at least 2^n tile-chunks of work per launch (19: ~5 ms); small values make several launches of a small run
 	long long probe_lds = 1;         // probes through LDS: column rows staged segment by segment, carriers tested there (ld_list.hip.h k_probe_lds_t); 0: gathers from L2
+	long long async_delivery = 1;    // region calls with a sink: finished launches' survivors are copied aside on the device and taken to the host by a second thread (delivery_loop); 0: by the thread that runs the launches (round 4)
 	long long probe_cols = 0;        // probes: columns a block takes (2, 4, 8, 16: phased planes; unphased planes half of it; ld_list.hip.h k_probe_strip_t); 0: one column per block
 	long long three = 1;             // UnphasedMath on the plain unphased planes with an r2 cut-off: the three-product contraction (HH + S, ld_count.hip.h) and a
 	                                 // recount of the candidates' four products; 0: the four-product forms; 2: also when a launch turned out candidate-rich
@@ -161,14 +168,27 @@ const OptionKey OPTION_KEYS[] = {
 	{"record_cap", &Options::record_cap, 0, 1ll << 40, false},
 	{"probe", &Options::probe, 0, 1, false}, {"band_launch", &Options::band_launch, 0, 1, false}, {"band_list_entries", &Options::band_list_entries, 0, 1ll << 32, false},
 	{"band_work_log2", &Options::band_work_log2, 0, 40, false}, {"band_max_launches", &Options::band_max_launches, 1, 64, false}, {"timeline", &Options::timeline, 0, 1, false}, {"band_reverse", &Options::band_reverse, 0, 1, false}, {"probe_zone", &Options::probe_zone, 0, 1, false}, {"probe_unroll", &Options::probe_unroll, 1, 4, false},
-	{"three", &Options::three, 0, 2, false}, {"probe_cols", &Options::probe_cols, 0, 16, false}, {"probe_lds", &Options::probe_lds, 0, 1, false},
+	{"three", &Options::three, 0, 2, false}, {"probe_cols", &Options::probe_cols, 0, 16, false}, {"probe_lds", &Options::probe_lds, 0, 1, false}, {"async_delivery", &Options::async_delivery, 0, 1, false},
 };
 }  // namespace
+
+// The delivery thread's state (delivery_loop): finished launches' survivors, copied aside on the device, waiting for the host.
+struct Delivery {
+	struct Item { size_t buf; const twk_hip_record* p; unsigned long long n; twk_hip_record_sink sink; void* user; };      // (the sink of the call that finished the launch: a sample's records go nowhere)
+	struct Buf { twk_hip_record* p; unsigned long long cap; bool busy; };
+	std::thread th;
+	std::mutex mu; std::condition_variable cv;
+	std::deque<Item> q;              // under mu: in the order of the launches
+	std::vector<Buf> pool;           // under mu: device buffers of the call (freed when it ends)
+	bool stop = false, active = false;
+	std::atomic<int> rc{0};          // the first failure (the sink's, a copy's)
+};
 
 struct twk_hip_ctx {
 	int device = 0;
 	Options opt;
-	hipStream_t s_compute = nullptr, s_copy = nullptr;
+	hipStream_t s_compute = nullptr, s_copy = nullptr, s_deliver = nullptr;      // s_deliver: the delivery thread's copies to the host
+	Delivery dl;
 	uint32_t N = 0, M = 0, M_alloc = 0;
 	uint32_t Wp = 0, Wu = 0;       // padded words per row: raw (2N bits) / unphased planes (N bits)
 	uint32_t* raw = nullptr;       // [M_alloc][Wp]
@@ -739,7 +759,10 @@ int enqueue_tile(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, const twk
 	if (two_pass) { rc = ensure_planes(c, kind2); if (rc) return rc; }
 	const Geometry g = tile_geometry(pl.Pmax, t);
 	if (list_words && !fused_form_applies(c, mode, f)) return TWK_HIP_E_STATE;
+	const auto tl0 = std::chrono::steady_clock::now();
+	auto tl = [&](const char* what) { if (c->opt.timeline) fprintf(stderr, "[timeline]     enqueue_tile: %s at +%.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tl0).count()); };
 	rc = ensure_slot(c, s, list_words ? list_words : (size_t)g.rowsA * g.rowsB, capacity); if (rc) return rc;
+	tl("slot buffers");
 	s.two_pass = two_pass;
 
 	HIPCHK(c, hipMemsetAsync(s.n_out, 0, N_SLOT_COUNTERS * sizeof(unsigned long long), c->s_compute));
@@ -785,6 +808,7 @@ int enqueue_tile(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, const twk
 	s.deferred = false; s.was_deferred = false; s.presorted = false;
 	rc = launch_count(c, kind1, t, s, 0, s.ev_c0, s.ev_c1, &s.row_pairs, cr, want_fused ? &fa : nullptr, &s.fused, &d_stats, want_three, &d_screen); if (rc) return rc;
 	s.three = want_three; s.three_plain = want_three && !s.fused; s.plane_set = kind1;
+	tl("count kernel enqueued");
 	if (list_words) {
 		// A band launch stops here for now: how many survivors it can have is how many candidates it found, and only the count
 		// kernel knows.  The counters travel to the host behind it; enqueue_band_math sizes the survivor buffer by them and
@@ -1037,15 +1061,121 @@ void watch_launch(twk_hip_ctx* c, const Slot& s, float ms, const twk_hip_tile_de
 	c->launches_seen += 1;
 }
 
+// kept sorted records on the device -> the host, through the pinned staging buffer, handed to `sink` in pieces of HOST_CHUNK records, each
+// piece while the next is being copied (a launch may hold tens of millions of survivors: page-locking a buffer for all of them would cost
+// more than the copy).  Called by the thread that finishes the launch, or by the delivery thread.
+constexpr unsigned long long HOST_CHUNK = 1ull << 20;       // records per piece (109 MB)
+int deliver_records(twk_hip_ctx* c, const twk_hip_record* sorted, unsigned long long kept, twk_hip_record_sink sink, void* user, hipStream_t st, double tl_wait) {
+	auto since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
+	double tl_copy = 0, tl_sink = 0;
+	int rc;
+	if (kept <= HOST_CHUNK) {
+		rc = ensure_host_records(c, kept); if (rc) return rc;
+		if (kept) HIPCHK(c, hipMemcpyAsync(c->h_recs, sorted, (size_t)kept * sizeof(twk_hip_record), hipMemcpyDeviceToHost, st));
+		HIPCHK(c, hipStreamSynchronize(st));
+		if (kept && sink(user, c->h_recs, kept)) return TWK_HIP_E_INVALID;
+		return TWK_HIP_OK;
+	}
+	rc = ensure_host_records(c, 2 * HOST_CHUNK); if (rc) return rc;
+	auto copy_piece = [&](unsigned long long first) -> hipError_t {
+		const unsigned long long m = std::min(HOST_CHUNK, kept - first);
+		return hipMemcpyAsync(c->h_recs + ((first / HOST_CHUNK) & 1) * HOST_CHUNK, sorted + first, (size_t)m * sizeof(twk_hip_record), hipMemcpyDeviceToHost, st);
+	};
+	HIPCHK(c, copy_piece(0));
+	for (unsigned long long first = 0; first < kept; first += HOST_CHUNK) {
+		auto t1 = std::chrono::steady_clock::now();
+		HIPCHK(c, hipStreamSynchronize(st));                                          // piece `first` has arrived
+		if (first + HOST_CHUNK < kept) HIPCHK(c, copy_piece(first + HOST_CHUNK));     // the next one travels while the sink works (into the other half)
+		tl_copy += since(t1); t1 = std::chrono::steady_clock::now();
+		if (sink(user, c->h_recs + ((first / HOST_CHUNK) & 1) * HOST_CHUNK, std::min(HOST_CHUNK, kept - first))) {
+			(void)hipStreamSynchronize(st);
+			return TWK_HIP_E_INVALID;
+		}
+		tl_sink += since(t1);
+	}
+	if (c->opt.timeline) fprintf(stderr, "[timeline]   inside: waited %.3f ms for the launch, %.3f ms for copies, %.3f ms in the sink (%llu records)\n", tl_wait, tl_copy, tl_sink, kept);
+	return TWK_HIP_OK;
+}
+
+// ---- the delivery thread (option async_delivery) ----------------------------------------------------------------------------
+// A launch rich in survivors holds the thread that finishes it for as long as the output side needs for them - 13 M records of the
+// 2,504 x 531,500 run: 130 ms - and while it does, no launch is enqueued: the device idles (profiles/r05_delivery_thread.txt).
+// During a region call with a sink the finished launch's sorted survivors are therefore copied aside on the device (a millisecond
+// a gigabyte) and queued; a second thread takes the queue to the host, in order, through deliver_records.  The sink is then called
+// from that thread - one call at a time, in the order of the launches, as before.
+void delivery_loop(twk_hip_ctx* c) {
+	(void)hipSetDevice(c->device);
+	Delivery& d = c->dl;
+	for (;;) {
+		Delivery::Item it;
+		{
+			std::unique_lock<std::mutex> lk(d.mu);
+			d.cv.wait(lk, [&] { return d.stop || !d.q.empty(); });
+			if (d.q.empty()) return;
+			it = d.q.front(); d.q.pop_front();
+		}
+		int rc = TWK_HIP_OK;
+		if (!d.rc.load()) rc = deliver_records(c, it.p, it.n, it.sink, it.user, c->s_deliver, 0.0);
+		std::lock_guard<std::mutex> lk(d.mu);
+		if (rc && !d.rc.load()) d.rc.store(rc);
+		d.pool[it.buf].busy = false;
+	}
+}
+void delivery_begin(twk_hip_ctx* c, twk_hip_record_sink sink, void* user) {
+	Delivery& d = c->dl;
+	if (d.active || !sink || c->device_sink || !c->opt.async_delivery) return;
+	(void)user; d.stop = false; d.rc.store(0);
+	d.th = std::thread(delivery_loop, c);
+	d.active = true;
+}
+// -> the delivery thread's result once everything queued has reached the sink
+int delivery_end(twk_hip_ctx* c) {
+	Delivery& d = c->dl;
+	if (!d.active) return TWK_HIP_OK;
+	{ std::lock_guard<std::mutex> lk(d.mu); d.stop = true; }
+	d.cv.notify_all();
+	d.th.join();
+	d.active = false;
+	for (auto& b : d.pool) if (b.p) (void)hipFree(b.p);
+	d.pool.clear();
+	return d.rc.load();
+}
+int discard_records(void*, const twk_hip_record*, uint64_t);
+int stage_for_delivery(twk_hip_ctx* c, const twk_hip_record* sorted, unsigned long long kept, twk_hip_record_sink sink, void* user) {
+	Delivery& d = c->dl;
+	if (d.rc.load()) return d.rc.load();
+	if (!kept || sink == discard_records) return TWK_HIP_OK;
+	size_t at = SIZE_MAX;
+	{
+		std::lock_guard<std::mutex> lk(d.mu);
+		for (size_t k = 0; k < d.pool.size(); ++k)
+			if (!d.pool[k].busy && d.pool[k].cap >= kept && (at == SIZE_MAX || d.pool[k].cap < d.pool[at].cap)) at = k;
+		if (at != SIZE_MAX) d.pool[at].busy = true;
+	}
+	if (at == SIZE_MAX) {
+		twk_hip_record* p = nullptr;
+		const unsigned long long cap = std::max<unsigned long long>(kept + kept / 8, 1ull << 16);
+		HIPCHK(c, hipMalloc((void**)&p, (size_t)cap * sizeof(twk_hip_record)));
+		std::lock_guard<std::mutex> lk(d.mu);
+		d.pool.push_back(Delivery::Buf{p, cap, true});
+		at = d.pool.size() - 1;
+	}
+	twk_hip_record* dst;
+	{ std::lock_guard<std::mutex> lk(d.mu); dst = d.pool[at].p; }
+	HIPCHK(c, hipMemcpyAsync(dst, sorted, (size_t)kept * sizeof(twk_hip_record), hipMemcpyDeviceToDevice, c->s_copy));
+	HIPCHK(c, hipStreamSynchronize(c->s_copy));
+	{ std::lock_guard<std::mutex> lk(d.mu); d.q.push_back(Delivery::Item{at, dst, kept, sink, user}); }
+	d.cv.notify_one();
+	return TWK_HIP_OK;
+}
+
 // Wait for slot s, account timing, put its records in (idxA, idxB) order and hand them on: appended to the device sink
 // (!to_host), or through the pinned staging buffer to the host - left there whole (sink == null: c->h_recs, for the
 // single-tile entry point), or handed to `sink` in pieces of HOST_CHUNK records, each piece while the next is being copied
 // (a launch may hold tens of millions of survivors: page-locking a buffer for all of them would cost more than the copy).
-constexpr unsigned long long HOST_CHUNK = 1ull << 20;       // records per piece (109 MB)
 int finish_tile(twk_hip_ctx* c, Slot& s, const twk_hip_tile_desc& t, unsigned long long* n_out, bool to_host = true,
                 twk_hip_record_sink sink = nullptr, void* user = nullptr) {
 	const auto tl0 = std::chrono::steady_clock::now();
-	double tl_copy = 0, tl_sink = 0;
 	auto since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
 	HIPCHK(c, hipEventSynchronize(s.ev_s1));
 	const double tl_wait = since(tl0);
@@ -1107,6 +1237,7 @@ int finish_tile(twk_hip_ctx* c, Slot& s, const twk_hip_tile_desc& t, unsigned lo
 	if (!s.presorted) { rc = sort_records(c, s.out, s.keys, s.vals, n, dropped != 0, c->s_copy); if (rc) return rc; }
 	const twk_hip_record* sorted = s.presorted ? s.sorted : c->d_sorted;      // (a band launch sorted its own behind Fisher's test: enqueue_band_math)
 	*n_out = kept;
+	if (to_host && sink && c->dl.active) return stage_for_delivery(c, sorted, kept, sink, user);      // (the delivery thread takes them to the host: below, deliver_records)
 	if (!to_host) {
 		rc = ensure_device_keep(c, kept); if (rc) return rc;
 		if (kept) HIPCHK(c, hipMemcpyAsync(c->d_keep + c->d_keep_n, sorted, (size_t)kept * sizeof(twk_hip_record), hipMemcpyDeviceToDevice, c->s_copy));
@@ -1114,32 +1245,13 @@ int finish_tile(twk_hip_ctx* c, Slot& s, const twk_hip_tile_desc& t, unsigned lo
 		HIPCHK(c, hipStreamSynchronize(c->s_copy));
 		return TWK_HIP_OK;
 	}
-	if (!sink || kept <= HOST_CHUNK) {
+	if (!sink) {
 		rc = ensure_host_records(c, kept); if (rc) return rc;
 		if (kept) HIPCHK(c, hipMemcpyAsync(c->h_recs, sorted, (size_t)kept * sizeof(twk_hip_record), hipMemcpyDeviceToHost, c->s_copy));
 		HIPCHK(c, hipStreamSynchronize(c->s_copy));
-		if (sink && kept && sink(user, c->h_recs, kept)) return TWK_HIP_E_INVALID;
 		return TWK_HIP_OK;
 	}
-	rc = ensure_host_records(c, 2 * HOST_CHUNK); if (rc) return rc;
-	auto copy_piece = [&](unsigned long long first) -> hipError_t {
-		const unsigned long long m = std::min(HOST_CHUNK, kept - first);
-		return hipMemcpyAsync(c->h_recs + ((first / HOST_CHUNK) & 1) * HOST_CHUNK, sorted + first, (size_t)m * sizeof(twk_hip_record), hipMemcpyDeviceToHost, c->s_copy);
-	};
-	HIPCHK(c, copy_piece(0));
-	for (unsigned long long first = 0; first < kept; first += HOST_CHUNK) {
-		auto t1 = std::chrono::steady_clock::now();
-		HIPCHK(c, hipStreamSynchronize(c->s_copy));                                   // piece `first` has arrived
-		if (first + HOST_CHUNK < kept) HIPCHK(c, copy_piece(first + HOST_CHUNK));     // the next one travels while the sink works (into the other half)
-		tl_copy += since(t1); t1 = std::chrono::steady_clock::now();
-		if (sink(user, c->h_recs + ((first / HOST_CHUNK) & 1) * HOST_CHUNK, std::min(HOST_CHUNK, kept - first))) {
-			(void)hipStreamSynchronize(c->s_copy);
-			return TWK_HIP_E_INVALID;
-		}
-		tl_sink += since(t1);
-	}
-	if (c->opt.timeline) fprintf(stderr, "[timeline]   inside: waited %.3f ms for the launch, %.3f ms for copies, %.3f ms in the sink (%llu records)\n", tl_wait, tl_copy, tl_sink, kept);
-	return TWK_HIP_OK;
+	return deliver_records(c, sorted, kept, sink, user, c->s_copy, tl_wait);
 }
 
 // Rows [row0, row0 + n_rows) of the list zone of the allele-count-sorted phased set, synchronously on the spare slot: every
@@ -1401,6 +1513,7 @@ int twk_hip_ctx_create(int device, twk_hip_ctx** out) {
 		int lo = 0, hi = 0;
 		if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = hi = 0; }
 		if (hipStreamCreateWithPriority(&c->s_copy, hipStreamNonBlocking, hi) != hipSuccess) return fail(TWK_HIP_E_DEVICE);
+		if (hipStreamCreateWithPriority(&c->s_deliver, hipStreamNonBlocking, hi) != hipSuccess) return fail(TWK_HIP_E_DEVICE);
 	}
 	if (hipMalloc((void**)&c->tickets, 2 * (PIPE_SLOTS + 1) * 8 * sizeof(uint32_t)) != hipSuccess) return fail(TWK_HIP_E_NOMEM);
 	for (auto& s : c->slot) {
@@ -1445,6 +1558,7 @@ int twk_hip_ctx_destroy(twk_hip_ctx* c) {
 	if (c->d_col_hi) (void)hipFree(c->d_col_hi);
 	if (c->s_compute) (void)hipStreamDestroy(c->s_compute);
 	if (c->s_copy) (void)hipStreamDestroy(c->s_copy);
+	if (c->s_deliver) (void)hipStreamDestroy(c->s_deliver);
 	delete c;
 	return TWK_HIP_OK;
 }
@@ -1960,20 +2074,24 @@ struct RegionRun {
 		std::vector<char> skipped(n, 0);
 		size_t issued = 0, done = 0, math_issued = 0;      // band launches [0, math_issued) have had the second half of their work enqueued
 		int rc = TWK_HIP_OK;
+		auto issue_next = [&]() -> int {
+			const BandLaunch* b = issued < plan.bands.size() ? &plan.bands[issued] : nullptr;
+			if (b && !c->fused_ok) skipped[issued] = 1;                 // an earlier launch gave the fused form up: this one goes the matrix way when its turn comes
+			else {
+				mark("enqueue launch", issued);
+				const bool three_was = c->three_ok;
+				c->three_ok = three_was && want_three[issued] != 0;       // (the launch's own sample)
+				const int r = enqueue_tile(c, mode, mine[issued], *f, c->slot[issued % PIPE_SLOTS], b ? 1 : cap_default, cr(), b ? b->list_words : 0);
+				c->three_ok = three_was;
+				if (r) return r;
+				mark("enqueued launch", issued);
+			}
+			++issued;
+			return TWK_HIP_OK;
+		};
 		while (done < n) {
 			while (issued < n && issued < done + PIPE_SLOTS) {
-				const BandLaunch* b = issued < plan.bands.size() ? &plan.bands[issued] : nullptr;
-				if (b && !c->fused_ok) skipped[issued] = 1;                 // an earlier launch gave the fused form up: this one goes the matrix way when its turn comes
-				else {
-					mark("enqueue launch", issued);
-					const bool three_was = c->three_ok;
-					c->three_ok = three_was && want_three[issued] != 0;       // (the launch's own sample)
-					rc = enqueue_tile(c, mode, mine[issued], *f, c->slot[issued % PIPE_SLOTS], b ? 1 : cap_default, cr(), b ? b->list_words : 0);
-					c->three_ok = three_was;
-					if (rc) return rc;
-					mark("enqueued launch", issued);
-				}
-				++issued;
+				rc = issue_next(); if (rc) return rc;
 				while (math_issued + 1 < issued) { rc = band_math(math_issued, skipped); if (rc) return rc; ++math_issued; }
 			}
 			while (math_issued <= done && math_issued < issued) { rc = band_math(math_issued, skipped); if (rc) return rc; ++math_issued; }
@@ -2041,7 +2159,13 @@ int twk_hip_ld_region(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint32
                       uint32_t b0, uint32_t nB, int32_t triangle, uint32_t part, uint32_t n_parts,
                       uint32_t tile_variants, int32_t window, uint32_t l_window, twk_hip_record_sink sink,
                       void* user, uint64_t* n_pairs, uint64_t* n_records) {
-	const int rc = region_dispatch(c, mode, f, a0, nA, b0, nB, triangle, part, n_parts, tile_variants, window, l_window, sink, user, n_pairs, n_records);
+	if (c) delivery_begin(c, sink, user);
+	int rc = region_dispatch(c, mode, f, a0, nA, b0, nB, triangle, part, n_parts, tile_variants, window, l_window, sink, user, n_pairs, n_records);
+	if (c) {                                // every record staged so far reaches the sink before the call returns, whatever the call's own result
+		(void)hipSetDevice(c->device);
+		const int drc = delivery_end(c);
+		if (rc == TWK_HIP_OK && drc) { rc = drc; snprintf(c->err, sizeof(c->err), "the record sink failed (or a copy to the host did)"); }
+	}
 	if (c && !c->graveyard.empty()) {       // buffers outgrown during the call (regrow): nothing is in flight any more
 		(void)hipSetDevice(c->device);
 		for (void* p : c->graveyard) (void)hipFree(p);
