@@ -51,3 +51,40 @@ def test_fused_launches_are_logged_by_kind(hip, opt):
     hip.ld_all(T.MODE_UNPHASED, f)
     kinds = [x["kind"] for x in hip.launch_log()[0]]
     assert kinds and set(kinds) == {2, 3, 4} and kinds == sorted(kinds, key=lambda k: {2: 0, 4: 1, 3: 2}[k])
+
+
+def test_delivery_thread_hands_over_the_same_records_in_the_same_order(hip, opt):
+    """Option async_delivery (default 1): a finished launch's sorted survivors are copied aside on the device and a second
+    thread of the engine takes them to the sink while the caller's thread enqueues the next launches.  Same records, same
+    order, same totals as with the caller's thread doing both - for band launches (fused, sampled for their candidate density:
+    the samples' own survivors must not reach the sink), matrix-sized tiles, a window, list / probe passes - and a sink that
+    fails still fails the call, after every launch in front of it was delivered."""
+    import ctypes as C
+    from tomahawk_amd import hip as H
+    N, M = 2504, 1500
+    al = util.mosaic_alleles(M, N, 31, n_founders=10, switch=0.05, mut=0.01)
+    util.upload(hip, al)
+    cases = [(T.MODE_UNPHASED, dict(minR2=0.1), dict()), (T.MODE_UNPHASED, dict(minR2=0.004), dict(window=T.OPT_R2_SCREEN)),
+             (T.MODE_PHASED, dict(minR2=0.02), dict()), (T.MODE_PHASED, dict(minR2=0.0), dict(tile_variants=256)),
+             (T.MODE_AUTO, dict(minR2=0.1), dict(window=T.OPT_WINDOW, l_window=4000))]
+    for mode, fk, kw in cases:
+        got = {}
+        for on in (0, 1):
+            opt.set("async_delivery", on)
+            got[on] = hip.ld_all(mode, T.Filters(**fk), **kw)
+        assert got[0][1:] == got[1][1:] and got[0][2] == len(got[0][0]) > 100
+        assert got[0][0].tobytes() == got[1][0].tobytes()            # the same records in the same order
+    # a failing sink: the call reports it whichever thread ran the sink
+    calls = []
+
+    def bad_sink(_user, recs, n):
+        calls.append(n)
+        return 1 if len(calls) >= 2 else 0
+
+    for on in (0, 1):
+        opt.set("async_delivery", on)
+        del calls[:]
+        cb = H._SINK(bad_sink)
+        f = T.Filters(minR2=0.0)._c()
+        rc = hip._lib.twk_hip_ld_all(hip._ctx, T.MODE_PHASED, C.byref(f), 0, 1, 128, 0, 0, cb, None, None, None)
+        assert rc != 0 and len(calls) >= 2

@@ -221,6 +221,7 @@ struct twk_hip_ctx {
 	// the other kind may be running on the copy stream
 	unsigned long long* d_band_keys = nullptr; uint32_t* d_band_vals = nullptr; unsigned long long band_sort_cap = 0;
 	void* d_band_tmp = nullptr; size_t band_tmp_bytes = 0;
+	std::vector<void*> host_graveyard; // the same for page-locked host buffers
 	std::vector<void*> graveyard;      // device buffers outgrown while launches were in flight: hipFree waits for the device, so they are freed when the call ends
 	twk_hip_timing timing{};
 	std::vector<twk_hip_launch_stat> launch_ring; uint64_t launches_seen = 0;      // the outlier watch's log (twk_hip_launch_log): the last LAUNCH_RING count launches
@@ -424,17 +425,19 @@ int ensure_planes(twk_hip_ctx* c, int set) {
 	return TWK_HIP_OK;
 }
 
+// (Outgrown buffers go to the graveyard - freed when the region call ends, or with the context: hipFree waits for the whole device,
+// every stream, and in the middle of a region's pipeline that was a stall of 50-250 ms a time: profiles/r05_delivery_thread.txt.)
 int ensure_slot(twk_hip_ctx* c, Slot& s, size_t C_words, unsigned long long capacity) {
 	if (s.C_words < C_words) {
-		if (s.C) (void)hipFree(s.C);
+		if (s.C) c->graveyard.push_back(s.C);
 		s.C = nullptr; s.C_words = 0;
 		HIPCHK(c, hipMalloc((void**)&s.C, C_words * 4));
 		s.C_words = C_words;
 	}
 	if (s.capacity < capacity) {
-		if (s.out) (void)hipFree(s.out);
-		if (s.keys) (void)hipFree(s.keys);
-		if (s.vals) (void)hipFree(s.vals);
+		if (s.out) c->graveyard.push_back(s.out);
+		if (s.keys) c->graveyard.push_back(s.keys);
+		if (s.vals) c->graveyard.push_back(s.vals);
 		s.out = nullptr; s.keys = nullptr; s.vals = nullptr; s.capacity = 0;
 		HIPCHK(c, hipMalloc((void**)&s.out, (size_t)capacity * sizeof(twk_hip_record)));
 		HIPCHK(c, hipMalloc((void**)&s.keys, (size_t)capacity * sizeof(unsigned long long)));
@@ -583,8 +586,8 @@ int launch_count(twk_hip_ctx* c, int set, const twk_hip_tile_desc& t, Slot& s, i
 	const size_t fa_words = (sizeof(FusedArgs) + 15) / 16 * 4;
 	const size_t words = words_units + (with_args ? fa_words : 0);               // [... | FusedArgs] for a fused or three-product launch
 	if (s.tiles_cap[which] < words) {
-		if (s.h_tiles[which]) (void)hipHostFree(s.h_tiles[which]);
-		if (s.d_tiles[which]) (void)hipFree(s.d_tiles[which]);
+		if (s.h_tiles[which]) c->host_graveyard.push_back(s.h_tiles[which]);      // (the device copy of the previous launch's table may still be travelling)
+		if (s.d_tiles[which]) c->graveyard.push_back(s.d_tiles[which]);
 		s.h_tiles[which] = s.d_tiles[which] = nullptr; s.tiles_cap[which] = 0;
 		const size_t cap = std::max<size_t>(words, 16384);
 		HIPCHK(c, hipHostMalloc((void**)&s.h_tiles[which], cap * 4, hipHostMallocDefault));
@@ -977,9 +980,9 @@ static_assert(sizeof(twk_hip_record) % 8 == 0, "record gather copies 8-byte word
 int sort_records(twk_hip_ctx* c, const twk_hip_record* recs, unsigned long long* keys_in, uint32_t* vals_in, unsigned long long n, bool any_dropped, hipStream_t st) {
 	if (n > 0xFFFFFFFFull) return TWK_HIP_E_INVALID;
 	if (c->sort_cap < n) {
-		if (c->d_sort_keys) (void)hipFree(c->d_sort_keys);
-		if (c->d_sort_vals) (void)hipFree(c->d_sort_vals);
-		if (c->d_sorted) (void)hipFree(c->d_sorted);
+		if (c->d_sort_keys) c->graveyard.push_back(c->d_sort_keys);       // (not hipFree: it waits for every stream of the device)
+		if (c->d_sort_vals) c->graveyard.push_back(c->d_sort_vals);
+		if (c->d_sorted) c->graveyard.push_back(c->d_sorted);
 		c->d_sort_keys = nullptr; c->d_sort_vals = nullptr; c->d_sorted = nullptr; c->sort_cap = 0;
 		const unsigned long long cap = std::max<unsigned long long>(n + n / 4, 1ull << 16);
 		HIPCHK(c, hipMalloc((void**)&c->d_sort_keys, (size_t)cap * sizeof(unsigned long long)));
@@ -996,7 +999,7 @@ int sort_records(twk_hip_ctx* c, const twk_hip_record* recs, unsigned long long*
 	size_t tmp = 0;
 	HIPCHK(c, rocprim::radix_sort_pairs(nullptr, tmp, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u, end_bit, st));
 	if (!c->d_sort_tmp || tmp > c->sort_tmp_bytes) {          // (a null scratch pointer would turn the sort into another size query)
-		if (c->d_sort_tmp) (void)hipFree(c->d_sort_tmp);
+		if (c->d_sort_tmp) c->graveyard.push_back(c->d_sort_tmp);
 		c->d_sort_tmp = nullptr; c->sort_tmp_bytes = 0;
 		const size_t want = std::max<size_t>(tmp + tmp / 4, 4096);
 		HIPCHK(c, hipMalloc(&c->d_sort_tmp, want));
@@ -1551,6 +1554,8 @@ int twk_hip_ctx_destroy(twk_hip_ctx* c) {
 	if (c->d_band_tmp) (void)hipFree(c->d_band_tmp);
 	for (void* p : c->graveyard) (void)hipFree(p);
 	c->graveyard.clear();
+	for (void* p : c->host_graveyard) (void)hipHostFree(p);
+	c->host_graveyard.clear();
 	if (c->tickets) (void)hipFree(c->tickets);
 	if (c->d_rle) (void)hipFree(c->d_rle);
 	if (c->d_rle_desc) (void)hipFree(c->d_rle_desc);
@@ -1794,6 +1799,17 @@ int twk_hip_get_marginals(twk_hip_ctx* c, uint32_t* ac, uint32_t* n_het, uint32_
 	return TWK_HIP_OK;
 }
 
+// Buffers outgrown during a call (regrow, ensure_slot, sort_records): freed once nothing is in flight any more.
+static void flush_graveyard(twk_hip_ctx* c) {
+	if (c->graveyard.empty() && c->host_graveyard.empty()) return;
+	(void)hipSetDevice(c->device);
+	(void)hipDeviceSynchronize();
+	for (void* p : c->graveyard) (void)hipFree(p);
+	c->graveyard.clear();
+	for (void* p : c->host_graveyard) (void)hipHostFree(p);
+	c->host_graveyard.clear();
+}
+
 int twk_hip_count_tile(twk_hip_ctx* c, int mode, const twk_hip_tile_desc* t, uint64_t* out) {
 	if (!c || !out || (mode != TWK_HIP_MODE_PHASED && mode != TWK_HIP_MODE_UNPHASED)) return TWK_HIP_E_INVALID;
 	if (!c->raw) return TWK_HIP_E_STATE;
@@ -1817,6 +1833,7 @@ int twk_hip_count_tile(twk_hip_ctx* c, int mode, const twk_hip_tile_desc* t, uin
 	if (e == hipSuccess) e = hipMemcpyAsync(out, d_cells, n * 8, hipMemcpyDeviceToHost, c->s_compute);
 	if (e == hipSuccess) e = hipStreamSynchronize(c->s_compute);
 	(void)hipFree(d_cells);
+	flush_graveyard(c);
 	HIPCHK(c, e);
 	return TWK_HIP_OK;
 }
@@ -1830,6 +1847,7 @@ int twk_hip_ld_tile(twk_hip_ctx* c, int mode, const twk_hip_tile_desc* t, const 
 	c->fused_ok = true; c->three_ok = true;
 	unsigned long long n = 0;
 	int rc = run_tile_sync(c, mode, *t, *f, std::max<unsigned long long>(capacity, 1), &n);
+	flush_graveyard(c);
 	*n_out = n;
 	if (n_pairs) *n_pairs = pairs_in_tile(c, *t);
 	if (rc == TWK_HIP_OK && n > capacity) rc = TWK_HIP_E_OVERFLOW;
@@ -2166,11 +2184,7 @@ int twk_hip_ld_region(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint32
 		const int drc = delivery_end(c);
 		if (rc == TWK_HIP_OK && drc) { rc = drc; snprintf(c->err, sizeof(c->err), "the record sink failed (or a copy to the host did)"); }
 	}
-	if (c && !c->graveyard.empty()) {       // buffers outgrown during the call (regrow): nothing is in flight any more
-		(void)hipSetDevice(c->device);
-		for (void* p : c->graveyard) (void)hipFree(p);
-		c->graveyard.clear();
-	}
+	if (c) flush_graveyard(c);               // buffers outgrown during the call: nothing is in flight any more
 	return rc;
 }
 
