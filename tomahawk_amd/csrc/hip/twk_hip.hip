@@ -2092,6 +2092,13 @@ struct RegionRun {
 		std::vector<char> skipped(n, 0);
 		size_t issued = 0, done = 0, math_issued = 0;      // band launches [0, math_issued) have had the second half of their work enqueued
 		int rc = TWK_HIP_OK;
+		// every slot's candidate list at the size of the largest band launch it will hold: growing one between two launches costs an
+		// allocation of gigabytes in the middle of the pipeline (40 ms on the 2,504 x 531,500 run: profiles/r05_delivery_thread.txt)
+		for (int k = 0; k < PIPE_SLOTS && (size_t)k < plan.bands.size(); ++k) {
+			size_t words = 0;
+			for (size_t i = (size_t)k; i < plan.bands.size(); i += PIPE_SLOTS) words = std::max(words, plan.bands[i].list_words);
+			if (words && c->fused_ok) { rc = ensure_slot(c, c->slot[k], words, 1); if (rc) return rc; }
+		}
 		auto issue_next = [&]() -> int {
 			const BandLaunch* b = issued < plan.bands.size() ? &plan.bands[issued] : nullptr;
 			if (b && !c->fused_ok) skipped[issued] = 1;                 // an earlier launch gave the fused form up: this one goes the matrix way when its turn comes
