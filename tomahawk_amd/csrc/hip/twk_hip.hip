@@ -180,7 +180,8 @@ struct Delivery {
 	std::mutex mu; std::condition_variable cv;
 	std::deque<Item> q;              // under mu: in the order of the launches
 	std::vector<Buf> pool;           // under mu: device buffers of the call (freed when it ends)
-	bool stop = false, active = false;
+	bool stop = false, active = false, busy = false;     // busy (under mu): the thread is handing an item over
+	std::condition_variable cv_idle;
 	std::atomic<int> rc{0};          // the first failure (the sink's, a copy's)
 };
 
@@ -189,6 +190,7 @@ struct twk_hip_ctx {
 	Options opt;
 	hipStream_t s_compute = nullptr, s_copy = nullptr, s_deliver = nullptr;      // s_deliver: the delivery thread's copies to the host
 	Delivery dl;
+	bool deliver_warm = false;       // s_deliver has carried a copy (delivery_loop)
 	uint32_t N = 0, M = 0, M_alloc = 0;
 	uint32_t Wp = 0, Wu = 0;       // padded words per row: raw (2N bits) / unphased planes (N bits)
 	uint32_t* raw = nullptr;       // [M_alloc][Wp]
@@ -1109,26 +1111,32 @@ int deliver_records(twk_hip_ctx* c, const twk_hip_record* sorted, unsigned long 
 void delivery_loop(twk_hip_ctx* c) {
 	(void)hipSetDevice(c->device);
 	Delivery& d = c->dl;
+	if (!c->deliver_warm) {          // this thread's and this stream's first copy sets up a queue (tens of milliseconds): now, behind the first launches
+		uint32_t x = 0;
+		if (c->tickets && hipMemcpyAsync(&x, c->tickets, 4, hipMemcpyDeviceToHost, c->s_deliver) == hipSuccess) (void)hipStreamSynchronize(c->s_deliver);
+		c->deliver_warm = true;
+	}
 	for (;;) {
 		Delivery::Item it;
 		{
 			std::unique_lock<std::mutex> lk(d.mu);
 			d.cv.wait(lk, [&] { return d.stop || !d.q.empty(); });
 			if (d.q.empty()) return;
-			it = d.q.front(); d.q.pop_front();
+			it = d.q.front(); d.q.pop_front(); d.busy = true;
 		}
 		int rc = TWK_HIP_OK;
 		if (!d.rc.load()) rc = deliver_records(c, it.p, it.n, it.sink, it.user, c->s_deliver, 0.0);
 		std::lock_guard<std::mutex> lk(d.mu);
 		if (rc && !d.rc.load()) d.rc.store(rc);
-		d.pool[it.buf].busy = false;
+		d.pool[it.buf].busy = false; d.busy = false;
+		if (d.q.empty()) d.cv_idle.notify_all();
 	}
 }
 void delivery_begin(twk_hip_ctx* c, twk_hip_record_sink sink, void* user) {
 	Delivery& d = c->dl;
 	if (d.active || !sink || c->device_sink || !c->opt.async_delivery) return;
 	(void)user; d.stop = false; d.rc.store(0);
-	d.th = std::thread(delivery_loop, c);
+	try { d.th = std::thread(delivery_loop, c); } catch (...) { return; }      // (no thread to be had: the caller's thread delivers, as with the option off)
 	d.active = true;
 }
 // -> the delivery thread's result once everything queued has reached the sink
@@ -1144,6 +1152,14 @@ int delivery_end(twk_hip_ctx* c) {
 	return d.rc.load();
 }
 int discard_records(void*, const twk_hip_record*, uint64_t);
+// everything queued so far has reached its sink (the caller may then hand records over itself, in order: finish_tile does for launches with
+// few survivors, which are not worth a staging copy and a thread hand-off)
+int delivery_drain(twk_hip_ctx* c) {
+	Delivery& d = c->dl;
+	std::unique_lock<std::mutex> lk(d.mu);
+	d.cv_idle.wait(lk, [&] { return d.q.empty() && !d.busy; });
+	return d.rc.load();
+}
 int stage_for_delivery(twk_hip_ctx* c, const twk_hip_record* sorted, unsigned long long kept, twk_hip_record_sink sink, void* user) {
 	Delivery& d = c->dl;
 	if (d.rc.load()) return d.rc.load();
@@ -1240,7 +1256,12 @@ int finish_tile(twk_hip_ctx* c, Slot& s, const twk_hip_tile_desc& t, unsigned lo
 	if (!s.presorted) { rc = sort_records(c, s.out, s.keys, s.vals, n, dropped != 0, c->s_copy); if (rc) return rc; }
 	const twk_hip_record* sorted = s.presorted ? s.sorted : c->d_sorted;      // (a band launch sorted its own behind Fisher's test: enqueue_band_math)
 	*n_out = kept;
-	if (to_host && sink && c->dl.active) return stage_for_delivery(c, sorted, kept, sink, user);      // (the delivery thread takes them to the host: below, deliver_records)
+	if (to_host && sink && c->dl.active) {
+		// many survivors: the delivery thread takes them to the host (deliver_records) while this thread goes on with the launches; few
+		// (a hand-over of a millisecond or two): this thread does, behind whatever is queued
+		if (kept >= HOST_CHUNK / 4 || sink == discard_records) return stage_for_delivery(c, sorted, kept, sink, user);
+		rc = delivery_drain(c); if (rc) return rc;
+	}
 	if (!to_host) {
 		rc = ensure_device_keep(c, kept); if (rc) return rc;
 		if (kept) HIPCHK(c, hipMemcpyAsync(c->d_keep + c->d_keep_n, sorted, (size_t)kept * sizeof(twk_hip_record), hipMemcpyDeviceToDevice, c->s_copy));
@@ -2092,13 +2113,6 @@ struct RegionRun {
 		std::vector<char> skipped(n, 0);
 		size_t issued = 0, done = 0, math_issued = 0;      // band launches [0, math_issued) have had the second half of their work enqueued
 		int rc = TWK_HIP_OK;
-		// every slot's candidate list at the size of the largest band launch it will hold: growing one between two launches costs an
-		// allocation of gigabytes in the middle of the pipeline (40 ms on the 2,504 x 531,500 run: profiles/r05_delivery_thread.txt)
-		for (int k = 0; k < PIPE_SLOTS && (size_t)k < plan.bands.size(); ++k) {
-			size_t words = 0;
-			for (size_t i = (size_t)k; i < plan.bands.size(); i += PIPE_SLOTS) words = std::max(words, plan.bands[i].list_words);
-			if (words && c->fused_ok) { rc = ensure_slot(c, c->slot[k], words, 1); if (rc) return rc; }
-		}
 		auto issue_next = [&]() -> int {
 			const BandLaunch* b = issued < plan.bands.size() ? &plan.bands[issued] : nullptr;
 			if (b && !c->fused_ok) skipped[issued] = 1;                 // an earlier launch gave the fused form up: this one goes the matrix way when its turn comes
