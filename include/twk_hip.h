@@ -222,9 +222,11 @@ int twk_hip_ld_tile(twk_hip_ctx* ctx, int mode, const twk_hip_tile_desc* tile,
  * tile_variants = edge of a super-tile in variants (0 = choose: launches sized
  * by their work where no count matrix is kept, see the "band_launch" switch).
  * Survivors are handed to `sink` (may be NULL to discard) launch by launch, one
- * call at a time, all of them before this function returns - from a second
- * thread of the engine while the calling thread runs the launches (option
- * "async_delivery", default 1; 0: on the calling thread) -
+ * call at a time, all of them before this function returns - launches with
+ * many survivors from a second thread of the engine while the calling thread
+ * goes on with the launches, the others from the calling thread once that
+ * thread has caught up (option "async_delivery", default 1; 0: always the
+ * calling thread) -
  * a launch's survivors in pieces of at most 2^20 records; the
  * records of one sink call are in (idxA, idxB) order (sorted on the device), the
  * pieces of a launch follow each other in that order, and a piece stays valid
