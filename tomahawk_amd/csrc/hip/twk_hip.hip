@@ -1174,7 +1174,12 @@ int stage_for_delivery(twk_hip_ctx* c, const twk_hip_record* sorted, unsigned lo
 	if (at == SIZE_MAX) {
 		twk_hip_record* p = nullptr;
 		const unsigned long long cap = std::max<unsigned long long>(kept + kept / 8, 1ull << 16);
-		HIPCHK(c, hipMalloc((void**)&p, (size_t)cap * sizeof(twk_hip_record)));
+		if (hipMalloc((void**)&p, (size_t)cap * sizeof(twk_hip_record)) != hipSuccess) {
+			// no room for a copy on the device: this thread hands the records over itself, behind what is queued (as with the option off)
+			(void)hipGetLastError();
+			const int rc = delivery_drain(c); if (rc) return rc;
+			return deliver_records(c, sorted, kept, sink, user, c->s_copy, 0.0);
+		}
 		std::lock_guard<std::mutex> lk(d.mu);
 		d.pool.push_back(Delivery::Buf{p, cap, true});
 		at = d.pool.size() - 1;
