@@ -47,12 +47,12 @@ def test_full_size_problem_sampled_against_the_oracle(hip, name, N, M, mode):
         for k in range(10):
             assert np.array_equal(cells[ii[k], jj[k]], counter(rows_a[k], None, rows_b[k], None, N)), (name, a0 + ii[k], b0 + jj[k])
     # records of a far-corner region inside the full problem == the same variants as a problem of their own == the oracle
-    ids = np.concatenate([np.arange(M - 96, M), np.arange(M - 4000, M - 4000 + 64)])          # 160 variants, two clusters
+    ids = np.concatenate([np.arange(M - 96, M), np.arange(M - 4000, M - 4000 + 32)])          # 128 variants, two clusters
     ids.sort()
     f = T.Filters(minR2=0.0)
     a, npa, _ = hip.ld_region(mode, f, M - 96, 96, M - 96, 96, True)
-    b, npb, _ = hip.ld_region(mode, f, M - 4000, 64, M - 96, 96, False)
-    assert npa == 96 * 95 // 2 and npb == 64 * 96
+    b, npb, _ = hip.ld_region(mode, f, M - 4000, 32, M - 96, 96, False)
+    assert npa == 96 * 95 // 2 and npb == 32 * 96
     data = _rows(N, ids)
     variants = _variants(N, ids, data)
     st = O.settings(minR2=0.0, phased=phased, unphased=not phased)
