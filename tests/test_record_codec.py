@@ -168,3 +168,31 @@ def test_blocks_the_encoder_is_not_made_for_go_through_libzstd(tmp_path):
     blk = np.uint32(len(small)).tobytes() * 2 + small.tobytes()
     dst = C.create_string_buffer(z.ZSTD_compressBound(len(blk)))
     assert _roundtrip(z, blk, 106) > 1.5 * z.ZSTD_compress(dst, len(dst), blk, len(blk), 1)
+
+
+def test_randomised_inputs_decode(tmp_path):
+    """300 random inputs: strides 1 .. 400, sizes around one to three blocks, a random mix of segments that repeat the bytes one
+    stride back, flip a few of them, or are noise - so that matches start and end anywhere relative to the 128 KiB block edges,
+    follow each other with no literal between them, and blocks with and without sequences alternate within a frame."""
+    z = _zstd()
+    rng = np.random.default_rng(12)
+    for case in range(300):
+        stride = int(rng.integers(1, 401))
+        n = int(rng.choice([rng.integers(0, 5000), (1 << 17) + rng.integers(-300, 300), 2 * (1 << 17) + rng.integers(-300, 300), rng.integers(1 << 17, 3 << 17)]))
+        a = rng.integers(0, 256, n, dtype=np.uint8)
+        pos = stride
+        while pos < n:
+            seg = int(rng.choice([1, 2, 3, 4, 5, 8, 40, 300, 5000, 140_000]))
+            end = min(n, pos + seg)
+            kind = rng.integers(0, 3)
+            if kind == 0:                                  # equal to the bytes one stride back (propagating: a long match)
+                for q in range(pos, end, stride):
+                    e2 = min(end, q + stride)
+                    a[q:e2] = a[q - stride:e2 - stride]
+            elif kind == 1 and end - pos > 8:              # equal but for a few bytes
+                for q in range(pos, end, stride):
+                    e2 = min(end, q + stride)
+                    a[q:e2] = a[q - stride:e2 - stride]
+                a[rng.integers(pos, end, max(1, (end - pos) // 50))] ^= 0x5A
+            pos = end
+        _roundtrip(z, a.tobytes(), stride)
