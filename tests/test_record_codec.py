@@ -196,3 +196,21 @@ def test_randomised_inputs_decode(tmp_path):
                 a[rng.integers(pos, end, max(1, (end - pos) // 50))] ^= 0x5A
             pos = end
         _roundtrip(z, a.tobytes(), stride)
+
+
+def test_sort_writes_the_same_sorted_file_with_the_record_codec(tmp_path):
+    """`tomahawk sort -c 1048577` (compression level 2^20 + k: the records' encoder, libzstd level k where it does not fit): the sorted
+    records, the blocks and the index (but for the compressed sizes) are those of `-c 1`."""
+    recs = _records(60_000, seed=3)
+    recs = recs[np.random.default_rng(4).permutation(len(recs))]
+    src = str(tmp_path / "in.two")
+    hostlib.write_two(src, recs, n_samples=10)
+    got = {}
+    for level in (1, hostlib.RECORD_CODEC_LEVEL):
+        out = str(tmp_path / f"sorted{level}.two")
+        r = subprocess.run([hostlib.CLI_PATH, "sort", "-i", src, "-o", out, "-c", str(level), "-t", "4"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        back, info = hostlib.read_two(out)
+        state, ent, contigs = hostlib.two_index(out)
+        got[level] = (back.tobytes(), info["n_blocks"], state, ent[:, :5].tolist(), contigs.tolist())
+    assert got[1] == got[hostlib.RECORD_CODEC_LEVEL] and got[1][2] == 2
