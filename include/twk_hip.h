@@ -30,7 +30,8 @@ extern "C" {
  *    its structs in: compare twk_hip_abi_version() with the header it was compiled with. */
 /* 3: twk_hip_set_option / twk_hip_get_option; the library no longer reads environment variables. */
 /* 4: twk_hip_timing grew (three-product launches); option "three". */
-#define TWK_HIP_ABI_VERSION 4
+/* 5: twk_hip_generate_synthetic_planted / twk_synth_planted_bitvector / twk_synth_plant_source (synthetic input with planted LD pairs). */
+#define TWK_HIP_ABI_VERSION 5
 
 enum {
 	TWK_HIP_OK         =  0,
@@ -189,6 +190,29 @@ int twk_hip_generate_synthetic_range(twk_hip_ctx* ctx, uint64_t seed, uint32_t f
 /* Host twin of the device generator: writes variant v's bitvector
  * (ceil(2N/64) words) and returns its ALT allele count. */
 uint32_t twk_synth_bitvector(uint64_t seed, uint32_t n_samples, uint32_t v, uint64_t* out_words);
+
+/* The same input with LD planted in it: iid genotypes have no pair near the default r2 cut-off, so a run over them exercises
+ * neither the recount of screened-in pairs nor the pair math, Fisher's test, the sort and the way out.  With a plant, odd variant
+ * 2k + 1 (k < n_planted; global ids) is a noisy copy of the even variant 2 ((k mult + offset) mod half): every allele of the
+ * source flipped with probability eps_k = max_eps u_k, u_k ~ U[0, 1) from the seed.  Sources are never copies, and with mult
+ * coprime to half no two copies share a source: the data set then holds exactly n_planted pairs in LD - r2 from 1 down to about
+ * (1 - 2 max_eps)^2 - spread over the whole pair triangle (mult large) or at a fixed distance 2 offset - 1 (mult = 1; window
+ * runs), and nothing else above r2 ~ 30 / N.  plant == NULL or n_planted == 0: twk_hip_generate_synthetic_range.
+ * Constraints (else TWK_HIP_E_INVALID): n_planted <= half, mult >= 1, 0 <= max_eps <= 0.5.  `half` describes the GLOBAL data
+ * set (n_variants / 2): the slabs of one data set (first_variant) all pass the same plant and agree on every variant they share.
+ * No reference counterpart (the reference's benchmarks read 1000 Genomes files, docs/tutorial.md:177-199). */
+typedef struct {
+	uint32_t n_planted; /* copies: global variants 1, 3, ..., 2 n_planted - 1                       */
+	uint32_t half;      /* sources are the global variants 2 j, j < half                             */
+	uint32_t mult;      /* j = (k mult + offset) mod half                                            */
+	uint32_t offset;
+	double   max_eps;   /* largest flip probability                                                  */
+} twk_hip_plant;
+int twk_hip_generate_synthetic_planted(twk_hip_ctx* ctx, uint64_t seed, uint32_t first_variant, const twk_hip_plant* plant);
+/* Host twins: global variant v of the planted data set (ceil(2N/64) words; returns its ALT allele count), and whether v is a
+ * copy (returns 1 and its source / flip probability; 0 and *src = v, *eps = 0 otherwise).  Bit-identical to the device. */
+uint32_t twk_synth_planted_bitvector(uint64_t seed, uint32_t n_samples, uint32_t v, const twk_hip_plant* plant, uint64_t* out_words);
+int twk_synth_plant_source(uint64_t seed, const twk_hip_plant* plant, uint32_t v, uint32_t* src, double* eps);
 
 /* Copy back per-variant ALT allele count / het / hom-alt / missing-sample
  * counts as seen by the device (popcounts of the planes).  Any pointer may be

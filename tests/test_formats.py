@@ -24,7 +24,7 @@ def test_c_abi_exports_every_declared_symbol():
     lib = T.load_library()
     for n in names:
         assert hasattr(lib, n), f"libtwk_hip.so does not export {n}"
-    assert lib.twk_hip_abi_version() == 4
+    assert lib.twk_hip_abi_version() == 5
     assert lib.twk_hip_strerror(-4).decode() == "record buffer too small"
 
 

@@ -126,6 +126,44 @@ def test_config5_ten_million_samples_all_modes(hip, ten_million, mode, ph):
             assert np.array_equal(c[i, j], counter(data[i], mi, data[j], mj, N)), (i, j)
 
 
+@pytest.mark.parametrize("min_chunks", [8, 1])
+def test_config5_ten_million_samples_three_product_form(hip, opt, min_chunks):
+    """configs[4]'s sample count without missing genotypes - the planes on which bench.py's extra.cfg5_shard runs the three-product
+    form (k_count3_list_t: rows of 312,500 words, 9,766 K chunks, every tile cut along K and added with atomics): 20 variants from
+    the planted generator (copies next to their sources, flip probabilities from ~0 to 0.45), three = 2 against three = 0 byte for
+    byte and against the oracle, at the default cut-off, at the lowest cut-off the form takes (2e-6; unlinked pairs lie near
+    5e-8 at this N: the noisiest copies pass, nothing else), and as configs[4] specifies it: window + Fisher cut-off."""
+    N, M, seed = 10_000_000, 20, 5
+    plant = T.Plant.near(M, 1, max_eps=0.45)
+    hip.set_problem(N, M)
+    hip.generate_synthetic(seed, plant=plant)
+    data, _ = hip.download()
+    for v in (0, 7, 19):                                   # the device's rows are the host twin's
+        assert np.array_equal(data[v], T.synth_bitvector(seed, N, v, plant)[0]), v
+    variants = np.zeros(M, dtype=O.VARIANT_DTYPE)
+    variants["ac"] = hip.marginals()[0]; variants["pos"] = 1000 + 100 * np.arange(M); variants["hwe"] = 1.0; variants["gt_phase"] = 1
+    vet = util.double_root_vetter(data, None, variants, N)
+    opt.set("count_min_chunks", min_chunks)
+    order = ["idxA", "idxB"]
+    for minR2, minP, W in ((0.1, 1.0, 0), (2e-6, 1.0, 0), (0.05, 1e-6, 400)):
+        st = O.settings(minR2=minR2, minP=minP, unphased=True)
+        want = O.all_pairs(data, None, variants, N, st, vector_only=False)
+        if W:
+            want = _in_window(want, W)
+        f = T.Filters(minR2=minR2, minP=minP)
+        res = {}
+        for three in (0, 2):
+            opt.set("three", three)
+            hip.timing_reset()
+            res[three], _, _ = hip.ld_all(T.MODE_UNPHASED, f, window=T.OPT_WINDOW if W else 0, l_window=W)
+            tm = hip.timing()
+            assert (tm["three_launches"] > 0) == (three == 2) and tm["fused_launches"] == 0, (three, tm)
+        assert np.sort(res[0], order=order).tobytes() == np.sort(res[2], order=order).tobytes(), (minR2, minP, W)
+        assert len(want) == len(res[2]) >= 3, (minR2, len(want), len(res[2]))
+        util.assert_records_match(res[2], want, variants, double_root=vet)
+    opt.unset("three")
+
+
 @pytest.mark.parametrize("tile", [0, 128])
 def test_window_mode_regrouped_rows_straddle_contigs(hip, tile):
     """Default mode + missing data + `-w` on several contigs: the rows of the regrouped rectangle (variants

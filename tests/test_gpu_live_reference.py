@@ -85,6 +85,9 @@ RUNS = [
     ("clean", 1_000_000, 120, 15, 1, ["-u", "-r", "0.01"], None),
     ("mosaic", 1_000_000, 100, 16, 1, ["-r", "0.01"], None),
     ("clean", 1_000_000, 120, 15, 1, ["-p", "-r", "0.01"], None),
+    # ... and with the three-product form of the unphased contraction forced on (the launch sampler keeps to four products on data
+    # this rich in LD): k_count3_list_t + k_screen3_pairs + k_recount_unphased at the headline's row length against the reference itself
+    ("clean", 1_000_000, 120, 15, 1, ["-u", "-r", "0.01", "--engine-option", "three=2"], None),
     # configs[4]'s sample count (counts near 2e7: the int narrowing of Fisher's arguments, its stop-band instability)
     ("clean", 10_000_000, 24, 17, 1, ["-u", "-r", "0.001"], None),
 ]
@@ -98,10 +101,13 @@ def test_cli_equals_the_reference_run_live(tmp_path, kind, N, M, seed, n_contigs
     variants = O.variants_from_alleles(al, pos=pos, rid=rid, phase=1)
     index = {(int(r), int(p)): i for i, (r, p) in enumerate(zip(rid, pos))}
     ref_two, my_two = str(tmp_path / "ref.two"), str(tmp_path / "mine.two")
-    O.run_ref(["calc", "-i", twk, "-o", ref_two, "-t", "4"] + flags, stdin=subprocess.DEVNULL)
+    ref_flags = [x for i, x in enumerate(flags) if x != "--engine-option" and (i == 0 or flags[i - 1] != "--engine-option")]      # (the engine's own switch)
+    O.run_ref(["calc", "-i", twk, "-o", ref_two, "-t", "4"] + ref_flags, stdin=subprocess.DEVNULL)
     r = subprocess.run([hostlib.CLI_PATH, "calc", "-i", twk, "-o", my_two] + flags, capture_output=True, text=True,
                        env=dict(os.environ, **(env or {})))
     assert r.returncode == 0, r.stderr
+    if "three=2" in flags:
+        assert "launches in the three-product form" in r.stderr, r.stderr[-600:]
     want, n_ref = _forward_records(ref_two, index)
     got, n_mine = _forward_records(my_two, index)
     assert len(want) > 50, "the case produces too few records to mean anything"

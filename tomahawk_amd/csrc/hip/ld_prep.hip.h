@@ -40,20 +40,44 @@ __host__ __device__ __forceinline__ uint32_t synth_sample_bits(uint64_t seed, ui
 	return ((uint32_t)x < thr ? 1u : 0u) | ((uint32_t)(x >> 32) < thr ? 2u : 0u);
 }
 
+// Planted LD (twk_hip_plant, include/twk_hip.h): odd variant 2k + 1, k < n_planted, is not drawn by itself but is a noisy copy of
+// the even variant 2 ((k mult + offset) mod half) - every allele of the source flipped with probability eps_k = max_eps u_k,
+// u_k ~ U[0, 1) from the seed.  Sources are never copies themselves and (mult coprime with half) no two copies share one, so the
+// data set holds exactly n_planted variant pairs in LD - from r2 = 1 (eps 0) down to (1 - 2 eps)^2 x a ratio of the heterozygosities -
+// in a sea of unlinked variants.  Shared by the device generator and its host twin.
+struct SynthPlant { uint32_t n_planted, half, mult, offset; uint32_t eps_scale; };      // eps_scale: max_eps as a 32-bit fraction
+// -> true when global variant gv is a copy: its source and the 32-bit threshold of its flips
+__host__ __device__ __forceinline__ bool synth_plant_source(uint64_t seed, const SynthPlant& pl, uint32_t gv, uint32_t& src, uint32_t& eps_thr) {
+	if (!(gv & 1u) || (gv >> 1) >= pl.n_planted || pl.half == 0) return false;
+	const uint32_t k = gv >> 1;
+	src = 2u * (uint32_t)(((uint64_t)k * pl.mult + pl.offset) % pl.half);
+	const uint64_t u = mix64(seed ^ (0xA24BAED4963EE407ull * (uint64_t)(k + 1))) >> 32;      // 32 bits
+	eps_thr = (uint32_t)((u * (uint64_t)pl.eps_scale) >> 32);
+	return true;
+}
+// the flips of sample s of copy gv: low / high half of one 64-bit draw, like the alleles themselves
+__host__ __device__ __forceinline__ uint32_t synth_flip_bits(uint64_t seed, uint32_t gv, uint32_t s, uint32_t eps_thr) {
+	const uint64_t key = mix64(seed ^ (0x9FB21C651E98DF25ull * (uint64_t)(gv + 1)));
+	const uint64_t x = mix64(key + s);
+	return ((uint32_t)x < eps_thr ? 1u : 0u) | ((uint32_t)(x >> 32) < eps_thr ? 2u : 0u);
+}
+
 // Synthetic genotypes straight into the raw layout: one thread per 32-bit word
 // (16 samples).  raw[v * Wp + w].
 __global__ void k_synth(uint32_t* __restrict__ raw, uint32_t Wp, uint32_t n_samples, uint32_t n_variants,
-                        uint64_t seed, uint32_t first_variant) {
+                        uint64_t seed, uint32_t first_variant, SynthPlant plant) {
 	const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
 	if (w >= Wp) return;
 	for (uint32_t v = blockIdx.y; v < n_variants; v += gridDim.y) {     // grid.y is capped at 65535
 		const uint32_t gv = first_variant + v;                           // global variant id
-		const uint32_t thr = synth_threshold(seed, gv);
+		uint32_t src = gv, eps_thr = 0;
+		const bool copy = synth_plant_source(seed, plant, gv, src, eps_thr);
+		const uint32_t thr = synth_threshold(seed, src);
 		uint32_t word = 0;
 		const uint32_t s0 = w * 16;
 		for (uint32_t i = 0; i < 16; ++i) {
 			const uint32_t s = s0 + i;
-			if (s < n_samples) word |= synth_sample_bits(seed, gv, s, thr) << (2 * i);
+			if (s < n_samples) word |= (synth_sample_bits(seed, src, s, thr) ^ (copy ? synth_flip_bits(seed, gv, s, eps_thr) : 0u)) << (2 * i);
 		}
 		raw[(size_t)v * Wp + w] = word;
 	}

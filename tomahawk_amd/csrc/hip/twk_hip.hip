@@ -1753,17 +1753,30 @@ int twk_hip_download_bitvectors(twk_hip_ctx* c, uint32_t first, uint32_t count, 
 	return TWK_HIP_OK;
 }
 
-int twk_hip_generate_synthetic(twk_hip_ctx* c, uint64_t seed) { return twk_hip_generate_synthetic_range(c, seed, 0); }
+int twk_hip_generate_synthetic(twk_hip_ctx* c, uint64_t seed) { return twk_hip_generate_synthetic_planted(c, seed, 0, nullptr); }
+int twk_hip_generate_synthetic_range(twk_hip_ctx* c, uint64_t seed, uint32_t first_variant) { return twk_hip_generate_synthetic_planted(c, seed, first_variant, nullptr); }
 
-int twk_hip_generate_synthetic_range(twk_hip_ctx* c, uint64_t seed, uint32_t first_variant) {
+// twk_hip_plant -> the generator's own form (max_eps as a 32-bit fraction); false: out of range
+static bool plant_of(const twk_hip_plant* p, SynthPlant& out) {
+	out = SynthPlant{0, 0, 1, 0, 0};
+	if (!p || p->n_planted == 0) return true;
+	if (p->n_planted > p->half || p->mult == 0 || !(p->max_eps >= 0.0 && p->max_eps <= 0.5)) return false;
+	out.n_planted = p->n_planted; out.half = p->half; out.mult = p->mult; out.offset = p->offset;
+	out.eps_scale = (uint32_t)(p->max_eps * 4294967296.0);
+	return true;
+}
+
+int twk_hip_generate_synthetic_planted(twk_hip_ctx* c, uint64_t seed, uint32_t first_variant, const twk_hip_plant* plant) {
 	if (!c) return TWK_HIP_E_INVALID;
 	if ((uint64_t)first_variant + (c ? c->M : 0) > 0xFFFFFFFFull) return TWK_HIP_E_INVALID;
+	SynthPlant pl;
+	if (!plant_of(plant, pl)) return TWK_HIP_E_INVALID;
 	if (!c->raw) return TWK_HIP_E_STATE;
 	HIPCHK(c, hipSetDevice(c->device));
 	free_planes(c);
 	if (c->rawmask) { (void)hipFree(c->rawmask); c->rawmask = nullptr; }
 	c->any_missing = false;
-	hipLaunchKernelGGL(k_synth, dim3((c->Wp + 255) / 256, std::min<uint32_t>(c->M, 65535u)), dim3(256), 0, c->s_compute, c->raw, c->Wp, c->N, c->M, seed, first_variant);
+	hipLaunchKernelGGL(k_synth, dim3((c->Wp + 255) / 256, std::min<uint32_t>(c->M, 65535u)), dim3(256), 0, c->s_compute, c->raw, c->Wp, c->N, c->M, seed, first_variant, pl);
 	HIPCHK(c, hipGetLastError());
 	// metadata: ac = popcount, pos = 1000 + 100 v, one contig, hwe = 1
 	hipLaunchKernelGGL(k_row_popcount, dim3((c->M + 3) / 4), dim3(256), 0, c->s_compute, c->raw, c->Wp, c->M, c->d_ac);
@@ -1786,16 +1799,33 @@ int twk_hip_generate_synthetic_range(twk_hip_ctx* c, uint64_t seed, uint32_t fir
 }
 
 uint32_t twk_synth_bitvector(uint64_t seed, uint32_t n_samples, uint32_t v, uint64_t* out_words) {
+	return twk_synth_planted_bitvector(seed, n_samples, v, nullptr, out_words);
+}
+
+uint32_t twk_synth_planted_bitvector(uint64_t seed, uint32_t n_samples, uint32_t v, const twk_hip_plant* plant, uint64_t* out_words) {
 	const size_t w64 = ((size_t)2 * n_samples + 63) / 64;
 	std::memset(out_words, 0, w64 * 8);
-	const uint32_t thr = synth_threshold(seed, v);
+	SynthPlant pl;
+	if (!plant_of(plant, pl)) return 0;
+	uint32_t src = v, eps_thr = 0;
+	const bool copy = synth_plant_source(seed, pl, v, src, eps_thr);
+	const uint32_t thr = synth_threshold(seed, src);
 	uint32_t ac = 0;
 	for (uint32_t s = 0; s < n_samples; ++s) {
-		const uint64_t bits = synth_sample_bits(seed, v, s, thr);
+		const uint64_t bits = synth_sample_bits(seed, src, s, thr) ^ (copy ? synth_flip_bits(seed, v, s, eps_thr) : 0u);
 		out_words[(2ull * s) >> 6] |= bits << ((2ull * s) & 63);
 		ac += (uint32_t)(bits & 1) + (uint32_t)(bits >> 1);
 	}
 	return ac;
+}
+
+int twk_synth_plant_source(uint64_t seed, const twk_hip_plant* plant, uint32_t v, uint32_t* src, double* eps) {
+	SynthPlant pl;
+	uint32_t s = v, thr = 0;
+	const bool copy = plant_of(plant, pl) && synth_plant_source(seed, pl, v, s, thr);
+	if (src) *src = copy ? s : v;
+	if (eps) *eps = copy ? (double)thr / 4294967296.0 : 0.0;
+	return copy ? 1 : 0;
 }
 
 int twk_hip_get_marginals(twk_hip_ctx* c, uint32_t* ac, uint32_t* n_het, uint32_t* n_hom, uint32_t* n_miss) {

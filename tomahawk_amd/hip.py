@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libtwk_hip.so")
 
-ABI_VERSION = 4                 # TWK_HIP_ABI_VERSION of include/twk_hip.h (struct layouts below)
+ABI_VERSION = 5                 # TWK_HIP_ABI_VERSION of include/twk_hip.h (struct layouts below)
 MODE_PHASED, MODE_UNPHASED, MODE_AUTO = 1, 2, 3
 # option bits of twk_hip_tile_desc.window / the `window` argument of ld_all / ld_region (TWK_HIP_OPT_*)
 OPT_WINDOW, OPT_KEEP_LOW_AC, OPT_REF_COMPAT, OPT_R2_SCREEN = 1, 2, 4, 8
@@ -94,6 +94,23 @@ def plan_region(meta, n_samples, a0, nA, b0, nB, triangle=True, part=0, n_parts=
     return dict(tiles=tiles[:n_tiles.value], n_band_launches=n_bands.value, row_begin=r0.value, row_end=r1.value, n_pairs=pairs.value, lo=lo, hi=hi)
 
 
+class Plant(C.Structure):            # twk_hip_plant: LD planted in the synthetic input (include/twk_hip.h)
+    _fields_ = [("n_planted", C.c_uint32), ("half", C.c_uint32), ("mult", C.c_uint32), ("offset", C.c_uint32), ("max_eps", C.c_double)]
+
+    @classmethod
+    def spread(cls, n_variants: int, n_planted: int | None = None, max_eps: float = 0.3, mult: int = 1_000_003, offset: int = 12_345):
+        """Copies whose sources are spread over the whole data set (mult is prime: coprime with any half below it)."""
+        half = n_variants // 2
+        return cls(half if n_planted is None else n_planted, half, mult, offset % max(half, 1), max_eps)
+
+    @classmethod
+    def near(cls, n_variants: int, distance: int, n_planted: int | None = None, max_eps: float = 0.3):
+        """Copies at a fixed odd distance in front of their sources (window runs): copy 2k + 1 <- source 2k + 1 + distance."""
+        assert distance % 2 == 1
+        half = n_variants // 2
+        return cls(half if n_planted is None else n_planted, half, 1, (distance + 1) // 2, max_eps)
+
+
 class _LaunchStat(C.Structure):      # twk_hip_launch_stat
     _fields_ = [("ms", C.c_double), ("shader_mhz", C.c_double), ("xcd_finish_spread_us", C.c_double), ("row_pairs", C.c_uint64),
                 ("candidates", C.c_uint64), ("words_per_row", C.c_uint32), ("kind", C.c_uint32), ("outlier", C.c_uint32), ("_pad", C.c_uint32)]
@@ -151,6 +168,10 @@ def load_library() -> C.CDLL:
     lib.twk_hip_generate_synthetic_range.argtypes = [p, C.c_uint64, C.c_uint32]
     lib.twk_synth_bitvector.restype = C.c_uint32
     lib.twk_synth_bitvector.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, p]
+    lib.twk_hip_generate_synthetic_planted.argtypes = [p, C.c_uint64, C.c_uint32, C.POINTER(Plant)]
+    lib.twk_synth_planted_bitvector.restype = C.c_uint32
+    lib.twk_synth_planted_bitvector.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(Plant), p]
+    lib.twk_synth_plant_source.argtypes = [C.c_uint64, C.POINTER(Plant), C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
     lib.twk_hip_get_marginals.argtypes = [p, p, p, p, p]
     lib.twk_hip_count_tile.argtypes = [p, C.c_int, C.POINTER(_Tile), p]
     lib.twk_hip_ld_tile.argtypes = [p, C.c_int, C.POINTER(_Tile), C.POINTER(_Filters), p, C.c_uint64,
@@ -194,11 +215,19 @@ def words64(n_samples: int) -> int:
     return (2 * n_samples + 63) // 64
 
 
-def synth_bitvector(seed: int, n_samples: int, v: int) -> tuple[np.ndarray, int]:
-    """Host twin of the device generator (twk_synth_bitvector)."""
+def synth_bitvector(seed: int, n_samples: int, v: int, plant: "Plant | None" = None) -> tuple[np.ndarray, int]:
+    """Host twin of the device generator (twk_synth_bitvector / twk_synth_planted_bitvector)."""
     out = np.zeros(words64(n_samples), dtype=np.uint64)
-    ac = load_library().twk_synth_bitvector(seed, n_samples, v, out.ctypes.data)
+    ac = load_library().twk_synth_planted_bitvector(seed, n_samples, v, None if plant is None else C.byref(plant), out.ctypes.data)
     return out, int(ac)
+
+
+def plant_source(seed: int, plant: "Plant", v: int):
+    """-> (source variant, flip probability) when global variant v is a planted copy, else None (twk_synth_plant_source)."""
+    src, eps = C.c_uint32(0), C.c_double(0.0)
+    if load_library().twk_synth_plant_source(seed, C.byref(plant), v, C.byref(src), C.byref(eps)):
+        return int(src.value), float(eps.value)
+    return None
 
 
 class HipLd:
@@ -291,10 +320,10 @@ class HipLd:
                     "twk_hip_download_bitvectors")
         return data, mask
 
-    def generate_synthetic(self, seed: int = 42, first_variant: int = 0):
-        """Synthetic benchmark input for global variants [first_variant, first_variant + n_variants)."""
-        self._check(self._lib.twk_hip_generate_synthetic_range(self._ctx, seed, first_variant),
-                    "twk_hip_generate_synthetic_range")
+    def generate_synthetic(self, seed: int = 42, first_variant: int = 0, plant: "Plant | None" = None):
+        """Synthetic benchmark input for global variants [first_variant, first_variant + n_variants); plant: LD pairs planted in it."""
+        self._check(self._lib.twk_hip_generate_synthetic_planted(self._ctx, seed, first_variant, None if plant is None else C.byref(plant)),
+                    "twk_hip_generate_synthetic_planted")
 
     def marginals(self):
         M = self.n_variants
