@@ -186,7 +186,7 @@ def measure_traffic(config_args, log):
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="twk_pmc_")
         cmd = [rocprof, "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
-               "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-e2e", "--no-traffic", "--no-extra"] + config_args
+               "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-e2e", "--no-traffic", "--no-extra", "--no-planted"] + config_args
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=tempfile.gettempdir(), env=dict(os.environ, TMPDIR=tempfile.gettempdir()))
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
@@ -517,6 +517,7 @@ def main():
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 counter passes behind roofline.traffic (N=1)")
     ap.add_argument("--no-extra", action="store_true", help="skip the other regimes reported under \"extra\" (N=1, cfg3): configs[1], a "
                     "configs[4] shard, calc -u from disk, the reference's published 2,504 x 531,500 runs")
+    ap.add_argument("--no-planted", action="store_true", help="skip the survivor-bearing steps on the same problem with planted LD that follow the timed region (extra.<config>_planted)")
     ap.add_argument("--no-gather-check", action="store_true", help="skip the survivor-rich gather self-check that follows the timed region when N > 1")
     ap.add_argument("--e2e-variants", type=int, default=0, help="variants of the e2e input (0: the config's own count)")
     ap.add_argument("--engine-option", action="append", default=[], metavar="KEY=INT", help="a switch of the engine "
@@ -620,6 +621,7 @@ def main():
                                  n_threads=min(os.cpu_count() or 1, 32))
 
     written = {"records": 0}
+    last = {"recs": None}
     phase = {"compute": 0.0, "gather": 0.0, "write": 0.0,       # seconds, this rank, summed over the timed steps
              "xfer": 0.0, "xfer_bytes": 0}                      # rank 0: the transfers alone (after every rank has arrived) and their bytes
 
@@ -653,6 +655,7 @@ def main():
         if rank == 0:
             stream.append(recs)
             written["records"] += stream.close()
+            last["recs"] = recs            # (rank 0: every rank's survivors of this step, as the writer saw them)
         t_d = time.perf_counter()
         phase["compute"] += t_b - t_a; phase["gather"] += t_c - t_b; phase["write"] += t_d - t_c
         return npairs, nrec
@@ -677,7 +680,6 @@ def main():
         import shutil
         if args.keep_two and args.steps:
             shutil.copyfile(os.path.join(out_dir, f"step{args.steps - 1}.two"), args.keep_two)
-        shutil.rmtree(out_dir, ignore_errors=True)
     tm = eng.timing()
     spread = launch_spread(eng)
 
@@ -703,6 +705,96 @@ def main():
         except Exception as e:           # a failed check is reported, on every rank alike, not hidden
             gcheck = {"equal": False, "error": repr(e)[:300]} if rank == 0 else None
             log(f"gather_check failed: {e!r}")
+    def planted_leg():
+        """A survivor-bearing step of the SAME problem under the same clock (since round 1 the timed region has had 0 survivors: iid
+        genotypes hold no pair near r2 = 0.1): the input regenerated in place with LD planted in it (twk_hip_plant: every odd variant a
+        noisy copy of an even one, flip probability 0 .. 0.4 - r2 from 1 down to below the cut-off; n_variants / 2 pairs spread over
+        the triangle, or 7 variants apart in window runs), one warm-up + two steps through the same step() - count, screen, recount of
+        the candidates' four products, UnphasedMath, Fisher, sort, copy-back (N > 1: gather), .two writer - and one more step in the
+        four-product form, which screens nothing on (HH, S): every pair's full table goes through the math.  Self-check: the survivors of
+        the two forms are the same bytes, every survivor is a planted pair, and planted_found == planted_expected (the planted pairs the
+        four-product step kept).  The ORACLE's verdict on this very data set (same generator, seed and plant) is
+        tests/test_gpu_full_size.py::test_three_product_form_at_the_headline_size_against_the_oracle."""
+        plant = T.Plant.near(n_variants, 7, max_eps=0.4) if window_bp else T.Plant.spread(n_variants, max_eps=0.4)
+        t_g = time.perf_counter()
+        eng.generate_synthetic(args.seed, first_variant=slab[0] if slab else 0, plant=plant)
+        gen_s = time.perf_counter() - t_g
+
+        def run(n_steps, tag):
+            for k in phase:
+                phase[k] = 0
+            written["records"] = 0
+            streams = [open_stream(f"{tag}{i}") for i in range(n_steps)]
+            barrier()
+            eng.timing_reset()
+            t_s = time.perf_counter()
+            pr = rc = 0
+            for i in range(n_steps):
+                p_, r_ = step(streams[i])
+                pr += p_; rc += r_
+            barrier()
+            el = time.perf_counter() - t_s
+            st = torch.tensor([el, float(pr), float(rc)], dtype=torch.float64)
+            if world > 1:
+                mx = st.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+                dist.all_reduce(st, op=dist.ReduceOp.SUM)
+                st[0] = mx[0]
+            return float(st[0]), int(round(float(st[1]))), int(round(float(st[2]))), eng.timing(), dict(phase), last["recs"]
+
+        step(open_stream("pw"))                                   # warm-up: plane set rebuilt from the new rows
+        el3, pairs3, recs3, tm3, ph3, r3 = run(2, "p")
+        eng.set_option("three", 0)
+        el4, pairs4, recs4, tm4, ph4, r4 = run(1, "q")
+        eng.unset_option("three")
+        if rank != 0:
+            return None
+        key = lambda r: set(zip(r["idxA"].tolist(), r["idxB"].tolist())) if r is not None and len(r) else set()
+        k3, k4 = key(r3), key(r4)
+        planted = {}
+        for v in range(1, 2 * plant.n_planted, 2):
+            src, eps = T.plant_source(args.seed, plant, v)
+            if max(src, v) < n_variants:
+                planted[(min(src, v), max(src, v))] = eps
+        found, expected = k3 & set(planted), k4 & set(planted)
+        order = ["idxA", "idxB"]
+        same = (r3 is not None and r4 is not None and len(r3) == len(r4)
+                and np.sort(np.asarray(r3), order=order).tobytes() == np.sort(np.asarray(r4), order=order).tobytes())
+        missed = [e for kk, e in planted.items() if kk not in found]
+        products, ors, kernel, form = executed_work(tm3)
+        k_s = tm3["count_ms"] * 1e-3
+        res = {"workload": f"the headline's problem with LD planted in it: {plant.n_planted} noisy copies (flip probability 0 .. {plant.max_eps:g}, "
+                           + ("7 variants from their sources" if window_bp else "sources spread over the whole data set") + f"), same filters, 1 warm-up + 2 steps through the timed region's step()",
+               "steps": 2, "warmup": 1, "generate_s": gen_s, "pairs_per_step": pairs3 // 2, "value": pairs3 / el3, "unit": "variant-pairs/s",
+               "ms_per_step": el3 / 2 * 1e3, "survivors_per_step": recs3 / 2, "two_records_written_per_step": written["records"] if False else None,
+               "dominant_kernel": kernel, "form": form,
+               "count_kernel_ms_per_step": tm3["count_ms"] / 2, "count_launches_per_step": tm3["count_launches"] / 2,
+               "three_product_launches": int(tm3["three_launches"]), "recounted_candidates_per_step": tm3["recount_candidates"] / 2,
+               # rank 0's engine, per step: recount + UnphasedMath + Fisher (HIP events: from the count kernel's end to the end of Fisher's walks),
+               # and the host's wall from a finished launch to its records' hand-over (device sort, copy-back, the sink)
+               "math_kernels_ms_per_step": tm3["stats_ms"] / 2, "sort_copyback_sink_ms_per_step": tm3.get("finish_ms", 0.0) / 2,
+               "compute_ms_per_step": ph3["compute"] / 2 * 1e3, "gather_ms_per_step": ph3["gather"] / 2 * 1e3, "write_ms_per_step": ph3["write"] / 2 * 1e3,
+               "gather_bytes_per_step": ph3["xfer_bytes"] / 2, "gather_GBps": (ph3["xfer_bytes"] / ph3["xfer"] / 1e9) if ph3["xfer"] > 0 and ph3["xfer_bytes"] else None,
+               "executed_frac_of_issue_ceiling": (products + ors / 3.0) / k_s / VALU_PAIR_PEAK if k_s > 0 else None,
+               "four_product_step": {"ms_per_step": el4 * 1e3, "value": pairs4 / el4, "survivors": recs4, "count_kernel_ms": tm4["count_ms"],
+                                     "math_kernels_ms": tm4["stats_ms"], "three_product_launches": int(tm4["three_launches"]),
+                                     "executed_frac_of_and_bcnt_ceiling": (executed_work(tm4)[0] / (tm4["count_ms"] * 1e-3) / VALU_PAIR_PEAK) if tm4["count_ms"] > 0 else None},
+               "planted_pairs": len(planted), "planted_found": len(found), "planted_expected": len(expected),
+               "survivors_not_planted": len(k3 - set(planted)), "records_equal_four_product": bool(same),
+               "largest_flip_probability_found": max((planted[kk] for kk in found), default=None),
+               "smallest_flip_probability_missed": min(missed, default=None),
+               "self_check": bool(same and found == expected and len(found) > 0 and (filters.minR2 < 0.01 or not (k3 - set(planted)))),
+               "self_check_note": "planted_expected = planted pairs among the survivors of the four-product step (no (HH, S) screen); records compared byte for byte; "
+                                  "the oracle's check of this data set: tests/test_gpu_full_size.py"}
+        del res["two_records_written_per_step"]
+        log(f"planted: {res['ms_per_step']:.1f} ms/step, {res['survivors_per_step']:.0f} survivors, found {len(found)} of {len(expected)} expected, "
+            f"equal to four products: {same}; four-product step {el4 * 1e3:.1f} ms")
+        return res
+
+    planted = None
+    if not args.no_planted and args.steps > 0:
+        planted = planted_leg()
+    if rank == 0:
+        shutil.rmtree(out_dir, ignore_errors=True)
     elapsed_max, count_ms_max, stats_ms_max = (float(x) for x in stats.tolist())
     pairs_all, recs_all, launches_all, row_pairs_all = (float(x) for x in sums.tolist())
     if not args.emulate_shard:
@@ -784,6 +876,8 @@ def main():
         }
         if gcheck is not None:
             out["extra"] = {"gather_check": gcheck}
+        if planted is not None:
+            out.setdefault("extra", {})[f"{args.config}_planted"] = planted
         if world == 1 and not args.no_cpu_baseline:
             try:
                 cb = cpu_baseline(n_samples, mode, args.seed, log)
@@ -830,9 +924,8 @@ def main():
             # Every other regime the repository makes claims about, under the same clock as the headline (after the timed
             # region, like cpu_baseline / e2e): each with its pairs/s, dominant kernel, average launch and roofline fraction.
             eng.close()
-            extra = {}
-            for name, fn in (("cfg3_four_product", lambda: extra_in_process("cfg3", log, steps=2, warmup=1, options=(("three", 0),))),
-                             ("cfg2", lambda: extra_in_process("cfg2", log, steps=20, warmup=3)),
+            extra = out.get("extra", {})
+            for name, fn in (("cfg2", lambda: extra_in_process("cfg2", log, steps=20, warmup=3)),
                              ("cfg5_shard", lambda: extra_in_process("cfg5", log, steps=1, warmup=1, emulate_shard=(3, 8))),
                              ("e2e_u", lambda: e2e_from_disk(n_samples, args.e2e_variants or n_variants, log, flags=("-u",), tag="e2e_u")),
                              ("kg", lambda: extra_kg(log))):

@@ -414,6 +414,9 @@ typedef struct {
 	                                 AND+popcounts row_pairs x words_per_row stands for, plus 6 v_or per 24 of them */
 	uint64_t recount_candidates;  /* pairs that passed the three-product screen and had their four products counted afresh */
 	uint64_t outlier_launches;    /* count launches the outlier watch flagged (twk_hip_launch_log)                          */
+	double   finish_ms;           /* (ABI 5) the calling thread's wall time between a launch's last kernel and the hand-over of its
+	                                 records: device sort, copy to the host, the sink (launches the delivery thread takes: up to
+	                                 their copy aside on the device) - summed over the launches                              */
 } twk_hip_timing;
 /* Progress of twk_hip_ld_all / twk_hip_ld_region: `cb` runs on the calling thread after every tile
  * with the variant pairs finished so far in the current call and the tile counts.  Replaces the

@@ -569,7 +569,15 @@ def test_bench_with_eight_ranks_on_one_gpu_equals_one_rank(tmp_path, config, ext
     assert gc["equal"] is True and gc["equal_per_rank"] == [True] * 8 and gc["ranks_seen"] == list(range(8)), gc
     assert gc["records"] == sum(gc["records_per_rank"]) > 10_000 and gc["bytes"] == 104 * (gc["records"] - gc["records_per_rank"][0]) and gc["GBps"] > 0
     assert gc["pairs"] == 4096 * 4095 // 2 and gc["wall_s"] < 20 and gc["backend"] == "gloo"
-    assert "extra" not in d1
+    assert "gather_check" not in d1.get("extra", {})
+    # the survivor-bearing steps on the same problem with planted LD (extra.<config>_planted): same pairs found by one rank and by eight,
+    # the three-product form's records the four-product form's, and the eight ranks' survivors went through the gather
+    p1, p8 = d1["extra"][f"{config}_planted"], d8["extra"][f"{config}_planted"]
+    for pp in (p1, p8):
+        assert pp["records_equal_four_product"] is True and pp["planted_found"] == pp["planted_expected"] > 100, pp
+        assert pp["four_product_step"]["three_product_launches"] == 0
+    assert p1["planted_found"] == p8["planted_found"] and p1["survivors_per_step"] == p8["survivors_per_step"] > 0
+    assert p8["gather_bytes_per_step"] > 0 and p1["gather_bytes_per_step"] == 0
     assert d1["config"]["survivors_per_step"] == d8["config"]["survivors_per_step"] > 1000
     assert len(one) == len(eight) == 2 * d1["config"]["survivors_per_step"]
     order = ["ridA", "packA", "ridB", "packB"]

@@ -1203,6 +1203,10 @@ int finish_tile(twk_hip_ctx* c, Slot& s, const twk_hip_tile_desc& t, unsigned lo
 	auto since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
 	HIPCHK(c, hipEventSynchronize(s.ev_s1));
 	const double tl_wait = since(tl0);
+	struct FinishClock {          // timing.finish_ms: from here to whichever return hands the records on
+		twk_hip_ctx* c; std::chrono::steady_clock::time_point t0;
+		~FinishClock() { c->timing.finish_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+	} finish_clock{c, std::chrono::steady_clock::now()};
 	float ms = 0;
 	HIPCHK(c, hipEventElapsedTime(&ms, s.ev_c0, s.ev_c1));
 	if (!s.is_list) watch_launch(c, s, ms, t);

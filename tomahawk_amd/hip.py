@@ -54,7 +54,7 @@ class _Timing(C.Structure):
                 ("probe_ms", C.c_double), ("probe_launches", C.c_uint64), ("probe_pairs", C.c_uint64),
                 ("count_shader_cycles", C.c_uint64), ("count_wall_ticks", C.c_uint64),
                 ("three_launches", C.c_uint64), ("three_row_pairs", C.c_uint64), ("recount_candidates", C.c_uint64),
-                ("outlier_launches", C.c_uint64)]
+                ("outlier_launches", C.c_uint64), ("finish_ms", C.c_double)]
 
 
 class _PlanEnv(C.Structure):         # twk_hip_plan_env
@@ -98,9 +98,13 @@ class Plant(C.Structure):            # twk_hip_plant: LD planted in the syntheti
     _fields_ = [("n_planted", C.c_uint32), ("half", C.c_uint32), ("mult", C.c_uint32), ("offset", C.c_uint32), ("max_eps", C.c_double)]
 
     @classmethod
-    def spread(cls, n_variants: int, n_planted: int | None = None, max_eps: float = 0.3, mult: int = 1_000_003, offset: int = 12_345):
-        """Copies whose sources are spread over the whole data set (mult is prime: coprime with any half below it)."""
+    def spread(cls, n_variants: int, n_planted: int | None = None, max_eps: float = 0.3, mult: int = 2_654_435_761, offset: int = 12_345):
+        """Copies whose sources are scattered over the whole data set: j = (k mult + offset) mod half with the golden-ratio prime
+        2^32 / phi - coprime with every half it does not divide, and far from a small multiple of any half in sight, so that
+        neighbouring copies have sources far apart."""
+        import math
         half = n_variants // 2
+        assert half < 2 or math.gcd(mult, half) == 1, (mult, half)
         return cls(half if n_planted is None else n_planted, half, mult, offset % max(half, 1), max_eps)
 
     @classmethod
