@@ -88,14 +88,17 @@ def executed_work(tm):
     words = tm["words_per_row"]
     four = (tm["row_pairs"] - tm["three_row_pairs"]) * words
     three = tm["three_row_pairs"] * words * 0.75
+    wide = tm.get("three_wide_row_pairs", 0) * words * 0.75        # ... of them on the wide lane tile: one v_or per six products instead of one per four
     kernel = "twk::k_count_list_t"
     form = "four products per pair (HH, HQ, QH, QQ)"
     if tm["three_launches"]:
-        kernel = "twk::k_count3_list_t" if not tm["fused_launches"] else "twk::k_count3_screen_unphased_t"
+        kernel = ("twk::k_count3w_list_t" if wide else "twk::k_count3_list_t") if not tm["fused_launches"] else "twk::k_count3_screen_unphased_t"
         form = "three products per pair (HH and S = QH + HQ + 2 QQ; the four products of screened-in pairs recounted)"
         if tm["three_launches"] < tm["count_launches"]:
             form += f" in {tm['three_launches']} of {tm['count_launches']} launches"
-    return four + three, three / 4.0, kernel, form
+    if wide:
+        form += "; lane tile of four x four variants, the block's waves split over the halves of a chunk's K range"
+    return four + three, (three - wide) / 4.0 + wide / 6.0, kernel, form
 
 
 def launch_spread(eng):

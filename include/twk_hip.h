@@ -366,6 +366,9 @@ int twk_hip_fisher_exact(twk_hip_ctx* ctx, const int32_t* tables, uint64_t n, do
  *   "three"            1        UnphasedMath on planes without missing genotypes, r2 cut-off > 1e-6: contract three products per
  *                               pair (HH and S = QH + HQ + 2 QQ, all the screen reads) and recount the four products of the pairs
  *                               that pass; 0: four products for every pair; 2: keep to it even when a launch was candidate-rich
+ *   "three_wide"       1        ... through a count matrix (rows too long to fuse) on the wide lane tile: a lane holds four x four variant pairs, the
+ *                               block's eight waves are 2 x 2 over the tile x the two halves of a chunk's K range, both halves add into the matrix
+ *                               (k_count3w_list_t); 0: four x two variants a lane, whole tiles stored (k_count3_list_t) - same counts, 4 % slower
  *   "async_delivery"   1        region calls with a sink: a finished launch's sorted survivors are copied aside on the device and
  *                               a second thread of the engine takes them to the host and calls the sink - in the launches' order,
  *                               one call at a time - while the calling thread goes on enqueueing launches; 0: the calling thread
@@ -414,6 +417,8 @@ typedef struct {
 	                                 AND+popcounts row_pairs x words_per_row stands for, plus 6 v_or per 24 of them */
 	uint64_t recount_candidates;  /* pairs that passed the three-product screen and had their four products counted afresh */
 	uint64_t outlier_launches;    /* count launches the outlier watch flagged (twk_hip_launch_log)                          */
+	uint64_t three_wide_row_pairs;/* (ABI 5) ... of three_row_pairs, those of launches on the wide lane tile (k_count3w_list_t: four x four variants a
+	                                 lane, 8 v_or per 48 products instead of 6 per 24)                                       */
 	double   finish_ms;           /* (ABI 5) the calling thread's wall time between a launch's last kernel and the hand-over of its
 	                                 records: device sort, copy to the host, the sink (launches the delivery thread takes: up to
 	                                 their copy aside on the device) - summed over the launches                              */

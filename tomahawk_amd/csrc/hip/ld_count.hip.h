@@ -425,6 +425,21 @@ __device__ __forceinline__ void contract3_half(uint32_t (&acc)[8][4], const uint
 	            a[0].y, a[2].y, a[4].y, a[6].y, a[1].y, a[3].y, a[5].y, a[7].y, c0, c1, c2, c3, b[2].y, b[3].y);
 }
 
+// One WORD of the three-product form against NV column variants (the wide lane tile of k_count3w_list_t: four row variants x four
+// column variants per lane): aw[2s] / aw[2s + 1] the H / Q word of row variant s, bw[2v] / bw[2v + 1] of column variant v.  The row
+// carriers are formed once per word and serve all NV column variants: 4 + NV v_or per 12 NV products - 8 per 48 at NV = 4, where the
+// 4 x 2 tile pays 6 per 24.
+template <int TB, int NV>
+__device__ __forceinline__ void contract3_word(uint32_t (&acc)[8][TB], const uint32_t (&aw)[8], const uint32_t (&bw)[2 * NV]) {
+	static_assert(TB >= 2 * NV, "two plane rows per column variant");
+	uint32_t c0, c1, c2, c3;
+	or4v(c0, c1, c2, c3, aw[0], aw[1], aw[2], aw[3], aw[4], aw[5], aw[6], aw[7]);
+#pragma unroll
+	for (int v = 0; v < NV; ++v)
+		and_bcnt12v(acc[0][2 * v], acc[2][2 * v], acc[4][2 * v], acc[6][2 * v], acc[1][2 * v + 1], acc[3][2 * v + 1], acc[5][2 * v + 1], acc[7][2 * v + 1],
+		            aw[0], aw[2], aw[4], aw[6], aw[1], aw[3], aw[5], aw[7], c0, c1, c2, c3, bw[2 * v], bw[2 * v + 1]);
+}
+
 // ---- persistent work-list form of the same contraction ------------------------------------
 // One launch = a list of 128 x 128 tiles of one super-tile (only the tiles that hold wanted pairs:
 // on/above the diagonal, inside the window band, ...) run by P persistent blocks, P = the number
@@ -534,6 +549,7 @@ struct StoreCounts {
 	static constexpr int META_WORDS = 0;       // nothing to stage for the epilogue
 	static constexpr bool PAIRED_ROWS = false; // a lane's rows are li + 8t (see read_half)
 	static constexpr bool THREE_PRODUCTS = false;
+	static constexpr bool K_SPLIT = false;
 	uint32_t* C; uint32_t ldc;
 	__device__ __forceinline__ const uint32_t* meta_src(uint32_t, uint32_t) const { return nullptr; }
 	__device__ __forceinline__ void finish(SlotWindow&, int) const {}
@@ -561,6 +577,7 @@ struct StoreCounts3 {
 	static constexpr int META_WORDS = 0;
 	static constexpr bool PAIRED_ROWS = true;
 	static constexpr bool THREE_PRODUCTS = true;
+	static constexpr bool K_SPLIT = false;
 	uint32_t* C; uint32_t ldc;
 	__device__ __forceinline__ const uint32_t* meta_src(uint32_t, uint32_t) const { return nullptr; }
 	__device__ __forceinline__ void finish(SlotWindow&, int) const {}
@@ -580,9 +597,39 @@ struct StoreCounts3 {
 	}
 };
 
+// The wide lane tile of the three-product form (k_count3w_list_t): the block's eight waves are a 2 x 2 grid over the tile times the two
+// halves of every chunk's K range - wave w contracts half-slots [8 (w >> 2), 8 (w >> 2) + 8) of the 64 x 64 plane rows of quarter w & 3, a
+// lane four row variants x four column variants (32 accumulators: HH and S of 16 pairs).  Two waves thus hold partial sums of every
+// pair, and both ADD them into C: every tile of such a launch is zeroed beforehand (k_zero_tiles over the whole list), whole or not.
+template <int TB>
+struct StoreCounts3Wide {
+	static constexpr int META_WORDS = 0;
+	static constexpr bool PAIRED_ROWS = true;
+	static constexpr bool THREE_PRODUCTS = true;
+	static constexpr bool K_SPLIT = true;
+	uint32_t* C; uint32_t ldc;
+	__device__ __forceinline__ const uint32_t* meta_src(uint32_t, uint32_t) const { return nullptr; }
+	__device__ __forceinline__ void finish(SlotWindow&, int) const {}
+	__device__ __forceinline__ void operator()(uint32_t (&acc)[8][TB], uint32_t yx, int wr, int wc, int li, int lj, int lane, bool, const uint32_t*, SlotWindow&) const {
+		static_assert(TB == 8, "four column variants per lane");
+		// the lane's variant pairs: rows vA + 8 s (s = 0..3), columns vB + 8 v (v = 0..3) of the wave's 32 x 32 variant pairs
+		uint32_t* Cblk = C + (size_t)((yx >> 16) * (TILE / 2) + wr * 32 + li) * ldc + 2 * ((yx & 0xFFFFu) * (TILE / 2) + wc * 32 + lj);
+#pragma unroll
+		for (int s = 0; s < 4; ++s)
+#pragma unroll
+			for (int v = 0; v < 4; ++v) {
+				uint32_t* e = Cblk + (size_t)(8 * s) * ldc + 16 * v;
+				atomicAdd(e, acc[2 * s][2 * v]); atomicAdd(e + 1, acc[2 * s + 1][2 * v + 1]);
+				acc[2 * s][2 * v] = 0; acc[2 * s + 1][2 * v + 1] = 0;
+			}
+	}
+};
+
 template <int NW, int EXPERIMENT, class Epilogue>      // EXPERIMENT == 5: the dev tool's finish-time probe (overwrites C)
 __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilogue& epilogue) {
-	constexpr int WC = NW / 2;
+	constexpr bool KSPLIT = Epilogue::K_SPLIT;        // the wide lane tile: 2 x 2 waves over the tile x 2 halves of the chunk's K range (StoreCounts3Wide)
+	static_assert(!KSPLIT || NW == 8, "2 x 2 x 2 waves");
+	constexpr int WC = KSPLIT ? 2 : NW / 2;
 	constexpr int TB = 16 / WC;
 	constexpr int NSEG = 32 / NW;
 	__shared__ __attribute__((aligned(16))) uint32_t lds[2 * 2 * TILE * KC];
@@ -598,7 +645,9 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 	const int lane = tid & 63;
 	const int wave = tid >> 6;
 	const int wave_u = __builtin_amdgcn_readfirstlane(wave);      // (wave-uniform: lives in a scalar register, and so do the wave's tile coordinates)
-	const int wr = wave_u / WC, wc = wave_u % WC;
+	const int wq = KSPLIT ? (wave_u & 3) : wave_u;               // the wave's place in the grid over the tile
+	const int wr = wq / WC, wc = wq % WC;
+	const uint32_t kh = KSPLIT ? (uint32_t)(wave_u >> 2) : 0u;   // ... and the half of every chunk's K range it contracts
 	const int li = lane >> 3, lj = lane & 7;
 	const uint32_t nchunks = w.W / KC;
 	const uint32_t n_units = w.n_units;
@@ -651,7 +700,7 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 
 	constexpr bool PAIRED = Epilogue::PAIRED_ROWS;
 	constexpr bool THREE = Epilogue::THREE_PRODUCTS;      // the three-product form of the plain unphased planes (contract3_half)
-	static_assert(!THREE || (PAIRED && TB == 4), "the three-product form needs a variant's H and Q rows in one lane");
+	static_assert(!THREE || (PAIRED && (TB == 4 || (KSPLIT && TB == 8))), "the three-product form needs a variant's H and Q rows in one lane");
 	// The per-lane LDS read offsets and DMA source offsets of the K loop.  For the fused epilogues they are recomputed when a unit ends
 	// instead of being held through the epilogue: the epilogue is where the kernels' register demand peaks, and what the allocator evicts
 	// there it reloads from scratch inside the K loop (round 5: sixteen spilled offsets, scratch loads between the half-slots).  The lane
@@ -753,6 +802,52 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 		// the 12 reads just issued has arrived").
 		const uint32_t bufbase = lds_base + (uint32_t)buf * (2 * LDS_TILE_BYTES);
 		const int h_end = (c + 1 == nchunks && w.last_halves) ? (int)w.last_halves : 16;     // wave-uniform
+		if constexpr (KSPLIT) {
+			// This wave's eight half-slots [8 kh, 8 kh + 8) - slots [4 kh, 4 kh + 4): address bit 6 - of its 64 x 64 plane rows.  Sixteen reads a
+			// half-slot are one more than lgkmcnt counts, so they go out in two groups: the A rows of half-slot h + 1 in front of half-slot h's
+			// contraction, its B rows between the two words of it; lgkmcnt(8) behind the first group then says "half-slot h has arrived".
+			const uint32_t baseA = (bufbase + offA) ^ (kh << 6), baseB = (bufbase + offB) ^ (kh << 6);
+			const int h_lim = h_end - (int)kh * 8 < 8 ? h_end - (int)kh * 8 : 8;           // (the last chunk of a row may end inside or before this half)
+			if (h_lim == 8) {
+				uint2 ra[2][8], rb[2][TB];
+				read_half_a<TB, PAIRED>(ra[0], baseA, baseA, 0);
+				read_half_b<TB, PAIRED>(rb[0], baseB, baseB, 0);
+#pragma unroll
+				for (int h = 0; h < 8; ++h) {
+					const int q1 = (h + 1) >> 1;
+					if (h + 1 < 8) {
+						read_half_a<TB, PAIRED>(ra[(h + 1) & 1], baseA ^ (uint32_t)(q1 << 4), baseA ^ (uint32_t)(q1 << 4), (h + 1) & 1);
+						asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+					} else {
+						asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+					}
+					{
+						const uint2 (&a)[8] = ra[h & 1]; const uint2 (&b)[TB] = rb[h & 1];
+						const uint32_t ax[8] = {a[0].x, a[1].x, a[2].x, a[3].x, a[4].x, a[5].x, a[6].x, a[7].x};
+						const uint32_t bx[8] = {b[0].x, b[1].x, b[2].x, b[3].x, b[4].x, b[5].x, b[6].x, b[7].x};
+						contract3_word<TB, 4>(acc, ax, bx);
+						if (h + 1 < 8) read_half_b<TB, PAIRED>(rb[(h + 1) & 1], baseB ^ (uint32_t)(q1 << 4), baseB ^ (uint32_t)(q1 << 4), (h + 1) & 1);
+						const uint32_t ay[8] = {a[0].y, a[1].y, a[2].y, a[3].y, a[4].y, a[5].y, a[6].y, a[7].y};
+						const uint32_t by[8] = {b[0].y, b[1].y, b[2].y, b[3].y, b[4].y, b[5].y, b[6].y, b[7].y};
+						contract3_word<TB, 4>(acc, ay, by);
+					}
+				}
+			} else {
+#pragma unroll 1
+				for (int h = 0; h < h_lim; ++h) {
+					uint2 a[8], b[TB];
+					const uint32_t q = (uint32_t)(h >> 1) << 4, hb = (uint32_t)(h & 1) << 3;
+					read_half<TB, PAIRED>(a, b, (baseA ^ q) + hb, (baseA ^ q) + hb, (baseB ^ q) + hb, (baseB ^ q) + hb, 0);
+					asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+					const uint32_t ax[8] = {a[0].x, a[1].x, a[2].x, a[3].x, a[4].x, a[5].x, a[6].x, a[7].x};
+					const uint32_t bx[8] = {b[0].x, b[1].x, b[2].x, b[3].x, b[4].x, b[5].x, b[6].x, b[7].x};
+					contract3_word<TB, 4>(acc, ax, bx);
+					const uint32_t ay[8] = {a[0].y, a[1].y, a[2].y, a[3].y, a[4].y, a[5].y, a[6].y, a[7].y};
+					const uint32_t by[8] = {b[0].y, b[1].y, b[2].y, b[3].y, b[4].y, b[5].y, b[6].y, b[7].y};
+					contract3_word<TB, 4>(acc, ay, by);
+				}
+			}
+		} else
 		if (h_end == 16) {
 			uint2 ra[2][8], rb[2][TB];
 			const uint32_t baseA = bufbase + offA, baseB = bufbase + offB;
@@ -841,6 +936,12 @@ template <int NW, int EXPERIMENT = 0>
 __global__ __launch_bounds__(NW * 64, NW / 2)
 void k_count3_list_t(const CountWork w) {
 	count_list_body<NW, EXPERIMENT>(w, StoreCounts3<16 / (NW / 2)>{w.C, w.ldc});
+}
+
+template <int NW, int EXPERIMENT = 0>
+__global__ __launch_bounds__(NW * 64, NW / 2)
+void k_count3w_list_t(const CountWork w) {
+	count_list_body<NW, EXPERIMENT>(w, StoreCounts3Wide<8>{w.C, w.ldc});
 }
 
 // Inclusive prefix sum over the 64 lanes of a wave (all active) without LDS: Hillis-Steele inside each row of 16 lanes
@@ -934,6 +1035,7 @@ template <int TB>
 struct ScreenCounts {
 	static constexpr bool PAIRED_ROWS = false;
 	static constexpr bool THREE_PRODUCTS = false;
+	static constexpr bool K_SPLIT = false;
 	static constexpr int META_WORDS = 3 * TILE;      // allele counts of the tile's 128 rows, of its 128 columns, band limits of the rows
 	const ScreenWork* sp;              // in device memory: read where it is needed, not held in registers through the K loop
 	// where word i of the staged block comes from (always a readable address; what lies outside the region is masked in the epilogue)
@@ -1091,6 +1193,7 @@ template <int TB, bool THREE = false>
 struct ScreenCountsUnphased {
 	static constexpr bool PAIRED_ROWS = true;
 	static constexpr bool THREE_PRODUCTS = THREE;
+	static constexpr bool K_SPLIT = false;
 	static constexpr int META_WORDS = 2 * TILE + TILE / 2;     // H / Q counts of the tile's 128 plane rows, of its 128 plane columns, band limits of its 64 row variants
 	const ScreenWork* sp;
 	__device__ __forceinline__ const uint32_t* meta_src(uint32_t yx, uint32_t i) const {

@@ -106,6 +106,7 @@ struct Slot {                      // one in-flight tile (double buffered)
 	bool fused = false;                           // first launch ran the fused count -> screen kernel: C holds the candidate list
 	bool three = false;                           // ... in the three-product form (HH + S; the candidates' four products are recounted): fused, or
 	bool three_plain = false;                     // through a count matrix (long rows): C holds the (HH, S) matrix and, behind it, the candidate list
+	bool three_wide = false;                      // ... contracted on the wide lane tile (k_count3w_list_t)
 	uint32_t* cand = nullptr;                     // the candidate list of the launch (in C)
 	int plane_set = 0;                            // the plane set the launch contracted
 	unsigned long long cand_cap = 0;              // ... of this many entries; n_out[2] counts them
@@ -154,6 +155,8 @@ struct Options {
 	long long probe_lds = 1;         // probes through LDS: column rows staged segment by segment, carriers tested there (ld_list.hip.h k_probe_lds_t); 0: gathers from L2
 	long long async_delivery = 1;    // region calls with a sink: finished launches' survivors are copied aside on the device and taken to the host by a second thread (delivery_loop); 0: by the thread that runs the launches (round 4)
 	long long probe_cols = 0;        // probes: columns a block takes (2, 4, 8, 16: phased planes; unphased planes half of it; ld_list.hip.h k_probe_strip_t); 0: one column per block
+	long long three_wide = 1;        // the three-product form through a count matrix (long rows) on the wide lane tile: four x four variants a lane, the block's waves
+	                                 // split over the halves of a chunk's K range (k_count3w_list_t, ld_count.hip.h); 0: four x two (k_count3_list_t)
 	long long three = 1;             // UnphasedMath on the plain unphased planes with an r2 cut-off: the three-product contraction (HH + S, ld_count.hip.h) and a
 	                                 // recount of the candidates' four products; 0: the four-product forms; 2: also when a launch turned out candidate-rich
 };
@@ -168,7 +171,7 @@ const OptionKey OPTION_KEYS[] = {
 	{"record_cap", &Options::record_cap, 0, 1ll << 40, false},
 	{"probe", &Options::probe, 0, 1, false}, {"band_launch", &Options::band_launch, 0, 1, false}, {"band_list_entries", &Options::band_list_entries, 0, 1ll << 32, false},
 	{"band_work_log2", &Options::band_work_log2, 0, 40, false}, {"band_max_launches", &Options::band_max_launches, 1, 64, false}, {"timeline", &Options::timeline, 0, 1, false}, {"band_reverse", &Options::band_reverse, 0, 1, false}, {"probe_zone", &Options::probe_zone, 0, 1, false}, {"probe_unroll", &Options::probe_unroll, 1, 4, false},
-	{"three", &Options::three, 0, 2, false}, {"probe_cols", &Options::probe_cols, 0, 16, false}, {"probe_lds", &Options::probe_lds, 0, 1, false}, {"async_delivery", &Options::async_delivery, 0, 1, false},
+	{"three", &Options::three, 0, 2, false}, {"three_wide", &Options::three_wide, 0, 1, false}, {"probe_cols", &Options::probe_cols, 0, 16, false}, {"probe_lds", &Options::probe_lds, 0, 1, false}, {"async_delivery", &Options::async_delivery, 0, 1, false},
 };
 }  // namespace
 
@@ -623,6 +626,8 @@ int launch_count(twk_hip_ctx* c, int set, const twk_hip_tile_desc& t, Slot& s, i
 			if (w.last_halves > 12) w.last_halves = 0;
 		}
 		HIPCHK(c, hipMemsetAsync(w.ticket, 0, 8 * 4, c->s_compute));
+		const bool wide = three && !fuse && c->opt.three_wide != 0;      // (two waves add into every count: all tiles zeroed, none stored)
+		if (wide) first_split = 0;
 		if (first_split < T) {
 			hipLaunchKernelGGL(k_zero_tiles, dim3((uint32_t)T - first_split), dim3(256), 0, c->s_compute, w.tiles, first_split, w.C, w.ldc, (uint32_t)(three ? TILE / 2 : TILE));
 			HIPCHK(c, hipGetLastError());
@@ -632,6 +637,8 @@ int launch_count(twk_hip_ctx* c, int set, const twk_hip_tile_desc& t, Slot& s, i
 		if (with_args && d_screen) *d_screen = &d_fa->screen;
 		if (fuse && fa->unphased && three && c->sampling) hipLaunchKernelGGL((k_count3_screen_unphased_t<COUNT_NW, 1>), dim3(std::min(n_blocks, w.n_units)), dim3(COUNT_THREADS), 0, c->s_compute, w, &d_fa->screen);
 		else if (fuse && fa->unphased && three) hipLaunchKernelGGL((k_count3_screen_unphased_t<COUNT_NW>), dim3(std::min(n_blocks, w.n_units)), dim3(COUNT_THREADS), 0, c->s_compute, w, &d_fa->screen);
+		else if (wide && c->sampling) hipLaunchKernelGGL((k_count3w_list_t<COUNT_NW, 1>), dim3(std::min(n_blocks, w.n_units)), dim3(COUNT_THREADS), 0, c->s_compute, w);
+		else if (wide) hipLaunchKernelGGL((k_count3w_list_t<COUNT_NW>), dim3(std::min(n_blocks, w.n_units)), dim3(COUNT_THREADS), 0, c->s_compute, w);
 		else if (three && c->sampling) hipLaunchKernelGGL((k_count3_list_t<COUNT_NW, 1>), dim3(std::min(n_blocks, w.n_units)), dim3(COUNT_THREADS), 0, c->s_compute, w);
 		else if (three) hipLaunchKernelGGL((k_count3_list_t<COUNT_NW>), dim3(std::min(n_blocks, w.n_units)), dim3(COUNT_THREADS), 0, c->s_compute, w);
 		else if (fuse && fa->unphased) hipLaunchKernelGGL((k_count_screen_unphased_t<COUNT_NW>), dim3(std::min(n_blocks, w.n_units)), dim3(COUNT_THREADS), 0, c->s_compute, w, &d_fa->screen);
@@ -812,7 +819,7 @@ int enqueue_tile(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, const twk
 	const StatsParams* d_stats = nullptr; const ScreenWork* d_screen = nullptr;
 	s.deferred = false; s.was_deferred = false; s.presorted = false;
 	rc = launch_count(c, kind1, t, s, 0, s.ev_c0, s.ev_c1, &s.row_pairs, cr, want_fused ? &fa : nullptr, &s.fused, &d_stats, want_three, &d_screen); if (rc) return rc;
-	s.three = want_three; s.three_plain = want_three && !s.fused; s.plane_set = kind1;
+	s.three = want_three; s.three_plain = want_three && !s.fused; s.three_wide = s.three_plain && c->opt.three_wide != 0; s.plane_set = kind1;
 	tl("count kernel enqueued");
 	if (list_words) {
 		// A band launch stops here for now: how many survivors it can have is how many candidates it found, and only the count
@@ -1216,7 +1223,7 @@ int finish_tile(twk_hip_ctx* c, Slot& s, const twk_hip_tile_desc& t, unsigned lo
 	       c->timing.count_shader_cycles += s.h_n_out[4]; c->timing.count_wall_ticks += s.h_n_out[5]; }
 	if (s.fused) { c->timing.fused_launches += 1; c->timing.candidates += s.h_n_out[2]; }
 	if (s.three) {
-		c->timing.three_launches += 1; c->timing.three_row_pairs += s.row_pairs; c->timing.recount_candidates += std::min<unsigned long long>(s.h_n_out[2], s.cand_cap);
+		c->timing.three_launches += 1; c->timing.three_row_pairs += s.row_pairs; if (s.three_wide) c->timing.three_wide_row_pairs += s.row_pairs; c->timing.recount_candidates += std::min<unsigned long long>(s.h_n_out[2], s.cand_cap);
 		if (s.three_plain) c->timing.candidates += s.h_n_out[2];
 		if (s.h_n_out[3]) {      // the recount disagrees with the contraction: never to be papered over
 			snprintf(c->err, sizeof(c->err), "three-product contraction: %llu candidates whose (HH, S) differ from their recounted products (tile rows %u+%u, cols %u+%u)", s.h_n_out[3], t.rowA0, t.nA, t.rowB0, t.nB);
