@@ -62,13 +62,16 @@ asan-test: asan
 	LD_PRELOAD=$$($(CXX) -print-file-name=libasan.so):$$($(CXX) -print-file-name=libubsan.so) ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1 \
 	TWK_HOST_LIB=$(abspath $(ASAN_DIR))/libtomahawk_amd.so TWK_CLI=$(abspath $(ASAN_DIR))/tomahawk python -m pytest tests -x -q -m "not gpu"
 
-# ThreadSanitizer run of the record emitter (worker pool, ordered placing step, backlog, mapped output): the format and
-# emitter sources with -fsanitize=thread around csrc/tools/emitter_tsan.cpp
+# ThreadSanitizer runs: the record emitter (worker pool, ordered placing step, backlog, mapped output) - the format and emitter sources with
+# -fsanitize=thread around csrc/tools/emitter_tsan.cpp - and the engine's delivery queue (csrc/hip/twk_delivery.h) with the device operations
+# stubbed (csrc/tools/delivery_tsan.cpp)
 tsan:
 	@mkdir -p build
 	$(CXX) -O1 -g -std=c++17 -pthread -fsanitize=thread -Iinclude -I$(PKG)/csrc/host $(PKG)/csrc/tools/emitter_tsan.cpp $(PKG)/csrc/host/twk_format.cpp \
 		-o build/emitter_tsan $(ZSTD_LIB) $(ZLIB)
 	TSAN_OPTIONS=halt_on_error=1 ./build/emitter_tsan
+	$(CXX) -O1 -g -std=c++17 -pthread -fsanitize=thread $(PKG)/csrc/tools/delivery_tsan.cpp -o build/delivery_tsan
+	TSAN_OPTIONS=halt_on_error=1 ./build/delivery_tsan
 
 clean:
 	rm -rf $(LIBDIR) $(BINDIR) $(ASAN_DIR) build

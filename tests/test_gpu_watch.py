@@ -88,3 +88,73 @@ def test_delivery_thread_hands_over_the_same_records_in_the_same_order(hip, opt)
         f = T.Filters(minR2=0.0)._c()
         rc = hip._lib.twk_hip_ld_all(hip._ctx, T.MODE_PHASED, C.byref(f), 0, 1, 128, 0, 0, cb, None, None, None)
         assert rc != 0 and len(calls) >= 2
+
+
+def test_delivery_thread_failures_backpressure_and_recovery(hip, opt):
+    """The engine's second thread beyond the happy path (twk_delivery.h): launches big enough to be
+    staged (>= 2^18 survivors), with
+      * a sink that fails ON the delivery thread: the call returns the failure and its text, the thread is joined, the pool freed;
+      * a staging allocation that fails (option deliver_fail_alloc_at): the calling thread hands that launch over itself, behind
+        what is queued - same records, same order;
+      * a staging copy that fails (deliver_fail_copy_at): the call fails, the buffer goes back to the pool;
+      * one staging buffer and a sink slower than the launches (deliver_buffers = 1): launches wait for the buffer - same records;
+    and after every failure the context runs the next call as if nothing had happened."""
+    import ctypes as C
+    import time
+    from tomahawk_amd import hip as H
+    N, M = 500, 1500
+    al = util.random_alleles(M, N, 5)
+    util.upload(hip, al)
+    f = T.Filters(minR2=0.0)
+    kw = dict(tile_variants=1024)                       # launches of 523,776 / 487,424 / 113,050 pairs: two staged, one handed over directly
+    opt.set("async_delivery", 0)
+    want, npairs, nrec = hip.ld_all(T.MODE_PHASED, f, **kw)
+    opt.unset("async_delivery")
+    assert nrec == len(want) == npairs == M * (M - 1) // 2
+
+    def run_ok():
+        got, p, r = hip.ld_all(T.MODE_PHASED, f, **kw)
+        assert (p, r) == (npairs, nrec) and got.tobytes() == want.tobytes()
+
+    run_ok()
+    # the sink fails at its second call - on the delivery thread (the first launch is staged: 523,776 >= 2^18 records)
+    import threading
+    seen = []
+
+    def bad_sink(_user, recs, n):
+        seen.append((n, threading.get_ident()))
+        return 1 if len(seen) >= 2 else 0
+
+    cb = H._SINK(bad_sink)
+    fc = f._c()
+    rc = hip._lib.twk_hip_ld_all(hip._ctx, T.MODE_PHASED, C.byref(fc), 0, 1, 1024, 0, 0, cb, None, None, None)
+    assert rc != 0 and len(seen) >= 2 and seen[0][0] == 523_776 and seen[0][1] != threading.get_ident()
+    assert b"sink failed" in hip._lib.twk_hip_last_error(hip._ctx)
+    run_ok()
+    # a failing staging allocation: the launch is delivered by the calling thread; a failing staging copy: the call fails
+    for nth in (1, 2):
+        opt.set("deliver_fail_alloc_at", nth)
+        run_ok()
+        opt.unset("deliver_fail_alloc_at")
+    opt.set("deliver_fail_copy_at", 2)
+    with pytest.raises(T.HipError) as e:
+        hip.ld_all(T.MODE_PHASED, f, **kw)
+    assert "staging copy" in str(e.value)
+    opt.unset("deliver_fail_copy_at")
+    run_ok()
+    # back-pressure: one buffer, a slow sink
+    opt.set("deliver_buffers", 1)
+    chunks = []
+
+    def slow_sink(_user, recs, n):
+        time.sleep(0.05)
+        buf = (C.c_char * (n * T.RECORD_DTYPE.itemsize)).from_address(recs)
+        chunks.append(np.frombuffer(buf, dtype=T.RECORD_DTYPE).copy())
+        return 0
+
+    cb = H._SINK(slow_sink)
+    n_p, n_r = C.c_uint64(0), C.c_uint64(0)
+    rc = hip._lib.twk_hip_ld_all(hip._ctx, T.MODE_PHASED, C.byref(fc), 0, 1, 512, 0, 0, cb, None, C.byref(n_p), C.byref(n_r))
+    assert rc == 0 and n_r.value == nrec
+    got = np.concatenate(chunks)
+    assert np.sort(got, order=["idxA", "idxB"]).tobytes() == np.sort(want, order=["idxA", "idxB"]).tobytes()

@@ -648,7 +648,6 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 	const int wq = KSPLIT ? (wave_u & 3) : wave_u;               // the wave's place in the grid over the tile
 	const int wr = wq / WC, wc = wq % WC;
 	const uint32_t kh = KSPLIT ? (uint32_t)(wave_u >> 2) : 0u;   // ... and the half of every chunk's K range it contracts
-	const int li = lane >> 3, lj = lane & 7;
 	const uint32_t nchunks = w.W / KC;
 	const uint32_t n_units = w.n_units;
 	const unsigned long long probe_wall0 = wall_clock64(), probe_clk0 = clock64();      // the block's start on the constant 100 MHz clock and on the shader clock (scalar registers)

@@ -31,6 +31,7 @@
 #include "ld_list.hip.h"
 #include "ld_three.hip.h"
 #include "ld_plan.h"
+#include "twk_delivery.h"
 
 using namespace twk;
 
@@ -155,6 +156,8 @@ struct Options {
 	long long probe_lds = 1;         // probes through LDS: column rows staged segment by segment, carriers tested there (ld_list.hip.h k_probe_lds_t); 0: gathers from L2
 	long long async_delivery = 1;    // region calls with a sink: finished launches' survivors are copied aside on the device and taken to the host by a second thread (delivery_loop); 0: by the thread that runs the launches (round 4)
 	long long probe_cols = 0;        // probes: columns a block takes (2, 4, 8, 16: phased planes; unphased planes half of it; ld_list.hip.h k_probe_strip_t); 0: one column per block
+	long long deliver_buffers = 3;   // staging buffers the delivery thread may hold at a time (twk_delivery.h): a launch whose survivors find none free waits for one
+	long long deliver_fail_alloc_at = 0, deliver_fail_copy_at = 0;      // test hooks: the n-th staging allocation / copy aside of a region call fails (0: none)
 	long long three_wide = 1;        // the three-product form through a count matrix (long rows) on the wide lane tile: four x four variants a lane, the block's waves
 	                                 // split over the halves of a chunk's K range (k_count3w_list_t, ld_count.hip.h); 0: four x two (k_count3_list_t)
 	long long three = 1;             // UnphasedMath on the plain unphased planes with an r2 cut-off: the three-product contraction (HH + S, ld_count.hip.h) and a
@@ -171,29 +174,31 @@ const OptionKey OPTION_KEYS[] = {
 	{"record_cap", &Options::record_cap, 0, 1ll << 40, false},
 	{"probe", &Options::probe, 0, 1, false}, {"band_launch", &Options::band_launch, 0, 1, false}, {"band_list_entries", &Options::band_list_entries, 0, 1ll << 32, false},
 	{"band_work_log2", &Options::band_work_log2, 0, 40, false}, {"band_max_launches", &Options::band_max_launches, 1, 64, false}, {"timeline", &Options::timeline, 0, 1, false}, {"band_reverse", &Options::band_reverse, 0, 1, false}, {"probe_zone", &Options::probe_zone, 0, 1, false}, {"probe_unroll", &Options::probe_unroll, 1, 4, false},
-	{"three", &Options::three, 0, 2, false}, {"three_wide", &Options::three_wide, 0, 1, false}, {"probe_cols", &Options::probe_cols, 0, 16, false}, {"probe_lds", &Options::probe_lds, 0, 1, false}, {"async_delivery", &Options::async_delivery, 0, 1, false},
+	{"three", &Options::three, 0, 2, false}, {"three_wide", &Options::three_wide, 0, 1, false},
+	{"deliver_buffers", &Options::deliver_buffers, 1, 64, false}, {"deliver_fail_alloc_at", &Options::deliver_fail_alloc_at, 0, 1 << 30, false}, {"deliver_fail_copy_at", &Options::deliver_fail_copy_at, 0, 1 << 30, false}, {"probe_cols", &Options::probe_cols, 0, 16, false}, {"probe_lds", &Options::probe_lds, 0, 1, false}, {"async_delivery", &Options::async_delivery, 0, 1, false},
 };
 }  // namespace
 
-// The delivery thread's state (delivery_loop): finished launches' survivors, copied aside on the device, waiting for the host.
-struct Delivery {
-	struct Item { size_t buf; const twk_hip_record* p; unsigned long long n; twk_hip_record_sink sink; void* user; };      // (the sink of the call that finished the launch: a sample's records go nowhere)
-	struct Buf { twk_hip_record* p; unsigned long long cap; bool busy; };
-	std::thread th;
-	std::mutex mu; std::condition_variable cv;
-	std::deque<Item> q;              // under mu: in the order of the launches
-	std::vector<Buf> pool;           // under mu: device buffers of the call (freed when it ends)
-	bool stop = false, active = false, busy = false;     // busy (under mu): the thread is handing an item over
-	std::condition_variable cv_idle;
-	std::atomic<int> rc{0};          // the first failure (the sink's, a copy's)
+// The delivery thread of a region call (twk_delivery.h): the queue's device operations.
+struct twk_hip_ctx;
+struct HipDeliveryOps {
+	twk_hip_ctx* c = nullptr;
+	long long n_alloc = 0, n_copy = 0;       // of the current call (test hooks deliver_fail_alloc_at / deliver_fail_copy_at)
+	void* alloc(size_t bytes);
+	void release(void* p);
+	int copy_aside(void* dst, const void* src, size_t bytes);
+	int deliver(const void* recs, uint64_t n, twk_hip_record_sink sink, void* user, char* err, size_t err_len);
+	void thread_begin();
 };
+typedef twk::DeliveryQueue<HipDeliveryOps, twk_hip_record_sink> Delivery;
 
 struct twk_hip_ctx {
 	int device = 0;
 	Options opt;
 	hipStream_t s_compute = nullptr, s_copy = nullptr, s_deliver = nullptr;      // s_deliver: the delivery thread's copies to the host
-	Delivery dl;
-	bool deliver_warm = false;       // s_deliver has carried a copy (delivery_loop)
+	HipDeliveryOps dl_ops;
+	Delivery dl{sizeof(twk_hip_record)};
+	bool deliver_warm = false;       // s_deliver has carried a copy (HipDeliveryOps::thread_begin)
 	uint32_t N = 0, M = 0, M_alloc = 0;
 	uint32_t Wp = 0, Wu = 0;       // padded words per row: raw (2N bits) / unphased planes (N bits)
 	uint32_t* raw = nullptr;       // [M_alloc][Wp]
@@ -215,6 +220,8 @@ struct twk_hip_ctx {
 	bool three_ok = true;           // cleared for the rest of a call when a three-product launch had too many candidates for the recount to stay cheap
 	bool sampling = false;          // the launch being enqueued is a density sample (RegionRun::decide_three_by_samples): its count kernel runs under its own name
 	                                // (k_count3_list_t<.., 1>), so that a kernel trace's statistics of the real launches are not diluted by half-millisecond ones
+	bool sorted_keeps_no_lists[2] = {false, false};      // [phased, unphased]: the allele-count-sorted set was built once for a run below the band's cut-off and
+	                                                     // kept no carrier lists: such runs go the file-order way without building it again (cleared with the planes)
 	bool device_sink = false;
 	twk_hip_record* d_keep = nullptr; unsigned long long d_keep_n = 0, d_keep_cap = 0;
 	// the survivors of a tile leave in (idxA, idxB) order: sort keys / permutation (double-buffered), the
@@ -256,6 +263,7 @@ namespace {
 
 void free_planes(twk_hip_ctx* c) {
 	c->h_popc.clear();
+	c->sorted_keeps_no_lists[0] = c->sorted_keeps_no_lists[1] = false;
 	for (auto& p : c->planes) {
 		if (p.owns_rows && p.rows) (void)hipFree(p.rows);
 		if (p.rowpop) (void)hipFree(p.rowpop);
@@ -432,11 +440,19 @@ int ensure_planes(twk_hip_ctx* c, int set) {
 
 // (Outgrown buffers go to the graveyard - freed when the region call ends, or with the context: hipFree waits for the whole device,
 // every stream, and in the middle of a region's pipeline that was a stall of 50-250 ms a time: profiles/r05_delivery_thread.txt.)
+// hipMalloc for the buffers of a running call: out of memory -> what the delivery queue holds idle and what the call has outgrown is
+// given back (reclaim_device_memory, below) and the allocation tried once more, before the call fails.
+bool reclaim_device_memory(twk_hip_ctx* c);
+hipError_t dev_malloc(twk_hip_ctx* c, void** p, size_t bytes) {
+	hipError_t e = hipMalloc(p, bytes);
+	if (e == hipErrorOutOfMemory && reclaim_device_memory(c)) e = hipMalloc(p, bytes);
+	return e;
+}
 int ensure_slot(twk_hip_ctx* c, Slot& s, size_t C_words, unsigned long long capacity) {
 	if (s.C_words < C_words) {
 		if (s.C) c->graveyard.push_back(s.C);
 		s.C = nullptr; s.C_words = 0;
-		HIPCHK(c, hipMalloc((void**)&s.C, C_words * 4));
+		HIPCHK(c, dev_malloc(c, (void**)&s.C, C_words * 4));
 		s.C_words = C_words;
 	}
 	if (s.capacity < capacity) {
@@ -444,21 +460,32 @@ int ensure_slot(twk_hip_ctx* c, Slot& s, size_t C_words, unsigned long long capa
 		if (s.keys) c->graveyard.push_back(s.keys);
 		if (s.vals) c->graveyard.push_back(s.vals);
 		s.out = nullptr; s.keys = nullptr; s.vals = nullptr; s.capacity = 0;
-		HIPCHK(c, hipMalloc((void**)&s.out, (size_t)capacity * sizeof(twk_hip_record)));
-		HIPCHK(c, hipMalloc((void**)&s.keys, (size_t)capacity * sizeof(unsigned long long)));
-		HIPCHK(c, hipMalloc((void**)&s.vals, (size_t)capacity * sizeof(uint32_t)));
+		HIPCHK(c, dev_malloc(c, (void**)&s.out, (size_t)capacity * sizeof(twk_hip_record)));
+		HIPCHK(c, dev_malloc(c, (void**)&s.keys, (size_t)capacity * sizeof(unsigned long long)));
+		HIPCHK(c, dev_malloc(c, (void**)&s.vals, (size_t)capacity * sizeof(uint32_t)));
 		s.capacity = capacity;
 	}
 	s.cap_use = capacity;
 	return TWK_HIP_OK;
 }
 
-int ensure_host_records(twk_hip_ctx* c, unsigned long long n) {
+// (err: where a failure's text goes - c->err on the calling thread, the delivery queue's own buffer on its thread)
+#define HIPCHK_E(err, err_len, call)                                                              \
+	do {                                                                                          \
+		hipError_t e__ = (call);                                                                  \
+		if (e__ != hipSuccess) {                                                                  \
+			snprintf((err), (err_len), "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+			return e__ == hipErrorOutOfMemory ? TWK_HIP_E_NOMEM : TWK_HIP_E_DEVICE;               \
+		}                                                                                         \
+	} while (0)
+
+int ensure_host_records(twk_hip_ctx* c, unsigned long long n, char* err = nullptr, size_t err_len = 0) {
+	if (!err) { err = c->err; err_len = sizeof(c->err); }
 	if (c->h_recs_cap >= n) return TWK_HIP_OK;
 	if (c->h_recs) (void)hipHostFree(c->h_recs);
 	c->h_recs = nullptr; c->h_recs_cap = 0;
 	const unsigned long long cap = std::max<unsigned long long>(n, 1ull << 16);
-	HIPCHK(c, hipHostMalloc((void**)&c->h_recs, (size_t)cap * sizeof(twk_hip_record), hipHostMallocDefault));
+	HIPCHK_E(err, err_len, hipHostMalloc((void**)&c->h_recs, (size_t)cap * sizeof(twk_hip_record), hipHostMallocDefault));
 	c->h_recs_cap = cap;
 	return TWK_HIP_OK;
 }
@@ -890,7 +917,7 @@ int regrow(twk_hip_ctx* c, void** p, unsigned long long* cap, unsigned long long
 	if (*cap >= need) return TWK_HIP_OK;
 	const unsigned long long want = need + need / 4;
 	void* q = nullptr;
-	HIPCHK(c, hipMalloc(&q, (size_t)want * item));
+	HIPCHK(c, dev_malloc(c, &q, (size_t)want * item));
 	if (*p) c->graveyard.push_back(*p);
 	*p = q; *cap = want;
 	return TWK_HIP_OK;
@@ -994,9 +1021,9 @@ int sort_records(twk_hip_ctx* c, const twk_hip_record* recs, unsigned long long*
 		if (c->d_sorted) c->graveyard.push_back(c->d_sorted);
 		c->d_sort_keys = nullptr; c->d_sort_vals = nullptr; c->d_sorted = nullptr; c->sort_cap = 0;
 		const unsigned long long cap = std::max<unsigned long long>(n + n / 4, 1ull << 16);
-		HIPCHK(c, hipMalloc((void**)&c->d_sort_keys, (size_t)cap * sizeof(unsigned long long)));
-		HIPCHK(c, hipMalloc((void**)&c->d_sort_vals, (size_t)cap * sizeof(uint32_t)));
-		HIPCHK(c, hipMalloc((void**)&c->d_sorted, (size_t)cap * sizeof(twk_hip_record)));
+		HIPCHK(c, dev_malloc(c, (void**)&c->d_sort_keys, (size_t)cap * sizeof(unsigned long long)));
+		HIPCHK(c, dev_malloc(c, (void**)&c->d_sort_vals, (size_t)cap * sizeof(uint32_t)));
+		HIPCHK(c, dev_malloc(c, (void**)&c->d_sorted, (size_t)cap * sizeof(twk_hip_record)));
 		c->sort_cap = cap;
 	}
 	unsigned long long* keys_out = c->d_sort_keys;
@@ -1011,7 +1038,7 @@ int sort_records(twk_hip_ctx* c, const twk_hip_record* recs, unsigned long long*
 		if (c->d_sort_tmp) c->graveyard.push_back(c->d_sort_tmp);
 		c->d_sort_tmp = nullptr; c->sort_tmp_bytes = 0;
 		const size_t want = std::max<size_t>(tmp + tmp / 4, 4096);
-		HIPCHK(c, hipMalloc(&c->d_sort_tmp, want));
+		HIPCHK(c, dev_malloc(c, &c->d_sort_tmp, want));
 		c->sort_tmp_bytes = want;
 	}
 	tmp = c->sort_tmp_bytes;
@@ -1028,7 +1055,7 @@ int ensure_device_keep(twk_hip_ctx* c, unsigned long long n_more) {
 	if (need <= c->d_keep_cap) return TWK_HIP_OK;
 	const unsigned long long cap = std::max<unsigned long long>(need + need / 2, 1ull << 16);
 	twk_hip_record* p = nullptr;
-	HIPCHK(c, hipMalloc((void**)&p, (size_t)cap * sizeof(twk_hip_record)));
+	HIPCHK(c, dev_malloc(c, (void**)&p, (size_t)cap * sizeof(twk_hip_record)));
 	if (c->d_keep_n) {
 		const hipError_t e = hipMemcpyAsync(p, c->d_keep, (size_t)c->d_keep_n * sizeof(twk_hip_record), hipMemcpyDeviceToDevice, c->s_copy);
 		if (e != hipSuccess) { (void)hipFree(p); HIPCHK(c, e); }
@@ -1077,30 +1104,33 @@ void watch_launch(twk_hip_ctx* c, const Slot& s, float ms, const twk_hip_tile_de
 // piece while the next is being copied (a launch may hold tens of millions of survivors: page-locking a buffer for all of them would cost
 // more than the copy).  Called by the thread that finishes the launch, or by the delivery thread.
 constexpr unsigned long long HOST_CHUNK = 1ull << 20;       // records per piece (109 MB)
-int deliver_records(twk_hip_ctx* c, const twk_hip_record* sorted, unsigned long long kept, twk_hip_record_sink sink, void* user, hipStream_t st, double tl_wait) {
+int deliver_records(twk_hip_ctx* c, const twk_hip_record* sorted, unsigned long long kept, twk_hip_record_sink sink, void* user, hipStream_t st, double tl_wait,
+                    char* err = nullptr, size_t err_len = 0) {
+	if (!err) { err = c->err; err_len = sizeof(c->err); }
 	auto since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
 	double tl_copy = 0, tl_sink = 0;
 	int rc;
 	if (kept <= HOST_CHUNK) {
-		rc = ensure_host_records(c, kept); if (rc) return rc;
-		if (kept) HIPCHK(c, hipMemcpyAsync(c->h_recs, sorted, (size_t)kept * sizeof(twk_hip_record), hipMemcpyDeviceToHost, st));
-		HIPCHK(c, hipStreamSynchronize(st));
-		if (kept && sink(user, c->h_recs, kept)) return TWK_HIP_E_INVALID;
+		rc = ensure_host_records(c, kept, err, err_len); if (rc) return rc;
+		if (kept) HIPCHK_E(err, err_len, hipMemcpyAsync(c->h_recs, sorted, (size_t)kept * sizeof(twk_hip_record), hipMemcpyDeviceToHost, st));
+		HIPCHK_E(err, err_len, hipStreamSynchronize(st));
+		if (kept && sink(user, c->h_recs, kept)) { snprintf(err, err_len, "the record sink failed"); return TWK_HIP_E_INVALID; }
 		return TWK_HIP_OK;
 	}
-	rc = ensure_host_records(c, 2 * HOST_CHUNK); if (rc) return rc;
+	rc = ensure_host_records(c, 2 * HOST_CHUNK, err, err_len); if (rc) return rc;
 	auto copy_piece = [&](unsigned long long first) -> hipError_t {
 		const unsigned long long m = std::min(HOST_CHUNK, kept - first);
 		return hipMemcpyAsync(c->h_recs + ((first / HOST_CHUNK) & 1) * HOST_CHUNK, sorted + first, (size_t)m * sizeof(twk_hip_record), hipMemcpyDeviceToHost, st);
 	};
-	HIPCHK(c, copy_piece(0));
+	HIPCHK_E(err, err_len, copy_piece(0));
 	for (unsigned long long first = 0; first < kept; first += HOST_CHUNK) {
 		auto t1 = std::chrono::steady_clock::now();
-		HIPCHK(c, hipStreamSynchronize(st));                                          // piece `first` has arrived
-		if (first + HOST_CHUNK < kept) HIPCHK(c, copy_piece(first + HOST_CHUNK));     // the next one travels while the sink works (into the other half)
+		HIPCHK_E(err, err_len, hipStreamSynchronize(st));                                          // piece `first` has arrived
+		if (first + HOST_CHUNK < kept) HIPCHK_E(err, err_len, copy_piece(first + HOST_CHUNK));     // the next one travels while the sink works (into the other half)
 		tl_copy += since(t1); t1 = std::chrono::steady_clock::now();
 		if (sink(user, c->h_recs + ((first / HOST_CHUNK) & 1) * HOST_CHUNK, std::min(HOST_CHUNK, kept - first))) {
 			(void)hipStreamSynchronize(st);
+			snprintf(err, err_len, "the record sink failed");
 			return TWK_HIP_E_INVALID;
 		}
 		tl_sink += since(t1);
@@ -1109,95 +1139,48 @@ int deliver_records(twk_hip_ctx* c, const twk_hip_record* sorted, unsigned long 
 	return TWK_HIP_OK;
 }
 
-// ---- the delivery thread (option async_delivery) ----------------------------------------------------------------------------
-// A launch rich in survivors holds the thread that finishes it for as long as the output side needs for them - 13 M records of the
-// 2,504 x 531,500 run: 130 ms - and while it does, no launch is enqueued: the device idles (profiles/r05_delivery_thread.txt).
-// During a region call with a sink the finished launch's sorted survivors are therefore copied aside on the device (a millisecond
-// a gigabyte) and queued; a second thread takes the queue to the host, in order, through deliver_records.  The sink is then called
-// from that thread - one call at a time, in the order of the launches, as before.
-void delivery_loop(twk_hip_ctx* c) {
-	(void)hipSetDevice(c->device);
-	Delivery& d = c->dl;
-	if (!c->deliver_warm) {          // this thread's and this stream's first copy sets up a queue (tens of milliseconds): now, behind the first launches
-		uint32_t x = 0;
-		if (c->tickets && hipMemcpyAsync(&x, c->tickets, 4, hipMemcpyDeviceToHost, c->s_deliver) == hipSuccess) (void)hipStreamSynchronize(c->s_deliver);
-		c->deliver_warm = true;
-	}
-	for (;;) {
-		Delivery::Item it;
-		{
-			std::unique_lock<std::mutex> lk(d.mu);
-			d.cv.wait(lk, [&] { return d.stop || !d.q.empty(); });
-			if (d.q.empty()) return;
-			it = d.q.front(); d.q.pop_front(); d.busy = true;
-		}
-		int rc = TWK_HIP_OK;
-		if (!d.rc.load()) rc = deliver_records(c, it.p, it.n, it.sink, it.user, c->s_deliver, 0.0);
-		std::lock_guard<std::mutex> lk(d.mu);
-		if (rc && !d.rc.load()) d.rc.store(rc);
-		d.pool[it.buf].busy = false; d.busy = false;
-		if (d.q.empty()) d.cv_idle.notify_all();
-	}
-}
-void delivery_begin(twk_hip_ctx* c, twk_hip_record_sink sink, void* user) {
-	Delivery& d = c->dl;
-	if (d.active || !sink || c->device_sink || !c->opt.async_delivery) return;
-	(void)user; d.stop = false; d.rc.store(0);
-	try { d.th = std::thread(delivery_loop, c); } catch (...) { return; }      // (no thread to be had: the caller's thread delivers, as with the option off)
-	d.active = true;
-}
-// -> the delivery thread's result once everything queued has reached the sink
-int delivery_end(twk_hip_ctx* c) {
-	Delivery& d = c->dl;
-	if (!d.active) return TWK_HIP_OK;
-	{ std::lock_guard<std::mutex> lk(d.mu); d.stop = true; }
-	d.cv.notify_all();
-	d.th.join();
-	d.active = false;
-	for (auto& b : d.pool) if (b.p) (void)hipFree(b.p);
-	d.pool.clear();
-	return d.rc.load();
-}
+// ---- the delivery thread (option async_delivery; the queue itself: twk_delivery.h) -----------------------------------------------
+// During a region call with a sink a finished launch's sorted survivors are copied aside on the device (a millisecond a gigabyte) into
+// one of at most `deliver_buffers` staging buffers and queued; a second thread takes the queue to the host, in order, through
+// deliver_records.  The sink is then called from that thread - one call at a time, in the order of the launches, as before.
 int discard_records(void*, const twk_hip_record*, uint64_t);
+void delivery_begin(twk_hip_ctx* c, twk_hip_record_sink sink) {
+	if (c->dl.active() || !sink || c->device_sink || !c->opt.async_delivery) return;
+	c->dl_ops.c = c; c->dl_ops.n_alloc = 0; c->dl_ops.n_copy = 0;
+	(void)c->dl.begin(&c->dl_ops, (size_t)c->opt.deliver_buffers);      // (no thread to be had: the caller's thread delivers, as with the option off)
+}
+// -> the delivery thread's result once everything queued has reached the sink; its error text into c->err
+int delivery_end(twk_hip_ctx* c) {
+	if (!c->dl.active()) return TWK_HIP_OK;
+	const int rc = c->dl.end();
+	if (rc && c->dl.error()[0]) snprintf(c->err, sizeof(c->err), "%s", c->dl.error());
+	return rc;
+}
 // everything queued so far has reached its sink (the caller may then hand records over itself, in order: finish_tile does for launches with
 // few survivors, which are not worth a staging copy and a thread hand-off)
-int delivery_drain(twk_hip_ctx* c) {
-	Delivery& d = c->dl;
-	std::unique_lock<std::mutex> lk(d.mu);
-	d.cv_idle.wait(lk, [&] { return d.q.empty() && !d.busy; });
-	return d.rc.load();
-}
+int delivery_drain(twk_hip_ctx* c) { return c->dl.drain(); }
 int stage_for_delivery(twk_hip_ctx* c, const twk_hip_record* sorted, unsigned long long kept, twk_hip_record_sink sink, void* user) {
-	Delivery& d = c->dl;
-	if (d.rc.load()) return d.rc.load();
 	if (!kept || sink == discard_records) return TWK_HIP_OK;
-	size_t at = SIZE_MAX;
-	{
-		std::lock_guard<std::mutex> lk(d.mu);
-		for (size_t k = 0; k < d.pool.size(); ++k)
-			if (!d.pool[k].busy && d.pool[k].cap >= kept && (at == SIZE_MAX || d.pool[k].cap < d.pool[at].cap)) at = k;
-		if (at != SIZE_MAX) d.pool[at].busy = true;
+	const int rc = c->dl.stage(sorted, kept, sink, user);
+	if (rc == Delivery::STAGE_DELIVER_YOURSELF) {
+		// no room for a copy on the device: this thread hands the records over itself, behind what is queued (as with the option off)
+		(void)hipGetLastError();
+		const int drc = delivery_drain(c); if (drc) return drc;
+		return deliver_records(c, sorted, kept, sink, user, c->s_copy, 0.0);
 	}
-	if (at == SIZE_MAX) {
-		twk_hip_record* p = nullptr;
-		const unsigned long long cap = std::max<unsigned long long>(kept + kept / 8, 1ull << 16);
-		if (hipMalloc((void**)&p, (size_t)cap * sizeof(twk_hip_record)) != hipSuccess) {
-			// no room for a copy on the device: this thread hands the records over itself, behind what is queued (as with the option off)
-			(void)hipGetLastError();
-			const int rc = delivery_drain(c); if (rc) return rc;
-			return deliver_records(c, sorted, kept, sink, user, c->s_copy, 0.0);
-		}
-		std::lock_guard<std::mutex> lk(d.mu);
-		d.pool.push_back(Delivery::Buf{p, cap, true});
-		at = d.pool.size() - 1;
+	return rc;
+}
+// The calling thread is out of device memory (ensure_slot, regrow, sort_records): everything queued goes to the sink, the idle staging
+// buffers and what the call has outgrown so far are freed -> true when anything was given back (the allocation is then tried once more).
+bool reclaim_device_memory(twk_hip_ctx* c) {
+	(void)hipGetLastError();
+	size_t bytes = c->dl.active() ? c->dl.reclaim() : 0;
+	if (!c->graveyard.empty()) {
+		(void)hipDeviceSynchronize();            // (outgrown buffers may still be read by launches in flight)
+		for (void* p : c->graveyard) { (void)hipFree(p); ++bytes; }
+		c->graveyard.clear();
 	}
-	twk_hip_record* dst;
-	{ std::lock_guard<std::mutex> lk(d.mu); dst = d.pool[at].p; }
-	HIPCHK(c, hipMemcpyAsync(dst, sorted, (size_t)kept * sizeof(twk_hip_record), hipMemcpyDeviceToDevice, c->s_copy));
-	HIPCHK(c, hipStreamSynchronize(c->s_copy));
-	{ std::lock_guard<std::mutex> lk(d.mu); d.q.push_back(Delivery::Item{at, dst, kept, sink, user}); }
-	d.cv.notify_one();
-	return TWK_HIP_OK;
+	return bytes != 0;
 }
 
 // Wait for slot s, account timing, put its records in (idxA, idxB) order and hand them on: appended to the device sink
@@ -1272,7 +1255,7 @@ int finish_tile(twk_hip_ctx* c, Slot& s, const twk_hip_tile_desc& t, unsigned lo
 	if (!s.presorted) { rc = sort_records(c, s.out, s.keys, s.vals, n, dropped != 0, c->s_copy); if (rc) return rc; }
 	const twk_hip_record* sorted = s.presorted ? s.sorted : c->d_sorted;      // (a band launch sorted its own behind Fisher's test: enqueue_band_math)
 	*n_out = kept;
-	if (to_host && sink && c->dl.active) {
+	if (to_host && sink && c->dl.active()) {
 		// many survivors: the delivery thread takes them to the host (deliver_records) while this thread goes on with the launches; few
 		// (a hand-over of a millisecond or two): this thread does, behind whatever is queued
 		if (kept >= HOST_CHUNK / 4 || sink == discard_records) return stage_for_delivery(c, sorted, kept, sink, user);
@@ -1504,6 +1487,34 @@ bool valid_tile(const twk_hip_ctx* c, const twk_hip_tile_desc* t) {
 }
 
 }  // namespace
+
+void* HipDeliveryOps::alloc(size_t bytes) {
+	if (c->opt.deliver_fail_alloc_at && ++n_alloc == c->opt.deliver_fail_alloc_at) return nullptr;      // (test hook)
+	void* p = nullptr;
+	if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+	return p;
+}
+void HipDeliveryOps::release(void* p) { (void)hipFree(p); }
+int HipDeliveryOps::copy_aside(void* dst, const void* src, size_t bytes) {
+	if (c->opt.deliver_fail_copy_at && ++n_copy == c->opt.deliver_fail_copy_at) {      // (test hook)
+		snprintf(c->err, sizeof(c->err), "staging copy of a launch's survivors failed (option deliver_fail_copy_at)");
+		return TWK_HIP_E_DEVICE;
+	}
+	HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->s_copy));
+	HIPCHK(c, hipStreamSynchronize(c->s_copy));
+	return TWK_HIP_OK;
+}
+int HipDeliveryOps::deliver(const void* recs, uint64_t n, twk_hip_record_sink sink, void* user, char* err, size_t err_len) {
+	return deliver_records(c, static_cast<const twk_hip_record*>(recs), n, sink, user, c->s_deliver, 0.0, err, err_len);
+}
+void HipDeliveryOps::thread_begin() {
+	(void)hipSetDevice(c->device);
+	if (!c->deliver_warm) {          // this thread's and this stream's first copy sets up a queue (tens of milliseconds): now, behind the first launches
+		uint32_t x = 0;
+		if (c->tickets && hipMemcpyAsync(&x, c->tickets, 4, hipMemcpyDeviceToHost, c->s_deliver) == hipSuccess) (void)hipStreamSynchronize(c->s_deliver);
+		c->deliver_warm = true;
+	}
+}
 
 // ================================ C ABI =======================================================
 extern "C" {
@@ -2244,12 +2255,12 @@ int twk_hip_ld_region(twk_hip_ctx* c, int mode, const twk_hip_filters* f, uint32
                       uint32_t b0, uint32_t nB, int32_t triangle, uint32_t part, uint32_t n_parts,
                       uint32_t tile_variants, int32_t window, uint32_t l_window, twk_hip_record_sink sink,
                       void* user, uint64_t* n_pairs, uint64_t* n_records) {
-	if (c) delivery_begin(c, sink, user);
+	if (c) delivery_begin(c, sink);
 	int rc = region_dispatch(c, mode, f, a0, nA, b0, nB, triangle, part, n_parts, tile_variants, window, l_window, sink, user, n_pairs, n_records);
 	if (c) {                                // every record staged so far reaches the sink before the call returns, whatever the call's own result
 		(void)hipSetDevice(c->device);
 		const int drc = delivery_end(c);
-		if (rc == TWK_HIP_OK && drc) { rc = drc; snprintf(c->err, sizeof(c->err), "the record sink failed (or a copy to the host did)"); }
+		if (rc == TWK_HIP_OK && drc) rc = drc;            // (its text is in c->err: delivery_end)
 	}
 	if (c) flush_graveyard(c);               // buffers outgrown during the call: nothing is in flight any more
 	return rc;
@@ -2278,10 +2289,12 @@ static int region_dispatch(twk_hip_ctx* c, int mode, const twk_hip_filters* f, u
 		// run the plain matrix path in sorted order with a band that covers everything: twice the plane memory for nothing).
 		const int sset = mode == TWK_HIP_MODE_UNPHASED ? PS_SORTED_U : PS_SORTED_P;
 		bool keep_sorted = true;
-		if (f->minR2 < 1e-3) {
+		bool& known_useless = c->sorted_keeps_no_lists[sset == PS_SORTED_U ? 1 : 0];      // (every region call of a multi-step run used to build and drop the set again)
+		if (f->minR2 < 1e-3 && known_useless) keep_sorted = false;
+		else if (f->minR2 < 1e-3) {
 			const int rc = ensure_planes(c, sset); if (rc) return rc;
 			if (c->planes[sset].n_list < 2) {
-				keep_sorted = false;
+				keep_sorted = false; known_useless = true;
 				HIPCHK(c, hipDeviceSynchronize());
 				PlaneSet& ps = c->planes[sset];
 				if (ps.owns_rows && ps.rows) (void)hipFree(ps.rows);

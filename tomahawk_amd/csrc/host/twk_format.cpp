@@ -471,8 +471,9 @@ bool TwoWriter::write_packed(const Packed& p) {
 		uint8_t head[9];
 		head[0] = marker; std::memcpy(head + 1, &unc, 4); std::memcpy(head + 5, &cmp, 4);
 		const uint64_t bytes = 9 + p.z.size();
-		while (reserved_end_ < off_ + bytes) {               // space ahead of the writes (a hint: where it cannot be had the writes allocate as they go)
-			if (::fallocate(dfd_, FALLOC_FL_KEEP_SIZE, (off_t)reserved_end_, (off_t)(1ull << 30)) != 0 && errno == ENOSPC) return false;
+		while (reserved_end_ < off_ + bytes) {               // space ahead of the writes: a hint only - where a gigabyte ahead cannot be had (a small
+			// /dev/shm, a quota) the writes allocate as they go, and pwritev reports the ENOSPC that is real
+			(void)::fallocate(dfd_, FALLOC_FL_KEEP_SIZE, (off_t)reserved_end_, (off_t)(1ull << 30));
 			reserved_end_ += 1ull << 30;
 		}
 		struct iovec iov[2] = {{head, 9}, {const_cast<uint8_t*>(p.z.data()), p.z.size()}};
