@@ -45,3 +45,39 @@ def test_cubic_floor_is_bounded_even_when_the_root_error_model_says_infinity():
     ok[cubic[0]]["D"] += 0.5 * util.DX_CEILING
     util.assert_records_match(ok, want, variants, double_root=hopeless, count=False)
     assert util.ROOT_ERROR_FACTOR * 8.6e-12 < util.DX_CEILING < 5e-11 * util.ROOT_ERROR_FACTOR * 2
+
+
+def test_ledger_records_how_much_of_a_floor_was_used_not_how_much_was_granted():
+    """parity_exemptions.json's largest_floor_used_fraction: (|got - want| - rtol |want|) / floor of the record that came closest to its
+    floor - the need, where largest_floor reports the allowance (and sits at the ceiling whenever one badly conditioned record was seen).
+    A record that uses half of its floor or more fails the session."""
+    import collections
+    N, M = 200, 24
+    al = util.random_alleles(M, N, seed=11)
+    data, mask = O.bitvectors_from_alleles(al)
+    variants = O.variants_from_alleles(al)
+    want = O.all_pairs(data, mask, variants, N, O.settings(minR2=0.0, unphased=True), vector_only=True)
+    cubic = [i for i, r in enumerate(want) if not (int(r["controller"]) & 1) and abs(float(r["D"])) < 1e-4]
+    assert cubic
+    got = _as_device_records(want, variants)
+
+    def vet(*_):
+        return False
+    vet.root_error = lambda A, B, f11: (1e-11, 1.0, 1.0)              # floor on D: ROOT_ERROR_FACTOR x 1e-11 = 4e-11
+    keep = (dict(util.FLOOR_USED), dict(util.LARGEST_FLOOR), collections.Counter(util.EXEMPTIONS), collections.Counter(util.COMPARED))
+    try:
+        util.FLOOR_USED.clear()
+        off = got.copy()
+        off[cubic[0]]["D"] += 1e-11                                    # a quarter of the floor (the relative bar covers < 1e-10 of a D this small)
+        util.assert_records_match(off, want, variants, double_root=vet)
+        used = util.FLOOR_USED["D"]
+        assert 0.2 < used < 0.26, used
+        summary, bad = util.exemption_summary()
+        assert summary["largest_floor_used_fraction"] >= used and not [b for b in bad if "used" in b]
+        off[cubic[0]]["D"] += 1.5e-11                                  # now 2.5e-11 of 4e-11: passes the comparison, fails the session
+        util.assert_records_match(off, want, variants, double_root=vet)
+        assert util.FLOOR_USED["D"] > util.FLOOR_USE_CAP
+        assert [b for b in util.exemption_summary()[1] if "used" in b]
+    finally:
+        util.FLOOR_USED.clear(); util.FLOOR_USED.update(keep[0]); util.LARGEST_FLOOR.update(keep[1])
+        util.EXEMPTIONS.clear(); util.EXEMPTIONS.update(keep[2]); util.COMPARED.clear(); util.COMPARED.update(keep[3])

@@ -37,10 +37,15 @@ EXEMPTION_CAPS = {"floor:D": 3e-4, "floor:Dprime": 3e-4, "floor:R": 3e-4, "floor
 def exemption_summary():
     """Session totals + whether every kind stays under its cap -> (dict, list of violations)."""
     out = {"compared": dict(COMPARED), "exemptions": dict(EXEMPTIONS), "rates": {}, "caps": dict(EXEMPTION_CAPS),
-           "largest_floor": {"dx_f11_scale": LARGEST_FLOOR["dx"], "ceiling": DX_CEILING}}
+           "largest_floor": {"dx_f11_scale": LARGEST_FLOOR["dx"], "ceiling": DX_CEILING},
+           "largest_floor_used_fraction": max(FLOOR_USED.values(), default=0.0), "floor_used_fraction_by_field": dict(FLOOR_USED),
+           "floor_use_cap": FLOOR_USE_CAP}
     bad = []
     if LARGEST_FLOOR["dx"] > DX_CEILING:
         bad.append(f"largest cubic floor granted {LARGEST_FLOOR['dx']:.3g} > ceiling {DX_CEILING:g}")
+    for field, used in FLOOR_USED.items():
+        if used >= FLOOR_USE_CAP:
+            bad.append(f"a record used {used:.3g} of the floor its conditioning grants on {field} (cap {FLOOR_USE_CAP:g})")
     for kind, cap in EXEMPTION_CAPS.items():
         denom = COMPARED["records"] if kind in ("p-floor", "p-denormal", "tie:fisher-stop") else COMPARED["cubic"]
         rate = EXEMPTIONS[kind] / denom if denom else 0.0
@@ -254,6 +259,11 @@ ROOT_ERROR_FACTOR = 4.0
 # a session actually granted is written to parity_exemptions.json ("largest_floor") and held to the same ceiling there.
 DX_CEILING = 2e-10
 LARGEST_FLOOR = {"dx": 0.0}          # largest dx (f11 scale) behind a floor that a comparison actually needed
+# ... and how much of its floor a record that needed one actually USED: (|got - want| - rtol |want|) / floor, per field, the largest over
+# the session.  The figure above reports the allowance (and sits at the ceiling whenever one badly conditioned record was compared); this one
+# reports the need.  Held below FLOOR_USE_CAP: a record that uses half of what its conditioning grants is a reason to look.
+FLOOR_USED = {}                      # field -> largest used fraction
+FLOOR_USE_CAP = 0.5
 
 
 def cubic_floors(cnt, r, dx):
@@ -358,6 +368,9 @@ def assert_records_match(gpu_recs, orc_recs, variants, n_samples=None, rtol=1e-6
                 bad.append((k, "cnt", g["cnt"].tolist(), w["cnt"].tolist(), cnt_floor))
             elif not np.allclose(g["cnt"], w["cnt"], rtol=rtol, atol=0.0):
                 used["floor:cnt"] += 1
+                if count and cnt_floor > 0 and np.isfinite(cnt_floor):
+                    need = float(np.max(np.abs(g["cnt"] - w["cnt"]) - rtol * np.abs(w["cnt"])))
+                    FLOOR_USED["cnt"] = max(FLOOR_USED.get("cnt", 0.0), need / cnt_floor)
             if (int(g["flags"]) ^ int(w["controller"])) & (1 << 5):
                 # root multiplicity may flip when a second root sits on the admissibility boundary
                 ties.append((k, "roots"))
@@ -368,6 +381,9 @@ def assert_records_match(gpu_recs, orc_recs, variants, n_samples=None, rtol=1e-6
                 used["floor:" + f] += 1
                 if count and f == "D":
                     LARGEST_FLOOR["dx"] = max(LARGEST_FLOOR["dx"], float(atol))
+                if count and np.isfinite(atol):
+                    need = abs(float(g[f]) - float(w[f])) - rtol * abs(float(w[f]))
+                    FLOOR_USED[f] = max(FLOOR_USED.get(f, 0.0), need / float(atol))
         # Fisher P underflows to exactly 0 for strong associations: absolute floor.
         # UnphasedMath runs Fisher on round(expected counts) (ld_engine.cpp:1656).  The expected counts
         # are only as good as the cubic root (above), so when one of them lies within that error of a
