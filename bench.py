@@ -350,9 +350,9 @@ def extra_kg(log):
                                    "window_4mb": "72.1 M pairs/s (4,784,608 variants)"}}
     out["all_pairs"] = timed_cli("kg_all", twk, ["-p"], threads, log, runs=1, warm=True)
     out["window_4mb"] = timed_cli("kg_w4m", twk, ["-p", "-w", "4000000"], threads, log, runs=1, warm=False)
-    # the same run with the output blocks' zstd frames from the records' own encoder (csrc/host/twk_repcodec.h; off by default:
-    # the file is a few per cent larger than libzstd level 1 makes it) - what is left is the one stream into the file
-    out["window_4mb_record_codec"] = timed_cli("kg_w4m_codec", twk, ["-p", "-w", "4000000", "--engine-option", "record_codec=1"], threads, log, runs=1, warm=False)
+    # (the default since round 6: at -k 1 the output blocks' zstd frames come from the records' own encoder, csrc/host/twk_repcodec.h - a file
+    # a few per cent larger, written without libzstd's level-1 match search on the critical path)  The same run through libzstd, as in round 5:
+    out["window_4mb_libzstd"] = timed_cli("kg_w4m_libzstd", twk, ["-p", "-w", "4000000", "--engine-option", "record_codec=0"], threads, log, runs=1, warm=False)
     return out
 
 

@@ -385,7 +385,7 @@ def test_cli_hand_off_queue_writes_the_same_file(tmp_path):
 
 @pytest.mark.gpu
 def test_cli_record_codec_writes_the_same_records_and_the_reference_reads_them(tmp_path):
-    """`--engine-option record_codec=1`: the output blocks' zstd frames come from the records' own encoder
+    """The default at `-k 1` (round 6; `--engine-option record_codec=0` for libzstd): the output blocks' zstd frames come from the records' own encoder
     (csrc/host/twk_repcodec.h) or, where its 32 KiB sample comes out a quarter larger than libzstd's, from libzstd as before.
     Two inputs: 1,200 samples (noisy statistics: the encoder's kind of block - the file must differ from the default's and stay
     within 15 % of it) and 64 samples (few distinct values: left to libzstd, same size).  Either way the records, the blocks and
@@ -396,16 +396,20 @@ def test_cli_record_codec_writes_the_same_records_and_the_reference_reads_them(t
         twk = str(tmp_path / f"in{N}.twk")
         hostlib.write_twk(twk, al, (1000 + 10 * np.arange(M)).astype(np.uint32), np.zeros(M, np.uint32), np.ones(M, np.uint8), block_size=100)
         got = {}
-        for codec in (0, 1):
+        for codec in (0, 1, "default", "k3"):
             out = str(tmp_path / f"c{N}_{codec}.two")
-            r = subprocess.run([hostlib.CLI_PATH, "calc", "-i", twk, "-o", out, "-p", "-r", "0", "-P", "1", "--engine-option", f"record_codec={codec}"],
-                               capture_output=True, text=True)
+            extra = ["--engine-option", f"record_codec={codec}"] if codec in (0, 1) else ["-k", "3"] if codec == "k3" else []
+            r = subprocess.run([hostlib.CLI_PATH, "calc", "-i", twk, "-o", out, "-p", "-r", "0", "-P", "1"] + extra, capture_output=True, text=True)
             assert r.returncode == 0, r.stderr
             recs, info = hostlib.read_two(out)
             state, ent, _ = hostlib.two_index(out)
             got[codec] = (hashlib.sha256(recs.tobytes()).hexdigest(), info["n_blocks"], ent[:, :5].tolist(), os.path.getsize(out), out)
             assert len(recs) > 300_000
-        assert got[0][:3] == got[1][:3]
+        assert got[0][:3] == got[1][:3] == got["default"][:3] == got["k3"][:3]
+        # the default (-k 1, the reference's) takes the records' encoder; -k 3 asks for ratio and gets libzstd at that level
+        assert abs(got["default"][3] - got[1][3]) < 200
+        if want_codec:
+            assert got["k3"][3] < got[1][3] and got[0][3] < got[1][3]
         if want_codec:
             assert got[0][3] != got[1][3] and got[1][3] < 1.15 * got[0][3]
         else:
