@@ -30,7 +30,8 @@ extern "C" {
  *    its structs in: compare twk_hip_abi_version() with the header it was compiled with. */
 /* 3: twk_hip_set_option / twk_hip_get_option; the library no longer reads environment variables. */
 /* 4: twk_hip_timing grew (three-product launches); option "three". */
-/* 5: twk_hip_generate_synthetic_planted / twk_synth_planted_bitvector / twk_synth_plant_source (synthetic input with planted LD pairs). */
+/* 5: twk_hip_generate_synthetic_planted / twk_synth_planted_bitvector / twk_synth_plant_source (synthetic input with planted LD pairs);
+ *    twk_hip_option_describe; twk_hip_timing grew (three_wide_row_pairs, finish_ms). */
 #define TWK_HIP_ABI_VERSION 5
 
 enum {
@@ -331,54 +332,21 @@ int twk_hip_fisher_exact(twk_hip_ctx* ctx, const int32_t* tables, uint64_t n, do
 /* Measurement and test switches of one ctx, by name.  The library reads NO environment variable: a process that
  * embeds it gets the documented defaults unless it calls this.  There is no reference counterpart (the reference's
  * closest relative is the compile-time SLAVE_DEBUG_MODE / SIMD_AVAILABLE switches, lib/ld/ld_engine.h:20-24).
- *   key                default  meaning
- *   "fused"            1        fused count -> r2 screen kernel: 0 never, 1 rows of <= 128 K-chunks, 2 always
- *   "lists"            1        carrier lists for the rare head of the sorted plane sets: 0 never, 1 rows of >= 4096
- *                               words, 2 always (lists of >= 8 carriers)
- *   "list_max"         0        longest carrier list kept (0: row words / 128, / 64 for unphased math)
- *   "probe"            1        pairs of a listed variant with one that keeps no list: probes of its carriers into the
- *                               partner's row instead of the dense contraction (0: dense)
- *   "record_cap"       0        cap on a launch's survivor buffer in records (0: none) - forces the overflow path: a matrix-sized tile
- *                               is redone in row strips, a band launch as matrix-sized tiles
- *   "count_min_chunks" 8        shortest K range a tile of the count kernel is split into
- *   "patch_rows/_cols" 8 / 8    patch of tiles in the count kernel's work order
- *   "seg"              0        walk a patch in K segments of this many chunks (0: whole tiles)
- *   "xcd_queues"       0        one unit queue per XCD (2..8; 0: one queue)
- *   "skip_pad"         1        leave the zero padding behind a row's last live 8 bytes uncontracted
- *   "fisher_order"     1        Fisher walks binned by length
- *   "fisher_lds"       1        log-factorial table in LDS while it fits
- *   "cand_chunk"       -1       candidate slots a wave reserves at a time (-1: sized from the list)
- *   "band_launch"      1        fused runs: launches sized by their work (a band of rows over all the columns it reaches,
- *                               at most 8 per region, at least ~5 ms of work each) instead of by a count matrix; 0: matrix-sized tiles only
- *   "band_work_log2"   19       ... of at least 2^n tile-chunks each (19: about 5 ms of contraction)
- *   "band_max_launches" 8       ... and at most this many per region
- *   "probe_zone"       1        rows with a list short enough to probe take every column behind them that way, the list
- *                               zone's own included (0: pairs inside the zone are merges of two lists)
- *   "probe_unroll"     4        list entries the unphased probe kernel takes at a time (1, 2, 4: their loads in flight together)
- *   "band_reverse"     1        allele-count-sorted runs: the last band (commonest variants, most survivors) first
- *   "timeline"         0        1: the host's steps through a region's launch pipeline, with times, on stderr
- *   "band_list_entries" 0       candidate slots of such a launch (0: 1/32 of its pairs, 4 M .. 256 M); a launch that
- *                               outgrows them, or its survivor buffer, is redone as matrix-sized tiles
- *   "probe_lds"        1        probe kernels: the column rows are staged into LDS segment by segment and the carriers tested there
- *                               (512 zone rows x 4 columns a block; 2 columns of unphased planes); 0: gathers from L2, as chosen by
- *   "probe_cols"       0        ... a strip of 2 / 4 / 8 / 16 columns a block, every list entry probing all of them (unphased planes: half as
- *                               many); 0: one column per block (the round-4 kernels)
- *   "three"            1        UnphasedMath on planes without missing genotypes, r2 cut-off > 1e-6: contract three products per
- *                               pair (HH and S = QH + HQ + 2 QQ, all the screen reads) and recount the four products of the pairs
- *                               that pass; 0: four products for every pair; 2: keep to it even when a launch was candidate-rich
- *   "three_wide"       1        ... through a count matrix (rows too long to fuse) on the wide lane tile: a lane holds four x four variant pairs, the
- *                               block's eight waves are 2 x 2 over the tile x the two halves of a chunk's K range, both halves add into the matrix
- *                               (k_count3w_list_t); 0: four x two variants a lane, whole tiles stored (k_count3_list_t) - same counts, 4 % slower
- *   "async_delivery"   1        region calls with a sink: a finished launch's sorted survivors are copied aside on the device and
- *                               a second thread of the engine takes them to the host and calls the sink - in the launches' order,
- *                               one call at a time - while the calling thread goes on enqueueing launches; 0: the calling thread
- *                               does both (round 4)
+ * The keys, their defaults, ranges and meaning are ONE table in the engine (TWK_HIP_OPTIONS, csrc/hip/twk_hip.hip), readable through
+ * twk_hip_option_describe() below and printed as the table of INTEGRATION.md 1 (tests/test_docs_consistency.py keeps the document in
+ * step with it).  In short: "fused", "three", "three_wide" pick the form of the contraction; "lists", "list_max", "probe", "probe_zone",
+ * "probe_lds" the carrier-list passes for rare variants; "band_*" the launches of fused runs; "patch_rows" / "patch_cols" / "seg" /
+ * "xcd_queues" / "skip_pad" / "count_min_chunks" / "cand_chunk" the count kernel's work order; "fisher_*" Fisher's test;
+ * "async_delivery", "deliver_buffers" the engine's delivery thread; "record_cap", "deliver_fail_*_at" are test hooks; "timeline" a log.
  * Keys of the host side (`tomahawk calc --engine-option`, twk_ld::SetEngineOption - handled in csrc/host/twk_ld.cpp, unknown to this
  * function): "force_device", "progress_ms", "map_output", "emit_workers", "emit_backlog_mb", "emit_queue_pieces", "record_codec", "direct_output" (INTEGRATION.md 1).
  * None of them changes a record (tests/test_gpu_fused.py, test_gpu_lists.py); "lists" / "list_max" drop the derived
  * plane sets, which are rebuilt on next use.  Unknown key or value out of range: TWK_HIP_E_INVALID. */
 int twk_hip_set_option(twk_hip_ctx* ctx, const char* key, int64_t value);
 int twk_hip_get_option(const twk_hip_ctx* ctx, const char* key, int64_t* value);
+/* Entry `index` (0, 1, ... until TWK_HIP_E_INVALID) of the engine's option table: key, default, range, one line of meaning (static strings;
+ * any pointer may be NULL).  Needs no device and no ctx. */
+int twk_hip_option_describe(uint32_t index, const char** key, int64_t* dflt, int64_t* lo, int64_t* hi, const char** meaning);
 
 /* ---- measurement ------------------------------------------------------ */
 /* Cumulative device time (HIP events on the engine's own stream) and launch

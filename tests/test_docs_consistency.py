@@ -37,12 +37,19 @@ def test_the_engine_library_reads_no_environment_and_its_switches_are_documented
     for f in os.listdir(host_dir):
         host_env |= set(re.findall(r'getenv\("([A-Z0-9_]+)"\)', _read(host_dir, f)))
     assert host_env == {"TWK_HIP_DEVICE", "TWK_HIP_GPUS", "TWK_HIP_PART", "TWK_REF_COMPAT", "TWK_HIP_NO_SCREEN"}, host_env
-    keys = re.findall(r'\{"([a-z_]+)", &Options::', _read(hip_dir, "twk_hip.hip"))
-    assert len(keys) >= 13
-    header, guide = _read("include", "twk_hip.h"), _read("INTEGRATION.md")
-    for k in keys:
-        stem = k[:-5] if k.endswith(("_rows", "_cols")) else k          # "patch_rows/_cols" is one line of the header's table
-        assert stem in header and k in guide, k
+    # ONE option table: the engine's own (TWK_HIP_OPTIONS -> twk_hip_option_describe), printed into INTEGRATION.md between its markers
+    import tomahawk_amd.hip as H
+    table = H.option_table()
+    assert len(table) >= 25 and len({k for k, *_ in table}) == len(table)
+    for key, dflt, lo, hi, doc in table:
+        assert lo <= dflt <= hi and len(doc) > 10, key
+    guide = _read("INTEGRATION.md")
+    block = guide[guide.index("<!-- engine options:"):guide.index("<!-- /engine options -->")]
+    assert block.split("-->", 1)[1].strip() == H.option_table_markdown().strip(), "INTEGRATION.md's option table is stale: regenerate it with tomahawk_amd.hip.option_table_markdown()"
+    # the header names every family of keys and points at the table; nothing else in the repository carries a second table of them
+    header = _read("include", "twk_hip.h")
+    assert "twk_hip_option_describe" in header and "INTEGRATION.md" in header
+    assert not re.search(r'^ \*   "[a-z_]+"\s+-?\d+\s', header, re.M), "include/twk_hip.h carries an option table of its own again"
 
 
 def test_profiles_readme_names_only_files_that_exist():

@@ -168,8 +168,8 @@ def test_probe_pass_equals_dense_and_merges_only(hip, opt, mode, N, forced):
              # them the zone's pairs are still merged and probed (calc -r 0.0009 at N = 1 M: DESIGN 3.5)
              lambda: hip.ld_all(mode, T.Filters(minR2=0.0007), window=T.OPT_R2_SCREEN)[0]]
 
-    def run(lists, probe, cap=0, probe_zone=1, probe_cols=0, probe_lds=1):
-        opt.set("lists", lists); opt.set("probe", probe); opt.set("record_cap", cap); opt.set("probe_zone", probe_zone); opt.set("probe_cols", probe_cols); opt.set("probe_lds", probe_lds)
+    def run(lists, probe, cap=0, probe_zone=1, probe_lds=1):
+        opt.set("lists", lists); opt.set("probe", probe); opt.set("record_cap", cap); opt.set("probe_zone", probe_zone); opt.set("probe_lds", probe_lds)
         hip.set_problem(N, M)
         hip.upload(data, util.to_hip_meta(variants), None)
         out = []
@@ -185,9 +185,9 @@ def test_probe_pass_equals_dense_and_merges_only(hip, opt, mode, N, forced):
     tiny = run(2 if forced else 1, 1, cap=60)
     # probes for the columns beyond the zone only: the zone's own pairs are merges of two lists (round 4's first form)
     outer = run(2 if forced else 1, 1, probe_zone=0)
-    # the probes as gathers from L2 instead of through LDS (k_probe_lds_t, the default): one column per block (the round-4 kernels), a strip of columns
+    # the probes as gathers from L2 instead of through LDS (k_probe_lds_t, the default): one column per block (the round-4 kernels)
     single = run(2 if forced else 1, 1, probe_lds=0)
-    single_outer = run(2 if forced else 1, 1, probe_zone=0, probe_lds=0, probe_cols=8)
+    single_outer = run(2 if forced else 1, 1, probe_zone=0, probe_lds=0)
     for k, (d, m, p, t, o, s1, s2) in enumerate(zip(dense, merges, probes, tiny, outer, single, single_outer)):
         assert d[1] > 20 and d[0] == m[0] == p[0] == t[0] == o[0] == s1[0] == s2[0], (k, d[1], m[1], p[1], t[1], o[1], s1[1], s2[1])
         assert s1[2]["probe_pairs"] == p[2]["probe_pairs"] and s1[2]["candidates"] == p[2]["candidates"], (k, s1[2], p[2])

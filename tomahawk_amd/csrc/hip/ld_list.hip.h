@@ -370,162 +370,11 @@ void k_probe_screen_unphased_t(const ProbeWork p, uint32_t n_samples) {
 	}
 }
 
-// ---- the same probes, a strip of columns at a time (round 5) -----------------------------------------------------------
-// k_probe_screen / k_probe_screen_unphased_t above run one column per block: every lane re-reads its whole list for every
-// column (lists of a zone are tens of megabytes: from beyond L2) and has four gathers in flight.  Here a block is 256 zone rows
-// against a strip of C consecutive columns, and the loops are the other way round: a lane takes ONE list entry and probes all C
-// column rows with it - the entry is read once per strip instead of once per column, the C gathers (same word offset in C rows:
-// one address register, C scalar row bases) are independent and in flight together, and the lane keeps C running counts in
-// registers.  Blocks of one strip are neighbours in the grid (block id = strip x row blocks + row block), so the strip's C
-// rows (C x 250 KB at a million samples) stay in L2 while the zone works through them.  One candidate reservation per wave and
-// strip.  Same counts, same screen, same candidates as the one-column kernels (tests/test_gpu_lists.py compares the records).
-template <int C>
-__global__ __launch_bounds__(256)
-void k_probe_strip_t(const ProbeWork p) {
-	const ListWork& w = p.lw;
-	const uint32_t sb = blockIdx.x / p.n_row_blocks, rb = blockIdx.x - sb * p.n_row_blocks;
-	const uint32_t i = w.row0 + rb * 256 + threadIdx.x, j0 = p.col0 + sb * C;
-	const uint32_t col_end = p.col0 + p.n_cols;
-	const bool row_ok = i < w.row0 + w.n_rows;
-	const uint32_t limit0 = row_ok ? (w.col_hi ? w.hi_b0 + w.col_hi[i - w.hi_a0] : 0xFFFFFFFFu) : 0u;
-	const uint32_t limit = limit0 < col_end ? limit0 : col_end;          // first column the row does not take
-	const bool any = row_ok && j0 < limit && j0 + C > i + 1;              // some column of the strip lies in (i, limit)
-	const uint32_t na = any ? w.mac[i] : 0u;
-	const uint32_t* a = w.lists + (size_t)i * w.stride;
-	const uint32_t* base = p.rows + (size_t)j0 * p.W;                     // (uniform) row of the strip's first column
-	uint32_t x[C];
-#pragma unroll
-	for (int c = 0; c < C; ++c) x[c] = 0;
-	uint32_t h = na ? a[0] : 0u;
-	for (uint32_t k = 0; k < na; ++k) {
-		const uint32_t hn = k + 1 < na ? a[k + 1] : 0u;                   // the next entry travels behind this one's gathers
-		const uint32_t off = h >> 5, sh = h & 31u;
-		uint32_t r[C];
-#pragma unroll
-		for (int c = 0; c < C; ++c) r[c] = (base + (size_t)c * p.W)[off];
-#pragma unroll
-		for (int c = 0; c < C; ++c) x[c] += (r[c] >> sh) & 1u;
-		h = hn;
-	}
-	uint32_t keepmask = 0;
-	if (any) {
-		const uint32_t acA = w.rowpop[i];
-		const bool flip = w.flip[i] != 0;
-		const double da = (double)acA, fA = w.cut * (da * (w.two_n - da));
-#pragma unroll
-		for (int c = 0; c < C; ++c) {
-			const uint32_t j = j0 + c;
-			if (j < limit && j > i) {                                  // (j > i: columns inside the zone - the triangle's other half belongs to row j)
-				const uint32_t acB = w.rowpop[j];
-				x[c] = flip ? acB - x[c] : x[c];                        // the list holds the carriers of A's minor allele: ALT, or (flip) REF - then ALT_A & ALT_B = ALT_B minus those
-				const double db = (double)acB;
-				const double dn = w.two_n * (double)x[c] - da * db;
-				if (dn != 0.0 && dn * dn >= fA * (db * (w.two_n - db))) keepmask |= 1u << c;
-			}
-		}
-	}
-	if (__ballot(keepmask != 0)) {
-		const int lane = threadIdx.x & 63;
-		const uint32_t cnt = __popc(keepmask);
-		const uint32_t incl = wave_scan_inclusive(cnt);
-		const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-		unsigned long long first = 0;
-		if (lane == 0) first = atomicAdd(w.n_cand, (unsigned long long)total);
-		first = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)first) | (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(first >> 32)) << 32;
-		unsigned long long slot = first + (incl - cnt);
-#pragma unroll
-		for (int c = 0; c < C; ++c)
-			if ((keepmask >> c) & 1u) {
-				if (slot < w.cap) { uint32_t* e = w.cand + slot * 3; e[0] = i; e[1] = j0 + c; e[2] = x[c]; }
-				++slot;
-			}
-	}
-}
-
-template <int C>
-__global__ __launch_bounds__(256)
-void k_probe_strip_unphased_t(const ProbeWork p) {
-	const ListWork& w = p.lw;
-	const uint32_t sb = blockIdx.x / p.n_row_blocks, rb = blockIdx.x - sb * p.n_row_blocks;
-	const uint32_t i = w.row0 + rb * 256 + threadIdx.x, j0 = p.col0 + sb * C;
-	const uint32_t col_end = p.col0 + p.n_cols;
-	const bool row_ok = i < w.row0 + w.n_rows;
-	const uint32_t limit0 = row_ok ? (w.col_hi ? w.hi_b0 + w.col_hi[i - w.hi_a0] : 0xFFFFFFFFu) : 0u;
-	const uint32_t limit = limit0 < col_end ? limit0 : col_end;
-	const bool any = row_ok && j0 < limit && j0 + C > i + 1;
-	const uint32_t na = any ? w.mac[i] : 0u;
-	const uint32_t* a = w.lists + (size_t)i * w.stride;
-	const uint32_t* base = p.rows + (size_t)(2 * j0) * p.W;               // (uniform) H row of the strip's first column; its Q row follows, then the next column's H row
-	// per column four 16-bit counters [gA][class of B: 0 het, 1 hom-alt], two to a 32-bit word: x0 for A's hets, x1 for its rare homozygotes
-	// (32-bit words, no 64-bit shifts: see k_probe_screen_unphased_t)
-	uint32_t x0[C], x1[C];
-#pragma unroll
-	for (int c = 0; c < C; ++c) { x0[c] = 0; x1[c] = 0; }
-	uint32_t e = na ? a[0] : 0u;
-	for (uint32_t k = 0; k < na; ++k) {
-		const uint32_t en = k + 1 < na ? a[k + 1] : 0u;
-		const uint32_t off = e >> 6, sm = (e >> 1) & 31u;
-		const bool rare = (e & 1u) != 0;
-		uint32_t hw[C], qw[C];
-#pragma unroll
-		for (int c = 0; c < C; ++c) { hw[c] = (base + (size_t)(2 * c) * p.W)[off]; qw[c] = (base + (size_t)(2 * c + 1) * p.W)[off]; }
-#pragma unroll
-		for (int c = 0; c < C; ++c) {
-			const uint32_t add = ((hw[c] >> sm) & 1u) | (((qw[c] >> sm) & 1u) << 16);
-			x0[c] += rare ? 0u : add;
-			x1[c] += rare ? add : 0u;
-		}
-		e = en;
-	}
-	uint32_t keepmask = 0;
-	uint32_t HQ_[C], QH_[C], QQ_[C];
-	if (any) {
-		const uint32_t hA = w.rowpop[2 * i], qA = w.rowpop[2 * i + 1];
-		const bool flip = w.flip[i] != 0;
-		const double T = w.two_n, eps = 1e-5 * (T * T);
-		const double da = (double)(hA + 2u * qA), ra = T - da, fA = w.cut * (da * ra);
-#pragma unroll
-		for (int c = 0; c < C; ++c) {
-			const uint32_t j = j0 + c;
-			HQ_[c] = 0; QH_[c] = 0; QQ_[c] = 0;
-			if (j < limit && j > i) {
-				const uint32_t hB = w.rowpop[2 * j], qB = w.rowpop[2 * j + 1];
-				const uint32_t x0h = x0[c] & 0xFFFFu, x0q = x0[c] >> 16, x1h = x1[c] & 0xFFFFu, x1q = x1[c] >> 16;
-				const uint32_t HH = x0h, HQ = x0q;
-				uint32_t QH, QQ;
-				if (!flip) { QH = x1h; QQ = x1q; }                                   // A's hom-alt samples are the listed rare homozygotes
-				else { QH = hB - x0h - x1h; QQ = qB - x0q - x1q; }                     // A's hom-alt samples are everyone *not* listed
-				const double db = (double)(hB + 2u * qB), rbb = T - db;
-				const double n11 = (ra - db) + (double)(QH + HQ + 2u * QQ);
-				const double e_lo = (n11 * T - ra * rbb) - eps, e_hi = ((n11 + (double)HH) * T - ra * rbb) + eps;
-				const double bound = fA * (db * rbb);
-				if (!(e_lo * e_lo < bound && e_hi * e_hi < bound)) { keepmask |= 1u << c; x0[c] = HH; HQ_[c] = HQ; QH_[c] = QH; QQ_[c] = QQ; }
-			}
-		}
-	}
-	if (__ballot(keepmask != 0)) {
-		const int lane = threadIdx.x & 63;
-		const uint32_t cnt = __popc(keepmask);
-		const uint32_t incl = wave_scan_inclusive(cnt);
-		const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-		unsigned long long first = 0;
-		if (lane == 0) first = atomicAdd(w.n_cand, (unsigned long long)total);
-		first = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)first) | (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(first >> 32)) << 32;
-		unsigned long long slot = first + (incl - cnt);
-#pragma unroll
-		for (int c = 0; c < C; ++c)
-			if ((keepmask >> c) & 1u) {
-				if (slot < w.cap) { uint32_t* o = w.cand + slot * 6; o[0] = i; o[1] = j0 + c; o[2] = x0[c]; o[3] = HQ_[c]; o[4] = QH_[c]; o[5] = QQ_[c]; }
-				++slot;
-			}
-	}
-}
-
 // ---- probes through LDS (round 5) ---------------------------------------------------------------------------------------
 // What bounds the probe kernels above is not latency but requests: every probe is a gather of one word from a 250 KB row -
 // its own cache line, its own request to L2 - and every list entry read is another (a block's lists do not fit the CU's L1):
-// two L2 requests per (pair, carrier), 2.4e11 a second on the whole chip (the strip kernels, with 16 gathers in flight per lane
-// instead of 4, are no faster: profiles/r05_probe_kernels.txt).  Here the column rows come to the probes instead: a block is
+// two L2 requests per (pair, carrier), 2.4e11 a second on the whole chip (round 5's strip kernels - a block against a strip of columns, 16
+// gathers in flight per lane instead of 4 - were slower at every width and are gone: profiles/r05_probe_kernels.txt).  Here the column rows come to the probes instead: a block is
 // PROBE_ROWS zone rows against C columns, and walks the columns' rows segment by segment - SEGW words of each of the C rows are
 // copied into LDS with coalesced 16-byte loads (1/2 KB per pair instead of one line per carrier), and every lane tests the
 // carriers of its (ascending) list that fall into the segment against all C rows *in LDS*: C ds_read_b32 per carrier, no L2

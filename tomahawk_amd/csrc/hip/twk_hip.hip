@@ -131,51 +131,48 @@ struct ColRange { const uint32_t* lo = nullptr; const uint32_t* hi = nullptr; ui
 namespace {
 // Measurement and test switches (twk_hip_set_option): what used to be TWK_HIP_* environment variables.  The library
 // reads no environment variable; a host that embeds it gets the defaults below unless it says otherwise.
+// ONE table - X(key, default, lowest, highest, drops the derived plane sets, meaning): the Options struct, the key table of
+// twk_hip_set_option / twk_hip_get_option and - through twk_hip_option_describe - the table of INTEGRATION.md 1 all come from it
+// (tests/test_docs_consistency.py holds the document to it).
+#define TWK_HIP_OPTIONS(X) \
+	X(fused, 1, 0, 2, false, "fused count -> r2 screen kernel (no count matrix; DESIGN 3.2a): 0 never, 1 rows of <= 128 K chunks, 2 always") \
+	X(three, 1, 0, 2, false, "UnphasedMath on planes without missing genotypes, r2 cut-off > 1e-6: contract three products a pair (HH and S = QH + HQ + 2 QQ: all the screen reads) and recount the four products of the pairs that pass (DESIGN 3.1a); 0: four products for every pair; 2: keep to three whatever a launch's candidate density (1 samples every launch first)") \
+	X(three_wide, 1, 0, 1, false, "... through a count matrix (rows too long to fuse) on the wide lane tile: four x four variants a lane, the block's waves split over the halves of a chunk's K range, both halves add into the matrix (k_count3w_list_t); 0: four x two variants a lane, whole tiles stored (k_count3_list_t): same counts, 4 % slower (profiles/r06_three_tile.txt)") \
+	X(count_min_chunks, 8, 1, 1 << 20, false, "shortest K range a tile of the count kernel is split into at the end of a launch (test hook: 1 splits short rows too)") \
+	X(patch_rows, 8, 1, 4096, false, "rows of a patch of tiles in the count kernel's work order (DESIGN 3.1, profiles/r03_patch_pmc.txt)") \
+	X(patch_cols, 8, 1, 4096, false, "... and its columns") \
+	X(seg, 0, 0, 1 << 20, false, "walk a patch in K segments of this many chunks (0: whole tiles)") \
+	X(xcd_queues, 0, 0, 8, false, "one unit queue per XCD (2..8; 0: one queue): -42 % fabric traffic at +0.5 % kernel time") \
+	X(skip_pad, 1, 0, 1, false, "leave the zero padding behind a row's last live 8 bytes uncontracted (0: contract it)") \
+	X(cand_chunk, -1, -1, 1 << 20, false, "candidate slots a wave of the fused kernels reserves at a time (-1: sized from the list)") \
+	X(lists, 1, 0, 2, true, "carrier lists for the rare head of the allele-count-sorted plane sets (DESIGN 3.5): 0 never, 1 rows of >= 4096 words, 2 always (lists of >= 8 carriers)") \
+	X(list_max, 0, 0, 60000, true, "longest carrier list kept (0: row words / 128, / 64 for UnphasedMath)") \
+	X(probe, 1, 0, 1, false, "pairs of a listed variant with one that keeps no list: probes of its carriers into the partner's row (0: the dense contraction)") \
+	X(probe_zone, 1, 0, 1, false, "rows with a list short enough to probe take every column behind them that way, the list zone's own included (0: pairs inside the zone are merges of two lists)") \
+	X(probe_lds, 1, 0, 1, false, "probe kernels: the column rows are staged into LDS segment by segment and the carriers tested there (512 zone rows x 4 columns a block; 2 columns of unphased planes); 0: gathers from L2, one column a block (the twin the LDS form is tested against)") \
+	X(band_launch, 1, 0, 1, false, "fused runs: launches sized by their work - a band of rows over all the columns it reaches - instead of by a count matrix; 0: matrix-sized tiles only") \
+	X(band_work_log2, 19, 0, 40, false, "... of at least 2^n tile-chunks each (19: about 5 ms of contraction)") \
+	X(band_max_launches, 8, 1, 64, false, "... and at most this many a region") \
+	X(band_list_entries, 0, 0, 1ll << 32, false, "candidate slots of such a launch (0: 1/32 of its pairs, 4 M .. 256 M); a launch that outgrows them, or its survivor buffer, is redone as matrix-sized tiles") \
+	X(band_reverse, 1, 0, 1, false, "allele-count-sorted runs: the last band (commonest variants, most survivors) first") \
+	X(fisher_order, 1, 0, 1, false, "Fisher's walks binned by their length (DESIGN 3.2)") \
+	X(fisher_lds, 1, 0, 1, false, "log-factorial table in LDS while it fits") \
+	X(async_delivery, 1, 0, 1, false, "region calls with a sink: a finished launch's sorted survivors are copied aside on the device and a second thread of the engine takes them to the host and calls the sink - in the launches' order, one call at a time - while the calling thread goes on enqueueing launches (twk_delivery.h); 0: the calling thread does both") \
+	X(deliver_buffers, 3, 1, 64, false, "staging buffers that thread may hold at a time: a launch whose survivors find none free waits for one (back-pressure)") \
+	X(record_cap, 0, 0, 1ll << 40, false, "test hook: cap on a launch's survivor buffer in records (0: none) - forces the overflow paths: a matrix-sized tile is redone in row strips, a band launch as matrix-sized tiles") \
+	X(deliver_fail_alloc_at, 0, 0, 1 << 30, false, "test hook: the n-th staging allocation of a region call fails (the calling thread then delivers that launch itself)") \
+	X(deliver_fail_copy_at, 0, 0, 1 << 30, false, "test hook: the n-th copy aside of a region call fails (the call fails)") \
+	X(timeline, 0, 0, 1, false, "1: the host's steps through a region's launch pipeline, with times, and the outlier watch's findings on stderr")
 struct Options {
-	long long lists = 1;             // carrier lists for the rare head of the sorted sets: 0 never, 1 rows of >= 4096 words, 2 always (>= 8 carriers)
-	long long list_max = 0;          // longest carrier list kept (0: W / 128 phased, W / 64 unphased)
-	long long patch_rows = 8, patch_cols = 8;      // shape of a patch of tiles in the count kernel's work order
-	long long count_min_chunks = 8;  // shortest K range a tile is split into
-	long long fused = 1;             // fused count -> screen kernel: 0 never, 1 rows of <= FUSED_MAX_CHUNKS chunks, 2 always
-	long long seg = 0;               // walk a patch in K segments of this many chunks (0: whole tiles)
-	long long xcd_queues = 0;        // one unit queue per XCD (2..8; 0: one queue)
-	long long skip_pad = 1;          // do not contract the zero padding behind a row's last live half-slot
-	long long fisher_order = 1;      // Fisher walks in the order of their length
-	long long fisher_lds = 1;        // log-factorial table in LDS while it fits
-	long long cand_chunk = -1;       // candidate slots a wave reserves at a time (-1: sized from the list)
-	long long record_cap = 0;        // cap on the survivor buffer of a launch (0: none): forces the overflow / strip path
-	long long probe = 1;             // zone rows x columns outside the zone: carrier-list probes into the column's row instead of the dense contraction (0: dense)
-	long long band_launch = 1;       // fused runs: launches sized by work (a band of rows, all its columns), not by a count matrix
-	long long band_list_entries = 0; // candidate slots of such a launch (0: 1/32 of its pairs, 4 M .. 256 M; else exactly this many): small values force its fallback
-	long long band_max_launches = 8; // ... at most this many per region
-	long long probe_unroll = 4;      // list entries the unphased probe kernel takes at a time (1, 2, 4: their loads in flight together; ld_list.hip.h)
-	long long probe_zone = 1;        // rows with a list short enough to probe take *every* column behind them that way, the zone's own included (0: zone x zone pairs are list merges)
-	long long band_reverse = 1;      // allele-count-sorted runs: the last band (the commonest variants, most survivors) first
-	long long timeline = 0;          // 1: the host's steps through the launch pipeline of a region, with times, on stderr (measurement)
-	long long band_work_log2 = 19;   // ... and at least 2^n tile-chunks of work per launch (19: ~5 ms); small values make several launches of a small run
-	long long probe_lds = 1;         // probes through LDS: column rows staged segment by segment, carriers tested there (ld_list.hip.h k_probe_lds_t); 0: gathers from L2
-	long long async_delivery = 1;    // region calls with a sink: finished launches' survivors are copied aside on the device and taken to the host by a second thread (delivery_loop); 0: by the thread that runs the launches (round 4)
-	long long probe_cols = 0;        // probes: columns a block takes (2, 4, 8, 16: phased planes; unphased planes half of it; ld_list.hip.h k_probe_strip_t); 0: one column per block
-	long long deliver_buffers = 3;   // staging buffers the delivery thread may hold at a time (twk_delivery.h): a launch whose survivors find none free waits for one
-	long long deliver_fail_alloc_at = 0, deliver_fail_copy_at = 0;      // test hooks: the n-th staging allocation / copy aside of a region call fails (0: none)
-	long long three_wide = 1;        // the three-product form through a count matrix (long rows) on the wide lane tile: four x four variants a lane, the block's waves
-	                                 // split over the halves of a chunk's K range (k_count3w_list_t, ld_count.hip.h); 0: four x two (k_count3_list_t)
-	long long three = 1;             // UnphasedMath on the plain unphased planes with an r2 cut-off: the three-product contraction (HH + S, ld_count.hip.h) and a
-	                                 // recount of the candidates' four products; 0: the four-product forms; 2: also when a launch turned out candidate-rich
+#define X(key, dflt, lo, hi, rebuilds, doc) long long key = dflt;
+	TWK_HIP_OPTIONS(X)
+#undef X
 };
-struct OptionKey { const char* name; long long Options::* field; long long lo, hi; bool rebuilds_planes; };
+struct OptionKey { const char* name; long long Options::* field; long long dflt, lo, hi; bool rebuilds_planes; const char* doc; };
 const OptionKey OPTION_KEYS[] = {
-	{"lists", &Options::lists, 0, 2, true}, {"list_max", &Options::list_max, 0, 60000, true},
-	{"patch_rows", &Options::patch_rows, 1, 4096, false}, {"patch_cols", &Options::patch_cols, 1, 4096, false},
-	{"count_min_chunks", &Options::count_min_chunks, 1, 1 << 20, false}, {"fused", &Options::fused, 0, 2, false},
-	{"seg", &Options::seg, 0, 1 << 20, false}, {"xcd_queues", &Options::xcd_queues, 0, 8, false},
-	{"skip_pad", &Options::skip_pad, 0, 1, false}, {"fisher_order", &Options::fisher_order, 0, 1, false},
-	{"fisher_lds", &Options::fisher_lds, 0, 1, false}, {"cand_chunk", &Options::cand_chunk, -1, 1 << 20, false},
-	{"record_cap", &Options::record_cap, 0, 1ll << 40, false},
-	{"probe", &Options::probe, 0, 1, false}, {"band_launch", &Options::band_launch, 0, 1, false}, {"band_list_entries", &Options::band_list_entries, 0, 1ll << 32, false},
-	{"band_work_log2", &Options::band_work_log2, 0, 40, false}, {"band_max_launches", &Options::band_max_launches, 1, 64, false}, {"timeline", &Options::timeline, 0, 1, false}, {"band_reverse", &Options::band_reverse, 0, 1, false}, {"probe_zone", &Options::probe_zone, 0, 1, false}, {"probe_unroll", &Options::probe_unroll, 1, 4, false},
-	{"three", &Options::three, 0, 2, false}, {"three_wide", &Options::three_wide, 0, 1, false},
-	{"deliver_buffers", &Options::deliver_buffers, 1, 64, false}, {"deliver_fail_alloc_at", &Options::deliver_fail_alloc_at, 0, 1 << 30, false}, {"deliver_fail_copy_at", &Options::deliver_fail_copy_at, 0, 1 << 30, false}, {"probe_cols", &Options::probe_cols, 0, 16, false}, {"probe_lds", &Options::probe_lds, 0, 1, false}, {"async_delivery", &Options::async_delivery, 0, 1, false},
+#define X(key, dflt, lo, hi, rebuilds, doc) {#key, &Options::key, dflt, lo, hi, rebuilds, doc},
+	TWK_HIP_OPTIONS(X)
+#undef X
 };
 }  // namespace
 
@@ -1359,8 +1356,8 @@ int run_probe_block(twk_hip_ctx* c, const twk_hip_filters& f, bool unphased, uin
 	w.col_hi = cr.d_hi; w.hi_a0 = cr.a0; w.hi_b0 = cr.b0;
 	w.two_n = 2.0 * (double)c->N; w.cut = f.minR2 * (1.0 - 1e-6);
 	w.cand = s.C; w.cap = s.cand_cap; w.n_cand = s.n_out + 2;
-	// through LDS (k_probe_lds_t: 512 rows x 4 columns a block, 2 columns of unphased planes), option probe_lds = 0: straight from L2 (a strip
-	// of probe_cols columns a block, or one)
+	// through LDS (k_probe_lds_t: 512 rows x 4 columns a block, 2 columns of unphased planes); option probe_lds = 0: gathers straight from L2, one
+	// column a block (the round-4 kernels: kept as the twin the LDS form is tested against)
 	const bool via_lds = c->opt.probe_lds != 0;
 	p.rows = ps.rows; p.W = ps.W; p.col0 = col0; p.n_cols = n_cols; p.n_row_blocks = via_lds ? (n_rows + PROBE_ROWS - 1) / PROBE_ROWS : (n_rows + 255) / 256;
 	s.row_pairs = 0;
@@ -1369,32 +1366,17 @@ int run_probe_block(twk_hip_ctx* c, const twk_hip_filters& f, bool unphased, uin
 		const uint32_t first = std::max(col0, i + 1);             // (columns inside the zone: those behind the row)
 		if (lim > first) s.row_pairs += lim - first;              // pairs probed (accounting only)
 	}
-	// a strip of columns per block (k_probe_strip_t; option probe_cols = columns of a strip, phased planes - unphased planes take half as many,
-	// two rows each); 0: one column per block (the round-4 kernels)
 	constexpr uint32_t LDS_COLS_P = 4, LDS_COLS_U = 2;
-	const uint32_t strip_cols = via_lds ? (unphased ? LDS_COLS_U : LDS_COLS_P) : unphased ? (uint32_t)c->opt.probe_cols / 2 : (uint32_t)c->opt.probe_cols;
-	const bool strips = strip_cols >= 2;
-	const uint64_t n_blocks = (uint64_t)p.n_row_blocks * (strips ? (n_cols + strip_cols - 1) / strip_cols : n_cols);
+	const uint32_t strip_cols = via_lds ? (unphased ? LDS_COLS_U : LDS_COLS_P) : 1;
+	const uint64_t n_blocks = (uint64_t)p.n_row_blocks * ((n_cols + strip_cols - 1) / strip_cols);
 	if (n_blocks > 0x7FFFFFFFull) return TWK_HIP_E_INVALID;
 	HIPCHK(c, hipEventRecord(s.ev_c0, c->s_compute));
 	if (s.row_pairs) {
-		const dim3 grid((uint32_t)n_blocks), blk(256);
+		const dim3 grid((uint32_t)n_blocks);
 		if (via_lds && unphased) hipLaunchKernelGGL(k_probe_lds_unphased_t<LDS_COLS_U>, grid, dim3(PROBE_ROWS), 0, c->s_compute, p);
 		else if (via_lds) hipLaunchKernelGGL(k_probe_lds_t<LDS_COLS_P>, grid, dim3(PROBE_ROWS), 0, c->s_compute, p);
-		else if (strips && unphased) {
-			if (strip_cols == 2) hipLaunchKernelGGL(k_probe_strip_unphased_t<2>, grid, blk, 0, c->s_compute, p);
-			else if (strip_cols == 4) hipLaunchKernelGGL(k_probe_strip_unphased_t<4>, grid, blk, 0, c->s_compute, p);
-			else hipLaunchKernelGGL(k_probe_strip_unphased_t<8>, grid, blk, 0, c->s_compute, p);
-		} else if (strips) {
-			if (strip_cols == 2) hipLaunchKernelGGL(k_probe_strip_t<2>, grid, blk, 0, c->s_compute, p);
-			else if (strip_cols == 4) hipLaunchKernelGGL(k_probe_strip_t<4>, grid, blk, 0, c->s_compute, p);
-			else if (strip_cols == 8) hipLaunchKernelGGL(k_probe_strip_t<8>, grid, blk, 0, c->s_compute, p);
-			else hipLaunchKernelGGL(k_probe_strip_t<16>, grid, blk, 0, c->s_compute, p);
-		}
-		else if (unphased && c->opt.probe_unroll == 4) hipLaunchKernelGGL(k_probe_screen_unphased_t<4>, dim3((uint32_t)n_blocks), dim3(256), 0, c->s_compute, p, c->N);
-		else if (unphased && c->opt.probe_unroll == 2) hipLaunchKernelGGL(k_probe_screen_unphased_t<2>, dim3((uint32_t)n_blocks), dim3(256), 0, c->s_compute, p, c->N);
-		else if (unphased) hipLaunchKernelGGL(k_probe_screen_unphased_t<1>, dim3((uint32_t)n_blocks), dim3(256), 0, c->s_compute, p, c->N);
-		else hipLaunchKernelGGL(k_probe_screen, dim3((uint32_t)n_blocks), dim3(256), 0, c->s_compute, p);
+		else if (unphased) hipLaunchKernelGGL(k_probe_screen_unphased_t<4>, grid, dim3(256), 0, c->s_compute, p, c->N);
+		else hipLaunchKernelGGL(k_probe_screen, grid, dim3(256), 0, c->s_compute, p);
 		HIPCHK(c, hipGetLastError());
 	}
 	HIPCHK(c, hipEventRecord(s.ev_c1, c->s_compute));
@@ -2484,6 +2466,17 @@ int twk_hip_set_option(twk_hip_ctx* c, const char* key, int64_t value) {
 	}
 	snprintf(c->err, sizeof(c->err), "unknown option %s", key);
 	return TWK_HIP_E_INVALID;
+}
+
+int twk_hip_option_describe(uint32_t index, const char** key, int64_t* dflt, int64_t* lo, int64_t* hi, const char** meaning) {
+	if (index >= sizeof(OPTION_KEYS) / sizeof(OPTION_KEYS[0])) return TWK_HIP_E_INVALID;
+	const OptionKey& k = OPTION_KEYS[index];
+	if (key) *key = k.name;
+	if (dflt) *dflt = k.dflt;
+	if (lo) *lo = k.lo;
+	if (hi) *hi = k.hi;
+	if (meaning) *meaning = k.doc;
+	return TWK_HIP_OK;
 }
 
 int twk_hip_get_option(const twk_hip_ctx* c, const char* key, int64_t* value) {

@@ -195,10 +195,36 @@ def load_library() -> C.CDLL:
     lib.twk_hip_device_records.argtypes = [p, C.POINTER(p), C.POINTER(C.c_uint64)]
     lib.twk_hip_set_option.argtypes = [p, C.c_char_p, C.c_int64]
     lib.twk_hip_get_option.argtypes = [p, C.c_char_p, C.POINTER(C.c_int64)]
+    lib.twk_hip_option_describe.argtypes = [C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_char_p)]
     lib.twk_hip_timing_reset.argtypes = [p]
     lib.twk_hip_timing_get.argtypes = [p, C.POINTER(_Timing)]
     _lib = lib
     return lib
+
+
+def option_table():
+    """The engine's option table (twk_hip_option_describe: needs no device) -> list of (key, default, lowest, highest, meaning)."""
+    lib = load_library()
+    out, i = [], 0
+    while True:
+        key, doc = C.c_char_p(), C.c_char_p()
+        d, lo, hi = C.c_int64(), C.c_int64(), C.c_int64()
+        if lib.twk_hip_option_describe(i, C.byref(key), C.byref(d), C.byref(lo), C.byref(hi), C.byref(doc)) != 0:
+            return out
+        out.append((key.value.decode(), d.value, lo.value, hi.value, doc.value.decode()))
+        i += 1
+
+
+def option_table_markdown() -> str:
+    """... as the table INTEGRATION.md 1 carries between its `<!-- engine options -->` markers (tests/test_docs_consistency.py)."""
+    def num(x):
+        for k in (20, 30, 32, 40):
+            if x == 1 << k:
+                return f"2^{k}"
+        return str(x)
+    rows = ["| key | default | range | meaning |", "|---|---|---|---|"]
+    rows += [f"| `{k}` | {num(d)} | {num(lo)} .. {num(hi)} | {doc} |" for k, d, lo, hi, doc in option_table()]
+    return "\n".join(rows)
 
 
 def device_count() -> int:
