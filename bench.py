@@ -685,14 +685,15 @@ def main():
             shutil.copyfile(os.path.join(out_dir, f"step{args.steps - 1}.two"), args.keep_two)
     tm = eng.timing()
     spread = launch_spread(eng)
+    written_timed, phase_timed = dict(written), dict(phase)          # the timed region's own figures (the legs below go through the same step())
 
     stats = torch.tensor([elapsed, tm["count_ms"], tm["stats_ms"]], dtype=torch.float64)
     sums = torch.tensor([my_pairs, my_recs, tm["count_launches"], tm["row_pairs"]], dtype=torch.float64)
-    per_rank_ms, ranks_seen = [phase["compute"] / max(args.steps, 1) * 1e3], [rank]
+    per_rank_ms, ranks_seen = [phase_timed["compute"] / max(args.steps, 1) * 1e3], [rank]
     if world > 1:
         dist.all_reduce(stats, op=dist.ReduceOp.MAX)
         dist.all_reduce(sums, op=dist.ReduceOp.SUM)
-        mine = torch.tensor([phase["compute"] / max(args.steps, 1) * 1e3], dtype=torch.float64)
+        mine = torch.tensor([phase_timed["compute"] / max(args.steps, 1) * 1e3], dtype=torch.float64)
         every = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
         per_rank_ms = [float(x.item()) for x in every]
@@ -701,13 +702,7 @@ def main():
         seen = [torch.zeros_like(me) for _ in range(world)]
         dist.all_gather(seen, me, group=gather_group)
         ranks_seen = sorted(int(x.item()) for x in seen)
-    gcheck = None
-    if world > 1 and not args.no_gather_check:
-        try:
-            gcheck = gather_check(eng, rank, world, xdev, gather_group, collective, args.seed, log)
-        except Exception as e:           # a failed check is reported, on every rank alike, not hidden
-            gcheck = {"equal": False, "error": repr(e)[:300]} if rank == 0 else None
-            log(f"gather_check failed: {e!r}")
+
     def planted_leg():
         """A survivor-bearing step of the SAME problem under the same clock (since round 1 the timed region has had 0 survivors: iid
         genotypes hold no pair near r2 = 0.1): the input regenerated in place with LD planted in it (twk_hip_plant: every odd variant a
@@ -768,7 +763,7 @@ def main():
         res = {"workload": f"the headline's problem with LD planted in it: {plant.n_planted} noisy copies (flip probability 0 .. {plant.max_eps:g}, "
                            + ("7 variants from their sources" if window_bp else "sources spread over the whole data set") + f"), same filters, 1 warm-up + 2 steps through the timed region's step()",
                "steps": 2, "warmup": 1, "generate_s": gen_s, "pairs_per_step": pairs3 // 2, "value": pairs3 / el3, "unit": "variant-pairs/s",
-               "ms_per_step": el3 / 2 * 1e3, "survivors_per_step": recs3 / 2, "two_records_written_per_step": written["records"] if False else None,
+               "ms_per_step": el3 / 2 * 1e3, "survivors_per_step": recs3 / 2,
                "dominant_kernel": kernel, "form": form,
                "count_kernel_ms_per_step": tm3["count_ms"] / 2, "count_launches_per_step": tm3["count_launches"] / 2,
                "three_product_launches": int(tm3["three_launches"]), "recounted_candidates_per_step": tm3["recount_candidates"] / 2,
@@ -788,7 +783,6 @@ def main():
                "self_check": bool(same and found == expected and len(found) > 0 and (filters.minR2 < 0.01 or not (k3 - set(planted)))),
                "self_check_note": "planted_expected = planted pairs among the survivors of the four-product step (no (HH, S) screen); records compared byte for byte; "
                                   "the oracle's check of this data set: tests/test_gpu_full_size.py"}
-        del res["two_records_written_per_step"]
         log(f"planted: {res['ms_per_step']:.1f} ms/step, {res['survivors_per_step']:.0f} survivors, found {len(found)} of {len(expected)} expected, "
             f"equal to four products: {same}; four-product step {el4 * 1e3:.1f} ms")
         return res
@@ -798,6 +792,13 @@ def main():
         planted = planted_leg()
     if rank == 0:
         shutil.rmtree(out_dir, ignore_errors=True)
+    gcheck = None
+    if world > 1 and not args.no_gather_check:
+        try:
+            gcheck = gather_check(eng, rank, world, xdev, gather_group, collective, args.seed, log)
+        except Exception as e:           # a failed check is reported, on every rank alike, not hidden
+            gcheck = {"equal": False, "error": repr(e)[:300]} if rank == 0 else None
+            log(f"gather_check failed: {e!r}")
     elapsed_max, count_ms_max, stats_ms_max = (float(x) for x in stats.tolist())
     pairs_all, recs_all, launches_all, row_pairs_all = (float(x) for x in sums.tolist())
     if not args.emulate_shard:
@@ -838,7 +839,7 @@ def main():
                                      + ", rank 0 writes the .two file"),
                        "collective_backend": collective,
                        "survivors_per_step": recs_all / args.steps,
-                       "two_records_written_per_step": written["records"] / args.steps},
+                       "two_records_written_per_step": written_timed["records"] / args.steps},
             # achieved / frac: lane-ops the kernel EXECUTED (v_and + v_bcnt per product, plus the three-product form's v_or) - it cannot grow by
             # counting work that was not done; algorithmic_*: SURVEY 8(d)'s figure per pair (four products per unphased pair) over the same time
             "roofline": {"bound": "valu", "achieved": executed_lane_ops_per_s / 1e12, "peak": VALU_LANE_PEAK / 1e12,
@@ -871,10 +872,10 @@ def main():
                                  "(v_bcnt_u32_b32 is half rate: profiles/*microbench_valu_rate.txt)"},
             "kernel_ms": {"count": count_ms_max, "math": stats_ms_max, "wall": elapsed_max * 1e3},
             "per_rank_ms": per_rank_ms,                                   # compute per step, every rank (balance of the bands)
-            "gather_ms": phase["gather"] / max(args.steps, 1) * 1e3,      # rank 0, per step: waits for the slowest rank, then the transfers
-            "write_ms": phase["write"] / max(args.steps, 1) * 1e3,        # rank 0, per step: survivors -> .two blocks -> file
-            "gather_bytes": phase["xfer_bytes"] / max(args.steps, 1),     # rank 0, per step: record bytes received from the other ranks
-            "gather_GBps": (phase["xfer_bytes"] / phase["xfer"] / 1e9) if phase["xfer"] > 0 and phase["xfer_bytes"] else None,   # over the transfers alone
+            "gather_ms": phase_timed["gather"] / max(args.steps, 1) * 1e3,      # rank 0, per step: waits for the slowest rank, then the transfers
+            "write_ms": phase_timed["write"] / max(args.steps, 1) * 1e3,        # rank 0, per step: survivors -> .two blocks -> file
+            "gather_bytes": phase_timed["xfer_bytes"] / max(args.steps, 1),     # rank 0, per step: record bytes received from the other ranks
+            "gather_GBps": (phase_timed["xfer_bytes"] / phase_timed["xfer"] / 1e9) if phase_timed["xfer"] > 0 and phase_timed["xfer_bytes"] else None,   # over the transfers alone
             "ranks_seen": ranks_seen,
         }
         if gcheck is not None:

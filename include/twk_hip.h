@@ -31,7 +31,8 @@ extern "C" {
 /* 3: twk_hip_set_option / twk_hip_get_option; the library no longer reads environment variables. */
 /* 4: twk_hip_timing grew (three-product launches); option "three". */
 /* 5: twk_hip_generate_synthetic_planted / twk_synth_planted_bitvector / twk_synth_plant_source (synthetic input with planted LD pairs);
- *    twk_hip_option_describe; twk_hip_timing grew (three_wide_row_pairs, finish_ms). */
+ *    twk_hip_option_describe; twk_hip_timing grew (three_wide_row_pairs, finish_ms); twk_hip_gather_records / twk_hip_gather_backend /
+ *    twk_hip_drain_device_sink (the RCCL gather of a one-process multi-GPU run). */
 #define TWK_HIP_ABI_VERSION 5
 
 enum {
@@ -282,6 +283,24 @@ int twk_hip_ld_region(twk_hip_ctx* ctx, int mode, const twk_hip_filters* filters
  * until the next compute call or twk_hip_set_device_sink; NULL when *n == 0. */
 int twk_hip_set_device_sink(twk_hip_ctx* ctx, int on);
 int twk_hip_device_records(twk_hip_ctx* ctx, const twk_hip_record** records, uint64_t* n);
+
+/* One process, several GPUs (`tomahawk calc` with TWK_HIP_GPUS = n and engine option "gather" = 1): gather the device sinks of n
+ * contexts - one per GPU, each with twk_hip_set_device_sink on and its region calls done - into the device sink of ctxs[dst], GPU to
+ * GPU over RCCL: one communicator clique per set of devices (ncclCommInitAll, kept for the life of the process), then ONE group of
+ * exact-size ncclSend / ncclRecv on the contexts' copy streams - no padding to a common size, no host hop.  Afterwards ctxs[dst]'s
+ * sink holds its own records followed by those of the other contexts in the order of ctxs[]; the others' sinks are empty.
+ * This is the north star's "final RCCL gather of .two output blocks over xGMI" inside the C++ product; it replaces every slave's
+ * flush of its output block into the shared writer (lib/ld/ld_engine.cpp:1742-1802).  librccl is opened on first use (dlopen), never
+ * linked: twk_hip_gather_backend() says what was found.  n == 1: nothing to move - unless flags has TWK_HIP_GATHER_SELF_LOOP, which
+ * sends the one context's records from its sink to itself through the same group of calls (what a one-GPU box can exercise of the
+ * path).  *transfer_ms (may be NULL): the transfers' duration on the destination's stream (HIP events).  Everything gathered must fit
+ * the destination's HBM beside its problem (TWK_HIP_E_NOMEM otherwise: the caller falls back to per-GPU copies to the host). */
+enum { TWK_HIP_GATHER_SELF_LOOP = 1 };
+int twk_hip_gather_records(twk_hip_ctx* const* ctxs, uint32_t n, uint32_t dst, int32_t flags, uint64_t* n_records, double* transfer_ms);
+const char* twk_hip_gather_backend(void);      /* "rccl <version code>" or "unavailable (<why>)" */
+/* Hand what the device sink holds to `sink` on the host - in pieces of at most 2^20 records through the engine's pinned staging, in the
+ * order they lie in the sink - and empty it.  (The records of a gathered run leave the destination GPU this way, once.) */
+int twk_hip_drain_device_sink(twk_hip_ctx* ctx, twk_hip_record_sink sink, void* user, uint64_t* n_records);
 
 /* The row band [row_begin,row_end) that shard `part` of `n_parts` owns in a region of
  * n_rows x n_cols variants (triangle != 0: col > row only, n_rows == n_cols) and the

@@ -8,7 +8,7 @@ for tests, benchmarks and scripting; it contains no compute and no CPU fallback.
 """
 from .hip import (HipLd, HipError, Filters, RECORD_DTYPE, MODE_PHASED, MODE_UNPHASED, MODE_AUTO,
                   OPT_WINDOW, OPT_KEEP_LOW_AC, OPT_REF_COMPAT, OPT_R2_SCREEN, RLE_DESC_DTYPE, META_DTYPE,
-                  device_count, load_library, synth_bitvector, shard_rows, plan_region, TILE_DTYPE, Plant, plant_source)
+                  device_count, load_library, synth_bitvector, shard_rows, plan_region, TILE_DTYPE, Plant, plant_source, gather_records, gather_backend)
 
 __all__ = ["HipLd", "HipError", "Filters", "RECORD_DTYPE", "MODE_PHASED", "MODE_UNPHASED",
-           "MODE_AUTO", "OPT_WINDOW", "OPT_KEEP_LOW_AC", "OPT_REF_COMPAT", "OPT_R2_SCREEN", "RLE_DESC_DTYPE", "META_DTYPE", "device_count", "load_library", "synth_bitvector", "shard_rows", "plan_region", "TILE_DTYPE", "Plant", "plant_source"]
+           "MODE_AUTO", "OPT_WINDOW", "OPT_KEEP_LOW_AC", "OPT_REF_COMPAT", "OPT_R2_SCREEN", "RLE_DESC_DTYPE", "META_DTYPE", "device_count", "load_library", "synth_bitvector", "shard_rows", "plan_region", "TILE_DTYPE", "Plant", "plant_source", "gather_records", "gather_backend"]

@@ -23,6 +23,9 @@
 #include <chrono>
 #include <string.h>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rccl/rccl.h>          // types only: the library is opened on first use (twk_hip_gather_records), never linked
+#include <dlfcn.h>
+#include <map>
 
 #include "../../../include/twk_hip.h"
 #include "ld_count.hip.h"
@@ -2448,6 +2451,146 @@ int twk_hip_device_records(twk_hip_ctx* c, const twk_hip_record** records, uint6
 	*records = c->d_keep_n ? c->d_keep : nullptr;
 	*n = c->d_keep_n;
 	return TWK_HIP_OK;
+}
+
+// ---- the gather of a one-process multi-GPU run: device sink -> device sink over RCCL ------------------------------------------------
+// (north star: "a final RCCL gather of .two output blocks over xGMI"; the reference's counterpart is every slave's flush of its output
+// block into the shared writer, lib/ld/ld_engine.cpp:1742-1802).  librccl is opened when the first gather asks for it - a process that
+// never gathers, or a box without RCCL, loses nothing - and one communicator clique per set of devices is kept for the life of the process.
+extern "C++" {
+namespace {
+struct Rccl {
+	void* lib = nullptr; bool tried = false; char why[256] = {0}; int version = 0;
+	ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+	ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+	ncclResult_t (*GroupStart)() = nullptr;
+	ncclResult_t (*GroupEnd)() = nullptr;
+	ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+	ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+	ncclResult_t (*GetVersion)(int*) = nullptr;
+	const char* (*GetErrorString)(ncclResult_t) = nullptr;
+	std::map<std::vector<int>, std::vector<ncclComm_t>> cliques;
+	std::mutex mu;
+	bool open() {
+		if (tried) return lib != nullptr;
+		tried = true;
+		for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { lib = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (lib) break; }
+		if (!lib) { snprintf(why, sizeof(why), "librccl.so.1 cannot be opened: %s", dlerror()); return false; }
+		auto sym = [&](const char* n) { void* p = dlsym(lib, n); if (!p) snprintf(why, sizeof(why), "librccl lacks %s", n); return p; };
+		CommInitAll = (decltype(CommInitAll))sym("ncclCommInitAll"); CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
+		GroupStart = (decltype(GroupStart))sym("ncclGroupStart"); GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
+		Send = (decltype(Send))sym("ncclSend"); Recv = (decltype(Recv))sym("ncclRecv");
+		GetVersion = (decltype(GetVersion))sym("ncclGetVersion"); GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+		if (!(CommInitAll && CommDestroy && GroupStart && GroupEnd && Send && Recv && GetVersion && GetErrorString)) { dlclose(lib); lib = nullptr; return false; }
+		(void)GetVersion(&version);
+		return true;
+	}
+};
+Rccl& rccl() { static Rccl r; return r; }
+}  // namespace
+}  // extern "C++"
+
+const char* twk_hip_gather_backend(void) {
+	Rccl& r = rccl();
+	std::lock_guard<std::mutex> lk(r.mu);
+	static char text[320];
+	if (r.open()) snprintf(text, sizeof(text), "rccl %d", r.version);
+	else snprintf(text, sizeof(text), "unavailable (%s)", r.why);
+	return text;
+}
+
+int twk_hip_gather_records(twk_hip_ctx* const* ctxs, uint32_t n, uint32_t dst, int32_t flags, uint64_t* n_records, double* transfer_ms) {
+	if (!ctxs || n == 0 || dst >= n) return TWK_HIP_E_INVALID;
+	for (uint32_t r = 0; r < n; ++r) {
+		if (!ctxs[r]) return TWK_HIP_E_INVALID;
+		if (!ctxs[r]->device_sink) return TWK_HIP_E_STATE;
+		for (uint32_t q = 0; q < r; ++q) if (ctxs[q]->device == ctxs[r]->device) return TWK_HIP_E_INVALID;      // one context per GPU: RCCL refuses a device twice
+	}
+	twk_hip_ctx* d = ctxs[dst];
+	const bool loop = n == 1 && (flags & TWK_HIP_GATHER_SELF_LOOP);
+	if (n_records) *n_records = d->d_keep_n;
+	if (transfer_ms) *transfer_ms = 0.0;
+	if (n == 1 && !loop) return TWK_HIP_OK;
+	Rccl& rc = rccl();
+	std::lock_guard<std::mutex> lk(rc.mu);
+	if (!rc.open()) { snprintf(d->err, sizeof(d->err), "RCCL gather: %s", rc.why); return TWK_HIP_E_DEVICE; }
+	auto NCHK = [&](ncclResult_t e, const char* what) -> int {
+		if (e == ncclSuccess) return TWK_HIP_OK;
+		snprintf(d->err, sizeof(d->err), "RCCL gather: %s failed: %s", what, rc.GetErrorString(e));
+		return TWK_HIP_E_DEVICE;
+	};
+	std::vector<int> devs(n);
+	for (uint32_t r = 0; r < n; ++r) devs[r] = ctxs[r]->device;
+	auto it = rc.cliques.find(devs);
+	if (it == rc.cliques.end()) {
+		std::vector<ncclComm_t> comms(n);
+		if (const int e = NCHK(rc.CommInitAll(comms.data(), (int)n, devs.data()), "ncclCommInitAll")) return e;
+		it = rc.cliques.emplace(devs, std::move(comms)).first;
+	}
+	const std::vector<ncclComm_t>& comm = it->second;
+	// every context's survivors are final (their copies ran on the contexts' copy streams): counts on the host, room on the destination
+	unsigned long long total = 0;
+	std::vector<unsigned long long> cnt(n), off(n);
+	for (uint32_t r = 0; r < n; ++r) { HIPCHK(d, hipSetDevice(ctxs[r]->device)); HIPCHK(d, hipStreamSynchronize(ctxs[r]->s_copy)); cnt[r] = ctxs[r]->d_keep_n; }
+	off[dst] = 0; total = cnt[dst];
+	for (uint32_t r = 0; r < n; ++r) if (r != dst) { off[r] = total; total += cnt[r]; }
+	HIPCHK(d, hipSetDevice(d->device));
+	twk_hip_record* loop_buf = nullptr;
+	if (loop) {          // one GPU: the same group of ncclSend / ncclRecv, from the sink to itself through a second buffer (what a one-GPU box can show of the path)
+		if (cnt[0]) HIPCHK(d, hipMalloc((void**)&loop_buf, (size_t)cnt[0] * sizeof(twk_hip_record)));
+	} else {
+		const unsigned long long own = d->d_keep_n;
+		d->d_keep_n = own;
+		const int e = ensure_device_keep(d, total - own); if (e) return e;         // (keeps the destination's own records, at the front)
+	}
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	HIPCHK(d, hipEventCreate(&e0)); HIPCHK(d, hipEventCreate(&e1));
+	HIPCHK(d, hipEventRecord(e0, d->s_copy));
+	int rcode = NCHK(rc.GroupStart(), "ncclGroupStart");
+	for (uint32_t r = 0; r < n && !rcode; ++r) {
+		if (!loop && r == dst) continue;
+		const size_t bytes = (size_t)cnt[r] * sizeof(twk_hip_record);
+		if (!bytes) continue;
+		if (hipSetDevice(ctxs[r]->device) != hipSuccess) { rcode = TWK_HIP_E_DEVICE; break; }
+		rcode = NCHK(rc.Send(ctxs[r]->d_keep, bytes, ncclUint8, (int)dst, comm[r], ctxs[r]->s_copy), "ncclSend");
+		if (rcode) break;
+		if (hipSetDevice(d->device) != hipSuccess) { rcode = TWK_HIP_E_DEVICE; break; }
+		rcode = NCHK(rc.Recv(loop ? loop_buf : d->d_keep + off[r], bytes, ncclUint8, (int)r, comm[dst], d->s_copy), "ncclRecv");
+	}
+	{ const int e = NCHK(rc.GroupEnd(), "ncclGroupEnd"); if (!rcode) rcode = e; }
+	(void)hipSetDevice(d->device);
+	if (!rcode && hipEventRecord(e1, d->s_copy) != hipSuccess) rcode = TWK_HIP_E_DEVICE;
+	for (uint32_t r = 0; r < n && !rcode; ++r) {
+		if (hipSetDevice(ctxs[r]->device) != hipSuccess || hipStreamSynchronize(ctxs[r]->s_copy) != hipSuccess) rcode = TWK_HIP_E_DEVICE;
+	}
+	(void)hipSetDevice(d->device);
+	float ms = 0;
+	if (!rcode && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && transfer_ms) *transfer_ms = ms;
+	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+	if (rcode) { if (loop_buf) (void)hipFree(loop_buf); if (!d->err[0]) snprintf(d->err, sizeof(d->err), "RCCL gather: a HIP call failed"); return rcode; }
+	if (loop) {
+		if (loop_buf) {        // the records that went round are the sink's content from here on
+			if (d->d_keep) (void)hipFree(d->d_keep);
+			d->d_keep = loop_buf; d->d_keep_cap = cnt[0];
+		}
+	} else {
+		d->d_keep_n = total;
+		for (uint32_t r = 0; r < n; ++r) if (r != dst) ctxs[r]->d_keep_n = 0;
+	}
+	if (n_records) *n_records = d->d_keep_n;
+	return TWK_HIP_OK;
+}
+
+int twk_hip_drain_device_sink(twk_hip_ctx* c, twk_hip_record_sink sink, void* user, uint64_t* n_records) {
+	if (!c || !sink) return TWK_HIP_E_INVALID;
+	if (!c->device_sink) return TWK_HIP_E_STATE;
+	HIPCHK(c, hipSetDevice(c->device));
+	HIPCHK(c, hipStreamSynchronize(c->s_copy));
+	const unsigned long long n = c->d_keep_n;
+	if (n_records) *n_records = n;
+	const int rc = n ? deliver_records(c, c->d_keep, n, sink, user, c->s_copy, 0.0) : TWK_HIP_OK;
+	c->d_keep_n = 0;
+	return rc;
 }
 
 int twk_hip_set_option(twk_hip_ctx* c, const char* key, int64_t value) {

@@ -503,7 +503,7 @@ static bool create_devices(DeviceCtxs& dc, int n_gpus, const std::vector<std::pa
 		if (!hip_ok(nullptr, twk_hip_ctx_create(device, &c), "twk_hip_ctx_create")) return false;
 		dc.ctx.push_back(c);
 		for (const auto& kv : options) {
-			if (kv.first == "force_device" || kv.first == "progress_ms" || kv.first == "map_output" || kv.first == "emit_workers" || kv.first == "emit_backlog_mb" || kv.first == "emit_queue_pieces" || kv.first == "record_codec" || kv.first == "direct_output") continue;       // this class's own
+			if (kv.first == "force_device" || kv.first == "progress_ms" || kv.first == "map_output" || kv.first == "emit_workers" || kv.first == "emit_backlog_mb" || kv.first == "emit_queue_pieces" || kv.first == "record_codec" || kv.first == "direct_output" || kv.first == "gather") continue;       // this class's own
 			if (!hip_ok(c, twk_hip_set_option(c, kv.first.c_str(), kv.second), "twk_hip_set_option")) return false;
 		}
 	}
@@ -636,6 +636,13 @@ bool twk_ld::twk_ld_impl::run(twk_ld_settings& settings, const Header& hdr, cons
 	// for the compression whatever the queue holds, within their noise - profiles/r04_band_sort_ab.txt)
 	const size_t pieces = (size_t)std::max<int64_t>(0, option("emit_queue_pieces", 8));
 	for (int g = 0; g < n_gpus; ++g) drivers.emplace_back(new Driver(this, n_workers, backlog, pieces));
+	// Engine option "gather" = 1 (the north star's "final RCCL gather of .two output blocks over xGMI", inside this one process): every GPU keeps
+	// its survivors in HBM (twk_hip_set_device_sink), and when all are done they travel GPU to GPU over RCCL into GPU 0's sink
+	// (twk_hip_gather_records: one group of exact-size ncclSend / ncclRecv), from where they leave for the host once, into ONE emitter.  Default 0:
+	// every GPU's driver thread streams its survivors to the host while it computes (one hop fewer for a file sink, and no bound on the
+	// survivors by GPU 0's memory: INTEGRATION 1).  With one GPU the records take the same calls in a loop from the sink to itself.
+	const bool gather = option("gather", 0) != 0;
+	if (gather) for (int g = 0; g < n_gpus; ++g) if (!hip_ok(ctxs[g], twk_hip_set_device_sink(ctxs[g], 1), "twk_hip_set_device_sink")) return false;
 	auto drive = [&](int g) {
 		Driver& d = *drivers[g];
 		twk_hip_ctx* ctx = ctxs[g];
@@ -661,6 +668,7 @@ bool twk_ld::twk_ld_impl::run(twk_ld_settings& settings, const Header& hdr, cons
 			d.pairs += np;
 		}
 		twk_hip_set_progress(ctx, nullptr, nullptr);
+		if (gather) return;                 // (the survivors are still in HBM: gathered and written below)
 		if (!d.drain()) d.write_failed = true;
 		if (d.rc == TWK_HIP_OK && !d.write_failed && !d.emitter.emit(nullptr, 0, true)) d.write_failed = true;     // close the open blocks
 	};
@@ -669,6 +677,62 @@ bool twk_ld::twk_ld_impl::run(twk_ld_settings& settings, const Header& hdr, cons
 		std::vector<std::thread> th;
 		for (int g = 0; g < n_gpus; ++g) th.emplace_back(drive, g);
 		for (auto& t : th) t.join();
+	}
+	if (gather) {
+		for (int g = 0; g < n_gpus; ++g) if (!hip_ok(ctxs[g], drivers[g]->rc, "twk_hip_ld_region")) return false;
+		// what every GPU holds (its slab's index shift applies to its records wherever they travel), then the gather, then GPU 0 -> host -> emitter 0
+		struct Feed {
+			Driver* d0; std::vector<uint64_t> end; std::vector<uint32_t> shift; uint64_t seen = 0; std::vector<twk_hip_record> tmp;
+			static int sink(void* user, const twk_hip_record* recs, uint64_t n) {
+				auto* f = static_cast<Feed*>(user);
+				uint64_t i = 0;
+				while (i < n) {
+					size_t g = 0;
+					while (g + 1 < f->end.size() && f->seen >= f->end[g]) ++g;
+					const uint64_t m = std::min<uint64_t>(n - i, f->end[g] > f->seen ? f->end[g] - f->seen : n - i);
+					f->tmp.clear();
+					for (uint64_t k = 0; k < m; ++k) {
+						twk_hip_record r = recs[i + k];
+						r.idxA += f->shift[g]; r.idxB += f->shift[g];
+						if (!f->d0->self->cw.on || f->d0->self->compat_keep(r.idxA, r.idxB)) f->tmp.push_back(r);
+					}
+					// (a piece of the sink may span launches: each launch's records are in order, the piece need not be - the emitter sorts what is not)
+					if (!f->tmp.empty() && !f->d0->emitter.emit(f->tmp.data(), f->tmp.size(), false, false)) { f->d0->write_failed = true; return 1; }
+					f->seen += m; i += m;
+				}
+				return 0;
+			}
+		} feed;
+		feed.d0 = drivers[0].get();
+		uint64_t total = 0;
+		std::vector<uint64_t> held(n_gpus, 0);
+		for (int g = 0; g < n_gpus; ++g) {
+			const twk_hip_record* p = nullptr;
+			if (!hip_ok(ctxs[g], twk_hip_device_records(ctxs[g], &p, &held[g]), "twk_hip_device_records")) return false;
+			total += held[g];
+			feed.end.push_back(total); feed.shift.push_back(drivers[g]->shift);
+		}
+		const auto t_g = clock::now();
+		uint64_t got = 0; double xfer_ms = 0;
+		int grc = twk_hip_gather_records(ctxs.data(), (uint32_t)n_gpus, 0, n_gpus == 1 ? TWK_HIP_GATHER_SELF_LOOP : 0, &got, &xfer_ms);
+		if (grc == TWK_HIP_OK) {
+			if (got != total) { std::cerr << stamp("ERROR", "HIP") << "gather: " << got << " records arrived, " << total << " were held." << std::endl; return false; }
+			std::cerr << stamp("LOG", "HIP") << "Gathered " << pretty(total) << " records of " << n_gpus << " GPU(s) into GPU 0 over " << twk_hip_gather_backend()
+			          << (n_gpus == 1 ? " (one GPU: from its sink to itself)" : "") << ": " << pretty((total - held[0]) * sizeof(twk_hip_record)) << " bytes moved"
+			          << (n_gpus == 1 ? " (+ the loop's " + pretty(held[0] * sizeof(twk_hip_record)) + ")" : std::string()) << ", transfers " << xfer_ms << " ms, "
+			          << std::chrono::duration<double, std::milli>(clock::now() - t_g).count() << " ms in all." << std::endl;
+			uint64_t nd = 0;
+			if (!hip_ok(ctxs[0], twk_hip_drain_device_sink(ctxs[0], &Feed::sink, &feed, &nd), "twk_hip_drain_device_sink")) return false;
+		} else {
+			// no RCCL, or not enough room on GPU 0 for everybody's survivors: every GPU's sink goes to the host by itself, one after the other
+			std::cerr << stamp("WARNING", "HIP") << "gather over RCCL not possible (" << twk_hip_last_error(ctxs[0]) << "): the GPUs' survivors go to the host one GPU at a time." << std::endl;
+			for (int g = 0; g < n_gpus; ++g) {
+				uint64_t nd = 0;
+				if (!hip_ok(ctxs[g], twk_hip_drain_device_sink(ctxs[g], &Feed::sink, &feed, &nd), "twk_hip_drain_device_sink")) return false;
+			}
+		}
+		for (int g = 0; g < n_gpus; ++g) (void)twk_hip_set_device_sink(ctxs[g], 0);
+		if (!drivers[0]->write_failed && !drivers[0]->emitter.emit(nullptr, 0, true)) drivers[0]->write_failed = true;
 	}
 	for (int g = 0; g < n_gpus; ++g) {
 		if (drivers[g]->write_failed) { std::cerr << stamp("ERROR", "WRITER") << "Failed to write output block!" << std::endl; return false; }

@@ -195,6 +195,9 @@ def load_library() -> C.CDLL:
     lib.twk_hip_device_records.argtypes = [p, C.POINTER(p), C.POINTER(C.c_uint64)]
     lib.twk_hip_set_option.argtypes = [p, C.c_char_p, C.c_int64]
     lib.twk_hip_get_option.argtypes = [p, C.c_char_p, C.POINTER(C.c_int64)]
+    lib.twk_hip_gather_records.argtypes = [C.POINTER(p), C.c_uint32, C.c_uint32, C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
+    lib.twk_hip_gather_backend.restype = C.c_char_p
+    lib.twk_hip_drain_device_sink.argtypes = [p, _SINK, p, C.POINTER(C.c_uint64)]
     lib.twk_hip_option_describe.argtypes = [C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_char_p)]
     lib.twk_hip_timing_reset.argtypes = [p]
     lib.twk_hip_timing_get.argtypes = [p, C.POINTER(_Timing)]
@@ -225,6 +228,25 @@ def option_table_markdown() -> str:
     rows = ["| key | default | range | meaning |", "|---|---|---|---|"]
     rows += [f"| `{k}` | {num(d)} | {num(lo)} .. {num(hi)} | {doc} |" for k, d, lo, hi, doc in option_table()]
     return "\n".join(rows)
+
+
+GATHER_SELF_LOOP = 1
+
+
+def gather_backend() -> str:
+    """What twk_hip_gather_records moves records with: "rccl <version>" or "unavailable (<why>)"."""
+    return load_library().twk_hip_gather_backend().decode()
+
+
+def gather_records(engines, dst: int = 0, self_loop: bool = False):
+    """One process, one HipLd per GPU, each with its device sink on: gather their survivors into engines[dst]'s sink over RCCL
+    (twk_hip_gather_records) -> (records now held by engines[dst], milliseconds of the transfers)."""
+    lib = load_library()
+    arr = (C.c_void_p * len(engines))(*[e._ctx for e in engines])
+    n, ms = C.c_uint64(0), C.c_double(0.0)
+    rc = lib.twk_hip_gather_records(arr, len(engines), dst, GATHER_SELF_LOOP if self_loop else 0, C.byref(n), C.byref(ms))
+    engines[dst]._check(rc, "twk_hip_gather_records")
+    return n.value, ms.value
 
 
 def device_count() -> int:
@@ -453,6 +475,22 @@ class HipLd:
         ptr, n = C.c_void_p(), C.c_uint64(0)
         self._check(self._lib.twk_hip_device_records(self._ctx, C.byref(ptr), C.byref(n)), "twk_hip_device_records")
         return (ptr.value or 0), n.value
+
+    def drain_device_sink(self) -> np.ndarray:
+        """The device sink's records on the host, in the order they lie in the sink; the sink is empty afterwards (twk_hip_drain_device_sink)."""
+        chunks = []
+
+        def sink(_user, recs, n):
+            buf = (C.c_char * (n * RECORD_DTYPE.itemsize)).from_address(recs)
+            chunks.append(np.frombuffer(buf, dtype=RECORD_DTYPE).copy())
+            return 0
+
+        cb = _SINK(sink)
+        n = C.c_uint64(0)
+        self._check(self._lib.twk_hip_drain_device_sink(self._ctx, cb, None, C.byref(n)), "twk_hip_drain_device_sink")
+        out = np.concatenate(chunks) if chunks else np.zeros(0, dtype=RECORD_DTYPE)
+        assert len(out) == n.value
+        return out
 
     def device_records_tensor(self):
         """The device sink's records as a torch uint8 tensor [n * 104] that aliases the engine's HBM buffer (no copy):
