@@ -638,7 +638,7 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 	// unit starts - one dword per lane, no registers held - and published by the chunk barriers like the operand chunks, so
 	// that the epilogue finds it in LDS instead of waiting a memory round trip per tile.
 	constexpr int META = Epilogue::META_WORDS;
-	static_assert(META % 64 == 0 && META <= NW * 64, "whole waves, at most one dword per thread");
+	static_assert(META % 64 == 0 && META <= 2 * NW * 64, "whole waves, at most two dwords per thread");
 	__shared__ uint32_t meta[META ? META : 1];
 
 	const int tid  = threadIdx.x;
@@ -761,15 +761,19 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 			++n_started;
 			if (thread0()) fetched = draw();
 			if (META) {
-				if (wave_u < META / 64) {
-					const uint32_t yx_m = tile_yx;
-					// (the lane id is taken afresh from the hardware, by volatile asm: derived from threadIdx.x the compiler computed
-					// wave * 64 + lane once in front of the loop and kept it in scratch - the kernels' one spilled register, and the
-					// only reason they needed scratch memory at all)
-					uint32_t ln;
-					asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
-					const uint32_t mi = (uint32_t)wave_u * 64u + ln;
-					glds4(epilogue.meta_src(yx_m, mi), (uint32_t)(uintptr_t)(lptr_t*)meta + (uint32_t)wave_u * 256u);
+#pragma unroll
+				for (int round = 0; round < (META + NW * 64 - 1) / (NW * 64); ++round) {
+					const int mw = wave_u + round * NW;          // the 64 dwords this wave fetches in this round
+					if (mw < META / 64) {
+						const uint32_t yx_m = tile_yx;
+						// (the lane id is taken afresh from the hardware, by volatile asm: derived from threadIdx.x the compiler computed
+						// wave * 64 + lane once in front of the loop and kept it in scratch - the kernels' one spilled register, and the
+						// only reason they needed scratch memory at all)
+						uint32_t ln;
+						asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+						const uint32_t mi = (uint32_t)mw * 64u + ln;
+						glds4(epilogue.meta_src(yx_m, mi), (uint32_t)(uintptr_t)(lptr_t*)meta + (uint32_t)mw * 256u);
+					}
 				}
 				if (c + 1 == c_end) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // a one-chunk unit needs it in this very iteration: the barrier below publishes it
 			}
@@ -985,7 +989,27 @@ struct ScreenWork {
 	uint32_t* cand; unsigned long long cap;            // [cap][3]: set position A, set position B, AA  (unphased form: [cap][6]: ..., HH, HQ, QH, QQ)
 	unsigned long long* n_cand;        // device counter of the slots handed out (may run past cap: the host then redoes the tile the plain way)
 	uint32_t chunk;                    // slots a wave reserves at a time (0: exactly what a tile needs, one atomic per wave and tile)
+	// The FP32 prefilter's per-variant terms, computed once per run (k_screen_terms) instead of per lane and tile: terms[pos] = {a / T, sqrt(cut
+	// a (T - a)) / T, b, sqrt(b (T - b)) (1 - 2^-16)} for the variant at set position pos in its role as a row / as a column (a = b = its
+	// ALT allele count; UnphasedMath: its dosage h + 2 q); +inf in the square roots' place where a (T - a) = 0 - a variant that is fixed, or
+	// a padding row: no pair of it can pass the exact test (its D is exactly 0), and +inf keeps it from passing this one.
+	const float4* terms;
+	float slack;                       // 0.5 + T 2^-20 counts: four times the worst rounding of the prefilter's left side
 };
+// -> terms[] of ScreenWork for n_pos set positions (P = 1: rowpop[pos]; P = 2: rowpop[2 pos] + 2 rowpop[2 pos + 1])
+__global__ void k_screen_terms(const uint32_t* __restrict__ rowpop, uint32_t n_pos, int P, double two_n, double cut, float4* __restrict__ terms) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_pos) return;
+	const uint32_t a = P == 1 ? rowpop[i] : rowpop[2 * i] + 2u * rowpop[2 * i + 1];
+	const float T = (float)two_n, af = (float)a, w = af * (T - af);
+	const float inf = __builtin_inff();
+	float4 t;
+	t.x = af / T;
+	t.y = w > 0.0f ? sqrtf((float)cut * w) / T * (1.0f - 1.0f / 65536.0f) : inf;
+	t.z = af;
+	t.w = w > 0.0f ? sqrtf(w) * (1.0f - 1.0f / 65536.0f) : inf;
+	terms[i] = t;
+}
 // Slots are handed out through one counter.  One atomic per wave and tile is 3.9 M atomics on one address in the unphased
 // 2,504-sample window run - at the ~12 ns an L2 channel takes for each, as long as the whole kernel (48 ms where the same
 // tiles with a cut-off few pairs pass take 33).  So a wave reserves `chunk` slots at a time and numbers its candidates
@@ -1035,88 +1059,80 @@ struct ScreenCounts {
 	static constexpr bool PAIRED_ROWS = false;
 	static constexpr bool THREE_PRODUCTS = false;
 	static constexpr bool K_SPLIT = false;
-	static constexpr int META_WORDS = 3 * TILE;      // allele counts of the tile's 128 rows, of its 128 columns, band limits of the rows
+	// staged per tile: [0, 2 TILE) the prefilter's (a / T, sA) of its 128 rows, [2 TILE, 4 TILE) (b, sB) of its 128 columns (ScreenWork::terms),
+	// then - for the exact test - the allele counts of the rows, of the columns, and the rows' band limits
+	static constexpr int META_WORDS = 7 * TILE;
+	static constexpr int M_COLF = 2 * TILE, M_ROWS = 4 * TILE, M_COLS = 5 * TILE, M_REACH = 6 * TILE;
 	const ScreenWork* sp;              // in device memory: read where it is needed, not held in registers through the K loop
 	// where word i of the staged block comes from (always a readable address; what lies outside the region is masked in the epilogue)
 	__device__ __forceinline__ const uint32_t* meta_src(uint32_t yx, uint32_t i) const {
 		const ScreenWork& s = *sp;
-		const uint32_t r = i & (TILE - 1), sA = s.a0 + (yx >> 16) * TILE + r, sB = s.b0 + (yx & 0xFFFFu) * TILE + r;
-		if (i < TILE) return s.rowpop + sA;
-		if (i < 2 * TILE) return s.rowpop + sB;
+		const uint32_t tA = s.a0 + (yx >> 16) * TILE, tB = s.b0 + (yx & 0xFFFFu) * TILE;
+		if (i < (uint32_t)M_COLF) return reinterpret_cast<const uint32_t*>(s.terms + tA + (i >> 1)) + (i & 1u);
+		if (i < (uint32_t)M_ROWS) return reinterpret_cast<const uint32_t*>(s.terms + tB + ((i - M_COLF) >> 1)) + 2 + (i & 1u);
+		const uint32_t r = i & (TILE - 1);
+		if (i < (uint32_t)M_COLS) return s.rowpop + tA + r;
+		if (i < (uint32_t)M_REACH) return s.rowpop + tB + r;
 		if (!s.col_hi) return s.rowpop;
-		const uint32_t k = sA - s.hi_a0;
+		const uint32_t k = tA + r - s.hi_a0;
 		return s.col_hi + (k < s.hi_n ? k : s.hi_n - 1);
 	}
 	__device__ __forceinline__ void finish(SlotWindow& win, int lane) const { release_slots<3>(*sp, win, lane); }
 	__device__ __forceinline__ void operator()(uint32_t (&acc)[8][TB], uint32_t yx, int wr, int wc, int li, int lj, int lane, bool, const uint32_t* meta, SlotWindow& win) const {
 		const ScreenWork& s = *sp;
+		// Round 6: the FP32 prefilter in front of everything, on terms computed once per run (ScreenWork::terms) - per pair a convert, two
+		// fused multiply-adds and a compare:
+		//     |AA - a' b| >= sA sB - slack          a' = a / T, sA = sqrt(cut a (T - a)) / T, sB = sqrt(b (T - b)) (1 - 2^-16)
+		// (AA, a, b <= 2N exact in FP32 below 2^24; slack = 0.5 + T 2^-20 counts is four times the worst rounding of the left side: no pair the
+		// exact test below passes fails this one).  It holds for ANY tile - what the structural tests take away they take away from the pairs
+		// that pass - and rows beyond the matrix or of fixed variants carry sA = +inf.  No lane of the wave with such a pair - the rule for
+		// unlinked variants - and the wave is done: no structural test, no mask, no parameter block read (round 5 took this way out for
+		// interior tiles only, and spent a third of it on the square roots that are now a table).
+		// (not behind a tile that had candidates - win.w[3]: where pairs are in LD their neighbours are too, and a way out that fails is paid on
+		// top of the exact test below)
+		if (uniform(win.w[3]) == 0) {
+			const float slack = s.slack;
+			float2 fa[8], fb[TB];
+#pragma unroll
+			for (int t = 0; t < 8; ++t) fa[t] = *reinterpret_cast<const float2*>(meta + 2 * (wr * 64 + li + 8 * t));
+#pragma unroll
+			for (int u = 0; u < TB; ++u) fb[u] = *reinterpret_cast<const float2*>(meta + M_COLF + 2 * (wc * 8 * TB + lj + 8 * u));
+			bool any = false;
+#pragma unroll
+			for (int t = 0; t < 8; ++t)
+#pragma unroll
+				for (int u = 0; u < TB; ++u)
+					any |= __builtin_fabsf(__builtin_fmaf(-fa[t].x, fb[u].x, (float)acc[t][u])) >= __builtin_fmaf(fa[t].y, fb[u].y, -slack);
+			if (!__ballot(any)) {
+#pragma unroll
+				for (int t = 0; t < 8; ++t)
+#pragma unroll
+					for (int u = 0; u < TB; ++u) acc[t][u] = 0;
+				return;
+			}
+		}
 		const uint32_t r0 = (yx >> 16) * TILE + wr * 64 + li;             // this lane's rows: r0 + 8t
 		const uint32_t c0 = (yx & 0xFFFFu) * TILE + wc * 8 * TB + lj;     // and columns: c0 + 8u
 		const double two_n = s.two_n, cut = s.cut;
 		const uint32_t a0 = s.a0, b0 = s.b0;
-		// everything the lane needs of the staged block in one go (twenty LDS reads in flight, one wait)
-		uint32_t rawB[TB], rawA[8], rawH[8];
-#pragma unroll
-		for (int u = 0; u < TB; ++u) rawB[u] = meta[TILE + wc * 8 * TB + lj + 8 * u];
-#pragma unroll
-		for (int t = 0; t < 8; ++t) { rawA[t] = meta[wr * 64 + li + 8 * t]; rawH[t] = meta[2 * TILE + wr * 64 + li + 8 * t]; }
-		const uint32_t first_reach = meta[2 * TILE];                        // band limit of the tile's first row (the limits never decrease along the rows)
 		const bool diag = s.diag != 0, banded = s.col_hi != nullptr;
 		const uint32_t zone = s.list_zone, pzone = s.probe_zone, nA = s.nA, nB = s.nB, n_variants = s.n_variants, hi_b0 = s.hi_b0;
-		// Fast way out (round 5; csrc/tools/count_microbench.hip FUSED=1: the epilogue was 7.5 % of a five-chunk tile's time and 13 % of a
-		// three-chunk tile's, and most of it is not the screen's arithmetic but the structural tests and the candidate mask built per pair,
-		// ~600 instructions per lane and tile).  A tile that lies wholly inside what its rows take - all 128 x 128 pairs are wanted pairs:
-		// inside the matrix, strictly above the diagonal, below the first row's band limit, outside the list / probe zones - needs none of
-		// them, and whether ANY of the lane's 32 pairs can be a candidate is one FP32 test per pair: with a' = a / T
-		//     |AA - a' b| + slack >= sqrt(cut a (T - a)) / T * sqrt(b (T - b)) * (1 - 2^-16)
-		// (AA, a, b <= 2N exact in FP32 below 2^24; v_rcp / v_sqrt are good to 1 ulp; slack = 0.5 + T 2^-20 counts is four times the worst
-		// rounding of the left side at any T: no pair the exact test below passes fails this one).  No lane of the wave with such a pair - the
-		// rule for unlinked variants - and the wave is done; otherwise the full path runs as before.
-		{
-			const uint32_t rA0 = a0 + (yx >> 16) * TILE, cB0 = b0 + (yx & 0xFFFFu) * TILE;        // set positions of the tile's first row / column
-			const uint32_t endA = a0 + nA < n_variants ? a0 + nA : n_variants, endB = b0 + nB < n_variants ? b0 + nB : n_variants;
-			const bool interior = rA0 + TILE <= endA && cB0 + TILE <= endB && (!diag || cB0 >= rA0 + TILE) && rA0 >= pzone && !(rA0 < zone && cB0 < zone)
-			                      && (!banded || hi_b0 + first_reach >= cB0 + TILE);
-			// (not when the wave's previous tile had candidates - win.w[3]: where pairs are in LD their neighbours are too, and a fast way out
-			// that fails is paid on top of the full path: the survivor-rich window run of 2,504 samples lost 4 % to it before this test)
-			if (interior && uniform(win.w[3]) == 0) {
-				const float Tf = (float)two_n, invT = __builtin_amdgcn_rcpf(Tf), cutf = (float)cut, slack = 0.5f + Tf * (1.0f / 1048576.0f);
-				float bf[TB], sBf[TB];
-#pragma unroll
-				for (int u = 0; u < TB; ++u) { bf[u] = (float)rawB[u]; sBf[u] = __builtin_amdgcn_sqrtf(bf[u] * (Tf - bf[u])) * (1.0f - 1.0f / 65536.0f); }
-				bool any = false;
-#pragma unroll
-				for (int t = 0; t < 8; ++t) {
-					const float af = (float)rawA[t], apf = af * invT;
-					const float sAf = __builtin_amdgcn_sqrtf(cutf * (af * (Tf - af))) * invT;
-#pragma unroll
-					for (int u = 0; u < TB; ++u) any |= __builtin_fabsf(__builtin_fmaf(-apf, bf[u], (float)acc[t][u])) + slack >= sAf * sBf[u];
-				}
-				if (!__ballot(any)) {
-#pragma unroll
-					for (int t = 0; t < 8; ++t)
-#pragma unroll
-						for (int u = 0; u < TB; ++u) acc[t][u] = 0;
-					return;
-				}
-			}
-		}
 		// allele counts of the lane's rows and columns; hiA: first column the row does not reach (0 for a row outside the
 		// tile's variants: reaches nothing) - the columns outside the tile's variants lie beyond every row's reach
 		uint32_t acB[TB], acA[8], hiA[8];
 #pragma unroll
 		for (int u = 0; u < TB; ++u) {
 			const uint32_t cu = c0 + 8 * u, sB = b0 + cu;
-			acB[u] = (cu < nB && sB < n_variants) ? rawB[u] : 0u;
+			acB[u] = (cu < nB && sB < n_variants) ? meta[M_COLS + wc * 8 * TB + lj + 8 * u] : 0u;
 		}
 #pragma unroll
 		for (int t = 0; t < 8; ++t) {
 			const uint32_t rt = r0 + 8 * t, sA = a0 + rt;
 			const bool ok = rt < nA && sA < n_variants;
-			acA[t] = ok ? rawA[t] : 0u;
+			acA[t] = ok ? meta[M_ROWS + wr * 64 + li + 8 * t] : 0u;
 			// first column the row does not reach: the end of the tile's columns, of the matrix, of the row's r2 band
 			uint32_t h = b0 + nB < n_variants ? b0 + nB : n_variants;
-			if (banded) { const uint32_t hb = hi_b0 + rawH[t]; h = hb < h ? hb : h; }
+			if (banded) { const uint32_t hb = hi_b0 + meta[M_REACH + wr * 64 + li + 8 * t]; h = hb < h ? hb : h; }
 			hiA[t] = ok ? h : 0u;
 		}
 		uint32_t m = 0;                  // bit 4t + u: pair (t, u) is a candidate
@@ -1134,8 +1150,6 @@ struct ScreenCounts {
 				m |= (ok ? 1u : 0u) << (4 * t + u);
 			}
 		}
-		// (A per-pair FP32 prefilter in front of this test - with the structural tests and the mask still built per pair - was tried first and
-		// cost more than it saved: 145.1 -> 147.0 ms on the all-pairs run of 2,504 x 200,000, profiles/r05_fused_epilogue.txt.)
 		const bool wave_has = __ballot(m != 0) != 0;
 		if (lane == 0) win.w[3] = wave_has ? 1u : 0u;
 		if (wave_has) {          // (most tiles of unlinked variants end here)
@@ -1193,14 +1207,20 @@ struct ScreenCountsUnphased {
 	static constexpr bool PAIRED_ROWS = true;
 	static constexpr bool THREE_PRODUCTS = THREE;
 	static constexpr bool K_SPLIT = false;
-	static constexpr int META_WORDS = 2 * TILE + TILE / 2;     // H / Q counts of the tile's 128 plane rows, of its 128 plane columns, band limits of its 64 row variants
+	// staged per tile: the prefilter's (da / T, sA) of its 64 row variants and (db, sB) of its 64 column variants (ScreenWork::terms), then - for the
+	// exact test - the H / Q counts of its 128 plane rows and of its 128 plane columns, and the band limits of its 64 row variants
+	static constexpr int U_COLF = TILE, U_ROWS = 2 * TILE, U_COLS = 3 * TILE, U_REACH = 4 * TILE;
+	static constexpr int META_WORDS = 4 * TILE + TILE / 2;
 	const ScreenWork* sp;
 	__device__ __forceinline__ const uint32_t* meta_src(uint32_t yx, uint32_t i) const {
 		const ScreenWork& s = *sp;
-		if (i < TILE) return s.rowpop + 2 * s.a0 + (yx >> 16) * TILE + i;
-		if (i < 2 * TILE) return s.rowpop + 2 * s.b0 + (yx & 0xFFFFu) * TILE + (i - TILE);
+		const uint32_t vA = s.a0 + (yx >> 16) * (TILE / 2), vB = s.b0 + (yx & 0xFFFFu) * (TILE / 2);       // the tile's first row / column variant
+		if (i < (uint32_t)U_COLF) return reinterpret_cast<const uint32_t*>(s.terms + vA + (i >> 1)) + (i & 1u);
+		if (i < (uint32_t)U_ROWS) return reinterpret_cast<const uint32_t*>(s.terms + vB + ((i - U_COLF) >> 1)) + 2 + (i & 1u);
+		if (i < (uint32_t)U_COLS) return s.rowpop + 2 * vA + (i - U_ROWS);
+		if (i < (uint32_t)U_REACH) return s.rowpop + 2 * vB + (i - U_COLS);
 		if (!s.col_hi) return s.rowpop;
-		const uint32_t k = s.a0 + (yx >> 16) * (TILE / 2) + (i - 2 * TILE) - s.hi_a0;
+		const uint32_t k = vA + (i - U_REACH) - s.hi_a0;
 		return s.col_hi + (k < s.hi_n ? k : s.hi_n - 1);
 	}
 	__device__ __forceinline__ void finish(SlotWindow& win, int lane) const { release_slots<6>(*sp, win, lane); }
@@ -1216,70 +1236,55 @@ struct ScreenCountsUnphased {
 		//     ((f11 - P Q) T^2)^2 >= cut a ra b rb.
 		const double T2n = s.two_n, cut = s.cut, eps = 1e-5 * (T2n * T2n);
 		const bool diag = s.diag != 0;
-		// Prefilter in FP32 (round 5, as in ScreenCounts).  Divided by T the two ends of the interval read
+		// Prefilter in FP32 (round 5; round 6: on terms computed once per run, ScreenWork::terms).  Divided by T the two ends of the interval read
 		//     e_lo / T = S - da db / T - eps',   e_hi / T = e_lo / T + HH + 2 eps'      (eps' = 1e-5 T; n11 - ra rb / T = S - da db / T),
-		// and the pair can pass only if max(e_hi, -e_lo) / T >= sqrt(cut da ra db rb) / T = sA * sB[v]: two converts, one fma, three adds, a
-		// max, a multiply and a compare per pair.  S, HH, da, db <= 2N are exact in FP32 below 2^24; the rest is covered by `slack` as there.
+		// and the pair can pass only if max(e_hi, -e_lo) / T >= sqrt(cut da ra db rb) / T = sA sB: a convert or two, two fused multiply-adds, two adds,
+		// a max and a compare per pair.  S, HH, da, db <= 2N are exact in FP32 below 2^24; the rest is covered by `slack` as in ScreenCounts.
 		// Only pairs the prefilter lets through reach the exact FP64 test, so the candidates are those of the exact test alone.
-		const float Tf = (float)T2n, invT = __builtin_amdgcn_rcpf(Tf), epsf = 1e-5f * Tf, slack = 0.5f + Tf * (1.0f / 1048576.0f);
-		// (everything the lane needs of the staged block in one go, as in ScreenCounts)
-		uint32_t rawB[2][2], rawA[4][2], rawH[4];
+		const float Tf = (float)T2n, epsf = 1e-5f * Tf, slack = s.slack;
+		float2 fa[4], fb[2];
 #pragma unroll
-		for (int v = 0; v < 2; ++v) { const int colB = TILE + wc * 8 * TB + 2 * lj + 16 * v; rawB[v][0] = meta[colB]; rawB[v][1] = meta[colB + 1]; }      // plane columns of the variant's H / Q rows within the tile
+		for (int sI = 0; sI < 4; ++sI) fa[sI] = *reinterpret_cast<const float2*>(meta + 2 * (wr * 32 + li + 8 * sI));
 #pragma unroll
-		for (int sI = 0; sI < 4; ++sI) { const int rowA = wr * 64 + 2 * li + 16 * sI; rawA[sI][0] = meta[rowA]; rawA[sI][1] = meta[rowA + 1]; rawH[sI] = meta[2 * TILE + wr * 32 + li + 8 * sI]; }
-		const bool banded = s.col_hi != nullptr;
-		const uint32_t hi_b0 = s.hi_b0, endA = s.a0 + s.nA, endB = s.b0 + s.nB, n_variants = s.n_variants, list_zone = s.list_zone, probe_zone = s.probe_zone;
-		// Fast way out, as in ScreenCounts: a tile wholly inside what its rows take (64 x 64 variant pairs, all wanted) needs no structural
-		// test and no mask - one FP32 test per pair tells whether the lane has a candidate at all, and a wave without one is done.
-		{
-			const uint32_t vrA0 = s.a0 + (yx >> 16) * (TILE / 2), vcB0 = s.b0 + (yx & 0xFFFFu) * (TILE / 2);        // the tile's first row / column variant
-			const uint32_t lastA = endA < n_variants ? endA : n_variants, lastB = endB < n_variants ? endB : n_variants;
-			const uint32_t first_reach = meta[2 * TILE];                       // band limit of the tile's first row variant (never decreasing along the rows)
-			const bool interior = vrA0 + TILE / 2 <= lastA && vcB0 + TILE / 2 <= lastB && (!diag || vcB0 >= vrA0 + TILE / 2) && vrA0 >= probe_zone
-			                      && !(vrA0 < list_zone && vcB0 < list_zone) && (!banded || hi_b0 + first_reach >= vcB0 + TILE / 2);
-			if (interior && uniform(win.w[3]) == 0) {      // (see ScreenCounts: not behind a tile that had candidates)
-				float dbf_[2], sBf_[2];
+		for (int v = 0; v < 2; ++v) fb[v] = *reinterpret_cast<const float2*>(meta + U_COLF + 2 * (wc * (4 * TB) + lj + 8 * v));
+		// Way out, for any tile (round 5: interior tiles only - the structural tests can only take pairs away, and variants beyond the matrix or
+		// fixed ones carry sA = +inf): one FP32 test per pair tells whether the lane has a candidate at all, and a wave without one is done.
+		if (uniform(win.w[3]) == 0) {      // (see ScreenCounts: not behind a tile that had candidates)
+			bool any = false;
 #pragma unroll
-				for (int v = 0; v < 2; ++v) { dbf_[v] = (float)(rawB[v][0] + 2u * rawB[v][1]); sBf_[v] = __builtin_amdgcn_sqrtf(dbf_[v] * (Tf - dbf_[v])) * (1.0f - 1.0f / 65536.0f); }
-				bool any = false;
+			for (int sI = 0; sI < 4; ++sI)
 #pragma unroll
-				for (int sI = 0; sI < 4; ++sI) {
-					const float daf = (float)(rawA[sI][0] + 2u * rawA[sI][1]), paf = daf * invT;
-					const float sAf = __builtin_amdgcn_sqrtf((float)cut * (daf * (Tf - daf))) * invT;
-#pragma unroll
-					for (int v = 0; v < 2; ++v) {
-						const uint32_t hh = acc[2 * sI][2 * v];
-						const uint32_t s_sum = THREE ? acc[2 * sI + 1][2 * v + 1] : acc[2 * sI + 1][2 * v] + acc[2 * sI][2 * v + 1] + 2u * acc[2 * sI + 1][2 * v + 1];
-						const float q = __builtin_fmaf(-paf, dbf_[v], (float)s_sum);
-						any |= __builtin_fmaxf(q + ((float)hh + epsf), epsf - q) + slack >= sAf * sBf_[v];
-					}
+				for (int v = 0; v < 2; ++v) {
+					const uint32_t hh = acc[2 * sI][2 * v];
+					const uint32_t s_sum = THREE ? acc[2 * sI + 1][2 * v + 1] : acc[2 * sI + 1][2 * v] + acc[2 * sI][2 * v + 1] + 2u * acc[2 * sI + 1][2 * v + 1];
+					const float q = __builtin_fmaf(-fa[sI].x, fb[v].x, (float)s_sum);
+					any |= __builtin_fmaxf(q + ((float)hh + epsf), epsf - q) >= __builtin_fmaf(fa[sI].y, fb[v].y, -slack);
 				}
-				if (!__ballot(any)) {
+			if (!__ballot(any)) {
 #pragma unroll
-					for (int t = 0; t < 8; ++t)
+				for (int t = 0; t < 8; ++t)
 #pragma unroll
-						for (int u = 0; u < TB; ++u) acc[t][u] = 0;
-					return;
-				}
+					for (int u = 0; u < TB; ++u) acc[t][u] = 0;
+				return;
 			}
 		}
-		uint32_t vB[2]; float dbf[2], sBf[2];
+		// everything else the lane needs of the staged block in one go
+		uint32_t rawA[4][2], rawH[4];
+#pragma unroll
+		for (int sI = 0; sI < 4; ++sI) { const int rowA = U_ROWS + wr * 64 + 2 * li + 16 * sI; rawA[sI][0] = meta[rowA]; rawA[sI][1] = meta[rowA + 1]; rawH[sI] = meta[U_REACH + wr * 32 + li + 8 * sI]; }
+		const bool banded = s.col_hi != nullptr;
+		const uint32_t hi_b0 = s.hi_b0, endA = s.a0 + s.nA, endB = s.b0 + s.nB, n_variants = s.n_variants, list_zone = s.list_zone, probe_zone = s.probe_zone;
+		uint32_t vB[2];
 #pragma unroll
 		for (int v = 0; v < 2; ++v) {
 			vB[v] = vB0 + 8 * v;
-			const bool okB = vB[v] < endB && vB[v] < n_variants;
-			dbf[v] = (float)(okB ? rawB[v][0] + 2u * rawB[v][1] : 0u);
-			sBf[v] = __builtin_amdgcn_sqrtf(dbf[v] * (Tf - dbf[v]));
-			if (!okB) vB[v] = 0xFFFFFFFFu;                                  // (beyond every row's reach)
+			if (!(vB[v] < endB && vB[v] < n_variants)) vB[v] = 0xFFFFFFFFu;              // (beyond every row's reach)
 		}
-		uint32_t mp = 0;                 // bit 2 sI + v: the pair passes the prefilter
+		uint32_t mp = 0;                 // bit 2 sI + v: the pair passes the prefilter and the structural tests
 #pragma unroll
 		for (int sI = 0; sI < 4; ++sI) {
 			const uint32_t vA = vA0 + 8 * sI;
 			const bool okA = vA < endA && vA < n_variants;
-			const float daf = (float)(okA ? rawA[sI][0] + 2u * rawA[sI][1] : 0u), paf = daf * invT;
-			const float sAf = __builtin_amdgcn_sqrtf((float)cut * (daf * (Tf - daf))) * invT * (1.0f - 1.0f / 65536.0f);
 			uint32_t hi = banded ? hi_b0 + rawH[sI] : 0xFFFFFFFFu;
 			if (!okA || vA < probe_zone) hi = 0;
 			uint32_t lo = diag ? vA + 1 : 0u;
@@ -1289,9 +1294,9 @@ struct ScreenCountsUnphased {
 			for (int v = 0; v < 2; ++v) {
 				const uint32_t hh = acc[2 * sI][2 * v];
 				const uint32_t s_sum = THREE ? acc[2 * sI + 1][2 * v + 1] : acc[2 * sI + 1][2 * v] + acc[2 * sI][2 * v + 1] + 2u * acc[2 * sI + 1][2 * v + 1];      // QH + HQ + 2 QQ
-				const float q = __builtin_fmaf(-paf, dbf[v], (float)s_sum);      // S - da db / T
+				const float q = __builtin_fmaf(-fa[sI].x, fb[v].x, (float)s_sum);      // S - da db / T
 				const float e = __builtin_fmaxf(q + ((float)hh + epsf), epsf - q);
-				const bool ok = (vB[v] - lo) < width && e + slack >= sAf * sBf[v];
+				const bool ok = (vB[v] - lo) < width && e >= __builtin_fmaf(fa[sI].y, fb[v].y, -slack);
 				mp |= (ok ? 1u : 0u) << (2 * sI + v);
 			}
 		}
@@ -1308,7 +1313,7 @@ struct ScreenCountsUnphased {
 					const uint32_t hh = acc[2 * sI][2 * v];
 					const uint32_t s_sum = THREE ? acc[2 * sI + 1][2 * v + 1] : acc[2 * sI + 1][2 * v] + acc[2 * sI][2 * v + 1] + 2u * acc[2 * sI + 1][2 * v + 1];
 					// n11 = ra - b + (QH + HQ + 2 QQ): the (REF, REF) haplotypes that are certain
-					const double dbv = (double)dbf[v], rbv = T2n - dbv;
+					const double dbv = (double)fb[v].x, rbv = T2n - dbv;
 					const double n11 = (ra - dbv) + (double)s_sum;
 					const double e_lo = (n11 * T2n - ra * rbv) - eps;
 					const double e_hi = ((n11 + (double)hh) * T2n - ra * rbv) + eps;

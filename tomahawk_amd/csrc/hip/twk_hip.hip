@@ -60,6 +60,8 @@ struct PlaneSet {
 	uint32_t* lists = nullptr; uint32_t* list_mac = nullptr; uint32_t* list_flip = nullptr;
 	uint32_t  n_list = 0, list_max = 0;
 	uint32_t  n_probe = 0;         // <= n_list: the leading variants whose lists are short enough for probing to beat the dense pair (ld_list.hip.h)
+	// fused screen kernels: the prefilter's per-variant terms at the cut-off of the run that built them (ScreenWork::terms, k_screen_terms)
+	float4*   terms = nullptr; double terms_cut = -1.0;
 };
 
 // Plane sets a context can hold: one per PlaneKind in file order, plus the masked unphased planes
@@ -271,6 +273,7 @@ void free_planes(twk_hip_ctx* c) {
 		if (p.lists) (void)hipFree(p.lists);
 		if (p.list_mac) (void)hipFree(p.list_mac);
 		if (p.list_flip) (void)hipFree(p.list_flip);
+		if (p.terms) (void)hipFree(p.terms);
 		p = PlaneSet();
 	}
 }
@@ -828,7 +831,16 @@ int enqueue_tile(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, const twk
 		s.cand_cap = std::min<unsigned long long>(room, c->opt.three == 2 ? room : std::max<unsigned long long>(pairs / 128, 4096));
 	}
 	if (want_fused) {
-		const PlaneSet& ps = c->planes[kind1];
+		PlaneSet& ps = c->planes[kind1];
+		sw.cut = f.minR2 * (1.0 - 1e-6); sw.two_n = 2.0 * (double)c->N;
+		if (fuses && (!ps.terms || ps.terms_cut != sw.cut)) {      // the prefilter's per-variant terms: once per plane set and cut-off, on the stream the kernels follow
+			const uint32_t P1 = (uint32_t)planes_per_variant(set_kind(kind1)), n_pos = ps.rows_alloc / P1;
+			if (!ps.terms) HIPCHK(c, hipMalloc((void**)&ps.terms, (size_t)n_pos * sizeof(float4)));
+			hipLaunchKernelGGL(k_screen_terms, dim3((n_pos + 255) / 256), dim3(256), 0, c->s_compute, (const uint32_t*)ps.rowpop, n_pos, (int)P1, sw.two_n, sw.cut, ps.terms);
+			HIPCHK(c, hipGetLastError());
+			ps.terms_cut = sw.cut;
+		}
+		sw.terms = ps.terms; sw.slack = 0.5f + (float)sw.two_n * (1.0f / 1048576.0f);
 		fa.stats = make_stats(c, kind1, t, s, phased, pl.select1, f, cr);
 		sw.rowpop = ps.rowpop; sw.a0 = t.rowA0; sw.b0 = t.rowB0; sw.nA = t.nA; sw.nB = t.nB;
 		sw.n_variants = c->M; sw.diag = (t.diag && t.rowA0 == t.rowB0) ? 1 : 0;
@@ -2288,6 +2300,7 @@ static int region_dispatch(twk_hip_ctx* c, int mode, const twk_hip_filters* f, u
 				if (ps.lists) (void)hipFree(ps.lists);
 				if (ps.list_mac) (void)hipFree(ps.list_mac);
 				if (ps.list_flip) (void)hipFree(ps.list_flip);
+				if (ps.terms) (void)hipFree(ps.terms);
 				ps = PlaneSet();
 			}
 		}

@@ -107,9 +107,12 @@ int main(int argc,char**argv){
     twk::ScreenWork sw{}; sw.rowpop=dpop; sw.a0=0; sw.b0=0; sw.n_variants=R; sw.diag=0; sw.col_hi=nullptr; sw.list_zone=0; sw.probe_zone=0; sw.cut=0.1*(1.0-1e-6);
     sw.cand=C; sw.cap=(unsigned long long)R*R/8; sw.n_cand=dn; sw.chunk=64;
     twk::ScreenWork* dsw; CK(hipMalloc(&dsw,sizeof(sw)));
+    float4* dterms; CK(hipMalloc(&dterms,(size_t)(R+256)*sizeof(float4)));
     const double tiles=(double)list.size();
     for(int form=0; form<3; ++form){   // 0 phased (rows = variants), 1 unphased four products, 2 unphased three products (rows 2v, 2v+1 = H, Q)
       sw.nA=sw.nB= form? R/2 : R; sw.n_variants=sw.nA; sw.two_n = form? 2.0*W*32 : 1.0*W*32;
+      hipLaunchKernelGGL(twk::k_screen_terms,dim3((sw.nA+255)/256),dim3(256),0,0,(const uint32_t*)dpop,sw.nA,form?2:1,sw.two_n,sw.cut,dterms);
+      sw.terms=dterms; sw.slack=0.5f+(float)sw.two_n*(1.0f/1048576.0f);
       CK(hipMemcpy(dsw,&sw,sizeof(sw),hipMemcpyHostToDevice));
       for(int noepi=0; noepi<2; ++noepi){
         auto launch=[&](){ CK(hipMemsetAsync(tick,0,4,0)); CK(hipMemsetAsync(dn,0,8,0));
