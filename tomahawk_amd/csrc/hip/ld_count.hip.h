@@ -542,7 +542,8 @@ inline void fill_unit_tiles(Vec& units, const uint32_t* tiles) { for (auto& u : 
 // the counts go to the super-tile's C matrix (stored for a whole tile, added for a part of its K range).
 // What a wave keeps between the units it runs (fused forms: the candidate slots it has reserved and not yet used): three
 // words of LDS per wave - the first free slot (64 bits) and how many are left; in registers they were spilled.
-struct SlotWindow { uint32_t* w; };
+struct SlotWindow { uint32_t* w; uint2* q; };       // q: the wave's queue of pairs that passed the prefilter (ScreenCounts: QUEUE entries; else null)
+constexpr int SCREEN_QUEUE = 128;     // two entries per lane of the wave: the exact test of a tile's flagged pairs is one or two passes of the wave
 
 template <int TB>
 struct StoreCounts {
@@ -550,6 +551,7 @@ struct StoreCounts {
 	static constexpr bool PAIRED_ROWS = false; // a lane's rows are li + 8t (see read_half)
 	static constexpr bool THREE_PRODUCTS = false;
 	static constexpr bool K_SPLIT = false;
+	static constexpr bool QUEUED = false;
 	uint32_t* C; uint32_t ldc;
 	__device__ __forceinline__ const uint32_t* meta_src(uint32_t, uint32_t) const { return nullptr; }
 	__device__ __forceinline__ void finish(SlotWindow&, int) const {}
@@ -578,6 +580,7 @@ struct StoreCounts3 {
 	static constexpr bool PAIRED_ROWS = true;
 	static constexpr bool THREE_PRODUCTS = true;
 	static constexpr bool K_SPLIT = false;
+	static constexpr bool QUEUED = false;
 	uint32_t* C; uint32_t ldc;
 	__device__ __forceinline__ const uint32_t* meta_src(uint32_t, uint32_t) const { return nullptr; }
 	__device__ __forceinline__ void finish(SlotWindow&, int) const {}
@@ -607,6 +610,7 @@ struct StoreCounts3Wide {
 	static constexpr bool PAIRED_ROWS = true;
 	static constexpr bool THREE_PRODUCTS = true;
 	static constexpr bool K_SPLIT = true;
+	static constexpr bool QUEUED = false;
 	uint32_t* C; uint32_t ldc;
 	__device__ __forceinline__ const uint32_t* meta_src(uint32_t, uint32_t) const { return nullptr; }
 	__device__ __forceinline__ void finish(SlotWindow&, int) const {}
@@ -742,9 +746,11 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 	uint32_t st_row0 = stage_row0(tile_yx);
 	stage_rows_s(w.rows, w.W, st_row0, c, st_lds, st_seg0, NSEG, voff_even, voff_odd);
 	uint32_t seg_c0 = c;
-	__shared__ uint32_t window_words[NW][4];
-	SlotWindow window{&window_words[wave_u][0]};
-	if (lane < 4) window.w[lane] = 0;           // (wave-private: no barrier)
+	__shared__ uint32_t window_words[NW][8];
+	constexpr bool QUEUED = Epilogue::QUEUED;
+	__shared__ uint2 queue_words[QUEUED ? NW : 1][QUEUED ? SCREEN_QUEUE : 1];
+	SlotWindow window{&window_words[wave_u][0], QUEUED ? &queue_words[wave_u][0] : nullptr};
+	if (lane < 8) window.w[lane] = 0;           // (wave-private: no barrier)
 	int buf = 0;
 	for (;;) {
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1059,6 +1065,7 @@ struct ScreenCounts {
 	static constexpr bool PAIRED_ROWS = false;
 	static constexpr bool THREE_PRODUCTS = false;
 	static constexpr bool K_SPLIT = false;
+	static constexpr bool QUEUED = true;       // the wave's queue of prefilter-passing pairs (SlotWindow::q)
 	// staged per tile: [0, 2 TILE) the prefilter's (a / T, sA) of its 128 rows, [2 TILE, 4 TILE) (b, sB) of its 128 columns (ScreenWork::terms),
 	// then - for the exact test - the allele counts of the rows, of the columns, and the rows' band limits
 	static constexpr int META_WORDS = 7 * TILE;
@@ -1088,35 +1095,78 @@ struct ScreenCounts {
 		// that pass - and rows beyond the matrix or of fixed variants carry sA = +inf.  No lane of the wave with such a pair - the rule for
 		// unlinked variants - and the wave is done: no structural test, no mask, no parameter block read (round 5 took this way out for
 		// interior tiles only, and spent a third of it on the square roots that are now a table).
-		// (not behind a tile that had candidates - win.w[3]: where pairs are in LD their neighbours are too, and a way out that fails is paid on
-		// top of the exact test below)
-		if (uniform(win.w[3]) == 0) {
-			const float slack = s.slack;
-			float2 fa[8], fb[TB];
-#pragma unroll
-			for (int t = 0; t < 8; ++t) fa[t] = *reinterpret_cast<const float2*>(meta + 2 * (wr * 64 + li + 8 * t));
-#pragma unroll
-			for (int u = 0; u < TB; ++u) fb[u] = *reinterpret_cast<const float2*>(meta + M_COLF + 2 * (wc * 8 * TB + lj + 8 * u));
-			bool any = false;
-#pragma unroll
-			for (int t = 0; t < 8; ++t)
-#pragma unroll
-				for (int u = 0; u < TB; ++u)
-					any |= __builtin_fabsf(__builtin_fmaf(-fa[t].x, fb[u].x, (float)acc[t][u])) >= __builtin_fmaf(fa[t].y, fb[u].y, -slack);
-			if (!__ballot(any)) {
-#pragma unroll
-				for (int t = 0; t < 8; ++t)
-#pragma unroll
-					for (int u = 0; u < TB; ++u) acc[t][u] = 0;
-				return;
-			}
-		}
+		// The wave has pairs to look at - where variants are in LD, a handful among its 2,048.  Round 5 ran the structural tests and the FP64
+		// screen for all thirty-two pairs of every lane then; slot by slot behind wave-uniform branches it costs the same (a wave executes a
+		// slot's test for one lane's sake).  Instead the lanes QUEUE their flagged pairs - (lane, slot, count), one LDS atomic each, in the wave's
+		// own 64-entry queue - and the wave then tests the queue's entries one per lane: one pass of the exact test per tile instead of thirty-two.
+		// A tile with more flagged pairs than the queue holds (dense LD next to the diagonal) takes round 5's way.
 		const uint32_t r0 = (yx >> 16) * TILE + wr * 64 + li;             // this lane's rows: r0 + 8t
 		const uint32_t c0 = (yx & 0xFFFFu) * TILE + wc * 8 * TB + lj;     // and columns: c0 + 8u
 		const double two_n = s.two_n, cut = s.cut;
 		const uint32_t a0 = s.a0, b0 = s.b0;
 		const bool diag = s.diag != 0, banded = s.col_hi != nullptr;
 		const uint32_t zone = s.list_zone, pzone = s.probe_zone, nA = s.nA, nB = s.nB, n_variants = s.n_variants, hi_b0 = s.hi_b0;
+		typedef __attribute__((address_space(3))) uint32_t l_u32;
+		// (win.w[5]: the wave's previous tile overflowed the queue - dense LD comes in runs of tiles, and queueing that fails is paid on top of
+		// the full test; the full test clears the flag again when it finds a tile the queue would have held)
+		const bool try_queue = uniform(win.w[5]) == 0;
+		uint32_t n_q = SCREEN_QUEUE + 1;
+		if (try_queue) {
+			if (lane == 0) win.w[4] = 0;
+			const float slack = s.slack;
+#pragma unroll
+			for (int t = 0; t < 8; ++t) {
+				const float2 fa = *reinterpret_cast<const float2*>(meta + 2 * (wr * 64 + li + 8 * t));
+#pragma unroll
+				for (int u = 0; u < TB; ++u) {
+					const float2 fb = *reinterpret_cast<const float2*>(meta + M_COLF + 2 * (wc * 8 * TB + lj + 8 * u));
+					if (__builtin_fabsf(__builtin_fmaf(-fa.x, fb.x, (float)acc[t][u])) >= __builtin_fmaf(fa.y, fb.y, -slack)) {
+						const uint32_t at = __hip_atomic_fetch_add((l_u32*)&win.w[4], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+						if (at < (uint32_t)SCREEN_QUEUE) win.q[at] = make_uint2(((uint32_t)lane << 8) | (uint32_t)(4 * t + u), acc[t][u]);
+					}
+				}
+			}
+			n_q = uniform(win.w[4]);
+			if (n_q > (uint32_t)SCREEN_QUEUE && lane == 0) win.w[5] = 1;
+		}
+		if (n_q <= (uint32_t)SCREEN_QUEUE) {
+			bool any_ok = false;
+			for (uint32_t base = 0; base < n_q; base += 64) {          // (wave-uniform: one pass, two for a tile with more than 64 flagged pairs)
+				bool ok = false; uint32_t eA = 0, eB = 0, eN = 0;
+				if (base + (uint32_t)lane < n_q) {
+					const uint2 e = win.q[base + lane];
+					const uint32_t src = e.x >> 8, slot = e.x & 31u, t = slot >> 2, u = slot & 3u;
+					const uint32_t tr = (uint32_t)wr * 64 + (src >> 3) + 8 * t, tc = (uint32_t)wc * 8 * TB + (src & 7u) + 8 * u;       // row / column within the tile
+					const uint32_t rt = (yx >> 16) * TILE + tr, cu = (yx & 0xFFFFu) * TILE + tc;
+					const uint32_t sA = a0 + rt, sB = b0 + cu;
+					eA = sA; eB = sB; eN = e.y;
+					if (rt < nA && sA < n_variants && cu < nB && sB < n_variants) {
+						uint32_t h = b0 + nB < n_variants ? b0 + nB : n_variants;
+						if (banded) { const uint32_t hb = hi_b0 + meta[M_REACH + tr]; h = hb < h ? hb : h; }
+						const double a = (double)meta[M_ROWS + tr], b = (double)meta[M_COLS + tc];
+						const double dn = two_n * (double)e.y - a * b;
+						ok = (!diag || sB > sA) && sB < h && !((sA < zone && sB < zone) || sA < pzone) && dn != 0.0 && dn * dn >= (cut * (a * (two_n - a))) * (b * (two_n - b));
+					}
+				}
+				const unsigned long long votes = __ballot(ok);
+				if (votes) {
+					typedef __attribute__((address_space(1))) uint32_t g_u32;
+					any_ok = true;
+					const uint32_t total = (uint32_t)__popcll(votes);
+					const SlotRange slots = reserve_slots(s, win, total, lane);
+					if (ok) {
+						const unsigned long long slot = slots[(uint32_t)__popcll(votes & ((1ull << lane) - 1ull))];
+						if (slot < s.cap) { g_u32* o = (g_u32*)s.cand + slot * 3; o[0] = eA; o[1] = eB; o[2] = eN; }
+					}
+				}
+			}
+			if (lane == 0) win.w[3] = any_ok ? 1u : 0u;
+#pragma unroll
+			for (int t = 0; t < 8; ++t)
+#pragma unroll
+				for (int u = 0; u < TB; ++u) acc[t][u] = 0;
+			return;
+		}
 		// allele counts of the lane's rows and columns; hiA: first column the row does not reach (0 for a row outside the
 		// tile's variants: reaches nothing) - the columns outside the tile's variants lie beyond every row's reach
 		uint32_t acB[TB], acA[8], hiA[8];
@@ -1128,12 +1178,12 @@ struct ScreenCounts {
 #pragma unroll
 		for (int t = 0; t < 8; ++t) {
 			const uint32_t rt = r0 + 8 * t, sA = a0 + rt;
-			const bool ok = rt < nA && sA < n_variants;
-			acA[t] = ok ? meta[M_ROWS + wr * 64 + li + 8 * t] : 0u;
+			const bool okr = rt < nA && sA < n_variants;
+			acA[t] = okr ? meta[M_ROWS + wr * 64 + li + 8 * t] : 0u;
 			// first column the row does not reach: the end of the tile's columns, of the matrix, of the row's r2 band
 			uint32_t h = b0 + nB < n_variants ? b0 + nB : n_variants;
 			if (banded) { const uint32_t hb = hi_b0 + meta[M_REACH + wr * 64 + li + 8 * t]; h = hb < h ? hb : h; }
-			hiA[t] = ok ? h : 0u;
+			hiA[t] = okr ? h : 0u;
 		}
 		uint32_t m = 0;                  // bit 4t + u: pair (t, u) is a candidate
 #pragma unroll
@@ -1146,16 +1196,18 @@ struct ScreenCounts {
 				const uint32_t sB = b0 + c0 + 8 * u;
 				const double b = (double)acB[u];
 				const double dn = two_n * (double)acc[t][u] - a * b;
-				const bool ok = (!diag || sB > sA) && sB < hiA[t] && !((sA < zone && sB < zone) || sA < pzone) && dn != 0.0 && dn * dn >= fA * (b * (two_n - b));
-				m |= (ok ? 1u : 0u) << (4 * t + u);
+				const bool okp = (!diag || sB > sA) && sB < hiA[t] && !((sA < zone && sB < zone) || sA < pzone) && dn != 0.0 && dn * dn >= fA * (b * (two_n - b));
+				m |= (okp ? 1u : 0u) << (4 * t + u);
 			}
 		}
 		const bool wave_has = __ballot(m != 0) != 0;
 		if (lane == 0) win.w[3] = wave_has ? 1u : 0u;
-		if (wave_has) {          // (most tiles of unlinked variants end here)
+		{
 			const uint32_t cnt = __popc(m);
 			const uint32_t incl = wave_scan_inclusive(cnt);
 			const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+			if (lane == 0) win.w[5] = total > (uint32_t)(SCREEN_QUEUE / 4) ? 1u : 0u;      // (the prefilter flags a few times the pairs that pass: back to the queue where the tile held few)
+			if (wave_has) {
 			// (the pointers come out of the parameter block as generic addresses: say that they are global memory, or
 			// every candidate store becomes a flat store that also waits on the LDS queue)
 			typedef __attribute__((address_space(1))) uint32_t g_u32;
@@ -1174,6 +1226,7 @@ struct ScreenCounts {
 						}
 						++mine;
 					}
+			}
 		}
 #pragma unroll
 		for (int t = 0; t < 8; ++t)
@@ -1207,6 +1260,7 @@ struct ScreenCountsUnphased {
 	static constexpr bool PAIRED_ROWS = true;
 	static constexpr bool THREE_PRODUCTS = THREE;
 	static constexpr bool K_SPLIT = false;
+	static constexpr bool QUEUED = false;
 	// staged per tile: the prefilter's (da / T, sA) of its 64 row variants and (db, sB) of its 64 column variants (ScreenWork::terms), then - for the
 	// exact test - the H / Q counts of its 128 plane rows and of its 128 plane columns, and the band limits of its 64 row variants
 	static constexpr int U_COLF = TILE, U_ROWS = 2 * TILE, U_COLS = 3 * TILE, U_REACH = 4 * TILE;
