@@ -16,7 +16,7 @@ stats() {   # stats <name> <bench args...>: kernel trace + stats of one bench ru
 	local name=$1; shift
 	rm -rf /tmp/prof_$name
 	timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -o $name -- \
-		python3 $R/bench.py --no-cpu-baseline --no-e2e --no-traffic --no-extra "$@" > $OUT/${name}_under_rocprof.json 2> $OUT/${name}_under_rocprof.log < /dev/null
+		python3 $R/bench.py --no-cpu-baseline --no-e2e --no-traffic --no-extra --no-planted "$@" > $OUT/${name}_under_rocprof.json 2> $OUT/${name}_under_rocprof.log < /dev/null
 	echo "$name stats rc=$?"
 	local f; f=$(find /tmp/prof_$name -name "*kernel_stats.csv" | head -1)
 	[ -n "$f" ] && cp "$f" $OUT/${name}_kernel_stats.csv && head -5 "$f" | cut -c1-220
@@ -25,7 +25,7 @@ pmc() {     # pmc <name> <counter list> <bench args...>: one counter pass, per-k
 	local name=$1 ctr=$2; shift 2
 	rm -rf /tmp/pmc_$name
 	timeout 900 rocprofv3 --pmc $ctr --output-format csv -d /tmp/pmc_$name -o $name -- \
-		python3 $R/bench.py --no-cpu-baseline --no-e2e --no-traffic --no-extra "$@" > $OUT/${name}_pmc.json 2> $OUT/${name}_pmc.log < /dev/null
+		python3 $R/bench.py --no-cpu-baseline --no-e2e --no-traffic --no-extra --no-planted "$@" > $OUT/${name}_pmc.json 2> $OUT/${name}_pmc.log < /dev/null
 	echo "$name pmc rc=$?"
 	local f; f=$(find /tmp/pmc_$name -name "*counter_collection.csv" | head -1)
 	[ -n "$f" ] && python3 $R/profiles/sum_counters.py "$f" > $OUT/${name}_pmc_sums.json && cat $OUT/${name}_pmc_sums.json | head -60
