@@ -768,8 +768,10 @@ def main():
                "count_kernel_ms_per_step": tm3["count_ms"] / 2, "count_launches_per_step": tm3["count_launches"] / 2,
                "three_product_launches": int(tm3["three_launches"]), "recounted_candidates_per_step": tm3["recount_candidates"] / 2,
                # rank 0's engine, per step: recount + UnphasedMath + Fisher (HIP events: from the count kernel's end to the end of Fisher's walks),
-               # and the host's wall from a finished launch to its records' hand-over (device sort, copy-back, the sink)
-               "math_kernels_ms_per_step": tm3["stats_ms"] / 2, "sort_copyback_sink_ms_per_step": tm3.get("finish_ms", 0.0) / 2,
+               # and the calling thread's wall from a launch's last kernel to its records' hand-over (device sort, copy-back, the sink), summed over
+               # the launches - most of it waiting for the sort's kernels to get registers beside the NEXT launch's persistent count kernel (the wide
+               # lane tile fills the register file), and overlapped by it: the pipeline keeps three launches in flight, compute_ms_per_step says what is left
+               "math_kernels_ms_per_step": tm3["stats_ms"] / 2, "sort_copyback_sink_wall_ms_per_step_overlapped": tm3.get("finish_ms", 0.0) / 2,
                "compute_ms_per_step": ph3["compute"] / 2 * 1e3, "gather_ms_per_step": ph3["gather"] / 2 * 1e3, "write_ms_per_step": ph3["write"] / 2 * 1e3,
                "gather_bytes_per_step": ph3["xfer_bytes"] / 2, "gather_GBps": (ph3["xfer_bytes"] / ph3["xfer"] / 1e9) if ph3["xfer"] > 0 and ph3["xfer_bytes"] else None,
                "executed_frac_of_issue_ceiling": (products + ors / 3.0) / k_s / VALU_PAIR_PEAK if k_s > 0 else None,
