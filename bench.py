@@ -529,6 +529,15 @@ def main():
                     "sharded configs on a single-GPU box; the value then covers that shard only)")
     args = ap.parse_args()
 
+    # The contract is ONE JSON line on stdout.  Libraries underneath do not know that - RCCL prints a banner of its version, the host name
+    # and its own path to stdout the first time a communicator comes up (in every rank of an N > 1 run, and in the native-gather leg at N = 1),
+    # through C stdio, flushed when the process ends: behind the JSON line.  So file descriptor 1 is pointed at stderr for the life of the
+    # process and the line goes out through a duplicate of the real stdout made before that.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    os.environ.setdefault("NCCL_DEBUG", "NONE")       # (... and RCCL is told not to print it at all, unless the caller wants its log)
+
     import torch
     import torch.distributed as dist
     import numpy as np
@@ -744,6 +753,33 @@ def main():
         eng.set_option("three", 0)
         el4, pairs4, recs4, tm4, ph4, r4 = run(1, "q")
         eng.unset_option("three")
+        native = None
+        if world == 1:
+            # One GPU: what can be shown of the C++ product's own gather (twk_hip_gather_records: dlopen'd librccl, ncclCommInitAll, one group of
+            # exact-size ncclSend / ncclRecv, device sink to device sink) - one more step with the survivors kept in HBM, then round RCCL's loop
+            # from the sink to itself, then to the host once (twk_hip_drain_device_sink), and compared with the step above.
+            try:
+                eng.set_device_sink(True)
+                t_n = time.perf_counter()
+                if slab:
+                    _, _, n_rec = eng.ld_region(hip_mode, filters, 0, slab[1] - slab[0], 0, slab[2] - slab[0], True, tile_variants=args.tile, window=1, l_window=window_bp)
+                else:
+                    _, _, n_rec = eng.ld_all(hip_mode, filters, part=shard_rank, n_parts=shard_world, tile_variants=args.tile)
+                t_c = time.perf_counter()
+                n_g, xfer_ms = T.gather_records([eng], self_loop=True)
+                back = eng.drain_device_sink()
+                if slab and len(back) and slab[0]:
+                    back["idxA"] += slab[0]; back["idxB"] += slab[0]
+                order_n = ["idxA", "idxB"]
+                native = {"backend": T.gather_backend(), "records": int(n_g), "bytes": int(n_g) * T.RECORD_DTYPE.itemsize, "transfer_ms": xfer_ms,
+                          "GBps": (n_g * T.RECORD_DTYPE.itemsize / (xfer_ms * 1e-3) / 1e9) if xfer_ms > 0 and n_g else None,
+                          "compute_ms": (t_c - t_n) * 1e3, "gather_and_drain_ms": (time.perf_counter() - t_c) * 1e3,
+                          "equal_to_streamed_step": bool(r3 is not None and n_g == n_rec == len(r3) and np.sort(back, order=order_n).tobytes() == np.sort(np.asarray(r3), order=order_n).tobytes()),
+                          "note": "one GPU: the one context's records go from its device sink to itself through the same group of ncclSend / ncclRecv a multi-GPU run uses"}
+            except Exception as e:           # never take the leg down with it
+                native = {"error": repr(e)[:300]}
+            finally:
+                eng.set_device_sink(False)
         if rank != 0:
             return None
         key = lambda r: set(zip(r["idxA"].tolist(), r["idxB"].tolist())) if r is not None and len(r) else set()
@@ -778,6 +814,7 @@ def main():
                "four_product_step": {"ms_per_step": el4 * 1e3, "value": pairs4 / el4, "survivors": recs4, "count_kernel_ms": tm4["count_ms"],
                                      "math_kernels_ms": tm4["stats_ms"], "three_product_launches": int(tm4["three_launches"]),
                                      "executed_frac_of_and_bcnt_ceiling": (executed_work(tm4)[0] / (tm4["count_ms"] * 1e-3) / VALU_PAIR_PEAK) if tm4["count_ms"] > 0 else None},
+               "native_gather_self_loop": native,
                "planted_pairs": len(planted), "planted_found": len(found), "planted_expected": len(expected),
                "survivors_not_planted": len(k3 - set(planted)), "records_equal_four_product": bool(same),
                "largest_flip_probability_found": max((planted[kk] for kk in found), default=None),
@@ -943,7 +980,8 @@ def main():
                     extra[name] = None
                 log(f"extra {name}: {time.time() - t_x:.1f}s")
             out["extra"] = extra
-        print(json.dumps(out), flush=True)
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
     eng.close()
     if world > 1:
         dist.barrier()

@@ -291,7 +291,8 @@ int twk_hip_device_records(twk_hip_ctx* ctx, const twk_hip_record** records, uin
  * sink holds its own records followed by those of the other contexts in the order of ctxs[]; the others' sinks are empty.
  * This is the north star's "final RCCL gather of .two output blocks over xGMI" inside the C++ product; it replaces every slave's
  * flush of its output block into the shared writer (lib/ld/ld_engine.cpp:1742-1802).  librccl is opened on first use (dlopen), never
- * linked: twk_hip_gather_backend() says what was found.  n == 1: nothing to move - unless flags has TWK_HIP_GATHER_SELF_LOOP, which
+ * linked: twk_hip_gather_backend() says what was found (and NCCL_DEBUG is set to NONE unless the caller has set it: RCCL otherwise
+ * prints a banner to stdout when its first communicator comes up).  n == 1: nothing to move - unless flags has TWK_HIP_GATHER_SELF_LOOP, which
  * sends the one context's records from its sink to itself through the same group of calls (what a one-GPU box can exercise of the
  * path).  *transfer_ms (may be NULL): the transfers' duration on the destination's stream (HIP events).  Everything gathered must fit
  * the destination's HBM beside its problem (TWK_HIP_E_NOMEM otherwise: the caller falls back to per-GPU copies to the host). */

@@ -539,8 +539,8 @@ def _run_bench(tmp_path, world, extra, tag, backend="gloo"):
                "--master-port", str(port), os.path.join(root, "bench.py"), "--backend", backend] + common
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, cwd=root)
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]          # ONE JSON line and nothing else on stdout, whatever the libraries print
     recs, info = hostlib.read_two(two)
     return json.loads(lines[0]), recs
 

@@ -64,6 +64,7 @@ def test_cli_gather_option_writes_the_same_file_records(tmp_path):
         assert r.returncode == 0, r.stderr
         if "gather" in tag:
             assert "Gathered" in r.stderr and " over rccl " in r.stderr, r.stderr[-800:]
+        assert r.stdout == "", r.stdout[:300]            # (RCCL's start-up banner goes to stdout unless told otherwise: the engine tells it)
         recs, _ = hostlib.read_two(out)
         outs[tag] = np.sort(recs, order=["ridA", "packA", "ridB", "packB"])
     assert len(outs["stream"]) > 10_000 and outs["stream"].tobytes() == outs["gather"].tobytes()

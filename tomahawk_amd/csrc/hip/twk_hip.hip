@@ -2487,6 +2487,9 @@ struct Rccl {
 	bool open() {
 		if (tried) return lib != nullptr;
 		tried = true;
+		// RCCL 2.27 prints a banner (its version, HIP's, the host name, its own path) to STDOUT when the first communicator comes up, unless
+		// NCCL_DEBUG says NONE: a `tomahawk calc` whose stdout is somebody's pipe must not grow five lines.  Left alone if the caller set it.
+		(void)setenv("NCCL_DEBUG", "NONE", 0);
 		for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { lib = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (lib) break; }
 		if (!lib) { snprintf(why, sizeof(why), "librccl.so.1 cannot be opened: %s", dlerror()); return false; }
 		auto sym = [&](const char* n) { void* p = dlsym(lib, n); if (!p) snprintf(why, sizeof(why), "librccl lacks %s", n); return p; };
@@ -2556,7 +2559,12 @@ int twk_hip_gather_records(twk_hip_ctx* const* ctxs, uint32_t n, uint32_t dst, i
 		d->d_keep_n = own;
 		const int e = ensure_device_keep(d, total - own); if (e) return e;         // (keeps the destination's own records, at the front)
 	}
-	hipEvent_t e0 = nullptr, e1 = nullptr;
+	struct Events {          // (destroyed on every way out)
+		hipEvent_t e0 = nullptr, e1 = nullptr;
+		~Events() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
+	} ev;
+	hipEvent_t& e0 = ev.e0; hipEvent_t& e1 = ev.e1;
+	struct LoopBuf { twk_hip_record** p; ~LoopBuf() { if (*p) (void)hipFree(*p); } } loop_guard{&loop_buf};      // (freed unless it became the sink)
 	HIPCHK(d, hipEventCreate(&e0)); HIPCHK(d, hipEventCreate(&e1));
 	HIPCHK(d, hipEventRecord(e0, d->s_copy));
 	int rcode = NCHK(rc.GroupStart(), "ncclGroupStart");
@@ -2579,12 +2587,12 @@ int twk_hip_gather_records(twk_hip_ctx* const* ctxs, uint32_t n, uint32_t dst, i
 	(void)hipSetDevice(d->device);
 	float ms = 0;
 	if (!rcode && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && transfer_ms) *transfer_ms = ms;
-	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-	if (rcode) { if (loop_buf) (void)hipFree(loop_buf); if (!d->err[0]) snprintf(d->err, sizeof(d->err), "RCCL gather: a HIP call failed"); return rcode; }
+	if (rcode) { if (!d->err[0]) snprintf(d->err, sizeof(d->err), "RCCL gather: a HIP call failed"); return rcode; }
 	if (loop) {
 		if (loop_buf) {        // the records that went round are the sink's content from here on
 			if (d->d_keep) (void)hipFree(d->d_keep);
 			d->d_keep = loop_buf; d->d_keep_cap = cnt[0];
+			loop_buf = nullptr;
 		}
 	} else {
 		d->d_keep_n = total;
