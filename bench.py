@@ -536,7 +536,8 @@ def main():
     sys.stdout.flush()
     json_out = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
-    os.environ.setdefault("NCCL_DEBUG", "NONE")       # (... and RCCL is told not to print it at all, unless the caller wants its log)
+    os.environ.setdefault("NCCL_DEBUG", "NONE")       # (... and RCCL is told not to print it at all, unless the caller wants its log - this pool's
+                                                      # image exports NCCL_DEBUG=VERSION, so here the redirection is what keeps the line alone)
 
     import torch
     import torch.distributed as dist

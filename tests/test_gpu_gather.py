@@ -60,11 +60,12 @@ def test_cli_gather_option_writes_the_same_file_records(tmp_path):
     outs = {}
     for tag, extra in (("stream", []), ("gather", ["--engine-option", "gather=1"]), ("gather_w", ["--engine-option", "gather=1", "-w", "9000"]), ("stream_w", ["-w", "9000"])):
         out = str(tmp_path / f"{tag}.two")
-        r = subprocess.run([hostlib.CLI_PATH, "calc", "-i", twk, "-o", out, "-r", "0.01"] + extra, capture_output=True, text=True)
+        env = {k: v for k, v in os.environ.items() if k != "NCCL_DEBUG"}       # (this pool's image exports NCCL_DEBUG=VERSION, which asks RCCL for its banner)
+        r = subprocess.run([hostlib.CLI_PATH, "calc", "-i", twk, "-o", out, "-r", "0.01"] + extra, capture_output=True, text=True, env=env)
         assert r.returncode == 0, r.stderr
         if "gather" in tag:
             assert "Gathered" in r.stderr and " over rccl " in r.stderr, r.stderr[-800:]
-        assert r.stdout == "", r.stdout[:300]            # (RCCL's start-up banner goes to stdout unless told otherwise: the engine tells it)
+        assert r.stdout == "", r.stdout[:300]            # (RCCL's start-up banner goes to stdout unless NCCL_DEBUG says NONE: the engine says so where the caller says nothing)
         recs, _ = hostlib.read_two(out)
         outs[tag] = np.sort(recs, order=["ridA", "packA", "ridB", "packB"])
     assert len(outs["stream"]) > 10_000 and outs["stream"].tobytes() == outs["gather"].tobytes()
