@@ -83,22 +83,19 @@ VALU_PAIR_PEAK = 256 * 4 * 64 / 6.0 * 2.4e9   # and(2 cyc)+bcnt(4 cyc) per wave6
 
 def executed_work(tm):
     """What the count launches issued, from the engine's timing: AND+popcount products (one per word of a plane-row pair; three for
-    every four of them in the three-product form of UnphasedMath's contraction) and the v_or that form adds (one per four of its
-    products) -> (products, ors, name of the kernel, name of the form)."""
+    every four of them in the three-product form of UnphasedMath's contraction, whose Q & (H | Q) terms are one v_bitop3_b32 each
+    since round 6: no v_or any more) -> (products, other VALU ops of the loop (0), name of the kernel, name of the form)."""
     words = tm["words_per_row"]
     four = (tm["row_pairs"] - tm["three_row_pairs"]) * words
     three = tm["three_row_pairs"] * words * 0.75
-    wide = tm.get("three_wide_row_pairs", 0) * words * 0.75        # ... of them on the wide lane tile: one v_or per six products instead of one per four
     kernel = "twk::k_count_list_t"
     form = "four products per pair (HH, HQ, QH, QQ)"
     if tm["three_launches"]:
-        kernel = ("twk::k_count3w_list_t" if wide else "twk::k_count3_list_t") if not tm["fused_launches"] else "twk::k_count3_screen_unphased_t"
+        kernel = "twk::k_count3_list_t" if not tm["fused_launches"] else "twk::k_count3_screen_unphased_t"
         form = "three products per pair (HH and S = QH + HQ + 2 QQ; the four products of screened-in pairs recounted)"
         if tm["three_launches"] < tm["count_launches"]:
             form += f" in {tm['three_launches']} of {tm['count_launches']} launches"
-    if wide:
-        form += "; lane tile of four x four variants, the block's waves split over the halves of a chunk's K range"
-    return four + three, (three - wide) / 4.0 + wide / 6.0, kernel, form
+    return four + three, 0.0, kernel, form
 
 
 def launch_spread(eng):
@@ -106,7 +103,7 @@ def launch_spread(eng):
     above the median's - a run that silently took 1.7 x as long (round 4 saw such runs) shows here - and what the engine's outlier watch
     flagged.  -> dict for the JSON line."""
     stats, seen = eng.launch_log()
-    cost = [x["ms"] / (x["row_pairs"] * x["words_per_row"] * (0.8125 if x["kind"] in (1, 4) else 1.0)) for x in stats if x["row_pairs"] and x["ms"] >= 0.3]
+    cost = [x["ms"] / (x["row_pairs"] * x["words_per_row"] * (0.75 if x["kind"] in (1, 4) else 1.0)) for x in stats if x["row_pairs"] and x["ms"] >= 0.3]
     if not cost:
         return {"launches": seen}
     srt = sorted(cost)
@@ -114,7 +111,7 @@ def launch_spread(eng):
     ms = sorted(x["ms"] for x in stats)
     # the same in shader cycles (cost x the clock the launch's blocks ran at): a launch that is slow in milliseconds and ordinary in cycles ran
     # at a low clock - the one cause the watch has caught so far (profiles/r05_outliers.txt: 1.1-1.6 GHz for seconds, 1.47-1.76 x the time)
-    cyc = sorted(x["ms"] * x["shader_mhz"] / (x["row_pairs"] * x["words_per_row"] * (0.8125 if x["kind"] in (1, 4) else 1.0))
+    cyc = sorted(x["ms"] * x["shader_mhz"] / (x["row_pairs"] * x["words_per_row"] * (0.75 if x["kind"] in (1, 4) else 1.0))
                  for x in stats if x["row_pairs"] and x["ms"] >= 0.3 and x["shader_mhz"])
     return {"launches": seen, "launch_ms_max": ms[-1], "launch_ms_median": ms[len(ms) // 2],
             "launch_cost_max_over_median": srt[-1] / med if med > 0 else None, "launch_cost_min_over_median": srt[0] / med if med > 0 else None,

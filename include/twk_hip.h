@@ -31,7 +31,7 @@ extern "C" {
 /* 3: twk_hip_set_option / twk_hip_get_option; the library no longer reads environment variables. */
 /* 4: twk_hip_timing grew (three-product launches); option "three". */
 /* 5: twk_hip_generate_synthetic_planted / twk_synth_planted_bitvector / twk_synth_plant_source (synthetic input with planted LD pairs);
- *    twk_hip_option_describe; twk_hip_timing grew (three_wide_row_pairs, finish_ms); twk_hip_gather_records / twk_hip_gather_backend /
+ *    twk_hip_option_describe; twk_hip_timing grew (finish_ms); twk_hip_gather_records / twk_hip_gather_backend /
  *    twk_hip_drain_device_sink (the RCCL gather of a one-process multi-GPU run). */
 #define TWK_HIP_ABI_VERSION 5
 
@@ -354,7 +354,7 @@ int twk_hip_fisher_exact(twk_hip_ctx* ctx, const int32_t* tables, uint64_t n, do
  * closest relative is the compile-time SLAVE_DEBUG_MODE / SIMD_AVAILABLE switches, lib/ld/ld_engine.h:20-24).
  * The keys, their defaults, ranges and meaning are ONE table in the engine (TWK_HIP_OPTIONS, csrc/hip/twk_hip.hip), readable through
  * twk_hip_option_describe() below and printed as the table of INTEGRATION.md 1 (tests/test_docs_consistency.py keeps the document in
- * step with it).  In short: "fused", "three", "three_wide" pick the form of the contraction; "lists", "list_max", "probe", "probe_zone",
+ * step with it).  In short: "fused", "three" pick the form of the contraction; "lists", "list_max", "probe", "probe_zone",
  * "probe_lds" the carrier-list passes for rare variants; "band_*" the launches of fused runs; "patch_rows" / "patch_cols" / "seg" /
  * "xcd_queues" / "skip_pad" / "count_min_chunks" / "cand_chunk" the count kernel's work order; "fisher_*" Fisher's test;
  * "async_delivery", "deliver_buffers" the engine's delivery thread; "record_cap", "deliver_fail_*_at" are test hooks; "timeline" a log.
@@ -402,11 +402,9 @@ typedef struct {
 	                                 products HH, HQ, QH, QQ; the reference's list kernel likewise takes one popcount and the other
 	                                 cells from the margins (ld_engine.cpp:244-246) */
 	uint64_t three_row_pairs;     /* ... and the plane-row pairs of those launches (of row_pairs): they executed 3/4 of the
-	                                 AND+popcounts row_pairs x words_per_row stands for, plus 6 v_or per 24 of them */
+	                                 AND+popcounts row_pairs x words_per_row stands for (one v_and / v_bitop3 + one v_bcnt each) */
 	uint64_t recount_candidates;  /* pairs that passed the three-product screen and had their four products counted afresh */
 	uint64_t outlier_launches;    /* count launches the outlier watch flagged (twk_hip_launch_log)                          */
-	uint64_t three_wide_row_pairs;/* (ABI 5) ... of three_row_pairs, those of launches on the wide lane tile (k_count3w_list_t: four x four variants a
-	                                 lane, 8 v_or per 48 products instead of 6 per 24)                                       */
 	double   finish_ms;           /* (ABI 5) the calling thread's wall time between a launch's last kernel and the hand-over of its
 	                                 records: device sort, copy to the host, the sink (launches the delivery thread takes: up to
 	                                 their copy aside on the device) - summed over the launches                              */
@@ -419,7 +417,7 @@ typedef void (*twk_hip_progress_cb)(void* user, uint64_t pairs_done, uint32_t ti
 int twk_hip_set_progress(twk_hip_ctx* ctx, twk_hip_progress_cb cb, void* user);
 
 /* The count launches one by one, since the last twk_hip_timing_reset (a ring of the last 4096): what the engine's outlier watch
- * looks at.  A launch is an outlier when its time per unit of work (row_pairs x words_per_row, the three-product form's at 13/16)
+ * looks at.  A launch is an outlier when its time per unit of work (row_pairs x words_per_row, the three-product form's at 3/4)
  * exceeds 1.4 x the median of the launches of its own kind and row length before it (at least 8 of them, launches of >= 0.3 ms);
  * option "timeline" >= 1 prints such a launch - with the shader clock its blocks ran at and how far apart the XCDs finished - on
  * stderr as it is found.  Measurement integrity (round 4 saw the same run take 1.7 x as long now and then); no reference counterpart. */

@@ -128,12 +128,6 @@ def test_three_product_form_at_the_headline_size_against_the_oracle(hip, opt, mi
         three = call()
         tm = hip.timing()
         assert tm["three_launches"] > 0 and tm["fused_launches"] == 0 and tm["three_launches"] == tm["count_launches"], tm
-        assert tm["three_wide_row_pairs"] == tm["three_row_pairs"] > 0           # the default: the wide lane tile (k_count3w_list_t) ...
-        opt.set("three_wide", 0); hip.timing_reset()                             # ... and the 4 x 2 one (k_count3_list_t): the same bytes
-        narrow = call()
-        assert hip.timing()["three_wide_row_pairs"] == 0 and hip.timing()["three_launches"] > 0
-        opt.unset("three_wide")
-        assert _bytes_equal(narrow[0], three[0])
         return four, three, tm
 
     # (a)

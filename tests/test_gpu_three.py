@@ -93,31 +93,26 @@ def test_three_product_equals_four_product_and_oracle(hip, opt, N, fused):
     util.assert_records_match(got, want, variants[sub], double_root=util.double_root_vetter(data[sub], None, variants[sub], N))
 
 
-@pytest.mark.parametrize("wide", [1, 0])
 @pytest.mark.parametrize("min_chunks", [8, 1])
-def test_three_product_on_long_rows_with_tiles_split_along_k(hip, opt, min_chunks, wide):
+def test_three_product_on_long_rows_with_tiles_split_along_k(hip, opt, min_chunks):
     """N = 300,000: rows of 293 chunks - beyond the fused form, and the last tiles of a launch are cut along K, their (HH, S)
-    added into the matrix with atomics (StoreCounts3, k_zero_tiles over 64-row tiles).  count_min_chunks = 1 cuts them finer.
-    wide: the lane tile of four x four variants with the block's waves split over the halves of a chunk (k_count3w_list_t, the
-    default: every count is the sum of two waves' adds) or four x two (k_count3_list_t)."""
+    added into the matrix with atomics (StoreCounts3, k_zero_tiles over 64-row tiles).  count_min_chunks = 1 cuts them finer."""
     N, M = 300_000, 420
     al = _cohort_alleles(M, N, 4242)
     util.upload(hip, al)
     opt.set("count_min_chunks", min_chunks)
-    opt.set("three_wide", wide)
     for minR2, wopt in ((0.1, 0), (0.3, T.OPT_R2_SCREEN), (0.02, 0)):
         f = T.Filters(minR2=minR2)
         (p, np0, _), (q, np1, nr), tm = _both(hip, opt, lambda: hip.ld_all(T.MODE_UNPHASED, f, window=wopt), expect_three=(minR2 >= 0.1), on=2)
         assert tm["fused_launches"] == 0 and np0 == np1 and nr == len(q) == len(p) > 20 and _same(p, q), (minR2, wopt)
     (p, _, _), (q, _, _), tm = _both(hip, opt, lambda: hip.ld_all(T.MODE_UNPHASED, T.Filters(minR2=0.1), tile_variants=128), on=2)
-    assert tm["three_launches"] >= 6 and _same(p, q) and (tm["three_wide_row_pairs"] == tm["three_row_pairs"]) == bool(wide)
+    assert tm["three_launches"] >= 6 and _same(p, q)
 
 
 @pytest.mark.parametrize("N", [40_000, 131_072 + 64])
-def test_wide_lane_tile_on_rows_that_end_in_either_half_of_their_last_chunk(hip, opt, N):
-    """The wide three-product kernel splits every chunk's sixteen half-slots between two waves; a row's last chunk may end inside the
-    first half (the second wave then contracts nothing of it) or inside the second.  fused = 0 sends rows this short through the
-    count matrix.  N = 40,000: 1,250 words = 39 chunks + 2 words (1 live half-slot); 131,136: 4,098 words = 128 chunks + 2 words; and
+def test_matrix_form_on_rows_that_end_inside_their_last_chunk(hip, opt, N):
+    """The three-product kernel through the count matrix (fused = 0 sends rows this short that way) on rows whose last chunk is partly
+    filled: the rolled loop over its live half-slots reads a variant's H and Q words with one ds_read2_b64, like the unrolled one.  N = 40,000: 1,250 words = 39 chunks + 2 words (1 live half-slot); 131,136: 4,098 words = 128 chunks + 2 words; and
     rows whose last chunk holds 9 .. 12 half-slots: N = 40,000 + 32 * 18 .. """
     M = 500
     for n in (N, N + 32 * 18, N + 32 * 23):
@@ -126,7 +121,7 @@ def test_wide_lane_tile_on_rows_that_end_in_either_half_of_their_last_chunk(hip,
         opt.set("fused", 0)
         f = T.Filters(minR2=0.1)
         (p, np0, _), (q, np1, nr), tm = _both(hip, opt, lambda: hip.ld_all(T.MODE_UNPHASED, f), on=2)
-        assert tm["fused_launches"] == 0 and tm["three_wide_row_pairs"] == tm["three_row_pairs"] > 0
+        assert tm["fused_launches"] == 0 and tm["three_launches"] > 0
         assert np0 == np1 and nr == len(q) == len(p) > 50 and _same(p, q), n
         opt.set("skip_pad", 0)
         r, _, _ = hip.ld_all(T.MODE_UNPHASED, f)

@@ -347,97 +347,81 @@ __device__ __forceinline__ void contract_half(uint32_t (&acc)[8][TB], int u, con
 
 // ---- three-product form for the plain unphased planes (rows H, Q of a variant; PAIRED lane rows) ----------------
 // What UnphasedMath's r2 screen reads of a pair is HH = popc(H_A & H_B) and S = QH + HQ + 2 QQ (ScreenCountsUnphased below,
-// d_unphased_math), not the four products one by one, and with C = H | Q (the carriers)
-//     S = popc(Q_A & C_B) + popc(C_A & Q_B)            (H and Q are disjoint: Q_A & C_B = QH + QQ, C_A & Q_B = HQ + QQ)
+// d_unphased_math), not the four products one by one, and with C = H | Q (the carriers; H and Q are disjoint)
+//     S = popc(Q_A & C_B) + popc(C_A & Q_B)            (Q_A & C_B = QH + QQ, C_A & Q_B = HQ + QQ)
 // - three AND+popcounts per word and variant pair into two accumulators (v_bcnt adds, so both halves of S land in one
 // register) instead of four into four.  The reference does the like in its list kernel: one popcount, the other cells from
-// the margins (ld_engine.cpp:244-246).  C is formed in registers behind the LDS read: 4 + 2 v_or per word for the lane's
-// 4 x 2 variant pairs, 12 cycles next to the 24 x 6 of the products (the planes in HBM and the LDS image stay what they are).
-// Only pairs that pass the screen need HQ, QH and QQ themselves: k_recount_unphased (below) counts those few from their rows.
-// One B variant against the lane's four A variants, one word: hh[s] += popc(hA[s] & hB), ss[s] += popc(qA[s] & cB) +
-// popc(cA[s] & qB) with cB = hB | qB formed here; same (AND, s_nop, BCNT) issue pattern as and_bcnt8v.
+// the margins (ld_engine.cpp:244-246).  Only pairs that pass the screen need HQ, QH and QQ themselves: k_recount_unphased
+// (ld_three.hip.h) counts those few from their rows.
+// Round 6: the carriers are never formed.  gfx950 has a three-input boolean instruction, v_bitop3_b32 (truth table in the
+// instruction: 0xE0 = a & (b | c)), that issues at the rate of v_and_b32 (csrc/tools/bitop3_probe.hip: 24 x (v_bitop3, s_nop, v_bcnt)
+// 2.527e13 products/s against 2.518e13 for v_and - and the three-product mix at 96.1 % of the and+bcnt ceiling where the v_or of
+// rounds 5 and 6a left 85.4 / 88.7 %): Q_A & (H_B | Q_B) and Q_B & (H_A | Q_A) are one instruction each, so a product of the
+// three-product form costs exactly what a product of the four-product form costs, and there are three of them.
+// One B variant against the lane's four A variants, one word: hh[s] += popc(hA[s] & hB), ss[s] += popc(qA[s] & (hB | qB)) +
+// popc(qB & (hA[s] | qA[s])); same (op, s_nop, BCNT) issue pattern as and_bcnt8v.
 __device__ __forceinline__ void and_bcnt12v(uint32_t& hh0, uint32_t& hh1, uint32_t& hh2, uint32_t& hh3,
                                             uint32_t& ss0, uint32_t& ss1, uint32_t& ss2, uint32_t& ss3,
                                             uint32_t h0, uint32_t h1, uint32_t h2, uint32_t h3,
-                                            uint32_t q0, uint32_t q1, uint32_t q2, uint32_t q3,
-                                            uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t hb, uint32_t qb) {
-	uint32_t t0, t1, cb;
-	asm volatile("v_or_b32 %10, %23, %24\n\t"
-	    "v_and_b32 %8, %11, %23\n\t"
+                                            uint32_t q0, uint32_t q1, uint32_t q2, uint32_t q3, uint32_t hb, uint32_t qb) {
+	uint32_t t0, t1;
+	asm volatile("v_and_b32 %8, %10, %18\n\t"
 	    "s_nop 0\n\t"
 	    "v_bcnt_u32_b32 %0, %8, %0\n\t"
-	    "v_and_b32 %9, %12, %23\n\t"
+	    "v_and_b32 %9, %11, %18\n\t"
 	    "s_nop 0\n\t"
 	    "v_bcnt_u32_b32 %1, %9, %1\n\t"
-	    "v_and_b32 %8, %13, %23\n\t"
+	    "v_and_b32 %8, %12, %18\n\t"
 	    "s_nop 0\n\t"
 	    "v_bcnt_u32_b32 %2, %8, %2\n\t"
-	    "v_and_b32 %9, %14, %23\n\t"
+	    "v_and_b32 %9, %13, %18\n\t"
 	    "s_nop 0\n\t"
 	    "v_bcnt_u32_b32 %3, %9, %3\n\t"
-	    "v_and_b32 %8, %15, %10\n\t"
+	    "v_bitop3_b32 %8, %14, %18, %19 bitop3:0xe0\n\t"
 	    "s_nop 0\n\t"
 	    "v_bcnt_u32_b32 %4, %8, %4\n\t"
-	    "v_and_b32 %9, %16, %10\n\t"
+	    "v_bitop3_b32 %9, %15, %18, %19 bitop3:0xe0\n\t"
 	    "s_nop 0\n\t"
 	    "v_bcnt_u32_b32 %5, %9, %5\n\t"
-	    "v_and_b32 %8, %17, %10\n\t"
+	    "v_bitop3_b32 %8, %16, %18, %19 bitop3:0xe0\n\t"
 	    "s_nop 0\n\t"
 	    "v_bcnt_u32_b32 %6, %8, %6\n\t"
-	    "v_and_b32 %9, %18, %10\n\t"
+	    "v_bitop3_b32 %9, %17, %18, %19 bitop3:0xe0\n\t"
 	    "s_nop 0\n\t"
 	    "v_bcnt_u32_b32 %7, %9, %7\n\t"
-	    "v_and_b32 %8, %19, %24\n\t"
+	    "v_bitop3_b32 %8, %19, %10, %14 bitop3:0xe0\n\t"
 	    "s_nop 0\n\t"
 	    "v_bcnt_u32_b32 %4, %8, %4\n\t"
-	    "v_and_b32 %9, %20, %24\n\t"
+	    "v_bitop3_b32 %9, %19, %11, %15 bitop3:0xe0\n\t"
 	    "s_nop 0\n\t"
 	    "v_bcnt_u32_b32 %5, %9, %5\n\t"
-	    "v_and_b32 %8, %21, %24\n\t"
+	    "v_bitop3_b32 %8, %19, %12, %16 bitop3:0xe0\n\t"
 	    "s_nop 0\n\t"
 	    "v_bcnt_u32_b32 %6, %8, %6\n\t"
-	    "v_and_b32 %9, %22, %24\n\t"
+	    "v_bitop3_b32 %9, %19, %13, %17 bitop3:0xe0\n\t"
 	    "s_nop 0\n\t"
 	    "v_bcnt_u32_b32 %7, %9, %7"
-	    : "+v"(hh0), "+v"(hh1), "+v"(hh2), "+v"(hh3), "+v"(ss0), "+v"(ss1), "+v"(ss2), "+v"(ss3), "=&v"(t0), "=&v"(t1), "=&v"(cb)
-	    : "v"(h0), "v"(h1), "v"(h2), "v"(h3), "v"(q0), "v"(q1), "v"(q2), "v"(q3), "v"(c0), "v"(c1), "v"(c2), "v"(c3), "v"(hb), "v"(qb));
-}
-// The carriers of the lane's four A variants, one word (volatile: keeps its place in front of the products that read them).
-__device__ __forceinline__ void or4v(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t h0, uint32_t q0, uint32_t h1, uint32_t q1,
-                                     uint32_t h2, uint32_t q2, uint32_t h3, uint32_t q3) {
-	asm volatile("v_or_b32 %0, %4, %5\n\tv_or_b32 %1, %6, %7\n\tv_or_b32 %2, %8, %9\n\tv_or_b32 %3, %10, %11"
-	    : "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(c3) : "v"(h0), "v"(q0), "v"(h1), "v"(q1), "v"(h2), "v"(q2), "v"(h3), "v"(q3));
+	    : "+v"(hh0), "+v"(hh1), "+v"(hh2), "+v"(hh3), "+v"(ss0), "+v"(ss1), "+v"(ss2), "+v"(ss3), "=&v"(t0), "=&v"(t1)
+	    : "v"(h0), "v"(h1), "v"(h2), "v"(h3), "v"(q0), "v"(q1), "v"(q2), "v"(q3), "v"(hb), "v"(qb));
 }
 // One half-slot (two words) of the three-product form.  a[2s] / a[2s + 1]: the H / Q words of the lane's A variant s, b[2v] /
 // b[2v + 1] of its B variant v (PAIRED lane rows); HH of the pair (s, v) accumulates in acc[2s][2v], S in acc[2s + 1][2v + 1]
 // (the registers acc[2s][2v + 1] and acc[2s + 1][2v] of the four-product form are never touched and cost nothing).
+// Round 6 looked for the rest (profiles/r06_three_bitop3.txt): in the kernel the loop runs at 88.0 % of the and+bcnt ceiling, the same loop with
+// v_and_b32 in the place of every v_bitop3_b32 (wrong S, timing only) at 92.1 %, the four-product kernel at 93.0 %.  Not the chunk barrier
+// (without it: 87.7 %), not the operand staging (88.7 %), not VGPR banks (H and Q words read by one ds_read2_b64 into a 128-bit tuple, no
+// v_bitop3 with its three sources in one bank: 86.6 %), not the number of LDS instructions (whole slots with ds_read_b128, half as many
+// reads, 126 VGPRs: 87.9 %), not the operand order (0xA8, c & (a | b): 87.9 %), not the lane tile (4 x 4 variants with the waves split over
+// the halves of a chunk: 88.0 %).  The form below - 80 VGPRs - is what stays.
 __device__ __forceinline__ void contract3_half(uint32_t (&acc)[8][4], const uint2 (&a)[8], const uint2 (&b)[4]) {
-	uint32_t c0, c1, c2, c3;
-	or4v(c0, c1, c2, c3, a[0].x, a[1].x, a[2].x, a[3].x, a[4].x, a[5].x, a[6].x, a[7].x);
 	and_bcnt12v(acc[0][0], acc[2][0], acc[4][0], acc[6][0], acc[1][1], acc[3][1], acc[5][1], acc[7][1],
-	            a[0].x, a[2].x, a[4].x, a[6].x, a[1].x, a[3].x, a[5].x, a[7].x, c0, c1, c2, c3, b[0].x, b[1].x);
+	            a[0].x, a[2].x, a[4].x, a[6].x, a[1].x, a[3].x, a[5].x, a[7].x, b[0].x, b[1].x);
 	and_bcnt12v(acc[0][2], acc[2][2], acc[4][2], acc[6][2], acc[1][3], acc[3][3], acc[5][3], acc[7][3],
-	            a[0].x, a[2].x, a[4].x, a[6].x, a[1].x, a[3].x, a[5].x, a[7].x, c0, c1, c2, c3, b[2].x, b[3].x);
-	or4v(c0, c1, c2, c3, a[0].y, a[1].y, a[2].y, a[3].y, a[4].y, a[5].y, a[6].y, a[7].y);
+	            a[0].x, a[2].x, a[4].x, a[6].x, a[1].x, a[3].x, a[5].x, a[7].x, b[2].x, b[3].x);
 	and_bcnt12v(acc[0][0], acc[2][0], acc[4][0], acc[6][0], acc[1][1], acc[3][1], acc[5][1], acc[7][1],
-	            a[0].y, a[2].y, a[4].y, a[6].y, a[1].y, a[3].y, a[5].y, a[7].y, c0, c1, c2, c3, b[0].y, b[1].y);
+	            a[0].y, a[2].y, a[4].y, a[6].y, a[1].y, a[3].y, a[5].y, a[7].y, b[0].y, b[1].y);
 	and_bcnt12v(acc[0][2], acc[2][2], acc[4][2], acc[6][2], acc[1][3], acc[3][3], acc[5][3], acc[7][3],
-	            a[0].y, a[2].y, a[4].y, a[6].y, a[1].y, a[3].y, a[5].y, a[7].y, c0, c1, c2, c3, b[2].y, b[3].y);
-}
-
-// One WORD of the three-product form against NV column variants (the wide lane tile of k_count3w_list_t: four row variants x four
-// column variants per lane): aw[2s] / aw[2s + 1] the H / Q word of row variant s, bw[2v] / bw[2v + 1] of column variant v.  The row
-// carriers are formed once per word and serve all NV column variants: 4 + NV v_or per 12 NV products - 8 per 48 at NV = 4, where the
-// 4 x 2 tile pays 6 per 24.
-template <int TB, int NV>
-__device__ __forceinline__ void contract3_word(uint32_t (&acc)[8][TB], const uint32_t (&aw)[8], const uint32_t (&bw)[2 * NV]) {
-	static_assert(TB >= 2 * NV, "two plane rows per column variant");
-	uint32_t c0, c1, c2, c3;
-	or4v(c0, c1, c2, c3, aw[0], aw[1], aw[2], aw[3], aw[4], aw[5], aw[6], aw[7]);
-#pragma unroll
-	for (int v = 0; v < NV; ++v)
-		and_bcnt12v(acc[0][2 * v], acc[2][2 * v], acc[4][2 * v], acc[6][2 * v], acc[1][2 * v + 1], acc[3][2 * v + 1], acc[5][2 * v + 1], acc[7][2 * v + 1],
-		            aw[0], aw[2], aw[4], aw[6], aw[1], aw[3], aw[5], aw[7], c0, c1, c2, c3, bw[2 * v], bw[2 * v + 1]);
+	            a[0].y, a[2].y, a[4].y, a[6].y, a[1].y, a[3].y, a[5].y, a[7].y, b[2].y, b[3].y);
 }
 
 // ---- persistent work-list form of the same contraction ------------------------------------
@@ -550,7 +534,6 @@ struct StoreCounts {
 	static constexpr int META_WORDS = 0;       // nothing to stage for the epilogue
 	static constexpr bool PAIRED_ROWS = false; // a lane's rows are li + 8t (see read_half)
 	static constexpr bool THREE_PRODUCTS = false;
-	static constexpr bool K_SPLIT = false;
 	static constexpr bool QUEUED = false;
 	uint32_t* C; uint32_t ldc;
 	__device__ __forceinline__ const uint32_t* meta_src(uint32_t, uint32_t) const { return nullptr; }
@@ -579,7 +562,6 @@ struct StoreCounts3 {
 	static constexpr int META_WORDS = 0;
 	static constexpr bool PAIRED_ROWS = true;
 	static constexpr bool THREE_PRODUCTS = true;
-	static constexpr bool K_SPLIT = false;
 	static constexpr bool QUEUED = false;
 	uint32_t* C; uint32_t ldc;
 	__device__ __forceinline__ const uint32_t* meta_src(uint32_t, uint32_t) const { return nullptr; }
@@ -600,40 +582,9 @@ struct StoreCounts3 {
 	}
 };
 
-// The wide lane tile of the three-product form (k_count3w_list_t): the block's eight waves are a 2 x 2 grid over the tile times the two
-// halves of every chunk's K range - wave w contracts half-slots [8 (w >> 2), 8 (w >> 2) + 8) of the 64 x 64 plane rows of quarter w & 3, a
-// lane four row variants x four column variants (32 accumulators: HH and S of 16 pairs).  Two waves thus hold partial sums of every
-// pair, and both ADD them into C: every tile of such a launch is zeroed beforehand (k_zero_tiles over the whole list), whole or not.
-template <int TB>
-struct StoreCounts3Wide {
-	static constexpr int META_WORDS = 0;
-	static constexpr bool PAIRED_ROWS = true;
-	static constexpr bool THREE_PRODUCTS = true;
-	static constexpr bool K_SPLIT = true;
-	static constexpr bool QUEUED = false;
-	uint32_t* C; uint32_t ldc;
-	__device__ __forceinline__ const uint32_t* meta_src(uint32_t, uint32_t) const { return nullptr; }
-	__device__ __forceinline__ void finish(SlotWindow&, int) const {}
-	__device__ __forceinline__ void operator()(uint32_t (&acc)[8][TB], uint32_t yx, int wr, int wc, int li, int lj, int lane, bool, const uint32_t*, SlotWindow&) const {
-		static_assert(TB == 8, "four column variants per lane");
-		// the lane's variant pairs: rows vA + 8 s (s = 0..3), columns vB + 8 v (v = 0..3) of the wave's 32 x 32 variant pairs
-		uint32_t* Cblk = C + (size_t)((yx >> 16) * (TILE / 2) + wr * 32 + li) * ldc + 2 * ((yx & 0xFFFFu) * (TILE / 2) + wc * 32 + lj);
-#pragma unroll
-		for (int s = 0; s < 4; ++s)
-#pragma unroll
-			for (int v = 0; v < 4; ++v) {
-				uint32_t* e = Cblk + (size_t)(8 * s) * ldc + 16 * v;
-				atomicAdd(e, acc[2 * s][2 * v]); atomicAdd(e + 1, acc[2 * s + 1][2 * v + 1]);
-				acc[2 * s][2 * v] = 0; acc[2 * s + 1][2 * v + 1] = 0;
-			}
-	}
-};
-
 template <int NW, int EXPERIMENT, class Epilogue>      // EXPERIMENT == 5: the dev tool's finish-time probe (overwrites C)
 __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilogue& epilogue) {
-	constexpr bool KSPLIT = Epilogue::K_SPLIT;        // the wide lane tile: 2 x 2 waves over the tile x 2 halves of the chunk's K range (StoreCounts3Wide)
-	static_assert(!KSPLIT || NW == 8, "2 x 2 x 2 waves");
-	constexpr int WC = KSPLIT ? 2 : NW / 2;
+	constexpr int WC = NW / 2;
 	constexpr int TB = 16 / WC;
 	constexpr int NSEG = 32 / NW;
 	__shared__ __attribute__((aligned(16))) uint32_t lds[2 * 2 * TILE * KC];
@@ -649,9 +600,7 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 	const int lane = tid & 63;
 	const int wave = tid >> 6;
 	const int wave_u = __builtin_amdgcn_readfirstlane(wave);      // (wave-uniform: lives in a scalar register, and so do the wave's tile coordinates)
-	const int wq = KSPLIT ? (wave_u & 3) : wave_u;               // the wave's place in the grid over the tile
-	const int wr = wq / WC, wc = wq % WC;
-	const uint32_t kh = KSPLIT ? (uint32_t)(wave_u >> 2) : 0u;   // ... and the half of every chunk's K range it contracts
+	const int wr = wave_u / WC, wc = wave_u % WC;
 	const uint32_t nchunks = w.W / KC;
 	const uint32_t n_units = w.n_units;
 	const unsigned long long probe_wall0 = wall_clock64(), probe_clk0 = clock64();      // the block's start on the constant 100 MHz clock and on the shader clock (scalar registers)
@@ -703,7 +652,7 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 
 	constexpr bool PAIRED = Epilogue::PAIRED_ROWS;
 	constexpr bool THREE = Epilogue::THREE_PRODUCTS;      // the three-product form of the plain unphased planes (contract3_half)
-	static_assert(!THREE || (PAIRED && (TB == 4 || (KSPLIT && TB == 8))), "the three-product form needs a variant's H and Q rows in one lane");
+	static_assert(!THREE || (PAIRED && TB == 4), "the three-product form needs a variant's H and Q rows in one lane");
 	// The per-lane LDS read offsets and DMA source offsets of the K loop.  For the fused epilogues they are recomputed when a unit ends
 	// instead of being held through the epilogue: the epilogue is where the kernels' register demand peaks, and what the allocator evicts
 	// there it reloads from scratch inside the K loop (round 5: sixteen spilled offsets, scratch loads between the half-slots).  The lane
@@ -756,7 +705,7 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		// the ticket fetched one iteration ago has arrived with everything else: publish it
 		if (want_next && thread0()) mbox[n_started & 1u] = fetched;
-		__syncthreads();
+		if (EXPERIMENT != 7 || unit_start || want_next) __syncthreads();      // (7: the dev tool's timing WITHOUT the chunk barrier - wrong counts: what the barrier costs)
 		if (want_next) { unit_next = __builtin_amdgcn_readfirstlane(mbox[n_started & 1u]); want_next = false; }
 		if (unit_start) {
 			// First chunk of a unit: thread 0 draws the ticket of the next unit.  It is needed when the
@@ -801,7 +750,7 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 		}
 		// (issued here, in front of the chunk's LDS reads; behind the first or the third half-slot's contraction it is neither faster nor
 		// slower - 18.31 / 18.31 / 18.26 ms on the 1 M-sample microbenchmark, round 5)
-		if (more) stage_rows_s(w.rows, w.W, st_row0, n_c, st_lds + (buf ^ 1) * (2 * LDS_TILE_BYTES), st_seg0, NSEG, voff_even, voff_odd);
+		if (more && (EXPERIMENT != 8 || n_c == 0 || n_c + 1 >= n_end)) stage_rows_s(w.rows, w.W, st_row0, n_c, st_lds + (buf ^ 1) * (2 * LDS_TILE_BYTES), st_seg0, NSEG, voff_even, voff_odd);      // (8: the dev tool's timing WITHOUT the operand staging)
 		// The chunk in 16 half-slots of 8 bytes per row.  The 12 LDS reads of half-slot h + 1 (8 A rows,
 		// TB B rows, ds_read_b64) are issued before the contraction of half-slot h, into the other
 		// register set, so the contraction never waits for LDS except at the first half-slot of a chunk.
@@ -811,52 +760,6 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 		// the 12 reads just issued has arrived").
 		const uint32_t bufbase = lds_base + (uint32_t)buf * (2 * LDS_TILE_BYTES);
 		const int h_end = (c + 1 == nchunks && w.last_halves) ? (int)w.last_halves : 16;     // wave-uniform
-		if constexpr (KSPLIT) {
-			// This wave's eight half-slots [8 kh, 8 kh + 8) - slots [4 kh, 4 kh + 4): address bit 6 - of its 64 x 64 plane rows.  Sixteen reads a
-			// half-slot are one more than lgkmcnt counts, so they go out in two groups: the A rows of half-slot h + 1 in front of half-slot h's
-			// contraction, its B rows between the two words of it; lgkmcnt(8) behind the first group then says "half-slot h has arrived".
-			const uint32_t baseA = (bufbase + offA) ^ (kh << 6), baseB = (bufbase + offB) ^ (kh << 6);
-			const int h_lim = h_end - (int)kh * 8 < 8 ? h_end - (int)kh * 8 : 8;           // (the last chunk of a row may end inside or before this half)
-			if (h_lim == 8) {
-				uint2 ra[2][8], rb[2][TB];
-				read_half_a<TB, PAIRED>(ra[0], baseA, baseA, 0);
-				read_half_b<TB, PAIRED>(rb[0], baseB, baseB, 0);
-#pragma unroll
-				for (int h = 0; h < 8; ++h) {
-					const int q1 = (h + 1) >> 1;
-					if (h + 1 < 8) {
-						read_half_a<TB, PAIRED>(ra[(h + 1) & 1], baseA ^ (uint32_t)(q1 << 4), baseA ^ (uint32_t)(q1 << 4), (h + 1) & 1);
-						asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-					} else {
-						asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-					}
-					{
-						const uint2 (&a)[8] = ra[h & 1]; const uint2 (&b)[TB] = rb[h & 1];
-						const uint32_t ax[8] = {a[0].x, a[1].x, a[2].x, a[3].x, a[4].x, a[5].x, a[6].x, a[7].x};
-						const uint32_t bx[8] = {b[0].x, b[1].x, b[2].x, b[3].x, b[4].x, b[5].x, b[6].x, b[7].x};
-						contract3_word<TB, 4>(acc, ax, bx);
-						if (h + 1 < 8) read_half_b<TB, PAIRED>(rb[(h + 1) & 1], baseB ^ (uint32_t)(q1 << 4), baseB ^ (uint32_t)(q1 << 4), (h + 1) & 1);
-						const uint32_t ay[8] = {a[0].y, a[1].y, a[2].y, a[3].y, a[4].y, a[5].y, a[6].y, a[7].y};
-						const uint32_t by[8] = {b[0].y, b[1].y, b[2].y, b[3].y, b[4].y, b[5].y, b[6].y, b[7].y};
-						contract3_word<TB, 4>(acc, ay, by);
-					}
-				}
-			} else {
-#pragma unroll 1
-				for (int h = 0; h < h_lim; ++h) {
-					uint2 a[8], b[TB];
-					const uint32_t q = (uint32_t)(h >> 1) << 4, hb = (uint32_t)(h & 1) << 3;
-					read_half<TB, PAIRED>(a, b, (baseA ^ q) + hb, (baseA ^ q) + hb, (baseB ^ q) + hb, (baseB ^ q) + hb, 0);
-					asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-					const uint32_t ax[8] = {a[0].x, a[1].x, a[2].x, a[3].x, a[4].x, a[5].x, a[6].x, a[7].x};
-					const uint32_t bx[8] = {b[0].x, b[1].x, b[2].x, b[3].x, b[4].x, b[5].x, b[6].x, b[7].x};
-					contract3_word<TB, 4>(acc, ax, bx);
-					const uint32_t ay[8] = {a[0].y, a[1].y, a[2].y, a[3].y, a[4].y, a[5].y, a[6].y, a[7].y};
-					const uint32_t by[8] = {b[0].y, b[1].y, b[2].y, b[3].y, b[4].y, b[5].y, b[6].y, b[7].y};
-					contract3_word<TB, 4>(acc, ay, by);
-				}
-			}
-		} else
 		if (h_end == 16) {
 			uint2 ra[2][8], rb[2][TB];
 			const uint32_t baseA = bufbase + offA, baseB = bufbase + offB;
@@ -945,12 +848,6 @@ template <int NW, int EXPERIMENT = 0>
 __global__ __launch_bounds__(NW * 64, NW / 2)
 void k_count3_list_t(const CountWork w) {
 	count_list_body<NW, EXPERIMENT>(w, StoreCounts3<16 / (NW / 2)>{w.C, w.ldc});
-}
-
-template <int NW, int EXPERIMENT = 0>
-__global__ __launch_bounds__(NW * 64, NW / 2)
-void k_count3w_list_t(const CountWork w) {
-	count_list_body<NW, EXPERIMENT>(w, StoreCounts3Wide<8>{w.C, w.ldc});
 }
 
 // Inclusive prefix sum over the 64 lanes of a wave (all active) without LDS: Hillis-Steele inside each row of 16 lanes
@@ -1064,7 +961,6 @@ template <int TB>
 struct ScreenCounts {
 	static constexpr bool PAIRED_ROWS = false;
 	static constexpr bool THREE_PRODUCTS = false;
-	static constexpr bool K_SPLIT = false;
 	static constexpr bool QUEUED = true;       // the wave's queue of prefilter-passing pairs (SlotWindow::q)
 	// staged per tile: [0, 2 TILE) the prefilter's (a / T, sA) of its 128 rows, [2 TILE, 4 TILE) (b, sB) of its 128 columns (ScreenWork::terms),
 	// then - for the exact test - the allele counts of the rows, of the columns, and the rows' band limits
@@ -1259,7 +1155,6 @@ template <int TB, bool THREE = false>
 struct ScreenCountsUnphased {
 	static constexpr bool PAIRED_ROWS = true;
 	static constexpr bool THREE_PRODUCTS = THREE;
-	static constexpr bool K_SPLIT = false;
 	static constexpr bool QUEUED = false;
 	// staged per tile: the prefilter's (da / T, sA) of its 64 row variants and (db, sB) of its 64 column variants (ScreenWork::terms), then - for the
 	// exact test - the H / Q counts of its 128 plane rows and of its 128 plane columns, and the band limits of its 64 row variants

@@ -112,7 +112,6 @@ struct Slot {                      // one in-flight tile (double buffered)
 	bool fused = false;                           // first launch ran the fused count -> screen kernel: C holds the candidate list
 	bool three = false;                           // ... in the three-product form (HH + S; the candidates' four products are recounted): fused, or
 	bool three_plain = false;                     // through a count matrix (long rows): C holds the (HH, S) matrix and, behind it, the candidate list
-	bool three_wide = false;                      // ... contracted on the wide lane tile (k_count3w_list_t)
 	uint32_t* cand = nullptr;                     // the candidate list of the launch (in C)
 	int plane_set = 0;                            // the plane set the launch contracted
 	unsigned long long cand_cap = 0;              // ... of this many entries; n_out[2] counts them
@@ -142,7 +141,6 @@ namespace {
 #define TWK_HIP_OPTIONS(X) \
 	X(fused, 1, 0, 2, false, "fused count -> r2 screen kernel (no count matrix; DESIGN 3.2a): 0 never, 1 rows of <= 128 K chunks, 2 always") \
 	X(three, 1, 0, 2, false, "UnphasedMath on planes without missing genotypes, r2 cut-off > 1e-6: contract three products a pair (HH and S = QH + HQ + 2 QQ: all the screen reads) and recount the four products of the pairs that pass (DESIGN 3.1a); 0: four products for every pair; 2: keep to three whatever a launch's candidate density (1 samples every launch first)") \
-	X(three_wide, 1, 0, 1, false, "... through a count matrix (rows too long to fuse) on the wide lane tile: four x four variants a lane, the block's waves split over the halves of a chunk's K range, both halves add into the matrix (k_count3w_list_t); 0: four x two variants a lane, whole tiles stored (k_count3_list_t): same counts, 4 % slower (profiles/r06_three_tile.txt)") \
 	X(count_min_chunks, 8, 1, 1 << 20, false, "shortest K range a tile of the count kernel is split into at the end of a launch (test hook: 1 splits short rows too)") \
 	X(patch_rows, 8, 1, 4096, false, "rows of a patch of tiles in the count kernel's work order (DESIGN 3.1, profiles/r03_patch_pmc.txt)") \
 	X(patch_cols, 8, 1, 4096, false, "... and its columns") \
@@ -656,8 +654,6 @@ int launch_count(twk_hip_ctx* c, int set, const twk_hip_tile_desc& t, Slot& s, i
 			if (w.last_halves > 12) w.last_halves = 0;
 		}
 		HIPCHK(c, hipMemsetAsync(w.ticket, 0, 8 * 4, c->s_compute));
-		const bool wide = three && !fuse && c->opt.three_wide != 0;      // (two waves add into every count: all tiles zeroed, none stored)
-		if (wide) first_split = 0;
 		if (first_split < T) {
 			hipLaunchKernelGGL(k_zero_tiles, dim3((uint32_t)T - first_split), dim3(256), 0, c->s_compute, w.tiles, first_split, w.C, w.ldc, (uint32_t)(three ? TILE / 2 : TILE));
 			HIPCHK(c, hipGetLastError());
@@ -667,8 +663,6 @@ int launch_count(twk_hip_ctx* c, int set, const twk_hip_tile_desc& t, Slot& s, i
 		if (with_args && d_screen) *d_screen = &d_fa->screen;
 		if (fuse && fa->unphased && three && c->sampling) hipLaunchKernelGGL((k_count3_screen_unphased_t<COUNT_NW, 1>), dim3(std::min(n_blocks, w.n_units)), dim3(COUNT_THREADS), 0, c->s_compute, w, &d_fa->screen);
 		else if (fuse && fa->unphased && three) hipLaunchKernelGGL((k_count3_screen_unphased_t<COUNT_NW>), dim3(std::min(n_blocks, w.n_units)), dim3(COUNT_THREADS), 0, c->s_compute, w, &d_fa->screen);
-		else if (wide && c->sampling) hipLaunchKernelGGL((k_count3w_list_t<COUNT_NW, 1>), dim3(std::min(n_blocks, w.n_units)), dim3(COUNT_THREADS), 0, c->s_compute, w);
-		else if (wide) hipLaunchKernelGGL((k_count3w_list_t<COUNT_NW>), dim3(std::min(n_blocks, w.n_units)), dim3(COUNT_THREADS), 0, c->s_compute, w);
 		else if (three && c->sampling) hipLaunchKernelGGL((k_count3_list_t<COUNT_NW, 1>), dim3(std::min(n_blocks, w.n_units)), dim3(COUNT_THREADS), 0, c->s_compute, w);
 		else if (three) hipLaunchKernelGGL((k_count3_list_t<COUNT_NW>), dim3(std::min(n_blocks, w.n_units)), dim3(COUNT_THREADS), 0, c->s_compute, w);
 		else if (fuse && fa->unphased) hipLaunchKernelGGL((k_count_screen_unphased_t<COUNT_NW>), dim3(std::min(n_blocks, w.n_units)), dim3(COUNT_THREADS), 0, c->s_compute, w, &d_fa->screen);
@@ -858,7 +852,7 @@ int enqueue_tile(twk_hip_ctx* c, int mode, const twk_hip_tile_desc& t, const twk
 	const StatsParams* d_stats = nullptr; const ScreenWork* d_screen = nullptr;
 	s.deferred = false; s.was_deferred = false; s.presorted = false;
 	rc = launch_count(c, kind1, t, s, 0, s.ev_c0, s.ev_c1, &s.row_pairs, cr, want_fused ? &fa : nullptr, &s.fused, &d_stats, want_three, &d_screen); if (rc) return rc;
-	s.three = want_three; s.three_plain = want_three && !s.fused; s.three_wide = s.three_plain && c->opt.three_wide != 0; s.plane_set = kind1;
+	s.three = want_three; s.three_plain = want_three && !s.fused; s.plane_set = kind1;
 	tl("count kernel enqueued");
 	if (list_words) {
 		// A band launch stops here for now: how many survivors it can have is how many candidates it found, and only the count
@@ -1091,7 +1085,7 @@ void watch_launch(twk_hip_ctx* c, const Slot& s, float ms, const twk_hip_tile_de
 	unsigned long long lo = ~0ull, hi = 0;
 	for (int x = 0; x < 8; ++x) if (s.h_n_out[8 + x]) { lo = std::min(lo, s.h_n_out[8 + x]); hi = std::max(hi, s.h_n_out[8 + x]); }
 	st.xcd_finish_spread_us = hi ? (double)(hi - lo) / 100.0 : 0.0;
-	auto cost = [](const twk_hip_launch_stat& x) { return x.row_pairs ? x.ms / ((double)x.row_pairs * (double)x.words_per_row * ((x.kind == 1 || x.kind == 4) ? 0.8125 : 1.0)) : 0.0; };
+	auto cost = [](const twk_hip_launch_stat& x) { return x.row_pairs ? x.ms / ((double)x.row_pairs * (double)x.words_per_row * ((x.kind == 1 || x.kind == 4) ? 0.75 : 1.0)) : 0.0; };
 	if (st.ms >= 0.3 && st.row_pairs) {
 		std::vector<double> peers;
 		for (const auto& x : c->launch_ring)
@@ -1218,7 +1212,7 @@ int finish_tile(twk_hip_ctx* c, Slot& s, const twk_hip_tile_desc& t, unsigned lo
 	       c->timing.count_shader_cycles += s.h_n_out[4]; c->timing.count_wall_ticks += s.h_n_out[5]; }
 	if (s.fused) { c->timing.fused_launches += 1; c->timing.candidates += s.h_n_out[2]; }
 	if (s.three) {
-		c->timing.three_launches += 1; c->timing.three_row_pairs += s.row_pairs; if (s.three_wide) c->timing.three_wide_row_pairs += s.row_pairs; c->timing.recount_candidates += std::min<unsigned long long>(s.h_n_out[2], s.cand_cap);
+		c->timing.three_launches += 1; c->timing.three_row_pairs += s.row_pairs; c->timing.recount_candidates += std::min<unsigned long long>(s.h_n_out[2], s.cand_cap);
 		if (s.three_plain) c->timing.candidates += s.h_n_out[2];
 		if (s.h_n_out[3]) {      // the recount disagrees with the contraction: never to be papered over
 			snprintf(c->err, sizeof(c->err), "three-product contraction: %llu candidates whose (HH, S) differ from their recounted products (tile rows %u+%u, cols %u+%u)", s.h_n_out[3], t.rowA0, t.nA, t.rowB0, t.nB);

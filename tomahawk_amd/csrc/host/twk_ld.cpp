@@ -751,8 +751,8 @@ bool twk_ld::twk_ld_impl::run(twk_ld_settings& settings, const Header& hdr, cons
 			std::cerr << stamp("LOG", "HIP") << (n_gpus > 1 ? "GPU " + std::to_string(g) + ": " : std::string()) << "count kernel " << tm.count_ms << " ms in "
 			          << tm.count_launches << " launches ("
 			          // what the launches issued: one AND+popcount (6 cycles per wave) per word of a plane-row pair - three for every four of them in
-			          // the three-product form, plus one v_or (2 cycles) per four of its products
-			          << (tm.count_ms > 0 ? ((double)(tm.row_pairs - tm.three_row_pairs) + (double)(tm.three_row_pairs - tm.three_wide_row_pairs) * (0.75 + 0.75 / 4.0 / 3.0) + (double)tm.three_wide_row_pairs * (0.75 + 0.75 / 6.0 / 3.0)) * (double)tm.words_per_row / (tm.count_ms * 1e-3) / 2.62e13 * 100.0 : 0.0)
+			          // the three-product form (v_and / v_bitop3 + v_bcnt: no other instruction since round 6)
+			          << (tm.count_ms > 0 ? ((double)(tm.row_pairs - tm.three_row_pairs) + (double)tm.three_row_pairs * 0.75) * (double)tm.words_per_row / (tm.count_ms * 1e-3) / 2.62e13 * 100.0 : 0.0)
 			          << " % of the and+bcnt issue ceiling over the tiles it contracted"
 			          << (tm.count_wall_ticks ? "; its blocks ran at " + std::to_string((int)((double)tm.count_shader_cycles / (double)tm.count_wall_ticks * 100.0 + 0.5)) + " MHz" : std::string())
 			          << "), math kernels " << tm.stats_ms << " ms"

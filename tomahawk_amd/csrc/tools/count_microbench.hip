@@ -124,8 +124,8 @@ int main(int argc,char**argv){
         for(int i=0;i<reps;++i){ CK(hipEventRecord(e0)); launch(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms,e0,e1)); if(ms<best)best=ms; }
         unsigned long long nc=0; CK(hipMemcpy(&nc,dn,8,hipMemcpyDeviceToHost));
         const uint32_t words_done = w.last_halves? (W/twk::KC-1)*twk::KC + 2*w.last_halves : W;
-        const double prod = tiles*128*128*words_done*(form==2?0.75:1.0), equiv = prod*(form==2? 0.8125/0.75 : 1.0);
-        printf("fused %-22s %-12s R=%u W=%u live=%u tiles=%.0f best %.3f ms  products/s %.3e  (%.1f%% of the issue ceiling 2.62e13, v_or priced)  candidates %llu\n",
+        const double prod = tiles*128*128*words_done*(form==2?0.75:1.0), equiv = prod;
+        printf("fused %-22s %-12s R=%u W=%u live=%u tiles=%.0f best %.3f ms  products/s %.3e  (%.1f%% of the and+bcnt ceiling 2.62e13)  candidates %llu\n",
                form==0?"phased":form==1?"unphased four-product":"unphased three-product", noepi?"no epilogue":"with screen", R,W,live,tiles,best,prod/best*1e3,equiv/best*1e3/2.6214e13*100,nc);
       }
     }
@@ -138,12 +138,24 @@ int main(int argc,char**argv){
     first_split=twk::build_count_units((uint32_t)list.size(),W/twk::KC,P,min_chunks,units,8,8); twk::fill_unit_tiles(units,list.data());
     CK(hipMemcpy(du,units.data(),units.size()*16,hipMemcpyHostToDevice)); w.units=du; w.n_units=(uint32_t)units.size(); w.n_queues=1; w.queue_begin[0]=0; w.queue_begin[1]=w.n_units;
     const double tiles=(double)list.size(), wordops=tiles*128*128*W;
-    for(int three=0; three<3; ++three){      // 0 four products, 1 three products on the 4 x 2 lane tile, 2 on the wide (4 x 4, K-split) one
+    if(const char* ex=getenv("EXPER")){   // timing only (wrong counts): the three- and four-product list kernels without the chunk barrier (7) / without the operand staging (8)
+      const int which=atoi(ex);
+      for(int three=0; three<2; ++three){
+        auto launch=[&](){ CK(hipMemsetAsync(tick,0,4,0));
+          if(which==7){ if(three) hipLaunchKernelGGL((twk::k_count3_list_t<twk::COUNT_NW,7>),dim3(P),block,0,0,w); else hipLaunchKernelGGL((twk::k_count_list_t<twk::COUNT_NW,7>),dim3(P),block,0,0,w); }
+          else { if(three) hipLaunchKernelGGL((twk::k_count3_list_t<twk::COUNT_NW,8>),dim3(P),block,0,0,w); else hipLaunchKernelGGL((twk::k_count_list_t<twk::COUNT_NW,8>),dim3(P),block,0,0,w); } };
+        launch(); CK(hipDeviceSynchronize()); float best=1e30f;
+        for(int i=0;i<reps;++i){ CK(hipEventRecord(e0)); launch(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms,e0,e1)); if(ms<best)best=ms; }
+        const double exec=three? wordops*0.75 : wordops;
+        printf("EXPERIMENT %d %-13s best %.3f ms  executed word-pairs/s %.3e (%.1f%% of the and+bcnt ceiling)\n",which,three?"three-product":"four-product",best,exec/best*1e3,exec/best*1e3/2.6214e13*100);
+      }
+      return 0;
+    }
+    for(int three=0; three<2; ++three){
       auto launch=[&](){ CK(hipMemsetAsync(tick,0,4,0));
-        const uint32_t fs = three==2? 0u : first_split;
+        const uint32_t fs = first_split;
         if(fs<list.size()) hipLaunchKernelGGL(twk::k_zero_tiles,dim3((uint32_t)list.size()-fs),dim3(256),0,0,w.tiles,fs,C,R,three?64u:128u);
-        if(three==2) hipLaunchKernelGGL((twk::k_count3w_list_t<twk::COUNT_NW>),dim3(P),block,0,0,w);
-        else if(three) hipLaunchKernelGGL((twk::k_count3_list_t<twk::COUNT_NW>),dim3(P),block,0,0,w); else hipLaunchKernelGGL((twk::k_count_list_t<twk::COUNT_NW>),dim3(P),block,0,0,w); };
+        if(three) hipLaunchKernelGGL((twk::k_count3_list_t<twk::COUNT_NW>),dim3(P),block,0,0,w); else hipLaunchKernelGGL((twk::k_count_list_t<twk::COUNT_NW>),dim3(P),block,0,0,w); };
       CK(hipMemset(C,0xff,(size_t)R*R*4)); launch(); CK(hipDeviceSynchronize());
       if(three){ std::vector<uint32_t> hc((size_t)R*R/2); CK(hipMemcpy(hc.data(),C,hc.size()*4,hipMemcpyDeviceToHost)); int bad=0; std::mt19937 r2(7);
         for(int s=0;s<2000;++s){ const uint32_t a=r2()%(R/2), b=r2()%(R/2); uint32_t hh=0, ss=0;
@@ -151,13 +163,13 @@ int main(int argc,char**argv){
             hh+=__builtin_popcount(ha&hb); ss+=__builtin_popcount(qa&(hb|qb))+__builtin_popcount((ha|qa)&qb); }
           const uint32_t g0=hc[(size_t)a*R+2*b], g1=hc[(size_t)a*R+2*b+1];
           if(g0!=hh||g1!=ss){ if(bad<5) printf("MISMATCH three (%u,%u) ref %u %u got %u %u\n",a,b,hh,ss,g0,g1); ++bad; } }
-        printf("check %s: %d mismatches\n",three==2?"three-wide":"three-product",bad); bad_total+=bad; }
+        printf("check %s: %d mismatches\n","three-product",bad); bad_total+=bad; }
       else check("four-product",0);
       float best=1e30f;
       for(int i=0;i<reps;++i){ CK(hipEventRecord(e0)); launch(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms,e0,e1)); if(ms<best)best=ms; }
       const double exec=three? wordops*0.75 : wordops;
       printf("%-13s R=%u W=%u P=%u tiles=%.0f whole=%u units=%u best %.3f ms  variant pairs/s %.4e  executed word-pairs/s %.3e (%.1f%% of the and+bcnt ceiling 2.62e13)\n",
-             three==2?"three-wide":three?"three-product":"four-product",R,W,P,tiles,first_split,w.n_units,best,tiles*64*64/best*1e3,exec/best*1e3,exec/best*1e3/2.6214e13*100);
+             three?"three-product":"four-product",R,W,P,tiles,first_split,w.n_units,best,tiles*64*64/best*1e3,exec/best*1e3,exec/best*1e3/2.6214e13*100);
     }
     return bad_total!=0;
   }

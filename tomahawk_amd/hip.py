@@ -54,7 +54,7 @@ class _Timing(C.Structure):
                 ("probe_ms", C.c_double), ("probe_launches", C.c_uint64), ("probe_pairs", C.c_uint64),
                 ("count_shader_cycles", C.c_uint64), ("count_wall_ticks", C.c_uint64),
                 ("three_launches", C.c_uint64), ("three_row_pairs", C.c_uint64), ("recount_candidates", C.c_uint64),
-                ("outlier_launches", C.c_uint64), ("three_wide_row_pairs", C.c_uint64), ("finish_ms", C.c_double)]
+                ("outlier_launches", C.c_uint64), ("finish_ms", C.c_double)]
 
 
 class _PlanEnv(C.Structure):         # twk_hip_plan_env
