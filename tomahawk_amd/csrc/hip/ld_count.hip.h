@@ -424,6 +424,53 @@ __device__ __forceinline__ void contract3_half(uint32_t (&acc)[8][4], const uint
 	            a[0].y, a[2].y, a[4].y, a[6].y, a[1].y, a[3].y, a[5].y, a[7].y, b[2].y, b[3].y);
 }
 
+// A whole chunk (16 half-slots) of the three-product form with its operand registers fixed by hand - round 6, after csrc/tools/bitop3_probe.hip found
+// what the loop above loses: a VGPR's bank is its number mod 4, 64-bit tuples sit on even registers, so word x of EVERY ds_read_b64 pair lies in
+// bank 0 or 2 and word y in bank 1 or 3 - any v_bitop3 of three x words has two sources in one bank, and that costs (the probe's half-slots:
+// 78.6 % of the and+bcnt ceiling as above, 85.2 % with the four words of a product group - hA qA hB qB - in four banks, 85.3 % with v_and for every
+// v_bitop3).  So: the B pairs are read by ds_read2_b32 offset0:1 offset1:0 - word y into the even register, word x into the odd one (86.6 % in the
+// probe) - H pairs sit on registers = 0 and Q pairs on registers = 2 (mod 4), and no v_bitop3 (nor v_and) reads a bank twice.  hipcc cannot be told
+// any of this, hence one asm statement over v32..v79: set X = v[32:55] holds the lower halves of the slots (half-slots 0, 2, ..), set Y = v[56:79] the
+// upper ones; within a set the A pairs a[t] (t = 2 s: H of the lane's A variant s, 2 s + 1: its Q) are v[set + 2 t : set + 2 t + 1], the B pairs
+// v[set + 16 + 2 u : ..] with their words swapped.  Reads, waits and products are in the order of the loop in count_list_body (the twelve reads of
+// half-slot h + 1 in front of the products of half-slot h).  bA / bB: the lane's A / B row of the chunk's buffer (slot q at b ^ (q << 4): the
+// swizzle is in address bits 4..6, the B variants' second pair of rows is 2048 bytes on - beyond ds_read2_b32's offsets - and has its own address).
+#define TWK_PR_AND(T, A, B, ACC) "v_and_b32 %[" #T "], v" #A ", v" #B "\n\ts_nop 0\n\tv_bcnt_u32_b32 %[" #ACC "], %[" #T "], %[" #ACC "]\n\t"
+#define TWK_PR_BIT(T, A, B, C, ACC) "v_bitop3_b32 %[" #T "], v" #A ", v" #B ", v" #C " bitop3:0xe0\n\ts_nop 0\n\tv_bcnt_u32_b32 %[" #ACC "], %[" #T "], %[" #ACC "]\n\t"
+// one B variant V against the lane's four A variants, one word: HH[s][V] += popc(hA[s] & hB), S[s][V] += popc(qA[s] & (hB | qB)) + popc(qB & (hA[s] | qA[s]))
+#define TWK_G12(H0, H1, H2, H3, Q0, Q1, Q2, Q3, HB, QB, V) \
+	TWK_PR_AND(t0, H0, HB, h0##V) TWK_PR_AND(t1, H1, HB, h1##V) TWK_PR_AND(t0, H2, HB, h2##V) TWK_PR_AND(t1, H3, HB, h3##V) \
+	TWK_PR_BIT(t0, Q0, HB, QB, s0##V) TWK_PR_BIT(t1, Q1, HB, QB, s1##V) TWK_PR_BIT(t0, Q2, HB, QB, s2##V) TWK_PR_BIT(t1, Q3, HB, QB, s3##V) \
+	TWK_PR_BIT(t0, QB, H0, Q0, s0##V) TWK_PR_BIT(t1, QB, H1, Q1, s1##V) TWK_PR_BIT(t0, QB, H2, Q2, s2##V) TWK_PR_BIT(t1, QB, H3, Q3, s3##V)
+#define TWK_HALF_X TWK_G12(32, 36, 40, 44, 34, 38, 42, 46, 49, 51, 0) TWK_G12(32, 36, 40, 44, 34, 38, 42, 46, 53, 55, 1) \
+                   TWK_G12(33, 37, 41, 45, 35, 39, 43, 47, 48, 50, 0) TWK_G12(33, 37, 41, 45, 35, 39, 43, 47, 52, 54, 1)
+#define TWK_HALF_Y TWK_G12(56, 60, 64, 68, 58, 62, 66, 70, 73, 75, 0) TWK_G12(56, 60, 64, 68, 58, 62, 66, 70, 77, 79, 1) \
+                   TWK_G12(57, 61, 65, 69, 59, 63, 67, 71, 72, 74, 0) TWK_G12(57, 61, 65, 69, 59, 63, 67, 71, 76, 78, 1)
+#define TWK_RD_A(LO, HI, OFF) "ds_read_b64 v[" #LO ":" #HI "], %[aA] offset:" #OFF "\n\t"
+#define TWK_RD_B(LO, HI, ADDR, O0, O1) "ds_read2_b32 v[" #LO ":" #HI "], %[" #ADDR "] offset0:" #O0 " offset1:" #O1 "\n\t"
+#define TWK_READ_X TWK_RD_A(32, 33, 0) TWK_RD_A(34, 35, 128) TWK_RD_A(36, 37, 2048) TWK_RD_A(38, 39, 2176) TWK_RD_A(40, 41, 4096) TWK_RD_A(42, 43, 4224) TWK_RD_A(44, 45, 6144) TWK_RD_A(46, 47, 6272) \
+                   TWK_RD_B(48, 49, aB, 1, 0) TWK_RD_B(50, 51, aB, 33, 32) TWK_RD_B(52, 53, aB2, 1, 0) TWK_RD_B(54, 55, aB2, 33, 32)
+#define TWK_READ_Y TWK_RD_A(56, 57, 8) TWK_RD_A(58, 59, 136) TWK_RD_A(60, 61, 2056) TWK_RD_A(62, 63, 2184) TWK_RD_A(64, 65, 4104) TWK_RD_A(66, 67, 4232) TWK_RD_A(68, 69, 6152) TWK_RD_A(70, 71, 6280) \
+                   TWK_RD_B(72, 73, aB, 3, 2) TWK_RD_B(74, 75, aB, 35, 34) TWK_RD_B(76, 77, aB2, 3, 2) TWK_RD_B(78, 79, aB2, 35, 34)
+#define TWK_SLOT_ADDR(Q16) "v_xor_b32 %[aA], " #Q16 ", %[bA]\n\tv_xor_b32 %[aB], " #Q16 ", %[bB]\n\tv_xor_b32 %[aB2], " #Q16 ", %[bB2]\n\t"
+#define TWK_WAIT12 "s_waitcnt lgkmcnt(12)\n\t"
+// slot q, with the address and the first reads of slot q + 1 behind its first half
+#define TWK_SLOT(NEXT_Q16) TWK_READ_Y TWK_WAIT12 TWK_HALF_X TWK_SLOT_ADDR(NEXT_Q16) TWK_READ_X TWK_WAIT12 TWK_HALF_Y
+__device__ __forceinline__ void contract3_chunk(uint32_t (&acc)[8][4], uint32_t bA, uint32_t bB) {
+	static_assert(KC * 4 == 128 && lane_row_offset<true, 1>() == 128 && lane_row_offset<true, 2>() == 2048 && lane_row_offset<true, 7>() == 6272, "the offsets in TWK_READ_X / _Y");
+	uint32_t t0, t1, aA, aB, aB2;
+	asm volatile(TWK_SLOT_ADDR(0) TWK_READ_X
+	             TWK_SLOT(16) TWK_SLOT(32) TWK_SLOT(48) TWK_SLOT(64) TWK_SLOT(80) TWK_SLOT(96) TWK_SLOT(112)
+	             TWK_READ_Y TWK_WAIT12 TWK_HALF_X "s_waitcnt lgkmcnt(0)\n\t" TWK_HALF_Y
+	             : [h00] "+v"(acc[0][0]), [h01] "+v"(acc[0][2]), [h10] "+v"(acc[2][0]), [h11] "+v"(acc[2][2]), [h20] "+v"(acc[4][0]), [h21] "+v"(acc[4][2]),
+	               [h30] "+v"(acc[6][0]), [h31] "+v"(acc[6][2]), [s00] "+v"(acc[1][1]), [s01] "+v"(acc[1][3]), [s10] "+v"(acc[3][1]), [s11] "+v"(acc[3][3]),
+	               [s20] "+v"(acc[5][1]), [s21] "+v"(acc[5][3]), [s30] "+v"(acc[7][1]), [s31] "+v"(acc[7][3]),
+	               [t0] "=&v"(t0), [t1] "=&v"(t1), [aA] "=&v"(aA), [aB] "=&v"(aB), [aB2] "=&v"(aB2)
+	             : [bA] "v"(bA), [bB] "v"(bB), [bB2] "v"(bB + 2048u)
+	             : "memory", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55",
+	               "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79");
+}
+
 // ---- persistent work-list form of the same contraction ------------------------------------
 // One launch = a list of 128 x 128 tiles of one super-tile (only the tiles that hold wanted pairs:
 // on/above the diagonal, inside the window band, ...) run by P persistent blocks, P = the number
@@ -760,7 +807,9 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 		// the 12 reads just issued has arrived").
 		const uint32_t bufbase = lds_base + (uint32_t)buf * (2 * LDS_TILE_BYTES);
 		const int h_end = (c + 1 == nchunks && w.last_halves) ? (int)w.last_halves : 16;     // wave-uniform
-		if (h_end == 16) {
+		if (THREE && h_end == 16) {
+			if constexpr (THREE) contract3_chunk(acc, bufbase + offA, bufbase + offB);
+		} else if (h_end == 16) {
 			uint2 ra[2][8], rb[2][TB];
 			const uint32_t baseA = bufbase + offA, baseB = bufbase + offB;
 			read_half<TB, PAIRED>(ra[0], rb[0], baseA, baseA ^ (uint32_t)(ODD << 4), baseB, baseB ^ (uint32_t)(ODD << 4), 0);

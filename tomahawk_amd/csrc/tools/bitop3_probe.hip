@@ -25,12 +25,29 @@
 #define LDS4 "ds_read_b64 v[44:45], v72\n\tds_read_b64 v[46:47], v72 offset:128\n\tds_read_b64 v[52:53], v73 offset:4096\n\tds_read_b64 v[54:55], v73 offset:4224\n\ts_waitcnt lgkmcnt(4)\n\t"
 #define LDS6x128 "ds_read_b128 v[44:47], v72\n\tds_read_b128 v[48:51], v72 offset:2048\n\tds_read_b128 v[52:55], v72 offset:4096\n\tds_read_b128 v[58:61], v72 offset:6144\n\t" \
              "ds_read_b128 v[44:47], v73\n\tds_read_b128 v[48:51], v73 offset:2048\n\ts_waitcnt lgkmcnt(6)\n\t"
+// ... and the same twelve reads spread through the products instead of in front of them: three in front of every AND12 (LDS3a..d), one after every fourth
+// product (PL: a product with a read after it), and one IN THE PLACE of a product's s_nop (PN)
+#define RD(D0,D1,A,OFF) "ds_read_b64 v[" #D0 ":" #D1 "], v" #A " offset:" #OFF "\n\t"
+#define LDS3a RD(44,45,72,0) RD(46,47,72,128) RD(48,49,72,2048)
+#define LDS3b RD(50,51,72,2176) RD(52,53,72,4096) RD(54,55,72,4224)
+#define LDS3c RD(58,59,72,6144) RD(60,61,72,6272) RD(44,45,73,0)
+#define LDS3d RD(46,47,73,128) RD(48,49,73,2048) RD(50,51,73,2176) "s_waitcnt lgkmcnt(12)\n\t"
+#define PN(T,A,B,C,D0,D1,AD,OFF) "v_and_b32 v" #T ", v" #A ", v" #B "\n\tds_read_b64 v[" #D0 ":" #D1 "], v" #AD " offset:" #OFF "\n\tv_bcnt_u32_b32 v" #C ", v" #T ", v" #C "\n\t"
+#define PL(T,A,B,C,D0,D1,AD,OFF) P(T,A,B,C) RD(D0,D1,AD,OFF)
+#define AND12_L3(R0,R1,R2) P(56,33,41,64) P(57,35,41,65) P(56,37,41,66) R0 P(57,39,41,67) P(56,34,41,68) P(57,36,41,69) P(56,38,41,70) R1 P(57,40,41,71) P(56,33,42,68) P(57,35,42,69) P(56,37,42,70) R2 P(57,39,42,71)
+#define AND12_N3(D0,D1,D2,D3,D4,D5,AD,O0,O1,O2) PN(56,33,41,64,D0,D1,AD,O0) P(57,35,41,65) P(56,37,41,66) P(57,39,41,67) PN(56,34,41,68,D2,D3,AD,O1) P(57,36,41,69) P(56,38,41,70) P(57,40,41,71) PN(56,33,42,68,D4,D5,AD,O2) P(57,35,42,69) P(56,37,42,70) P(57,39,42,71)
+#define MIX12_L3(R0,R1,R2) P(56,33,41,64) P(57,35,41,65) P(56,37,41,66) R0 P(57,39,41,67) B3(56,34,41,42,68) B3(57,36,41,42,69) B3(56,38,41,42,70) R1 B3(57,40,41,42,71) B3(56,42,33,34,68) B3(57,42,35,36,69) B3(56,42,37,38,70) R2 B3(57,42,39,40,71)
 #define R8(X) X X X X X X X X
+// (3) the half-slot as the count kernel runs it (bitop3_probe_gen.h): the reads of the next half-slot into one register set, the 48 products of this one
+//     from the other - with v_and in the place of every v_bitop3 (timing only) and as it is; and the same with the reads landing apart from the products' sources
+#include "bitop3_probe_gen.h"
+#define CLOB3 "v12","v13","v14","v15","v16","v17","v18","v19","v20","v21","v22","v23","v24","v25","v26","v27","v28","v29","v30","v31"
+#define CLOB2 "v76","v77","v78","v79","v80","v81","v82","v83","v84","v85","v86","v87","v88","v89","v90","v91","v92","v93","v94","v95","v96","v97","v98","v99","v100","v101","v102","v103","v104","v105","v106","v107","v108","v109","v110","v111","v112","v113","v114","v115","v116","v117","v118","v119","v120","v121","v122","v123","v124","v125","v126","v127"
 template<int MODE> __global__ __launch_bounds__(512, 2) void k(uint32_t* out, int iters){
   __shared__ uint32_t lds[16384];
   if(MODE>=3){ for(int i=threadIdx.x;i<16384;i+=512) lds[i]=i; __syncthreads();
-    const uint32_t a=(uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds + (threadIdx.x>>3&7)*256 + ((threadIdx.x>>3&7)<<4), b=a+8192+((threadIdx.x&7)*256);
-    asm volatile("v_mov_b32 v72, %0\n\tv_mov_b32 v73, %1" :: "v"(a), "v"(b) : "v72", "v73"); }
+    const uint32_t a=(uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds + (threadIdx.x>>3&7)*256 + ((threadIdx.x>>3&7)<<4), b=(uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds + 8192 + (threadIdx.x&7)*256 + ((threadIdx.x&7)<<4);      // (the count kernel's PAIRED lane rows: no bank conflicts)
+    asm volatile("v_mov_b32 v72, %0\n\tv_mov_b32 v73, %1\n\tv_add_u32 v74, 2048, v73" :: "v"(a), "v"(b) : "v72", "v73", "v74"); }
   for(int it=0; it<iters; ++it){
     if(MODE==0) asm volatile(R8(AND12 AND12) ::: CLOB);
     else if(MODE==1) asm volatile(R8(BIT12 BIT12) ::: CLOB);
@@ -39,9 +56,28 @@ template<int MODE> __global__ __launch_bounds__(512, 2) void k(uint32_t* out, in
     else if(MODE==4) asm volatile(R8(LDS12 MIX12 MIX12 MIX12 MIX12) ::: CLOB, "v72", "v73");
     else if(MODE==5) asm volatile(R8(LDS8 AND12 AND12 AND12 AND12) ::: CLOB, "v72", "v73");
     else if(MODE==6) asm volatile(R8(LDS4 AND12 AND12 AND12 AND12) ::: CLOB, "v72", "v73");
-    else asm volatile(R8(LDS6x128 AND12 AND12 AND12 AND12) ::: CLOB, "v72", "v73");
+    else if(MODE==7) asm volatile(R8(LDS6x128 AND12 AND12 AND12 AND12) ::: CLOB, "v72", "v73");
+    else if(MODE==8) asm volatile(R8(LDS3a AND12 LDS3b AND12 LDS3c AND12 LDS3d AND12) ::: CLOB, "v72", "v73");
+    else if(MODE==9) asm volatile(R8(AND12_L3(RD(44,45,72,0),RD(46,47,72,128),RD(48,49,72,2048)) AND12_L3(RD(50,51,72,2176),RD(52,53,72,4096),RD(54,55,72,4224))
+                                     AND12_L3(RD(58,59,72,6144),RD(60,61,72,6272),RD(44,45,73,0)) AND12_L3(RD(46,47,73,128),RD(48,49,73,2048),RD(50,51,73,2176)) "s_waitcnt lgkmcnt(12)\n\t") ::: CLOB, "v72", "v73");
+    else if(MODE==10) asm volatile(R8(AND12_N3(44,45,46,47,48,49,72,0,128,2048) AND12_N3(50,51,52,53,54,55,72,2176,4096,4224)
+                                      AND12_N3(58,59,60,61,44,45,73,6144,6272,0) AND12_N3(46,47,48,49,50,51,73,128,2048,2176) "s_waitcnt lgkmcnt(12)\n\t") ::: CLOB, "v72", "v73");
+    else if(MODE==12) asm volatile(STEP_AND STEP_AND STEP_AND STEP_AND ::: CLOB, CLOB2, "v72", "v73");
+    else if(MODE==13) asm volatile(STEP_BITOP3 STEP_BITOP3 STEP_BITOP3 STEP_BITOP3 ::: CLOB, CLOB2, "v72", "v73");
+    else if(MODE==14) asm volatile(STEP_AND_APART STEP_AND_APART STEP_AND_APART STEP_AND_APART ::: CLOB, CLOB2, "v72", "v73");
+    else if(MODE==15) asm volatile(STEP_BITOP3_APART STEP_BITOP3_APART STEP_BITOP3_APART STEP_BITOP3_APART ::: CLOB, CLOB2, "v72", "v73");
+    else if(MODE==16) asm volatile(STEP_AND_APART_SWAPB STEP_AND_APART_SWAPB STEP_AND_APART_SWAPB STEP_AND_APART_SWAPB ::: CLOB, CLOB2, "v72", "v73");
+    else if(MODE==17) asm volatile(STEP_BITOP3_APART_SWAPB STEP_BITOP3_APART_SWAPB STEP_BITOP3_APART_SWAPB STEP_BITOP3_APART_SWAPB ::: CLOB, CLOB2, "v72", "v73");
+    else if(MODE==18) asm volatile(STEP_AND_SWAPB STEP_AND_SWAPB STEP_AND_SWAPB STEP_AND_SWAPB ::: CLOB, CLOB2, "v72", "v73", "v74");
+    else if(MODE==19) asm volatile(STEP_BITOP3_SWAPB STEP_BITOP3_SWAPB STEP_BITOP3_SWAPB STEP_BITOP3_SWAPB ::: CLOB, CLOB2, "v72", "v73", "v74");
+    else if(MODE==20) asm volatile(STEP_BITOP3_SWAPB_TUPLEA STEP_BITOP3_SWAPB_TUPLEA STEP_BITOP3_SWAPB_TUPLEA STEP_BITOP3_SWAPB_TUPLEA ::: CLOB, CLOB2, "v72", "v73", "v74", "v75");
+    else if(MODE==21) asm volatile(STEP_BITOP3_TUPLEA STEP_BITOP3_TUPLEA STEP_BITOP3_TUPLEA STEP_BITOP3_TUPLEA ::: CLOB, CLOB2, "v72", "v73", "v74", "v75");
+    else if(MODE==22) asm volatile(STEP_AND_WIDEA STEP_AND_WIDEA STEP_AND_WIDEA STEP_AND_WIDEA ::: CLOB3, CLOB, CLOB2, "v72", "v73", "v74");
+    else if(MODE==23) asm volatile(STEP_BITOP3_WIDEA STEP_BITOP3_WIDEA STEP_BITOP3_WIDEA STEP_BITOP3_WIDEA ::: CLOB3, CLOB, CLOB2, "v72", "v73", "v74");
+    else asm volatile(R8(MIX12_L3(RD(44,45,72,0),RD(46,47,72,128),RD(48,49,72,2048)) MIX12_L3(RD(50,51,72,2176),RD(52,53,72,4096),RD(54,55,72,4224))
+                                     MIX12_L3(RD(58,59,72,6144),RD(60,61,72,6272),RD(44,45,73,0)) MIX12_L3(RD(46,47,73,128),RD(48,49,73,2048),RD(50,51,73,2176)) "s_waitcnt lgkmcnt(12)\n\t") ::: CLOB, "v72", "v73");
   }
-  uint32_t s; asm volatile("v_add_u32 %0, v64, v68" : "=v"(s)); out[blockIdx.x*blockDim.x+threadIdx.x]=s;
+  uint32_t s; asm volatile("v_add_u32 %0, v64, v68\n\tv_add_u32 %0, %0, v12\n\tv_add_u32 %0, %0, v20" : "=v"(s)); out[blockIdx.x*blockDim.x+threadIdx.x]=s;
 }
 template<int MODE> void run(const char* name){
   int blocks=256*2; uint32_t* d; CK(hipMalloc(&d,(size_t)blocks*512*4));
@@ -49,7 +85,7 @@ template<int MODE> void run(const char* name){
   hipLaunchKernelGGL((k<MODE>),dim3(blocks),dim3(512),0,0,d,2000); CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0)); hipLaunchKernelGGL((k<MODE>),dim3(blocks),dim3(512),0,0,d,iters); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms,e0,e1));
-  const double steps=(double)blocks*512*iters*8*(MODE>=3?2:1);
+  const double steps=(double)blocks*512*iters*(MODE>=12&&MODE<=23 ? 16 : 8*(MODE>=3?2:1));      // (in units of 24 products)
   printf("%-58s %.3f ms  products/s %.3e (%.1f %% of the and+bcnt ceiling 2.62e13)\n",name,ms,steps*24/ms*1e3,steps*24/ms*1e3/2.6214e13*100); fflush(stdout);
 }
 __global__ void k_check(const uint32_t* a, const uint32_t* b, const uint32_t* c, uint32_t* o, int n){
@@ -72,5 +108,21 @@ int main(){
   run<5>("48 x v_and products + 8 ds_read_b64");
   run<6>("48 x v_and products + 4 ds_read_b64");
   run<7>("48 x v_and products + 6 ds_read_b128 (the bytes of 12 b64)");
+  run<8>("48 x v_and products, 3 ds_read_b64 in front of every 12");
+  run<9>("48 x v_and products, a ds_read_b64 after every 4th");
+  run<10>("48 x v_and products, a ds_read_b64 for every 4th s_nop");
+  run<11>("48 products of the mix, a ds_read_b64 after every 4th");
+  run<12>("half-slots as in the kernel, v_and for every v_bitop3");
+  run<13>("half-slots as in the kernel (8 v_and + 16 v_bitop3 per 24)");
+  run<14>("... v_and only, reads landing apart from the sources");
+  run<15>("... the mix, reads landing apart from the sources");
+  run<16>("... v_and only, reads apart, hA qA hB qB in four banks");
+  run<17>("... the mix, reads apart, hA qA hB qB in four banks");
+  run<18>("half-slots, v_and only, B pairs by swapped ds_read2_b32");
+  run<19>("half-slots, the mix, B pairs by swapped ds_read2_b32");
+  run<20>("... and the A variants' H Q by one ds_read2_b64 each");
+  run<21>("half-slots, the mix, ds_read2_b64 for A, B plain (two in a bank)");
+  run<22>("whole A slots by ds_read_b128, swapped B pairs, v_and only");
+  run<23>("whole A slots by ds_read_b128, swapped B pairs, the mix");
   return bad!=0;
 }
