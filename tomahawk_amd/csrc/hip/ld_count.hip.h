@@ -357,84 +357,25 @@ __device__ __forceinline__ void contract_half(uint32_t (&acc)[8][TB], int u, con
 // instruction: 0xE0 = a & (b | c)), that issues at the rate of v_and_b32 (csrc/tools/bitop3_probe.hip: 24 x (v_bitop3, s_nop, v_bcnt)
 // 2.527e13 products/s against 2.518e13 for v_and - and the three-product mix at 96.1 % of the and+bcnt ceiling where the v_or of
 // rounds 5 and 6a left 85.4 / 88.7 %): Q_A & (H_B | Q_B) and Q_B & (H_A | Q_A) are one instruction each, so a product of the
-// three-product form costs exactly what a product of the four-product form costs, and there are three of them.
-// One B variant against the lane's four A variants, one word: hh[s] += popc(hA[s] & hB), ss[s] += popc(qA[s] & (hB | qB)) +
-// popc(qB & (hA[s] | qA[s])); same (op, s_nop, BCNT) issue pattern as and_bcnt8v.
-__device__ __forceinline__ void and_bcnt12v(uint32_t& hh0, uint32_t& hh1, uint32_t& hh2, uint32_t& hh3,
-                                            uint32_t& ss0, uint32_t& ss1, uint32_t& ss2, uint32_t& ss3,
-                                            uint32_t h0, uint32_t h1, uint32_t h2, uint32_t h3,
-                                            uint32_t q0, uint32_t q1, uint32_t q2, uint32_t q3, uint32_t hb, uint32_t qb) {
-	uint32_t t0, t1;
-	asm volatile("v_and_b32 %8, %10, %18\n\t"
-	    "s_nop 0\n\t"
-	    "v_bcnt_u32_b32 %0, %8, %0\n\t"
-	    "v_and_b32 %9, %11, %18\n\t"
-	    "s_nop 0\n\t"
-	    "v_bcnt_u32_b32 %1, %9, %1\n\t"
-	    "v_and_b32 %8, %12, %18\n\t"
-	    "s_nop 0\n\t"
-	    "v_bcnt_u32_b32 %2, %8, %2\n\t"
-	    "v_and_b32 %9, %13, %18\n\t"
-	    "s_nop 0\n\t"
-	    "v_bcnt_u32_b32 %3, %9, %3\n\t"
-	    "v_bitop3_b32 %8, %14, %18, %19 bitop3:0xe0\n\t"
-	    "s_nop 0\n\t"
-	    "v_bcnt_u32_b32 %4, %8, %4\n\t"
-	    "v_bitop3_b32 %9, %15, %18, %19 bitop3:0xe0\n\t"
-	    "s_nop 0\n\t"
-	    "v_bcnt_u32_b32 %5, %9, %5\n\t"
-	    "v_bitop3_b32 %8, %16, %18, %19 bitop3:0xe0\n\t"
-	    "s_nop 0\n\t"
-	    "v_bcnt_u32_b32 %6, %8, %6\n\t"
-	    "v_bitop3_b32 %9, %17, %18, %19 bitop3:0xe0\n\t"
-	    "s_nop 0\n\t"
-	    "v_bcnt_u32_b32 %7, %9, %7\n\t"
-	    "v_bitop3_b32 %8, %19, %10, %14 bitop3:0xe0\n\t"
-	    "s_nop 0\n\t"
-	    "v_bcnt_u32_b32 %4, %8, %4\n\t"
-	    "v_bitop3_b32 %9, %19, %11, %15 bitop3:0xe0\n\t"
-	    "s_nop 0\n\t"
-	    "v_bcnt_u32_b32 %5, %9, %5\n\t"
-	    "v_bitop3_b32 %8, %19, %12, %16 bitop3:0xe0\n\t"
-	    "s_nop 0\n\t"
-	    "v_bcnt_u32_b32 %6, %8, %6\n\t"
-	    "v_bitop3_b32 %9, %19, %13, %17 bitop3:0xe0\n\t"
-	    "s_nop 0\n\t"
-	    "v_bcnt_u32_b32 %7, %9, %7"
-	    : "+v"(hh0), "+v"(hh1), "+v"(hh2), "+v"(hh3), "+v"(ss0), "+v"(ss1), "+v"(ss2), "+v"(ss3), "=&v"(t0), "=&v"(t1)
-	    : "v"(h0), "v"(h1), "v"(h2), "v"(h3), "v"(q0), "v"(q1), "v"(q2), "v"(q3), "v"(hb), "v"(qb));
-}
-// One half-slot (two words) of the three-product form.  a[2s] / a[2s + 1]: the H / Q words of the lane's A variant s, b[2v] /
-// b[2v + 1] of its B variant v (PAIRED lane rows); HH of the pair (s, v) accumulates in acc[2s][2v], S in acc[2s + 1][2v + 1]
-// (the registers acc[2s][2v + 1] and acc[2s + 1][2v] of the four-product form are never touched and cost nothing).
-// Round 6 looked for the rest (profiles/r06_three_bitop3.txt): in the kernel the loop runs at 88.0 % of the and+bcnt ceiling, the same loop with
-// v_and_b32 in the place of every v_bitop3_b32 (wrong S, timing only) at 92.1 %, the four-product kernel at 93.0 %.  Not the chunk barrier
-// (without it: 87.7 %), not the operand staging (88.7 %), not VGPR banks (H and Q words read by one ds_read2_b64 into a 128-bit tuple, no
-// v_bitop3 with its three sources in one bank: 86.6 %), not the number of LDS instructions (whole slots with ds_read_b128, half as many
-// reads, 126 VGPRs: 87.9 %), not the operand order (0xA8, c & (a | b): 87.9 %), not the lane tile (4 x 4 variants with the waves split over
-// the halves of a chunk: 88.0 %).  The form below - 80 VGPRs - is what stays.
-__device__ __forceinline__ void contract3_half(uint32_t (&acc)[8][4], const uint2 (&a)[8], const uint2 (&b)[4]) {
-	and_bcnt12v(acc[0][0], acc[2][0], acc[4][0], acc[6][0], acc[1][1], acc[3][1], acc[5][1], acc[7][1],
-	            a[0].x, a[2].x, a[4].x, a[6].x, a[1].x, a[3].x, a[5].x, a[7].x, b[0].x, b[1].x);
-	and_bcnt12v(acc[0][2], acc[2][2], acc[4][2], acc[6][2], acc[1][3], acc[3][3], acc[5][3], acc[7][3],
-	            a[0].x, a[2].x, a[4].x, a[6].x, a[1].x, a[3].x, a[5].x, a[7].x, b[2].x, b[3].x);
-	and_bcnt12v(acc[0][0], acc[2][0], acc[4][0], acc[6][0], acc[1][1], acc[3][1], acc[5][1], acc[7][1],
-	            a[0].y, a[2].y, a[4].y, a[6].y, a[1].y, a[3].y, a[5].y, a[7].y, b[0].y, b[1].y);
-	and_bcnt12v(acc[0][2], acc[2][2], acc[4][2], acc[6][2], acc[1][3], acc[3][3], acc[5][3], acc[7][3],
-	            a[0].y, a[2].y, a[4].y, a[6].y, a[1].y, a[3].y, a[5].y, a[7].y, b[2].y, b[3].y);
-}
-
-// A whole chunk (16 half-slots) of the three-product form with its operand registers fixed by hand - round 6, after csrc/tools/bitop3_probe.hip found
-// what the loop above loses: a VGPR's bank is its number mod 4, 64-bit tuples sit on even registers, so word x of EVERY ds_read_b64 pair lies in
-// bank 0 or 2 and word y in bank 1 or 3 - any v_bitop3 of three x words has two sources in one bank, and that costs (the probe's half-slots:
-// 78.6 % of the and+bcnt ceiling as above, 85.2 % with the four words of a product group - hA qA hB qB - in four banks, 85.3 % with v_and for every
-// v_bitop3).  So: the B pairs are read by ds_read2_b32 offset0:1 offset1:0 - word y into the even register, word x into the odd one (86.6 % in the
-// probe) - H pairs sit on registers = 0 and Q pairs on registers = 2 (mod 4), and no v_bitop3 (nor v_and) reads a bank twice.  hipcc cannot be told
-// any of this, hence one asm statement over v32..v79: set X = v[32:55] holds the lower halves of the slots (half-slots 0, 2, ..), set Y = v[56:79] the
-// upper ones; within a set the A pairs a[t] (t = 2 s: H of the lane's A variant s, 2 s + 1: its Q) are v[set + 2 t : set + 2 t + 1], the B pairs
-// v[set + 16 + 2 u : ..] with their words swapped.  Reads, waits and products are in the order of the loop in count_list_body (the twelve reads of
-// half-slot h + 1 in front of the products of half-slot h).  bA / bB: the lane's A / B row of the chunk's buffer (slot q at b ^ (q << 4): the
-// swizzle is in address bits 4..6, the B variants' second pair of rows is 2048 bytes on - beyond ds_read2_b32's offsets - and has its own address).
+// three-product form costs what a product of the four-product form costs, and there are three of them - PROVIDED no v_bitop3 reads
+// a VGPR bank twice, which is what the rest of this section is about (profiles/r06_three_bitop3.txt has the numbers of every step).
+//
+// A whole chunk (8 slots of 4 words) of the three-product form with its operand registers placed by hand.  What csrc/tools/bitop3_probe.hip found:
+//  * a VGPR's bank is its number mod 4 and register tuples start on even registers, so word x of EVERY ds_read_b64 pair lies in bank 0 or 2 and
+//    word y in bank 1 or 3: any v_bitop3 of three same-numbered words has two sources in one bank, and that costs - the probe's half-slots run at
+//    78.6 % of the and+bcnt ceiling in compiler-like registers, at 85.2 % with the four words of a product group (hA qA hB qB) in four banks, at
+//    85.3 % with v_and in the place of every v_bitop3.  So the B pairs are read by ds_read2_b32 offset0:1 offset1:0 - the odd word into the even
+//    register - H tuples start on registers = 0 and Q tuples on registers = 2 (mod 4), and no v_bitop3 (nor v_and) reads a bank twice;
+//  * an LDS read costs the wave's VALU stream about the same whatever its width, and reads in one batch cost less than the same reads spread
+//    through the products: the A variants' H and Q rows are read a whole slot at a time (ds_read_b128: 8 + 4 + 4 reads per 96 products where the
+//    half-slot form had 24).
+// hipcc cannot be told any of this, hence one asm statement with the operands in v36..v123 (the count kernel's other values fit below, above and in
+// the gaps: 125 VGPRs, no scratch): A sets P and R (a slot each: H tuples of the lane's four A variants v36.. / v72.., their Q tuples v54.. / v90..), B sets
+// BX = v108..v115 (lower half of a slot: the pairs hB0 qB0 hB1 qB1, words swapped) and BY = v116..v123 (upper half).  Order: the B pairs of a slot's upper half
+// are read in front of its lower half's products, all of the next slot's A tuples and lower B pairs in front of its upper half's; LDS returns in
+// order, so lgkmcnt(n) = "everything but the n reads just issued has arrived".  bA / bB: the lane's A / B row in the chunk's buffer; slot q
+// lies at b ^ (q << 4) (the swizzle is in address bits 4..6); the B variants' second pair of rows is 2048 bytes on, beyond ds_read2_b32's
+// offsets, and gets its own address.
 #define TWK_PR_AND(T, A, B, ACC) "v_and_b32 %[" #T "], v" #A ", v" #B "\n\ts_nop 0\n\tv_bcnt_u32_b32 %[" #ACC "], %[" #T "], %[" #ACC "]\n\t"
 #define TWK_PR_BIT(T, A, B, C, ACC) "v_bitop3_b32 %[" #T "], v" #A ", v" #B ", v" #C " bitop3:0xe0\n\ts_nop 0\n\tv_bcnt_u32_b32 %[" #ACC "], %[" #T "], %[" #ACC "]\n\t"
 // one B variant V against the lane's four A variants, one word: HH[s][V] += popc(hA[s] & hB), S[s][V] += popc(qA[s] & (hB | qB)) + popc(qB & (hA[s] | qA[s]))
@@ -442,33 +383,51 @@ __device__ __forceinline__ void contract3_half(uint32_t (&acc)[8][4], const uint
 	TWK_PR_AND(t0, H0, HB, h0##V) TWK_PR_AND(t1, H1, HB, h1##V) TWK_PR_AND(t0, H2, HB, h2##V) TWK_PR_AND(t1, H3, HB, h3##V) \
 	TWK_PR_BIT(t0, Q0, HB, QB, s0##V) TWK_PR_BIT(t1, Q1, HB, QB, s1##V) TWK_PR_BIT(t0, Q2, HB, QB, s2##V) TWK_PR_BIT(t1, Q3, HB, QB, s3##V) \
 	TWK_PR_BIT(t0, QB, H0, Q0, s0##V) TWK_PR_BIT(t1, QB, H1, Q1, s1##V) TWK_PR_BIT(t0, QB, H2, Q2, s2##V) TWK_PR_BIT(t1, QB, H3, Q3, s3##V)
-#define TWK_HALF_X TWK_G12(32, 36, 40, 44, 34, 38, 42, 46, 49, 51, 0) TWK_G12(32, 36, 40, 44, 34, 38, 42, 46, 53, 55, 1) \
-                   TWK_G12(33, 37, 41, 45, 35, 39, 43, 47, 48, 50, 0) TWK_G12(33, 37, 41, 45, 35, 39, 43, 47, 52, 54, 1)
-#define TWK_HALF_Y TWK_G12(56, 60, 64, 68, 58, 62, 66, 70, 73, 75, 0) TWK_G12(56, 60, 64, 68, 58, 62, 66, 70, 77, 79, 1) \
-                   TWK_G12(57, 61, 65, 69, 59, 63, 67, 71, 72, 74, 0) TWK_G12(57, 61, 65, 69, 59, 63, 67, 71, 76, 78, 1)
-#define TWK_RD_A(LO, HI, OFF) "ds_read_b64 v[" #LO ":" #HI "], %[aA] offset:" #OFF "\n\t"
+#define TWK_HALF0_P TWK_G12(36, 40, 44, 48, 54, 58, 62, 66, 109, 111, 0) TWK_G12(36, 40, 44, 48, 54, 58, 62, 66, 113, 115, 1) \
+                    TWK_G12(37, 41, 45, 49, 55, 59, 63, 67, 108, 110, 0) TWK_G12(37, 41, 45, 49, 55, 59, 63, 67, 112, 114, 1)
+#define TWK_HALF1_P TWK_G12(38, 42, 46, 50, 56, 60, 64, 68, 117, 119, 0) TWK_G12(38, 42, 46, 50, 56, 60, 64, 68, 121, 123, 1) \
+                    TWK_G12(39, 43, 47, 51, 57, 61, 65, 69, 116, 118, 0) TWK_G12(39, 43, 47, 51, 57, 61, 65, 69, 120, 122, 1)
+#define TWK_HALF0_R TWK_G12(72, 76, 80, 84, 90, 94, 98, 102, 109, 111, 0) TWK_G12(72, 76, 80, 84, 90, 94, 98, 102, 113, 115, 1) \
+                    TWK_G12(73, 77, 81, 85, 91, 95, 99, 103, 108, 110, 0) TWK_G12(73, 77, 81, 85, 91, 95, 99, 103, 112, 114, 1)
+#define TWK_HALF1_R TWK_G12(74, 78, 82, 86, 92, 96, 100, 104, 117, 119, 0) TWK_G12(74, 78, 82, 86, 92, 96, 100, 104, 121, 123, 1) \
+                    TWK_G12(75, 79, 83, 87, 93, 97, 101, 105, 116, 118, 0) TWK_G12(75, 79, 83, 87, 93, 97, 101, 105, 120, 122, 1)
+#define TWK_RD_A(LO, HI, OFF) "ds_read_b128 v[" #LO ":" #HI "], %[aA] offset:" #OFF "\n\t"
 #define TWK_RD_B(LO, HI, ADDR, O0, O1) "ds_read2_b32 v[" #LO ":" #HI "], %[" #ADDR "] offset0:" #O0 " offset1:" #O1 "\n\t"
-#define TWK_READ_X TWK_RD_A(32, 33, 0) TWK_RD_A(34, 35, 128) TWK_RD_A(36, 37, 2048) TWK_RD_A(38, 39, 2176) TWK_RD_A(40, 41, 4096) TWK_RD_A(42, 43, 4224) TWK_RD_A(44, 45, 6144) TWK_RD_A(46, 47, 6272) \
-                   TWK_RD_B(48, 49, aB, 1, 0) TWK_RD_B(50, 51, aB, 33, 32) TWK_RD_B(52, 53, aB2, 1, 0) TWK_RD_B(54, 55, aB2, 33, 32)
-#define TWK_READ_Y TWK_RD_A(56, 57, 8) TWK_RD_A(58, 59, 136) TWK_RD_A(60, 61, 2056) TWK_RD_A(62, 63, 2184) TWK_RD_A(64, 65, 4104) TWK_RD_A(66, 67, 4232) TWK_RD_A(68, 69, 6152) TWK_RD_A(70, 71, 6280) \
-                   TWK_RD_B(72, 73, aB, 3, 2) TWK_RD_B(74, 75, aB, 35, 34) TWK_RD_B(76, 77, aB2, 3, 2) TWK_RD_B(78, 79, aB2, 35, 34)
-#define TWK_SLOT_ADDR(Q16) "v_xor_b32 %[aA], " #Q16 ", %[bA]\n\tv_xor_b32 %[aB], " #Q16 ", %[bB]\n\tv_xor_b32 %[aB2], " #Q16 ", %[bB2]\n\t"
-#define TWK_WAIT12 "s_waitcnt lgkmcnt(12)\n\t"
-// slot q, with the address and the first reads of slot q + 1 behind its first half
-#define TWK_SLOT(NEXT_Q16) TWK_READ_Y TWK_WAIT12 TWK_HALF_X TWK_SLOT_ADDR(NEXT_Q16) TWK_READ_X TWK_WAIT12 TWK_HALF_Y
+#define TWK_READ_P TWK_RD_A(36, 39, 0) TWK_RD_A(54, 57, 128) TWK_RD_A(40, 43, 2048) TWK_RD_A(58, 61, 2176) TWK_RD_A(44, 47, 4096) TWK_RD_A(62, 65, 4224) TWK_RD_A(48, 51, 6144) TWK_RD_A(66, 69, 6272)
+#define TWK_READ_R TWK_RD_A(72, 75, 0) TWK_RD_A(90, 93, 128) TWK_RD_A(76, 79, 2048) TWK_RD_A(94, 97, 2176) TWK_RD_A(80, 83, 4096) TWK_RD_A(98, 101, 4224) TWK_RD_A(84, 87, 6144) TWK_RD_A(102, 105, 6272)
+#define TWK_READ_BX TWK_RD_B(108, 109, aB, 1, 0) TWK_RD_B(110, 111, aB, 33, 32) TWK_RD_B(112, 113, aB2, 1, 0) TWK_RD_B(114, 115, aB2, 33, 32)
+#define TWK_READ_BY TWK_RD_B(116, 117, aB, 3, 2) TWK_RD_B(118, 119, aB, 35, 34) TWK_RD_B(120, 121, aB2, 3, 2) TWK_RD_B(122, 123, aB2, 35, 34)
+#define TWK_CLOBBER_P "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69"
+#define TWK_CLOBBER_R "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105"
+#define TWK_CLOBBER_B "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123"
+#define TWK_SLOT_ADDR(Q16) "v_xor_b32 %[aA], " #Q16 ", %[bA]\n\tv_xor_b32 %[aB], " #Q16 ", %[bB]\n\tv_add_u32 %[aB2], 0x800, %[aB]\n\t"
+// slot q out of A set CUR: the B pairs of its upper half are read in front of its lower half's products, the whole of slot q + 1 (A set NXT, the
+// lower B pairs) in front of its upper half's
+#define TWK_SLOT(CUR, NXT, NEXT_Q16) TWK_READ_BY "s_waitcnt lgkmcnt(4)\n\t" TWK_HALF0_##CUR TWK_SLOT_ADDR(NEXT_Q16) TWK_READ_##NXT TWK_READ_BX "s_waitcnt lgkmcnt(12)\n\t" TWK_HALF1_##CUR
 __device__ __forceinline__ void contract3_chunk(uint32_t (&acc)[8][4], uint32_t bA, uint32_t bB) {
-	static_assert(KC * 4 == 128 && lane_row_offset<true, 1>() == 128 && lane_row_offset<true, 2>() == 2048 && lane_row_offset<true, 7>() == 6272, "the offsets in TWK_READ_X / _Y");
+	static_assert(KC * 4 == 128 && lane_row_offset<true, 1>() == 128 && lane_row_offset<true, 2>() == 2048 && lane_row_offset<true, 7>() == 6272, "the offsets in TWK_READ_P / _R / _BX / _BY");
 	uint32_t t0, t1, aA, aB, aB2;
-	asm volatile(TWK_SLOT_ADDR(0) TWK_READ_X
-	             TWK_SLOT(16) TWK_SLOT(32) TWK_SLOT(48) TWK_SLOT(64) TWK_SLOT(80) TWK_SLOT(96) TWK_SLOT(112)
-	             TWK_READ_Y TWK_WAIT12 TWK_HALF_X "s_waitcnt lgkmcnt(0)\n\t" TWK_HALF_Y
+	asm volatile(TWK_SLOT_ADDR(0) TWK_READ_P TWK_READ_BX
+	             TWK_SLOT(P, R, 16) TWK_SLOT(R, P, 32) TWK_SLOT(P, R, 48) TWK_SLOT(R, P, 64) TWK_SLOT(P, R, 80) TWK_SLOT(R, P, 96) TWK_SLOT(P, R, 112)
+	             TWK_READ_BY "s_waitcnt lgkmcnt(4)\n\t" TWK_HALF0_R "s_waitcnt lgkmcnt(0)\n\t" TWK_HALF1_R
 	             : [h00] "+v"(acc[0][0]), [h01] "+v"(acc[0][2]), [h10] "+v"(acc[2][0]), [h11] "+v"(acc[2][2]), [h20] "+v"(acc[4][0]), [h21] "+v"(acc[4][2]),
 	               [h30] "+v"(acc[6][0]), [h31] "+v"(acc[6][2]), [s00] "+v"(acc[1][1]), [s01] "+v"(acc[1][3]), [s10] "+v"(acc[3][1]), [s11] "+v"(acc[3][3]),
 	               [s20] "+v"(acc[5][1]), [s21] "+v"(acc[5][3]), [s30] "+v"(acc[7][1]), [s31] "+v"(acc[7][3]),
 	               [t0] "=&v"(t0), [t1] "=&v"(t1), [aA] "=&v"(aA), [aB] "=&v"(aB), [aB2] "=&v"(aB2)
-	             : [bA] "v"(bA), [bB] "v"(bB), [bB2] "v"(bB + 2048u)
-	             : "memory", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55",
-	               "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79");
+	             : [bA] "v"(bA), [bB] "v"(bB)
+	             : "memory", TWK_CLOBBER_P, TWK_CLOBBER_R, TWK_CLOBBER_B);
+}
+
+// One slot the plain way (reads, wait, products): the last chunk of rows that end inside it (CountWork::last_halves), one such chunk per unit.
+__device__ __forceinline__ void contract3_slot(uint32_t (&acc)[8][4], uint32_t aA, uint32_t aB) {
+	uint32_t t0, t1, aB2;
+	asm volatile("v_add_u32 %[aB2], 0x800, %[aB]\n\t" TWK_READ_P TWK_READ_BX TWK_READ_BY "s_waitcnt lgkmcnt(0)\n\t" TWK_HALF0_P TWK_HALF1_P
+	             : [h00] "+v"(acc[0][0]), [h01] "+v"(acc[0][2]), [h10] "+v"(acc[2][0]), [h11] "+v"(acc[2][2]), [h20] "+v"(acc[4][0]), [h21] "+v"(acc[4][2]),
+	               [h30] "+v"(acc[6][0]), [h31] "+v"(acc[6][2]), [s00] "+v"(acc[1][1]), [s01] "+v"(acc[1][3]), [s10] "+v"(acc[3][1]), [s11] "+v"(acc[3][3]),
+	               [s20] "+v"(acc[5][1]), [s21] "+v"(acc[5][3]), [s30] "+v"(acc[7][1]), [s31] "+v"(acc[7][3]),
+	               [t0] "=&v"(t0), [t1] "=&v"(t1), [aB2] "=&v"(aB2)
+	             : [aA] "v"(aA), [aB] "v"(aB)
+	             : "memory", TWK_CLOBBER_P, TWK_CLOBBER_B);
 }
 
 // ---- persistent work-list form of the same contraction ------------------------------------
@@ -698,7 +657,7 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 		for (int u = 0; u < TB; ++u) acc[t][u] = 0;
 
 	constexpr bool PAIRED = Epilogue::PAIRED_ROWS;
-	constexpr bool THREE = Epilogue::THREE_PRODUCTS;      // the three-product form of the plain unphased planes (contract3_half)
+	constexpr bool THREE = Epilogue::THREE_PRODUCTS;      // the three-product form of the plain unphased planes (contract3_chunk)
 	static_assert(!THREE || (PAIRED && TB == 4), "the three-product form needs a variant's H and Q rows in one lane");
 	// The per-lane LDS read offsets and DMA source offsets of the K loop.  For the fused epilogues they are recomputed when a unit ends
 	// instead of being held through the epilogue: the epilogue is where the kernels' register demand peaks, and what the allocator evicts
@@ -807,8 +766,14 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 		// the 12 reads just issued has arrived").
 		const uint32_t bufbase = lds_base + (uint32_t)buf * (2 * LDS_TILE_BYTES);
 		const int h_end = (c + 1 == nchunks && w.last_halves) ? (int)w.last_halves : 16;     // wave-uniform
-		if (THREE && h_end == 16) {
-			if constexpr (THREE) contract3_chunk(acc, bufbase + offA, bufbase + offB);
+		if constexpr (THREE) {
+			// (operand registers placed by hand, see contract3_chunk; a row's last, partly filled chunk slot by slot - the half-slot of padding that may
+			// come with it is zeros)
+			if (h_end == 16) contract3_chunk(acc, bufbase + offA, bufbase + offB);
+			else {
+#pragma unroll 1
+				for (uint32_t q = 0; q < (uint32_t)(h_end + 1) >> 1; ++q) contract3_slot(acc, bufbase + (offA ^ (q << 4)), bufbase + (offB ^ (q << 4)));
+			}
 		} else if (h_end == 16) {
 			uint2 ra[2][8], rb[2][TB];
 			const uint32_t baseA = bufbase + offA, baseB = bufbase + offB;
@@ -823,11 +788,8 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 				} else {
 					asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 				}
-				if constexpr (THREE) contract3_half(acc, ra[h & 1], rb[h & 1]);
-				else {
 #pragma unroll
-					for (int u = 0; u < TB; ++u) contract_half<TB>(acc, u, ra[h & 1], rb[h & 1][u]);
-				}
+				for (int u = 0; u < TB; ++u) contract_half<TB>(acc, u, ra[h & 1], rb[h & 1][u]);
 			}
 		} else {
 			// The last chunk of a row whose data ends before the chunk does (CountWork::last_halves): the zero padding is not contracted.
@@ -844,11 +806,8 @@ __device__ __forceinline__ void count_list_body(const CountWork& w, const Epilog
 				uint2 ra[8], rb[TB];
 				rd(ra, rb, h);
 				asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-				if constexpr (THREE) contract3_half(acc, ra, rb);
-				else {
 #pragma unroll
-					for (int u = 0; u < TB; ++u) contract_half<TB>(acc, u, ra, rb[u]);
-				}
+				for (int u = 0; u < TB; ++u) contract_half<TB>(acc, u, ra, rb[u]);
 			}
 		}
 
@@ -1198,7 +1157,7 @@ static_assert(16 / (8 / 2) == 4, "ScreenCounts packs (t, u) as 4t + u: TB = 4");
 // r2 = D^2 / (P (1 - P) Q (1 - Q)) with the REF frequencies P = 1 - (h_A + 2 q_A) / 2N, Q likewise: the pair can pass only if
 // one end of that interval reaches the cut-off.  For unlinked variants the interval is centred on P Q with half width
 // P (1 - P) Q (1 - Q), which is below any cut-off above 1/16: at the default r2 >= 0.1 only pairs in LD are candidates.
-// THREE: the three-product contraction (contract3_half) - the lane holds HH and S = QH + HQ + 2 QQ of a pair, which is all the
+// THREE: the three-product contraction (contract3_chunk) - the lane holds HH and S = QH + HQ + 2 QQ of a pair, which is all the
 // screen reads; a candidate's entry then carries (A, B, HH, S, -, -) and k_recount_unphased fills in the four products.
 template <int TB, bool THREE = false>
 struct ScreenCountsUnphased {
