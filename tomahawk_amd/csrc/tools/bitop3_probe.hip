@@ -85,7 +85,7 @@ template<int MODE> void run(const char* name){
   hipLaunchKernelGGL((k<MODE>),dim3(blocks),dim3(512),0,0,d,2000); CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0)); hipLaunchKernelGGL((k<MODE>),dim3(blocks),dim3(512),0,0,d,iters); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms,e0,e1));
-  const double steps=(double)blocks*512*iters*(MODE>=12&&MODE<=23 ? 16 : 8*(MODE>=3?2:1));      // (in units of 24 products)
+  const double steps=(double)blocks*512*iters*(MODE>=22 ? 32 : MODE>=12 ? 16 : 8*(MODE>=3?2:1));      // (in units of 24 products)
   printf("%-58s %.3f ms  products/s %.3e (%.1f %% of the and+bcnt ceiling 2.62e13)\n",name,ms,steps*24/ms*1e3,steps*24/ms*1e3/2.6214e13*100); fflush(stdout);
 }
 __global__ void k_check(const uint32_t* a, const uint32_t* b, const uint32_t* c, uint32_t* o, int n){
