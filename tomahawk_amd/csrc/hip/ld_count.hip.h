@@ -376,8 +376,10 @@ __device__ __forceinline__ void contract_half(uint32_t (&acc)[8][TB], int u, con
 // order, so lgkmcnt(n) = "everything but the n reads just issued has arrived".  bA / bB: the lane's A / B row in the chunk's buffer; slot q
 // lies at b ^ (q << 4) (the swizzle is in address bits 4..6); the B variants' second pair of rows is 2048 bytes on, beyond ds_read2_b32's
 // offsets, and gets its own address.
-#define TWK_PR_AND(T, A, B, ACC) "v_and_b32 %[" #T "], v" #A ", v" #B "\n\ts_nop 0\n\tv_bcnt_u32_b32 %[" #ACC "], %[" #T "], %[" #ACC "]\n\t"
-#define TWK_PR_BIT(T, A, B, C, ACC) "v_bitop3_b32 %[" #T "], v" #A ", v" #B ", v" #C " bitop3:0xe0\n\ts_nop 0\n\tv_bcnt_u32_b32 %[" #ACC "], %[" #T "], %[" #ACC "]\n\t"
+// ((op, s_nop 0, v_bcnt) as in and_bcnt8v: without the s_nop behind the v_bitop3 the kernel runs at 82.8 % instead of 90.3 % of the and+bcnt ceiling, without
+// any at 76.0 %; s_setprio around the read batches, either way round, costs 0.3 - 0.7 points - profiles/r06_three_bitop3.txt)
+#define TWK_PR_AND(T, A, B, ACC) "v_and_b32 %[" #T "], v" #A ", v" #B "\n\t" "s_nop 0\n\tv_bcnt_u32_b32 %[" #ACC "], %[" #T "], %[" #ACC "]\n\t"
+#define TWK_PR_BIT(T, A, B, C, ACC) "v_bitop3_b32 %[" #T "], v" #A ", v" #B ", v" #C " bitop3:0xe0\n\t" "s_nop 0\n\tv_bcnt_u32_b32 %[" #ACC "], %[" #T "], %[" #ACC "]\n\t"
 // one B variant V against the lane's four A variants, one word: HH[s][V] += popc(hA[s] & hB), S[s][V] += popc(qA[s] & (hB | qB)) + popc(qB & (hA[s] | qA[s]))
 #define TWK_G12(H0, H1, H2, H3, Q0, Q1, Q2, Q3, HB, QB, V) \
 	TWK_PR_AND(t0, H0, HB, h0##V) TWK_PR_AND(t1, H1, HB, h1##V) TWK_PR_AND(t0, H2, HB, h2##V) TWK_PR_AND(t1, H3, HB, h3##V) \
