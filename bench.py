@@ -877,8 +877,8 @@ def main():
                        "collective_backend": collective,
                        "survivors_per_step": recs_all / args.steps,
                        "two_records_written_per_step": written_timed["records"] / args.steps},
-            # achieved / frac: lane-ops the kernel EXECUTED (v_and + v_bcnt per product, plus the three-product form's v_or) - it cannot grow by
-            # counting work that was not done; algorithmic_*: SURVEY 8(d)'s figure per pair (four products per unphased pair) over the same time
+            # achieved / frac: lane-ops the kernel EXECUTED (v_and or v_bitop3 + v_bcnt per product; rounds 5 / 6a also counted the three-product form's
+            # v_or, which no longer exist - so `frac` fell from 0.621 while pairs/s rose) - it cannot grow by counting work that was not done; algorithmic_*: SURVEY 8(d)'s figure per pair (four products per unphased pair) over the same time
             "roofline": {"bound": "valu", "achieved": executed_lane_ops_per_s / 1e12, "peak": VALU_LANE_PEAK / 1e12,
                          "unit": "Tlane-op/s", "frac": executed_lane_ops_per_s / VALU_LANE_PEAK,
                          "algorithmic_achieved": lane_ops_per_s / 1e12, "algorithmic_frac": lane_ops_per_s / VALU_LANE_PEAK,
@@ -906,7 +906,9 @@ def main():
                                                      "from LDS, so this exceeds 1 and does not bound the kernel"},
                          "note": "integer AND+popcount: bound by VALU issue. peak = 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz; "
                                  "and+bcnt ceiling = 64 lanes / (2 + 4 cycles) per SIMD = 2.62e13 word pairs/s "
-                                 "(v_bcnt_u32_b32 is half rate: profiles/*microbench_valu_rate.txt)"},
+                                 "(v_bcnt_u32_b32 is half rate: profiles/*microbench_valu_rate.txt), i.e. frac <= 0.667 for a loop of nothing "
+                                 "but products; the three-product form executes 3 products per word pair (HH, Q_A & (H_B | Q_B), Q_B & (H_A | Q_A): "
+                                 "the last two one v_bitop3_b32 each, no v_or), algorithmic_* prices SURVEY 8(d)'s four"},
             "kernel_ms": {"count": count_ms_max, "math": stats_ms_max, "wall": elapsed_max * 1e3},
             "per_rank_ms": per_rank_ms,                                   # compute per step, every rank (balance of the bands)
             "gather_ms": phase_timed["gather"] / max(args.steps, 1) * 1e3,      # rank 0, per step: waits for the slowest rank, then the transfers
