@@ -47,7 +47,7 @@ template<int MODE> __global__ __launch_bounds__(512, 2) void k(uint32_t* out, in
   __shared__ uint32_t lds[16384];
   if(MODE>=3){ for(int i=threadIdx.x;i<16384;i+=512) lds[i]=i; __syncthreads();
     const uint32_t a=(uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds + (threadIdx.x>>3&7)*256 + ((threadIdx.x>>3&7)<<4), b=(uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds + 8192 + (threadIdx.x&7)*256 + ((threadIdx.x&7)<<4);      // (the count kernel's PAIRED lane rows: no bank conflicts)
-    asm volatile("v_mov_b32 v72, %0\n\tv_mov_b32 v73, %1\n\tv_add_u32 v74, 2048, v73" :: "v"(a), "v"(b) : "v72", "v73", "v74"); }
+    asm volatile("v_mov_b32 v72, %0\n\tv_mov_b32 v73, %1\n\tv_add_u32 v74, 2048, v73\n\tv_mov_b32 v10, %0\n\tv_mov_b32 v11, %1" :: "v"(a), "v"(b) : "v72", "v73", "v74", "v10", "v11"); }
   for(int it=0; it<iters; ++it){
     if(MODE==0) asm volatile(R8(AND12 AND12) ::: CLOB);
     else if(MODE==1) asm volatile(R8(BIT12 BIT12) ::: CLOB);
@@ -74,6 +74,8 @@ template<int MODE> __global__ __launch_bounds__(512, 2) void k(uint32_t* out, in
     else if(MODE==21) asm volatile(STEP_BITOP3_TUPLEA STEP_BITOP3_TUPLEA STEP_BITOP3_TUPLEA STEP_BITOP3_TUPLEA ::: CLOB, CLOB2, "v72", "v73", "v74", "v75");
     else if(MODE==22) asm volatile(STEP_AND_WIDEA STEP_AND_WIDEA STEP_AND_WIDEA STEP_AND_WIDEA ::: CLOB3, CLOB, CLOB2, "v72", "v73", "v74");
     else if(MODE==23) asm volatile(STEP_BITOP3_WIDEA STEP_BITOP3_WIDEA STEP_BITOP3_WIDEA STEP_BITOP3_WIDEA ::: CLOB3, CLOB, CLOB2, "v72", "v73", "v74");
+    else if(MODE==24) asm volatile(STEP_AND_SLOTS STEP_AND_SLOTS STEP_AND_SLOTS STEP_AND_SLOTS ::: CLOB3, CLOB, CLOB2, "v72", "v73", "v74", "v75", "v10", "v11");
+    else if(MODE==25) asm volatile(STEP_BITOP3_SLOTS STEP_BITOP3_SLOTS STEP_BITOP3_SLOTS STEP_BITOP3_SLOTS ::: CLOB3, CLOB, CLOB2, "v72", "v73", "v74", "v75", "v10", "v11");
     else asm volatile(R8(MIX12_L3(RD(44,45,72,0),RD(46,47,72,128),RD(48,49,72,2048)) MIX12_L3(RD(50,51,72,2176),RD(52,53,72,4096),RD(54,55,72,4224))
                                      MIX12_L3(RD(58,59,72,6144),RD(60,61,72,6272),RD(44,45,73,0)) MIX12_L3(RD(46,47,73,128),RD(48,49,73,2048),RD(50,51,73,2176)) "s_waitcnt lgkmcnt(12)\n\t") ::: CLOB, "v72", "v73");
   }
@@ -124,5 +126,7 @@ int main(){
   run<21>("half-slots, the mix, ds_read2_b64 for A, B plain (two in a bank)");
   run<22>("whole A slots by ds_read_b128, swapped B pairs, v_and only");
   run<23>("whole A slots by ds_read_b128, swapped B pairs, the mix");
+  run<24>("whole A and B slots by ds_read_b128 (B image swapped), v_and only");
+  run<25>("whole A and B slots by ds_read_b128 (B image swapped), the mix");
   return bad!=0;
 }
