@@ -49,6 +49,9 @@ for stage in "$@"; do
 	cfg3_sq)   # the work-is-done check of the headline kernel, every round: VALU instructions issued against the products + v_or the launches stand for
 		pmc cfg3_sq "SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" --steps 1 --warmup 0
 		;;
+	cfg3_lds)  # how busy the headline kernel keeps the LDS (what is left in the three-product loop)
+		pmc cfg3_lds "SQ_ACTIVE_INST_LDS SQ_INSTS_LDS_LOAD SQ_INST_LEVEL_LDS SQ_WAIT_INST_LDS SQ_LDS_ADDR_CONFLICT SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU" --steps 1 --warmup 0
+		;;
 	cfg3_pmc)
 		pmc cfg3_fetch FETCH_SIZE --steps 1 --warmup 0 --variants 16384
 		pmc cfg3_write WRITE_SIZE --steps 1 --warmup 0 --variants 16384
