@@ -18,8 +18,8 @@ The JSON line also carries
   roofline     the dominant kernel (twk::k_count3_list_t: the three-product form of the unphased contraction - HH and
                S = QH + HQ + 2 QQ per pair, all UnphasedMath's r2 screen reads; the four products of the pairs that pass are
                recounted; twk::k_count_list_t where that form does not apply), timed live with HIP events on the engine's
-               own stream.  `frac` counts the lane-ops the kernel EXECUTED (v_and + v_bcnt per product, the v_or of the
-               three-product form); `algorithmic_frac` SURVEY 8(d)'s four products per unphased pair over the same time.  The kernel tiles 128 x 128 plane rows through LDS, so each streamed row is
+               own stream.  `frac` counts the lane-ops the kernel EXECUTED (v_and or v_bitop3 + v_bcnt per product; no v_or since
+               round 6); `algorithmic_frac` SURVEY 8(d)'s four products per unphased pair over the same time.  The kernel tiles 128 x 128 plane rows through LDS, so each streamed row is
                reused 128x and HBM is not what binds it: the binding unit is the VALU (v_and_b32 +
                v_bcnt_u32_b32 per 32-bit word pair, no MFMA as the north star requires).  bound="valu":
                achieved = algorithmic lane-ops (2*ceil(2N/32) per pair phased,
@@ -402,7 +402,7 @@ def extra_in_process(config, log, steps, warmup, seed=42, emulate_shard=None, op
            "dominant_kernel": kernel, "form": form, "count_launches_per_step": tm["count_launches"] / steps,
            "avg_launch_ms": tm["count_ms"] / max(tm["count_launches"], 1), "count_kernel_ms_per_step": tm["count_ms"] / steps,
            "math_kernels_ms_per_step": tm["stats_ms"] / steps,
-           # frac: executed lane-ops (v_and + v_bcnt per product, the three-product form's v_or) against the lane peak;
+           # frac: executed lane-ops (v_and or v_bitop3 + v_bcnt per product; `ors` is 0 since round 6) against the lane peak;
            # algorithmic_frac: SURVEY 8(d)'s four products per unphased pair, whatever was executed
            "frac": (2 * products + ors) / k_s / VALU_LANE_PEAK if k_s > 0 else None,
            "algorithmic_frac": pairs * lane_ops / k_s / VALU_LANE_PEAK if k_s > 0 else None,
@@ -854,8 +854,8 @@ def main():
         hbm_alg = k_pairs * bytes_per_pair / k_s / 1e9 if k_ms > 0 else 0.0
         words = tm["words_per_row"]
         # what the kernel actually executed (whole 128 x 128 tiles: includes the lower half of diagonal
-        # tiles, row padding and, in window mode, the tile corners outside the window): AND+popcount products and,
-        # in the three-product form, the v_or that form the carrier words
+        # tiles, row padding and, in window mode, the tile corners outside the window): AND+popcount products (and, until
+        # round 6, the v_or that formed the three-product form's carrier words: `ors`, now 0)
         products, ors, kernel_name, form = executed_work(tm)
         word_pairs_per_s = products / k_s if k_ms > 0 else 0.0
         executed_lane_ops_per_s = (2 * products + ors) / k_s if k_ms > 0 else 0.0
