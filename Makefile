@@ -44,13 +44,17 @@ $(BINDIR)/tomahawk: $(PKG)/csrc/host/calc_main.cpp $(LIBDIR)/libtomahawk_amd.so
 oracle:
 	$(MAKE) -C oracle all
 
-tools: build/count_microbench build/valu_rate build/hbm_read_bw build/issue_test2 build/fisher_probe build/bank_test2 build/list_vs_dense build/probe_vs_dense build/shift64_probe build/issue_test3 build/lds_dma3_probe build/bitop3_probe
+tools: build/count_microbench build/valu_rate build/hbm_read_bw build/issue_test2 build/fisher_probe build/bank_test2 build/list_vs_dense build/probe_vs_dense build/shift64_probe build/issue_test3 build/lds_dma3_probe build/bitop3_probe build/sgpr_probe
 build/%: $(PKG)/csrc/tools/%.hip $(HIP_DEPS)
 	@mkdir -p build
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -Ibuild $< -o $@
 # (the probe's instruction streams with every register fixed by hand are written by a script)
 build/bitop3_probe: build/bitop3_probe_gen.h
 build/bitop3_probe_gen.h: $(PKG)/csrc/tools/bitop3_probe_gen.py
+	@mkdir -p build
+	python3 $< > $@
+build/sgpr_probe: build/sgpr_probe_gen.h
+build/sgpr_probe_gen.h: $(PKG)/csrc/tools/sgpr_probe_gen.py
 	@mkdir -p build
 	python3 $< > $@
 
