@@ -147,6 +147,7 @@ uint64_t twk_ld::n_records() const { return mImpl->n_records; }
 
 bool twk_ld::Compute(const twk_ld_settings& s) { settings = s; return Compute(); }
 bool twk_ld::ComputeSingle(const twk_ld_settings& s, bool verbose, bool progress) { settings = s; return ComputeSingle(verbose, progress); }
+// (the reference's own default build answers the same way: TWK_SLAVE_DEBUG_MODE is 0, lib/ld/ld_engine.h:20, lib/ld/ld.cpp:878-882)
 bool twk_ld::ComputePerformance() {
 	std::cerr << stamp("ERROR") << "ComputePerformance is a compile-time debug harness of the CPU reference; not available." << std::endl;
 	return false;
